@@ -1,0 +1,117 @@
+"""ctypes binding of the C ABI in ``include/ie_hip.h`` (``libie_hip.so``).
+
+BASELINE.json's north_star names cffi for this layer; cffi is not installed in the build
+image (probed), and the ABI is plain C, so ctypes is the loader.  The library is built
+in-tree by ``__graft_entry__.build()`` / ``csrc/build.sh``.  If it is missing, every entry
+point raises ``IEError`` -- there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libie_hip.so")
+
+IE_F32, IE_F16, IE_BF16, IE_U8 = 0, 1, 2, 3
+DTYPES = {"f32": IE_F32, "fp32": IE_F32, "float32": IE_F32, "f16": IE_F16, "fp16": IE_F16, "float16": IE_F16,
+          "bf16": IE_BF16, "bfloat16": IE_BF16}
+ACT = {"none": 0, "relu": 1, "lrelu": 2, "tanh": 3, "sigmoid": 4}
+PAD = {"zeros": 0, "replicate": 1}
+VAR_SYNC_STAGE, VAR_NARROW_STORE, VAR_NO_DMA = 1, 2, 4
+
+# every exported symbol of include/ie_hip.h (checked by tests/test_capi_symbols.py)
+SYMBOLS = [
+    "ie_abi_version", "ie_last_error", "ie_device_info",
+    "ie_nchw_f32_to_nhwc", "ie_nhwc_to_nchw_f32", "ie_nchw_f32_to_u8_nhwc", "ie_u8_nhwc_to_nchw_f32",
+    "ie_resize_bilinear_nchw_f32",
+    "ie_conv2d_nhwc_f32", "ie_pack_weight_hwio_f32", "ie_le_curve",
+    "ie_zdce_create", "ie_zdce_set_layer", "ie_zdce_finalize", "ie_zdce_reserve", "ie_zdce_forward",
+    "ie_zdce_get_feature", "ie_zdce_workspace_bytes", "ie_zdce_destroy", "ie_zdce_time_forward",
+    "ie_zdce_profile_forward", "ie_zdce_set_tuning",
+]
+
+
+class IEError(RuntimeError):
+    pass
+
+
+class ZdceConfig(C.Structure):
+    _fields_ = [("in_channels", C.c_int), ("num_channels", C.c_int), ("num_iters", C.c_int),
+                ("compute_dtype", C.c_int), ("device", C.c_int), ("variant", C.c_int)]
+
+
+class Conv2dDesc(C.Structure):
+    _fields_ = [("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C0", C.c_int), ("C1", C.c_int),
+                ("Cout", C.c_int), ("kh", C.c_int), ("kw", C.c_int), ("stride", C.c_int), ("pad", C.c_int),
+                ("pad_mode", C.c_int), ("groups", C.c_int), ("act", C.c_int), ("slope", C.c_float),
+                ("Ho", C.c_int), ("Wo", C.c_int)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libie_hip.so once; raise loudly if the HIP extension is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise IEError(f"HIP library not built: {LIB_PATH} is missing. Run `python -c 'import __graft_entry__ as g; "
+                      f"g.build()'` (needs hipcc). There is no CPU fallback for the product path.")
+    L = C.CDLL(LIB_PATH)
+    vp, ip, fp = C.c_void_p, C.c_int, C.c_float
+    L.ie_abi_version.restype = ip
+    L.ie_last_error.restype = C.c_char_p
+    L.ie_device_info.argtypes = [ip, C.c_char_p, ip, C.POINTER(ip), C.POINTER(C.c_size_t)]
+    L.ie_nchw_f32_to_nhwc.argtypes = [vp, vp, ip, ip, ip, ip, ip, ip, vp]
+    L.ie_nhwc_to_nchw_f32.argtypes = [vp, ip, vp, ip, ip, ip, ip, ip, vp]
+    L.ie_nchw_f32_to_u8_nhwc.argtypes = [vp, vp, ip, ip, ip, ip, ip, vp]
+    L.ie_u8_nhwc_to_nchw_f32.argtypes = [vp, vp, ip, ip, ip, ip, vp]
+    L.ie_resize_bilinear_nchw_f32.argtypes = [vp, vp, ip, ip, ip, ip, ip, ip, ip, vp]
+    L.ie_conv2d_nhwc_f32.argtypes = [C.POINTER(Conv2dDesc), vp, vp, vp, vp, vp, vp]
+    L.ie_pack_weight_hwio_f32.argtypes = [vp, ip, ip, ip, ip, vp, vp]
+    L.ie_le_curve.argtypes = [vp, vp, ip, vp, ip, ip, ip, ip, vp]
+    L.ie_zdce_create.argtypes = [C.POINTER(ZdceConfig), C.POINTER(vp)]
+    L.ie_zdce_set_layer.argtypes = [vp, ip, vp, vp, ip, ip]
+    L.ie_zdce_finalize.argtypes = [vp, vp]
+    L.ie_zdce_reserve.argtypes = [vp, ip, ip, ip]
+    L.ie_zdce_forward.argtypes = [vp, vp, vp, vp, vp, ip, ip, ip, vp]
+    L.ie_zdce_get_feature.argtypes = [vp, ip, vp, vp]
+    L.ie_zdce_workspace_bytes.argtypes = [vp]
+    L.ie_zdce_workspace_bytes.restype = C.c_size_t
+    L.ie_zdce_destroy.argtypes = [vp]
+    L.ie_zdce_time_forward.argtypes = [vp, vp, vp, vp, vp, ip, ip, ip, ip, vp, C.POINTER(fp)]
+    L.ie_zdce_profile_forward.argtypes = [vp, vp, vp, vp, vp, ip, ip, ip, vp, C.POINTER(fp),
+                                          C.POINTER(C.c_char_p), C.POINTER(ip), ip, C.POINTER(ip)]
+    L.ie_zdce_set_tuning.argtypes = [vp, ip, ip, ip]
+    for name in SYMBOLS:
+        fn = getattr(L, name)
+        if fn.restype is C.c_int and name not in ("ie_abi_version",):
+            fn.restype = ip
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().ie_last_error()
+        raise IEError(f"{what or 'ie call'} failed (status {rc}): {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """Device/host pointer of a torch tensor (or None)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def current_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def device_info(device: int = 0):
+    name = C.create_string_buffer(64)
+    cu = C.c_int(0)
+    mem = C.c_size_t(0)
+    check(lib().ie_device_info(device, name, 64, C.byref(cu), C.byref(mem)), "ie_device_info")
+    return {"arch": name.value.decode(), "cu": cu.value, "hbm_bytes": mem.value}

@@ -1,0 +1,90 @@
+// Shared host/device helpers for the gfx950 image-enhancement library.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/ie_hip.h"
+
+#define IE_EXPORT extern "C" __attribute__((visibility("default")))
+
+// ---- error plumbing (thread-local message, negative status codes) ----------
+void ie_set_error(const char* fmt, ...);
+#define IE_FAIL(code, ...) do { ie_set_error(__VA_ARGS__); return (code); } while (0)
+#define IE_HIP_CHECK(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { \
+    ie_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+    return IE_ERR_HIP; } } while (0)
+#define IE_LAUNCH_CHECK() IE_HIP_CHECK(hipGetLastError())
+
+static inline size_t ie_dtype_size(int dt) {
+    switch (dt) { case IE_F32: return 4; case IE_F16: case IE_BF16: return 2; case IE_U8: return 1; default: return 0; }
+}
+static inline int ie_cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---- device vector types -----------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) _Float16 ie_half8;
+typedef __attribute__((ext_vector_type(8))) __bf16 ie_bf16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 ie_half4;
+typedef __attribute__((ext_vector_type(4))) __bf16 ie_bf16x4;
+typedef __attribute__((ext_vector_type(16))) float ie_f32x16;
+typedef __attribute__((ext_vector_type(4))) float ie_f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int ie_u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int ie_u32x2;
+
+#ifdef __HIPCC__
+// Element-type traits for the 16-bit MFMA paths.
+template <typename T> struct ie_elem;
+template <> struct ie_elem<_Float16> {
+    using frag = ie_half8;
+    static constexpr int dtype = IE_F16;
+    static __device__ __forceinline__ ie_f32x16 mfma32(frag a, frag b, ie_f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ ie_f32x4 mfma16(frag a, frag b, ie_f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct ie_elem<__bf16> {
+    using frag = ie_bf16x8;
+    static constexpr int dtype = IE_BF16;
+    static __device__ __forceinline__ ie_f32x16 mfma32(frag a, frag b, ie_f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ ie_f32x4 mfma16(frag a, frag b, ie_f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+};
+
+// Pack two floats into one dword of 2 x T (round-to-nearest-even casts).
+template <typename T> __device__ __forceinline__ unsigned ie_pack2(float lo, float hi) {
+    T a = (T)lo, b = (T)hi;
+    unsigned short ua = __builtin_bit_cast(unsigned short, a), ub = __builtin_bit_cast(unsigned short, b);
+    return (unsigned)ua | ((unsigned)ub << 16);
+}
+
+// tanh as 1 - 2/(exp(2x)+1) on the hardware exp2/rcp units: absolute error
+// <= ~3e-7 (the LE curve consumes r as a multiplier, so absolute error is what
+// matters); saturates correctly to +-1.
+__device__ __forceinline__ float ie_tanh_fast(float x) {
+    const float e = __builtin_amdgcn_exp2f(x * 2.885390081777927f); // exp(2x)
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+__device__ __forceinline__ float ie_sigmoid_fast(float x) {
+    const float e = __builtin_amdgcn_exp2f(-x * 1.4426950408889634f);
+    return __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+// One LE-curve step in the reference's fp32 association order
+// (zero_dce.py:187: y + r * (pow(y,2) - y)); no FMA contraction.
+__device__ __forceinline__ float ie_curve_step(float y, float r) {
+    const float t = __fmul_rn(y, y);
+    const float u = __fsub_rn(t, y);
+    return __fadd_rn(y, __fmul_rn(r, u));
+}
+// torchvision save_image rule: clamp(x*255+0.5, 0, 255) -> u8 (truncate).
+__device__ __forceinline__ unsigned char ie_quant_u8(float v) {
+    float q = __fadd_rn(__fmul_rn(v, 255.0f), 0.5f);
+    q = fminf(fmaxf(q, 0.0f), 255.0f);
+    return (unsigned char)q;
+}
+#endif

@@ -1,0 +1,13 @@
+// Internal (non-ABI) interface between the Zero-DCE plan and its kernel launchers.
+#pragma once
+#include "ie_common.h"
+
+struct ZdceConvLaunch {
+    const void* src0; const void* src1; const void* wpk; const float* bias; void* dst;
+    const float* img; float* enhanced; float* adjust; unsigned char* u8;
+    int N, H, W, y_begin, y_end, n_begin, n_count, rows_per_block;
+    int nsrc, epi, dtype, variant;
+};
+int ie_zdce_launch_mfma(const ZdceConvLaunch& a, hipStream_t st);
+int ie_zdce_launch_conv1(const float* img, const float* wk, const float* bias, void* dst, int dtype, int N, int H,
+                         int W, int y_begin, int y_end, int n_begin, int n_count, hipStream_t st);

@@ -1,0 +1,381 @@
+// Zero-DCE plan: host side of the fused hot path (weights repack, workspace, launch schedule).
+// Replaces ZeroDCE_RE.forward (src/mon/vision/enhance/llie/zero_dce/zero_dce.py:173-191).
+//
+// Schedule: the batch is processed in groups of `group_frames` frames and horizontal bands of
+// `band_rows` rows; inside one (group, band) job the 7 layers run back to back on the caller's
+// stream, layer k computing the band plus a (7-k)-row apron so the next layer's halo is there.
+// The x1..x6 intermediates live in a plan-owned workspace sized for one group (NHWC, 32 ch).
+#include "ie_common.h"
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include <new>
+
+#include "ie_zdce_internal.h"
+
+namespace {
+constexpr int NL = 7;
+const char* const kLayerNames[NL] = {"zdce_conv1", "zdce_conv2", "zdce_conv3", "zdce_conv4",
+                                     "zdce_conv5", "zdce_conv6", "zdce_conv7_curve"};
+
+unsigned short f32_to_f16_bits(float f) { _Float16 h = (_Float16)f; unsigned short u; memcpy(&u, &h, 2); return u; }
+unsigned short f32_to_bf16_bits(float f) {
+    unsigned u; memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);  // NaN stays NaN
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+int env_int(const char* name, int dflt) { const char* v = getenv(name); return (v && *v) ? atoi(v) : dflt; }
+}  // namespace
+
+struct ie_zdce_plan {
+    ie_zdce_config cfg;
+    std::vector<float> w[NL], b[NL];
+    bool set[NL] = {false, false, false, false, false, false, false};
+    bool finalized = false;
+    // device weights: one allocation
+    char* d_w = nullptr;
+    size_t off_w[NL] = {0}, off_b[NL] = {0};
+    // workspace
+    char* ws = nullptr;
+    size_t ws_bytes = 0;
+    int cap_frames = 0, cap_H = 0, cap_W = 0;
+    // schedule knobs
+    int rows_per_block = 0, band_rows = 0, group_frames = 0;
+    // last forward (for get_feature)
+    int last_N = 0, last_H = 0, last_W = 0;
+    bool last_whole = false;
+    // profiling hooks
+    bool prof = false;
+    std::vector<hipEvent_t> ev;      // pairs
+    std::vector<int> ev_layer;
+};
+
+static size_t elem_size(const ie_zdce_plan* p) { return ie_dtype_size(p->cfg.compute_dtype); }
+static size_t frame_elems(int H, int W, int C) { return (size_t)H * W * C; }
+
+static void pick_schedule(const ie_zdce_plan* p, int N, int H, int W, int* group, int* band, int* rb) {
+    const bool f32 = p->cfg.compute_dtype == IE_F32;
+    int g = p->group_frames > 0 ? p->group_frames : (f32 ? 1 : 8);
+    if (g > N) g = N;
+    int bd = p->band_rows > 0 ? p->band_rows : H;
+    if (bd > H) bd = H;
+    int r = p->rows_per_block > 0 ? p->rows_per_block : 0;
+    if (r <= 0) {
+        // enough workgroups to fill 256 CUs x 2 several times over, but rows long enough to amortise the
+        // 2-row apron: aim for >= 2048 workgroups per launch, 8 <= RB <= 64
+        const long long strips = (W + 127) / 128;
+        long long want = 2048;
+        long long rows_total = (long long)g * bd;
+        long long rbv = rows_total * strips / want;
+        if (rbv < 8) rbv = 8;
+        if (rbv > 64) rbv = 64;
+        r = (int)rbv;
+    }
+    (void)W;
+    *group = g; *band = bd; *rb = r;
+}
+
+IE_EXPORT int ie_zdce_create(const ie_zdce_config* cfg, ie_zdce_plan** out) {
+    if (!cfg || !out) IE_FAIL(IE_ERR_INVALID, "ie_zdce_create: null argument");
+    if (cfg->in_channels != 3 || cfg->num_channels != 32 || cfg->num_iters != 8)
+        IE_FAIL(IE_ERR_UNSUPPORTED, "ie_zdce_create: this build supports in_channels=3, num_channels=32, num_iters=8 (got %d, %d, %d)",
+                cfg->in_channels, cfg->num_channels, cfg->num_iters);
+    if (cfg->compute_dtype != IE_F32 && cfg->compute_dtype != IE_F16 && cfg->compute_dtype != IE_BF16)
+        IE_FAIL(IE_ERR_INVALID, "ie_zdce_create: compute_dtype %d", cfg->compute_dtype);
+    int ndev = 0;
+    IE_HIP_CHECK(hipGetDeviceCount(&ndev));
+    if (cfg->device < 0 || cfg->device >= ndev) IE_FAIL(IE_ERR_INVALID, "ie_zdce_create: device %d of %d", cfg->device, ndev);
+    ie_zdce_plan* p = new (std::nothrow) ie_zdce_plan();
+    if (!p) IE_FAIL(IE_ERR_NOMEM, "ie_zdce_create: out of host memory");
+    p->cfg = *cfg;
+    p->rows_per_block = env_int("IE_ZDCE_RB", 0);
+    p->band_rows = env_int("IE_ZDCE_BAND", 0);
+    p->group_frames = env_int("IE_ZDCE_GROUP", 0);
+    *out = p;
+    return IE_OK;
+}
+
+IE_EXPORT int ie_zdce_set_tuning(ie_zdce_plan* p, int rows_per_block, int band_rows, int group_frames) {
+    if (!p) IE_FAIL(IE_ERR_INVALID, "ie_zdce_set_tuning: null plan");
+    p->rows_per_block = rows_per_block; p->band_rows = band_rows; p->group_frames = group_frames;
+    return IE_OK;
+}
+
+IE_EXPORT int ie_zdce_set_layer(ie_zdce_plan* p, int layer, const float* w, const float* b, int Cout, int Cin) {
+    if (!p || !w || !b) IE_FAIL(IE_ERR_INVALID, "ie_zdce_set_layer: null argument");
+    if (layer < 1 || layer > NL) IE_FAIL(IE_ERR_INVALID, "ie_zdce_set_layer: layer %d not in 1..7", layer);
+    const int nc = p->cfg.num_channels;
+    const int eCo = layer == 7 ? 3 * p->cfg.num_iters : nc;
+    const int eCi = layer == 1 ? p->cfg.in_channels : (layer >= 5 ? 2 * nc : nc);
+    if (Cout != eCo || Cin != eCi)
+        IE_FAIL(IE_ERR_INVALID, "ie_zdce_set_layer: e_conv%d expects (%d,%d,3,3), got (%d,%d,3,3)", layer, eCo, eCi, Cout, Cin);
+    p->w[layer - 1].assign(w, w + (size_t)Cout * Cin * 9);
+    p->b[layer - 1].assign(b, b + Cout);
+    p->set[layer - 1] = true;
+    p->finalized = false;
+    return IE_OK;
+}
+
+IE_EXPORT int ie_zdce_finalize(ie_zdce_plan* p, void* stream) {
+    if (!p) IE_FAIL(IE_ERR_INVALID, "ie_zdce_finalize: null plan");
+    for (int l = 0; l < NL; ++l) if (!p->set[l]) IE_FAIL(IE_ERR_STATE, "ie_zdce_finalize: e_conv%d not set", l + 1);
+    IE_HIP_CHECK(hipSetDevice(p->cfg.device));
+    const int dt = p->cfg.compute_dtype;
+    const int nc = 32;
+    std::vector<char> host;
+    auto align = [&](size_t a) { while (host.size() % a) host.push_back(0); };
+    for (int l = 0; l < NL; ++l) {
+        const int Co = l == 6 ? 24 : nc;
+        const int Ci = l == 0 ? 3 : (l >= 4 ? 64 : 32);
+        const float* w = p->w[l].data();
+        align(256);
+        p->off_w[l] = host.size();
+        if (dt == IE_F32) {
+            // HWIO fp32, conv1's Cin padded 3 -> 4 (zero weights) so the input is a 16-byte NHWC4 pixel
+            const int Cip = l == 0 ? 4 : Ci;
+            std::vector<float> hw((size_t)9 * Cip * Co, 0.f);
+            for (int o = 0; o < Co; ++o) for (int c = 0; c < Ci; ++c) for (int t = 0; t < 9; ++t)
+                hw[((size_t)t * Cip + c) * Co + o] = w[((size_t)o * Ci + c) * 9 + t];
+            const char* q = (const char*)hw.data();
+            host.insert(host.end(), q, q + hw.size() * 4);
+        } else if (l == 0) {
+            // conv1 VALU kernel: [(ky*3+kx)*3 + c][32] fp32
+            std::vector<float> hw((size_t)27 * 32, 0.f);
+            for (int o = 0; o < 32; ++o) for (int c = 0; c < 3; ++c) for (int t = 0; t < 9; ++t)
+                hw[((size_t)t * 3 + c) * 32 + o] = w[((size_t)o * 3 + c) * 9 + t];
+            const char* q = (const char*)hw.data();
+            host.insert(host.end(), q, q + hw.size() * 4);
+        } else {
+            // MFMA (16x16x32) A-operand fragments, per cout half hc:
+            //   [hc][f = s*9 + ky*3 + kx][lane][j] = W[cout 16hc + (lane&15)][cin s*32 + 8*(lane>>4) + j][ky][kx]
+            // couts >= Co (e_conv7: 24..31) are zero rows.
+            const int nsrc = Ci / 32;
+            std::vector<unsigned short> hw((size_t)2 * nsrc * 9 * 64 * 8, 0);
+            for (int hc = 0; hc < 2; ++hc) for (int s = 0; s < nsrc; ++s) for (int t = 0; t < 9; ++t)
+                for (int lane = 0; lane < 64; ++lane) for (int j = 0; j < 8; ++j) {
+                    const int f = s * 9 + t;
+                    const int co = 16 * hc + (lane & 15);
+                    const int ci = s * 32 + 8 * (lane >> 4) + j;
+                    const float v = co < Co ? w[((size_t)co * Ci + ci) * 9 + t] : 0.f;
+                    hw[(((size_t)hc * nsrc * 9 + f) * 64 + lane) * 8 + j] = dt == IE_F16 ? f32_to_f16_bits(v) : f32_to_bf16_bits(v);
+                }
+            const char* q = (const char*)hw.data();
+            host.insert(host.end(), q, q + hw.size() * 2);
+        }
+        align(256);
+        p->off_b[l] = host.size();
+        std::vector<float> hb(32, 0.f);
+        for (int o = 0; o < Co; ++o) hb[o] = p->b[l][o];
+        const char* q = (const char*)hb.data();
+        host.insert(host.end(), q, q + 32 * 4);
+    }
+    if (p->d_w) { hipFree(p->d_w); p->d_w = nullptr; }
+    IE_HIP_CHECK(hipMalloc(&p->d_w, host.size()));
+    hipStream_t st = (hipStream_t)stream;
+    IE_HIP_CHECK(hipMemcpyAsync(p->d_w, host.data(), host.size(), hipMemcpyHostToDevice, st));
+    IE_HIP_CHECK(hipStreamSynchronize(st));  // host staging vector dies at return
+    p->finalized = true;
+    return IE_OK;
+}
+
+// bytes of workspace per frame
+static size_t ws_per_frame(const ie_zdce_plan* p, int H, int W) {
+    if (p->cfg.compute_dtype == IE_F32) return (frame_elems(H, W, 4) + 6 * frame_elems(H, W, 32) + frame_elems(H, W, 24)) * 4;
+    return 6 * frame_elems(H, W, 32) * elem_size(p);
+}
+
+IE_EXPORT int ie_zdce_reserve(ie_zdce_plan* p, int N, int H, int W) {
+    if (!p || N <= 0 || H <= 0 || W <= 0) IE_FAIL(IE_ERR_INVALID, "ie_zdce_reserve: bad args");
+    int g, bd, rb;
+    pick_schedule(p, N, H, W, &g, &bd, &rb);
+    const size_t need = ws_per_frame(p, H, W) * g + 1024;
+    if (need > p->ws_bytes) {
+        IE_HIP_CHECK(hipSetDevice(p->cfg.device));
+        if (p->ws) { IE_HIP_CHECK(hipDeviceSynchronize()); hipFree(p->ws); p->ws = nullptr; p->ws_bytes = 0; }
+        hipError_t e = hipMalloc(&p->ws, need);
+        if (e != hipSuccess) { ie_set_error("ie_zdce_reserve: hipMalloc(%zu) failed: %s", need, hipGetErrorString(e)); return IE_ERR_NOMEM; }
+        p->ws_bytes = need;
+    }
+    p->cap_frames = g; p->cap_H = H; p->cap_W = W;
+    return IE_OK;
+}
+
+IE_EXPORT size_t ie_zdce_workspace_bytes(const ie_zdce_plan* p) { return p ? p->ws_bytes : 0; }
+
+namespace {
+struct ProfScope {
+    ie_zdce_plan* p; hipStream_t st; bool on;
+    ProfScope(ie_zdce_plan* p_, int layer, hipStream_t st_) : p(p_), st(st_), on(p_->prof) {
+        if (!on) return;
+        hipEvent_t a, b;
+        hipEventCreate(&a); hipEventCreate(&b);
+        p->ev.push_back(a); p->ev.push_back(b); p->ev_layer.push_back(layer);
+        hipEventRecord(a, st);
+    }
+    ~ProfScope() { if (on) hipEventRecord(p->ev.back(), st); }
+};
+}  // namespace
+
+static int forward_f32(ie_zdce_plan* p, const float* image, float* enhanced, float* adjust, uint8_t* u8, int N, int H,
+                       int W, hipStream_t st, int group) {
+    // parity mode: every layer on the generic fp32 VALU conv; whole frames, `group` frames per pass
+    const size_t e4 = frame_elems(H, W, 4), e32 = frame_elems(H, W, 32), e24 = frame_elems(H, W, 24);
+    for (int n0 = 0; n0 < N; n0 += group) {
+        const int g = (N - n0) < group ? (N - n0) : group;
+        float* x0 = (float*)p->ws;
+        float* x[7];
+        x[0] = x0;
+        for (int k = 1; k <= 6; ++k) x[k] = x0 + e4 * group + e32 * group * (k - 1);
+        float* adj = x0 + e4 * group + e32 * group * 6;
+        const float* img = image + (size_t)n0 * 3 * H * W;
+        int rc = ie_nchw_f32_to_nhwc(img, x0, IE_F32, g, 3, H, W, 4, st);
+        if (rc) return rc;
+        const int s0i[NL] = {0, 1, 2, 3, 3, 2, 1}, s1i[NL] = {-1, -1, -1, -1, 4, 5, 6};
+        for (int l = 0; l < NL; ++l) {
+            ProfScope ps(p, l, st);
+            ie_conv2d_desc d;
+            memset(&d, 0, sizeof(d));
+            d.N = g; d.H = H; d.W = W; d.C0 = l == 0 ? 4 : 32; d.C1 = s1i[l] >= 0 ? 32 : 0; d.Cout = l == 6 ? 24 : 32;
+            d.kh = d.kw = 3; d.stride = 1; d.pad = 1; d.pad_mode = IE_PAD_ZEROS; d.groups = 1;
+            d.act = l == 6 ? IE_ACT_TANH : IE_ACT_RELU;
+            rc = ie_conv2d_nhwc_f32(&d, x[s0i[l]], s1i[l] >= 0 ? x[s1i[l]] : nullptr, (const float*)(p->d_w + p->off_w[l]),
+                                    (const float*)(p->d_w + p->off_b[l]), l == 6 ? adj : x[l + 1], st);
+            if (rc) return rc;
+        }
+        (void)e24;
+        float* enh = enhanced ? enhanced + (size_t)n0 * 3 * H * W : nullptr;
+        float* tmp_enh = enh;
+        if (!tmp_enh) tmp_enh = x[1];  // x1 is dead after conv7: reuse as scratch for u8-only output
+        rc = ie_le_curve(img, adj, 24, tmp_enh, g, H, W, 8, st);
+        if (rc) return rc;
+        if (u8) { rc = ie_nchw_f32_to_u8_nhwc(tmp_enh, u8 + (size_t)n0 * H * W * 3, g, 3, H, W, 0, st); if (rc) return rc; }
+        if (adjust) { rc = ie_nhwc_to_nchw_f32(adj, IE_F32, adjust + (size_t)n0 * 24 * H * W, g, 24, H, W, 24, st); if (rc) return rc; }
+    }
+    return IE_OK;
+}
+
+static int forward_mfma(ie_zdce_plan* p, const float* image, float* enhanced, float* adjust, uint8_t* u8, int N, int H,
+                        int W, hipStream_t st, int group, int band, int rb) {
+    const int dt = p->cfg.compute_dtype;
+    const size_t fb = frame_elems(H, W, 32) * elem_size(p);   // bytes per frame of one intermediate
+    for (int n0 = 0; n0 < N; n0 += group) {
+        const int g = (N - n0) < group ? (N - n0) : group;
+        // the kernels index frames by absolute n: bias the workspace pointers by -n0 frames
+        char* x[7];
+        x[0] = nullptr;
+        for (int k = 1; k <= 6; ++k) x[k] = p->ws + fb * group * (k - 1) - fb * (size_t)n0;
+        for (int b0 = 0; b0 < H; b0 += band) {
+            const int b1 = (b0 + band) < H ? (b0 + band) : H;
+            auto lo = [&](int k) { int v = b0 - (7 - k); return v < 0 ? 0 : v; };
+            auto hi = [&](int k) { int v = b1 + (7 - k); return v > H ? H : v; };
+            {
+                ProfScope ps(p, 0, st);
+                int rc = ie_zdce_launch_conv1(image, (const float*)(p->d_w + p->off_w[0]), (const float*)(p->d_w + p->off_b[0]),
+                                              x[1], dt, N, H, W, lo(1), hi(1), n0, g, st);
+                if (rc) return rc;
+            }
+            const int s0i[NL] = {0, 1, 2, 3, 3, 2, 1}, s1i[NL] = {-1, -1, -1, -1, 4, 5, 6};
+            for (int l = 1; l < NL; ++l) {
+                ProfScope ps(p, l, st);
+                ZdceConvLaunch a;
+                memset(&a, 0, sizeof(a));
+                a.src0 = x[s0i[l]]; a.src1 = s1i[l] >= 0 ? x[s1i[l]] : nullptr;
+                a.wpk = p->d_w + p->off_w[l]; a.bias = (const float*)(p->d_w + p->off_b[l]);
+                a.N = N; a.H = H; a.W = W; a.n_begin = n0; a.n_count = g; a.rows_per_block = rb;
+                a.nsrc = s1i[l] >= 0 ? 2 : 1; a.dtype = dt; a.variant = p->cfg.variant;
+                if (l < 6) { a.epi = 0; a.dst = x[l + 1]; a.y_begin = lo(l + 1); a.y_end = hi(l + 1); }
+                else { a.epi = 1; a.img = image; a.enhanced = enhanced; a.adjust = adjust; a.u8 = u8; a.y_begin = b0; a.y_end = b1; }
+                int rc = ie_zdce_launch_mfma(a, st);
+                if (rc) return rc;
+            }
+        }
+    }
+    return IE_OK;
+}
+
+IE_EXPORT int ie_zdce_forward(ie_zdce_plan* p, const float* image, float* enhanced, float* adjust, uint8_t* u8, int N,
+                              int H, int W, void* stream) {
+    if (!p || !image) IE_FAIL(IE_ERR_INVALID, "ie_zdce_forward: null plan/image");
+    if (!p->finalized) IE_FAIL(IE_ERR_STATE, "ie_zdce_forward: plan not finalized (set 7 layers, then ie_zdce_finalize)");
+    if (N <= 0 || H <= 0 || W <= 0) IE_FAIL(IE_ERR_INVALID, "ie_zdce_forward: bad shape N=%d H=%d W=%d", N, H, W);
+    if (!enhanced && !adjust && !u8) IE_FAIL(IE_ERR_INVALID, "ie_zdce_forward: no output requested");
+    int g, bd, rb;
+    pick_schedule(p, N, H, W, &g, &bd, &rb);
+    if (p->cap_frames < g || p->cap_H != H || p->cap_W != W || ws_per_frame(p, H, W) * g + 1024 > p->ws_bytes) {
+        int rc = ie_zdce_reserve(p, N, H, W);
+        if (rc) return rc;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    p->last_N = N; p->last_H = H; p->last_W = W;
+    p->last_whole = (g >= N);
+    if (p->cfg.compute_dtype == IE_F32) return forward_f32(p, image, enhanced, adjust, u8, N, H, W, st, g);
+    return forward_mfma(p, image, enhanced, adjust, u8, N, H, W, st, g, bd, rb);
+}
+
+IE_EXPORT int ie_zdce_get_feature(ie_zdce_plan* p, int idx, float* dst, void* stream) {
+    if (!p || !dst || idx < 1 || idx > 6) IE_FAIL(IE_ERR_INVALID, "ie_zdce_get_feature: bad args");
+    if (!p->last_whole) IE_FAIL(IE_ERR_STATE, "ie_zdce_get_feature: last forward did not keep the whole batch in one group");
+    const int N = p->last_N, H = p->last_H, W = p->last_W;
+    int g, bd, rb;
+    pick_schedule(p, N, H, W, &g, &bd, &rb);
+    if (p->cfg.compute_dtype == IE_F32) {
+        const float* x0 = (const float*)p->ws;
+        const float* xk = x0 + frame_elems(H, W, 4) * g + frame_elems(H, W, 32) * g * (idx - 1);
+        return ie_nhwc_to_nchw_f32(xk, IE_F32, dst, N, 32, H, W, 32, stream);
+    }
+    const size_t fb = frame_elems(H, W, 32) * elem_size(p);
+    return ie_nhwc_to_nchw_f32(p->ws + fb * g * (idx - 1), (ie_dtype)p->cfg.compute_dtype, dst, N, 32, H, W, 32, stream);
+}
+
+IE_EXPORT int ie_zdce_destroy(ie_zdce_plan* p) {
+    if (!p) return IE_OK;
+    hipSetDevice(p->cfg.device);
+    hipDeviceSynchronize();
+    if (p->d_w) hipFree(p->d_w);
+    if (p->ws) hipFree(p->ws);
+    for (hipEvent_t e : p->ev) hipEventDestroy(e);
+    delete p;
+    return IE_OK;
+}
+
+IE_EXPORT int ie_zdce_time_forward(ie_zdce_plan* p, const float* image, float* enhanced, float* adjust, uint8_t* u8,
+                                   int N, int H, int W, int iters, void* stream, float* ms_total) {
+    if (!p || iters <= 0 || !ms_total) IE_FAIL(IE_ERR_INVALID, "ie_zdce_time_forward: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t a, b;
+    IE_HIP_CHECK(hipEventCreate(&a));
+    IE_HIP_CHECK(hipEventCreate(&b));
+    int rc = IE_OK;
+    IE_HIP_CHECK(hipEventRecord(a, st));
+    for (int i = 0; i < iters && rc == IE_OK; ++i) rc = ie_zdce_forward(p, image, enhanced, adjust, u8, N, H, W, stream);
+    IE_HIP_CHECK(hipEventRecord(b, st));
+    IE_HIP_CHECK(hipEventSynchronize(b));
+    if (rc == IE_OK) IE_HIP_CHECK(hipEventElapsedTime(ms_total, a, b));
+    hipEventDestroy(a);
+    hipEventDestroy(b);
+    return rc;
+}
+
+IE_EXPORT int ie_zdce_profile_forward(ie_zdce_plan* p, const float* image, float* enhanced, float* adjust, uint8_t* u8,
+                                      int N, int H, int W, void* stream, float* ms, const char** names, int* launches,
+                                      int cap, int* n) {
+    if (!p || !ms || !names || !n || cap < NL) IE_FAIL(IE_ERR_INVALID, "ie_zdce_profile_forward: bad args (cap >= 7)");
+    for (hipEvent_t e : p->ev) hipEventDestroy(e);
+    p->ev.clear(); p->ev_layer.clear();
+    p->prof = true;
+    int rc = ie_zdce_forward(p, image, enhanced, adjust, u8, N, H, W, stream);
+    p->prof = false;
+    if (rc) return rc;
+    IE_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    for (int l = 0; l < NL; ++l) { ms[l] = 0.f; names[l] = kLayerNames[l]; if (launches) launches[l] = 0; }
+    for (size_t i = 0; i < p->ev_layer.size(); ++i) {
+        float t = 0.f;
+        IE_HIP_CHECK(hipEventElapsedTime(&t, p->ev[2 * i], p->ev[2 * i + 1]));
+        ms[p->ev_layer[i]] += t;
+        if (launches) launches[p->ev_layer[i]] += 1;
+    }
+    *n = NL;
+    for (hipEvent_t e : p->ev) hipEventDestroy(e);
+    p->ev.clear(); p->ev_layer.clear();
+    return IE_OK;
+}

@@ -1,0 +1,20 @@
+"""Enums mirrored from src/mon/globals.py:649-699 (only the members the hot path uses)."""
+from enum import Enum
+
+
+class Task(Enum):
+    LLIE = "llie"
+    DENOISE = "denoise"
+    DERAIN = "derain"
+    DEBLUR = "deblur"
+    SEGMENT = "segment"
+
+
+class Scheme(Enum):
+    SUPERVISED = "supervised"
+    UNSUPERVISED = "unsupervised"
+    ZERO_REFERENCE = "zero_reference"
+    ZERO_SHOT = "zero_shot"
+
+
+WEIGHTS_FILE_FORMATS = [".pt", ".pth", ".onnx"]  # src/mon/globals.py:709

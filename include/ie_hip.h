@@ -1,0 +1,159 @@
+/* ie_hip.h -- C ABI of the MI355X (gfx950) image-enhancement hot path.
+ *
+ * Drop-in boundary: the reference is pure Python and its hot
+ * path bottoms out in ATen calls (torch.nn.Conv2d / F.conv2d / tanh / pow ...)
+ * made from `forward(datapoint)`; there is no reference FFI.  The entry points
+ * below are what a reference-side binding (ctypes / cffi)
+ * calls instead of those ATen ops.  Each declaration cites the reference
+ * interface it replaces (paths relative to /root/reference).
+ *
+ * Conventions
+ *   - plain C types only; every pointer named *_dev is a device pointer owned
+ *     by the caller (e.g. torch.Tensor.data_ptr()); *_host pointers are host
+ *     memory read during the call.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream). All
+ *     work is enqueued on it; no entry point synchronises the device except
+ *     ie_plan_destroy / ie_zdce_reserve (allocation).
+ *   - return value: 0 (IE_OK) or a negative ie_status; ie_last_error() gives a
+ *     thread-local message.  Nothing throws or aborts.
+ *   - activations between layers are NHWC ("channels last"), element type
+ *     ie_dtype; images at the boundary are NCHW fp32 in [0,1] like the
+ *     reference's datapoint["image"].
+ */
+#ifndef IE_HIP_H
+#define IE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IE_ABI_VERSION 1
+
+typedef enum ie_status {
+    IE_OK = 0,
+    IE_ERR_INVALID = -1,     /* bad argument / shape */
+    IE_ERR_HIP = -2,         /* a HIP runtime call failed */
+    IE_ERR_UNSUPPORTED = -3, /* valid request this build has no kernel for */
+    IE_ERR_STATE = -4,       /* plan not finalised / weight missing */
+    IE_ERR_NOMEM = -5
+} ie_status;
+
+typedef enum ie_dtype { IE_F32 = 0, IE_F16 = 1, IE_BF16 = 2, IE_U8 = 3 } ie_dtype;
+typedef enum ie_act { IE_ACT_NONE = 0, IE_ACT_RELU = 1, IE_ACT_LRELU = 2, IE_ACT_TANH = 3, IE_ACT_SIGMOID = 4 } ie_act;
+typedef enum ie_pad_mode { IE_PAD_ZEROS = 0, IE_PAD_REPLICATE = 1 } ie_pad_mode;
+
+/* ---- library ---------------------------------------------------------- */
+int ie_abi_version(void);
+const char* ie_last_error(void);
+/* Fills name (<= cap bytes) with the gcnArchName of `device`; *cu = CU count. */
+int ie_device_info(int device, char* name, int cap, int* cu, size_t* hbm_bytes);
+
+/* ---- layout / boundary ops -------------------------------------------- */
+/* NCHW fp32 -> NHWC dtype, channels zero-padded C -> Cp.
+ * Replaces the implicit layout of datapoint["image"] (vision/model.py:97-109). */
+int ie_nchw_f32_to_nhwc(const float* src_dev, void* dst_dev, ie_dtype dt, int N, int C, int H, int W, int Cp, void* stream);
+/* NHWC dtype (Cp channels, first C used) -> NCHW fp32. */
+int ie_nhwc_to_nchw_f32(const void* src_dev, ie_dtype dt, float* dst_dev, int N, int C, int H, int W, int Cp, void* stream);
+/* float NCHW [0,1] -> uint8 NHWC.  mode 0: torchvision save_image rule
+ * clamp(x*255+0.5,0,255) (core/image/io.py:139-140); mode 1: truncating
+ * (uint8)(x*255) of the clamped value (core/image/utils.py:795). */
+int ie_nchw_f32_to_u8_nhwc(const float* src_dev, uint8_t* dst_dev, int N, int C, int H, int W, int mode, void* stream);
+/* uint8 NHWC -> float NCHW /255 (core/image/utils.py:801-847 to_image_tensor(normalize)). */
+int ie_u8_nhwc_to_nchw_f32(const uint8_t* src_dev, float* dst_dev, int N, int C, int H, int W, void* stream);
+
+/* Bilinear resize NCHW fp32 with F.interpolate semantics.  align_corners=0 is what
+ * core.resize -> kornia resize does inside VisionModel.infer (vision/model.py:104-106,119-123;
+ * core/image/geometry/transform.py:216-223); align_corners=1 is nn.Upsample(bilinear,
+ * align_corners=True) (llunetpp.py:182, unet.py:82). */
+int ie_resize_bilinear_nchw_f32(const float* src_dev, float* dst_dev, int N, int C, int Hi, int Wi, int Ho, int Wo,
+                                int align_corners, void* stream);
+
+/* ---- generic conv2d (fp32, NHWC) -------------------------------------- */
+/* Replaces torch.nn.Conv2d / F.conv2d as aliased by mon.nn.Conv2d
+ * (src/mon/nn/modules/conv/base.py:45) for every shape on the path:
+ * k in {1,3,4,9}, stride {1,2}, zero or replicate padding
+ * (mon_extra/.../retinexnet/model.py:26-66), groups in {1, Cin} (depthwise,
+ * nn/modules/conv/dsconv.py:122-134), fused bias + activation, and a virtual
+ * channel concat of two sources (torch.cat(dim=1), zero_dce.py:180-182).
+ * Weights: HWIO fp32 [kh][kw][Cin/groups][Cout] on the device (repack with
+ * ie_pack_weight_hwio_f32 from the checkpoint's OIHW). */
+typedef struct ie_conv2d_desc {
+    int N, H, W;        /* input spatial size */
+    int C0, C1;         /* channels of source 0 / source 1 (C1 = 0: single source) */
+    int Cout;
+    int kh, kw, stride, pad;
+    int pad_mode;       /* ie_pad_mode */
+    int groups;         /* 1 or C0 (depthwise; C1 must be 0) */
+    int act;            /* ie_act */
+    float slope;        /* LeakyReLU slope */
+    int Ho, Wo;         /* out: filled by the call */
+} ie_conv2d_desc;
+int ie_conv2d_nhwc_f32(ie_conv2d_desc* d, const float* src0_dev, const float* src1_dev,
+                       const float* w_hwio_dev, const float* bias_dev, float* dst_dev, void* stream);
+/* OIHW fp32 host -> HWIO fp32 device. */
+int ie_pack_weight_hwio_f32(const float* w_oihw_host, int Cout, int Cin, int kh, int kw, float* dst_dev, void* stream);
+
+/* ---- LE curve (zero_dce.py:186-188) ------------------------------------ */
+/* y <- y + r_i (y^2 - y), i < iters; img NCHW fp32 (N,3,H,W); adjust NHWC fp32
+ * with Cp channels (first 3*iters used, already tanh'ed); out NCHW fp32. */
+int ie_le_curve(const float* img_dev, const float* adjust_nhwc_dev, int Cp, float* enhanced_dev,
+                int N, int H, int W, int iters, void* stream);
+
+/* ---- Zero-DCE plan: the fused hot path --------------------------------- */
+/* Replaces ZeroDCE_RE.forward (src/mon/vision/enhance/llie/zero_dce/zero_dce.py:173-191)
+ * == enhance_net_nopool.forward (src/mon_extra/vision/enhance/llie/zero_dce/model.py:28-50). */
+typedef struct ie_zdce_plan ie_zdce_plan;
+
+typedef struct ie_zdce_config {
+    int in_channels;   /* 3 */
+    int num_channels;  /* 32 */
+    int num_iters;     /* 8 */
+    int compute_dtype; /* ie_dtype: IE_F32 (parity mode, VALU fp32), IE_F16 or IE_BF16 (MFMA, fp32 accumulate) */
+    int device;        /* HIP device ordinal */
+    int variant;       /* kernel variant bitmask, 0 = default; see IE_ZDCE_VAR_* */
+} ie_zdce_config;
+
+#define IE_ZDCE_VAR_SYNC_STAGE 1 /* drain the LDS-DMA ring every row (debug / A-B) */
+#define IE_ZDCE_VAR_NARROW_STORE 2 /* 8-byte epilogue stores instead of permlane-widened 16-byte */
+#define IE_ZDCE_VAR_NO_DMA 4 /* register-staged global->LDS copies instead of LDS-DMA (debug / A-B) */
+
+int ie_zdce_create(const ie_zdce_config* cfg, ie_zdce_plan** out);
+/* layer in 1..7 (e_conv{layer}); w OIHW fp32 host, b fp32 host; shapes per zero_dce.py:133-139. */
+int ie_zdce_set_layer(ie_zdce_plan* p, int layer, const float* w_oihw_host, const float* b_host, int Cout, int Cin);
+/* Uploads the repacked weights; all 7 layers must be set. */
+int ie_zdce_finalize(ie_zdce_plan* p, void* stream);
+/* Ensure workspace for (N,H,W); may hipMalloc (synchronises). Called implicitly by forward. */
+int ie_zdce_reserve(ie_zdce_plan* p, int N, int H, int W);
+/* image_dev: NCHW fp32 (N,3,H,W).  Any of the outputs may be NULL:
+ *   enhanced_dev  NCHW fp32 (N,3,H,W)        outputs["enhanced"]
+ *   adjust_dev    NCHW fp32 (N,3*iters,H,W)  outputs["adjust"] (split views give adjust_i)
+ *   u8_dev        NHWC uint8 (N,H,W,3)       save_image rule applied to enhanced */
+int ie_zdce_forward(ie_zdce_plan* p, const float* image_dev, float* enhanced_dev, float* adjust_dev,
+                    uint8_t* u8_dev, int N, int H, int W, void* stream);
+/* Debug/unit parity: copy intermediate feature x{idx} (idx 1..6) of the last forward to
+ * NCHW fp32 (N,num_channels,H,W). */
+int ie_zdce_get_feature(ie_zdce_plan* p, int idx, float* dst_dev, void* stream);
+size_t ie_zdce_workspace_bytes(const ie_zdce_plan* p);
+int ie_zdce_destroy(ie_zdce_plan* p);
+
+/* Timing helper for bench.py: runs `iters` forwards back to back on `stream`
+ * bracketed by hipEvents recorded on that same stream; *ms_total = elapsed ms. */
+int ie_zdce_time_forward(ie_zdce_plan* p, const float* image_dev, float* enhanced_dev, float* adjust_dev,
+                         uint8_t* u8_dev, int N, int H, int W, int iters, void* stream, float* ms_total);
+/* Per-kernel timing of one forward (hipEvents around each launch, same stream):
+ * per layer (cap >= 7): ms[] = summed kernel time, launches[] = launch count (may be NULL),
+ * names[] = static strings; *n = 7. */
+int ie_zdce_profile_forward(ie_zdce_plan* p, const float* image_dev, float* enhanced_dev, float* adjust_dev,
+                            uint8_t* u8_dev, int N, int H, int W, void* stream,
+                            float* ms, const char** names, int* launches, int cap, int* n);
+/* Schedule knobs (0 = automatic): rows per workgroup, rows per band, frames per group.
+ * Also read from IE_ZDCE_RB / IE_ZDCE_BAND / IE_ZDCE_GROUP at create time. */
+int ie_zdce_set_tuning(ie_zdce_plan* p, int rows_per_block, int band_rows, int group_frames);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IE_HIP_H */

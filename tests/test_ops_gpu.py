@@ -1,0 +1,148 @@
+"""GPU parity of the per-op C-ABI entry points against torch CPU / the plain-C oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from mon_amd import capi, image
+from oracle import c_oracle
+from tests.helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _conv_gpu(x, w, b, stride=1, pad=1, pad_mode="zeros", groups=1, act="none", slope=0.0, x1=None):
+    """x, x1: NCHW cpu tensors; runs ie_conv2d_nhwc_f32 and returns NCHW cpu."""
+    L = capi.lib()
+    st = capi.current_stream()
+    n, c0, h, wd = x.shape
+    xs = x.permute(0, 2, 3, 1).contiguous().cuda()
+    x1s = None if x1 is None else x1.permute(0, 2, 3, 1).contiguous().cuda()
+    co, cig, kh, kw = w.shape
+    wdev = torch.empty(kh * kw * cig * co, device="cuda")
+    wc = w.contiguous()
+    capi.check(L.ie_pack_weight_hwio_f32(capi.ptr(wc), co, cig, kh, kw, capi.ptr(wdev), st))
+    bdev = None if b is None else b.cuda()
+    d = capi.Conv2dDesc(n, h, wd, c0, 0 if x1 is None else x1.shape[1], co, kh, kw, stride, pad, capi.PAD[pad_mode],
+                        groups, capi.ACT[act], slope, 0, 0)
+    ho = (h + 2 * pad - kh) // stride + 1
+    wo = (wd + 2 * pad - kw) // stride + 1
+    out = torch.empty((n, ho, wo, co), device="cuda")
+    capi.check(L.ie_conv2d_nhwc_f32(C.byref(d), capi.ptr(xs), capi.ptr(x1s), capi.ptr(wdev), capi.ptr(bdev), capi.ptr(out), st),
+               "ie_conv2d_nhwc_f32")
+    assert (d.Ho, d.Wo) == (ho, wo)
+    return out.permute(0, 3, 1, 2).contiguous().cpu()
+
+
+CASES = [
+    dict(ci=32, co=32, k=3, s=1, p=1, mode="zeros", act="relu"),          # zero_dce.py:134
+    dict(ci=3, co=32, k=3, s=1, p=1, mode="zeros", act="relu"),           # first layer, Cin % 4 != 0
+    dict(ci=4, co=64, k=9, s=1, p=4, mode="replicate", act="none"),       # retinexnet/model.py:26
+    dict(ci=64, co=64, k=3, s=2, p=1, mode="replicate", act="relu"),      # retinexnet/model.py:60
+    dict(ci=192, co=64, k=1, s=1, p=1, mode="replicate", act="none"),     # retinexnet/model.py:66 (grows the map)
+    dict(ci=64, co=1, k=3, s=1, p=0, mode="zeros", act="none"),           # retinexnet/model.py:67
+    dict(ci=64, co=64, k=4, s=2, p=1, mode="zeros", act="none", bias=False),  # hinet.py:65
+    dict(ci=32, co=24, k=3, s=1, p=1, mode="zeros", act="tanh"),
+    dict(ci=16, co=3, k=3, s=1, p=1, mode="zeros", act="sigmoid"),        # zero_ig.py:331
+    dict(ci=32, co=30, k=1, s=1, p=0, mode="zeros", act="lrelu", slope=0.2),
+]
+
+
+@pytest.mark.parametrize("c", CASES, ids=lambda c: f"{c['ci']}-{c['co']}-k{c['k']}s{c['s']}p{c['p']}{c['mode'][0]}-{c['act']}")
+def test_conv2d_generic(c):
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, c["ci"], 21, 37, generator=g)
+    w = torch.randn(c["co"], c["ci"], c["k"], c["k"], generator=g) / (c["ci"] * c["k"] ** 2) ** 0.5
+    b = None if c.get("bias") is False else torch.randn(c["co"], generator=g)
+    xp = F.pad(x, (c["p"],) * 4, mode="replicate") if c["mode"] == "replicate" else x
+    ref = F.conv2d(xp, w, b, stride=c["s"], padding=0 if c["mode"] == "replicate" else c["p"])
+    ref = {"none": lambda t: t, "relu": F.relu, "tanh": torch.tanh, "sigmoid": torch.sigmoid,
+           "lrelu": lambda t: F.leaky_relu(t, c.get("slope", 0.2))}[c["act"]](ref)
+    got = _conv_gpu(x, w, b, c["s"], c["p"], c["mode"], 1, c["act"], c.get("slope", 0.0))
+    assert got.shape == ref.shape
+    assert rel_err(got, ref) <= 2e-5
+
+
+def test_conv2d_two_sources_is_channel_concat():
+    g = torch.Generator().manual_seed(2)
+    a, b2 = torch.randn(1, 32, 19, 23, generator=g), torch.randn(1, 32, 19, 23, generator=g)
+    w = torch.randn(32, 64, 3, 3, generator=g) * 0.05
+    bias = torch.randn(32, generator=g)
+    ref = F.relu(F.conv2d(torch.cat([a, b2], 1), w, bias, padding=1))
+    got = _conv_gpu(a, w, bias, act="relu", x1=b2)
+    assert rel_err(got, ref) <= 2e-5
+
+
+def test_conv2d_depthwise_matches_c_oracle():
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 32, 15, 18, generator=g)
+    w = torch.randn(32, 1, 3, 3, generator=g) * 0.3
+    b = torch.randn(32, generator=g)
+    ref = c_oracle.conv2d(x.numpy(), w.numpy(), b.numpy(), groups=32)
+    got = _conv_gpu(x, w, b, groups=32)
+    assert rel_err(got, ref) <= 2e-5
+
+
+def test_conv2d_rejects_bad_arguments():
+    L = capi.lib()
+    d = capi.Conv2dDesc(1, 8, 8, 4, 0, 4, 3, 3, 1, 1, 0, 2, 0, 0.0, 0, 0)     # groups=2 unsupported
+    t = torch.zeros(1024, device="cuda")
+    assert L.ie_conv2d_nhwc_f32(C.byref(d), capi.ptr(t), None, capi.ptr(t), None, capi.ptr(t), None) == -3
+    assert b"groups" in L.ie_last_error()
+    d = capi.Conv2dDesc(1, 8, 8, 0, 0, 4, 3, 3, 1, 1, 0, 1, 0, 0.0, 0, 0)
+    assert L.ie_conv2d_nhwc_f32(C.byref(d), capi.ptr(t), None, capi.ptr(t), None, capi.ptr(t), None) == -1
+
+
+@pytest.mark.parametrize("dt,tol", [("f32", 0.0), ("f16", 1e-3), ("bf16", 8e-3)])
+def test_layout_roundtrip(dt, tol):
+    L = capi.lib()
+    st = capi.current_stream()
+    x = torch.rand(2, 3, 11, 13, generator=torch.Generator().manual_seed(4)).cuda()
+    esz = {"f32": 4, "f16": 2, "bf16": 2}[dt]
+    mid = torch.zeros(2 * 11 * 13 * 8 * esz, dtype=torch.uint8, device="cuda")
+    back = torch.empty_like(x)
+    capi.check(L.ie_nchw_f32_to_nhwc(capi.ptr(x), capi.ptr(mid), capi.DTYPES[dt], 2, 3, 11, 13, 8, st))
+    capi.check(L.ie_nhwc_to_nchw_f32(capi.ptr(mid), capi.DTYPES[dt], capi.ptr(back), 2, 3, 11, 13, 8, st))
+    assert float((back - x).abs().max()) <= tol
+    if dt == "f32":
+        nhwc = mid.view(torch.float32).reshape(2, 11, 13, 8).cpu()
+        assert torch.equal(nhwc[..., :3], x.cpu().permute(0, 2, 3, 1)) and float(nhwc[..., 3:].abs().max()) == 0.0
+
+
+def test_uint8_rules_and_back():
+    x = torch.cat([torch.rand(1, 3, 31, 33, generator=torch.Generator().manual_seed(5)) * 1.2 - 0.1,
+                   torch.tensor([0.0, 1.0, 0.5, 0.49803922, 127.5 / 255, 254.5 / 255, -3.0, 7.0, 1 / 255, 0.00196]).repeat(3, 1)
+                   .reshape(1, 3, 1, 10).expand(1, 3, 31, 10)], dim=3).contiguous()
+    ref_round = x.mul(255).add(0.5).clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1)
+    ref_trunc = x.mul(255).clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1)
+    assert torch.equal(image.to_uint8(x.cuda(), "save_image").cpu(), ref_round)
+    assert torch.equal(image.to_uint8(x.cuda(), "truncate").cpu(), ref_trunc)
+    u = torch.randint(0, 256, (2, 9, 7, 3), dtype=torch.uint8)
+    assert torch.equal(image.to_float(u.cuda()).cpu(), (u.float() / 255.0).permute(0, 3, 1, 2))
+    # u8 -> float -> u8 is the identity under the save_image rule
+    assert torch.equal(image.to_uint8(image.to_float(u.cuda())).cpu(), u)
+
+
+@pytest.mark.parametrize("ac", [0, 1])
+@pytest.mark.parametrize("sizes", [((40, 72), (64, 96)), ((64, 96), (40, 72)), ((1080 // 8, 1920 // 8), (1088 // 8, 1920 // 8)), ((5, 7), (10, 14))])
+def test_resize_bilinear(ac, sizes):
+    (hi, wi), (ho, wo) = sizes
+    x = torch.rand(2, 3, hi, wi, generator=torch.Generator().manual_seed(6))
+    ref = F.interpolate(x, size=(ho, wo), mode="bilinear", align_corners=bool(ac))
+    out = torch.empty(2, 3, ho, wo, device="cuda")
+    capi.check(capi.lib().ie_resize_bilinear_nchw_f32(capi.ptr(x.cuda()), capi.ptr(out), 2, 3, hi, wi, ho, wo, ac, capi.current_stream()))
+    assert float((out.cpu() - ref).abs().max()) <= 2e-6
+
+
+def test_le_curve_matches_reference_order_bitwise():
+    g = torch.Generator().manual_seed(7)
+    x = torch.rand(2, 3, 17, 19, generator=g)
+    r = torch.rand(2, 24, 17, 19, generator=g) * 2 - 1
+    from oracle import zero_dce as o
+    ref = o.curve(x, r)
+    out = torch.empty(2, 3, 17, 19, device="cuda")
+    adj = r.permute(0, 2, 3, 1).contiguous().cuda()
+    capi.check(capi.lib().ie_le_curve(capi.ptr(x.cuda()), capi.ptr(adj), 24, capi.ptr(out), 2, 17, 19, 8, capi.current_stream()))
+    assert torch.equal(out.cpu(), ref)    # same fp32 association order, no FMA contraction

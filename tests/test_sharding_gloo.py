@@ -1,0 +1,46 @@
+"""CPU, world_size 2 over gloo: the multi-GPU inference path shards frames with no data-path
+collective; gather brings uneven shards back in order."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, n_total, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from mon_amd.sharding import gather_frames, scatter_frames, shard_range
+    frames = torch.arange(n_total * 6, dtype=torch.float32).reshape(n_total, 1, 2, 3)
+    local = scatter_frames(frames, rank, world)
+    lo, hi = shard_range(n_total, rank, world)
+    assert local.shape[0] == hi - lo
+    processed = local * 2 + 1          # stands in for the per-rank enhancement
+    # max-over-ranks timing reduction used by bench.py
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    assert t.item() == world
+    out = gather_frames(processed, n_total, dst=0)
+    if rank == 0:
+        ret["ok"] = bool(torch.equal(out, frames * 2 + 1))
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_scatter_gather_world2():
+    for n_total in (5, 8):
+        mgr = mp.Manager()
+        ret = mgr.dict()
+        port = _free_port()
+        mp.spawn(_worker, args=(2, port, n_total, ret), nprocs=2, join=True)
+        assert ret.get("ok") is True

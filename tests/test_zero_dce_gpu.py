@@ -1,0 +1,162 @@
+"""GPU parity: the HIP Zero-DCE path (through the C ABI) against the reference-generated goldens,
+the CPU oracle on seeded inputs, and size-independent properties at 1080p.
+
+Tolerances (max |a-b| / max |b|, the 'relative fp32' measure of the north star):
+    f32  (VALU parity mode)        <= 1e-4 on every tensor      (bound asked: 1e-3)
+    f16  (MFMA, fp32 accumulate)   <= 1e-3 on `enhanced`; features <= 2e-3
+    bf16 (MFMA, fp32 accumulate)   <= 2e-2 on `enhanced`, PSNR >= 45 dB (storage rounding 2^-9)
+uint8 (save_image rule): f32 mode must differ from the reference in <= 0.1 % of bytes and by at
+most 1 LSB (an fp32 reordering can flip x*255+0.5 across an integer); f16/bf16 <= 1 / 2 LSB.
+"""
+import numpy as np
+import pytest
+import torch
+
+import mon_amd
+from mon_amd import capi
+from oracle import zero_dce as o_zdce
+from tests.helpers import load_golden, psnr, rel_err, zero_dce_goldens
+
+pytestmark = pytest.mark.gpu
+
+TOL_ENH = {"f32": 1e-4, "f16": 1e-3, "bf16": 2e-2}
+TOL_FEAT = {"f32": 1e-4, "f16": 2e-3, "bf16": 2e-2}
+U8_MAXDIFF = {"f32": 1, "f16": 1, "bf16": 2}
+
+
+def _model(sd, dtype, variant=0):
+    return mon_amd.MODELS.build(name="zero_dce_re", weights=dict(sd), compute_dtype=dtype, variant=variant).to("cuda").eval()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("path", zero_dce_goldens(), ids=lambda p: p.split("zero_dce_")[-1][:-4])
+def test_golden_parity(path, dtype):
+    sd, g = load_golden(path)
+    m = _model(sd, dtype)
+    x = torch.from_numpy(g["image"]).cuda()
+    out = m.forward({"image": x})
+    assert list(out.keys())[-1] == "enhanced" and "adjust_7" in out
+    assert out["adjust_3"].data_ptr() == out["adjust"][:, 9:12].data_ptr()
+    enh, adj = out["enhanced"].cpu(), out["adjust"].cpu()
+    assert rel_err(enh, g["enhanced"]) <= TOL_ENH[dtype]
+    assert rel_err(adj, g["adjust"]) <= max(TOL_ENH[dtype], 5 * TOL_ENH[dtype] * (dtype != "f32"))
+    u8 = m.enhance(x, want_enhanced=False, want_u8=True)["u8"].cpu().numpy()
+    d = np.abs(u8.astype(int) - g["enhanced_u8"].astype(int))
+    assert d.max() <= U8_MAXDIFF[dtype]
+    if dtype == "f32":
+        assert (d != 0).mean() <= 1e-3
+    # u8 of the library == save_image rule applied to its own float output
+    own = o_zdce.to_uint8_save_image(enh).numpy()
+    assert np.array_equal(u8, own)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16", "bf16"])
+def test_feature_parity_per_layer(dtype):
+    sd, g = load_golden(zero_dce_goldens()[-1])
+    m = _model(sd, dtype)
+    x = torch.from_numpy(g["image"])
+    ref = o_zdce.forward(sd, x, return_features=True)["_features"]
+    m.enhance(x.cuda())
+    for k in range(1, 7):
+        f = m.feature(k).cpu()
+        assert rel_err(f, ref[k - 1]) <= TOL_FEAT[dtype], f"x{k}"
+
+
+@pytest.mark.parametrize("variant", [capi.VAR_SYNC_STAGE, capi.VAR_NARROW_STORE, capi.VAR_NO_DMA,
+                                     capi.VAR_NO_DMA | capi.VAR_NARROW_STORE])
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_kernel_variants_bit_identical(variant, dtype):
+    """LDS-DMA vs register staging, counted vs drained waits, wide vs narrow stores: same bits."""
+    sd, g = load_golden(zero_dce_goldens()[-1])
+    x = torch.from_numpy(g["image"]).cuda()
+    a = _model(sd, dtype, 0).forward({"image": x})
+    b = _model(sd, dtype, variant).forward({"image": x})
+    assert torch.equal(a["enhanced"], b["enhanced"]) and torch.equal(a["adjust"], b["adjust"])
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1), (1, 3, 5), (2, 2, 129), (1, 17, 128), (3, 9, 257), (1, 130, 64)])
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_ragged_and_tiny_shapes(shape, dtype):
+    n, h, w = shape
+    sd = o_zdce.init_state_dict(seed=11, gain=3.0)
+    x = torch.rand(n, 3, h, w, generator=torch.Generator().manual_seed(5))
+    ref = o_zdce.forward(sd, x)
+    out = _model(sd, dtype).forward({"image": x.cuda()})
+    assert tuple(out["enhanced"].shape) == (n, 3, h, w)
+    assert rel_err(out["enhanced"].cpu(), ref["enhanced"]) <= TOL_ENH[dtype]
+    assert rel_err(out["adjust"].cpu(), ref["adjust"]) <= 5 * TOL_ENH[dtype]
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_schedule_invariance(dtype):
+    """rows-per-workgroup / band / frame-group choices change the launch geometry only: bit-identical."""
+    sd = o_zdce.init_state_dict(seed=12, gain=3.0)
+    x = torch.rand(5, 3, 75, 200, generator=torch.Generator().manual_seed(6)).cuda()
+    m = _model(sd, dtype)
+    base = m.enhance(x, want_adjust=True)
+    for rb, band, group in [(1, 0, 0), (3, 0, 2), (64, 16, 1), (7, 20, 3), (5, 1, 5)]:
+        m.set_tuning(rb, band, group)
+        o = m.enhance(x, want_adjust=True)
+        assert torch.equal(o["enhanced"], base["enhanced"]), (rb, band, group)
+        assert torch.equal(o["adjust"], base["adjust"]), (rb, band, group)
+
+
+def test_oracle_parity_512_config1():
+    """BASELINE config 1: single 512x512 frame against the CPU restatement."""
+    sd = o_zdce.init_state_dict(seed=1, gain=3.0)
+    x = torch.rand(1, 3, 512, 512, generator=torch.Generator().manual_seed(0)) ** 2.2 * 0.25
+    ref = o_zdce.forward(sd, x)["enhanced"]
+    for dtype in ("f32", "f16", "bf16"):
+        out = _model(sd, dtype).enhance(x.cuda())["enhanced"].cpu()
+        assert rel_err(out, ref) <= TOL_ENH[dtype], dtype
+        if dtype == "bf16":
+            assert psnr(out, ref) >= 45.0
+
+
+def test_1080p_properties():
+    """Full-size checks that need no CPU reference: batch independence, determinism, row-band
+    consistency with a cropped run away from the borders, and identity curve for zero weights."""
+    sd = o_zdce.init_state_dict(seed=3, gain=3.0)
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(3, 3, 1080, 1920, generator=g).cuda()
+    m = _model(sd, "f16")
+    full = m.enhance(x, want_u8=True)
+    again = m.enhance(x, want_u8=True)
+    assert torch.equal(full["enhanced"], again["enhanced"]) and torch.equal(full["u8"], again["u8"])
+    single = m.enhance(x[1:2])
+    assert torch.equal(full["enhanced"][1:2], single["enhanced"])             # frames are independent
+    # a 7-layer 3x3 stack has a 7-pixel receptive radius: a crop agrees on its interior
+    crop = m.enhance(x[:1, :, 300:500, 600:1000].contiguous())["enhanced"]
+    assert torch.equal(crop[:, :, 7:-7, 7:-7], full["enhanced"][:1, :, 307:493, 607:993])
+    assert float(full["enhanced"].min()) >= 0.0 and float(full["enhanced"].max()) <= 1.0
+    # all-zero weights and biases: r = tanh(0) = 0, the curve is the identity -> output == input bit for bit
+    z = {k: torch.zeros_like(v) for k, v in sd.items()}
+    ident = _model(z, "bf16").enhance(x[:1])["enhanced"]
+    assert torch.equal(ident, x[:1])
+
+
+def test_infer_resizes_to_multiple_of_32_and_back():
+    sd = o_zdce.init_state_dict(seed=4, gain=2.0)
+    m = _model(sd, "f32")
+    x = torch.rand(1, 3, 40, 72, generator=torch.Generator().manual_seed(2))
+    out = m.infer({"image": x.clone()})
+    assert tuple(out["enhanced"].shape) == (1, 3, 40, 72) and out["time"] > 0
+    import torch.nn.functional as F
+    xr = F.interpolate(x, size=(64, 96), mode="bilinear", align_corners=False)
+    ref = F.interpolate(o_zdce.forward(sd, xr)["enhanced"], size=(40, 72), mode="bilinear", align_corners=False)
+    assert rel_err(out["enhanced"].cpu(), ref) <= 1e-4
+    # sizes already divisible by 32 take no resize: infer == forward
+    y = torch.rand(1, 3, 64, 96, generator=torch.Generator().manual_seed(3)).cuda()
+    assert torch.equal(m.infer({"image": y})["enhanced"], m.forward({"image": y})["enhanced"])
+
+
+def test_error_behaviour_on_gpu():
+    m = mon_amd.ZeroDCE_RE(seed=1).to("cuda")
+    with pytest.raises(ValueError):
+        m.forward({"image": torch.rand(1, 4, 8, 8).cuda()})
+    with pytest.raises(ValueError):
+        m.forward({"ref_image": torch.rand(1, 3, 8, 8).cuda()})
+    with pytest.raises(ValueError):
+        mon_amd.ZeroDCE_RE(compute_dtype="int8")
+    with pytest.raises(capi.IEError):
+        mon_amd.ZeroDCE_RE(num_channels=16, seed=1).to("cuda").forward({"image": torch.rand(1, 3, 8, 8).cuda()})
