@@ -1,0 +1,185 @@
+#!/usr/bin/env python
+"""Headline benchmark: enhanced images/sec @1920x1080, Zero-DCE, batch 64 per GPU (BASELINE.json
+configs[1]), bf16 storage / fp32 accumulate, inputs resident in HBM.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one pass of the hot path (ZeroDCE_RE forward: NCHW fp32 frames in -> `enhanced` NCHW
+fp32 out) over one batch of 64 synthetic frames per GPU.  Frames are independent, so ranks shard
+the frames with no data-path collective ("scaling": "weak": per-GPU work is fixed).  Rank 0 prints
+ONE JSON line; see DESIGN.md "Measurement" for the definition of every field.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H, W = 1080, 1920
+BATCH_PER_GPU = 64
+FLOP_PER_PX = 158400                      # 2 * 79,200 MAC
+# per-layer algorithmic work per pixel: (flop, bytes moved at 2 B/elem activations, fp32 image)
+LAYER_FLOP_PX = [2 * 27 * 32, 2 * 288 * 32, 2 * 288 * 32, 2 * 288 * 32, 2 * 576 * 32, 2 * 576 * 32, 2 * 576 * 24]
+LAYER_BYTES_PX = [12 + 64, 64 + 64, 64 + 64, 64 + 64, 128 + 64, 128 + 64, 128 + 12 + 12]
+PEAK_MFMA_TFLOPS = 2500.0                 # dense bf16/f16, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="frames per GPU per step")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
+    ap.add_argument("--output", default="f32", choices=["f32", "u8"], help="enhanced as fp32 NCHW or uint8 NHWC")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import mon_amd
+    from mon_amd import capi
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from oracle import zero_dce as o_zdce      # only for the seeded weight rule + the CPU baseline leg
+    sd = o_zdce.init_state_dict(seed=1, gain=3.0)
+    model = mon_amd.MODELS.build(name="zero_dce_re", weights=dict(sd), compute_dtype=args.dtype).to(dev).eval()
+
+    n = args.batch
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    x = torch.rand((n, 3, H, W), generator=g, device=dev, dtype=torch.float32)
+    out = {"enhanced": torch.empty_like(x)} if args.output == "f32" else {"u8": torch.empty((n, H, W, 3), device=dev, dtype=torch.uint8)}
+    kw = dict(want_enhanced=args.output == "f32", want_u8=args.output == "u8", out=out)
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        model.enhance(x, **kw)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        model.enhance(x, **kw)
+    sync_all()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    ms_per_step = dt / args.steps * 1e3
+    value = n * world * args.steps / dt
+
+    roofline = None
+    cpu_baseline = None
+    parity = None
+    if rank == 0:
+        # ---- per-kernel timing with hipEvents on the launch stream (ie_zdce_profile_forward) ----
+        import ctypes as C
+        L = capi.lib()
+        plan = model._ensure_plan()
+        ms = (C.c_float * 8)()
+        names = (C.c_char_p * 8)()
+        launches = (C.c_int * 8)()
+        cnt = C.c_int(0)
+        reps = 3
+        acc = [0.0] * 7
+        nl = [0] * 7
+        for _ in range(reps):
+            capi.check(L.ie_zdce_profile_forward(plan, capi.ptr(x), capi.ptr(out.get("enhanced")), None, capi.ptr(out.get("u8")),
+                                                 n, H, W, capi.current_stream(), ms, names, launches, 8, C.byref(cnt)))
+            for i in range(7):
+                acc[i] += ms[i] / reps
+                nl[i] = launches[i]
+        layer_ms = {names[i].decode(): round(acc[i], 4) for i in range(7)}
+        dom = max(range(7), key=lambda i: acc[i])
+        px_per_launch = n * H * W / max(nl[dom], 1)
+        avg_ms = acc[dom] / max(nl[dom], 1)
+        flops = LAYER_FLOP_PX[dom] * px_per_launch
+        byts = LAYER_BYTES_PX[dom] * px_per_launch
+        hbm_bound = (LAYER_FLOP_PX[dom] / LAYER_BYTES_PX[dom]) < (PEAK_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9))
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(names[dom].decode())
+            except Exception:
+                traffic = None
+        if hbm_bound:
+            achieved = byts / (avg_ms * 1e-3) / 1e9
+            roofline = {"kernel": names[dom].decode(), "bound": "hbm", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS,
+                        "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": traffic,
+                        "avg_launch_ms": round(avg_ms, 4), "launches_per_step": nl[dom],
+                        "mfma_tflops": round(flops / (avg_ms * 1e-3) / 1e12, 1)}
+        else:
+            achieved = flops / (avg_ms * 1e-3) / 1e12
+            roofline = {"kernel": names[dom].decode(), "bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_MFMA_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(achieved / PEAK_MFMA_TFLOPS, 4), "traffic": traffic,
+                        "avg_launch_ms": round(avg_ms, 4), "launches_per_step": nl[dom]}
+        roofline["layer_ms_per_step"] = layer_ms
+        roofline["model_mfma_frac"] = round(value / world * H * W * FLOP_PER_PX / (PEAK_MFMA_TFLOPS * 1e12), 4)
+
+        # ---- parity of this very configuration on one frame + CPU baseline (oracle, "port") ----
+        if world == 1 and not args.no_cpu_baseline:
+            xs = x[:1].cpu()
+            torch.set_num_threads(os.cpu_count() or 1)
+            with torch.no_grad():
+                o_zdce.forward(sd, xs)                  # warm-up
+                ts = []
+                for _ in range(3):
+                    c0 = time.perf_counter()
+                    ref = o_zdce.forward(sd, xs)["enhanced"]
+                    ts.append(time.perf_counter() - c0)
+            ts.sort()
+            cpu_baseline = {"value": round(1.0 / ts[1], 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+                            "sample": "1 frame 1920x1080 fp32, torch CPU restatement (oracle/zero_dce.py), 1 warm-up + median of 3"}
+            got = model.enhance(x[:1], want_enhanced=True, want_u8=True)
+            e = got["enhanced"].cpu()
+            err = float((e - ref).abs().max() / ref.abs().max())
+            mse = float(((e.double() - ref.double()) ** 2).mean())
+            import math
+            u8ref = o_zdce.to_uint8_save_image(ref)
+            d = (got["u8"].cpu().int() - u8ref.int()).abs()
+            parity = {"max_rel_err": float(f"{err:.3e}"), "psnr_db_vs_cpu_fp32": round(10 * math.log10(1.0 / mse), 2) if mse > 0 else None,
+                      "u8_exact_match": round(float((d == 0).float().mean()), 5), "u8_max_abs_diff": int(d.max())}
+
+        line = {
+            "metric": "enhanced_images_per_sec_1080p", "value": round(value, 2), "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "zero_dce_re batch=64/GPU 1920x1080 (BASELINE.json configs[1])", "frames_per_gpu": n,
+                       "global_batch": n * world, "height": H, "width": W, "input": "NCHW fp32 in HBM",
+                       "output": "enhanced NCHW fp32" if args.output == "f32" else "enhanced NHWC uint8",
+                       "parallelism": f"frames sharded over {world} GPU(s), no collective", "tflops_per_gpu": round(value / world * H * W * FLOP_PER_PX / 1e12, 1)},
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,
+        }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

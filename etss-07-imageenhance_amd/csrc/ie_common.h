@@ -77,13 +77,17 @@ __device__ __forceinline__ float ie_sigmoid_fast(float x) {
 // One LE-curve step in the reference's fp32 association order
 // (zero_dce.py:187: y + r * (pow(y,2) - y)); no FMA contraction.
 __device__ __forceinline__ float ie_curve_step(float y, float r) {
-    const float t = __fmul_rn(y, y);
-    const float u = __fsub_rn(t, y);
-    return __fadd_rn(y, __fmul_rn(r, u));
+#pragma clang fp contract(off)
+    const float t = y * y;
+    const float u = t - y;
+    const float v = r * u;
+    return y + v;
 }
 // torchvision save_image rule: clamp(x*255+0.5, 0, 255) -> u8 (truncate).
 __device__ __forceinline__ unsigned char ie_quant_u8(float v) {
-    float q = __fadd_rn(__fmul_rn(v, 255.0f), 0.5f);
+#pragma clang fp contract(off)
+    float q = v * 255.0f;
+    q = q + 0.5f;
     q = fminf(fmaxf(q, 0.0f), 255.0f);
     return (unsigned char)q;
 }

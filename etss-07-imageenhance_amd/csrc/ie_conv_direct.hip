@@ -185,7 +185,7 @@ IE_EXPORT int ie_pack_weight_hwio_f32(const float* w_oihw_host, int Cout, int Ci
         e = hipGetLastError();
     }
     hipError_t e2 = hipStreamSynchronize(st);
-    hipFree(tmp);
+    (void)hipFree(tmp);
     if (e != hipSuccess) IE_FAIL(IE_ERR_HIP, "ie_pack_weight_hwio_f32: %s", hipGetErrorString(e));
     if (e2 != hipSuccess) IE_FAIL(IE_ERR_HIP, "ie_pack_weight_hwio_f32: %s", hipGetErrorString(e2));
     return IE_OK;

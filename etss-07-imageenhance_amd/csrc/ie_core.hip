@@ -63,7 +63,7 @@ __global__ void f32_to_u8_kernel(const float* __restrict__ src, unsigned char* _
     for (int c = 0; c < C; ++c) {
         const float v = s[(size_t)c * plane];
         if (mode == 0) d[c] = ie_quant_u8(v);
-        else d[c] = (unsigned char)fminf(fmaxf(__fmul_rn(v, 255.f), 0.f), 255.f);
+        else d[c] = (unsigned char)fminf(fmaxf(v * 255.f, 0.f), 255.f);
     }
 }
 

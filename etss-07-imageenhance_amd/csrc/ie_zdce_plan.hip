@@ -169,7 +169,7 @@ IE_EXPORT int ie_zdce_finalize(ie_zdce_plan* p, void* stream) {
         const char* q = (const char*)hb.data();
         host.insert(host.end(), q, q + 32 * 4);
     }
-    if (p->d_w) { hipFree(p->d_w); p->d_w = nullptr; }
+    if (p->d_w) { (void)hipFree(p->d_w); p->d_w = nullptr; }
     IE_HIP_CHECK(hipMalloc(&p->d_w, host.size()));
     hipStream_t st = (hipStream_t)stream;
     IE_HIP_CHECK(hipMemcpyAsync(p->d_w, host.data(), host.size(), hipMemcpyHostToDevice, st));
@@ -180,7 +180,7 @@ IE_EXPORT int ie_zdce_finalize(ie_zdce_plan* p, void* stream) {
 
 // bytes of workspace per frame
 static size_t ws_per_frame(const ie_zdce_plan* p, int H, int W) {
-    if (p->cfg.compute_dtype == IE_F32) return (frame_elems(H, W, 4) + 6 * frame_elems(H, W, 32) + frame_elems(H, W, 24)) * 4;
+    if (p->cfg.compute_dtype == IE_F32) return (2 * frame_elems(H, W, 4) + 6 * frame_elems(H, W, 32) + frame_elems(H, W, 24)) * 4;
     return 6 * frame_elems(H, W, 32) * elem_size(p);
 }
 
@@ -191,7 +191,7 @@ IE_EXPORT int ie_zdce_reserve(ie_zdce_plan* p, int N, int H, int W) {
     const size_t need = ws_per_frame(p, H, W) * g + 1024;
     if (need > p->ws_bytes) {
         IE_HIP_CHECK(hipSetDevice(p->cfg.device));
-        if (p->ws) { IE_HIP_CHECK(hipDeviceSynchronize()); hipFree(p->ws); p->ws = nullptr; p->ws_bytes = 0; }
+        if (p->ws) { IE_HIP_CHECK(hipDeviceSynchronize()); (void)hipFree(p->ws); p->ws = nullptr; p->ws_bytes = 0; }
         hipError_t e = hipMalloc(&p->ws, need);
         if (e != hipSuccess) { ie_set_error("ie_zdce_reserve: hipMalloc(%zu) failed: %s", need, hipGetErrorString(e)); return IE_ERR_NOMEM; }
         p->ws_bytes = need;
@@ -208,11 +208,11 @@ struct ProfScope {
     ProfScope(ie_zdce_plan* p_, int layer, hipStream_t st_) : p(p_), st(st_), on(p_->prof) {
         if (!on) return;
         hipEvent_t a, b;
-        hipEventCreate(&a); hipEventCreate(&b);
+        (void)hipEventCreate(&a); (void)hipEventCreate(&b);
         p->ev.push_back(a); p->ev.push_back(b); p->ev_layer.push_back(layer);
-        hipEventRecord(a, st);
+        (void)hipEventRecord(a, st);
     }
-    ~ProfScope() { if (on) hipEventRecord(p->ev.back(), st); }
+    ~ProfScope() { if (on) (void)hipEventRecord(p->ev.back(), st); }
 };
 }  // namespace
 
@@ -242,10 +242,9 @@ static int forward_f32(ie_zdce_plan* p, const float* image, float* enhanced, flo
                                     (const float*)(p->d_w + p->off_b[l]), l == 6 ? adj : x[l + 1], st);
             if (rc) return rc;
         }
-        (void)e24;
         float* enh = enhanced ? enhanced + (size_t)n0 * 3 * H * W : nullptr;
         float* tmp_enh = enh;
-        if (!tmp_enh) tmp_enh = x[1];  // x1 is dead after conv7: reuse as scratch for u8-only output
+        if (!tmp_enh) tmp_enh = adj + e24 * group;  // plan-owned scratch for u8-only output
         rc = ie_le_curve(img, adj, 24, tmp_enh, g, H, W, 8, st);
         if (rc) return rc;
         if (u8) { rc = ie_nchw_f32_to_u8_nhwc(tmp_enh, u8 + (size_t)n0 * H * W * 3, g, 3, H, W, 0, st); if (rc) return rc; }
@@ -329,11 +328,11 @@ IE_EXPORT int ie_zdce_get_feature(ie_zdce_plan* p, int idx, float* dst, void* st
 
 IE_EXPORT int ie_zdce_destroy(ie_zdce_plan* p) {
     if (!p) return IE_OK;
-    hipSetDevice(p->cfg.device);
-    hipDeviceSynchronize();
-    if (p->d_w) hipFree(p->d_w);
-    if (p->ws) hipFree(p->ws);
-    for (hipEvent_t e : p->ev) hipEventDestroy(e);
+    (void)hipSetDevice(p->cfg.device);
+    (void)hipDeviceSynchronize();
+    if (p->d_w) (void)hipFree(p->d_w);
+    if (p->ws) (void)hipFree(p->ws);
+    for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
     delete p;
     return IE_OK;
 }
@@ -351,8 +350,8 @@ IE_EXPORT int ie_zdce_time_forward(ie_zdce_plan* p, const float* image, float* e
     IE_HIP_CHECK(hipEventRecord(b, st));
     IE_HIP_CHECK(hipEventSynchronize(b));
     if (rc == IE_OK) IE_HIP_CHECK(hipEventElapsedTime(ms_total, a, b));
-    hipEventDestroy(a);
-    hipEventDestroy(b);
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
     return rc;
 }
 
@@ -360,7 +359,7 @@ IE_EXPORT int ie_zdce_profile_forward(ie_zdce_plan* p, const float* image, float
                                       int N, int H, int W, void* stream, float* ms, const char** names, int* launches,
                                       int cap, int* n) {
     if (!p || !ms || !names || !n || cap < NL) IE_FAIL(IE_ERR_INVALID, "ie_zdce_profile_forward: bad args (cap >= 7)");
-    for (hipEvent_t e : p->ev) hipEventDestroy(e);
+    for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
     p->ev.clear(); p->ev_layer.clear();
     p->prof = true;
     int rc = ie_zdce_forward(p, image, enhanced, adjust, u8, N, H, W, stream);
@@ -375,7 +374,7 @@ IE_EXPORT int ie_zdce_profile_forward(ie_zdce_plan* p, const float* image, float
         if (launches) launches[p->ev_layer[i]] += 1;
     }
     *n = NL;
-    for (hipEvent_t e : p->ev) hipEventDestroy(e);
+    for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
     p->ev.clear(); p->ev_layer.clear();
     return IE_OK;
 }
