@@ -144,7 +144,8 @@ def main():
         # ---- parity of this very configuration on one frame + CPU baseline (oracle, "port") ----
         if world == 1 and not args.no_cpu_baseline:
             xs = x[:1].cpu()
-            torch.set_num_threads(os.cpu_count() or 1)
+            ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            torch.set_num_threads(max(1, min(ncpu, 64)))
             with torch.no_grad():
                 o_zdce.forward(sd, xs)                  # warm-up
                 ts = []
