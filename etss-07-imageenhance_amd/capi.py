@@ -18,7 +18,7 @@ DTYPES = {"f32": IE_F32, "fp32": IE_F32, "float32": IE_F32, "f16": IE_F16, "fp16
           "bf16": IE_BF16, "bfloat16": IE_BF16}
 ACT = {"none": 0, "relu": 1, "lrelu": 2, "tanh": 3, "sigmoid": 4}
 PAD = {"zeros": 0, "replicate": 1}
-VAR_SYNC_STAGE, VAR_NARROW_STORE, VAR_NO_DMA = 1, 2, 4
+VAR_SYNC_STAGE, VAR_NARROW_STORE, VAR_NO_DMA, VAR_UNFUSED = 1, 2, 4, 8
 
 # every exported symbol of include/ie_hip.h (checked by tests/test_capi_symbols.py)
 SYMBOLS = [

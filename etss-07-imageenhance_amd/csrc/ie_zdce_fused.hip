@@ -1,0 +1,504 @@
+// Two-stage fused strip kernels for Zero-DCE (gfx950): the intermediate of the pair never goes
+// to HBM (or goes there once, write-only, when a later layer needs it).
+//
+//   K12: e_conv1 (image -> x1, stored) + e_conv2 (x1 -> x2)           12+64+64 = 140 B/px (was 204)
+//   K45: e_conv4 (x3 -> x4, LDS only) + e_conv5 ([x3,x4] -> x5)       64+64    = 128 B/px (was 320)
+//   K67: e_conv6 ([x2,x5] -> x6, LDS only) + e_conv7 ([x1,x6]) + curve 192+12+12 = 216 B/px (was 344)
+//
+// Reference semantics: src/mon/vision/enhance/llie/zero_dce/zero_dce.py:173-191.
+//
+// One workgroup = 8 waves.  Waves 0-3 run stage A, waves 4-7 stage B, both on the same 128 computed
+// columns of a strip and in lock step down the rows (one s_barrier per row): at step t stage A
+// finishes row r of its output and writes it (ReLU, 16-bit, zero outside the image = the next
+// layer's zero padding) into a 2-slot LDS ring in exactly the swizzled [pixel][32ch] image the
+// consumer's ds_read_b128 fragments expect; stage B consumes that row at step t+1.  A-waves and
+// B-waves share each SIMD, so A's VALU/LDS work (im2col for e_conv1, ring writes) overlaps B's MFMAs.
+// Stage B needs a 1-column halo of A's output, so of the 128 computed columns the centre 126 are
+// stored and strips advance by 126 columns.
+//
+// Per-stage machinery is the one of zdce_conv3x3_mfma (ie_zdce_kernels.hip): weights as the MFMA A
+// operand in registers, HBM rows DMA'd once into LDS rings (buffer_load ... lds) behind counted
+// vmcnt waits, every pixel fragment feeding three MFMAs (ky = 0,1,2) into rotating accumulators.
+#include "ie_zdce_internal.h"
+
+namespace {
+
+constexpr int TW = 128;          // computed columns per workgroup
+constexpr int TS = 126;          // stored columns per workgroup (strip pitch)
+constexpr int ROW_PX = TW + 2;   // pixels per ring row (body + 2 halo)
+constexpr unsigned OOB = 0x80000000u;
+constexpr int PF = 3;            // rows of DMA issued ahead
+
+enum { K12 = 12, K45 = 45, K67 = 67 };
+
+struct FusedParams {
+    const void* a_src0;  // stage A HBM source 0 (NHWC T)            K45: x3, K67: x2
+    const void* a_src1;  // stage A HBM source 1                     K67: x5
+    const void* b_src;   // stage B HBM source with its own ring     K67: x1
+    const float* img;    // NCHW fp32 image                          K12 (A input), K67 (curve)
+    const void* a_w; const float* a_bias;
+    const void* b_w; const float* b_bias;
+    void* a_dst;         // K12: x1 (NHWC T)
+    void* b_dst;         // K12: x2, K45: x5
+    float* enhanced; float* adjust; unsigned char* u8;   // K67
+    int N, H, W;
+    int y_begin, y_end, rows_per_block, strips, chunks, n_begin;
+};
+
+__device__ __forceinline__ void wait_vm(int n) {
+    // s_waitcnt takes an immediate; n is wave-uniform.  n < 0: this wave has nothing to wait for.
+#define IE_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    switch (n) {
+    IE_W(1) IE_W(2) IE_W(3) IE_W(4) IE_W(5) IE_W(6) IE_W(7) IE_W(8) IE_W(9) IE_W(10) IE_W(11) IE_W(12) IE_W(13) IE_W(14)
+    IE_W(15) IE_W(16) IE_W(17) IE_W(18) IE_W(19) IE_W(20) IE_W(21) IE_W(22) IE_W(23) IE_W(24)
+    default: if (n >= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+#undef IE_W
+}
+
+}  // namespace
+
+template <typename T, int KIND>
+__device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
+    using E = ie_elem<T>;
+    using frag = typename E::frag;
+    constexpr int PXB = 32 * sizeof(T);                     // 64 B per pixel per tensor
+    constexpr int ROW_B = ROW_PX * PXB;                     // one ring row of one tensor
+    constexpr int NSA = (KIND == K67) ? 2 : (KIND == K45 ? 1 : 0);   // stage A HBM sources (K12: image)
+    constexpr int NSB = (KIND == K12) ? 1 : 2;                       // stage B sources (concat order)
+    constexpr int NW = 9 * (NSB > NSA ? NSB : (NSA > 0 ? NSA : 1));  // weight fragments held per wave
+    // ---- LDS carve ------------------------------------------------------------------------------
+    constexpr int NRA = (KIND == K45) ? PF + 3 : PF + 1;    // slots of the A rings (K45: B re-reads x3 two rows later)
+    constexpr int A_RING_B = NSA * NRA * ROW_B;
+    constexpr int NRB = PF + 1;                             // K67: x1 ring of stage B
+    constexpr int B_RING_B = (KIND == K67) ? NRB * ROW_B : 0;
+    constexpr int RA_B = 2 * ROW_B;                         // A -> B hand-off ring (2 slots)
+    constexpr int NRI = (KIND == K12) ? PF + 3 : PF + 1;    // image ring slots
+    constexpr int IMG_SLOT_B = 2048;                        // 3 planes x 132 px fp32 (K12) / 3 x 128 (K67)
+    constexpr int IMG_B = (KIND == K45) ? 0 : NRI * IMG_SLOT_B;
+    constexpr int OFF_BRING = A_RING_B, OFF_RA = OFF_BRING + B_RING_B, OFF_IMG = OFF_RA + RA_B, OFF_STAGE = OFF_IMG + IMG_B;   // K67: [24][128] fp32 tanh staging
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int stg = wave >> 2;          // 0 = stage A, 1 = stage B
+    const int sw = wave & 3;            // wave within the stage
+    const int p16 = lane & 15, kq = lane >> 4;
+    const int ph = sw & 1, ch = sw >> 1;
+
+    int b = blockIdx.x;
+    const int strip = b % p.strips; b /= p.strips;
+    const int chunk = b % p.chunks; b /= p.chunks;
+    const int n = p.n_begin + b;
+    const int xc0 = strip * TS - 1;                         // image column of computed column 0
+    const int ys = p.y_begin + chunk * p.rows_per_block;
+    const int ye = min(ys + p.rows_per_block, p.y_end);
+    const int n_steps = (ye - ys) + 5;
+    const int H = p.H, W = p.W;
+    const size_t plane = (size_t)H * W;
+    const size_t frame_b = plane * PXB;
+
+    // ---- buffer descriptors -----------------------------------------------------------------------
+    auto mk = [&](const void* base, size_t bytes) __attribute__((always_inline)) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+    };
+    const auto rsA0 = mk((const char*)(NSA >= 1 ? p.a_src0 : p.b_w) + (NSA >= 1 ? (size_t)n * frame_b : 0), frame_b);
+    const auto rsA1 = mk((const char*)(NSA >= 2 ? p.a_src1 : p.b_w) + (NSA >= 2 ? (size_t)n * frame_b : 0), frame_b);
+    const auto rsB = mk((const char*)(KIND == K67 ? p.b_src : p.b_w) + (KIND == K67 ? (size_t)n * frame_b : 0), frame_b);
+    const auto rsI = mk((const char*)(KIND != K45 ? (const void*)(p.img + (size_t)n * 3 * plane) : p.b_w), 3 * plane * 4);
+    const auto rsDa = mk((char*)(KIND == K12 ? p.a_dst : (void*)p.b_w) + (KIND == K12 ? (size_t)n * frame_b : 0), frame_b);
+    const auto rsDb = mk((char*)(KIND != K67 ? p.b_dst : (void*)p.b_w) + (KIND != K67 ? (size_t)n * frame_b : 0), frame_b);
+
+    // ---- weights of this wave's stage into registers -------------------------------------------
+    frag wv[NW];
+    {
+        const int nfr = stg ? 9 * NSB : (KIND == K12 ? 1 : 9 * NSA);   // fragments per cout half
+        const frag* wp = (const frag*)(stg ? p.b_w : p.a_w) + (size_t)ch * nfr * 64;
+#pragma unroll
+        for (int f = 0; f < NW; ++f) wv[f] = wp[(f < nfr ? f : 0) * 64 + lane];
+    }
+    ie_f32x4 bias4;
+    {
+        const float* bp = stg ? p.b_bias : p.a_bias;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bias4[i] = bp[16 * ch + 4 * kq + i];
+    }
+
+    // ---- DMA geometry ------------------------------------------------------------------------------
+    int body_xoff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int q = (2 * sw + j) * 16 + (lane >> 2);
+        const int s = (lane & 3) ^ ((q >> 1) & 3);
+        const int x = xc0 + q;
+        body_xoff[j] = (x >= 0 && x < W) ? (x * PXB + s * 16) : -1;
+    }
+    int halo_xoff;
+    {
+        const int x = (lane < 4) ? (xc0 - 1) : (xc0 + TW);
+        halo_xoff = (lane < 8 && x >= 0 && x < W) ? (x * PXB + (lane & 3) * 16) : -1;
+    }
+    // one ring row of one tensor: 2 body DMAs per wave + the halo DMA (wave 0 of the stage).
+    // (a macro, not a lambda: the buffer-resource type cannot be a host-side function parameter)
+#define IE_DMA_ROW(RS, SLOT, Y)                                                                                        \
+    do {                                                                                                               \
+        char* slot_ = (SLOT);                                                                                          \
+        const int y_ = (Y);                                                                                            \
+        const bool row_ok_ = (y_ >= 0) && (y_ < H);                                                                    \
+        const unsigned row_b_ = (unsigned)y_ * (unsigned)W * PXB;                                                      \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                \
+            const unsigned off_ = (row_ok_ && body_xoff[j] >= 0) ? row_b_ + (unsigned)body_xoff[j] : OOB;              \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (__attribute__((address_space(3))) void*)(slot_ + (2 * sw + j) * 1024), \
+                                                     16, (int)off_, 0, 0, 0);                                          \
+        }                                                                                                              \
+        if (sw == 0) {                                                                                                 \
+            const unsigned off_ = (row_ok_ && halo_xoff >= 0) ? row_b_ + (unsigned)halo_xoff : OOB;                    \
+            if (lane < 8)                                                                                              \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (__attribute__((address_space(3))) void*)(slot_ + TW * PXB), 16, \
+                                                         (int)off_, 0, 0, 0);                                          \
+        }                                                                                                              \
+    } while (0)
+    // K12 image ring: element e = 64*(2*sw+j) + lane over [3 planes][132 px]; px <-> x = xc0 - 1 + px
+    int img12_off[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int e = 64 * (2 * sw + j) + lane;
+        const int pl = e / 132, px = e - 132 * pl;
+        const int x = xc0 - 1 + px;
+        img12_off[j] = (pl < 3 && px < 130 && x >= 0 && x < W) ? (int)(pl * plane * 4 + (size_t)x * 4) : -1;
+    }
+    // K67 curve image ring: wave sw < 3 loads plane sw, columns xc0 + 64j + lane
+    int img67_off[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int x = xc0 + 64 * j + lane;
+        img67_off[j] = (x >= 0 && x < W) ? x * 4 : -1;
+    }
+
+    // issue the DMA for step `t` (this wave's stage only)
+    auto issue = [&](int t) __attribute__((always_inline)) {
+        if (stg == 0) {
+            if constexpr (NSA >= 1) IE_DMA_ROW(rsA0, smem + (t % NRA) * ROW_B, ys - 2 + t);
+            if constexpr (NSA >= 2) IE_DMA_ROW(rsA1, smem + NRA * ROW_B + (t % NRA) * ROW_B, ys - 2 + t);
+            if constexpr (KIND == K12) {
+                const int y = ys - 2 + t;
+                const bool row_ok = (y >= 0) && (y < H);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const unsigned off = (row_ok && img12_off[j] >= 0) ? (unsigned)img12_off[j] + (unsigned)y * (unsigned)W * 4u : OOB;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                        rsI, (__attribute__((address_space(3))) void*)(smem + OFF_IMG + (t % NRI) * IMG_SLOT_B + (2 * sw + j) * 256), 4,
+                        (int)off, 0, 0, 0);
+                }
+            }
+        } else {
+            if constexpr (KIND == K67) {
+                IE_DMA_ROW(rsB, smem + OFF_BRING + (t % NRB) * ROW_B, ys - 4 + t);
+                if (sw < 3) {
+                    const int yo = ys - 5 + t;
+                    const bool ok = (yo >= ys) && (yo < ye);
+                    const unsigned base = ((unsigned)sw * (unsigned)plane + (unsigned)yo * (unsigned)W) * 4u;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const unsigned off = (ok && img67_off[j] >= 0) ? base + (unsigned)img67_off[j] : OOB;
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                            rsI, (__attribute__((address_space(3))) void*)(smem + OFF_IMG + (t % NRI) * IMG_SLOT_B + sw * (TW * 4) + j * 256),
+                            4, (int)off, 0, 0, 0);
+                    }
+                }
+            }
+        }
+    };
+    // DMA instructions per step of this wave -> counted wait that leaves PF-1 younger rows in flight
+    // plus, for K12's stage A, the S = 4 unconditional (OOB-masked) x1 stores of every step >= 2 that
+    // were issued after the awaited row's loads.  Waves that issue no DMA do not wait at all.
+    int L = 0, S = 0;
+    if (stg == 0) { L = (KIND == K12) ? 2 : (2 * NSA + (sw == 0 ? NSA : 0)); S = (KIND == K12) ? 4 : 0; }
+    else if (KIND == K67) L = 2 + (sw == 0 ? 1 : 0) + (sw < 3 ? 2 : 0);
+    const int wait_base = L ? (PF - 1) * L : -1;
+
+    // ---- LDS read offsets of the B operand (as in zdce_conv3x3_mfma) --------------------------------
+    auto lds_px = [&](int q) __attribute__((always_inline)) { return q * PXB + ((kq ^ ((q >> 1) & 3)) << 4); };
+    int rd_base[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) rd_base[kx] = lds_px(64 * ph + 16 + p16 + kx - 1) - 1024;
+    int rd_first, rd_last;
+    {
+        const int xf = 64 * ph + p16 - 1;
+        rd_first = lds_px(xf < 0 ? TW : xf);
+        const int xl = 64 * ph + 48 + p16 + 1;
+        rd_last = lds_px(xl >= TW ? TW + 1 : xl);
+    }
+
+    // one source row into the three live accumulator sets
+    auto src_mfma = [&](const char* row, int wbase, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int off = (kx == 0 && nt == 0) ? rd_first : (kx == 2 && nt == 3) ? rd_last : rd_base[kx] + 1024 * nt;
+                const frag bx = *(const frag*)(row + off);
+                accN[nt] = E::mfma16(wv[wbase + 0 * 3 + kx], bx, accN[nt]);
+                accM[nt] = E::mfma16(wv[wbase + 1 * 3 + kx], bx, accM[nt]);
+                accO[nt] = E::mfma16(wv[wbase + 2 * 3 + kx], bx, accO[nt]);
+            }
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+        for (int f = 0; f < 12 - 3; ++f) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);
+    };
+
+    // write a finished stage-A row (ReLU, 16-bit, zero outside the image) into the hand-off ring slot,
+    // optionally also to HBM (K12: x1, centre columns of the block's own rows only)
+    auto a_emit = [&](const ie_f32x4 (&acc)[4], int t) __attribute__((always_inline)) {
+        const int ra = ys - 3 + t;
+        const bool row_in = (ra >= 0) && (ra < H);
+        char* slot = smem + OFF_RA + (t & 1) * ROW_B;
+        const unsigned row_b = (unsigned)ra * (unsigned)W * PXB;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int q = 64 * ph + 16 * nt + p16;
+            const int x = xc0 + q;
+            const bool in_img = row_in && x >= 0 && x < W;
+            ie_u32x2 pk;
+            pk[0] = in_img ? ie_pack2<T>(fmaxf(acc[nt][0], 0.f), fmaxf(acc[nt][1], 0.f)) : 0u;
+            pk[1] = in_img ? ie_pack2<T>(fmaxf(acc[nt][2], 0.f), fmaxf(acc[nt][3], 0.f)) : 0u;
+            const int c = 2 * ch + (kq >> 1);      // 16-byte chunk holding couts 16ch+4kq .. +3
+            *(ie_u32x2*)(slot + q * PXB + ((c ^ ((q >> 1) & 3)) << 4) + (kq & 1) * 8) = pk;
+            if constexpr (KIND == K12) {
+                const bool st = in_img && q >= 1 && q < TW - 1 && ra >= ys && ra < ye;
+                const unsigned off = st ? row_b + (unsigned)x * PXB + (unsigned)((16 * ch + 4 * kq) * sizeof(T)) : OOB;
+                __builtin_amdgcn_raw_buffer_store_b64(pk, rsDa, (int)off, 0, 0);
+            }
+        }
+    };
+
+    // stage-B ReLU epilogue to HBM (centre 126 columns)
+    auto b_store = [&](const ie_f32x4 (&acc)[4], int yo) __attribute__((always_inline)) {
+        const bool row_ok = (yo >= ys) && (yo < ye);
+        ie_u32x2 pk[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            pk[nt][0] = ie_pack2<T>(fmaxf(acc[nt][0], 0.f), fmaxf(acc[nt][1], 0.f));
+            pk[nt][1] = ie_pack2<T>(fmaxf(acc[nt][2], 0.f), fmaxf(acc[nt][3], 0.f));
+        }
+        const unsigned row_b = (unsigned)yo * (unsigned)W * PXB;
+#pragma unroll
+        for (int nt = 0; nt < 4; nt += 2) {
+            auto sx = __builtin_amdgcn_permlane16_swap(pk[nt][0], pk[nt + 1][0], false, false);
+            auto sy = __builtin_amdgcn_permlane16_swap(pk[nt][1], pk[nt + 1][1], false, false);
+            ie_u32x4 v = {sx[0], sy[0], sx[1], sy[1]};
+            const int q = 64 * ph + 16 * (nt + (kq & 1)) + p16;
+            const int xo = xc0 + q;
+            const bool ok = row_ok && q >= 1 && q < TW - 1 && xo < W;
+            const unsigned off = ok ? row_b + (unsigned)xo * PXB + (unsigned)((16 * ch + 4 * (kq & 2)) * sizeof(T)) : OOB;
+            __builtin_amdgcn_raw_buffer_store_b128(v, rsDb, (int)off, 0, 0);
+        }
+    };
+
+    // K67 curve epilogue (as in zdce_conv3x3_mfma): tanh -> LDS [24][128] -> one thread per pixel
+    auto stage_write = [&](const ie_f32x4 (&acc)[4]) __attribute__((always_inline)) {
+        float* sp = (float*)(smem + OFF_STAGE);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = 16 * ch + 4 * kq + i;
+                if (k < 24) sp[k * TW + 64 * ph + 16 * nt + p16] = ie_tanh_fast(acc[nt][i]);
+            }
+    };
+    auto curve_consume = [&](int t) __attribute__((always_inline)) {
+        const int yo = ys - 5 + t;
+        const int q = tid - 256;            // waves 4,5
+        const int xo = xc0 + q;
+        if (q >= 1 && q < TW - 1 && xo < W && yo >= ys && yo < ye) {
+            const float* sp = (const float*)(smem + OFF_STAGE);
+            const float* ip = (const float*)(smem + OFF_IMG + (t % NRI) * IMG_SLOT_B);
+            const size_t pix = (size_t)yo * W + xo;
+            float y[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float v = ip[c * TW + q];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v = ie_curve_step(v, sp[(3 * i + c) * TW + q]);
+                y[c] = v;
+            }
+            if (p.enhanced) {
+                float* ep = p.enhanced + (size_t)n * 3 * plane + pix;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) ep[(size_t)c * plane] = y[c];
+            }
+            if (p.u8) {
+                unsigned char* up = p.u8 + ((size_t)n * plane + pix) * 3;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) up[c] = ie_quant_u8(y[c]);
+            }
+            if (p.adjust) {
+                float* ap = p.adjust + (size_t)n * 24 * plane + pix;
+#pragma unroll
+                for (int k = 0; k < 24; ++k) ap[(size_t)k * plane] = sp[k * TW + q];
+            }
+        }
+    };
+
+    // K12 stage A: e_conv1 as one K=32 MFMA per 16-pixel tile on an im2col fragment gathered from
+    // the fp32 image ring: k = (ky*3 + kx)*3 + c (27 real, 5 zero).  bf16 keeps only 8 mantissa bits,
+    // so the pixel is split hi + lo (two MFMAs) and the fp32 image precision survives.
+    int el_off[8], el_ky[8];    // per-lane element geometry (k = 8kq + j), loop invariant
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 8 * kq + j;
+        const int tap = k / 3, c = k - 3 * tap;
+        const int ky = tap / 3, kx = tap - 3 * ky;
+        el_ky[j] = (k < 27) ? ky : 3;                               // 3 = padding element
+        el_off[j] = (c * 132 + kx + 64 * ph + p16) * 4;             // + 64*nt bytes per tile
+    }
+    auto conv1_row = [&](int t, ie_f32x4 (&acc)[4]) __attribute__((always_inline)) {
+        // image row ra + ky - 1 = ys-4+t+ky lives in slot (t - 2 + ky) % NRI
+        const int sb0 = OFF_IMG + ((t + NRI - 2) % NRI) * IMG_SLOT_B;
+        const int sb1 = OFF_IMG + ((t + NRI - 1) % NRI) * IMG_SLOT_B;
+        const int sb2 = OFF_IMG + (t % NRI) * IMG_SLOT_B;
+        int ea[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ea[j] = (el_ky[j] == 0 ? sb0 : (el_ky[j] == 1 ? sb1 : sb2)) + el_off[j];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            frag hi, lo;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float v = *(const float*)(smem + ea[j] + 64 * nt);
+                v = (el_ky[j] < 3) ? v : 0.f;
+                const T h = (T)v;
+                hi[j] = h;
+                lo[j] = (T)(v - (float)h);
+            }
+            ie_f32x4 a = bias4;
+            a = E::mfma16(wv[0], hi, a);
+            if constexpr (ie_elem<T>::dtype == IE_BF16) a = E::mfma16(wv[0], lo, a);
+            acc[nt] = a;
+        }
+    };
+
+    // ---- one step -----------------------------------------------------------------------------------
+    auto step = [&](int t, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4]) __attribute__((always_inline)) {
+        wait_vm(wait_base < 0 ? -1 : wait_base + S * min(max(t - 2, 0), PF));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // stage A's hand-off writes of step t-1
+        __builtin_amdgcn_s_barrier();
+        issue(t + PF);
+        if (stg == 0) {
+            if constexpr (KIND == K12) {
+                conv1_row(t, accO);
+                if (t >= 2) a_emit(accO, t);
+            } else {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) accN[nt] = bias4;
+                src_mfma(smem + (t % NRA) * ROW_B, 0, accN, accM, accO);
+                if constexpr (NSA == 2) src_mfma(smem + NRA * ROW_B + (t % NRA) * ROW_B, 9, accN, accM, accO);
+                if (t >= 2) a_emit(accO, t);
+            }
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) accN[nt] = bias4;
+            const char* ra_row = smem + OFF_RA + ((t + 1) & 1) * ROW_B;     // written by stage A at step t-1
+            if constexpr (KIND == K12) {
+                src_mfma(ra_row, 0, accN, accM, accO);
+            } else if constexpr (KIND == K45) {
+                src_mfma(smem + ((t + NRA - 2) % NRA) * ROW_B, 0, accN, accM, accO);   // x3 row ys-4+t
+                src_mfma(ra_row, 9, accN, accM, accO);                                  // x4 row ys-4+t
+            } else {
+                src_mfma(smem + OFF_BRING + (t % NRB) * ROW_B, 0, accN, accM, accO);    // x1 row ys-4+t
+                src_mfma(ra_row, 9, accN, accM, accO);                                  // x6 row ys-4+t
+            }
+            if constexpr (KIND != K67) {
+                if (t >= 5) b_store(accO, ys - 5 + t);
+            } else {
+                if (t >= 5) stage_write(accO);
+            }
+        }
+        if constexpr (KIND == K67) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (stg == 1 && t >= 5) curve_consume(t);
+        }
+    };
+
+#pragma unroll
+    for (int t = 0; t < PF; ++t) issue(t);
+
+    ie_f32x4 a0[4], a1[4], a2[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) { a0[nt] = bias4; a1[nt] = bias4; a2[nt] = bias4; }
+    for (int t = 0; t < n_steps; t += 3) {
+        step(t, a0, a1, a2);
+        if (t + 1 < n_steps) step(t + 1, a2, a0, a1);
+        if (t + 2 < n_steps) step(t + 2, a1, a2, a0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// Concrete kernels (readable names in rocprof traces; hipcc/ROCm 7.2 emitted the host stub of only
+// the first instantiation when the __global__ function itself was a template on KIND).
+#define IE_DEF_FUSED(NAME, T, KIND) \
+    __global__ __launch_bounds__(512, 2) void NAME(FusedParams p) { zdce_fused2_body<T, KIND>(p); }
+IE_DEF_FUSED(zdce_k12_conv1_conv2_f16, _Float16, K12)
+IE_DEF_FUSED(zdce_k45_conv4_conv5_f16, _Float16, K45)
+IE_DEF_FUSED(zdce_k67_conv6_conv7_curve_f16, _Float16, K67)
+IE_DEF_FUSED(zdce_k12_conv1_conv2_bf16, __bf16, K12)
+IE_DEF_FUSED(zdce_k45_conv4_conv5_bf16, __bf16, K45)
+IE_DEF_FUSED(zdce_k67_conv6_conv7_curve_bf16, __bf16, K67)
+#undef IE_DEF_FUSED
+
+template <typename T, int KIND> struct FusedKernel;
+#define IE_BIND(T, KIND, NAME) template <> struct FusedKernel<T, KIND> { static constexpr void (*fn)(FusedParams) = NAME; };
+IE_BIND(_Float16, K12, zdce_k12_conv1_conv2_f16)
+IE_BIND(_Float16, K45, zdce_k45_conv4_conv5_f16)
+IE_BIND(_Float16, K67, zdce_k67_conv6_conv7_curve_f16)
+IE_BIND(__bf16, K12, zdce_k12_conv1_conv2_bf16)
+IE_BIND(__bf16, K45, zdce_k45_conv4_conv5_bf16)
+IE_BIND(__bf16, K67, zdce_k67_conv6_conv7_curve_bf16)
+#undef IE_BIND
+
+template <typename T, int KIND>
+static int launch_fused_t(const ZdceFusedLaunch& a, hipStream_t st) {
+    FusedParams p;
+    p.a_src0 = a.a_src0; p.a_src1 = a.a_src1; p.b_src = a.b_src; p.img = a.img;
+    p.a_w = a.a_w; p.a_bias = a.a_bias; p.b_w = a.b_w; p.b_bias = a.b_bias; p.a_dst = a.a_dst; p.b_dst = a.b_dst;
+    p.enhanced = a.enhanced; p.adjust = a.adjust; p.u8 = a.u8;
+    p.N = a.N; p.H = a.H; p.W = a.W; p.y_begin = a.y_begin; p.y_end = a.y_end; p.rows_per_block = a.rows_per_block;
+    p.n_begin = a.n_begin;
+    p.strips = ie_cdiv(a.W, TS);
+    p.chunks = ie_cdiv(a.y_end - a.y_begin, a.rows_per_block);
+    const long long blocks = (long long)p.strips * p.chunks * a.n_count;
+    if (blocks <= 0 || blocks > 0x7fffffffLL) IE_FAIL(IE_ERR_INVALID, "zdce fused: bad grid %lld", blocks);
+    if ((size_t)a.H * a.W * 32 * sizeof(T) >= 0x7fffffffull) IE_FAIL(IE_ERR_UNSUPPORTED, "zdce fused: frame too large for 31-bit offsets");
+    constexpr int ROW_B = ROW_PX * 32 * (int)sizeof(T);
+    constexpr int NSA = (KIND == K67) ? 2 : (KIND == K45 ? 1 : 0);
+    constexpr int NRA = (KIND == K45) ? PF + 3 : PF + 1;
+    constexpr int NRI = (KIND == K12) ? PF + 3 : PF + 1;
+    const size_t lds = (size_t)NSA * NRA * ROW_B + (KIND == K67 ? (PF + 1) * ROW_B : 0) + 2 * ROW_B +
+                       (KIND == K45 ? 0 : NRI * 2048) + (KIND == K67 ? 24 * TW * 4 : 0);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)FusedKernel<T, KIND>::fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) IE_FAIL(IE_ERR_HIP, "hipFuncSetAttribute(lds=%zu): %s", lds, hipGetErrorString(e));
+        attr_set = true;
+    }
+    void* args[] = {(void*)&p};
+    IE_HIP_CHECK(hipLaunchKernel((const void*)FusedKernel<T, KIND>::fn, dim3((unsigned)blocks), dim3(512), args, lds, st));
+    return IE_OK;
+}
+
+int ie_zdce_launch_fused(const ZdceFusedLaunch& a, hipStream_t st) {
+#define IE_DISPATCH(T)                                           \
+    if (a.kind == 12) return launch_fused_t<T, K12>(a, st);      \
+    if (a.kind == 45) return launch_fused_t<T, K45>(a, st);      \
+    if (a.kind == 67) return launch_fused_t<T, K67>(a, st);
+    if (a.dtype == IE_F16) { IE_DISPATCH(_Float16) }
+    else if (a.dtype == IE_BF16) { IE_DISPATCH(__bf16) }
+#undef IE_DISPATCH
+    IE_FAIL(IE_ERR_UNSUPPORTED, "zdce fused: kind=%d dtype=%d", a.kind, a.dtype);
+}

@@ -11,3 +11,13 @@ struct ZdceConvLaunch {
 int ie_zdce_launch_mfma(const ZdceConvLaunch& a, hipStream_t st);
 int ie_zdce_launch_conv1(const float* img, const float* wk, const float* bias, void* dst, int dtype, int N, int H,
                          int W, int y_begin, int y_end, int n_begin, int n_count, hipStream_t st);
+
+// two-stage fused strip kernels (ie_zdce_fused.hip); kind = 12, 45 or 67
+struct ZdceFusedLaunch {
+    int kind, dtype;
+    const void* a_src0; const void* a_src1; const void* b_src; const float* img;
+    const void* a_w; const float* a_bias; const void* b_w; const float* b_bias;
+    void* a_dst; void* b_dst; float* enhanced; float* adjust; unsigned char* u8;
+    int N, H, W, y_begin, y_end, n_begin, n_count, rows_per_block;
+};
+int ie_zdce_launch_fused(const ZdceFusedLaunch& a, hipStream_t st);

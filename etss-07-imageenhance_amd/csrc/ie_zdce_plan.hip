@@ -35,6 +35,7 @@ struct ie_zdce_plan {
     // device weights: one allocation
     char* d_w = nullptr;
     size_t off_w[NL] = {0}, off_b[NL] = {0};
+    size_t off_w1m = 0;   // e_conv1 as MFMA A fragments (fused K12 kernel)
     // workspace
     char* ws = nullptr;
     size_t ws_bytes = 0;
@@ -169,6 +170,22 @@ IE_EXPORT int ie_zdce_finalize(ie_zdce_plan* p, void* stream) {
         const char* q = (const char*)hb.data();
         host.insert(host.end(), q, q + 32 * 4);
     }
+    if (dt != IE_F32) {
+        // e_conv1 for the fused K12 kernel: one K=32 fragment per cout half,
+        //   [hc][lane][j] = W1[16hc + (lane&15)][c][ky][kx] with k = 8*(lane>>4) + j = (ky*3 + kx)*3 + c  (k >= 27: 0)
+        align(256);
+        p->off_w1m = host.size();
+        const float* w = p->w[0].data();
+        std::vector<unsigned short> hw((size_t)2 * 64 * 8, 0);
+        for (int hc = 0; hc < 2; ++hc) for (int lane = 0; lane < 64; ++lane) for (int j = 0; j < 8; ++j) {
+            const int k = 8 * (lane >> 4) + j;
+            float v = 0.f;
+            if (k < 27) { const int tap = k / 3, c = k % 3; v = w[((size_t)(16 * hc + (lane & 15)) * 3 + c) * 9 + tap]; }
+            hw[((size_t)hc * 64 + lane) * 8 + j] = dt == IE_F16 ? f32_to_f16_bits(v) : f32_to_bf16_bits(v);
+        }
+        const char* q = (const char*)hw.data();
+        host.insert(host.end(), q, q + hw.size() * 2);
+    }
     if (p->d_w) { (void)hipFree(p->d_w); p->d_w = nullptr; }
     IE_HIP_CHECK(hipMalloc(&p->d_w, host.size()));
     hipStream_t st = (hipStream_t)stream;
@@ -267,26 +284,54 @@ static int forward_mfma(ie_zdce_plan* p, const float* image, float* enhanced, fl
             const int b1 = (b0 + band) < H ? (b0 + band) : H;
             auto lo = [&](int k) { int v = b0 - (7 - k); return v < 0 ? 0 : v; };
             auto hi = [&](int k) { int v = b1 + (7 - k); return v > H ? H : v; };
-            {
-                ProfScope ps(p, 0, st);
-                int rc = ie_zdce_launch_conv1(image, (const float*)(p->d_w + p->off_w[0]), (const float*)(p->d_w + p->off_b[0]),
-                                              x[1], dt, N, H, W, lo(1), hi(1), n0, g, st);
-                if (rc) return rc;
-            }
             const int s0i[NL] = {0, 1, 2, 3, 3, 2, 1}, s1i[NL] = {-1, -1, -1, -1, 4, 5, 6};
-            for (int l = 1; l < NL; ++l) {
+            auto W_ = [&](int l) { return (const void*)(p->d_w + p->off_w[l]); };
+            auto B_ = [&](int l) { return (const float*)(p->d_w + p->off_b[l]); };
+            auto single = [&](int l) -> int {      // layer l (1..6, 0-based) as a stand-alone MFMA kernel
                 ProfScope ps(p, l, st);
                 ZdceConvLaunch a;
                 memset(&a, 0, sizeof(a));
                 a.src0 = x[s0i[l]]; a.src1 = s1i[l] >= 0 ? x[s1i[l]] : nullptr;
-                a.wpk = p->d_w + p->off_w[l]; a.bias = (const float*)(p->d_w + p->off_b[l]);
+                a.wpk = W_(l); a.bias = B_(l);
                 a.N = N; a.H = H; a.W = W; a.n_begin = n0; a.n_count = g; a.rows_per_block = rb;
                 a.nsrc = s1i[l] >= 0 ? 2 : 1; a.dtype = dt; a.variant = p->cfg.variant;
                 if (l < 6) { a.epi = 0; a.dst = x[l + 1]; a.y_begin = lo(l + 1); a.y_end = hi(l + 1); }
                 else { a.epi = 1; a.img = image; a.enhanced = enhanced; a.adjust = adjust; a.u8 = u8; a.y_begin = b0; a.y_end = b1; }
-                int rc = ie_zdce_launch_mfma(a, st);
-                if (rc) return rc;
+                return ie_zdce_launch_mfma(a, st);
+            };
+            auto fused = [&](int kind, int prof_layer) -> int {
+                ProfScope ps(p, prof_layer, st);
+                ZdceFusedLaunch a;
+                memset(&a, 0, sizeof(a));
+                a.kind = kind; a.dtype = dt; a.N = N; a.H = H; a.W = W; a.n_begin = n0; a.n_count = g; a.rows_per_block = rb;
+                a.img = image;
+                if (kind == 12) {
+                    a.a_w = p->d_w + p->off_w1m; a.a_bias = B_(0); a.b_w = W_(1); a.b_bias = B_(1);
+                    a.a_dst = x[1]; a.b_dst = x[2]; a.y_begin = lo(2); a.y_end = hi(2);
+                } else if (kind == 45) {
+                    a.a_src0 = x[3]; a.a_w = W_(3); a.a_bias = B_(3); a.b_w = W_(4); a.b_bias = B_(4);
+                    a.b_dst = x[5]; a.y_begin = lo(5); a.y_end = hi(5);
+                } else {
+                    a.a_src0 = x[2]; a.a_src1 = x[5]; a.b_src = x[1]; a.a_w = W_(5); a.a_bias = B_(5); a.b_w = W_(6); a.b_bias = B_(6);
+                    a.enhanced = enhanced; a.adjust = adjust; a.u8 = u8; a.y_begin = b0; a.y_end = b1;
+                }
+                return ie_zdce_launch_fused(a, st);
+            };
+            int rc = IE_OK;
+            if (p->cfg.variant & IE_ZDCE_VAR_UNFUSED) {
+                {
+                    ProfScope ps(p, 0, st);
+                    rc = ie_zdce_launch_conv1(image, (const float*)W_(0), B_(0), x[1], dt, N, H, W, lo(1), hi(1), n0, g, st);
+                }
+                for (int l = 1; l < NL && rc == IE_OK; ++l) rc = single(l);
+            } else {
+                // K12 writes x1 over the rows conv7 and conv2's consumers need (= x2's range), then conv3, K45, K67
+                rc = fused(12, 1);
+                if (rc == IE_OK) rc = single(2);
+                if (rc == IE_OK) rc = fused(45, 4);
+                if (rc == IE_OK) rc = fused(67, 6);
             }
+            if (rc) return rc;
         }
     }
     return IE_OK;

@@ -119,6 +119,7 @@ typedef struct ie_zdce_config {
 #define IE_ZDCE_VAR_SYNC_STAGE 1 /* drain the LDS-DMA ring every row (debug / A-B) */
 #define IE_ZDCE_VAR_NARROW_STORE 2 /* 8-byte epilogue stores instead of permlane-widened 16-byte */
 #define IE_ZDCE_VAR_NO_DMA 4 /* register-staged global->LDS copies instead of LDS-DMA (debug / A-B) */
+#define IE_ZDCE_VAR_UNFUSED 8 /* one kernel per layer instead of the fused conv1+2 / conv4+5 / conv6+7 kernels */
 
 int ie_zdce_create(const ie_zdce_config* cfg, ie_zdce_plan** out);
 /* layer in 1..7 (e_conv{layer}); w OIHW fp32 host, b fp32 host; shapes per zero_dce.py:133-139. */

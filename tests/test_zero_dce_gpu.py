@@ -50,27 +50,43 @@ def test_golden_parity(path, dtype):
     assert np.array_equal(u8, own)
 
 
+@pytest.mark.parametrize("variant", [0, capi.VAR_UNFUSED])
 @pytest.mark.parametrize("dtype", ["f32", "f16", "bf16"])
-def test_feature_parity_per_layer(dtype):
+def test_feature_parity_per_layer(dtype, variant):
+    """x1..x6 against the oracle.  The fused schedule keeps x4 and x6 in LDS only, so they are
+    checked on the one-kernel-per-layer schedule."""
     sd, g = load_golden(zero_dce_goldens()[-1])
-    m = _model(sd, dtype)
+    m = _model(sd, dtype, variant)
     x = torch.from_numpy(g["image"])
     ref = o_zdce.forward(sd, x, return_features=True)["_features"]
     m.enhance(x.cuda())
-    for k in range(1, 7):
+    in_hbm = range(1, 7) if (variant or dtype == "f32") else (1, 2, 3, 5)
+    for k in in_hbm:
         f = m.feature(k).cpu()
         assert rel_err(f, ref[k - 1]) <= TOL_FEAT[dtype], f"x{k}"
 
 
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("path", zero_dce_goldens(), ids=lambda p: p.split("zero_dce_")[-1][:-4])
+def test_unfused_schedule_golden_parity(path, dtype):
+    """The one-kernel-per-layer schedule (IE_ZDCE_VAR_UNFUSED) meets the same bounds as the fused one."""
+    sd, g = load_golden(path)
+    out = _model(sd, dtype, capi.VAR_UNFUSED).forward({"image": torch.from_numpy(g["image"]).cuda()})
+    assert rel_err(out["enhanced"].cpu(), g["enhanced"]) <= TOL_ENH[dtype]
+    assert rel_err(out["adjust"].cpu(), g["adjust"]) <= 5 * TOL_ENH[dtype]
+
+
+@pytest.mark.parametrize("base", [0, capi.VAR_UNFUSED])
 @pytest.mark.parametrize("variant", [capi.VAR_SYNC_STAGE, capi.VAR_NARROW_STORE, capi.VAR_NO_DMA,
                                      capi.VAR_NO_DMA | capi.VAR_NARROW_STORE])
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
-def test_kernel_variants_bit_identical(variant, dtype):
-    """LDS-DMA vs register staging, counted vs drained waits, wide vs narrow stores: same bits."""
+def test_kernel_variants_bit_identical(variant, dtype, base):
+    """LDS-DMA vs register staging, counted vs drained waits, wide vs narrow stores: same bits
+    (on both the fused and the one-kernel-per-layer schedule)."""
     sd, g = load_golden(zero_dce_goldens()[-1])
     x = torch.from_numpy(g["image"]).cuda()
-    a = _model(sd, dtype, 0).forward({"image": x})
-    b = _model(sd, dtype, variant).forward({"image": x})
+    a = _model(sd, dtype, base).forward({"image": x})
+    b = _model(sd, dtype, base | variant).forward({"image": x})
     assert torch.equal(a["enhanced"], b["enhanced"]) and torch.equal(a["adjust"], b["adjust"])
 
 
@@ -94,7 +110,7 @@ def test_schedule_invariance(dtype):
     x = torch.rand(5, 3, 75, 200, generator=torch.Generator().manual_seed(6)).cuda()
     m = _model(sd, dtype)
     base = m.enhance(x, want_adjust=True)
-    for rb, band, group in [(1, 0, 0), (3, 0, 2), (64, 16, 1), (7, 20, 3), (5, 1, 5)]:
+    for rb, band, group in [(1, 0, 0), (3, 0, 2), (64, 16, 1), (7, 20, 3), (5, 1, 5), (2, 0, 0), (4, 33, 2)]:
         m.set_tuning(rb, band, group)
         o = m.enhance(x, want_adjust=True)
         assert torch.equal(o["enhanced"], base["enhanced"]), (rb, band, group)

@@ -41,8 +41,7 @@ def run(rb, band, group, reps=3):
           " ".join(f"{ms[i]:.2f}" for i in range(7)) + f" | launches {launches[1]}", flush=True)
 
 
-for cfg in [(0, 0, 0), (8, 0, 8), (16, 0, 8), (32, 0, 8), (64, 0, 8), (135, 0, 8), (270, 0, 8), (32, 0, 1), (32, 0, 2), (32, 0, 4),
-            (32, 0, 16), (16, 270, 1), (16, 135, 2), (8, 90, 1), (16, 540, 1), (32, 540, 2)]:
+for cfg in [(0, 0, 0), (16, 0, 8), (32, 0, 8), (64, 0, 8), (135, 0, 8), (270, 0, 8), (1080, 0, 8), (64, 0, 16), (64, 0, 4)]:
     if cfg[2] > N:
         continue
     run(*cfg)
