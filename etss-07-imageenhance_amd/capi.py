@@ -11,7 +11,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libie_hip.so")
+LIB_PATH = os.environ.get("IE_HIP_LIB") or os.path.join(_HERE, "libie_hip.so")   # IE_HIP_LIB: A/B builds
 
 IE_F32, IE_F16, IE_BF16, IE_U8 = 0, 1, 2, 3
 DTYPES = {"f32": IE_F32, "fp32": IE_F32, "float32": IE_F32, "f16": IE_F16, "fp16": IE_F16, "float16": IE_F16,

@@ -2,7 +2,7 @@
 # Build libie_hip.so (gfx950) in-tree.  Usage: build.sh [extra hipcc flags]
 set -e
 cd "$(dirname "$0")"
-OUT=../libie_hip.so
+OUT=${IE_OUT:-../libie_hip.so}
 SRCS="ie_core.hip ie_conv_direct.hip ie_zdce_kernels.hip ie_zdce_fused.hip ie_zdce_plan.hip"
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fvisibility=hidden \
       -Wall -Wno-unused-function -o "$OUT" $SRCS "$@"

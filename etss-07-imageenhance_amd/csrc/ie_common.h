@@ -55,11 +55,20 @@ template <> struct ie_elem<__bf16> {
     }
 };
 
-// Pack two floats into one dword of 2 x T (round-to-nearest-even casts).
+// Pack two floats into one dword of 2 x T: one v_cvt_pk_{bf16,f16}_f32 (round-to-nearest-even).
+typedef __attribute__((ext_vector_type(2))) float ie_f32x2;
+typedef __attribute__((ext_vector_type(2))) short ie_s16x2;
 template <typename T> __device__ __forceinline__ unsigned ie_pack2(float lo, float hi) {
-    T a = (T)lo, b = (T)hi;
-    unsigned short ua = __builtin_bit_cast(unsigned short, a), ub = __builtin_bit_cast(unsigned short, b);
-    return (unsigned)ua | ((unsigned)ub << 16);
+    typedef __attribute__((ext_vector_type(2))) T t2;
+    const ie_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, t2));
+}
+// ... followed by ReLU on the packed pair: negative 16-bit floats have the sign bit set, i.e. are
+// negative as int16, so ReLU == v_pk_max_i16(x, 0) (-0.0 -> +0.0; 2 instructions per 2 outputs).
+template <typename T> __device__ __forceinline__ unsigned ie_pack2_relu(float lo, float hi) {
+    ie_s16x2 s = __builtin_bit_cast(ie_s16x2, ie_pack2<T>(lo, hi));
+    const ie_s16x2 z = {0, 0};
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(s, z));
 }
 
 // tanh as 1 - 2/(exp(2x)+1) on the hardware exp2/rcp units: absolute error

@@ -27,7 +27,10 @@ constexpr int TW = 128;          // computed columns per workgroup
 constexpr int TS = 126;          // stored columns per workgroup (strip pitch)
 constexpr int ROW_PX = TW + 2;   // pixels per ring row (body + 2 halo)
 constexpr unsigned OOB = 0x80000000u;
-constexpr int PF = 3;            // rows of DMA issued ahead
+#ifndef IE_PF
+#define IE_PF 3
+#endif
+constexpr int PF_DEFAULT = IE_PF; // rows of DMA issued ahead (K67 is LDS-limited to 3)
 
 enum { K12 = 12, K45 = 45, K67 = 67 };
 
@@ -43,6 +46,7 @@ struct FusedParams {
     float* enhanced; float* adjust; unsigned char* u8;   // K67
     int N, H, W;
     int y_begin, y_end, rows_per_block, strips, chunks, n_begin;
+    unsigned long long* stamps;   // diagnostic builds (-DIE_STAMP) only: [block][wave][4] cycle sums
 };
 
 __device__ __forceinline__ void wait_vm(int n) {
@@ -58,25 +62,39 @@ __device__ __forceinline__ void wait_vm(int n) {
 
 }  // namespace
 
+#ifdef IE_STAMP
+#define IE_T(var) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define IE_T(var) do { } while (0)
+#endif
+
 template <typename T, int KIND>
 __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     using E = ie_elem<T>;
     using frag = typename E::frag;
+    constexpr int PF = (KIND == K67) ? 3 : PF_DEFAULT;
     constexpr int PXB = 32 * sizeof(T);                     // 64 B per pixel per tensor
     constexpr int ROW_B = ROW_PX * PXB;                     // one ring row of one tensor
     constexpr int NSA = (KIND == K67) ? 2 : (KIND == K45 ? 1 : 0);   // stage A HBM sources (K12: image)
     constexpr int NSB = (KIND == K12) ? 1 : 2;                       // stage B sources (concat order)
-    constexpr int NW = 9 * (NSB > NSA ? NSB : (NSA > 0 ? NSA : 1));  // weight fragments held per wave
+    constexpr int NW = 9 * (NSB > NSA ? NSB : (NSA > 0 ? NSA : 1));  // weight fragments held per wave (K12 stage A: 2)
     // ---- LDS carve ------------------------------------------------------------------------------
     constexpr int NRA = (KIND == K45) ? PF + 3 : PF + 1;    // slots of the A rings (K45: B re-reads x3 two rows later)
     constexpr int A_RING_B = NSA * NRA * ROW_B;
     constexpr int NRB = PF + 1;                             // K67: x1 ring of stage B
     constexpr int B_RING_B = (KIND == K67) ? NRB * ROW_B : 0;
     constexpr int RA_B = 2 * ROW_B;                         // A -> B hand-off ring (2 slots)
-    constexpr int NRI = (KIND == K12) ? PF + 3 : PF + 1;    // image ring slots
+    constexpr int LAG_A = (KIND == K12) ? 1 : 0;            // K12: stage A runs one row later (image row conversion)
+    constexpr int NRI = (KIND == K12) ? PF + 1 : PF + 3;    // fp32 image ring slots (K67: kept until the deferred curve)
     constexpr int IMG_SLOT_B = 2048;                        // 3 planes x 132 px fp32 (K12) / 3 x 128 (K67)
     constexpr int IMG_B = (KIND == K45) ? 0 : NRI * IMG_SLOT_B;
-    constexpr int OFF_BRING = A_RING_B, OFF_RA = OFF_BRING + B_RING_B, OFF_IMG = OFF_RA + RA_B, OFF_STAGE = OFF_IMG + IMG_B;   // K67: [24][128] fp32 tanh staging
+    constexpr int CV_PLANE_B = 1088;                        // K12: converted image row, [136 px][RGB0] 16-bit
+    constexpr int CV_SLOT_B = 2 * CV_PLANE_B;               //      hi plane + lo plane
+    constexpr int NRC = 4;
+    constexpr int CV_B = (KIND == K12) ? NRC * CV_SLOT_B : 0;
+    constexpr int STAGE_SLOT_B = 24 * TW * 4;               // K67: tanh(r) staging [24][128] fp32, double buffered
+    constexpr int OFF_BRING = A_RING_B, OFF_RA = OFF_BRING + B_RING_B, OFF_IMG = OFF_RA + RA_B, OFF_CV = OFF_IMG + IMG_B,
+                  OFF_STAGE = OFF_CV + CV_B;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -94,7 +112,7 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     const int xc0 = strip * TS - 1;                         // image column of computed column 0
     const int ys = p.y_begin + chunk * p.rows_per_block;
     const int ye = min(ys + p.rows_per_block, p.y_end);
-    const int n_steps = (ye - ys) + 5;
+    const int n_steps = (ye - ys) + 6 + LAG_A + (KIND == K67 ? 1 : 0);
     const int H = p.H, W = p.W;
     const size_t plane = (size_t)H * W;
     const size_t frame_b = plane * PXB;
@@ -113,7 +131,7 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     // ---- weights of this wave's stage into registers -------------------------------------------
     frag wv[NW];
     {
-        const int nfr = stg ? 9 * NSB : (KIND == K12 ? 1 : 9 * NSA);   // fragments per cout half
+        const int nfr = stg ? 9 * NSB : (KIND == K12 ? 2 : 9 * NSA);   // fragments per cout half
         const frag* wp = (const frag*)(stg ? p.b_w : p.a_w) + (size_t)ch * nfr * 64;
 #pragma unroll
         for (int f = 0; f < NW; ++f) wv[f] = wp[(f < nfr ? f : 0) * 64 + lane];
@@ -126,18 +144,18 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     }
 
     // ---- DMA geometry ------------------------------------------------------------------------------
-    int body_xoff[2];
+    unsigned body_xoff[2];   // byte offset inside an image row, or OOB (adding a row offset < 2^31 keeps it OOB)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int q = (2 * sw + j) * 16 + (lane >> 2);
         const int s = (lane & 3) ^ ((q >> 1) & 3);
         const int x = xc0 + q;
-        body_xoff[j] = (x >= 0 && x < W) ? (x * PXB + s * 16) : -1;
+        body_xoff[j] = (x >= 0 && x < W) ? (unsigned)(x * PXB + s * 16) : OOB;
     }
-    int halo_xoff;
+    unsigned halo_xoff;
     {
         const int x = (lane < 4) ? (xc0 - 1) : (xc0 + TW);
-        halo_xoff = (lane < 8 && x >= 0 && x < W) ? (x * PXB + (lane & 3) * 16) : -1;
+        halo_xoff = (lane < 8 && x >= 0 && x < W) ? (unsigned)(x * PXB + (lane & 3) * 16) : OOB;
     }
     // one ring row of one tensor: 2 body DMAs per wave + the halo DMA (wave 0 of the stage).
     // (a macro, not a lambda: the buffer-resource type cannot be a host-side function parameter)
@@ -145,35 +163,35 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     do {                                                                                                               \
         char* slot_ = (SLOT);                                                                                          \
         const int y_ = (Y);                                                                                            \
-        const bool row_ok_ = (y_ >= 0) && (y_ < H);                                                                    \
-        const unsigned row_b_ = (unsigned)y_ * (unsigned)W * PXB;                                                      \
+        const unsigned rmask_ = ((y_ >= 0) && (y_ < H)) ? 0u : OOB;                                                    \
+        const unsigned row_b_ = rmask_ ? 0u : (unsigned)y_ * (unsigned)W * PXB;                                        \
         _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                \
-            const unsigned off_ = (row_ok_ && body_xoff[j] >= 0) ? row_b_ + (unsigned)body_xoff[j] : OOB;              \
+            const unsigned off_ = (row_b_ + body_xoff[j]) | rmask_;                                                    \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (__attribute__((address_space(3))) void*)(slot_ + (2 * sw + j) * 1024), \
                                                      16, (int)off_, 0, 0, 0);                                          \
         }                                                                                                              \
         if (sw == 0) {                                                                                                 \
-            const unsigned off_ = (row_ok_ && halo_xoff >= 0) ? row_b_ + (unsigned)halo_xoff : OOB;                    \
+            const unsigned off_ = (row_b_ + halo_xoff) | rmask_;                                                       \
             if (lane < 8)                                                                                              \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (__attribute__((address_space(3))) void*)(slot_ + TW * PXB), 16, \
                                                          (int)off_, 0, 0, 0);                                          \
         }                                                                                                              \
     } while (0)
     // K12 image ring: element e = 64*(2*sw+j) + lane over [3 planes][132 px]; px <-> x = xc0 - 1 + px
-    int img12_off[2];
+    unsigned img12_off[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int e = 64 * (2 * sw + j) + lane;
         const int pl = e / 132, px = e - 132 * pl;
         const int x = xc0 - 1 + px;
-        img12_off[j] = (pl < 3 && px < 130 && x >= 0 && x < W) ? (int)(pl * plane * 4 + (size_t)x * 4) : -1;
+        img12_off[j] = (pl < 3 && px < 130 && x >= 0 && x < W) ? (unsigned)(pl * plane * 4 + (size_t)x * 4) : OOB;
     }
     // K67 curve image ring: wave sw < 3 loads plane sw, columns xc0 + 64j + lane
-    int img67_off[2];
+    unsigned img67_off[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int x = xc0 + 64 * j + lane;
-        img67_off[j] = (x >= 0 && x < W) ? x * 4 : -1;
+        img67_off[j] = (x >= 0 && x < W) ? (unsigned)(x * 4) : OOB;
     }
 
     // issue the DMA for step `t` (this wave's stage only)
@@ -183,10 +201,11 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
             if constexpr (NSA >= 2) IE_DMA_ROW(rsA1, smem + NRA * ROW_B + (t % NRA) * ROW_B, ys - 2 + t);
             if constexpr (KIND == K12) {
                 const int y = ys - 2 + t;
-                const bool row_ok = (y >= 0) && (y < H);
+                const unsigned rmask = ((y >= 0) && (y < H)) ? 0u : OOB;
+                const unsigned row_b = rmask ? 0u : (unsigned)y * (unsigned)W * 4u;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const unsigned off = (row_ok && img12_off[j] >= 0) ? (unsigned)img12_off[j] + (unsigned)y * (unsigned)W * 4u : OOB;
+                    const unsigned off = (img12_off[j] + row_b) | rmask;
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(
                         rsI, (__attribute__((address_space(3))) void*)(smem + OFF_IMG + (t % NRI) * IMG_SLOT_B + (2 * sw + j) * 256), 4,
                         (int)off, 0, 0, 0);
@@ -196,12 +215,12 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
             if constexpr (KIND == K67) {
                 IE_DMA_ROW(rsB, smem + OFF_BRING + (t % NRB) * ROW_B, ys - 4 + t);
                 if (sw < 3) {
-                    const int yo = ys - 5 + t;
-                    const bool ok = (yo >= ys) && (yo < ye);
-                    const unsigned base = ((unsigned)sw * (unsigned)plane + (unsigned)yo * (unsigned)W) * 4u;
+                    const int yo = ys - 5 + t;      // row finished at step t, consumed at step t+2
+                    const unsigned rmask = ((yo >= ys) && (yo < ye)) ? 0u : OOB;
+                    const unsigned base = rmask ? 0u : ((unsigned)sw * (unsigned)plane + (unsigned)yo * (unsigned)W) * 4u;
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
-                        const unsigned off = (ok && img67_off[j] >= 0) ? base + (unsigned)img67_off[j] : OOB;
+                        const unsigned off = (base + img67_off[j]) | rmask;
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(
                             rsI, (__attribute__((address_space(3))) void*)(smem + OFF_IMG + (t % NRI) * IMG_SLOT_B + sw * (TW * 4) + j * 256),
                             4, (int)off, 0, 0, 0);
@@ -211,12 +230,12 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
         }
     };
     // DMA instructions per step of this wave -> counted wait that leaves PF-1 younger rows in flight
-    // plus, for K12's stage A, the S = 4 unconditional (OOB-masked) x1 stores of every step >= 2 that
-    // were issued after the awaited row's loads.  Waves that issue no DMA do not wait at all.
+    // Waves that issue no DMA do not wait at all; stage-A waves issue no stores, so their count is exact.
     int L = 0, S = 0;
-    if (stg == 0) { L = (KIND == K12) ? 2 : (2 * NSA + (sw == 0 ? NSA : 0)); S = (KIND == K12) ? 4 : 0; }
+    if (stg == 0) { L = (KIND == K12) ? 2 : (2 * NSA + (sw == 0 ? NSA : 0)); }
     else if (KIND == K67) L = 2 + (sw == 0 ? 1 : 0) + (sw < 3 ? 2 : 0);
     const int wait_base = L ? (PF - 1) * L : -1;
+    (void)S;
 
     // ---- LDS read offsets of the B operand (as in zdce_conv3x3_mfma) --------------------------------
     auto lds_px = [&](int q) __attribute__((always_inline)) { return q * PXB + ((kq ^ ((q >> 1) & 3)) << 4); };
@@ -232,13 +251,23 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     }
 
     // one source row into the three live accumulator sets
-    auto src_mfma = [&](const char* row, int wbase, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4]) __attribute__((always_inline)) {
+    auto src_mfma = [&](const char* row, int wbase, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4], int x1_row) __attribute__((always_inline)) {
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 const int off = (kx == 0 && nt == 0) ? rd_first : (kx == 2 && nt == 3) ? rd_last : rd_base[kx] + 1024 * nt;
                 const frag bx = *(const frag*)(row + off);
+                if constexpr (KIND == K12) {
+                    // the centre-tap fragment of tile nt is pixel 64ph+16nt+p16, 16-byte chunk kq of x1:
+                    // store it (a wave writes 16 px x 64 B = 1 KB contiguous); one cout-half pair suffices
+                    if (kx == 1) {
+                        const int q = 64 * ph + 16 * nt + p16, x = xc0 + q;
+                        const bool st = (ch == 0) && x1_row >= ys && x1_row < ye && q >= 1 && q < TW - 1 && x < W;
+                        const unsigned off1 = st ? ((unsigned)x1_row * (unsigned)W + (unsigned)x) * PXB + (unsigned)kq * 16u : OOB;
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ie_u32x4, bx), rsDa, (int)off1, 0, 0);
+                    }
+                }
                 accN[nt] = E::mfma16(wv[wbase + 0 * 3 + kx], bx, accN[nt]);
                 accM[nt] = E::mfma16(wv[wbase + 1 * 3 + kx], bx, accM[nt]);
                 accO[nt] = E::mfma16(wv[wbase + 2 * 3 + kx], bx, accO[nt]);
@@ -252,28 +281,21 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
         __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);
     };
 
-    // write a finished stage-A row (ReLU, 16-bit, zero outside the image) into the hand-off ring slot,
-    // optionally also to HBM (K12: x1, centre columns of the block's own rows only)
+    // write a finished stage-A row (ReLU, 16-bit, zero outside the image) into the hand-off ring slot
     auto a_emit = [&](const ie_f32x4 (&acc)[4], int t) __attribute__((always_inline)) {
-        const int ra = ys - 3 + t;
+        const int ra = ys - 3 - LAG_A + t;
         const bool row_in = (ra >= 0) && (ra < H);
         char* slot = smem + OFF_RA + (t & 1) * ROW_B;
-        const unsigned row_b = (unsigned)ra * (unsigned)W * PXB;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             const int q = 64 * ph + 16 * nt + p16;
             const int x = xc0 + q;
             const bool in_img = row_in && x >= 0 && x < W;
             ie_u32x2 pk;
-            pk[0] = in_img ? ie_pack2<T>(fmaxf(acc[nt][0], 0.f), fmaxf(acc[nt][1], 0.f)) : 0u;
-            pk[1] = in_img ? ie_pack2<T>(fmaxf(acc[nt][2], 0.f), fmaxf(acc[nt][3], 0.f)) : 0u;
+            pk[0] = in_img ? ie_pack2_relu<T>(acc[nt][0], acc[nt][1]) : 0u;
+            pk[1] = in_img ? ie_pack2_relu<T>(acc[nt][2], acc[nt][3]) : 0u;
             const int c = 2 * ch + (kq >> 1);      // 16-byte chunk holding couts 16ch+4kq .. +3
             *(ie_u32x2*)(slot + q * PXB + ((c ^ ((q >> 1) & 3)) << 4) + (kq & 1) * 8) = pk;
-            if constexpr (KIND == K12) {
-                const bool st = in_img && q >= 1 && q < TW - 1 && ra >= ys && ra < ye;
-                const unsigned off = st ? row_b + (unsigned)x * PXB + (unsigned)((16 * ch + 4 * kq) * sizeof(T)) : OOB;
-                __builtin_amdgcn_raw_buffer_store_b64(pk, rsDa, (int)off, 0, 0);
-            }
         }
     };
 
@@ -283,8 +305,8 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
         ie_u32x2 pk[4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-            pk[nt][0] = ie_pack2<T>(fmaxf(acc[nt][0], 0.f), fmaxf(acc[nt][1], 0.f));
-            pk[nt][1] = ie_pack2<T>(fmaxf(acc[nt][2], 0.f), fmaxf(acc[nt][3], 0.f));
+            pk[nt][0] = ie_pack2_relu<T>(acc[nt][0], acc[nt][1]);
+            pk[nt][1] = ie_pack2_relu<T>(acc[nt][2], acc[nt][3]);
         }
         const unsigned row_b = (unsigned)yo * (unsigned)W * PXB;
 #pragma unroll
@@ -300,130 +322,152 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
         }
     };
 
-    // K67 curve epilogue (as in zdce_conv3x3_mfma): tanh -> LDS [24][128] -> one thread per pixel
-    auto stage_write = [&](const ie_f32x4 (&acc)[4]) __attribute__((always_inline)) {
-        float* sp = (float*)(smem + OFF_STAGE);
+    // K67 curve epilogue.  Stage B parks the raw e_conv7 outputs (bias included) of the row it finished
+    // in the previous step in LDS as [24][128] fp32 (double buffered); one step later ALL 8 waves run
+    // tanh + the 8-step LE curve, thread = (column, colour channel), on the fp32 input pixel from the
+    // image ring, and write enhanced / u8 / adjust with coalesced stores.  No extra barrier: the
+    // per-step barrier orders write -> read -> rewrite.
+    auto stage_write = [&](const ie_f32x4 (&acc)[4], int slot) __attribute__((always_inline)) {
+        float* sp = (float*)(smem + OFF_STAGE + slot * STAGE_SLOT_B);
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int k = 16 * ch + 4 * kq + i;
-                if (k < 24) sp[k * TW + 64 * ph + 16 * nt + p16] = ie_tanh_fast(acc[nt][i]);
+                if (k < 24) sp[k * TW + 64 * ph + 16 * nt + p16] = acc[nt][i];
             }
     };
-    auto curve_consume = [&](int t) __attribute__((always_inline)) {
-        const int yo = ys - 5 + t;
-        const int q = tid - 256;            // waves 4,5
+    auto curve_consume = [&](int s_fin) __attribute__((always_inline)) {   // s_fin: step at which the row was finished
+        const int yo = ys - 5 + s_fin;
+        const int q = tid & 127, c = tid >> 7;       // 512 threads: c = 0,1,2 colour channel, 3 idle
         const int xo = xc0 + q;
-        if (q >= 1 && q < TW - 1 && xo < W && yo >= ys && yo < ye) {
-            const float* sp = (const float*)(smem + OFF_STAGE);
-            const float* ip = (const float*)(smem + OFF_IMG + (t % NRI) * IMG_SLOT_B);
+        if (c < 3 && q >= 1 && q < TW - 1 && xo < W && yo >= ys && yo < ye) {
+            const float* sp = (const float*)(smem + OFF_STAGE + (s_fin & 1) * STAGE_SLOT_B) + q;
+            const float* ip = (const float*)(smem + OFF_IMG + (s_fin % NRI) * IMG_SLOT_B);
             const size_t pix = (size_t)yo * W + xo;
-            float y[3];
+            float v = ip[c * TW + q];
+            float r[8];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                float v = ip[c * TW + q];
+            for (int i = 0; i < 8; ++i) r[i] = ie_tanh_fast(sp[(3 * i + c) * TW]);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v = ie_curve_step(v, sp[(3 * i + c) * TW + q]);
-                y[c] = v;
-            }
-            if (p.enhanced) {
-                float* ep = p.enhanced + (size_t)n * 3 * plane + pix;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) ep[(size_t)c * plane] = y[c];
-            }
-            if (p.u8) {
-                unsigned char* up = p.u8 + ((size_t)n * plane + pix) * 3;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) up[c] = ie_quant_u8(y[c]);
-            }
+            for (int i = 0; i < 8; ++i) v = ie_curve_step(v, r[i]);
+            if (p.enhanced) p.enhanced[((size_t)n * 3 + c) * plane + pix] = v;
+            if (p.u8) p.u8[((size_t)n * plane + pix) * 3 + c] = ie_quant_u8(v);
             if (p.adjust) {
                 float* ap = p.adjust + (size_t)n * 24 * plane + pix;
 #pragma unroll
-                for (int k = 0; k < 24; ++k) ap[(size_t)k * plane] = sp[k * TW + q];
+                for (int i = 0; i < 8; ++i) ap[(size_t)(3 * i + c) * plane] = r[i];
             }
         }
     };
 
-    // K12 stage A: e_conv1 as one K=32 MFMA per 16-pixel tile on an im2col fragment gathered from
-    // the fp32 image ring: k = (ky*3 + kx)*3 + c (27 real, 5 zero).  bf16 keeps only 8 mantissa bits,
-    // so the pixel is split hi + lo (two MFMAs) and the fp32 image precision survives.
-    int el_off[8], el_ky[8];    // per-lane element geometry (k = 8kq + j), loop invariant
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int k = 8 * kq + j;
-        const int tap = k / 3, c = k - 3 * tap;
-        const int ky = tap / 3, kx = tap - 3 * ky;
-        el_ky[j] = (k < 27) ? ky : 3;                               // 3 = padding element
-        el_off[j] = (c * 132 + kx + 64 * ph + p16) * 4;             // + 64*nt bytes per tile
-    }
+    // K12 stage A: e_conv1 on the MFMA.  Every landed fp32 image row is converted once into a 16-bit
+    // pixel-interleaved row [px][R,G,B,0] (hi part, and for bf16 the lo = x - hi part, so the fp32
+    // pixel survives bf16's 8 mantissa bits).  K layout of the two K=32 MFMAs per 16-pixel tile:
+    //   MFMA m, lane group kq:  ky = 2m + (kq>>1),  kx = 2(kq&1) + (j>>2),  c = j&3     (ky,kx = 3: zero weights)
+    // so a lane's 8 k-values are two adjacent interleaved pixels = 16 contiguous bytes of the row.
+    auto convert_row = [&](int t) __attribute__((always_inline)) {
+        const int px = sw * 64 + lane;      // row R(t) = ys-2+t landed in fp32 slot t % NRI
+        if (px < 132) {                     // px 130/131 are read by the zero-weight pad tap: keep them finite (0)
+            const float* ip = (const float*)(smem + OFF_IMG + (t % NRI) * IMG_SLOT_B) + px;
+            const bool real = px < 130;
+            const float r = real ? ip[0] : 0.f, g = real ? ip[132] : 0.f, bl = real ? ip[264] : 0.f;
+            const T hr = (T)r, hg = (T)g, hb = (T)bl;
+            ie_u32x2 hi, lo;
+            hi[0] = ie_pack2<T>(r, g);
+            hi[1] = ie_pack2<T>(bl, 0.f);
+            lo[0] = ie_pack2<T>(r - (float)hr, g - (float)hg);
+            lo[1] = ie_pack2<T>(bl - (float)hb, 0.f);
+            char* cv = smem + OFF_CV + (t % NRC) * CV_SLOT_B + px * 8;
+            *(ie_u32x2*)cv = hi;
+            *(ie_u32x2*)(cv + CV_PLANE_B) = lo;
+        }
+    };
     auto conv1_row = [&](int t, ie_f32x4 (&acc)[4]) __attribute__((always_inline)) {
-        // image row ra + ky - 1 = ys-4+t+ky lives in slot (t - 2 + ky) % NRI
-        const int sb0 = OFF_IMG + ((t + NRI - 2) % NRI) * IMG_SLOT_B;
-        const int sb1 = OFF_IMG + ((t + NRI - 1) % NRI) * IMG_SLOT_B;
-        const int sb2 = OFF_IMG + (t % NRI) * IMG_SLOT_B;
-        int ea[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) ea[j] = (el_ky[j] == 0 ? sb0 : (el_ky[j] == 1 ? sb1 : sb2)) + el_off[j];
+        // output row ra = ys-4+t from converted rows R(t-3), R(t-2), R(t-1); this lane reads row
+        // ky = 2m + (kq>>1): slot (t - 3 + ky) % NRC
+        const int pxo = (64 * ph + p16 + 2 * (kq & 1)) * 8;
+        const int s0 = OFF_CV + ((t + NRC - 3 + (kq >> 1)) % NRC) * CV_SLOT_B + pxo;     // m = 0: ky = kq>>1
+        const int s1 = OFF_CV + ((t + NRC - 1) % NRC) * CV_SLOT_B + pxo;                 // m = 1: ky = 2 (kq < 2)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-            frag hi, lo;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float v = *(const float*)(smem + ea[j] + 64 * nt);
-                v = (el_ky[j] < 3) ? v : 0.f;
-                const T h = (T)v;
-                hi[j] = h;
-                lo[j] = (T)(v - (float)h);
-            }
             ie_f32x4 a = bias4;
-            a = E::mfma16(wv[0], hi, a);
-            if constexpr (ie_elem<T>::dtype == IE_BF16) a = E::mfma16(wv[0], lo, a);
+#pragma unroll
+            for (int part = 0; part < (ie_elem<T>::dtype == IE_BF16 ? 2 : 1); ++part) {
+                ie_u32x4 b0, b1;
+                const char* r0 = smem + s0 + part * CV_PLANE_B + 128 * nt;
+                const char* r1 = smem + s1 + part * CV_PLANE_B + 128 * nt;
+                const ie_u32x2 b0a = *(const ie_u32x2*)r0, b0b = *(const ie_u32x2*)(r0 + 8);
+                const ie_u32x2 b1a = *(const ie_u32x2*)r1, b1b = *(const ie_u32x2*)(r1 + 8);
+                b0 = ie_u32x4{b0a[0], b0a[1], b0b[0], b0b[1]};
+                b1 = ie_u32x4{b1a[0], b1a[1], b1b[0], b1b[1]};
+                a = E::mfma16(wv[0], __builtin_bit_cast(frag, b0), a);
+                a = E::mfma16(wv[1], __builtin_bit_cast(frag, b1), a);
+            }
             acc[nt] = a;
         }
     };
 
+#ifdef IE_STAMP
+    unsigned long long st_wait = 0, st_issue = 0, st_work = 0;
+#endif
     // ---- one step -----------------------------------------------------------------------------------
+    // Stage A: MFMAs first (the pipe is busy from the first cycle after the barrier), then its DMA
+    // issue, then the hand-off write.  Stage B: the epilogue of the row it finished in the PREVIOUS step
+    // first (that accumulator set is this step's accN, reset afterwards), then its MFMAs.  The two stages
+    // share each SIMD, so B's epilogue VALU runs under A's MFMAs and A's tail under B's MFMAs.
     auto step = [&](int t, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4]) __attribute__((always_inline)) {
-        wait_vm(wait_base < 0 ? -1 : wait_base + S * min(max(t - 2, 0), PF));
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // stage A's hand-off writes of step t-1
+        unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
+        (void)ts0; (void)ts1; (void)ts2; (void)ts3;
+        IE_T(ts0);
+        wait_vm(wait_base);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS writes of step t-1 (hand-off, staging)
         __builtin_amdgcn_s_barrier();
-        issue(t + PF);
+        IE_T(ts1);
         if (stg == 0) {
             if constexpr (KIND == K12) {
                 conv1_row(t, accO);
-                if (t >= 2) a_emit(accO, t);
+                IE_T(ts2);
+                issue(t + PF);
+                if (t >= 3) a_emit(accO, t);
             } else {
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) accN[nt] = bias4;
-                src_mfma(smem + (t % NRA) * ROW_B, 0, accN, accM, accO);
-                if constexpr (NSA == 2) src_mfma(smem + NRA * ROW_B + (t % NRA) * ROW_B, 9, accN, accM, accO);
+                src_mfma(smem + (t % NRA) * ROW_B, 0, accN, accM, accO, 0);
+                if constexpr (NSA == 2) src_mfma(smem + NRA * ROW_B + (t % NRA) * ROW_B, 9, accN, accM, accO, 0);
+                IE_T(ts2);
+                issue(t + PF);
                 if (t >= 2) a_emit(accO, t);
+                if constexpr (KIND == K67) { if (t >= 7) curve_consume(t - 2); }
             }
         } else {
+            issue(t + PF);
+            IE_T(ts2);
+            // accN still holds the output row finished at step t-1: ys-5-LAG_A+(t-1)
+            if constexpr (KIND == K12) convert_row(t);
+            if constexpr (KIND != K67) {
+                if (t >= 6 + LAG_A) b_store(accN, ys - 6 - LAG_A + t);
+            } else {
+                if (t >= 7) curve_consume(t - 2);
+                if (t >= 6) stage_write(accN, (t - 1) & 1);
+            }
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) accN[nt] = bias4;
             const char* ra_row = smem + OFF_RA + ((t + 1) & 1) * ROW_B;     // written by stage A at step t-1
             if constexpr (KIND == K12) {
-                src_mfma(ra_row, 0, accN, accM, accO);
+                src_mfma(ra_row, 0, accN, accM, accO, ys - 5 + t);                      // x1 row ys-5+t (also stored to HBM)
             } else if constexpr (KIND == K45) {
-                src_mfma(smem + ((t + NRA - 2) % NRA) * ROW_B, 0, accN, accM, accO);   // x3 row ys-4+t
-                src_mfma(ra_row, 9, accN, accM, accO);                                  // x4 row ys-4+t
+                src_mfma(smem + ((t + NRA - 2) % NRA) * ROW_B, 0, accN, accM, accO, 0);   // x3 row ys-4+t
+                src_mfma(ra_row, 9, accN, accM, accO, 0);                                  // x4 row ys-4+t
             } else {
-                src_mfma(smem + OFF_BRING + (t % NRB) * ROW_B, 0, accN, accM, accO);    // x1 row ys-4+t
-                src_mfma(ra_row, 9, accN, accM, accO);                                  // x6 row ys-4+t
-            }
-            if constexpr (KIND != K67) {
-                if (t >= 5) b_store(accO, ys - 5 + t);
-            } else {
-                if (t >= 5) stage_write(accO);
+                src_mfma(smem + OFF_BRING + (t % NRB) * ROW_B, 0, accN, accM, accO, 0);    // x1 row ys-4+t
+                src_mfma(ra_row, 9, accN, accM, accO, 0);                                  // x6 row ys-4+t
             }
         }
-        if constexpr (KIND == K67) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (stg == 1 && t >= 5) curve_consume(t);
-        }
+#ifdef IE_STAMP
+        IE_T(ts3);
+        st_wait += ts1 - ts0; st_issue += ts2 - ts1; st_work += ts3 - ts2;
+#endif
     };
 
 #pragma unroll
@@ -438,6 +482,12 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
         if (t + 2 < n_steps) step(t + 2, a1, a2, a0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef IE_STAMP
+    if (p.stamps && lane == 0) {
+        unsigned long long* d = p.stamps + ((size_t)blockIdx.x * 8 + wave) * 4;
+        d[0] = st_wait; d[1] = st_issue; d[2] = st_work; d[3] = n_steps;
+    }
+#endif
 }
 
 // Concrete kernels (readable names in rocprof traces; hipcc/ROCm 7.2 emitted the host stub of only
@@ -470,17 +520,19 @@ static int launch_fused_t(const ZdceFusedLaunch& a, hipStream_t st) {
     p.enhanced = a.enhanced; p.adjust = a.adjust; p.u8 = a.u8;
     p.N = a.N; p.H = a.H; p.W = a.W; p.y_begin = a.y_begin; p.y_end = a.y_end; p.rows_per_block = a.rows_per_block;
     p.n_begin = a.n_begin;
+    p.stamps = (unsigned long long*)a.stamps;
     p.strips = ie_cdiv(a.W, TS);
     p.chunks = ie_cdiv(a.y_end - a.y_begin, a.rows_per_block);
     const long long blocks = (long long)p.strips * p.chunks * a.n_count;
     if (blocks <= 0 || blocks > 0x7fffffffLL) IE_FAIL(IE_ERR_INVALID, "zdce fused: bad grid %lld", blocks);
     if ((size_t)a.H * a.W * 32 * sizeof(T) >= 0x7fffffffull) IE_FAIL(IE_ERR_UNSUPPORTED, "zdce fused: frame too large for 31-bit offsets");
+    constexpr int PF = (KIND == K67) ? 3 : PF_DEFAULT;
     constexpr int ROW_B = ROW_PX * 32 * (int)sizeof(T);
     constexpr int NSA = (KIND == K67) ? 2 : (KIND == K45 ? 1 : 0);
     constexpr int NRA = (KIND == K45) ? PF + 3 : PF + 1;
-    constexpr int NRI = (KIND == K12) ? PF + 3 : PF + 1;
+    constexpr int NRI = (KIND == K12) ? PF + 1 : PF + 3;
     const size_t lds = (size_t)NSA * NRA * ROW_B + (KIND == K67 ? (PF + 1) * ROW_B : 0) + 2 * ROW_B +
-                       (KIND == K45 ? 0 : NRI * 2048) + (KIND == K67 ? 24 * TW * 4 : 0);
+                       (KIND == K45 ? 0 : NRI * 2048) + (KIND == K12 ? 4 * 2 * 1088 : 0) + (KIND == K67 ? 2 * 24 * TW * 4 : 0);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)FusedKernel<T, KIND>::fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

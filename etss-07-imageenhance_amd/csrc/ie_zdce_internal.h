@@ -19,5 +19,6 @@ struct ZdceFusedLaunch {
     const void* a_w; const float* a_bias; const void* b_w; const float* b_bias;
     void* a_dst; void* b_dst; float* enhanced; float* adjust; unsigned char* u8;
     int N, H, W, y_begin, y_end, n_begin, n_count, rows_per_block;
+    void* stamps;   // diagnostic builds only
 };
 int ie_zdce_launch_fused(const ZdceFusedLaunch& a, hipStream_t st);

@@ -246,8 +246,8 @@ __global__ __launch_bounds__(NWAVE * 64, (NSRC == 1 ? 3 : 2)) void zdce_conv3x3_
         ie_u32x2 pk[4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-            pk[nt][0] = ie_pack2<T>(fmaxf(acc[nt][0], 0.f), fmaxf(acc[nt][1], 0.f));
-            pk[nt][1] = ie_pack2<T>(fmaxf(acc[nt][2], 0.f), fmaxf(acc[nt][3], 0.f));
+            pk[nt][0] = ie_pack2_relu<T>(acc[nt][0], acc[nt][1]);
+            pk[nt][1] = ie_pack2_relu<T>(acc[nt][2], acc[nt][3]);
         }
         const unsigned row_b = (unsigned)yo * (unsigned)W * PXB;
         if constexpr (WIDE) {
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256) void zdce_conv1_kernel(const float* __restrict
         ie_u32x4 o4;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            o4[i] = ie_pack2<T>(fmaxf(acc[8 * k + 2 * i], 0.f), fmaxf(acc[8 * k + 2 * i + 1], 0.f));
+            o4[i] = ie_pack2_relu<T>(acc[8 * k + 2 * i], acc[8 * k + 2 * i + 1]);
         out[k] = o4;
     }
 }

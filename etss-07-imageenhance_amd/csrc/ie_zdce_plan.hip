@@ -13,6 +13,9 @@
 
 #include "ie_zdce_internal.h"
 
+void* g_ie_stamps = nullptr;   // diagnostic builds (-DIE_STAMP): device buffer for in-kernel cycle stamps
+extern "C" __attribute__((visibility("default"))) void ie_debug_set_stamps(void* p) { g_ie_stamps = p; }
+
 namespace {
 constexpr int NL = 7;
 const char* const kLayerNames[NL] = {"zdce_conv1", "zdce_conv2", "zdce_conv3", "zdce_conv4",
@@ -171,17 +174,18 @@ IE_EXPORT int ie_zdce_finalize(ie_zdce_plan* p, void* stream) {
         host.insert(host.end(), q, q + 32 * 4);
     }
     if (dt != IE_F32) {
-        // e_conv1 for the fused K12 kernel: one K=32 fragment per cout half,
-        //   [hc][lane][j] = W1[16hc + (lane&15)][c][ky][kx] with k = 8*(lane>>4) + j = (ky*3 + kx)*3 + c  (k >= 27: 0)
+        // e_conv1 for the fused K12 kernel: two K=32 fragments (m = 0,1) per cout half over the
+        // interleaved [px][R,G,B,0] image rows:  [hc][m][lane][j] = W1[16hc + (lane&15)][c][ky][kx] with
+        //   kq = lane>>4, ky = 2m + (kq>>1), kx = 2(kq&1) + (j>>2), c = j&3   (ky, kx, c == 3: zero)
         align(256);
         p->off_w1m = host.size();
         const float* w = p->w[0].data();
-        std::vector<unsigned short> hw((size_t)2 * 64 * 8, 0);
-        for (int hc = 0; hc < 2; ++hc) for (int lane = 0; lane < 64; ++lane) for (int j = 0; j < 8; ++j) {
-            const int k = 8 * (lane >> 4) + j;
+        std::vector<unsigned short> hw((size_t)2 * 2 * 64 * 8, 0);
+        for (int hc = 0; hc < 2; ++hc) for (int m = 0; m < 2; ++m) for (int lane = 0; lane < 64; ++lane) for (int j = 0; j < 8; ++j) {
+            const int kq = lane >> 4, ky = 2 * m + (kq >> 1), kx = 2 * (kq & 1) + (j >> 2), c = j & 3;
             float v = 0.f;
-            if (k < 27) { const int tap = k / 3, c = k % 3; v = w[((size_t)(16 * hc + (lane & 15)) * 3 + c) * 9 + tap]; }
-            hw[((size_t)hc * 64 + lane) * 8 + j] = dt == IE_F16 ? f32_to_f16_bits(v) : f32_to_bf16_bits(v);
+            if (ky < 3 && kx < 3 && c < 3) v = w[((size_t)(16 * hc + (lane & 15)) * 3 + c) * 9 + ky * 3 + kx];
+            hw[(((size_t)hc * 2 + m) * 64 + lane) * 8 + j] = dt == IE_F16 ? f32_to_f16_bits(v) : f32_to_bf16_bits(v);
         }
         const char* q = (const char*)hw.data();
         host.insert(host.end(), q, q + hw.size() * 2);
@@ -305,6 +309,7 @@ static int forward_mfma(ie_zdce_plan* p, const float* image, float* enhanced, fl
                 memset(&a, 0, sizeof(a));
                 a.kind = kind; a.dtype = dt; a.N = N; a.H = H; a.W = W; a.n_begin = n0; a.n_count = g; a.rows_per_block = rb;
                 a.img = image;
+                a.stamps = g_ie_stamps ? (void*)((unsigned long long*)g_ie_stamps + (size_t)(kind == 12 ? 0 : kind == 45 ? 1 : 2) * (1u << 20)) : nullptr;
                 if (kind == 12) {
                     a.a_w = p->d_w + p->off_w1m; a.a_bias = B_(0); a.b_w = W_(1); a.b_bias = B_(1);
                     a.a_dst = x[1]; a.b_dst = x[2]; a.y_begin = lo(2); a.y_end = hi(2);
