@@ -22,9 +22,16 @@ sys.path.insert(0, ROOT)
 H, W = 1080, 1920
 BATCH_PER_GPU = 64
 FLOP_PER_PX = 158400                      # 2 * 79,200 MAC
-# per-layer algorithmic work per pixel: (flop, bytes moved at 2 B/elem activations, fp32 image)
-LAYER_FLOP_PX = [2 * 27 * 32, 2 * 288 * 32, 2 * 288 * 32, 2 * 288 * 32, 2 * 576 * 32, 2 * 576 * 32, 2 * 576 * 24]
-LAYER_BYTES_PX = [12 + 64, 64 + 64, 64 + 64, 64 + 64, 128 + 64, 128 + 64, 128 + 12 + 12]
+# per-kernel algorithmic work per pixel: (FLOP, HBM bytes with 16-bit activations and fp32 image/enhanced)
+_L = [2 * 27 * 32, 2 * 288 * 32, 2 * 288 * 32, 2 * 288 * 32, 2 * 576 * 32, 2 * 576 * 32, 2 * 576 * 24]
+KERNEL_WORK = {
+    "zdce_conv1": (_L[0], 12 + 64), "zdce_conv2": (_L[1], 128), "zdce_conv3": (_L[2], 128), "zdce_conv4": (_L[3], 128),
+    "zdce_conv5": (_L[4], 192), "zdce_conv6": (_L[5], 192), "zdce_conv7_curve": (_L[6], 128 + 12 + 12),
+    # fused strip kernels: the intermediate of the pair stays in LDS
+    "zdce_k12_conv1_conv2": (_L[0] + _L[1], 12 + 64 + 64),           # image in, x1 and x2 out
+    "zdce_k45_conv4_conv5": (_L[3] + _L[4], 64 + 64),                # x3 in, x5 out (x4 in LDS)
+    "zdce_k67_conv6_conv7_curve": (_L[5] + _L[6], 3 * 64 + 12 + 12),  # x2, x5, x1, image in, enhanced out
+}
 PEAK_MFMA_TFLOPS = 2500.0                 # dense bf16/f16, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 
@@ -113,13 +120,14 @@ def main():
             for i in range(7):
                 acc[i] += ms[i] / reps
                 nl[i] = launches[i]
-        layer_ms = {names[i].decode(): round(acc[i], 4) for i in range(7)}
+        layer_ms = {names[i].decode(): round(acc[i], 4) for i in range(7) if names[i]}
         dom = max(range(7), key=lambda i: acc[i])
+        kflop, kbytes = KERNEL_WORK[names[dom].decode()]
         px_per_launch = n * H * W / max(nl[dom], 1)
         avg_ms = acc[dom] / max(nl[dom], 1)
-        flops = LAYER_FLOP_PX[dom] * px_per_launch
-        byts = LAYER_BYTES_PX[dom] * px_per_launch
-        hbm_bound = (LAYER_FLOP_PX[dom] / LAYER_BYTES_PX[dom]) < (PEAK_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9))
+        flops = kflop * px_per_launch
+        byts = kbytes * px_per_launch
+        hbm_bound = (kflop / kbytes) < (PEAK_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9))
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
@@ -132,13 +140,16 @@ def main():
             roofline = {"kernel": names[dom].decode(), "bound": "hbm", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS,
                         "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": traffic,
                         "avg_launch_ms": round(avg_ms, 4), "launches_per_step": nl[dom],
-                        "mfma_tflops": round(flops / (avg_ms * 1e-3) / 1e12, 1)}
+                        "flop_per_byte": round(kflop / kbytes, 1),
+                        "mfma_tflops": round(flops / (avg_ms * 1e-3) / 1e12, 1),
+                        "mfma_frac": round(flops / (avg_ms * 1e-3) / 1e12 / PEAK_MFMA_TFLOPS, 4)}
         else:
             achieved = flops / (avg_ms * 1e-3) / 1e12
             roofline = {"kernel": names[dom].decode(), "bound": "mfma", "achieved": round(achieved, 1), "peak": PEAK_MFMA_TFLOPS,
                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_MFMA_TFLOPS, 4), "traffic": traffic,
                         "avg_launch_ms": round(avg_ms, 4), "launches_per_step": nl[dom]}
-        roofline["layer_ms_per_step"] = layer_ms
+        roofline["kernel_ms_per_step"] = layer_ms
+        roofline["model_bytes_per_px"] = sum(KERNEL_WORK[k][1] for k in layer_ms)
         roofline["model_mfma_frac"] = round(value / world * H * W * FLOP_PER_PX / (PEAK_MFMA_TFLOPS * 1e12), 4)
 
         # ---- parity of this very configuration on one frame + CPU baseline (oracle, "port") ----

@@ -272,13 +272,16 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
                 accM[nt] = E::mfma16(wv[wbase + 1 * 3 + kx], bx, accM[nt]);
                 accO[nt] = E::mfma16(wv[wbase + 2 * 3 + kx], bx, accO[nt]);
             }
-        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#ifndef IE_LDS_DEPTH
+#define IE_LDS_DEPTH 3
+#endif
+        __builtin_amdgcn_sched_group_barrier(0x100, IE_LDS_DEPTH, 0);
 #pragma unroll
-        for (int f = 0; f < 12 - 3; ++f) {
+        for (int f = 0; f < 12 - IE_LDS_DEPTH; ++f) {
             __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 3 * IE_LDS_DEPTH, 0);
     };
 
     // write a finished stage-A row (ReLU, 16-bit, zero outside the image) into the hand-off ring slot
@@ -328,27 +331,33 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     // image ring, and write enhanced / u8 / adjust with coalesced stores.  No extra barrier: the
     // per-step barrier orders write -> read -> rewrite.
     auto stage_write = [&](const ie_f32x4 (&acc)[4], int slot) __attribute__((always_inline)) {
+        // row k is stored rotated by 16*((k>>2)&1) columns: the 32 lanes of a ds_write_b32 group
+        // (2 kq values x 16 columns) then hit 32 distinct banks
         float* sp = (float*)(smem + OFF_STAGE + slot * STAGE_SLOT_B);
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int k = 16 * ch + 4 * kq + i;
-                if (k < 24) sp[k * TW + 64 * ph + 16 * nt + p16] = acc[nt][i];
+                if (k < 24) sp[k * TW + ((64 * ph + 16 * nt + p16 + 16 * (kq & 1)) & (TW - 1))] = acc[nt][i];
             }
     };
-    auto curve_consume = [&](int s_fin) __attribute__((always_inline)) {   // s_fin: step at which the row was finished
+    // 384 of the 512 threads: thread = (column q, colour channel c); s_fin: step at which the row was finished
+    auto curve_consume = [&](int s_fin) __attribute__((always_inline)) {
         const int yo = ys - 5 + s_fin;
-        const int q = tid & 127, c = tid >> 7;       // 512 threads: c = 0,1,2 colour channel, 3 idle
+        const int q = tid & 127, c = tid >> 7;       // c = 0,1 on stage-A waves, 2 on stage-B waves 4,5; 3: idle
         const int xo = xc0 + q;
         if (c < 3 && q >= 1 && q < TW - 1 && xo < W && yo >= ys && yo < ye) {
-            const float* sp = (const float*)(smem + OFF_STAGE + (s_fin & 1) * STAGE_SLOT_B) + q;
+            const float* sp = (const float*)(smem + OFF_STAGE + (s_fin & 1) * STAGE_SLOT_B);
             const float* ip = (const float*)(smem + OFF_IMG + (s_fin % NRI) * IMG_SLOT_B);
             const size_t pix = (size_t)yo * W + xo;
             float v = ip[c * TW + q];
             float r[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) r[i] = ie_tanh_fast(sp[(3 * i + c) * TW]);
+            for (int i = 0; i < 8; ++i) {
+                const int k = 3 * i + c;
+                r[i] = ie_tanh_fast(sp[k * TW + ((q + 16 * ((k >> 2) & 1)) & (TW - 1))]);
+            }
 #pragma unroll
             for (int i = 0; i < 8; ++i) v = ie_curve_step(v, r[i]);
             if (p.enhanced) p.enhanced[((size_t)n * 3 + c) * plane + pix] = v;
@@ -390,21 +399,23 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
         const int s0 = OFF_CV + ((t + NRC - 3 + (kq >> 1)) % NRC) * CV_SLOT_B + pxo;     // m = 0: ky = kq>>1
         const int s1 = OFF_CV + ((t + NRC - 1) % NRC) * CV_SLOT_B + pxo;                 // m = 1: ky = 2 (kq < 2)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            ie_f32x4 a = bias4;
+        for (int nt = 0; nt < 4; ++nt) acc[nt] = bias4;
 #pragma unroll
-            for (int part = 0; part < (ie_elem<T>::dtype == IE_BF16 ? 2 : 1); ++part) {
-                ie_u32x4 b0, b1;
+        for (int part = 0; part < (ie_elem<T>::dtype == IE_BF16 ? 2 : 1); ++part) {
+            ie_u32x4 b0[4], b1[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {       // all loads first: the four tiles are independent MFMA chains
                 const char* r0 = smem + s0 + part * CV_PLANE_B + 128 * nt;
                 const char* r1 = smem + s1 + part * CV_PLANE_B + 128 * nt;
                 const ie_u32x2 b0a = *(const ie_u32x2*)r0, b0b = *(const ie_u32x2*)(r0 + 8);
                 const ie_u32x2 b1a = *(const ie_u32x2*)r1, b1b = *(const ie_u32x2*)(r1 + 8);
-                b0 = ie_u32x4{b0a[0], b0a[1], b0b[0], b0b[1]};
-                b1 = ie_u32x4{b1a[0], b1a[1], b1b[0], b1b[1]};
-                a = E::mfma16(wv[0], __builtin_bit_cast(frag, b0), a);
-                a = E::mfma16(wv[1], __builtin_bit_cast(frag, b1), a);
+                b0[nt] = ie_u32x4{b0a[0], b0a[1], b0b[0], b0b[1]};
+                b1[nt] = ie_u32x4{b1a[0], b1a[1], b1b[0], b1b[1]};
             }
-            acc[nt] = a;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[nt] = E::mfma16(wv[0], __builtin_bit_cast(frag, b0[nt]), acc[nt]);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[nt] = E::mfma16(wv[1], __builtin_bit_cast(frag, b1[nt]), acc[nt]);
         }
     };
 

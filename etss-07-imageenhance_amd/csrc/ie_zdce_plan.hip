@@ -20,6 +20,9 @@ namespace {
 constexpr int NL = 7;
 const char* const kLayerNames[NL] = {"zdce_conv1", "zdce_conv2", "zdce_conv3", "zdce_conv4",
                                      "zdce_conv5", "zdce_conv6", "zdce_conv7_curve"};
+// profiling slots used by the fused schedule (slot index = last layer of the kernel)
+const char* const kFusedNames[NL] = {"", "zdce_k12_conv1_conv2", "zdce_conv3", "", "zdce_k45_conv4_conv5", "",
+                                     "zdce_k67_conv6_conv7_curve"};
 
 unsigned short f32_to_f16_bits(float f) { _Float16 h = (_Float16)f; unsigned short u; memcpy(&u, &h, 2); return u; }
 unsigned short f32_to_bf16_bits(float f) {
@@ -65,14 +68,13 @@ static void pick_schedule(const ie_zdce_plan* p, int N, int H, int W, int* group
     if (bd > H) bd = H;
     int r = p->rows_per_block > 0 ? p->rows_per_block : 0;
     if (r <= 0) {
-        // enough workgroups to fill 256 CUs x 2 several times over, but rows long enough to amortise the
-        // 2-row apron: aim for >= 2048 workgroups per launch, 8 <= RB <= 64
-        const long long strips = (W + 127) / 128;
-        long long want = 2048;
-        long long rows_total = (long long)g * bd;
-        long long rbv = rows_total * strips / want;
+        // The fused kernels run one 8-wave workgroup per CU: aim for two full rounds of 256 workgroups per
+        // launch (equal-length blocks -> no tail), with rows long enough to amortise the 6-7 apron steps.
+        const long long strips = (W + 125) / 126;
+        long long chunks = (512 + (long long)g * strips - 1) / ((long long)g * strips);
+        if (chunks < 1) chunks = 1;
+        long long rbv = (bd + chunks - 1) / chunks;
         if (rbv < 8) rbv = 8;
-        if (rbv > 64) rbv = 64;
         r = (int)rbv;
     }
     (void)W;
@@ -416,7 +418,8 @@ IE_EXPORT int ie_zdce_profile_forward(ie_zdce_plan* p, const float* image, float
     p->prof = false;
     if (rc) return rc;
     IE_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
-    for (int l = 0; l < NL; ++l) { ms[l] = 0.f; names[l] = kLayerNames[l]; if (launches) launches[l] = 0; }
+    const bool fused = p->cfg.compute_dtype != IE_F32 && !(p->cfg.variant & IE_ZDCE_VAR_UNFUSED);
+    for (int l = 0; l < NL; ++l) { ms[l] = 0.f; names[l] = fused ? kFusedNames[l] : kLayerNames[l]; if (launches) launches[l] = 0; }
     for (size_t i = 0; i < p->ev_layer.size(); ++i) {
         float t = 0.f;
         IE_HIP_CHECK(hipEventElapsedTime(&t, p->ev[2 * i], p->ev[2 * i + 1]));
