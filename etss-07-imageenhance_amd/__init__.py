@@ -13,9 +13,12 @@ from .globals_ import Task, Scheme
 from . import capi
 from .model import Model, VisionModel, ImageEnhancementModel
 from .zero_dce import ZeroDCE_RE
+from . import ops
+from .generators import ZeroDCEpp_RE, LLUnetpp_RE, UNet, ZeroIGEnhance, RetinexNet
 from . import image
 from . import sharding
 
 __version__ = "0.1.0"
 __all__ = ["Factory", "ModelFactory", "MODELS", "Task", "Scheme", "capi", "Model", "VisionModel",
-           "ImageEnhancementModel", "ZeroDCE_RE", "image", "sharding"]
+           "ImageEnhancementModel", "ZeroDCE_RE", "ZeroDCEpp_RE", "LLUnetpp_RE", "UNet", "ZeroIGEnhance", "RetinexNet",
+           "ops", "image", "sharding"]

@@ -26,6 +26,8 @@ SYMBOLS = [
     "ie_nchw_f32_to_nhwc", "ie_nhwc_to_nchw_f32", "ie_nchw_f32_to_u8_nhwc", "ie_u8_nhwc_to_nchw_f32",
     "ie_resize_bilinear_nchw_f32",
     "ie_conv2d_nhwc_f32", "ie_pack_weight_hwio_f32", "ie_le_curve",
+    "ie_convn_nhwc_f32", "ie_instnorm_nhwc_f32", "ie_maxpool2x2_nhwc_f32", "ie_resize_nhwc_f32", "ie_pixel_shuffle_nhwc_f32",
+    "ie_conv_transpose2x2_nhwc_f32", "ie_pad_nhwc_f32", "ie_eltwise_nhwc_f32", "ie_max_concat_nhwc_f32",
     "ie_zdce_create", "ie_zdce_set_layer", "ie_zdce_finalize", "ie_zdce_reserve", "ie_zdce_forward",
     "ie_zdce_get_feature", "ie_zdce_workspace_bytes", "ie_zdce_destroy", "ie_zdce_time_forward",
     "ie_zdce_profile_forward", "ie_zdce_set_tuning",
@@ -45,6 +47,13 @@ class Conv2dDesc(C.Structure):
     _fields_ = [("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C0", C.c_int), ("C1", C.c_int),
                 ("Cout", C.c_int), ("kh", C.c_int), ("kw", C.c_int), ("stride", C.c_int), ("pad", C.c_int),
                 ("pad_mode", C.c_int), ("groups", C.c_int), ("act", C.c_int), ("slope", C.c_float),
+                ("Ho", C.c_int), ("Wo", C.c_int)]
+
+
+class ConvNDesc(C.Structure):
+    _fields_ = [("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("nsrc", C.c_int), ("Cout", C.c_int), ("kh", C.c_int),
+                ("kw", C.c_int), ("stride", C.c_int), ("pad", C.c_int), ("pad_mode", C.c_int), ("act", C.c_int),
+                ("slope", C.c_float), ("clamp", C.c_int), ("clamp_lo", C.c_float), ("clamp_hi", C.c_float),
                 ("Ho", C.c_int), ("Wo", C.c_int)]
 
 
@@ -72,6 +81,15 @@ def lib():
     L.ie_conv2d_nhwc_f32.argtypes = [C.POINTER(Conv2dDesc), vp, vp, vp, vp, vp, vp]
     L.ie_pack_weight_hwio_f32.argtypes = [vp, ip, ip, ip, ip, vp, vp]
     L.ie_le_curve.argtypes = [vp, vp, ip, vp, ip, ip, ip, ip, vp]
+    L.ie_convn_nhwc_f32.argtypes = [C.POINTER(ConvNDesc), C.POINTER(vp), C.POINTER(ip), vp, vp, vp, vp, vp]
+    L.ie_instnorm_nhwc_f32.argtypes = [vp, vp, vp, vp, vp, ip, ip, ip, ip, ip, ip, fp, ip, fp, vp]
+    L.ie_maxpool2x2_nhwc_f32.argtypes = [vp, vp, ip, ip, ip, ip, vp]
+    L.ie_resize_nhwc_f32.argtypes = [vp, vp, ip, ip, ip, ip, ip, ip, ip, vp]
+    L.ie_pixel_shuffle_nhwc_f32.argtypes = [vp, vp, ip, ip, ip, ip, ip, vp]
+    L.ie_conv_transpose2x2_nhwc_f32.argtypes = [vp, vp, vp, vp, ip, ip, ip, ip, ip, vp]
+    L.ie_pad_nhwc_f32.argtypes = [vp, vp, ip, ip, ip, ip, ip, ip, ip, ip, vp]
+    L.ie_eltwise_nhwc_f32.argtypes = [ip, vp, vp, vp, C.c_size_t, ip, ip, fp, fp, vp]
+    L.ie_max_concat_nhwc_f32.argtypes = [vp, vp, C.c_size_t, ip, vp]
     L.ie_zdce_create.argtypes = [C.POINTER(ZdceConfig), C.POINTER(vp)]
     L.ie_zdce_set_layer.argtypes = [vp, ip, vp, vp, ip, ip]
     L.ie_zdce_finalize.argtypes = [vp, vp]

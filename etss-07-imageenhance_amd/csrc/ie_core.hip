@@ -78,14 +78,14 @@ __global__ void u8_to_f32_kernel(const unsigned char* __restrict__ src, float* _
 }
 
 __global__ void le_curve_kernel(const float* __restrict__ img, const float* __restrict__ adj, int Cp,
-                                float* __restrict__ out, size_t plane, size_t total_px, int iters) {
+                                float* __restrict__ out, size_t plane, size_t total_px, int iters, int shared) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total_px) return;
     const size_t n = i / plane, pix = i % plane;
     const float* a = adj + i * Cp;
     for (int c = 0; c < 3; ++c) {
         float y = img[(n * 3 + c) * plane + pix];
-        for (int k = 0; k < iters; ++k) y = ie_curve_step(y, a[3 * k + c]);
+        for (int k = 0; k < iters; ++k) y = ie_curve_step(y, a[shared ? c : 3 * k + c]);
         out[(n * 3 + c) * plane + pix] = y;
     }
 }
@@ -172,11 +172,12 @@ IE_EXPORT int ie_u8_nhwc_to_nchw_f32(const uint8_t* src, float* dst, int N, int 
 
 IE_EXPORT int ie_le_curve(const float* img, const float* adjust_nhwc, int Cp, float* enhanced, int N, int H, int W,
                           int iters, void* stream) {
-    if (!img || !adjust_nhwc || !enhanced || N <= 0 || H <= 0 || W <= 0 || iters <= 0 || Cp < 3 * iters)
+    const int shared = (Cp >= 3 && Cp < 3 * iters) ? 1 : 0;   // one 3-channel map for every iteration (zero_dcepp.py:201-203)
+    if (!img || !adjust_nhwc || !enhanced || N <= 0 || H <= 0 || W <= 0 || iters <= 0 || Cp < 3)
         IE_FAIL(IE_ERR_INVALID, "ie_le_curve: bad args");
     const size_t plane = (size_t)H * W, total = plane * N;
     hipLaunchKernelGGL(le_curve_kernel, grid_for(total, 256), 256, 0, (hipStream_t)stream, img, adjust_nhwc, Cp, enhanced,
-                       plane, total, iters);
+                       plane, total, iters, shared);
     IE_LAUNCH_CHECK();
     return IE_OK;
 }

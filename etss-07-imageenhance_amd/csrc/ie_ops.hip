@@ -1,0 +1,377 @@
+// fp32 NHWC building blocks of the U-Net / LLUnet++ / RetinexNet / Zero-DCE++ generators (parity path):
+// multi-source conv (virtual concat of up to 8 tensors) with fused bias + activation + residual +
+// clamp, instance norm, 2x2 max-pool, resize (nearest / bilinear), pixel-shuffle, 2x2 stride-2
+// transposed conv, zero pad, broadcast multiply, RetinexNet's max-channel concat.
+// All streaming kernels are HBM-bound (one read + one write of the tensor); the conv runs on the VALU.
+// Reference call sites are cited at each entry point in include/ie_hip.h.
+#include "ie_common.h"
+#include <math.h>
+
+namespace {
+
+__device__ __forceinline__ float act_f(float v, int act, float slope) {
+    switch (act) {
+    case IE_ACT_RELU: return fmaxf(v, 0.f);
+    case IE_ACT_LRELU: return v > 0.f ? v : v * slope;
+    case IE_ACT_TANH: return tanhf(v);
+    case IE_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+    default: return v;
+    }
+}
+
+constexpr int MAXS = IE_CONV_MAX_SRC;
+constexpr int CT = 8;   // output channels per thread
+
+struct ConvNParams {
+    const float* src[MAXS];
+    int cs[MAXS];
+    int nsrc;
+    const float* w; const float* bias; const float* res; float* dst;
+    int N, H, W, Cin, Cout, kh, kw, stride, pad, pad_mode, act, Ho, Wo, clamp;
+    float slope, lo, hi;
+};
+
+// lane = output pixel, wave = 8 output channels (weights wave-uniform -> scalar loads)
+__global__ __launch_bounds__(256) void convn_direct_kernel(ConvNParams p) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = blockIdx.z;
+    const int opix = blockIdx.x * 64 + lane;
+    const int co0 = (blockIdx.y * 4 + wave) * CT;
+    if (co0 >= p.Cout) return;
+    const bool live = opix < p.Ho * p.Wo;
+    const int ho = live ? opix / p.Wo : 0, wo = live ? opix % p.Wo : 0;
+    const int nco = min(CT, p.Cout - co0);
+    float acc[CT];
+#pragma unroll
+    for (int o = 0; o < CT; ++o) acc[o] = (p.bias && o < nco) ? p.bias[co0 + o] : 0.f;
+    for (int i = 0; i < p.kh; ++i)
+        for (int j = 0; j < p.kw; ++j) {
+            int hi = ho * p.stride + i - p.pad, wi = wo * p.stride + j - p.pad;
+            bool inb = true;
+            if (p.pad_mode == IE_PAD_REPLICATE) {
+                hi = min(max(hi, 0), p.H - 1);
+                wi = min(max(wi, 0), p.W - 1);
+            } else {
+                inb = hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+            }
+            const size_t pix = ((size_t)n * p.H + (inb ? hi : 0)) * p.W + (inb ? wi : 0);
+            const float* wtap = p.w + (size_t)(i * p.kw + j) * p.Cin * p.Cout + co0;
+            int cbase = 0;
+            for (int s = 0; s < p.nsrc; ++s) {
+                const int Cs = p.cs[s];
+                const float* sp = p.src[s] + pix * Cs;
+                const float* ws = wtap + (size_t)cbase * p.Cout;
+                if ((Cs & 3) == 0) {
+                    for (int c = 0; c < Cs; c += 4) {
+                        ie_f32x4 v = inb ? *(const ie_f32x4*)(sp + c) : ie_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float* wr = ws + (size_t)(c + k) * p.Cout;
+                            if (nco == CT) {
+#pragma unroll
+                                for (int o = 0; o < CT; ++o) acc[o] = fmaf(v[k], wr[o], acc[o]);
+                            } else {
+#pragma unroll
+                                for (int o = 0; o < CT; ++o) if (o < nco) acc[o] = fmaf(v[k], wr[o], acc[o]);
+                            }
+                        }
+                    }
+                } else {
+                    for (int c = 0; c < Cs; ++c) {
+                        const float v = inb ? sp[c] : 0.f;
+                        const float* wr = ws + (size_t)c * p.Cout;
+#pragma unroll
+                        for (int o = 0; o < CT; ++o) if (o < nco) acc[o] = fmaf(v, wr[o], acc[o]);
+                    }
+                }
+                cbase += Cs;
+            }
+        }
+    if (!live) return;
+    const size_t ob = (((size_t)n * p.Ho + ho) * p.Wo + wo) * p.Cout + co0;
+#pragma unroll
+    for (int o = 0; o < CT; ++o)
+        if (o < nco) {
+            float v = act_f(acc[o], p.act, p.slope);
+            if (p.res) v += p.res[ob + o];
+            if (p.clamp) v = fminf(fmaxf(v, p.lo), p.hi);
+            p.dst[ob + o] = v;
+        }
+}
+
+// ---- instance norm ---------------------------------------------------------------------------------
+// pass 1: per (n, c) sum and sum of squares.  Block = 256 threads = 64 pixels-lanes x 4 channel groups? No:
+// thread = (pixel stripe, channel): each thread walks pixels with stride, one channel -> coalesced across c.
+__global__ void instnorm_stats_kernel(const float* __restrict__ x, double* __restrict__ stats, int HW, int C, int c0,
+                                      int cn, int cn_total, int c_off) {
+    // grid: (chunks of pixels, N); block: 256 threads; thread t handles channel c0 + t % cn for pixels t / cn + k*(256/cn)...
+    const int n = blockIdx.y;
+    const int tpc = max(1, 256 / cn);            // pixel slots per block
+    const int c = threadIdx.x % cn, ps = threadIdx.x / cn;
+    double s = 0.0, ss = 0.0;
+    if (ps < tpc && c < cn) {
+        const float* xp = x + (size_t)n * HW * C + c0 + c;
+        for (int pix = blockIdx.x * tpc + ps; pix < HW; pix += gridDim.x * tpc) {
+            const float v = xp[(size_t)pix * C];
+            s += v; ss += (double)v * v;
+        }
+    }
+    __shared__ double sh[2][256];
+    sh[0][threadIdx.x] = s; sh[1][threadIdx.x] = ss;
+    __syncthreads();
+    if (ps == 0 && c < cn) {
+        for (int k = 1; k < tpc; ++k) { s += sh[0][k * cn + c]; ss += sh[1][k * cn + c]; }
+        atomicAdd(&stats[((size_t)n * cn_total + c_off + c) * 2 + 0], s);
+        atomicAdd(&stats[((size_t)n * cn_total + c_off + c) * 2 + 1], ss);
+    }
+}
+// pass 2: y = (x - mean) * rsqrt(var + eps) * gamma + beta, activation; channels outside [c0, c0+cn) copied
+__global__ void instnorm_apply_kernel(const float* __restrict__ x, const double* __restrict__ stats,
+                                      const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y,
+                                      int HW, int C, int c0, int cn, float eps, int act, float slope, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    const size_t n = i / ((size_t)HW * C);
+    float v = x[i];
+    if (c >= c0 && c < c0 + cn) {
+        const double s = stats[(n * cn + (c - c0)) * 2], ss = stats[(n * cn + (c - c0)) * 2 + 1];
+        const double mean = s / HW;
+        const double var = fmax(ss / HW - mean * mean, 0.0);
+        const float inv = (float)(1.0 / sqrt(var + (double)eps));
+        v = (v - (float)mean) * inv;
+        if (gamma) v = v * gamma[c - c0] + beta[c - c0];
+    }
+    y[i] = act_f(v, act, slope);
+}
+
+__global__ void maxpool2_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int C, int Ho, int Wo,
+                                size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    size_t r = i / C;
+    const int wo = (int)(r % Wo); r /= Wo;
+    const int ho = (int)(r % Ho);
+    const size_t n = r / Ho;
+    const float* p = x + ((n * H + 2 * ho) * W + 2 * wo) * C + c;
+    y[i] = fmaxf(fmaxf(p[0], p[C]), fmaxf(p[(size_t)W * C], p[(size_t)W * C + C]));
+}
+
+// mode 0: legacy nearest (src = floor(dst*in/out)); 1: bilinear align_corners=False; 2: bilinear align_corners=True
+__global__ void resize_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int Hi, int Wi, int C, int Ho, int Wo,
+                                   int mode, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    size_t r = i / C;
+    const int xo = (int)(r % Wo); r /= Wo;
+    const int yo = (int)(r % Ho);
+    const size_t n = r / Ho;
+    const float* p = x + n * (size_t)Hi * Wi * C + c;
+    if (mode == 0) {
+        const int ys = min((int)floorf(yo * ((float)Hi / (float)Ho)), Hi - 1);
+        const int xs = min((int)floorf(xo * ((float)Wi / (float)Wo)), Wi - 1);
+        y[i] = p[((size_t)ys * Wi + xs) * C];
+        return;
+    }
+    float sy, sx;
+    if (mode == 2) {
+        const float ry = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f;
+        const float rx = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
+        sy = ry * yo; sx = rx * xo;
+    } else {
+        sy = fmaxf((float)Hi / (float)Ho * (yo + 0.5f) - 0.5f, 0.f);
+        sx = fmaxf((float)Wi / (float)Wo * (xo + 0.5f) - 0.5f, 0.f);
+    }
+    const int y0 = min((int)sy, Hi - 1), x0 = min((int)sx, Wi - 1);
+    const int y1 = min(y0 + 1, Hi - 1), x1 = min(x0 + 1, Wi - 1);
+    const float ly = sy - (float)y0, lx = sx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+    const float v00 = p[((size_t)y0 * Wi + x0) * C], v01 = p[((size_t)y0 * Wi + x1) * C];
+    const float v10 = p[((size_t)y1 * Wi + x0) * C], v11 = p[((size_t)y1 * Wi + x1) * C];
+    y[i] = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+}
+
+// y[n, h*r+i, w*r+j, c] = x[n, h, w, c*r*r + i*r + j]
+__global__ void pixel_shuffle_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int Co, int r,
+                                     size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % Co);
+    size_t q = i / Co;
+    const int wo = (int)(q % (W * r)); q /= (size_t)W * r;
+    const int ho = (int)(q % (H * r));
+    const size_t n = q / ((size_t)H * r);
+    const int h = ho / r, ii = ho % r, w = wo / r, jj = wo % r;
+    y[i] = x[((n * H + h) * W + w) * (size_t)(Co * r * r) + c * r * r + ii * r + jj];
+}
+
+// ConvTranspose2d(k=2, s=2): y[n,2h+i,2w+j,o] = b[o] + sum_c x[n,h,w,c] W[c,o,i,j]; weights repacked [i][j][c][o]
+__global__ void convT2x2_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                float* __restrict__ y, int H, int W, int Ci, int Co, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int o = (int)(i % Co);
+    size_t q = i / Co;
+    const int wo = (int)(q % (2 * W)); q /= (size_t)2 * W;
+    const int ho = (int)(q % (2 * H));
+    const size_t n = q / ((size_t)2 * H);
+    const float* xp = x + ((n * H + ho / 2) * W + wo / 2) * Ci;
+    const float* wp = w + ((size_t)((ho & 1) * 2 + (wo & 1)) * Ci) * Co + o;
+    float acc = b ? b[o] : 0.f;
+    for (int c = 0; c < Ci; ++c) acc = fmaf(xp[c], wp[(size_t)c * Co], acc);
+    y[i] = acc;
+}
+
+__global__ void pad_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int C, int top, int left,
+                                int Ho, int Wo, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    size_t q = i / C;
+    const int wo = (int)(q % Wo); q /= Wo;
+    const int ho = (int)(q % Ho);
+    const size_t n = q / Ho;
+    const int h = ho - top, w = wo - left;
+    y[i] = (h >= 0 && h < H && w >= 0 && w < W) ? x[((n * H + h) * W + w) * C + c] : 0.f;
+}
+
+// op 0: a + b, 1: a * b, 2: clamp(a, lo, hi); b may have 1 channel (broadcast) or C channels
+__global__ void eltwise_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, int C, int Cb,
+                               int op, float lo, float hi, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    if (op == 3) { y[i] = a[(i / C) * (C + 1) + (i % C)] * b[i / C]; return; }
+    const float va = a[i];
+    float vb = 0.f;
+    if (b) vb = (Cb == C) ? b[i] : b[i / C];
+    y[i] = op == 0 ? va + vb : (op == 1 ? va * vb : fminf(fmaxf(va, lo), hi));
+}
+
+// RetinexNet DecomNet input (mon_extra/.../retinexnet/model.py:45-46): [max_c(x), x] -> 4 channels
+__global__ void max_concat_kernel(const float* __restrict__ x, float* __restrict__ y, int C, size_t npix) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    const float* p = x + i * C;
+    float m = p[0];
+    for (int c = 1; c < C; ++c) m = fmaxf(m, p[c]);
+    float* q = y + i * (C + 1);
+    q[0] = m;
+    for (int c = 0; c < C; ++c) q[c + 1] = p[c];
+}
+
+inline unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }
+
+}  // namespace
+
+IE_EXPORT int ie_convn_nhwc_f32(ie_convn_desc* d, const float* const* srcs, const int* cs, const float* w, const float* bias,
+                                const float* residual, float* dst, void* stream) {
+    if (!d || !srcs || !cs || !w || !dst) IE_FAIL(IE_ERR_INVALID, "ie_convn_nhwc_f32: null pointer");
+    if (d->nsrc < 1 || d->nsrc > MAXS) IE_FAIL(IE_ERR_INVALID, "ie_convn_nhwc_f32: nsrc=%d not in 1..%d", d->nsrc, MAXS);
+    if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->Cout <= 0 || d->kh <= 0 || d->kw <= 0 || d->stride <= 0 || d->pad < 0)
+        IE_FAIL(IE_ERR_INVALID, "ie_convn_nhwc_f32: bad shape");
+    ConvNParams p;
+    p.Cin = 0;
+    for (int s = 0; s < MAXS; ++s) { p.src[s] = nullptr; p.cs[s] = 0; }
+    for (int s = 0; s < d->nsrc; ++s) {
+        if (!srcs[s] || cs[s] <= 0) IE_FAIL(IE_ERR_INVALID, "ie_convn_nhwc_f32: source %d invalid", s);
+        p.src[s] = srcs[s]; p.cs[s] = cs[s]; p.Cin += cs[s];
+    }
+    d->Ho = (d->H + 2 * d->pad - d->kh) / d->stride + 1;
+    d->Wo = (d->W + 2 * d->pad - d->kw) / d->stride + 1;
+    if (d->Ho <= 0 || d->Wo <= 0) IE_FAIL(IE_ERR_INVALID, "ie_convn_nhwc_f32: empty output");
+    p.nsrc = d->nsrc; p.w = w; p.bias = bias; p.res = residual; p.dst = dst;
+    p.N = d->N; p.H = d->H; p.W = d->W; p.Cout = d->Cout; p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad = d->pad;
+    p.pad_mode = d->pad_mode; p.act = d->act; p.Ho = d->Ho; p.Wo = d->Wo; p.slope = d->slope;
+    p.clamp = d->clamp; p.lo = d->clamp_lo; p.hi = d->clamp_hi;
+    dim3 grid(ie_cdiv(d->Ho * d->Wo, 64), ie_cdiv(d->Cout, 4 * CT), d->N);
+    hipLaunchKernelGGL(convn_direct_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    IE_LAUNCH_CHECK();
+    return IE_OK;
+}
+
+IE_EXPORT int ie_instnorm_nhwc_f32(const float* x, const float* gamma, const float* beta, float* y, double* stats_ws, int N,
+                                   int H, int W, int C, int c_begin, int c_count, float eps, int act, float slope, void* stream) {
+    if (!x || !y || !stats_ws || N <= 0 || H <= 0 || W <= 0 || C <= 0 || c_begin < 0 || c_count <= 0 || c_begin + c_count > C ||
+        (gamma == nullptr) != (beta == nullptr))
+        IE_FAIL(IE_ERR_INVALID, "ie_instnorm_nhwc_f32: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    const int HW = H * W;
+    IE_HIP_CHECK(hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * (size_t)N * c_count, st));
+    for (int off = 0; off < c_count; off += 256) {     // <= 256 channels per launch (one thread column each)
+        const int cn = (c_count - off) < 256 ? (c_count - off) : 256;
+        const int tpc = 256 / cn > 0 ? 256 / cn : 1;
+        int chunks = ie_cdiv(HW, tpc * 64);
+        if (chunks > 1024) chunks = 1024;
+        if (chunks < 1) chunks = 1;
+        hipLaunchKernelGGL(instnorm_stats_kernel, dim3(chunks, N), dim3(256), 0, st, x, stats_ws, HW, C, c_begin + off, cn, c_count, off);
+        IE_LAUNCH_CHECK();
+    }
+    const size_t total = (size_t)N * HW * C;
+    hipLaunchKernelGGL(instnorm_apply_kernel, dim3(nblk(total)), dim3(256), 0, st, x, stats_ws, gamma, beta, y, HW, C, c_begin,
+                       c_count, eps, act, slope, total);
+    IE_LAUNCH_CHECK();
+    return IE_OK;
+}
+
+IE_EXPORT int ie_maxpool2x2_nhwc_f32(const float* x, float* y, int N, int H, int W, int C, void* stream) {
+    if (!x || !y || N <= 0 || H < 2 || W < 2 || C <= 0) IE_FAIL(IE_ERR_INVALID, "ie_maxpool2x2_nhwc_f32: bad args");
+    const int Ho = H / 2, Wo = W / 2;
+    const size_t total = (size_t)N * Ho * Wo * C;
+    hipLaunchKernelGGL(maxpool2_kernel, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, x, y, H, W, C, Ho, Wo, total);
+    IE_LAUNCH_CHECK();
+    return IE_OK;
+}
+
+IE_EXPORT int ie_resize_nhwc_f32(const float* x, float* y, int N, int Hi, int Wi, int C, int Ho, int Wo, int mode, void* stream) {
+    if (!x || !y || N <= 0 || Hi <= 0 || Wi <= 0 || C <= 0 || Ho <= 0 || Wo <= 0 || mode < 0 || mode > 2)
+        IE_FAIL(IE_ERR_INVALID, "ie_resize_nhwc_f32: bad args");
+    const size_t total = (size_t)N * Ho * Wo * C;
+    hipLaunchKernelGGL(resize_nhwc_kernel, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, x, y, Hi, Wi, C, Ho, Wo, mode, total);
+    IE_LAUNCH_CHECK();
+    return IE_OK;
+}
+
+IE_EXPORT int ie_pixel_shuffle_nhwc_f32(const float* x, float* y, int N, int H, int W, int Cout, int r, void* stream) {
+    if (!x || !y || N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || r <= 0) IE_FAIL(IE_ERR_INVALID, "ie_pixel_shuffle_nhwc_f32: bad args");
+    const size_t total = (size_t)N * H * r * W * r * Cout;
+    hipLaunchKernelGGL(pixel_shuffle_kernel, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, x, y, H, W, Cout, r, total);
+    IE_LAUNCH_CHECK();
+    return IE_OK;
+}
+
+IE_EXPORT int ie_conv_transpose2x2_nhwc_f32(const float* x, const float* w_ijco, const float* bias, float* y, int N, int H, int W,
+                                            int Cin, int Cout, void* stream) {
+    if (!x || !w_ijco || !y || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) IE_FAIL(IE_ERR_INVALID, "ie_conv_transpose2x2_nhwc_f32: bad args");
+    const size_t total = (size_t)N * 2 * H * 2 * W * Cout;
+    hipLaunchKernelGGL(convT2x2_kernel, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, x, w_ijco, bias, y, H, W, Cin, Cout, total);
+    IE_LAUNCH_CHECK();
+    return IE_OK;
+}
+
+IE_EXPORT int ie_pad_nhwc_f32(const float* x, float* y, int N, int H, int W, int C, int top, int bottom, int left, int right, void* stream) {
+    if (!x || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || top < 0 || bottom < 0 || left < 0 || right < 0)
+        IE_FAIL(IE_ERR_INVALID, "ie_pad_nhwc_f32: bad args");
+    const int Ho = H + top + bottom, Wo = W + left + right;
+    const size_t total = (size_t)N * Ho * Wo * C;
+    hipLaunchKernelGGL(pad_nhwc_kernel, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, x, y, H, W, C, top, left, Ho, Wo, total);
+    IE_LAUNCH_CHECK();
+    return IE_OK;
+}
+
+IE_EXPORT int ie_eltwise_nhwc_f32(int op, const float* a, const float* b, float* y, size_t npix, int C, int Cb, float lo, float hi, void* stream) {
+    if (!a || !y || npix == 0 || C <= 0 || op < 0 || op > 3 || (op != 2 && (!b || (Cb != C && Cb != 1))) || (op == 3 && Cb != 1))
+        IE_FAIL(IE_ERR_INVALID, "ie_eltwise_nhwc_f32: bad args");
+    const size_t total = npix * C;
+    hipLaunchKernelGGL(eltwise_kernel, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, a, b, y, C, Cb, op, lo, hi, total);
+    IE_LAUNCH_CHECK();
+    return IE_OK;
+}
+
+IE_EXPORT int ie_max_concat_nhwc_f32(const float* x, float* y, size_t npix, int C, void* stream) {
+    if (!x || !y || npix == 0 || C <= 0) IE_FAIL(IE_ERR_INVALID, "ie_max_concat_nhwc_f32: bad args");
+    hipLaunchKernelGGL(max_concat_kernel, dim3(nblk(npix)), dim3(256), 0, (hipStream_t)stream, x, y, C, npix);
+    IE_LAUNCH_CHECK();
+    return IE_OK;
+}

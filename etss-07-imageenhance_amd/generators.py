@@ -1,0 +1,500 @@
+"""The other generators of the hot path on the fp32 NHWC building blocks (``ops.py`` -> ``libie_hip.so``):
+
+  zero_dce++_re   ZeroDCEpp_RE   src/mon/vision/enhance/llie/zero_dce/zero_dcepp.py:86-208 (DSConv2d: nn/modules/conv/dsconv.py:106-149)
+  llunet++_re     LLUnetpp_RE    src/mon/vision/enhance/llie/llunetpp/llunetpp.py:97-243
+  unet            UNet           src/mon/vision/segment/unet/unet.py:35-197  (+ ``upsampler="pixelshuffle"``: nn/modules/encoder/edsr.py:88-123)
+  zero_ig_enhance Enhance        src/mon/vision/enhance/llie/zero_ig/zero_ig.py:307-348
+  retinexnet      RetinexNet     src/mon_extra/vision/enhance/llie/retinexnet/model.py:21-90, 199-238
+
+Same registry names, constructor hyper-parameters, checkpoint key names and output dicts as the reference
+classes; the arithmetic runs in the library's kernels (no torch ops on the data path; torch only
+allocates).  This is the parity path (fp32, VALU conv); the MFMA path exists for Zero-DCE only so far.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import Any
+
+import torch
+
+from . import capi, ops
+from .globals_ import Scheme, Task
+from .model import ImageEnhancementModel
+from .registry import MODELS
+
+
+class _GraphModel(ImageEnhancementModel):
+    """Host fp32 parameters + per-device repacked weights, rebuilt lazily."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._dev_cache = None
+
+    def _on_params_change(self):
+        self._dev_cache = None
+
+    def _on_device_change(self):
+        self._dev_cache = None
+
+    def _require_cuda(self):
+        if self.device.type != "cuda":
+            raise capi.IEError(f"{self.__class__.__name__} runs on the HIP device only (model.device = {self.device}); "
+                               f"call .to('cuda').  There is no CPU execution path in this engine.")
+
+    # torch.nn.Conv2d default init: kaiming_uniform(a=sqrt(5)) == U(+-1/sqrt(fan_in)) for weight and bias
+    def _init_conv(self, name: str, g: torch.Generator, std: float | None = None, bias: bool = True, zero_bias=False):
+        w = self._params[f"{name}.weight"]
+        fan_in = w.shape[1] * w.shape[2] * w.shape[3]
+        bound = 1.0 / math.sqrt(fan_in)
+        if std is None:
+            self._params[f"{name}.weight"] = (torch.rand(w.shape, generator=g) * 2 - 1) * bound
+        else:
+            self._params[f"{name}.weight"] = torch.randn(w.shape, generator=g) * std
+        if bias and f"{name}.bias" in self._params:
+            b = self._params[f"{name}.bias"]
+            self._params[f"{name}.bias"] = torch.zeros_like(b) if zero_bias else (torch.rand(b.shape, generator=g) * 2 - 1) * bound
+
+    def _gen(self, seed):
+        g = torch.Generator()
+        g.manual_seed(int(seed)) if seed is not None else g.seed()
+        return g
+
+    def _cw(self, name: str, bn: str | None = None) -> ops.ConvWeights:
+        """ConvWeights of conv ``name`` (optionally with eval-mode BatchNorm ``bn`` folded in), cached per device."""
+        if self._dev_cache is None:
+            self._dev_cache = {}
+        key = (name, bn)
+        if key not in self._dev_cache:
+            w = self._params[f"{name}.weight"]
+            b = self._params.get(f"{name}.bias")
+            if bn is not None:
+                w, b = ops.fold_bn(w, b, self._params[f"{bn}.weight"], self._params[f"{bn}.bias"],
+                                   self._params[f"{bn}.running_mean"], self._params[f"{bn}.running_var"])
+            self._dev_cache[key] = ops.ConvWeights(w, b, self.device)
+        return self._dev_cache[key]
+
+    def _vec(self, name: str) -> torch.Tensor:
+        if self._dev_cache is None:
+            self._dev_cache = {}
+        if name not in self._dev_cache:
+            self._dev_cache[name] = self._params[name].to(self.device, torch.float32).contiguous()
+        return self._dev_cache[name]
+
+    def _input(self, datapoint: dict) -> torch.Tensor:
+        self.assert_datapoint(datapoint)
+        self._require_cuda()
+        x = datapoint.get("image")
+        if x.dim() == 3:
+            x = x[None]
+        if x.dim() != 4 or x.shape[1] != self.in_channels:
+            raise ValueError(f"`image` must be (N,{self.in_channels},H,W), but got {tuple(x.shape)}.")
+        return ops.to_nhwc(x.to(self.device, torch.float32))
+
+    def _finish_init(self, seed):
+        has_tensor_weights = isinstance(self.weights, dict) and any(k.endswith(".weight") for k in self.weights)
+        if self.weights and (not isinstance(self.weights, dict) or "path" in self.weights or has_tensor_weights):
+            self.load_weights()
+        else:
+            self.init_weights(seed)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+@MODELS.register(name="zero_dce++_re", arch="zero_dce")
+class ZeroDCEpp_RE(_GraphModel):
+    """zero_dcepp.py:86-208.  DSConv2d = depthwise 3x3 (bias) then pointwise 1x1 (bias), state_dict keys
+    ``e_conv{k}.dw_conv.*`` / ``e_conv{k}.pw_conv.*`` (dsconv.py:122-143); the original repo's
+    ``depth_conv`` / ``point_conv`` spellings (zero_dce++/model.py:10-25) are accepted too."""
+
+    arch = "zero_dce"
+    tasks = [Task.LLIE]
+    schemes = [Scheme.UNSUPERVISED, Scheme.ZERO_REFERENCE]
+
+    def __init__(self, in_channels: int = 3, num_channels: int = 32, num_iters: int = 8, scale_factor: float = 1.0,
+                 weights: Any = None, seed: int = None, *args, **kwargs):
+        kwargs.pop("name", None)
+        super().__init__(name="zero_dce++_re", in_channels=in_channels, weights=weights, *args, **kwargs)
+        if isinstance(self.weights, dict):
+            in_channels = self.weights.get("in_channels", in_channels)
+            num_channels = self.weights.get("num_channels", num_channels)
+            num_iters = self.weights.get("num_iters", num_iters)
+            scale_factor = self.weights.get("scale_factor", scale_factor)
+        self.in_channels, self.num_channels, self.num_iters, self.scale_factor = in_channels, num_channels, num_iters, scale_factor
+        c = num_channels
+        for k, (ci, co) in enumerate([(in_channels, c), (c, c), (c, c), (c, c), (2 * c, c), (2 * c, c), (2 * c, self.out_channels)], 1):
+            self._params[f"e_conv{k}.dw_conv.weight"] = torch.zeros(ci, 1, 3, 3)
+            self._params[f"e_conv{k}.dw_conv.bias"] = torch.zeros(ci)
+            self._params[f"e_conv{k}.pw_conv.weight"] = torch.zeros(co, ci, 1, 1)
+            self._params[f"e_conv{k}.pw_conv.bias"] = torch.zeros(co)
+        self._finish_init(seed)
+
+    def map_key(self, k: str) -> str:
+        return k.replace(".depth_conv.", ".dw_conv.").replace(".point_conv.", ".pw_conv.")
+
+    def init_weights(self, seed: int = None):
+        g = self._gen(seed)
+        for k in range(1, 8):          # zero_dcepp.py:152-163: conv weights ~ N(0, 0.02)
+            self._init_conv(f"e_conv{k}.dw_conv", g, std=0.02)
+            self._init_conv(f"e_conv{k}.pw_conv", g, std=0.02)
+        self._on_params_change()
+
+    def _ds(self, k, srcs, act):
+        # depthwise over the concat == depthwise per source with the matching weight slice
+        outs, off = [], 0
+        for s in srcs:
+            c = s.shape[1]
+            key = ("dw", k, off)
+            if self._dev_cache is None:
+                self._dev_cache = {}
+            if key not in self._dev_cache:
+                self._dev_cache[key] = ops.ConvWeights(self._params[f"e_conv{k}.dw_conv.weight"][off:off + c],
+                                                       self._params[f"e_conv{k}.dw_conv.bias"][off:off + c], self.device)
+            outs.append(ops.depthwise_conv2d(s, self._dev_cache[key]))
+            off += c
+        return ops.conv2d(outs, self._cw(f"e_conv{k}.pw_conv"), pad=0, act=act)
+
+    def forward(self, datapoint: dict, *args, **kwargs) -> dict:
+        x = self._input(datapoint)
+        xd = x
+        if self.scale_factor != 1:
+            h, w = x.shape[2], x.shape[3]
+            # F.interpolate(scale_factor=1/s, mode="bilinear"): out = floor(in * (1/s)), align_corners=False
+            xd = ops.resize(x, (int(math.floor(h * (1 / self.scale_factor))), int(math.floor(w * (1 / self.scale_factor)))), "bilinear")
+        x1 = self._ds(1, [xd], "relu")
+        x2 = self._ds(2, [x1], "relu")
+        x3 = self._ds(3, [x2], "relu")
+        x4 = self._ds(4, [x3], "relu")
+        x5 = self._ds(5, [x3, x4], "relu")
+        x6 = self._ds(6, [x2, x5], "relu")
+        xr = self._ds(7, [x1, x6], "tanh")
+        if self.scale_factor != 1:
+            # nn.UpsamplingBilinear2d(scale_factor): align_corners=True, out = floor(in * s)
+            xr = ops.resize(xr, (int(math.floor(xr.shape[2] * self.scale_factor)), int(math.floor(xr.shape[3] * self.scale_factor))),
+                            "bilinear_align")
+        n, _, h, w = x.shape
+        # the curve with one shared 3-channel map for all iterations (zero_dcepp.py:201-203)
+        y = torch.empty((n, 3, h, w), device=x.device, dtype=torch.float32)
+        xin = ops.to_nchw(x)
+        with torch.cuda.device(x.device):
+            capi.check(capi.lib().ie_le_curve(capi.ptr(xin), capi.ptr(xr), 3, capi.ptr(y), n, h, w, self.num_iters,
+                                              capi.current_stream()), "ie_le_curve")
+        return OrderedDict(adjust=ops.to_nchw(xr), enhanced=y)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+@MODELS.register(name="llunet++_re", arch="llunet++")
+class LLUnetpp_RE(_GraphModel):
+    """llunetpp.py:144-243; block llunetpp.py:97-137.  Checkpoint keys per block ``conv1, norm1, conv2, conv3,
+    conv1_2, conv2_3`` (mon) or ``conv_1, norm1, conv_2, conv_3, conv_1_1_1, conv_1_1`` (original,
+    llunet++/model.py:9-20); ``loss.*`` ignored."""
+
+    arch = "llunet++"
+    tasks = [Task.LLIE]
+    schemes = [Scheme.SUPERVISED]
+    _BLOCKS = ["conv0_0", "conv1_0", "conv2_0", "conv3_0", "conv4_0", "conv0_1", "conv1_1", "conv2_1", "conv3_1",
+               "conv0_2", "conv1_2", "conv2_2", "conv0_3", "conv1_3", "conv0_4"]
+
+    def __init__(self, in_channels: int = 3, weights: Any = None, loss_weights=None, seed: int = None, *args, **kwargs):
+        kwargs.pop("name", None)
+        super().__init__(name="llunet++_re", in_channels=in_channels, weights=weights, *args, **kwargs)
+        if isinstance(self.weights, dict):
+            in_channels = self.weights.get("in_channels", in_channels)
+        self.in_channels = in_channels
+        self.predicting = True     # inference engine: no ref_image needed
+        f = [32, 64, 128, 256, 512]
+        io = {"conv0_0": (in_channels, f[0]), "conv1_0": (f[0], f[1]), "conv2_0": (f[1], f[2]), "conv3_0": (f[2], f[3]),
+              "conv4_0": (f[3], f[4]), "conv0_1": (f[0] + f[1], f[0]), "conv1_1": (f[1] + f[2], f[1]), "conv2_1": (f[2] + f[3], f[2]),
+              "conv3_1": (f[3] + f[4], f[3]), "conv0_2": (f[0] * 2 + f[1], f[0]), "conv1_2": (f[1] * 2 + f[2], f[1]),
+              "conv2_2": (f[2] * 2 + f[3], f[2]), "conv0_3": (f[0] * 3 + f[1], f[0]), "conv1_3": (f[1] * 3 + f[2], f[1]),
+              "conv0_4": (f[0] * 4 + f[1], f[0])}
+        self._io = io
+        for b in self._BLOCKS:
+            ci, co = io[b]
+            P = self._params
+            P[f"{b}.conv1.weight"], P[f"{b}.conv1.bias"] = torch.zeros(ci, ci, 3, 3), torch.zeros(ci)
+            P[f"{b}.norm1.weight"], P[f"{b}.norm1.bias"] = torch.ones(ci), torch.zeros(ci)
+            P[f"{b}.conv2.weight"], P[f"{b}.conv2.bias"] = torch.zeros(co, 2 * ci, 3, 3), torch.zeros(co)
+            P[f"{b}.conv3.weight"], P[f"{b}.conv3.bias"] = torch.zeros(co, co, 3, 3), torch.zeros(co)
+            P[f"{b}.conv1_2.weight"], P[f"{b}.conv1_2.bias"] = torch.zeros(ci, ci, 1, 1), torch.zeros(ci)
+            P[f"{b}.conv2_3.weight"], P[f"{b}.conv2_3.bias"] = torch.zeros(co, 2 * ci, 1, 1), torch.zeros(co)
+        self._params["final.weight"], self._params["final.bias"] = torch.zeros(self.out_channels, f[0], 1, 1), torch.zeros(self.out_channels)
+        self._finish_init(seed)
+
+    def map_key(self, k: str) -> str:
+        for a, b in ((".conv_1_1_1.", ".conv1_2."), (".conv_1_1.", ".conv2_3."), (".conv_1.", ".conv1."), (".conv_2.", ".conv2."),
+                     (".conv_3.", ".conv3.")):
+            k = k.replace(a, b)
+        return k
+
+    def init_weights(self, seed: int = None):
+        g = self._gen(seed)
+        for b in self._BLOCKS:
+            for c in ("conv1", "conv2", "conv3", "conv1_2", "conv2_3"):
+                self._init_conv(f"{b}.{c}", g)
+        self._init_conv("final", g)
+        self._on_params_change()
+
+    def _block(self, b: str, srcs):
+        x12 = ops.conv2d(srcs, self._cw(f"{b}.conv1_2"), pad=0)
+        x1 = ops.conv2d(srcs, self._cw(f"{b}.conv1"))
+        x1 = ops.instance_norm(x1, self._vec(f"{b}.norm1.weight"), self._vec(f"{b}.norm1.bias"), 1e-5, "lrelu", 0.2)
+        x23 = ops.conv2d([x1, x12], self._cw(f"{b}.conv2_3"), pad=0)
+        x2 = ops.conv2d([x1, x12], self._cw(f"{b}.conv2"), act="lrelu", slope=0.2)
+        return ops.conv2d(x2, self._cw(f"{b}.conv3"), act="lrelu", slope=0.2, residual=x23)
+
+    def forward(self, datapoint: dict, *args, **kwargs) -> dict:
+        x = self._input(datapoint)
+        if x.shape[2] % 16 or x.shape[3] % 16:
+            raise ValueError(f"LLUnet++ needs H and W divisible by 16 (got {x.shape[2]}x{x.shape[3]}); use infer(), which "
+                             f"resizes to a multiple of 32 like the reference (vision/model.py:106).")
+        B, up, pool = self._block, ops.upsample2x_bilinear, ops.maxpool2x2
+        x0_0 = B("conv0_0", [x])
+        x1_0 = B("conv1_0", [pool(x0_0)])
+        x0_1 = B("conv0_1", [x0_0, up(x1_0)])
+        x2_0 = B("conv2_0", [pool(x1_0)])
+        x1_1 = B("conv1_1", [x1_0, up(x2_0)])
+        x0_2 = B("conv0_2", [x0_0, x0_1, up(x1_1)])
+        x3_0 = B("conv3_0", [pool(x2_0)])
+        x2_1 = B("conv2_1", [x2_0, up(x3_0)])
+        x1_2 = B("conv1_2", [x1_0, x1_1, up(x2_1)])
+        x0_3 = B("conv0_3", [x0_0, x0_1, x0_2, up(x1_2)])
+        x4_0 = B("conv4_0", [pool(x3_0)])
+        x3_1 = B("conv3_1", [x3_0, up(x4_0)])
+        x2_2 = B("conv2_2", [x2_0, x2_1, up(x3_1)])
+        x1_3 = B("conv1_3", [x1_0, x1_1, x1_2, up(x2_2)])
+        x0_4 = B("conv0_4", [x0_0, x0_1, x0_2, x0_3, up(x1_3)])
+        y = ops.conv2d(x0_4, self._cw("final"), pad=0, clamp=(0.0, 1.0))
+        return OrderedDict(enhanced=ops.to_nchw(y))
+
+
+# ----------------------------------------------------------------------------------------------------------------
+@MODELS.register(name="unet", arch="unet")
+class UNet(_GraphModel):
+    """unet.py:115-197 with its intended semantics (line 51's ``self.con1`` is a typo for ``conv1``): (Conv3x3 no-bias ->
+    BatchNorm2d -> ReLU) x 2 blocks, MaxPool2d(2), bilinear x2 (align_corners=True) + zero pad + cat([skip, up]),
+    1x1 ``outc``.  BatchNorm runs in eval mode (running statistics) folded into the conv weights.
+
+    Engine extras (BASELINE config 3/5): ``base_channels`` (64 -> U-Net-64, 32 -> U-Net-32), ``upsampler``
+    ``"bilinear"`` (reference) or ``"pixelshuffle"`` (conv3x3(C -> 4*C/2... ) + PixelShuffle(2), edsr.py:88-123),
+    ``enhance=True`` returns ``enhanced = clamp(outc, 0, 1)`` (llunetpp.py:241-242) instead of ``semantic``."""
+
+    arch = "unet"
+    tasks = [Task.SEGMENT, Task.LLIE]
+    schemes = [Scheme.SUPERVISED]
+
+    def __init__(self, in_channels: int = 3, num_classes: int = 34, weights: Any = None, base_channels: int = 64,
+                 upsampler: str = "bilinear", enhance: bool = False, seed: int = None, *args, **kwargs):
+        kwargs.pop("name", None)
+        super().__init__(name="unet", in_channels=in_channels, num_classes=num_classes, weights=weights, *args, **kwargs)
+        if isinstance(self.weights, dict):
+            in_channels = self.weights.get("in_channels", in_channels)
+            num_classes = self.weights.get("num_classes", num_classes)
+        if upsampler not in ("bilinear", "pixelshuffle"):
+            raise ValueError(f"`upsampler` must be 'bilinear' or 'pixelshuffle', but got {upsampler}.")
+        self.in_channels, self.out_channels = in_channels, num_classes
+        self.base_channels, self.upsampler, self.enhance = base_channels, upsampler, enhance
+        self.predicting = True
+        f = [base_channels * m for m in (1, 2, 4, 8, 16)]
+        self._f = f
+
+        def dc(name, ci, co, mid=None):
+            mid = mid or co
+            P = self._params
+            P[f"{name}.conv1.weight"] = torch.zeros(mid, ci, 3, 3)
+            P[f"{name}.conv2.weight"] = torch.zeros(co, mid, 3, 3)
+            for nm, c in (("norm1", mid), ("norm2", co)):
+                P[f"{name}.{nm}.weight"], P[f"{name}.{nm}.bias"] = torch.ones(c), torch.zeros(c)
+                P[f"{name}.{nm}.running_mean"], P[f"{name}.{nm}.running_var"] = torch.zeros(c), torch.ones(c)
+
+        dc("inc", in_channels, f[0])
+        dc("down1.conv", f[0], f[1]); dc("down2.conv", f[1], f[2]); dc("down3.conv", f[2], f[3]); dc("down4.conv", f[3], f[4] // 2)
+        dc("up1.conv", f[4], f[3] // 2, f[4] // 2); dc("up2.conv", f[3], f[2] // 2, f[3] // 2)
+        dc("up3.conv", f[2], f[1] // 2, f[2] // 2); dc("up4.conv", f[1], f[0], f[1] // 2)
+        if upsampler == "pixelshuffle":       # Upsampler(scale 2): conv3x3(C -> 4C) + PixelShuffle(2), per decoder level
+            for k, c in zip((1, 2, 3, 4), (f[4] // 2, f[3] // 2, f[2] // 2, f[1] // 2)):
+                self._params[f"up{k}.up.0.weight"] = torch.zeros(4 * c, c, 3, 3)
+                self._params[f"up{k}.up.0.bias"] = torch.zeros(4 * c)
+        self._params["outc.conv.weight"], self._params["outc.conv.bias"] = torch.zeros(num_classes, f[0], 1, 1), torch.zeros(num_classes)
+        self._finish_init(seed)
+
+    def load_state_dict(self, state_dict: dict, strict: bool = True):
+        sd = {k: v for k, v in state_dict.items() if not k.endswith("num_batches_tracked")}
+        super().load_state_dict(sd, strict)
+
+    def init_weights(self, seed: int = None):
+        g = self._gen(seed)
+        for k in list(self._params):
+            if k.endswith(".weight") and self._params[k].dim() == 4:
+                self._init_conv(k[:-7], g)
+            elif k.endswith("running_mean"):      # seeded non-trivial BN statistics so that eval-mode BN is exercised
+                self._params[k] = torch.randn(self._params[k].shape, generator=g) * 0.1
+            elif k.endswith("running_var"):
+                self._params[k] = torch.rand(self._params[k].shape, generator=g) + 0.5
+            elif ".norm" in k and k.endswith(".weight"):
+                self._params[k] = 1.0 + torch.randn(self._params[k].shape, generator=g) * 0.02
+        self._on_params_change()
+
+    def _dc(self, name, srcs):
+        x = ops.conv2d(srcs, self._cw(f"{name}.conv1", f"{name}.norm1"), act="relu")
+        return ops.conv2d(x, self._cw(f"{name}.conv2", f"{name}.norm2"), act="relu")
+
+    def _up(self, k, x1, x2):
+        if self.upsampler == "bilinear":
+            x1 = ops.upsample2x_bilinear(x1)
+        else:
+            x1 = ops.pixel_shuffle(ops.conv2d(x1, self._cw(f"up{k}.up.0")), 2)
+        dy, dx = x2.shape[2] - x1.shape[2], x2.shape[3] - x1.shape[3]
+        x1 = ops.pad(x1, dy // 2, dy - dy // 2, dx // 2, dx - dx // 2)
+        return self._dc(f"up{k}.conv", [x2, x1])
+
+    def forward(self, datapoint: dict, *args, **kwargs) -> dict:
+        x = self._input(datapoint)
+        x1 = self._dc("inc", [x])
+        x2 = self._dc("down1.conv", [ops.maxpool2x2(x1)])
+        x3 = self._dc("down2.conv", [ops.maxpool2x2(x2)])
+        x4 = self._dc("down3.conv", [ops.maxpool2x2(x3)])
+        x5 = self._dc("down4.conv", [ops.maxpool2x2(x4)])
+        y = self._up(1, x5, x4)
+        y = self._up(2, y, x3)
+        y = self._up(3, y, x2)
+        y = self._up(4, y, x1)
+        y = ops.conv2d(y, self._cw("outc.conv"), pad=0, clamp=(0.0, 1.0) if self.enhance else None)
+        out = OrderedDict()
+        out["enhanced" if self.enhance else "semantic"] = ops.to_nchw(y)
+        return out
+
+    def assert_outputs(self, outputs: dict):
+        if not self.enhance:
+            return
+        super().assert_outputs(outputs)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+@MODELS.register(name="zero_ig_enhance", arch="zero_ig")
+class ZeroIGEnhance(_GraphModel):
+    """``Enhance`` of Zero-IG (zero_ig.py:307-348): Conv3x3+ReLU, ``layers`` x [fea + ReLU(BN(Conv3x3(fea)))] with ONE
+    shared block (zero_ig.py:324-326), Conv3x3+Sigmoid, clamp(1e-4, 1).  Keys ``in_conv.0.*``, ``conv.0.*``,
+    ``conv.1.*`` (BN), ``out_conv.0.*`` (``blocks.i.*`` aliases of the shared block are accepted)."""
+
+    arch = "zero_ig"
+    tasks = [Task.LLIE]
+    schemes = [Scheme.ZERO_SHOT]
+
+    def __init__(self, layers: int = 3, channels: int = 64, weights: Any = None, seed: int = None, *args, **kwargs):
+        kwargs.pop("name", None)
+        super().__init__(name="zero_ig_enhance", in_channels=3, weights=weights, *args, **kwargs)
+        self.layers, self.channels = layers, channels
+        P = self._params
+        P["in_conv.0.weight"], P["in_conv.0.bias"] = torch.zeros(channels, 3, 3, 3), torch.zeros(channels)
+        P["conv.0.weight"], P["conv.0.bias"] = torch.zeros(channels, channels, 3, 3), torch.zeros(channels)
+        P["conv.1.weight"], P["conv.1.bias"] = torch.ones(channels), torch.zeros(channels)
+        P["conv.1.running_mean"], P["conv.1.running_var"] = torch.zeros(channels), torch.ones(channels)
+        P["out_conv.0.weight"], P["out_conv.0.bias"] = torch.zeros(3, channels, 3, 3), torch.zeros(3)
+        self._finish_init(seed)
+
+    def load_state_dict(self, state_dict: dict, strict: bool = True):
+        sd = {k: v for k, v in state_dict.items() if not k.endswith("num_batches_tracked") and not k.startswith("blocks.")}
+        super().load_state_dict(sd, strict)
+
+    def init_weights(self, seed: int = None):
+        g = self._gen(seed)            # zero_ig.py:336-342: conv N(0, 0.02), bias 0, BN weight N(1, 0.02)
+        for n in ("in_conv.0", "conv.0", "out_conv.0"):
+            self._init_conv(n, g, std=0.02, zero_bias=True)
+        self._params["conv.1.weight"] = 1.0 + torch.randn(self.channels, generator=g) * 0.02
+        self._params["conv.1.running_mean"] = torch.randn(self.channels, generator=g) * 0.05
+        self._params["conv.1.running_var"] = torch.rand(self.channels, generator=g) + 0.5
+        self._on_params_change()
+
+    def forward(self, datapoint: dict, *args, **kwargs) -> dict:
+        x = self._input(datapoint)
+        fea = ops.conv2d(x, self._cw("in_conv.0"), act="relu")
+        for _ in range(self.layers):
+            fea = ops.conv2d(fea, self._cw("conv.0", "conv.1"), act="relu", residual=fea)
+        y = ops.conv2d(fea, self._cw("out_conv.0"), act="sigmoid", clamp=(0.0001, 1.0))
+        return OrderedDict(enhanced=ops.to_nchw(y))
+
+
+# ----------------------------------------------------------------------------------------------------------------
+@MODELS.register(name="retinexnet", arch="retinexnet")
+class RetinexNet(_GraphModel):
+    """DecomNet + RelightNet + ``S = R * I_delta`` (retinexnet/model.py:21-90, 199-238), single Decom pass.
+    Checkpoint keys ``net1_*`` (decom) and ``net2_*`` (relight); the reference stores them in two files
+    (``*_decom_*.tar`` / ``*_relight_*.tar``, model.py:455-465): pass ``weights={"decom": path, "relight": path}`` or
+    one merged state_dict."""
+
+    arch = "retinexnet"
+    tasks = [Task.LLIE]
+    schemes = [Scheme.SUPERVISED]
+
+    def __init__(self, channels: int = 64, weights: Any = None, seed: int = None, *args, **kwargs):
+        kwargs.pop("name", None)
+        two = isinstance(weights, dict) and "decom" in weights and "relight" in weights
+        super().__init__(name="retinexnet", in_channels=3, weights=None if two else weights, *args, **kwargs)
+        self.predicting = True
+        c = self.channels = channels
+        P = self._params
+        P["net1_conv0.weight"], P["net1_conv0.bias"] = torch.zeros(c, 4, 9, 9), torch.zeros(c)
+        for i in (0, 2, 4, 6, 8):
+            P[f"net1_convs.{i}.weight"], P[f"net1_convs.{i}.bias"] = torch.zeros(c, c, 3, 3), torch.zeros(c)
+        P["net1_recon.weight"], P["net1_recon.bias"] = torch.zeros(4, c, 3, 3), torch.zeros(4)
+        P["net2_conv0_1.weight"], P["net2_conv0_1.bias"] = torch.zeros(c, 4, 3, 3), torch.zeros(c)
+        for i in (1, 2, 3):
+            P[f"net2_conv1_{i}.weight"], P[f"net2_conv1_{i}.bias"] = torch.zeros(c, c, 3, 3), torch.zeros(c)
+            P[f"net2_deconv1_{i}.weight"], P[f"net2_deconv1_{i}.bias"] = torch.zeros(c, 2 * c, 3, 3), torch.zeros(c)
+        P["net2_fusion.weight"], P["net2_fusion.bias"] = torch.zeros(c, 3 * c, 1, 1), torch.zeros(c)
+        P["net2_output.weight"], P["net2_output.bias"] = torch.zeros(1, c, 3, 3), torch.zeros(1)
+        if two:
+            from .weights import read_state_dict
+            sd = dict(read_state_dict(weights["decom"]) if not isinstance(weights["decom"], dict) else weights["decom"])
+            sd.update(read_state_dict(weights["relight"]) if not isinstance(weights["relight"], dict) else weights["relight"])
+            self.load_state_dict(sd)
+        else:
+            self._finish_init(seed)
+
+    def map_key(self, k: str) -> str:
+        for pre in ("DecomNet.", "RelightNet."):
+            if k.startswith(pre):
+                k = k[len(pre):]
+        return k
+
+    def init_weights(self, seed: int = None):
+        g = self._gen(seed)
+        for k in list(self._params):
+            if k.endswith(".weight"):
+                self._init_conv(k[:-7], g)
+        self._on_params_change()
+
+    def decom(self, x):
+        R = "replicate"
+        f = ops.conv2d(ops.max_concat(x), self._cw("net1_conv0"), pad=4, pad_mode=R)
+        for i in (0, 2, 4, 6, 8):
+            f = ops.conv2d(f, self._cw(f"net1_convs.{i}"), pad_mode=R, act="relu")
+        return ops.conv2d(f, self._cw("net1_recon"), pad_mode=R, act="sigmoid")     # channels 0-2 = R, 3 = L
+
+    def relight(self, rl):
+        """rl: cat(R, L) == the 4-channel sigmoid output of DecomNet (model.py:72)."""
+        R = "replicate"
+        out0 = ops.conv2d(rl, self._cw("net2_conv0_1"), pad_mode=R)
+        out1 = ops.conv2d(out0, self._cw("net2_conv1_1"), stride=2, pad_mode=R, act="relu")
+        out2 = ops.conv2d(out1, self._cw("net2_conv1_2"), stride=2, pad_mode=R, act="relu")
+        out3 = ops.conv2d(out2, self._cw("net2_conv1_3"), stride=2, pad_mode=R, act="relu")
+        sz = lambda t: (t.shape[2], t.shape[3])
+        d1 = ops.conv2d([ops.resize(out3, sz(out2), "nearest"), out2], self._cw("net2_deconv1_1"), pad_mode=R, act="relu")
+        d2 = ops.conv2d([ops.resize(d1, sz(out1), "nearest"), out1], self._cw("net2_deconv1_2"), pad_mode=R, act="relu")
+        d3 = ops.conv2d([ops.resize(d2, sz(out0), "nearest"), out0], self._cw("net2_deconv1_3"), pad_mode=R, act="relu")
+        fus = ops.conv2d([ops.resize(d1, sz(rl), "nearest"), ops.resize(d2, sz(rl), "nearest"), d3], self._cw("net2_fusion"),
+                         pad=1, pad_mode=R)                                        # 1x1 with replicate padding 1: (H+2, W+2)
+        return ops.conv2d(fus, self._cw("net2_output"), pad=0)                      # 3x3 valid -> (H, W)
+
+    def forward(self, datapoint: dict, *args, **kwargs) -> dict:
+        x = self._input(datapoint)
+        rl = self.decom(x)
+        i_delta = self.relight(rl)
+        rl_nchw = ops.to_nchw(rl)
+        s = ops.mul_prefix(rl, i_delta)
+        out = OrderedDict()
+        out["reflectance"] = rl_nchw[:, 0:3]
+        out["illumination"] = rl_nchw[:, 3:4]
+        out["illumination_delta"] = ops.to_nchw(i_delta)
+        out["enhanced"] = ops.to_nchw(s)
+        return out

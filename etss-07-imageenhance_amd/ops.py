@@ -1,0 +1,247 @@
+"""Thin host wrappers over the fp32 NHWC building-block entry points of ``libie_hip.so``.
+
+Tensors are torch CUDA tensors of logical shape (N, C, H, W) in ``torch.channels_last`` memory
+format, i.e. physically NHWC -- the layout every kernel of the library works in.  torch is the
+container (allocation, stream); each function below is one C-ABI call.  The reference equivalents are
+the ``mon.nn`` aliases of ``torch.nn`` layers (src/mon/nn/modules/*); citations are in include/ie_hip.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import capi
+
+CL = torch.channels_last
+
+
+def _chk(t: torch.Tensor) -> torch.Tensor:
+    if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 4:
+        raise capi.IEError(f"expected a cuda float32 (N,C,H,W) tensor, got {tuple(t.shape)} {t.dtype} {t.device}")
+    if not t.is_contiguous(memory_format=CL):
+        raise capi.IEError("expected channels_last (NHWC) memory; use ops.to_nhwc()")
+    return t
+
+
+def empty_nhwc(n, c, h, w, device) -> torch.Tensor:
+    return torch.empty((n, c, h, w), device=device, dtype=torch.float32, memory_format=CL)
+
+
+def to_nhwc(x: torch.Tensor) -> torch.Tensor:
+    """NCHW-contiguous fp32 -> channels_last (ie_nchw_f32_to_nhwc)."""
+    x = x.to(torch.float32)
+    if x.dim() == 3:
+        x = x[None]
+    n, c, h, w = x.shape
+    if x.is_contiguous(memory_format=CL) and (c > 1 or not x.is_contiguous()):
+        return x
+    x = x.contiguous()
+    y = empty_nhwc(n, c, h, w, x.device)
+    with torch.cuda.device(x.device):
+        capi.check(capi.lib().ie_nchw_f32_to_nhwc(capi.ptr(x), capi.ptr(y), capi.IE_F32, n, c, h, w, c, capi.current_stream()),
+                   "ie_nchw_f32_to_nhwc")
+    return y
+
+
+def to_nchw(x: torch.Tensor) -> torch.Tensor:
+    """channels_last -> NCHW-contiguous fp32 (ie_nhwc_to_nchw_f32)."""
+    _chk(x)
+    n, c, h, w = x.shape
+    y = torch.empty((n, c, h, w), device=x.device, dtype=torch.float32)
+    with torch.cuda.device(x.device):
+        capi.check(capi.lib().ie_nhwc_to_nchw_f32(capi.ptr(x), capi.IE_F32, capi.ptr(y), n, c, h, w, c, capi.current_stream()),
+                   "ie_nhwc_to_nchw_f32")
+    return y
+
+
+class ConvWeights:
+    """Device-resident HWIO fp32 weights (+ bias) of one Conv2d, repacked once from the checkpoint's OIHW."""
+
+    def __init__(self, w_oihw: torch.Tensor, bias: torch.Tensor | None, device):
+        w = w_oihw.detach().to("cpu", torch.float32).contiguous()
+        self.cout, self.cin_g, self.kh, self.kw = w.shape
+        self.w = torch.empty(self.kh * self.kw * self.cin_g * self.cout, device=device, dtype=torch.float32)
+        with torch.cuda.device(device):
+            capi.check(capi.lib().ie_pack_weight_hwio_f32(capi.ptr(w), self.cout, self.cin_g, self.kh, self.kw, capi.ptr(self.w),
+                                                          capi.current_stream()), "ie_pack_weight_hwio_f32")
+        self.b = None if bias is None else bias.detach().to(device, torch.float32).contiguous()
+
+
+def fold_bn(w: torch.Tensor, b: torch.Tensor | None, gamma, beta, mean, var, eps: float = 1e-5):
+    """Eval-mode BatchNorm2d folded into the preceding conv: host-side, fp64."""
+    s = (gamma.double() / torch.sqrt(var.double() + eps))
+    w2 = (w.double() * s.view(-1, 1, 1, 1)).float()
+    b0 = torch.zeros_like(mean, dtype=torch.float64) if b is None else b.double()
+    b2 = ((b0 - mean.double()) * s + beta.double()).float()
+    return w2, b2
+
+
+def conv2d(srcs, cw: ConvWeights, stride=1, pad=1, pad_mode="zeros", act="none", slope=0.0, residual=None,
+           clamp=None) -> torch.Tensor:
+    """Conv2d over the channel concat of ``srcs`` (list of tensors or one tensor)."""
+    if isinstance(srcs, torch.Tensor):
+        srcs = [srcs]
+    for s in srcs:
+        _chk(s)
+    n, _, h, w = srcs[0].shape
+    cs = [int(s.shape[1]) for s in srcs]
+    if sum(cs) != cw.cin_g:
+        raise capi.IEError(f"conv2d: sources carry {sum(cs)} channels, weights expect {cw.cin_g}")
+    d = capi.ConvNDesc(n, h, w, len(srcs), cw.cout, cw.kh, cw.kw, stride, pad, capi.PAD[pad_mode], capi.ACT[act], slope,
+                       0 if clamp is None else 1, 0.0 if clamp is None else clamp[0], 0.0 if clamp is None else clamp[1], 0, 0)
+    ho = (h + 2 * pad - cw.kh) // stride + 1
+    wo = (w + 2 * pad - cw.kw) // stride + 1
+    out = empty_nhwc(n, cw.cout, ho, wo, srcs[0].device)
+    if residual is not None:
+        _chk(residual)
+        if tuple(residual.shape) != tuple(out.shape):
+            raise capi.IEError("conv2d: residual shape mismatch")
+    ptrs = (C.c_void_p * len(srcs))(*[s.data_ptr() for s in srcs])
+    chans = (C.c_int * len(srcs))(*cs)
+    with torch.cuda.device(out.device):
+        capi.check(capi.lib().ie_convn_nhwc_f32(C.byref(d), ptrs, chans, capi.ptr(cw.w), capi.ptr(cw.b), capi.ptr(residual),
+                                                capi.ptr(out), capi.current_stream()), "ie_convn_nhwc_f32")
+    return out
+
+
+def depthwise_conv2d(x, cw: ConvWeights, stride=1, pad=1, act="none") -> torch.Tensor:
+    _chk(x)
+    n, c, h, w = x.shape
+    d = capi.Conv2dDesc(n, h, w, c, 0, c, cw.kh, cw.kw, stride, pad, 0, c, capi.ACT[act], 0.0, 0, 0)
+    ho = (h + 2 * pad - cw.kh) // stride + 1
+    wo = (w + 2 * pad - cw.kw) // stride + 1
+    out = empty_nhwc(n, c, ho, wo, x.device)
+    with torch.cuda.device(x.device):
+        capi.check(capi.lib().ie_conv2d_nhwc_f32(C.byref(d), capi.ptr(x), None, capi.ptr(cw.w), capi.ptr(cw.b), capi.ptr(out),
+                                                 capi.current_stream()), "ie_conv2d_nhwc_f32(depthwise)")
+    return out
+
+
+def instance_norm(x, gamma=None, beta=None, eps=1e-5, act="none", slope=0.0, c_begin=0, c_count=None) -> torch.Tensor:
+    _chk(x)
+    n, c, h, w = x.shape
+    c_count = c - c_begin if c_count is None else c_count
+    y = torch.empty_like(x, memory_format=CL)
+    ws = torch.empty(2 * n * c_count, device=x.device, dtype=torch.float64)
+    with torch.cuda.device(x.device):
+        capi.check(capi.lib().ie_instnorm_nhwc_f32(capi.ptr(x), capi.ptr(gamma), capi.ptr(beta), capi.ptr(y), capi.ptr(ws), n, h, w,
+                                                   c, c_begin, c_count, eps, capi.ACT[act], slope, capi.current_stream()),
+                   "ie_instnorm_nhwc_f32")
+    return y
+
+
+def maxpool2x2(x) -> torch.Tensor:
+    _chk(x)
+    n, c, h, w = x.shape
+    y = empty_nhwc(n, c, h // 2, w // 2, x.device)
+    with torch.cuda.device(x.device):
+        capi.check(capi.lib().ie_maxpool2x2_nhwc_f32(capi.ptr(x), capi.ptr(y), n, h, w, c, capi.current_stream()), "ie_maxpool2x2_nhwc_f32")
+    return y
+
+
+_RESIZE = {"nearest": 0, "bilinear": 1, "bilinear_align": 2}
+
+
+def resize(x, size, mode="bilinear_align") -> torch.Tensor:
+    _chk(x)
+    n, c, h, w = x.shape
+    y = empty_nhwc(n, c, size[0], size[1], x.device)
+    with torch.cuda.device(x.device):
+        capi.check(capi.lib().ie_resize_nhwc_f32(capi.ptr(x), capi.ptr(y), n, h, w, c, size[0], size[1], _RESIZE[mode],
+                                                 capi.current_stream()), "ie_resize_nhwc_f32")
+    return y
+
+
+def upsample2x_bilinear(x) -> torch.Tensor:
+    return resize(x, (x.shape[2] * 2, x.shape[3] * 2), "bilinear_align")
+
+
+def pixel_shuffle(x, r=2) -> torch.Tensor:
+    _chk(x)
+    n, c, h, w = x.shape
+    co = c // (r * r)
+    y = empty_nhwc(n, co, h * r, w * r, x.device)
+    with torch.cuda.device(x.device):
+        capi.check(capi.lib().ie_pixel_shuffle_nhwc_f32(capi.ptr(x), capi.ptr(y), n, h, w, co, r, capi.current_stream()),
+                   "ie_pixel_shuffle_nhwc_f32")
+    return y
+
+
+class ConvT2x2Weights:
+    def __init__(self, w_iohw: torch.Tensor, bias, device):
+        w = w_iohw.detach().to(torch.float32)                 # (Cin, Cout, 2, 2)
+        self.cin, self.cout = w.shape[0], w.shape[1]
+        self.w = w.permute(2, 3, 0, 1).contiguous().to(device)   # [i][j][Cin][Cout]; host-side repack
+        self.b = None if bias is None else bias.detach().to(device, torch.float32).contiguous()
+
+
+def conv_transpose2x2(x, cw: ConvT2x2Weights) -> torch.Tensor:
+    _chk(x)
+    n, c, h, w = x.shape
+    y = empty_nhwc(n, cw.cout, 2 * h, 2 * w, x.device)
+    with torch.cuda.device(x.device):
+        capi.check(capi.lib().ie_conv_transpose2x2_nhwc_f32(capi.ptr(x), capi.ptr(cw.w), capi.ptr(cw.b), capi.ptr(y), n, h, w, c,
+                                                            cw.cout, capi.current_stream()), "ie_conv_transpose2x2_nhwc_f32")
+    return y
+
+
+def pad(x, top, bottom, left, right) -> torch.Tensor:
+    _chk(x)
+    if top == bottom == left == right == 0:
+        return x
+    n, c, h, w = x.shape
+    y = empty_nhwc(n, c, h + top + bottom, w + left + right, x.device)
+    with torch.cuda.device(x.device):
+        capi.check(capi.lib().ie_pad_nhwc_f32(capi.ptr(x), capi.ptr(y), n, h, w, c, top, bottom, left, right, capi.current_stream()),
+                   "ie_pad_nhwc_f32")
+    return y
+
+
+def _elt(op, a, b, lo=0.0, hi=0.0):
+    _chk(a)
+    n, c, h, w = a.shape
+    cb = c
+    if b is not None:
+        _chk(b)
+        cb = int(b.shape[1])
+    y = torch.empty_like(a, memory_format=CL)
+    with torch.cuda.device(a.device):
+        capi.check(capi.lib().ie_eltwise_nhwc_f32(op, capi.ptr(a), capi.ptr(b), capi.ptr(y), n * h * w, c, cb, lo, hi,
+                                                  capi.current_stream()), "ie_eltwise_nhwc_f32")
+    return y
+
+
+def add(a, b):
+    return _elt(0, a, b)
+
+
+def mul(a, b):
+    """a * b, where b has the same channels as a or a single channel (broadcast)."""
+    return _elt(1, a, b)
+
+
+def clamp(a, lo, hi):
+    return _elt(2, a, None, lo, hi)
+
+
+def mul_prefix(a, b) -> torch.Tensor:
+    """y = a[:, :C] * b for a with C+1 channels and a single-channel b (RetinexNet: S = R * I_delta)."""
+    _chk(a); _chk(b)
+    n, c1, h, w = a.shape
+    y = empty_nhwc(n, c1 - 1, h, w, a.device)
+    with torch.cuda.device(a.device):
+        capi.check(capi.lib().ie_eltwise_nhwc_f32(3, capi.ptr(a), capi.ptr(b), capi.ptr(y), n * h * w, c1 - 1, 1, 0.0, 0.0,
+                                                  capi.current_stream()), "ie_eltwise_nhwc_f32")
+    return y
+
+
+def max_concat(x) -> torch.Tensor:
+    """[max over channels, x] (RetinexNet DecomNet input)."""
+    _chk(x)
+    n, c, h, w = x.shape
+    y = empty_nhwc(n, c + 1, h, w, x.device)
+    with torch.cuda.device(x.device):
+        capi.check(capi.lib().ie_max_concat_nhwc_f32(capi.ptr(x), capi.ptr(y), n * h * w, c, capi.current_stream()),
+                   "ie_max_concat_nhwc_f32")
+    return y

@@ -96,9 +96,50 @@ int ie_conv2d_nhwc_f32(ie_conv2d_desc* d, const float* src0_dev, const float* sr
 /* OIHW fp32 host -> HWIO fp32 device. */
 int ie_pack_weight_hwio_f32(const float* w_oihw_host, int Cout, int Cin, int kh, int kw, float* dst_dev, void* stream);
 
+/* ---- generator building blocks, fp32 NHWC (parity path of U-Net / LLUnet++ / RetinexNet / Zero-DCE++) ---- */
+#define IE_CONV_MAX_SRC 8
+/* conv2d over the virtual channel concat of nsrc tensors (torch.cat(dim=1): llunetpp.py:224-239 concatenates
+ * up to 5 maps; unet.py:97; retinexnet/model.py:79-86) with fused bias + activation, then optional residual
+ * add (llunetpp.py:134 `x3 += x2_3`; zero_ig.py:343 `fea + conv(fea)`), then optional clamp (llunetpp.py:241,
+ * zero_ig.py:346).  Weights HWIO over the concatenated Cin. */
+typedef struct ie_convn_desc {
+    int N, H, W, nsrc, Cout, kh, kw, stride, pad;
+    int pad_mode;          /* ie_pad_mode */
+    int act;               /* ie_act */
+    float slope;
+    int clamp;             /* 0/1 */
+    float clamp_lo, clamp_hi;
+    int Ho, Wo;            /* out */
+} ie_convn_desc;
+int ie_convn_nhwc_f32(ie_convn_desc* d, const float* const* srcs_dev, const int* channels, const float* w_hwio_dev,
+                      const float* bias_dev, const float* residual_dev, float* dst_dev, void* stream);
+/* nn.InstanceNorm2d(affine) on channels [c_begin, c_begin + c_count) (biased variance over H*W per (n,c), eps;
+ * llunetpp.py:107; half-instance-norm hinet.py:75-77), other channels copied; fused activation.
+ * stats_ws_dev: >= 2*N*c_count doubles of scratch.  gamma/beta may both be NULL (affine=False). */
+int ie_instnorm_nhwc_f32(const float* x_dev, const float* gamma_dev, const float* beta_dev, float* y_dev, double* stats_ws_dev,
+                         int N, int H, int W, int C, int c_begin, int c_count, float eps, int act, float slope, void* stream);
+/* nn.MaxPool2d(2,2), floor mode (llunetpp.py:181, unet.py:65). */
+int ie_maxpool2x2_nhwc_f32(const float* x_dev, float* y_dev, int N, int H, int W, int C, void* stream);
+/* mode 0: F.interpolate default nearest (retinexnet/model.py:78-86); 1: bilinear align_corners=False;
+ * 2: bilinear align_corners=True (nn.Upsample, llunetpp.py:182, unet.py:82). */
+int ie_resize_nhwc_f32(const float* x_dev, float* y_dev, int N, int Hi, int Wi, int C, int Ho, int Wo, int mode, void* stream);
+/* nn.PixelShuffle(r) (nn/modules/shuffle.py:17-18, encoder/edsr.py:103): x (N,H,W,Cout*r*r) -> y (N,H*r,W*r,Cout). */
+int ie_pixel_shuffle_nhwc_f32(const float* x_dev, float* y_dev, int N, int H, int W, int Cout, int r, void* stream);
+/* nn.ConvTranspose2d(k=2, s=2) (hinet.py:101-107, unet.py:85); weights repacked [i][j][Cin][Cout]. */
+int ie_conv_transpose2x2_nhwc_f32(const float* x_dev, const float* w_ijco_dev, const float* bias_dev, float* y_dev, int N, int H,
+                                  int W, int Cin, int Cout, void* stream);
+/* F.pad zero padding (unet.py:90-93). */
+int ie_pad_nhwc_f32(const float* x_dev, float* y_dev, int N, int H, int W, int C, int top, int bottom, int left, int right, void* stream);
+/* op 0: a + b, 1: a * b (b with C or 1 channels), 2: clamp(a, lo, hi), 3: y(C ch) = a[:, :C] * b where a has
+ * C+1 channels and b one (S = R * I_delta with R = first 3 of DecomNet's 4 outputs, retinexnet/model.py:49-50,238). */
+int ie_eltwise_nhwc_f32(int op, const float* a_dev, const float* b_dev, float* y_dev, size_t npix, int C, int Cb, float lo, float hi, void* stream);
+/* [max_c(x), x] channel concat (retinexnet/model.py:45-46). */
+int ie_max_concat_nhwc_f32(const float* x_dev, float* y_dev, size_t npix, int C, void* stream);
+
 /* ---- LE curve (zero_dce.py:186-188) ------------------------------------ */
 /* y <- y + r_i (y^2 - y), i < iters; img NCHW fp32 (N,3,H,W); adjust NHWC fp32
- * with Cp channels (first 3*iters used, already tanh'ed); out NCHW fp32. */
+ * with Cp channels (first 3*iters used, already tanh'ed; 3 <= Cp < 3*iters: one
+ * shared 3-channel map for every iteration, zero_dcepp.py:201-203); out NCHW fp32. */
 int ie_le_curve(const float* img_dev, const float* adjust_nhwc_dev, int Cp, float* enhanced_dev,
                 int N, int H, int W, int iters, void* stream);
 

@@ -1,0 +1,156 @@
+"""Oracle (TEST INFRASTRUCTURE): CPU fp32 restatements (plain torch.nn.functional) of the other generators.
+
+  zero_dcepp_forward   src/mon/vision/enhance/llie/zero_dce/zero_dcepp.py:173-208 (DSConv2d dsconv.py:122-149)
+                       PINNED by tests/golden/zero_dcepp_*.npz (reference file mon_extra/.../zero_dce++/model.py)
+  llunetpp_forward     src/mon/vision/enhance/llie/llunetpp/llunetpp.py:97-137, 218-243
+                       PINNED by tests/golden/llunetpp_*.npz (reference file mon_extra/.../llunet++/model.py)
+  unet_forward         src/mon/vision/segment/unet/unet.py:35-197 with line 51's typo read as conv1; eval-mode BN.
+                       parity unpinned (the reference class does not run as shipped); leaf ops are torch's.
+  unet_ps variant      + Upsampler conv3x3 + nn.PixelShuffle(2) (nn/modules/encoder/edsr.py:88-123): parity unpinned.
+  zero_ig_enhance      src/mon/vision/enhance/llie/zero_ig/zero_ig.py:307-348: parity unpinned (mon not importable).
+  retinexnet_forward   src/mon_extra/vision/enhance/llie/retinexnet/model.py:21-90,199-238: parity unpinned (file
+                       imports cv2/thop/mon and hard-codes .cuda()); single Decom pass, S = R * I_delta.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+
+def _c(sd, name, x, stride=1, padding=1, groups=1, mode="zeros"):
+    w, b = sd[f"{name}.weight"], sd.get(f"{name}.bias")
+    if mode == "replicate" and padding > 0:
+        x = F.pad(x, (padding,) * 4, mode="replicate")
+        padding = 0
+    return F.conv2d(x, w, b, stride=stride, padding=padding, groups=groups)
+
+
+# ---- Zero-DCE++ -----------------------------------------------------------------------------------------------
+def zero_dcepp_forward(sd: dict, x: torch.Tensor, num_iters: int = 8, scale_factor: float = 1.0) -> dict:
+    def ds(k, t):
+        t = _c(sd, f"e_conv{k}.dw_conv", t, groups=t.shape[1])
+        return _c(sd, f"e_conv{k}.pw_conv", t, padding=0)
+    xd = x if scale_factor == 1 else F.interpolate(x, scale_factor=1 / scale_factor, mode="bilinear")
+    x1 = F.relu(ds(1, xd)); x2 = F.relu(ds(2, x1)); x3 = F.relu(ds(3, x2)); x4 = F.relu(ds(4, x3))
+    x5 = F.relu(ds(5, torch.cat([x3, x4], 1)))
+    x6 = F.relu(ds(6, torch.cat([x2, x5], 1)))
+    xr = torch.tanh(ds(7, torch.cat([x1, x6], 1)))
+    if scale_factor != 1:
+        xr = F.interpolate(xr, scale_factor=scale_factor, mode="bilinear", align_corners=True)   # nn.UpsamplingBilinear2d
+    y = x
+    for _ in range(num_iters):
+        y = y + xr * (torch.pow(y, 2) - y)
+    return {"adjust": xr, "enhanced": y}
+
+
+# ---- LLUnet++ -------------------------------------------------------------------------------------------------
+def _llunet_block(sd, b, x):
+    x12 = _c(sd, f"{b}.conv1_2", x, padding=0)
+    x1 = _c(sd, f"{b}.conv1", x)
+    x1 = F.instance_norm(x1, weight=sd[f"{b}.norm1.weight"], bias=sd[f"{b}.norm1.bias"], eps=1e-5)
+    x1 = F.leaky_relu(x1, 0.2)
+    x2 = torch.cat([x1, x12], 1)
+    x23 = _c(sd, f"{b}.conv2_3", x2, padding=0)
+    x2 = F.leaky_relu(_c(sd, f"{b}.conv2", x2), 0.2)
+    x3 = F.leaky_relu(_c(sd, f"{b}.conv3", x2), 0.2)
+    return x3 + x23
+
+
+def llunetpp_forward(sd: dict, x: torch.Tensor) -> dict:
+    B = lambda n, t: _llunet_block(sd, n, t)
+    pool = lambda t: F.max_pool2d(t, 2, 2)
+    up = lambda t: F.interpolate(t, scale_factor=2, mode="bilinear", align_corners=True)
+    cat = lambda *ts: torch.cat(ts, 1)
+    x0_0 = B("conv0_0", x)
+    x1_0 = B("conv1_0", pool(x0_0))
+    x0_1 = B("conv0_1", cat(x0_0, up(x1_0)))
+    x2_0 = B("conv2_0", pool(x1_0))
+    x1_1 = B("conv1_1", cat(x1_0, up(x2_0)))
+    x0_2 = B("conv0_2", cat(x0_0, x0_1, up(x1_1)))
+    x3_0 = B("conv3_0", pool(x2_0))
+    x2_1 = B("conv2_1", cat(x2_0, up(x3_0)))
+    x1_2 = B("conv1_2", cat(x1_0, x1_1, up(x2_1)))
+    x0_3 = B("conv0_3", cat(x0_0, x0_1, x0_2, up(x1_2)))
+    x4_0 = B("conv4_0", pool(x3_0))
+    x3_1 = B("conv3_1", cat(x3_0, up(x4_0)))
+    x2_2 = B("conv2_2", cat(x2_0, x2_1, up(x3_1)))
+    x1_3 = B("conv1_3", cat(x1_0, x1_1, x1_2, up(x2_2)))
+    x0_4 = B("conv0_4", cat(x0_0, x0_1, x0_2, x0_3, up(x1_3)))
+    return {"enhanced": torch.clamp(_c(sd, "final", x0_4, padding=0), 0, 1)}
+
+
+MON_EXTRA_LLUNET_KEYS = ((".conv1_2.", ".conv_1_1_1."), (".conv2_3.", ".conv_1_1."), (".conv1.", ".conv_1."),
+                         (".conv2.", ".conv_2."), (".conv3.", ".conv_3."))
+
+
+def llunetpp_to_extra_keys(sd: dict) -> dict:
+    """mon key names -> the original repository's (llunet++/model.py:9-20)."""
+    out = {}
+    for k, v in sd.items():
+        for a, b in MON_EXTRA_LLUNET_KEYS:
+            k = k.replace(a, b)
+        out[k] = v
+    return out
+
+
+# ---- U-Net ----------------------------------------------------------------------------------------------------
+def _bn(sd, n, x):
+    return F.batch_norm(x, sd[f"{n}.running_mean"], sd[f"{n}.running_var"], sd[f"{n}.weight"], sd[f"{n}.bias"], False, 0.1, 1e-5)
+
+
+def _dc(sd, n, x):
+    x = F.relu(_bn(sd, f"{n}.norm1", _c(sd, f"{n}.conv1", x)))
+    return F.relu(_bn(sd, f"{n}.norm2", _c(sd, f"{n}.conv2", x)))
+
+
+def unet_forward(sd: dict, x: torch.Tensor, upsampler: str = "bilinear", enhance: bool = False) -> dict:
+    x1 = _dc(sd, "inc", x)
+    x2 = _dc(sd, "down1.conv", F.max_pool2d(x1, 2))
+    x3 = _dc(sd, "down2.conv", F.max_pool2d(x2, 2))
+    x4 = _dc(sd, "down3.conv", F.max_pool2d(x3, 2))
+    x5 = _dc(sd, "down4.conv", F.max_pool2d(x4, 2))
+
+    def up(k, a, skip):
+        if upsampler == "bilinear":
+            a = F.interpolate(a, scale_factor=2, mode="bilinear", align_corners=True)
+        else:
+            a = F.pixel_shuffle(_c(sd, f"up{k}.up.0", a), 2)
+        dy, dx = skip.shape[2] - a.shape[2], skip.shape[3] - a.shape[3]
+        a = F.pad(a, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])
+        return _dc(sd, f"up{k}.conv", torch.cat([skip, a], 1))
+    y = up(1, x5, x4); y = up(2, y, x3); y = up(3, y, x2); y = up(4, y, x1)
+    y = _c(sd, "outc.conv", y, padding=0)
+    return {"enhanced": torch.clamp(y, 0, 1)} if enhance else {"semantic": y}
+
+
+# ---- Zero-IG Enhance -------------------------------------------------------------------------------------------
+def zero_ig_enhance_forward(sd: dict, x: torch.Tensor, layers: int = 3) -> dict:
+    fea = F.relu(_c(sd, "in_conv.0", x))
+    for _ in range(layers):
+        fea = fea + F.relu(_bn(sd, "conv.1", _c(sd, "conv.0", fea)))
+    fea = torch.sigmoid(_c(sd, "out_conv.0", fea))
+    return {"enhanced": torch.clamp(fea, 0.0001, 1)}
+
+
+# ---- RetinexNet ------------------------------------------------------------------------------------------------
+def retinexnet_forward(sd: dict, x: torch.Tensor) -> dict:
+    R = "replicate"
+    xin = torch.cat((torch.max(x, dim=1, keepdim=True)[0], x), dim=1)
+    f = _c(sd, "net1_conv0", xin, padding=4, mode=R)
+    for i in (0, 2, 4, 6, 8):
+        f = F.relu(_c(sd, f"net1_convs.{i}", f, mode=R))
+    outs = _c(sd, "net1_recon", f, mode=R)
+    r_low, i_low = torch.sigmoid(outs[:, 0:3]), torch.sigmoid(outs[:, 3:4])
+    img = torch.cat((r_low, i_low), 1)
+    out0 = _c(sd, "net2_conv0_1", img, mode=R)
+    out1 = F.relu(_c(sd, "net2_conv1_1", out0, stride=2, mode=R))
+    out2 = F.relu(_c(sd, "net2_conv1_2", out1, stride=2, mode=R))
+    out3 = F.relu(_c(sd, "net2_conv1_3", out2, stride=2, mode=R))
+    sz = lambda t: (t.shape[2], t.shape[3])
+    d1 = F.relu(_c(sd, "net2_deconv1_1", torch.cat((F.interpolate(out3, size=sz(out2)), out2), 1), mode=R))
+    d2 = F.relu(_c(sd, "net2_deconv1_2", torch.cat((F.interpolate(d1, size=sz(out1)), out1), 1), mode=R))
+    d3 = F.relu(_c(sd, "net2_deconv1_3", torch.cat((F.interpolate(d2, size=sz(out0)), out0), 1), mode=R))
+    feats = torch.cat((F.interpolate(d1, size=sz(x)), F.interpolate(d2, size=sz(x)), d3), 1)
+    fus = _c(sd, "net2_fusion", feats, padding=1, mode=R)
+    i_delta = _c(sd, "net2_output", fus, padding=0)
+    return {"reflectance": r_low, "illumination": i_low, "illumination_delta": i_delta, "enhanced": r_low * i_delta}

@@ -72,6 +72,51 @@ def gen_zero_dce():
               "| |r|max", float(r.abs().max()), "enh range", float(e.min()), float(e.max()))
 
 
+from tests.helpers import seeded_state_dict as _seeded  # noqa: E402
+
+
+def gen_zero_dcepp():
+    mod = _load("src/mon_extra/vision/enhance/llie/zero_dce++/model.py", "ref_zero_dcepp")
+    for name, scale, x, gain in (("s1_1x40x56", 1, torch.rand(1, 3, 40, 56, generator=torch.Generator().manual_seed(5)), 8.0),
+                                 ("s2_2x48x64", 2, torch.rand(2, 3, 48, 64, generator=torch.Generator().manual_seed(6)) ** 2.2 * 0.3, 8.0)):
+        net = mod.enhance_net_nopool(scale)
+        shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+        sd = _seeded(shapes, seed=21 + scale, std=0.02 * gain)
+        net.load_state_dict(sd, strict=True)
+        net.eval()
+        with torch.no_grad():
+            e, r = net(x)
+        out = {f"w.{k}": v.numpy() for k, v in sd.items()}       # original key names (depth_conv / point_conv)
+        out.update(image=x.numpy(), enhanced=e.numpy(), adjust=r.numpy(), scale_factor=np.array(scale))
+        path = os.path.join(HERE, f"zero_dcepp_{name}.npz")
+        np.savez_compressed(path, **out)
+        print("wrote", path, os.path.getsize(path) // 1024, "KiB | |r|max", float(r.abs().max()))
+
+
+def gen_llunetpp():
+    """LLUnet++ has 29 M parameters: the weights are NOT stored; they are regenerated from the seed by
+    oracle-side code (tests/helpers.llunetpp_seeded_weights) and only input/output travel."""
+    mod = _load("src/mon_extra/vision/enhance/llie/llunet++/model.py", "ref_llunetpp")
+    net = mod.NestedUNet()
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sd = _seeded(shapes, seed=31)
+    net.load_state_dict(sd, strict=True)
+    net.eval()
+    x = torch.rand(1, 3, 32, 48, generator=torch.Generator().manual_seed(7))
+    with torch.no_grad():
+        y = net(x)
+    path = os.path.join(HERE, "llunetpp_seed31_1x32x48.npz")
+    np.savez_compressed(path, image=x.numpy(), enhanced=y.numpy(), seed=np.array(31),
+                        key_order=np.array(list(shapes.keys())), key_shapes=np.array([str(s) for s in shapes.values()]))
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB | out range", float(y.min()), float(y.max()), "mean", float(y.mean()))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    gen_zero_dce()
+    which = sys.argv[1:] or ["zero_dce", "zero_dcepp", "llunetpp"]
+    if "zero_dce" in which:
+        gen_zero_dce()
+    if "zero_dcepp" in which:
+        gen_zero_dcepp()
+    if "llunetpp" in which:
+        gen_llunetpp()

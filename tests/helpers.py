@@ -32,3 +32,23 @@ def psnr(a, b):
     b = torch.as_tensor(b).double()
     mse = float(((a - b) ** 2).mean())
     return float("inf") if mse == 0 else 10.0 * np.log10(1.0 / mse)
+
+
+def seeded_state_dict(shapes: dict, seed: int, std=None) -> dict:
+    """Deterministic weights for architectures too large to store as fixtures (used by
+    tests/golden/make_golden.py and by the tests): U(+-1/sqrt(fan_in)) conv weights (or N(0, std)),
+    norm scale ~ N(1, 0.1), everything else U(+-0.1); ``final.bias`` lifted so outputs are not all clamped."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for k, shp in shapes.items():
+        shp = tuple(shp)
+        if len(shp) == 4:
+            bound = 1.0 / (shp[1] * shp[2] * shp[3]) ** 0.5
+            sd[k] = (torch.rand(shp, generator=g) * 2 - 1) * bound if std is None else torch.randn(shp, generator=g) * std
+        elif ".norm" in k and k.endswith(".weight"):
+            sd[k] = 1.0 + torch.randn(shp, generator=g) * 0.1
+        else:
+            sd[k] = (torch.rand(shp, generator=g) * 2 - 1) * 0.1
+    if "final.bias" in sd:
+        sd["final.bias"] = sd["final.bias"] + 0.45
+    return sd

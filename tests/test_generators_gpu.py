@@ -1,0 +1,140 @@
+"""GPU parity of the generator models (fp32 NHWC building blocks through the C ABI) against goldens and
+the CPU oracle.  Tolerance 1e-4 on max|a-b|/max|b| (bound asked: 1e-3)."""
+import ast
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import mon_amd
+from mon_amd import ops
+from oracle import generators as og
+from tests.helpers import GOLDEN, rel_err, seeded_state_dict
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "zero_dcepp_*.npz"))), ids=lambda p: os.path.basename(p)[11:-4])
+def test_zero_dcepp_golden(path):
+    g = np.load(path)
+    sd = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w.")}
+    m = mon_amd.MODELS.build(name="zero_dce++_re", scale_factor=float(g["scale_factor"]), weights=sd).to("cuda")
+    out = m.forward({"image": torch.from_numpy(g["image"]).cuda()})
+    assert list(out.keys()) == ["adjust", "enhanced"]
+    assert rel_err(out["enhanced"].cpu(), g["enhanced"]) <= TOL
+    assert rel_err(out["adjust"].cpu(), g["adjust"]) <= TOL
+
+
+def test_llunetpp_golden_and_infer():
+    g = np.load(os.path.join(GOLDEN, "llunetpp_seed31_1x32x48.npz"))
+    shapes = {str(k): ast.literal_eval(str(s)) for k, s in zip(g["key_order"], g["key_shapes"])}
+    sd = seeded_state_dict(shapes, int(g["seed"]))
+    m = mon_amd.MODELS.build(name="llunet++_re", weights=sd).to("cuda")
+    x = torch.from_numpy(g["image"])
+    out = m.forward({"image": x.cuda()})["enhanced"].cpu()
+    assert rel_err(out, g["enhanced"]) <= TOL
+    with pytest.raises(ValueError):                         # 1080-like sizes only work through infer
+        m.forward({"image": torch.rand(1, 3, 40, 48).cuda()})
+    y = torch.rand(1, 3, 40, 56, generator=torch.Generator().manual_seed(1))
+    got = m.infer({"image": y.clone()})["enhanced"].cpu()
+    yr = F.interpolate(y, size=(64, 64), mode="bilinear", align_corners=False)
+    ref = F.interpolate(og.llunetpp_forward(m.state_dict(), yr)["enhanced"], size=(40, 56), mode="bilinear", align_corners=False)
+    assert tuple(got.shape) == (1, 3, 40, 56) and rel_err(got, ref) <= TOL
+
+
+@pytest.mark.parametrize("cfg", [dict(base_channels=64, num_classes=34, enhance=False, upsampler="bilinear", hw=(33, 47)),
+                                 dict(base_channels=32, num_classes=3, enhance=True, upsampler="bilinear", hw=(135, 70)),
+                                 dict(base_channels=32, num_classes=3, enhance=True, upsampler="pixelshuffle", hw=(48, 64))],
+                         ids=["unet64-seg-odd", "unet32-enh-odd", "unet32-pixelshuffle"])
+def test_unet_vs_oracle(cfg):
+    hw = cfg.pop("hw")
+    m = mon_amd.MODELS.build(name="unet", seed=3, **cfg).to("cuda")
+    x = torch.rand(2, 3, *hw, generator=torch.Generator().manual_seed(2))
+    out = m.forward({"image": x.cuda()})
+    key = "enhanced" if cfg["enhance"] else "semantic"
+    ref = og.unet_forward(m.state_dict(), x, cfg["upsampler"], cfg["enhance"])[key]
+    assert tuple(out[key].shape) == tuple(ref.shape)
+    assert rel_err(out[key].cpu(), ref) <= TOL
+
+
+def test_unet_loads_reference_style_checkpoint(tmp_path):
+    """BatchNorm checkpoints carry num_batches_tracked; strict loading ignores exactly those."""
+    m = mon_amd.UNet(seed=5, base_channels=32, num_classes=3, enhance=True)
+    sd = m.state_dict()
+    sd["inc.norm1.num_batches_tracked"] = torch.tensor(7)
+    p = tmp_path / "unet.pt"
+    torch.save(sd, p)
+    m2 = mon_amd.MODELS.build(name="unet", weights=str(p), base_channels=32, num_classes=3, enhance=True).to("cuda")
+    x = torch.rand(1, 3, 32, 32, generator=torch.Generator().manual_seed(3))
+    assert rel_err(m2.forward({"image": x.cuda()})["enhanced"].cpu(), og.unet_forward(sd, x, "bilinear", True)["enhanced"]) <= TOL
+
+
+def test_zero_ig_enhance_vs_oracle():
+    m = mon_amd.MODELS.build(name="zero_ig_enhance", seed=4, layers=3, channels=64).to("cuda")
+    sd = m.state_dict()
+    sd = {k: (v * 6 if k.endswith("conv.0.weight") or k.endswith("in_conv.0.weight") else v) for k, v in sd.items()}
+    m.load_state_dict(sd)
+    x = torch.rand(2, 3, 37, 51, generator=torch.Generator().manual_seed(4))
+    out = m.forward({"image": x.cuda()})["enhanced"].cpu()
+    ref = og.zero_ig_enhance_forward(sd, x, 3)["enhanced"]
+    assert rel_err(out, ref) <= TOL and float(out.min()) >= 0.99e-4 and float(out.max()) <= 1.0
+
+
+@pytest.mark.parametrize("hw", [(40, 56), (45, 67)])
+def test_retinexnet_vs_oracle(hw):
+    m = mon_amd.MODELS.build(name="retinexnet", seed=6).to("cuda")
+    x = torch.rand(1, 3, *hw, generator=torch.Generator().manual_seed(5)) * 0.4
+    out = m.forward({"image": x.cuda()})
+    ref = og.retinexnet_forward(m.state_dict(), x)
+    assert list(out.keys())[-1] == "enhanced"
+    for k in ("reflectance", "illumination", "illumination_delta", "enhanced"):
+        assert tuple(out[k].shape) == tuple(ref[k].shape), k
+        assert rel_err(out[k].cpu(), ref[k]) <= TOL, k
+
+
+def test_retinexnet_two_file_checkpoints(tmp_path):
+    m = mon_amd.RetinexNet(seed=7)
+    sd = m.state_dict()
+    torch.save({k: v for k, v in sd.items() if k.startswith("net1_")}, tmp_path / "d.pt")
+    torch.save({k: v for k, v in sd.items() if k.startswith("net2_")}, tmp_path / "r.pt")
+    m2 = mon_amd.MODELS.build(name="retinexnet", weights={"decom": str(tmp_path / "d.pt"), "relight": str(tmp_path / "r.pt")})
+    assert all(torch.equal(m2.state_dict()[k], sd[k]) for k in sd)
+
+
+def test_building_blocks_against_torch():
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(2, 24, 18, 22, generator=g)
+    xn = ops.to_nhwc(x.cuda())
+    assert torch.equal(ops.to_nchw(xn).cpu(), x)
+    assert torch.equal(ops.to_nchw(ops.maxpool2x2(xn)).cpu(), F.max_pool2d(x, 2))
+    assert torch.equal(ops.to_nchw(ops.maxpool2x2(ops.to_nhwc(x[:, :, :17, :21].contiguous().cuda()))).cpu(), F.max_pool2d(x[:, :, :17, :21], 2))
+    for mode, kw in (("nearest", dict(mode="nearest")), ("bilinear", dict(mode="bilinear", align_corners=False)),
+                     ("bilinear_align", dict(mode="bilinear", align_corners=True))):
+        for size in ((36, 44), (9, 11), (25, 31)):
+            ref = F.interpolate(x, size=size, **kw)
+            assert (ops.to_nchw(ops.resize(xn, size, mode)).cpu() - ref).abs().max() <= 2e-6, (mode, size)
+    assert torch.equal(ops.to_nchw(ops.pixel_shuffle(xn, 2)).cpu(), F.pixel_shuffle(x, 2))
+    gamma, beta = torch.rand(24, generator=g) + 0.5, torch.randn(24, generator=g)
+    ref = F.leaky_relu(F.instance_norm(x, weight=gamma, bias=beta, eps=1e-5), 0.2)
+    got = ops.to_nchw(ops.instance_norm(xn, gamma.cuda(), beta.cuda(), 1e-5, "lrelu", 0.2)).cpu()
+    assert (got - ref).abs().max() <= 2e-5
+    # half instance norm (hinet.py:75-77): first half normalised, second half passed through
+    ref = torch.cat([F.instance_norm(x[:, :12], weight=gamma[:12], bias=beta[:12], eps=1e-5), x[:, 12:]], 1)
+    got = ops.to_nchw(ops.instance_norm(xn, gamma[:12].cuda(), beta[:12].cuda(), 1e-5, c_begin=0, c_count=12)).cpu()
+    assert (got - ref).abs().max() <= 2e-5
+    wt, bt = torch.randn(24, 10, 2, 2, generator=g) * 0.2, torch.randn(10, generator=g)
+    ref = F.conv_transpose2d(x, wt, bt, stride=2)
+    got = ops.to_nchw(ops.conv_transpose2x2(xn, ops.ConvT2x2Weights(wt, bt, "cuda"))).cpu()
+    assert (got - ref).abs().max() <= 2e-5
+    assert torch.equal(ops.to_nchw(ops.pad(xn, 1, 2, 0, 3)).cpu(), F.pad(x, [0, 3, 1, 2]))
+    y = torch.randn(2, 24, 18, 22, generator=g)
+    assert torch.equal(ops.to_nchw(ops.add(xn, ops.to_nhwc(y.cuda()))).cpu(), x + y)
+    one = torch.randn(2, 1, 18, 22, generator=g)
+    assert torch.equal(ops.to_nchw(ops.mul(xn, ops.to_nhwc(one.cuda()))).cpu(), x * one)
+    assert torch.equal(ops.to_nchw(ops.clamp(xn, -0.5, 0.25)).cpu(), x.clamp(-0.5, 0.25))
+    assert torch.equal(ops.to_nchw(ops.max_concat(xn)).cpu(), torch.cat([x.max(1, keepdim=True)[0], x], 1))
+    assert torch.equal(ops.to_nchw(ops.mul_prefix(xn, ops.to_nhwc(one.cuda()))).cpu(), x[:, :23] * one)
