@@ -1,9 +1,11 @@
 // Two-stage fused strip kernels for Zero-DCE (gfx950): the intermediate of the pair never goes
 // to HBM (or goes there once, write-only, when a later layer needs it).
 //
-//   K12: e_conv1 (image -> x1, stored) + e_conv2 (x1 -> x2)           12+64+64 = 140 B/px (was 204)
+//   K12: e_conv1 (image -> x1, LDS only) + e_conv2 (x1 -> x2) + the x1 half of e_conv7 (x1 -> P)   12+64+64 = 140 B/px
+//        (e_conv7([x1,x6]) = W7a*x1 + W7b*x6: P = W7a*x1 + bias7 is computed where x1 lives and replaces x1 in HBM,
+//         which halves stage B of K67 -- the busiest kernel -- and uses MFMA slots K12, a write-bound kernel, has free)
 //   K45: e_conv4 (x3 -> x4, LDS only) + e_conv5 ([x3,x4] -> x5)       64+64    = 128 B/px (was 320)
-//   K67: e_conv6 ([x2,x5] -> x6, LDS only) + e_conv7 ([x1,x6]) + curve 192+12+12 = 216 B/px (was 344)
+//   K67: e_conv6 ([x2,x5] -> x6, LDS only) + e_conv7 (P + W7b*x6) + curve  192+12+12 = 216 B/px (was 344)
 //
 // Reference semantics: src/mon/vision/enhance/llie/zero_dce/zero_dce.py:173-191.
 //
@@ -37,11 +39,12 @@ enum { K12 = 12, K45 = 45, K67 = 67 };
 struct FusedParams {
     const void* a_src0;  // stage A HBM source 0 (NHWC T)            K45: x3, K67: x2
     const void* a_src1;  // stage A HBM source 1                     K67: x5
-    const void* b_src;   // stage B HBM source with its own ring     K67: x1
+    const void* b_src;   // stage B HBM source with its own ring     K67: P (accumulator seed of e_conv7)
     const float* img;    // NCHW fp32 image                          K12 (A input), K67 (curve)
     const void* a_w; const float* a_bias;
     const void* b_w; const float* b_bias;
-    void* a_dst;         // K12: x1 (NHWC T)
+    const float* b2_bias; // K12: e_conv7's bias (folded into P)
+    void* a_dst;         // K12: P = W7a*x1 + bias7 (NHWC T, 32 ch, 24 used)
     void* b_dst;         // K12: x2, K45: x5
     float* enhanced; float* adjust; unsigned char* u8;   // K67
     int N, H, W;
@@ -76,8 +79,8 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     constexpr int PXB = 32 * sizeof(T);                     // 64 B per pixel per tensor
     constexpr int ROW_B = ROW_PX * PXB;                     // one ring row of one tensor
     constexpr int NSA = (KIND == K67) ? 2 : (KIND == K45 ? 1 : 0);   // stage A HBM sources (K12: image)
-    constexpr int NSB = (KIND == K12) ? 1 : 2;                       // stage B sources (concat order)
-    constexpr int NW = 9 * (NSB > NSA ? NSB : (NSA > 0 ? NSA : 1));  // weight fragments held per wave (K12 stage A: 2)
+    constexpr int NFB = (KIND == K45 || KIND == K12) ? 18 : 9;       // stage B weight fragments (K12: e_conv2 + e_conv7a)
+    constexpr int NW = (KIND == K67) ? 18 : NFB;                     // weight fragments held per wave (K12 stage A: 2, K67 stage A: 18)
     // ---- LDS carve ------------------------------------------------------------------------------
     constexpr int NRA = (KIND == K45) ? PF + 3 : PF + 1;    // slots of the A rings (K45: B re-reads x3 two rows later)
     constexpr int A_RING_B = NSA * NRA * ROW_B;
@@ -131,16 +134,18 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     // ---- weights of this wave's stage into registers -------------------------------------------
     frag wv[NW];
     {
-        const int nfr = stg ? 9 * NSB : (KIND == K12 ? 2 : 9 * NSA);   // fragments per cout half
+        const int nfr = stg ? NFB : (KIND == K12 ? 2 : 9 * NSA);   // fragments per cout half
         const frag* wp = (const frag*)(stg ? p.b_w : p.a_w) + (size_t)ch * nfr * 64;
 #pragma unroll
         for (int f = 0; f < NW; ++f) wv[f] = wp[(f < nfr ? f : 0) * 64 + lane];
     }
-    ie_f32x4 bias4;
+    ie_f32x4 bias4, bias4p;
     {
         const float* bp = stg ? p.b_bias : p.a_bias;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) bias4[i] = bp[16 * ch + 4 * kq + i];
+        for (int i = 0; i < 4; ++i) bias4[i] = (KIND == K67 && stg) ? 0.f : bp[16 * ch + 4 * kq + i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bias4p[i] = (KIND == K12) ? p.b2_bias[16 * ch + 4 * kq + i] : 0.f;
     }
 
     // ---- DMA geometry ------------------------------------------------------------------------------
@@ -213,7 +218,7 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
             }
         } else {
             if constexpr (KIND == K67) {
-                IE_DMA_ROW(rsB, smem + OFF_BRING + (t % NRB) * ROW_B, ys - 4 + t);
+                IE_DMA_ROW(rsB, smem + OFF_BRING + (t % NRB) * ROW_B, ys - 3 + t);   // P row that seeds the row started at step t
                 if (sw < 3) {
                     const int yo = ys - 5 + t;      // row finished at step t, consumed at step t+2
                     const unsigned rmask = ((yo >= ys) && (yo < ye)) ? 0u : OOB;
@@ -258,16 +263,6 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
             for (int nt = 0; nt < 4; ++nt) {
                 const int off = (kx == 0 && nt == 0) ? rd_first : (kx == 2 && nt == 3) ? rd_last : rd_base[kx] + 1024 * nt;
                 const frag bx = *(const frag*)(row + off);
-                if constexpr (KIND == K12) {
-                    // the centre-tap fragment of tile nt is pixel 64ph+16nt+p16, 16-byte chunk kq of x1:
-                    // store it (a wave writes 16 px x 64 B = 1 KB contiguous); one cout-half pair suffices
-                    if (kx == 1) {
-                        const int q = 64 * ph + 16 * nt + p16, x = xc0 + q;
-                        const bool st = (ch == 0) && x1_row >= ys && x1_row < ye && q >= 1 && q < TW - 1 && x < W;
-                        const unsigned off1 = st ? ((unsigned)x1_row * (unsigned)W + (unsigned)x) * PXB + (unsigned)kq * 16u : OOB;
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ie_u32x4, bx), rsDa, (int)off1, 0, 0);
-                    }
-                }
                 accN[nt] = E::mfma16(wv[wbase + 0 * 3 + kx], bx, accN[nt]);
                 accM[nt] = E::mfma16(wv[wbase + 1 * 3 + kx], bx, accM[nt]);
                 accO[nt] = E::mfma16(wv[wbase + 2 * 3 + kx], bx, accO[nt]);
@@ -282,6 +277,31 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
         __builtin_amdgcn_sched_group_barrier(0x008, 3 * IE_LDS_DEPTH, 0);
+    };
+
+    // K12 stage B: every x1 fragment feeds e_conv2 (weights 0..8 -> acc) and the x1 half of e_conv7 (weights 9..17 -> accp)
+    auto src_mfma2 = [&](const char* row, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4], ie_f32x4 (&pN)[4],
+                         ie_f32x4 (&pM)[4], ie_f32x4 (&pO)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int off = (kx == 0 && nt == 0) ? rd_first : (kx == 2 && nt == 3) ? rd_last : rd_base[kx] + 1024 * nt;
+                const frag bx = *(const frag*)(row + off);
+                accN[nt] = E::mfma16(wv[0 * 3 + kx], bx, accN[nt]);
+                accM[nt] = E::mfma16(wv[1 * 3 + kx], bx, accM[nt]);
+                accO[nt] = E::mfma16(wv[2 * 3 + kx], bx, accO[nt]);
+                pN[nt] = E::mfma16(wv[(NW > 9 ? 9 : 0) + 0 * 3 + kx], bx, pN[nt]);
+                pM[nt] = E::mfma16(wv[(NW > 9 ? 9 : 0) + 1 * 3 + kx], bx, pM[nt]);
+                pO[nt] = E::mfma16(wv[(NW > 9 ? 9 : 0) + 2 * 3 + kx], bx, pO[nt]);
+            }
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+        for (int f = 0; f < 12 - 3; ++f) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 18, 0);
     };
 
     // write a finished stage-A row (ReLU, 16-bit, zero outside the image) into the hand-off ring slot
@@ -302,26 +322,40 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
         }
     };
 
-    // stage-B ReLU epilogue to HBM (centre 126 columns)
-    auto b_store = [&](const ie_f32x4 (&acc)[4], int yo) __attribute__((always_inline)) {
-        const bool row_ok = (yo >= ys) && (yo < ye);
-        ie_u32x2 pk[4];
+    // stage-B epilogue to HBM (centre 126 columns): ReLU'd activations (x2, x5) or the raw P map (K12)
+#define IE_B_STORE(ACC, YO, RS, RELU)                                                                                     \
+    do {                                                                                                                  \
+        const int yo_ = (YO);                                                                                             \
+        const bool row_ok_ = (yo_ >= ys) && (yo_ < ye);                                                                   \
+        ie_u32x2 pk_[4];                                                                                                  \
+        _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                                                \
+            pk_[nt][0] = (RELU) ? ie_pack2_relu<T>(ACC[nt][0], ACC[nt][1]) : ie_pack2<T>(ACC[nt][0], ACC[nt][1]);         \
+            pk_[nt][1] = (RELU) ? ie_pack2_relu<T>(ACC[nt][2], ACC[nt][3]) : ie_pack2<T>(ACC[nt][2], ACC[nt][3]);         \
+        }                                                                                                                 \
+        const unsigned row_b_ = (unsigned)yo_ * (unsigned)W * PXB;                                                        \
+        _Pragma("unroll") for (int nt = 0; nt < 4; nt += 2) {                                                             \
+            auto sx_ = __builtin_amdgcn_permlane16_swap(pk_[nt][0], pk_[nt + 1][0], false, false);                        \
+            auto sy_ = __builtin_amdgcn_permlane16_swap(pk_[nt][1], pk_[nt + 1][1], false, false);                        \
+            ie_u32x4 v_ = {sx_[0], sy_[0], sx_[1], sy_[1]};                                                               \
+            const int q_ = 64 * ph + 16 * (nt + (kq & 1)) + p16;                                                          \
+            const int xo_ = xc0 + q_;                                                                                     \
+            const bool ok_ = row_ok_ && q_ >= 1 && q_ < TW - 1 && xo_ < W;                                                \
+            const unsigned off_ = ok_ ? row_b_ + (unsigned)xo_ * PXB + (unsigned)((16 * ch + 4 * (kq & 2)) * sizeof(T)) : OOB; \
+            __builtin_amdgcn_raw_buffer_store_b128(v_, RS, (int)off_, 0, 0);                                              \
+        }                                                                                                                 \
+    } while (0)
+
+    // K67 stage B: seed the accumulators of the output row started at step t with its P row (from the DMA ring)
+    auto seed_from_p = [&](int t, ie_f32x4 (&acc)[4]) __attribute__((always_inline)) {
+        const char* slot = smem + OFF_BRING + (t % NRB) * ROW_B;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-            pk[nt][0] = ie_pack2_relu<T>(acc[nt][0], acc[nt][1]);
-            pk[nt][1] = ie_pack2_relu<T>(acc[nt][2], acc[nt][3]);
-        }
-        const unsigned row_b = (unsigned)yo * (unsigned)W * PXB;
+            const int q = 64 * ph + 16 * nt + p16;
+            const int c = 2 * ch + (kq >> 1);
+            typedef __attribute__((ext_vector_type(4))) T t4;
+            const t4 v = *(const t4*)(slot + q * PXB + ((c ^ ((q >> 1) & 3)) << 4) + (kq & 1) * 8);
 #pragma unroll
-        for (int nt = 0; nt < 4; nt += 2) {
-            auto sx = __builtin_amdgcn_permlane16_swap(pk[nt][0], pk[nt + 1][0], false, false);
-            auto sy = __builtin_amdgcn_permlane16_swap(pk[nt][1], pk[nt + 1][1], false, false);
-            ie_u32x4 v = {sx[0], sy[0], sx[1], sy[1]};
-            const int q = 64 * ph + 16 * (nt + (kq & 1)) + p16;
-            const int xo = xc0 + q;
-            const bool ok = row_ok && q >= 1 && q < TW - 1 && xo < W;
-            const unsigned off = ok ? row_b + (unsigned)xo * PXB + (unsigned)((16 * ch + 4 * (kq & 2)) * sizeof(T)) : OOB;
-            __builtin_amdgcn_raw_buffer_store_b128(v, rsDb, (int)off, 0, 0);
+            for (int i = 0; i < 4; ++i) acc[nt][i] = (float)v[i];
         }
     };
 
@@ -427,7 +461,8 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     // issue, then the hand-off write.  Stage B: the epilogue of the row it finished in the PREVIOUS step
     // first (that accumulator set is this step's accN, reset afterwards), then its MFMAs.  The two stages
     // share each SIMD, so B's epilogue VALU runs under A's MFMAs and A's tail under B's MFMAs.
-    auto step = [&](int t, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4]) __attribute__((always_inline)) {
+    auto step = [&](int t, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4], ie_f32x4 (&pN)[4], ie_f32x4 (&pM)[4],
+                    ie_f32x4 (&pO)[4]) __attribute__((always_inline)) {
         unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
         (void)ts0; (void)ts1; (void)ts2; (void)ts3;
         IE_T(ts0);
@@ -454,25 +489,29 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
         } else {
             issue(t + PF);
             IE_T(ts2);
-            // accN still holds the output row finished at step t-1: ys-5-LAG_A+(t-1)
+            // accN (and pN) still hold the output row finished at step t-1: ys-5-LAG_A+(t-1)
             if constexpr (KIND == K12) convert_row(t);
-            if constexpr (KIND != K67) {
-                if (t >= 6 + LAG_A) b_store(accN, ys - 6 - LAG_A + t);
+            if constexpr (KIND == K12) {
+                if (t >= 6 + LAG_A) { IE_B_STORE(accN, ys - 6 - LAG_A + t, rsDb, true); IE_B_STORE(pN, ys - 6 - LAG_A + t, rsDa, false); }
+            } else if constexpr (KIND == K45) {
+                if (t >= 6) IE_B_STORE(accN, ys - 6 + t, rsDb, true);
             } else {
                 if (t >= 7) curve_consume(t - 2);
                 if (t >= 6) stage_write(accN, (t - 1) & 1);
             }
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) accN[nt] = bias4;
             const char* ra_row = smem + OFF_RA + ((t + 1) & 1) * ROW_B;     // written by stage A at step t-1
             if constexpr (KIND == K12) {
-                src_mfma(ra_row, 0, accN, accM, accO, ys - 5 + t);                      // x1 row ys-5+t (also stored to HBM)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) { accN[nt] = bias4; pN[nt] = bias4p; }
+                src_mfma2(ra_row, accN, accM, accO, pN, pM, pO);                           // x1 row ys-5+t
             } else if constexpr (KIND == K45) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) accN[nt] = bias4;
                 src_mfma(smem + ((t + NRA - 2) % NRA) * ROW_B, 0, accN, accM, accO, 0);   // x3 row ys-4+t
                 src_mfma(ra_row, 9, accN, accM, accO, 0);                                  // x4 row ys-4+t
             } else {
-                src_mfma(smem + OFF_BRING + (t % NRB) * ROW_B, 0, accN, accM, accO, 0);    // x1 row ys-4+t
-                src_mfma(ra_row, 9, accN, accM, accO, 0);                                  // x6 row ys-4+t
+                seed_from_p(t, accN);                                                      // P row ys-3+t = W7a*x1 + bias7
+                src_mfma(ra_row, 0, accN, accM, accO, 0);                                  // x6 row ys-4+t
             }
         }
 #ifdef IE_STAMP
@@ -485,13 +524,15 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     for (int t = 0; t < PF; ++t) issue(t);
 
     ie_f32x4 a0[4], a1[4], a2[4];
+    ie_f32x4 q0[4], q1[4], q2[4];     // K12 stage B: the e_conv7a (P) accumulator family
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) { a0[nt] = bias4; a1[nt] = bias4; a2[nt] = bias4; }
+    for (int nt = 0; nt < 4; ++nt) { a0[nt] = bias4; a1[nt] = bias4; a2[nt] = bias4; q0[nt] = bias4p; q1[nt] = bias4p; q2[nt] = bias4p; }
     for (int t = 0; t < n_steps; t += 3) {
-        step(t, a0, a1, a2);
-        if (t + 1 < n_steps) step(t + 1, a2, a0, a1);
-        if (t + 2 < n_steps) step(t + 2, a1, a2, a0);
+        step(t, a0, a1, a2, q0, q1, q2);
+        if (t + 1 < n_steps) step(t + 1, a2, a0, a1, q2, q0, q1);
+        if (t + 2 < n_steps) step(t + 2, a1, a2, a0, q1, q2, q0);
     }
+#undef IE_B_STORE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef IE_STAMP
     if (p.stamps && lane == 0) {
@@ -527,7 +568,7 @@ template <typename T, int KIND>
 static int launch_fused_t(const ZdceFusedLaunch& a, hipStream_t st) {
     FusedParams p;
     p.a_src0 = a.a_src0; p.a_src1 = a.a_src1; p.b_src = a.b_src; p.img = a.img;
-    p.a_w = a.a_w; p.a_bias = a.a_bias; p.b_w = a.b_w; p.b_bias = a.b_bias; p.a_dst = a.a_dst; p.b_dst = a.b_dst;
+    p.a_w = a.a_w; p.a_bias = a.a_bias; p.b_w = a.b_w; p.b_bias = a.b_bias; p.b2_bias = a.b2_bias; p.a_dst = a.a_dst; p.b_dst = a.b_dst;
     p.enhanced = a.enhanced; p.adjust = a.adjust; p.u8 = a.u8;
     p.N = a.N; p.H = a.H; p.W = a.W; p.y_begin = a.y_begin; p.y_end = a.y_end; p.rows_per_block = a.rows_per_block;
     p.n_begin = a.n_begin;

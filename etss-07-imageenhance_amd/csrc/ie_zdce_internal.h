@@ -16,7 +16,7 @@ int ie_zdce_launch_conv1(const float* img, const float* wk, const float* bias, v
 struct ZdceFusedLaunch {
     int kind, dtype;
     const void* a_src0; const void* a_src1; const void* b_src; const float* img;
-    const void* a_w; const float* a_bias; const void* b_w; const float* b_bias;
+    const void* a_w; const float* a_bias; const void* b_w; const float* b_bias; const float* b2_bias;
     void* a_dst; void* b_dst; float* enhanced; float* adjust; unsigned char* u8;
     int N, H, W, y_begin, y_end, n_begin, n_count, rows_per_block;
     void* stamps;   // diagnostic builds only

@@ -42,6 +42,8 @@ struct ie_zdce_plan {
     char* d_w = nullptr;
     size_t off_w[NL] = {0}, off_b[NL] = {0};
     size_t off_w1m = 0;   // e_conv1 as MFMA A fragments (fused K12 kernel)
+    size_t off_w27 = 0;   // K12 stage B: e_conv2 fragments followed by the x1 half of e_conv7
+    size_t off_w7b = 0;   // K67 stage B: the x6 half of e_conv7
     // workspace
     char* ws = nullptr;
     size_t ws_bytes = 0;
@@ -192,6 +194,37 @@ IE_EXPORT int ie_zdce_finalize(ie_zdce_plan* p, void* stream) {
         const char* q = (const char*)hw.data();
         host.insert(host.end(), q, q + hw.size() * 2);
     }
+    if (dt != IE_F32) {
+        // e_conv7([x1, x6]) = W7a * x1 + W7b * x6.  K12 computes P = W7a*x1 + bias7 next to e_conv2 (one fragment
+        // buffer [hc][e_conv2 9 | e_conv7a 9]), K67 adds W7b * x6.  Same fragment order as above.
+        auto pack9 = [&](std::vector<unsigned short>& hw, size_t base, int hc, const float* w, int Co, int Ci, int ci0) {
+            for (int t = 0; t < 9; ++t) for (int lane = 0; lane < 64; ++lane) for (int j = 0; j < 8; ++j) {
+                const int co = 16 * hc + (lane & 15);
+                const int ci = ci0 + 8 * (lane >> 4) + j;
+                const float v = co < Co ? w[((size_t)co * Ci + ci) * 9 + t] : 0.f;
+                hw[base + ((size_t)t * 64 + lane) * 8 + j] = dt == IE_F16 ? f32_to_f16_bits(v) : f32_to_bf16_bits(v);
+            }
+        };
+        align(256);
+        p->off_w27 = host.size();
+        {
+            std::vector<unsigned short> hw((size_t)2 * 18 * 64 * 8, 0);
+            for (int hc = 0; hc < 2; ++hc) {
+                pack9(hw, ((size_t)hc * 18 + 0) * 64 * 8, hc, p->w[1].data(), 32, 32, 0);
+                pack9(hw, ((size_t)hc * 18 + 9) * 64 * 8, hc, p->w[6].data(), 24, 64, 0);
+            }
+            const char* q = (const char*)hw.data();
+            host.insert(host.end(), q, q + hw.size() * 2);
+        }
+        align(256);
+        p->off_w7b = host.size();
+        {
+            std::vector<unsigned short> hw((size_t)2 * 9 * 64 * 8, 0);
+            for (int hc = 0; hc < 2; ++hc) pack9(hw, (size_t)hc * 9 * 64 * 8, hc, p->w[6].data(), 24, 64, 32);
+            const char* q = (const char*)hw.data();
+            host.insert(host.end(), q, q + hw.size() * 2);
+        }
+    }
     if (p->d_w) { (void)hipFree(p->d_w); p->d_w = nullptr; }
     IE_HIP_CHECK(hipMalloc(&p->d_w, host.size()));
     hipStream_t st = (hipStream_t)stream;
@@ -313,13 +346,13 @@ static int forward_mfma(ie_zdce_plan* p, const float* image, float* enhanced, fl
                 a.img = image;
                 a.stamps = g_ie_stamps ? (void*)((unsigned long long*)g_ie_stamps + (size_t)(kind == 12 ? 0 : kind == 45 ? 1 : 2) * (1u << 20)) : nullptr;
                 if (kind == 12) {
-                    a.a_w = p->d_w + p->off_w1m; a.a_bias = B_(0); a.b_w = W_(1); a.b_bias = B_(1);
-                    a.a_dst = x[1]; a.b_dst = x[2]; a.y_begin = lo(2); a.y_end = hi(2);
+                    a.a_w = p->d_w + p->off_w1m; a.a_bias = B_(0); a.b_w = p->d_w + p->off_w27; a.b_bias = B_(1); a.b2_bias = B_(6);
+                    a.a_dst = x[1]; a.b_dst = x[2]; a.y_begin = lo(2); a.y_end = hi(2);   // x[1] holds P = W7a*x1 + bias7, not x1
                 } else if (kind == 45) {
                     a.a_src0 = x[3]; a.a_w = W_(3); a.a_bias = B_(3); a.b_w = W_(4); a.b_bias = B_(4);
                     a.b_dst = x[5]; a.y_begin = lo(5); a.y_end = hi(5);
                 } else {
-                    a.a_src0 = x[2]; a.a_src1 = x[5]; a.b_src = x[1]; a.a_w = W_(5); a.a_bias = B_(5); a.b_w = W_(6); a.b_bias = B_(6);
+                    a.a_src0 = x[2]; a.a_src1 = x[5]; a.b_src = x[1]; a.a_w = W_(5); a.a_bias = B_(5); a.b_w = p->d_w + p->off_w7b; a.b_bias = B_(6);
                     a.enhanced = enhanced; a.adjust = adjust; a.u8 = u8; a.y_begin = b0; a.y_end = b1;
                 }
                 return ie_zdce_launch_fused(a, st);

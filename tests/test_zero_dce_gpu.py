@@ -53,14 +53,14 @@ def test_golden_parity(path, dtype):
 @pytest.mark.parametrize("variant", [0, capi.VAR_UNFUSED])
 @pytest.mark.parametrize("dtype", ["f32", "f16", "bf16"])
 def test_feature_parity_per_layer(dtype, variant):
-    """x1..x6 against the oracle.  The fused schedule keeps x4 and x6 in LDS only, so they are
-    checked on the one-kernel-per-layer schedule."""
+    """x1..x6 against the oracle.  The fused schedule keeps x1, x4 and x6 in LDS only (x1's HBM slot holds
+    P = W7a*x1 + bias7 instead), so those are checked on the one-kernel-per-layer schedule."""
     sd, g = load_golden(zero_dce_goldens()[-1])
     m = _model(sd, dtype, variant)
     x = torch.from_numpy(g["image"])
     ref = o_zdce.forward(sd, x, return_features=True)["_features"]
     m.enhance(x.cuda())
-    in_hbm = range(1, 7) if (variant or dtype == "f32") else (1, 2, 3, 5)
+    in_hbm = range(1, 7) if (variant or dtype == "f32") else (2, 3, 5)
     for k in in_hbm:
         f = m.feature(k).cpu()
         assert rel_err(f, ref[k - 1]) <= TOL_FEAT[dtype], f"x{k}"
