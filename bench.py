@@ -28,9 +28,9 @@ KERNEL_WORK = {
     "zdce_conv1": (_L[0], 12 + 64), "zdce_conv2": (_L[1], 128), "zdce_conv3": (_L[2], 128), "zdce_conv4": (_L[3], 128),
     "zdce_conv5": (_L[4], 192), "zdce_conv6": (_L[5], 192), "zdce_conv7_curve": (_L[6], 128 + 12 + 12),
     # fused strip kernels: the intermediate of the pair stays in LDS
-    "zdce_k12_conv1_conv2": (_L[0] + _L[1], 12 + 64 + 64),           # image in, x1 and x2 out
+    "zdce_k12_conv1_conv2": (_L[0] + _L[1] + 2 * 288 * 24, 12 + 64 + 64),   # image in; x2 and P = W7a*x1 + b7 out
     "zdce_k45_conv4_conv5": (_L[3] + _L[4], 64 + 64),                # x3 in, x5 out (x4 in LDS)
-    "zdce_k67_conv6_conv7_curve": (_L[5] + _L[6], 3 * 64 + 12 + 12),  # x2, x5, x1, image in, enhanced out
+    "zdce_k67_conv6_conv7_curve": (_L[5] + 2 * 288 * 24, 3 * 64 + 12 + 12),  # x2, x5, P, image in, enhanced out
 }
 PEAK_MFMA_TFLOPS = 2500.0                 # dense bf16/f16, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
@@ -57,15 +57,24 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
+    # IE_BENCH_BACKEND=gloo + IE_BENCH_ONE_DEVICE=1: rehearsal of the multi-rank control flow on a 1-GPU box
+    backend = os.environ.get("IE_BENCH_BACKEND", "nccl")
+    if os.environ.get("IE_BENCH_ONE_DEVICE"):
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        if backend == "nccl":
+            try:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            except TypeError:
+                dist.init_process_group("nccl", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")
 
     from oracle import zero_dce as o_zdce      # only for the seeded weight rule + the CPU baseline leg
     sd = o_zdce.init_state_dict(seed=1, gain=3.0)
@@ -92,7 +101,7 @@ def main():
     sync_all()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

@@ -1,0 +1,42 @@
+#!/usr/bin/env python
+"""Throughput of the other generators (fp32 NHWC parity path) at 1080p on one GPU, with the CPU oracle beside
+them on a bounded sample.  Not the headline metric (bench.py); numbers go to DESIGN.md / profiles/."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+
+import mon_amd
+from oracle import generators as og
+
+GFLOP = {"unet32": 634.5, "unet32_ps": None, "unet64": 2530.0, "llunet++": 11495.7, "retinexnet": 1374.5, "zero_dce++": 41.8}
+CASES = [
+    ("zero_dce++", dict(name="zero_dce++_re", seed=1), 4, (1080, 1920)),
+    ("unet32", dict(name="unet", seed=1, base_channels=32, num_classes=3, enhance=True), 2, (1080, 1920)),
+    ("unet32_ps", dict(name="unet", seed=1, base_channels=32, num_classes=3, enhance=True, upsampler="pixelshuffle"), 2, (1080, 1920)),
+    ("retinexnet", dict(name="retinexnet", seed=1), 2, (1080, 1920)),
+    ("llunet++", dict(name="llunet++_re", seed=1), 1, (1088, 1920)),
+]
+only = sys.argv[1:]
+for tag, cfg, n, hw in CASES:
+    if only and tag not in only:
+        continue
+    m = mon_amd.MODELS.build(**cfg).to("cuda")
+    x = torch.rand(n, 3, *hw, device="cuda")
+    m.forward({"image": x}); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 2
+    for _ in range(reps):
+        out = m.forward({"image": x})
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    rec = {"model": tag, "frames": n, "hw": hw, "ms_per_frame": round(dt / n * 1e3, 2), "frames_per_s": round(n / dt, 3)}
+    if GFLOP.get(tag):
+        rec["tflops"] = round(GFLOP[tag] * n / dt / 1e3, 2)
+    print(json.dumps(rec), flush=True)
+    del m, x, out
+    torch.cuda.empty_cache()
