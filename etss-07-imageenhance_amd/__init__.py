@@ -17,8 +17,11 @@ from . import ops
 from .generators import ZeroDCEpp_RE, LLUnetpp_RE, UNet, ZeroIGEnhance, RetinexNet
 from . import image
 from . import sharding
+from . import losses, train
+from .losses import LOSSES
+from .train import Trainer
 
 __version__ = "0.1.0"
 __all__ = ["Factory", "ModelFactory", "MODELS", "Task", "Scheme", "capi", "Model", "VisionModel",
            "ImageEnhancementModel", "ZeroDCE_RE", "ZeroDCEpp_RE", "LLUnetpp_RE", "UNet", "ZeroIGEnhance", "RetinexNet",
-           "ops", "image", "sharding"]
+           "ops", "image", "sharding", "losses", "train", "LOSSES", "Trainer"]

@@ -18,6 +18,7 @@ DTYPES = {"f32": IE_F32, "fp32": IE_F32, "float32": IE_F32, "f16": IE_F16, "fp16
           "bf16": IE_BF16, "bfloat16": IE_BF16}
 ACT = {"none": 0, "relu": 1, "lrelu": 2, "tanh": 3, "sigmoid": 4}
 PAD = {"zeros": 0, "replicate": 1}
+SUMSQ_WS_DOUBLES = 2048
 VAR_SYNC_STAGE, VAR_NARROW_STORE, VAR_NO_DMA, VAR_UNFUSED = 1, 2, 4, 8
 
 # every exported symbol of include/ie_hip.h (checked by tests/test_capi_symbols.py)
@@ -28,6 +29,9 @@ SYMBOLS = [
     "ie_conv2d_nhwc_f32", "ie_pack_weight_hwio_f32", "ie_le_curve",
     "ie_convn_nhwc_f32", "ie_instnorm_nhwc_f32", "ie_maxpool2x2_nhwc_f32", "ie_resize_nhwc_f32", "ie_pixel_shuffle_nhwc_f32",
     "ie_conv_transpose2x2_nhwc_f32", "ie_pad_nhwc_f32", "ie_eltwise_nhwc_f32", "ie_max_concat_nhwc_f32",
+    "ie_norm_forward_nhwc_f32", "ie_norm_backward_nhwc_f32", "ie_convn_wgrad_nhwc_f32", "ie_convn_dgrad_nhwc_f32",
+    "ie_maxpool2x2_backward_nhwc_f32", "ie_resize_backward_nhwc_f32", "ie_crop_nhwc_f32", "ie_pixel_unshuffle_nhwc_f32",
+    "ie_act_backward_f32", "ie_l1_loss_f32", "ie_ssim_forward_f32", "ie_ssim_backward_f32", "ie_sumsq_f32", "ie_adam_step_f32",
     "ie_zdce_create", "ie_zdce_set_layer", "ie_zdce_finalize", "ie_zdce_reserve", "ie_zdce_forward",
     "ie_zdce_get_feature", "ie_zdce_workspace_bytes", "ie_zdce_destroy", "ie_zdce_time_forward",
     "ie_zdce_profile_forward", "ie_zdce_set_tuning",
@@ -90,6 +94,21 @@ def lib():
     L.ie_pad_nhwc_f32.argtypes = [vp, vp, ip, ip, ip, ip, ip, ip, ip, ip, vp]
     L.ie_eltwise_nhwc_f32.argtypes = [ip, vp, vp, vp, C.c_size_t, ip, ip, fp, fp, vp]
     L.ie_max_concat_nhwc_f32.argtypes = [vp, vp, C.c_size_t, ip, vp]
+    i64, sz = C.c_int64, C.c_size_t
+    L.ie_norm_forward_nhwc_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, fp, ip, ip, ip, ip, ip, ip, ip, fp, ip, fp, vp]
+    L.ie_norm_backward_nhwc_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ip, ip, ip, ip, ip, ip, ip, ip, ip, fp, vp]
+    L.ie_convn_wgrad_nhwc_f32.argtypes = [C.POINTER(ConvNDesc), C.POINTER(vp), C.POINTER(ip), vp, vp, vp, ip, vp, vp]
+    L.ie_convn_dgrad_nhwc_f32.argtypes = [C.POINTER(ConvNDesc), vp, vp, C.POINTER(vp), C.POINTER(ip), C.POINTER(ip), vp]
+    L.ie_maxpool2x2_backward_nhwc_f32.argtypes = [vp, vp, vp, ip, ip, ip, ip, ip, vp]
+    L.ie_resize_backward_nhwc_f32.argtypes = [vp, vp, ip, ip, ip, ip, ip, ip, ip, ip, vp]
+    L.ie_crop_nhwc_f32.argtypes = [vp, vp, ip, ip, ip, ip, ip, ip, ip, ip, ip, vp]
+    L.ie_pixel_unshuffle_nhwc_f32.argtypes = [vp, vp, ip, ip, ip, ip, ip, ip, vp]
+    L.ie_act_backward_f32.argtypes = [vp, vp, vp, sz, ip, fp, fp, fp, ip, vp]
+    L.ie_l1_loss_f32.argtypes = [vp, vp, sz, vp, vp, fp, ip, vp]
+    L.ie_ssim_forward_f32.argtypes = [vp, vp, ip, ip, ip, ip, i64, i64, i64, i64, fp, fp, fp, fp, vp, vp, vp]
+    L.ie_ssim_backward_f32.argtypes = [vp, vp, vp, vp, vp, ip, ip, ip, ip, i64, i64, i64, i64, fp, fp, ip, ip, vp]
+    L.ie_sumsq_f32.argtypes = [vp, sz, fp, vp, vp, ip, vp]
+    L.ie_adam_step_f32.argtypes = [vp, vp, vp, vp, sz, ip, fp, fp, fp, fp, fp, fp, vp, fp, vp]
     L.ie_zdce_create.argtypes = [C.POINTER(ZdceConfig), C.POINTER(vp)]
     L.ie_zdce_set_layer.argtypes = [vp, ip, vp, vp, ip, ip]
     L.ie_zdce_finalize.argtypes = [vp, vp]

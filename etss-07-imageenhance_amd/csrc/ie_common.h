@@ -100,4 +100,23 @@ __device__ __forceinline__ unsigned char ie_quant_u8(float v) {
     q = fminf(fmaxf(q, 0.0f), 255.0f);
     return (unsigned char)q;
 }
+// activation and its derivative expressed in the OUTPUT y (what the backward pass keeps)
+__device__ __forceinline__ float ie_act_apply(float v, int act, float slope) {
+    switch (act) {
+    case IE_ACT_RELU: return fmaxf(v, 0.f);
+    case IE_ACT_LRELU: return v > 0.f ? v : v * slope;
+    case IE_ACT_TANH: return tanhf(v);
+    case IE_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+    default: return v;
+    }
+}
+__device__ __forceinline__ float ie_act_grad_from_output(float y, int act, float slope) {
+    switch (act) {
+    case IE_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+    case IE_ACT_LRELU: return y > 0.f ? 1.f : slope;
+    case IE_ACT_TANH: return 1.f - y * y;
+    case IE_ACT_SIGMOID: return y * (1.f - y);
+    default: return 1.f;
+    }
+}
 #endif

@@ -1,0 +1,185 @@
+// Normalisation layers on NHWC fp32, forward and backward: InstanceNorm2d (statistics per (n, c)) and
+// training-mode BatchNorm2d (statistics per c over N*H*W), optional channel sub-range (HINet's half
+// instance norm), fused affine + activation.  All passes are HBM-bound streams; the per-channel sums are
+// double-precision block partials + atomics (wave64 lanes walk channels, so loads stay coalesced).
+// Reference call sites are cited at the entry points in include/ie_hip.h.
+#include "ie_common.h"
+#include <math.h>
+
+namespace {
+
+inline unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }
+
+// thread = (pixel slot, channel); accumulates sum / sum of squares of x, or of g and g*xhat (backward)
+template <bool BWD>
+__global__ void norm_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ yact,
+                                   const float* __restrict__ mean, const float* __restrict__ inv, double* __restrict__ stats,
+                                   int HW, int C, int c0, int cn, int cn_total, int c_off, int n_mul, int act, float slope) {
+    const int n = blockIdx.y;
+    const int tpc = max(1, 256 / cn);
+    const int c = threadIdx.x % cn, ps = threadIdx.x / cn;
+    const int g = n * n_mul;
+    double s = 0.0, ss = 0.0;
+    if (ps < tpc) {
+        const size_t base = (size_t)n * HW * C + c0 + c;
+        float m = 0.f, iv = 1.f;
+        if (BWD) { m = mean[(size_t)g * cn_total + c_off + c]; iv = inv[(size_t)g * cn_total + c_off + c]; }
+        for (int pix = blockIdx.x * tpc + ps; pix < HW; pix += gridDim.x * tpc) {
+            const size_t i = base + (size_t)pix * C;
+            if (BWD) {
+                float gr = dy[i];
+                if (act != IE_ACT_NONE) gr *= ie_act_grad_from_output(yact[i], act, slope);
+                const float xh = (x[i] - m) * iv;
+                s += gr; ss += (double)gr * xh;
+            } else {
+                const float v = x[i];
+                s += v; ss += (double)v * v;
+            }
+        }
+    }
+    __shared__ double sh[2][256];
+    sh[0][threadIdx.x] = s; sh[1][threadIdx.x] = ss;
+    __syncthreads();
+    if (ps == 0) {
+        for (int k = 1; k < tpc; ++k) { s += sh[0][k * cn + c]; ss += sh[1][k * cn + c]; }
+        atomicAdd(&stats[((size_t)g * cn_total + c_off + c) * 2 + 0], s);
+        atomicAdd(&stats[((size_t)g * cn_total + c_off + c) * 2 + 1], ss);
+    }
+}
+
+// mean / 1/sqrt(var+eps) per (group, channel); BatchNorm running statistics (unbiased variance, nn.BatchNorm2d)
+__global__ void norm_finalize_kernel(const double* __restrict__ stats, float* __restrict__ mean, float* __restrict__ inv, int total,
+                                     double count, float eps, float* run_mean, float* run_var, float momentum) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const double m = stats[2 * (size_t)i] / count;
+    const double var = fmax(stats[2 * (size_t)i + 1] / count - m * m, 0.0);
+    mean[i] = (float)m;
+    inv[i] = (float)(1.0 / sqrt(var + (double)eps));
+    if (run_mean) {
+        run_mean[i] = (1.f - momentum) * run_mean[i] + momentum * (float)m;
+        const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+        run_var[i] = (1.f - momentum) * run_var[i] + momentum * (float)unb;
+    }
+}
+
+__global__ void norm_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ inv,
+                                  const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y, int HW,
+                                  int C, int c0, int cn, int n_mul, int act, float slope, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    float v = x[i];
+    if (c >= c0 && c < c0 + cn) {
+        const size_t g = (i / ((size_t)HW * C)) * n_mul;
+        v = (v - mean[g * cn + (c - c0)]) * inv[g * cn + (c - c0)];
+        if (gamma) v = v * gamma[c - c0] + beta[c - c0];
+    }
+    y[i] = ie_act_apply(v, act, slope);
+}
+
+// dx = gamma * inv * (g - mean(g) - xhat * mean(g * xhat)); channels outside the range: dx = g
+__global__ void norm_backward_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ yact,
+                                           const float* __restrict__ mean, const float* __restrict__ inv,
+                                           const float* __restrict__ gamma, const double* __restrict__ stats, float* __restrict__ dx,
+                                           int HW, int C, int c0, int cn, int n_mul, double count, int act, float slope, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    float gr = dy[i];
+    if (act != IE_ACT_NONE) gr *= ie_act_grad_from_output(yact[i], act, slope);
+    if (c >= c0 && c < c0 + cn) {
+        const size_t k = (i / ((size_t)HW * C)) * n_mul * cn + (c - c0);
+        const float iv = inv[k];
+        const float xh = (x[i] - mean[k]) * iv;
+        const float m1 = (float)(stats[2 * k] / count), m2 = (float)(stats[2 * k + 1] / count);
+        gr = (gamma ? gamma[c - c0] : 1.f) * iv * (gr - m1 - xh * m2);
+    }
+    dx[i] = gr;
+}
+
+// dgamma[c] = sum over groups of sum(g * xhat), dbeta[c] = sum over groups of sum(g)
+__global__ void norm_param_grad_kernel(const double* __restrict__ stats, float* dgamma, float* dbeta, int groups, int cn, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cn) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int g = 0; g < groups; ++g) { s1 += stats[((size_t)g * cn + c) * 2]; s2 += stats[((size_t)g * cn + c) * 2 + 1]; }
+    dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)s2;
+    dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
+}
+
+template <bool BWD>
+int launch_reduce(const float* x, const float* dy, const float* yact, const float* mean, const float* inv, double* ws, int N, int HW,
+                  int C, int c_begin, int c_count, int n_mul, int act, float slope, hipStream_t st) {
+    const int groups = n_mul ? N : 1;
+    IE_HIP_CHECK(hipMemsetAsync(ws, 0, sizeof(double) * 2 * (size_t)groups * c_count, st));
+    for (int off = 0; off < c_count; off += 256) {     // <= 256 channels per launch (one thread column each)
+        const int cn = (c_count - off) < 256 ? (c_count - off) : 256;
+        const int tpc = 256 / cn > 0 ? 256 / cn : 1;
+        int chunks = ie_cdiv(HW, tpc * 64);
+        const int cap = n_mul ? 1024 : (N >= 16 ? 64 : 1024 / N);
+        if (chunks > cap) chunks = cap;
+        if (chunks < 1) chunks = 1;
+        hipLaunchKernelGGL(norm_reduce_kernel<BWD>, dim3(chunks, N), dim3(256), 0, st, x, dy, yact, mean, inv, ws, HW, C, c_begin + off,
+                           cn, c_count, off, n_mul, act, slope);
+        IE_LAUNCH_CHECK();
+    }
+    return IE_OK;
+}
+
+}  // namespace
+
+IE_EXPORT int ie_norm_forward_nhwc_f32(const float* x, const float* gamma, const float* beta, float* y, double* ws, float* save_mean,
+                                       float* save_invstd, float* running_mean, float* running_var, float momentum, int per_sample,
+                                       int N, int H, int W, int C, int c_begin, int c_count, float eps, int act, float slope,
+                                       void* stream) {
+    if (!x || !y || !ws || !save_mean || !save_invstd || N <= 0 || H <= 0 || W <= 0 || C <= 0 || c_begin < 0 || c_count <= 0 ||
+        c_begin + c_count > C || (gamma == nullptr) != (beta == nullptr) || (running_mean == nullptr) != (running_var == nullptr) ||
+        (per_sample && running_mean))
+        IE_FAIL(IE_ERR_INVALID, "ie_norm_forward_nhwc_f32: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    const int HW = H * W, n_mul = per_sample ? 1 : 0, groups = per_sample ? N : 1;
+    int rc = launch_reduce<false>(x, nullptr, nullptr, nullptr, nullptr, ws, N, HW, C, c_begin, c_count, n_mul, 0, 0.f, st);
+    if (rc != IE_OK) return rc;
+    const double count = per_sample ? (double)HW : (double)N * HW;
+    hipLaunchKernelGGL(norm_finalize_kernel, dim3(nblk((size_t)groups * c_count)), dim3(256), 0, st, ws, save_mean, save_invstd,
+                       groups * c_count, count, eps, running_mean, running_var, momentum);
+    IE_LAUNCH_CHECK();
+    const size_t total = (size_t)N * HW * C;
+    hipLaunchKernelGGL(norm_apply_kernel, dim3(nblk(total)), dim3(256), 0, st, x, save_mean, save_invstd, gamma, beta, y, HW, C, c_begin,
+                       c_count, n_mul, act, slope, total);
+    IE_LAUNCH_CHECK();
+    return IE_OK;
+}
+
+IE_EXPORT int ie_instnorm_nhwc_f32(const float* x, const float* gamma, const float* beta, float* y, double* stats_ws, int N, int H,
+                                   int W, int C, int c_begin, int c_count, float eps, int act, float slope, void* stream) {
+    if (!stats_ws || N <= 0 || c_count <= 0) IE_FAIL(IE_ERR_INVALID, "ie_instnorm_nhwc_f32: bad args");
+    float* mean = (float*)(stats_ws + 2 * (size_t)N * c_count);
+    return ie_norm_forward_nhwc_f32(x, gamma, beta, y, stats_ws, mean, mean + (size_t)N * c_count, nullptr, nullptr, 0.f, 1, N, H, W, C,
+                                    c_begin, c_count, eps, act, slope, stream);
+}
+
+IE_EXPORT int ie_norm_backward_nhwc_f32(const float* x, const float* dy, const float* y, const float* gamma, const float* save_mean,
+                                        const float* save_invstd, double* ws, float* dx, float* dgamma, float* dbeta,
+                                        int accumulate_param_grads, int per_sample, int N, int H, int W, int C, int c_begin,
+                                        int c_count, int act, float slope, void* stream) {
+    if (!x || !dy || !save_mean || !save_invstd || !ws || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || c_begin < 0 || c_count <= 0 ||
+        c_begin + c_count > C || (act != IE_ACT_NONE && !y) || (dgamma == nullptr) != (dbeta == nullptr))
+        IE_FAIL(IE_ERR_INVALID, "ie_norm_backward_nhwc_f32: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    const int HW = H * W, n_mul = per_sample ? 1 : 0, groups = per_sample ? N : 1;
+    int rc = launch_reduce<true>(x, dy, y, save_mean, save_invstd, ws, N, HW, C, c_begin, c_count, n_mul, act, slope, st);
+    if (rc != IE_OK) return rc;
+    const double count = per_sample ? (double)HW : (double)N * HW;
+    const size_t total = (size_t)N * HW * C;
+    hipLaunchKernelGGL(norm_backward_apply_kernel, dim3(nblk(total)), dim3(256), 0, st, x, dy, y, save_mean, save_invstd, gamma, ws, dx,
+                       HW, C, c_begin, c_count, n_mul, count, act, slope, total);
+    IE_LAUNCH_CHECK();
+    if (dgamma) {
+        hipLaunchKernelGGL(norm_param_grad_kernel, dim3(nblk(c_count)), dim3(256), 0, st, ws, dgamma, dbeta, groups, c_count,
+                           accumulate_param_grads);
+        IE_LAUNCH_CHECK();
+    }
+    return IE_OK;
+}

@@ -1,6 +1,6 @@
 // fp32 NHWC building blocks of the U-Net / LLUnet++ / RetinexNet / Zero-DCE++ generators (parity path):
 // multi-source conv (virtual concat of up to 8 tensors) with fused bias + activation + residual +
-// clamp, instance norm, 2x2 max-pool, resize (nearest / bilinear), pixel-shuffle, 2x2 stride-2
+// clamp, 2x2 max-pool, resize (nearest / bilinear), pixel-shuffle, 2x2 stride-2
 // transposed conv, zero pad, broadcast multiply, RetinexNet's max-channel concat.
 // All streaming kernels are HBM-bound (one read + one write of the tensor); the conv runs on the VALU.
 // Reference call sites are cited at each entry point in include/ie_hip.h.
@@ -9,15 +9,7 @@
 
 namespace {
 
-__device__ __forceinline__ float act_f(float v, int act, float slope) {
-    switch (act) {
-    case IE_ACT_RELU: return fmaxf(v, 0.f);
-    case IE_ACT_LRELU: return v > 0.f ? v : v * slope;
-    case IE_ACT_TANH: return tanhf(v);
-    case IE_ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
-    default: return v;
-    }
-}
+__device__ __forceinline__ float act_f(float v, int act, float slope) { return ie_act_apply(v, act, slope); }
 
 constexpr int MAXS = IE_CONV_MAX_SRC;
 constexpr int CT = 8;   // output channels per thread
@@ -98,52 +90,6 @@ __global__ __launch_bounds__(256) void convn_direct_kernel(ConvNParams p) {
             if (p.clamp) v = fminf(fmaxf(v, p.lo), p.hi);
             p.dst[ob + o] = v;
         }
-}
-
-// ---- instance norm ---------------------------------------------------------------------------------
-// pass 1: per (n, c) sum and sum of squares.  Block = 256 threads = 64 pixels-lanes x 4 channel groups? No:
-// thread = (pixel stripe, channel): each thread walks pixels with stride, one channel -> coalesced across c.
-__global__ void instnorm_stats_kernel(const float* __restrict__ x, double* __restrict__ stats, int HW, int C, int c0,
-                                      int cn, int cn_total, int c_off) {
-    // grid: (chunks of pixels, N); block: 256 threads; thread t handles channel c0 + t % cn for pixels t / cn + k*(256/cn)...
-    const int n = blockIdx.y;
-    const int tpc = max(1, 256 / cn);            // pixel slots per block
-    const int c = threadIdx.x % cn, ps = threadIdx.x / cn;
-    double s = 0.0, ss = 0.0;
-    if (ps < tpc && c < cn) {
-        const float* xp = x + (size_t)n * HW * C + c0 + c;
-        for (int pix = blockIdx.x * tpc + ps; pix < HW; pix += gridDim.x * tpc) {
-            const float v = xp[(size_t)pix * C];
-            s += v; ss += (double)v * v;
-        }
-    }
-    __shared__ double sh[2][256];
-    sh[0][threadIdx.x] = s; sh[1][threadIdx.x] = ss;
-    __syncthreads();
-    if (ps == 0 && c < cn) {
-        for (int k = 1; k < tpc; ++k) { s += sh[0][k * cn + c]; ss += sh[1][k * cn + c]; }
-        atomicAdd(&stats[((size_t)n * cn_total + c_off + c) * 2 + 0], s);
-        atomicAdd(&stats[((size_t)n * cn_total + c_off + c) * 2 + 1], ss);
-    }
-}
-// pass 2: y = (x - mean) * rsqrt(var + eps) * gamma + beta, activation; channels outside [c0, c0+cn) copied
-__global__ void instnorm_apply_kernel(const float* __restrict__ x, const double* __restrict__ stats,
-                                      const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y,
-                                      int HW, int C, int c0, int cn, float eps, int act, float slope, size_t total) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int c = (int)(i % C);
-    const size_t n = i / ((size_t)HW * C);
-    float v = x[i];
-    if (c >= c0 && c < c0 + cn) {
-        const double s = stats[(n * cn + (c - c0)) * 2], ss = stats[(n * cn + (c - c0)) * 2 + 1];
-        const double mean = s / HW;
-        const double var = fmax(ss / HW - mean * mean, 0.0);
-        const float inv = (float)(1.0 / sqrt(var + (double)eps));
-        v = (v - (float)mean) * inv;
-        if (gamma) v = v * gamma[c - c0] + beta[c - c0];
-    }
-    y[i] = act_f(v, act, slope);
 }
 
 __global__ void maxpool2_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int C, int Ho, int Wo,
@@ -287,30 +233,6 @@ IE_EXPORT int ie_convn_nhwc_f32(ie_convn_desc* d, const float* const* srcs, cons
     p.clamp = d->clamp; p.lo = d->clamp_lo; p.hi = d->clamp_hi;
     dim3 grid(ie_cdiv(d->Ho * d->Wo, 64), ie_cdiv(d->Cout, 4 * CT), d->N);
     hipLaunchKernelGGL(convn_direct_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
-    IE_LAUNCH_CHECK();
-    return IE_OK;
-}
-
-IE_EXPORT int ie_instnorm_nhwc_f32(const float* x, const float* gamma, const float* beta, float* y, double* stats_ws, int N,
-                                   int H, int W, int C, int c_begin, int c_count, float eps, int act, float slope, void* stream) {
-    if (!x || !y || !stats_ws || N <= 0 || H <= 0 || W <= 0 || C <= 0 || c_begin < 0 || c_count <= 0 || c_begin + c_count > C ||
-        (gamma == nullptr) != (beta == nullptr))
-        IE_FAIL(IE_ERR_INVALID, "ie_instnorm_nhwc_f32: bad args");
-    hipStream_t st = (hipStream_t)stream;
-    const int HW = H * W;
-    IE_HIP_CHECK(hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * (size_t)N * c_count, st));
-    for (int off = 0; off < c_count; off += 256) {     // <= 256 channels per launch (one thread column each)
-        const int cn = (c_count - off) < 256 ? (c_count - off) : 256;
-        const int tpc = 256 / cn > 0 ? 256 / cn : 1;
-        int chunks = ie_cdiv(HW, tpc * 64);
-        if (chunks > 1024) chunks = 1024;
-        if (chunks < 1) chunks = 1;
-        hipLaunchKernelGGL(instnorm_stats_kernel, dim3(chunks, N), dim3(256), 0, st, x, stats_ws, HW, C, c_begin + off, cn, c_count, off);
-        IE_LAUNCH_CHECK();
-    }
-    const size_t total = (size_t)N * HW * C;
-    hipLaunchKernelGGL(instnorm_apply_kernel, dim3(nblk(total)), dim3(256), 0, st, x, stats_ws, gamma, beta, y, HW, C, c_begin,
-                       c_count, eps, act, slope, total);
     IE_LAUNCH_CHECK();
     return IE_OK;
 }

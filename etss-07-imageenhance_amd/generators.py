@@ -363,6 +363,40 @@ class UNet(_GraphModel):
         out["enhanced" if self.enhance else "semantic"] = ops.to_nchw(y)
         return out
 
+    def forward_train(self, x, store, tape):
+        """Training-mode graph (BatchNorm on batch statistics, running stats updated; activations kept on ``tape``):
+        what ``model.train(); model(x)`` runs in the reference (unet.py:35-197).  Returns the NHWC prediction."""
+        from . import train as T
+
+        def dc(name, srcs):
+            y = None
+            for i in (1, 2):
+                cn, nn_ = f"{name}.conv{i}", f"{name}.norm{i}"
+                z = T.t_conv(tape, srcs, store.conv(cn), *store.conv_grads(cn))
+                y = T.t_norm(tape, z, store.view(f"{nn_}.weight"), store.view(f"{nn_}.bias"), store.view(f"{nn_}.weight", store.grads),
+                             store.view(f"{nn_}.bias", store.grads), per_sample=False, running_mean=store.buffers[f"{nn_}.running_mean"],
+                             running_var=store.buffers[f"{nn_}.running_var"], momentum=0.1, eps=1e-5, act="relu")
+                srcs = [y]
+            return y
+
+        def up(k, a, skip):
+            if self.upsampler == "bilinear":
+                a = T.t_resize(tape, a, (a.shape[2] * 2, a.shape[3] * 2), "bilinear_align")
+            else:
+                a = T.t_pixel_shuffle(tape, T.t_conv(tape, a, store.conv(f"up{k}.up.0"), *store.conv_grads(f"up{k}.up.0")), 2)
+            dy, dx = skip.shape[2] - a.shape[2], skip.shape[3] - a.shape[3]
+            a = T.t_pad(tape, a, dy // 2, dy - dy // 2, dx // 2, dx - dx // 2)
+            return dc(f"up{k}.conv", [skip, a])
+
+        x1 = dc("inc", [x])
+        x2 = dc("down1.conv", [T.t_maxpool(tape, x1)])
+        x3 = dc("down2.conv", [T.t_maxpool(tape, x2)])
+        x4 = dc("down3.conv", [T.t_maxpool(tape, x3)])
+        x5 = dc("down4.conv", [T.t_maxpool(tape, x4)])
+        y = up(1, x5, x4); y = up(2, y, x3); y = up(3, y, x2); y = up(4, y, x1)
+        y = T.t_conv(tape, y, store.conv("outc.conv"), *store.conv_grads("outc.conv"), pad=0)
+        return T.t_clamp(tape, y, 0.0, 1.0) if self.enhance else y
+
     def assert_outputs(self, outputs: dict):
         if not self.enhance:
             return

@@ -123,7 +123,7 @@ def instance_norm(x, gamma=None, beta=None, eps=1e-5, act="none", slope=0.0, c_b
     n, c, h, w = x.shape
     c_count = c - c_begin if c_count is None else c_count
     y = torch.empty_like(x, memory_format=CL)
-    ws = torch.empty(2 * n * c_count, device=x.device, dtype=torch.float64)
+    ws = torch.empty(3 * n * c_count, device=x.device, dtype=torch.float64)
     with torch.cuda.device(x.device):
         capi.check(capi.lib().ie_instnorm_nhwc_f32(capi.ptr(x), capi.ptr(gamma), capi.ptr(beta), capi.ptr(y), capi.ptr(ws), n, h, w,
                                                    c, c_begin, c_count, eps, capi.ACT[act], slope, capi.current_stream()),
@@ -245,3 +245,135 @@ def max_concat(x) -> torch.Tensor:
         capi.check(capi.lib().ie_max_concat_nhwc_f32(capi.ptr(x), capi.ptr(y), n * h * w, c, capi.current_stream()),
                    "ie_max_concat_nhwc_f32")
     return y
+
+
+# ---- training path: norm layers with saved statistics, backward ops (include/ie_hip.h "training path") -------------
+class ConvWeightsView(ConvWeights):
+    """ConvWeights over caller-owned device storage (a slice of the trainer's flat parameter buffer, HWIO)."""
+
+    def __init__(self, w_flat: torch.Tensor, bias, cout: int, cin_g: int, kh: int, kw: int):
+        self.w, self.b, self.cout, self.cin_g, self.kh, self.kw = w_flat, bias, cout, cin_g, kh, kw
+
+
+def pack_hwio_into(w_oihw: torch.Tensor, dst_flat: torch.Tensor):
+    """Checkpoint OIHW (host) -> HWIO into ``dst_flat`` (device view)."""
+    w = w_oihw.detach().to("cpu", torch.float32).contiguous()
+    co, ci, kh, kw = w.shape
+    with torch.cuda.device(dst_flat.device):
+        capi.check(capi.lib().ie_pack_weight_hwio_f32(capi.ptr(w), co, ci, kh, kw, capi.ptr(dst_flat), capi.current_stream()),
+                   "ie_pack_weight_hwio_f32")
+        torch.cuda.current_stream().synchronize()      # `w` is a temporary host buffer
+
+
+def norm_forward(x, gamma, beta, per_sample: bool, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, act="none",
+                 slope=0.0, c_begin=0, c_count=None):
+    """InstanceNorm2d (per_sample) / training-mode BatchNorm2d; returns (y, save_mean, save_invstd)."""
+    _chk(x)
+    n, c, h, w = x.shape
+    c_count = c - c_begin if c_count is None else c_count
+    g = n if per_sample else 1
+    y = torch.empty_like(x, memory_format=CL)
+    ws = torch.empty(2 * g * c_count, device=x.device, dtype=torch.float64)
+    mean = torch.empty(g * c_count, device=x.device, dtype=torch.float32)
+    inv = torch.empty_like(mean)
+    with torch.cuda.device(x.device):
+        capi.check(capi.lib().ie_norm_forward_nhwc_f32(capi.ptr(x), capi.ptr(gamma), capi.ptr(beta), capi.ptr(y), capi.ptr(ws),
+                                                       capi.ptr(mean), capi.ptr(inv), capi.ptr(running_mean), capi.ptr(running_var),
+                                                       momentum, int(per_sample), n, h, w, c, c_begin, c_count, eps, capi.ACT[act],
+                                                       slope, capi.current_stream()), "ie_norm_forward_nhwc_f32")
+    return y, mean, inv
+
+
+def norm_backward(x, dy, y, gamma, mean, inv, per_sample: bool, dgamma=None, dbeta=None, accumulate=False, act="none", slope=0.0,
+                  c_begin=0, c_count=None):
+    _chk(x); _chk(dy)
+    n, c, h, w = x.shape
+    c_count = c - c_begin if c_count is None else c_count
+    g = n if per_sample else 1
+    dx = torch.empty_like(x, memory_format=CL)
+    ws = torch.empty(2 * g * c_count, device=x.device, dtype=torch.float64)
+    with torch.cuda.device(x.device):
+        capi.check(capi.lib().ie_norm_backward_nhwc_f32(capi.ptr(x), capi.ptr(dy), capi.ptr(y), capi.ptr(gamma), capi.ptr(mean),
+                                                        capi.ptr(inv), capi.ptr(ws), capi.ptr(dx), capi.ptr(dgamma), capi.ptr(dbeta),
+                                                        int(accumulate), int(per_sample), n, h, w, c, c_begin, c_count,
+                                                        capi.ACT[act], slope, capi.current_stream()), "ie_norm_backward_nhwc_f32")
+    return dx
+
+
+def _convn_desc(srcs, cw, stride, pad, pad_mode):
+    n, _, h, w = srcs[0].shape
+    return capi.ConvNDesc(n, h, w, len(srcs), cw.cout, cw.kh, cw.kw, stride, pad, capi.PAD[pad_mode], 0, 0.0, 0, 0.0, 0.0, 0, 0)
+
+
+def conv2d_wgrad(srcs, dy, cw: ConvWeights, dw: torch.Tensor, dbias=None, stride=1, pad=1, pad_mode="zeros", accumulate=False):
+    """dW (HWIO, flat) and optional dbias of conv2d(srcs, cw) given the gradient ``dy`` at its output."""
+    if isinstance(srcs, torch.Tensor):
+        srcs = [srcs]
+    for s in srcs:
+        _chk(s)
+    _chk(dy)
+    d = _convn_desc(srcs, cw, stride, pad, pad_mode)
+    cs = [int(s.shape[1]) for s in srcs]
+    if dw.numel() != cw.kh * cw.kw * sum(cs) * cw.cout:
+        raise capi.IEError("conv2d_wgrad: dw has the wrong size")
+    ptrs = (C.c_void_p * len(srcs))(*[s.data_ptr() for s in srcs])
+    chans = (C.c_int * len(srcs))(*cs)
+    ws = torch.empty(cw.cout, device=dy.device, dtype=torch.float64) if dbias is not None else None
+    with torch.cuda.device(dy.device):
+        capi.check(capi.lib().ie_convn_wgrad_nhwc_f32(C.byref(d), ptrs, chans, capi.ptr(dy), capi.ptr(dw), capi.ptr(dbias),
+                                                      int(accumulate), capi.ptr(ws), capi.current_stream()), "ie_convn_wgrad_nhwc_f32")
+
+
+def conv2d_dgrad(dy, cw: ConvWeights, src_shapes, dsts, accumulate, stride=1, pad=1, pad_mode="zeros"):
+    """Data gradients of conv2d over a virtual concat: ``dsts[i]`` (or None) receives the gradient of source i."""
+    _chk(dy)
+    n, _, h, w = src_shapes[0]
+    cs = [int(s[1]) for s in src_shapes]
+    d = capi.ConvNDesc(n, h, w, len(cs), cw.cout, cw.kh, cw.kw, stride, pad, capi.PAD[pad_mode], 0, 0.0, 0, 0.0, 0.0, 0, 0)
+    ptrs = (C.c_void_p * len(cs))(*[None if t is None else t.data_ptr() for t in dsts])
+    chans = (C.c_int * len(cs))(*cs)
+    acc = (C.c_int * len(cs))(*[int(a) for a in accumulate])
+    with torch.cuda.device(dy.device):
+        capi.check(capi.lib().ie_convn_dgrad_nhwc_f32(C.byref(d), capi.ptr(dy), capi.ptr(cw.w), ptrs, chans, acc,
+                                                      capi.current_stream()), "ie_convn_dgrad_nhwc_f32")
+
+
+def maxpool2x2_backward(x, dy, dx, accumulate):
+    _chk(x); _chk(dy); _chk(dx)
+    n, c, h, w = x.shape
+    with torch.cuda.device(x.device):
+        capi.check(capi.lib().ie_maxpool2x2_backward_nhwc_f32(capi.ptr(x), capi.ptr(dy), capi.ptr(dx), n, h, w, c, int(accumulate),
+                                                              capi.current_stream()), "ie_maxpool2x2_backward_nhwc_f32")
+
+
+def resize_backward(dy, dx, mode, accumulate):
+    _chk(dy); _chk(dx)
+    n, c, hi, wi = dx.shape
+    with torch.cuda.device(dy.device):
+        capi.check(capi.lib().ie_resize_backward_nhwc_f32(capi.ptr(dy), capi.ptr(dx), n, hi, wi, c, dy.shape[2], dy.shape[3],
+                                                          _RESIZE[mode], int(accumulate), capi.current_stream()),
+                   "ie_resize_backward_nhwc_f32")
+
+
+def crop_into(src, dst, top, left, accumulate):
+    _chk(src); _chk(dst)
+    n, c, h, w = dst.shape
+    with torch.cuda.device(src.device):
+        capi.check(capi.lib().ie_crop_nhwc_f32(capi.ptr(src), capi.ptr(dst), n, src.shape[2], src.shape[3], c, top, left, h, w,
+                                               int(accumulate), capi.current_stream()), "ie_crop_nhwc_f32")
+
+
+def pixel_unshuffle_into(dy, dx, r, accumulate):
+    _chk(dy); _chk(dx)
+    n, c, h, w = dx.shape
+    with torch.cuda.device(dy.device):
+        capi.check(capi.lib().ie_pixel_unshuffle_nhwc_f32(capi.ptr(dy), capi.ptr(dx), n, h, w, c // (r * r), r, int(accumulate),
+                                                          capi.current_stream()), "ie_pixel_unshuffle_nhwc_f32")
+
+
+def act_backward_into(dy, ref, dx, act, slope=0.0, lo=0.0, hi=0.0, accumulate=False):
+    """dx (+)= dy * act'(ref); act in ACT names (ref = activation output) or "clamp" (ref = clamp input)."""
+    code = 5 if act == "clamp" else capi.ACT[act]
+    with torch.cuda.device(dy.device):
+        capi.check(capi.lib().ie_act_backward_f32(capi.ptr(dy), capi.ptr(ref), capi.ptr(dx), dy.numel(), code, slope, lo, hi,
+                                                  int(accumulate), capi.current_stream()), "ie_act_backward_f32")

@@ -39,3 +39,16 @@ def gather_frames(local: torch.Tensor, n_total: int, group=None, dst: int = 0):
         return torch.cat([b[: hi - lo] for b, (lo, hi) in zip(bufs, sizes)], dim=0)
     dist.gather(pad, None, dst=dst, group=group)
     return None
+
+
+def allreduce_gradients(flat: torch.Tensor, group=None) -> float:
+    """Training path: ONE sum all-reduce of the flat gradient buffer over the process group (RCCL over xGMI on
+    GPUs); returns the factor 1/world that turns the sum into DDP's mean -- the caller fuses it into the clip/Adam kernels
+    instead of spending another pass over the buffer.  No-op (factor 1.0) without an initialised process group."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1.0
+    world = dist.get_world_size(group)
+    if world > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    return 1.0 / world

@@ -1,0 +1,362 @@
+"""Training path of the hot path: forward with saved activations -> loss -> hand-written backward
+kernels -> gradient all-reduce (RCCL) -> global-norm clip -> Adam, without torch.autograd.
+
+Reference: ``ImageEnhancementModel.forward_loss`` (src/mon/vision/enhance/base.py:47-57), ``Model.training_step``
+(src/mon/nn/model.py:701-746), ``configure_optimizers`` (:498-615; optimiser parameter filter nn/factory.py:66-80),
+Adam + ``gradient_clip_val`` (llie/zero_dce/config/zero_dce_re_sice_mix.py:46-51,106), Lightning DDP = mean of the
+per-rank gradients.
+
+Design: all trainable parameters live in ONE flat fp32 device buffer (conv weights in the kernels' HWIO layout), with
+flat gradient / Adam-moment buffers beside it: one all-reduce, one norm reduction and one Adam launch per step.
+``Tape`` is a minimal reverse-mode recorder over the ops of ``ops.py``; every backward op is one C-ABI call.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import torch
+
+from . import capi, ops
+from .losses import LOSSES, Loss
+
+CL = torch.channels_last
+
+
+class Tape:
+    """Reverse-mode recorder.  Gradient buffers are created on first use; a second producer accumulates."""
+
+    def __init__(self):
+        self._fns, self._g, self._nograd = [], {}, set()
+
+    def no_grad(self, t):
+        self._nograd.add(id(t))
+        self._g[id(t)] = (t, None)
+        return t
+
+    def is_no_grad(self, t):
+        return id(t) in self._nograd
+
+    def slot(self, t):
+        """(gradient buffer of ``t`` or None, accumulate flag) for a producer about to write into it."""
+        k = id(t)
+        if k in self._nograd:
+            return None, 0
+        if k in self._g:
+            return self._g[k][1], 1
+        buf = torch.empty_like(t, memory_format=CL)
+        self._g[k] = (t, buf)
+        return buf, 0
+
+    def seed(self, t, grad):
+        self._g[id(t)] = (t, grad)
+
+    def grad(self, t):
+        e = self._g.get(id(t))
+        return None if e is None else e[1]
+
+    def release(self, t):
+        """Drop the gradient buffer of ``t`` once its producer has consumed it."""
+        self._g.pop(id(t), None)
+
+    def record(self, fn):
+        self._fns.append(fn)
+
+    def backward(self):
+        for fn in reversed(self._fns):
+            fn()
+        self._fns = []
+
+
+class ParamStore:
+    """Flat device storage of a model's trainable parameters (+ gradient and Adam moments) and its buffers."""
+
+    def __init__(self, model, device):
+        self.device = device
+        self.index = OrderedDict()            # name -> (offset, numel, shape, is_conv)
+        self.buffers = OrderedDict()          # running_mean / running_var
+        off = 0
+        for k, v in model._params.items():
+            if k.endswith("running_mean") or k.endswith("running_var"):
+                self.buffers[k] = v.detach().to(device, torch.float32).contiguous().clone()
+                continue
+            if any(s in k for s in ("loss", "train/", "val/", "test/")):      # nn/factory.py:70-77
+                continue
+            self.index[k] = (off, v.numel(), tuple(v.shape), v.dim() == 4)
+            off += (v.numel() + 3) // 4 * 4                                    # keep every view 16-byte aligned
+        self.numel = off
+        self.params = torch.zeros(off, device=device, dtype=torch.float32)
+        self.grads = torch.zeros_like(self.params)
+        self.exp_avg = torch.zeros_like(self.params)
+        self.exp_avg_sq = torch.zeros_like(self.params)
+        for k, (o, n, shape, is_conv) in self.index.items():
+            if is_conv:
+                ops.pack_hwio_into(model._params[k], self.params[o:o + n])
+            else:
+                self.params[o:o + n].copy_(model._params[k].reshape(-1))
+
+    def view(self, name, of=None):
+        o, n, _, _ = self.index[name]
+        return (self.params if of is None else of)[o:o + n]
+
+    def conv(self, name) -> ops.ConvWeightsView:
+        _, _, (co, ci, kh, kw), _ = self.index[f"{name}.weight"]
+        b = self.view(f"{name}.bias") if f"{name}.bias" in self.index else None
+        return ops.ConvWeightsView(self.view(f"{name}.weight"), b, co, ci, kh, kw)
+
+    def conv_grads(self, name):
+        db = self.view(f"{name}.bias", self.grads) if f"{name}.bias" in self.index else None
+        return self.view(f"{name}.weight", self.grads), db
+
+    def export(self, of=None) -> "OrderedDict[str, torch.Tensor]":
+        """Checkpoint-layout (OIHW) host copies of the parameters (or of ``of`` = grads / moments), plus buffers."""
+        out = OrderedDict()
+        for k, (o, n, shape, is_conv) in self.index.items():
+            t = (self.params if of is None else of)[o:o + n]
+            if is_conv:
+                co, ci, kh, kw = shape
+                t = t.reshape(kh, kw, ci, co).permute(3, 2, 0, 1)
+            out[k] = t.reshape(shape).to("cpu").contiguous().clone()
+        if of is None:
+            for k, v in self.buffers.items():
+                out[k] = v.to("cpu").clone()
+        return out
+
+
+# ---- taped ops ---------------------------------------------------------------------------------------------------------
+def t_conv(tape, srcs, cw, dw, db, stride=1, pad=1, pad_mode="zeros", act="none", slope=0.0):
+    if isinstance(srcs, torch.Tensor):
+        srcs = [srcs]
+    y = ops.conv2d(srcs, cw, stride=stride, pad=pad, pad_mode=pad_mode, act=act, slope=slope)
+
+    def bwd():
+        dy = tape.grad(y)
+        if dy is None:
+            return
+        if act != "none":
+            g = torch.empty_like(dy, memory_format=CL)
+            ops.act_backward_into(dy, y, g, act, slope)
+            dy = g
+        ops.conv2d_wgrad(srcs, dy, cw, dw, db, stride, pad, pad_mode)
+        slots = [tape.slot(s) for s in srcs]
+        if any(b is not None for b, _ in slots):
+            ops.conv2d_dgrad(dy, cw, [tuple(s.shape) for s in srcs], [b for b, _ in slots], [a for _, a in slots], stride, pad, pad_mode)
+        tape.release(y)
+    tape.record(bwd)
+    return y
+
+
+def t_norm(tape, x, gamma, beta, dgamma, dbeta, per_sample, running_mean=None, running_var=None, momentum=0.1, eps=1e-5,
+           act="none", slope=0.0, c_begin=0, c_count=None):
+    y, mean, inv = ops.norm_forward(x, gamma, beta, per_sample, running_mean, running_var, momentum, eps, act, slope, c_begin, c_count)
+
+    def bwd():
+        dy = tape.grad(y)
+        if dy is None:
+            return
+        dx = ops.norm_backward(x, dy, y, gamma, mean, inv, per_sample, dgamma, dbeta, False, act, slope, c_begin, c_count)
+        if tape.is_no_grad(x):
+            return
+        if tape.grad(x) is not None:
+            _accumulate(tape.grad(x), dx)
+        else:
+            tape.seed(x, dx)
+        tape.release(y)
+    tape.record(bwd)
+    return y
+
+
+def _accumulate(buf, dx):
+    """buf += dx through the library's eltwise kernel (no torch arithmetic on the data path)."""
+    n, c, h, w = buf.shape
+    with torch.cuda.device(buf.device):
+        capi.check(capi.lib().ie_eltwise_nhwc_f32(0, capi.ptr(buf), capi.ptr(dx), capi.ptr(buf), n * h * w, c, c, 0.0, 0.0,
+                                                  capi.current_stream()), "ie_eltwise_nhwc_f32")
+
+
+def t_maxpool(tape, x):
+    y = ops.maxpool2x2(x)
+
+    def bwd():
+        dy = tape.grad(y)
+        if dy is None:
+            return
+        buf, acc = tape.slot(x)
+        if buf is not None:
+            ops.maxpool2x2_backward(x, dy, buf, acc)
+        tape.release(y)
+    tape.record(bwd)
+    return y
+
+
+def t_resize(tape, x, size, mode="bilinear_align"):
+    y = ops.resize(x, size, mode)
+
+    def bwd():
+        dy = tape.grad(y)
+        if dy is None:
+            return
+        buf, acc = tape.slot(x)
+        if buf is not None:
+            ops.resize_backward(dy, buf, mode, acc)
+        tape.release(y)
+    tape.record(bwd)
+    return y
+
+
+def t_pad(tape, x, top, bottom, left, right):
+    if top == bottom == left == right == 0:
+        return x
+    y = ops.pad(x, top, bottom, left, right)
+
+    def bwd():
+        dy = tape.grad(y)
+        if dy is None:
+            return
+        buf, acc = tape.slot(x)
+        if buf is not None:
+            ops.crop_into(dy, buf, top, left, acc)
+        tape.release(y)
+    tape.record(bwd)
+    return y
+
+
+def t_pixel_shuffle(tape, x, r=2):
+    y = ops.pixel_shuffle(x, r)
+
+    def bwd():
+        dy = tape.grad(y)
+        if dy is None:
+            return
+        buf, acc = tape.slot(x)
+        if buf is not None:
+            ops.pixel_unshuffle_into(dy, buf, r, acc)
+        tape.release(y)
+    tape.record(bwd)
+    return y
+
+
+def t_clamp(tape, x, lo, hi):
+    y = ops.clamp(x, lo, hi)
+
+    def bwd():
+        dy = tape.grad(y)
+        if dy is None:
+            return
+        buf, acc = tape.slot(x)
+        if buf is not None:
+            ops.act_backward_into(dy, x, buf, "clamp", 0.0, lo, hi, acc)
+        tape.release(y)
+    tape.record(bwd)
+    return y
+
+
+# ---- trainer -------------------------------------------------------------------------------------------------------------
+class Trainer:
+    """One-model fit driver: ``training_step(batch)`` = forward_loss + backward + all-reduce + clip + Adam.
+
+    ``model`` must implement ``forward_train(image_nhwc, store: ParamStore, tape: Tape) -> enhanced (NHWC tensor)``.
+    ``optimizer``: ``{"name": "adam", "lr": ..., "betas": (..), "eps": .., "weight_decay": ..}`` like the reference configs'
+    ``optimizers[0]["optimizer"]``; ``gradient_clip_val`` like the Lightning trainer config (norm clipping).
+    ``process_group``: torch.distributed group for data parallelism (default group when initialised)."""
+
+    def __init__(self, model, optimizer: dict | None = None, loss=None, gradient_clip_val: float | None = 0.1, process_group=None):
+        if not hasattr(model, "forward_train"):
+            raise capi.IEError(f"{model.__class__.__name__} has no training graph (forward_train)")
+        model._require_cuda()
+        self.model, self.device = model, model.device
+        opt = dict(optimizer or {})
+        name = opt.pop("name", "adam")
+        if name.lower() != "adam":
+            raise capi.IEError(f"optimizer {name!r} is not implemented (adam only)")
+        self.lr = float(opt.pop("lr", 1e-4))
+        self.betas = tuple(opt.pop("betas", (0.9, 0.999)))
+        self.eps = float(opt.pop("eps", 1e-8))
+        self.weight_decay = float(opt.pop("weight_decay", 0.0))
+        self.clip = float(gradient_clip_val) if gradient_clip_val else 0.0
+        if isinstance(loss, dict):
+            loss = LOSSES.build(config=loss)
+        self.loss = loss if loss is not None else LOSSES.build(name="l1_ssim_loss")
+        if not isinstance(self.loss, Loss):
+            raise TypeError("`loss` must be a mon_amd.losses.Loss or its config dict")
+        self.group = process_group
+        self.step = 0
+        self.store = ParamStore(model, self.device)
+        self._sumsq = torch.zeros(1, device=self.device, dtype=torch.float64)
+        self._sumsq_ws = torch.zeros(capi.SUMSQ_WS_DOUBLES, device=self.device, dtype=torch.float64)
+        model.predicting = False
+        model.train()
+
+    # nn/model.py:498 -- kept for API parity; the optimiser state lives in the ParamStore
+    def configure_optimizers(self):
+        return {"optimizer": {"name": "adam", "lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay}}
+
+    def _world(self):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_world_size(self.group)
+        return 1
+
+    def forward_loss(self, datapoint: dict, tape: Tape | None = None) -> dict:
+        """vision/enhance/base.py:47-57."""
+        m = self.model
+        m.assert_datapoint(datapoint)
+        x = ops.to_nhwc(datapoint["image"].to(self.device, torch.float32))
+        tape = tape or Tape()
+        tape.no_grad(x)
+        pred = m.forward_train(x, self.store, tape)
+        outputs = OrderedDict(enhanced=pred)
+        m.assert_outputs(outputs)
+        target = datapoint.get("ref_image")
+        outputs["loss"] = self.loss(pred, target.to(self.device, torch.float32))
+        outputs["_tape"] = tape
+        return outputs
+
+    def backward(self, outputs: dict):
+        tape, pred, loss = outputs["_tape"], outputs["enhanced"], outputs["loss"]
+        g = torch.empty_like(pred, memory_format=CL)
+        loss.backward_into(g, False, 1.0)
+        tape.seed(pred, g)
+        tape.backward()
+
+    def optimizer_step(self):
+        """DDP mean of the gradients (one flat all-reduce over RCCL) -> clip_grad_norm_ -> Adam, three launches."""
+        from .sharding import allreduce_gradients
+        st = self.store
+        scale = allreduce_gradients(st.grads, self.group)
+        self.step += 1
+        L = capi.lib()
+        with torch.cuda.device(self.device):
+            sumsq = None
+            if self.clip > 0:
+                capi.check(L.ie_sumsq_f32(capi.ptr(st.grads), st.numel, scale, capi.ptr(self._sumsq), capi.ptr(self._sumsq_ws), 1,
+                                          capi.current_stream()), "ie_sumsq_f32")
+                sumsq = self._sumsq
+            capi.check(L.ie_adam_step_f32(capi.ptr(st.params), capi.ptr(st.grads), capi.ptr(st.exp_avg), capi.ptr(st.exp_avg_sq), st.numel,
+                                          self.step, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, scale,
+                                          capi.ptr(sumsq), self.clip, capi.current_stream()), "ie_adam_step_f32")
+
+    def training_step(self, batch: dict, batch_idx: int = 0) -> dict:
+        """nn/model.py:701-746 (+ the optimiser step Lightning runs right after it)."""
+        outputs = self.forward_loss(batch)
+        self.backward(outputs)
+        self.optimizer_step()
+        outputs.pop("_tape")
+        return outputs
+
+    def grad_norm(self) -> float:
+        """Total gradient norm seen by the last optimizer_step (after the all-reduce mean)."""
+        return float(self._sumsq.item()) ** 0.5
+
+    def state_dict(self):
+        return self.store.export()
+
+    def gradients(self):
+        return self.store.export(self.store.grads)
+
+    def sync_to_model(self):
+        """Write the trained parameters back into the model object (for inference / checkpointing)."""
+        sd = self.state_dict()
+        for k, v in sd.items():
+            self.model._params[k] = v
+        self.model._on_params_change()
+        return self.model

@@ -115,7 +115,7 @@ int ie_convn_nhwc_f32(ie_convn_desc* d, const float* const* srcs_dev, const int*
                       const float* bias_dev, const float* residual_dev, float* dst_dev, void* stream);
 /* nn.InstanceNorm2d(affine) on channels [c_begin, c_begin + c_count) (biased variance over H*W per (n,c), eps;
  * llunetpp.py:107; half-instance-norm hinet.py:75-77), other channels copied; fused activation.
- * stats_ws_dev: >= 2*N*c_count doubles of scratch.  gamma/beta may both be NULL (affine=False). */
+ * stats_ws_dev: >= 3*N*c_count doubles of scratch.  gamma/beta may both be NULL (affine=False). */
 int ie_instnorm_nhwc_f32(const float* x_dev, const float* gamma_dev, const float* beta_dev, float* y_dev, double* stats_ws_dev,
                          int N, int H, int W, int C, int c_begin, int c_count, float eps, int act, float slope, void* stream);
 /* nn.MaxPool2d(2,2), floor mode (llunetpp.py:181, unet.py:65). */
@@ -135,6 +135,72 @@ int ie_pad_nhwc_f32(const float* x_dev, float* y_dev, int N, int H, int W, int C
 int ie_eltwise_nhwc_f32(int op, const float* a_dev, const float* b_dev, float* y_dev, size_t npix, int C, int Cb, float lo, float hi, void* stream);
 /* [max_c(x), x] channel concat (retinexnet/model.py:45-46). */
 int ie_max_concat_nhwc_f32(const float* x_dev, float* y_dev, size_t npix, int C, void* stream);
+
+/* ---- training path, fp32 NHWC: what torch.autograd does behind Model.training_step ---------
+ * (src/mon/nn/model.py:701-746) for the layers above, the L1 + SSIM losses and Adam with gradient-norm clipping. */
+/* Forward of nn.InstanceNorm2d (per_sample=1) or of nn.BatchNorm2d in training mode (per_sample=0: batch
+ * statistics over N*H*W, unet.py:43-48 under model.train()) on channels [c_begin, c_begin+c_count), fused
+ * affine + activation.  ws_dev: >= 2*G*c_count doubles; save_mean/save_invstd: G*c_count floats kept for the
+ * backward pass (G = N if per_sample else 1); running_mean/var (batch mode, may be NULL) are updated with
+ * `momentum` and the unbiased variance like torch. */
+int ie_norm_forward_nhwc_f32(const float* x_dev, const float* gamma_dev, const float* beta_dev, float* y_dev, double* ws_dev,
+                             float* save_mean_dev, float* save_invstd_dev, float* running_mean_dev, float* running_var_dev,
+                             float momentum, int per_sample, int N, int H, int W, int C, int c_begin, int c_count, float eps,
+                             int act, float slope, void* stream);
+/* Backward of the above: g = dy * act'(y); dx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)) (channels outside the
+ * range: dx = g); dgamma = sum g*xhat, dbeta = sum g (assigned, or added when accumulate_param_grads).
+ * y_dev (the layer's output) is needed when act != IE_ACT_NONE.  ws_dev: >= 2*G*c_count doubles. */
+int ie_norm_backward_nhwc_f32(const float* x_dev, const float* dy_dev, const float* y_dev, const float* gamma_dev,
+                              const float* save_mean_dev, const float* save_invstd_dev, double* ws_dev, float* dx_dev,
+                              float* dgamma_dev, float* dbeta_dev, int accumulate_param_grads, int per_sample, int N, int H, int W,
+                              int C, int c_begin, int c_count, int act, float slope, void* stream);
+/* Conv2d weight gradient dW (HWIO over the concatenated Cin, like the forward weights) and optional bias gradient
+ * (ws_dev: >= Cout doubles when dbias_dev != NULL).  d->act etc. are ignored: dy is the gradient at the conv output. */
+int ie_convn_wgrad_nhwc_f32(ie_convn_desc* d, const float* const* srcs_dev, const int* channels, const float* dy_dev,
+                            float* dw_hwio_dev, float* dbias_dev, int accumulate, double* ws_dev, void* stream);
+/* Conv2d data gradient, one tensor per source of the virtual concat (NULL entry = not needed); zero padding, any stride. */
+int ie_convn_dgrad_nhwc_f32(ie_convn_desc* d, const float* dy_dev, const float* w_hwio_dev, float* const* dsrcs_dev,
+                            const int* channels, const int* accumulate, void* stream);
+/* MaxPool2d(2,2) backward (gradient to the first maximum in scan order, like torch's saved indices). */
+int ie_maxpool2x2_backward_nhwc_f32(const float* x_dev, const float* dy_dev, float* dx_dev, int N, int H, int W, int C,
+                                    int accumulate, void* stream);
+/* Adjoint of ie_resize_nhwc_f32 (same modes): dy (N,Ho,Wo,C) -> dx (N,Hi,Wi,C), deterministic gather form. */
+int ie_resize_backward_nhwc_f32(const float* dy_dev, float* dx_dev, int N, int Hi, int Wi, int C, int Ho, int Wo, int mode,
+                                int accumulate, void* stream);
+/* dst (N,H,W,C) (+)= src[:, top:top+H, left:left+W, :] of an (N,Hs,Ws,C) tensor: adjoint of ie_pad_nhwc_f32. */
+int ie_crop_nhwc_f32(const float* src_dev, float* dst_dev, int N, int Hs, int Ws, int C, int top, int left, int H, int W,
+                     int accumulate, void* stream);
+/* Adjoint of ie_pixel_shuffle_nhwc_f32: dy (N,H*r,W*r,Cout) -> dx (N,H,W,Cout*r*r). */
+int ie_pixel_unshuffle_nhwc_f32(const float* dy_dev, float* dx_dev, int N, int H, int W, int Cout, int r, int accumulate, void* stream);
+/* dx (+)= dy * act'(ref): act = ie_act with ref = the activation's OUTPUT, or act = 5: clamp with ref = its INPUT
+ * (gradient passes where lo <= ref <= hi, like torch.clamp). */
+int ie_act_backward_f32(const float* dy_dev, const float* ref_dev, float* dx_dev, size_t n, int act, float slope, float lo, float hi,
+                        int accumulate, void* stream);
+/* L1Loss (nn/loss/base.py:164-178): *sum_dev = sum |pred - target| (caller divides by n for reduction="mean");
+ * grad_dev (may be NULL) (+)= grad_scale * sign(pred - target). */
+int ie_l1_loss_f32(const float* pred_dev, const float* target_dev, size_t n, double* sum_dev, float* grad_dev, float grad_scale,
+                   int accumulate, void* stream);
+/* custom_ssim (nn/metric/image.py:143-237): 11-tap Gaussian window (sigma), separable valid filtering, c1=(k1*R)^2,
+ * c2=(k2*R)^2.  Element (n,c,h,w) of both images is at n*sn + c*sc + h*sh + w*sw floats (NCHW or NHWC).
+ * sum_dev[N*C] = sum of the SSIM map per (n,c) (mean = sum / ((H-10)*(W-10))).  d_ws_dev (may be NULL):
+ * 3*N*C*(H-10)*(W-10) floats of per-pixel partial derivatives kept for ie_ssim_backward_f32. */
+int ie_ssim_forward_f32(const float* x_dev, const float* y_dev, int N, int C, int H, int W, int64_t sn, int64_t sc, int64_t sh,
+                        int64_t sw, float data_range, float k1, float k2, float sigma, double* sum_dev, float* d_ws_dev, void* stream);
+/* grad_dev (same strides as x) (+)= scale * d(sum of all SSIM-map pixels)/dx; SSIMLoss = 1 - mean(...) (nn/loss/image.py:862-865)
+ * means scale = -loss_weight / (N*C*(H-10)*(W-10)).  non_negative: planes whose SSIM sum is negative get no gradient (relu). */
+int ie_ssim_backward_f32(const float* x_dev, const float* y_dev, const float* d_ws_dev, const double* sum_dev, float* grad_dev, int N,
+                         int C, int H, int W, int64_t sn, int64_t sc, int64_t sh, int64_t sw, float sigma, float scale,
+                         int non_negative, int accumulate, void* stream);
+/* *acc_dev (+)= sum (scale*a_i)^2 -- global gradient norm for torch.nn.utils.clip_grad_norm_ (Lightning gradient_clip_val).
+ * Deterministic (no atomics): identical inputs give the identical bits on every data-parallel replica.
+ * ws_dev: IE_SUMSQ_WS_DOUBLES doubles of scratch. */
+#define IE_SUMSQ_WS_DOUBLES 2048
+int ie_sumsq_f32(const float* a_dev, size_t n, float scale, double* acc_dev, double* ws_dev, int zero_first, void* stream);
+/* torch.optim.Adam step t=`step` (>=1) on a flat buffer: g = grad*grad_scale*min(1, max_norm/(sqrt(*sumsq_dev)+1e-6))
+ * (+ weight_decay*p); sumsq_dev NULL or max_norm <= 0 disables clipping. */
+int ie_adam_step_f32(float* param_dev, const float* grad_dev, float* exp_avg_dev, float* exp_avg_sq_dev, size_t n, int step, float lr,
+                     float beta1, float beta2, float eps, float weight_decay, float grad_scale, const double* sumsq_dev,
+                     float max_norm, void* stream);
 
 /* ---- LE curve (zero_dce.py:186-188) ------------------------------------ */
 /* y <- y + r_i (y^2 - y), i < iters; img NCHW fp32 (N,3,H,W); adjust NHWC fp32

@@ -1,0 +1,108 @@
+"""Oracle (TEST INFRASTRUCTURE): torch-CPU restatement of the supervised training step.
+
+  l1_loss / ssim / ssim_loss   src/mon/nn/loss/base.py:164-178, src/mon/nn/metric/image.py:90-237, nn/loss/image.py:834-866
+  unet_forward_train           src/mon/vision/segment/unet/unet.py:35-197 under model.train() (BatchNorm on batch statistics)
+  training_step                forward_loss (vision/enhance/base.py:47-57) -> torch.autograd -> clip_grad_norm_
+                               (Lightning gradient_clip_val, norm) -> torch.optim.Adam (nn/model.py:498-615)
+
+Run it in float64 for gradient parity: torch's fp32 CPU backward of this network is itself ~5e-3 (relative) away from the
+float64 result (fp32 partial sums in BatchNorm's backward), far more than the HIP path's error.
+
+parity unpinned: metric/image.py imports torchmetrics at module level and the harness needs lightning, so neither can be
+imported here; the leaf arithmetic is torch's own (F.conv2d, F.batch_norm, autograd, torch.optim.Adam).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+
+def gauss_1d(size: int = 11, sigma: float = 1.5) -> torch.Tensor:
+    coords = torch.arange(size, dtype=torch.float) - size // 2
+    g = torch.exp(-(coords ** 2) / (2 * sigma ** 2))
+    return g / g.sum()
+
+
+def ssim(x, y, data_range=255.0, k=(0.01, 0.03), sigma=1.5, non_negative=False):
+    """custom_ssim(size_average=True): mean over (n, c) of the mean SSIM map."""
+    c = x.shape[1]
+    win = gauss_1d(11, sigma).to(x.dtype)
+    wh = win.view(1, 1, 11, 1).repeat(c, 1, 1, 1)
+    ww = win.view(1, 1, 1, 11).repeat(c, 1, 1, 1)
+
+    def filt(t):
+        return F.conv2d(F.conv2d(t, wh, groups=c), ww, groups=c)
+    c1, c2 = (k[0] * data_range) ** 2, (k[1] * data_range) ** 2
+    mu1, mu2 = filt(x), filt(y)
+    s1, s2, s12 = filt(x * x) - mu1 ** 2, filt(y * y) - mu2 ** 2, filt(x * y) - mu1 * mu2
+    cs = (2 * s12 + c2) / (s1 + s2 + c2)
+    m = ((2 * mu1 * mu2 + c1) / (mu1 ** 2 + mu2 ** 2 + c1)) * cs
+    per = m.flatten(2).mean(-1)
+    if non_negative:
+        per = torch.relu(per)
+    return per.mean()
+
+
+def l1_loss(x, y, loss_weight=1.0):
+    return loss_weight * F.l1_loss(x, y)
+
+
+def ssim_loss(x, y, data_range=255.0, non_negative=False):
+    return 1.0 - ssim(x, y, data_range=data_range, non_negative=non_negative)
+
+
+def l1_ssim_loss(x, y, l1_weight=1.0, ssim_weight=1.0, data_range=1.0, non_negative=False):
+    return l1_weight * l1_loss(x, y) + ssim_weight * ssim_loss(x, y, data_range, non_negative)
+
+
+def unet_forward_train(p: dict, buffers: dict, x, upsampler="bilinear", enhance=True):
+    """p: parameters (requires_grad), buffers: running statistics (updated in place, momentum 0.1)."""
+    def bn(n, t):
+        return F.batch_norm(t, buffers[f"{n}.running_mean"], buffers[f"{n}.running_var"], p[f"{n}.weight"], p[f"{n}.bias"], True, 0.1, 1e-5)
+
+    def dc(n, t):
+        t = F.relu(bn(f"{n}.norm1", F.conv2d(t, p[f"{n}.conv1.weight"], None, padding=1)))
+        return F.relu(bn(f"{n}.norm2", F.conv2d(t, p[f"{n}.conv2.weight"], None, padding=1)))
+    x1 = dc("inc", x)
+    x2 = dc("down1.conv", F.max_pool2d(x1, 2))
+    x3 = dc("down2.conv", F.max_pool2d(x2, 2))
+    x4 = dc("down3.conv", F.max_pool2d(x3, 2))
+    x5 = dc("down4.conv", F.max_pool2d(x4, 2))
+
+    def up(k, a, skip):
+        if upsampler == "bilinear":
+            a = F.interpolate(a, scale_factor=2, mode="bilinear", align_corners=True)
+        else:
+            a = F.pixel_shuffle(F.conv2d(a, p[f"up{k}.up.0.weight"], p[f"up{k}.up.0.bias"], padding=1), 2)
+        dy, dx = skip.shape[2] - a.shape[2], skip.shape[3] - a.shape[3]
+        a = F.pad(a, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])
+        return dc(f"up{k}.conv", torch.cat([skip, a], 1))
+    y = up(1, x5, x4); y = up(2, y, x3); y = up(3, y, x2); y = up(4, y, x1)
+    y = F.conv2d(y, p["outc.conv.weight"], p["outc.conv.bias"])
+    return torch.clamp(y, 0, 1) if enhance else y
+
+
+def training_steps(state_dict: dict, batches, forward_train, loss_fn, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
+                   clip=0.1, world_batches=None):
+    """Run len(batches) optimiser steps.  Returns per step: loss, gradients (before clipping), grad norm; and the final state.
+    ``world_batches``: optional list (per step) of lists of (image, target) shards -> DDP semantics (mean of shard gradients)."""
+    params = {k: v.clone().requires_grad_(True) for k, v in state_dict.items() if "running_" not in k}
+    buffers = {k: v.clone() for k, v in state_dict.items() if "running_" in k}
+    opt = torch.optim.Adam(list(params.values()), lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+    log = []
+    for step, (image, target) in enumerate(batches):
+        opt.zero_grad()
+        shards = world_batches[step] if world_batches else [(image, target)]
+        losses = []
+        for im, tg in shards:
+            pred = forward_train(params, buffers, im)
+            loss = loss_fn(pred, tg) / len(shards)
+            loss.backward()
+            losses.append(float(loss.detach()) * len(shards))
+        grads = {k: v.grad.clone() for k, v in params.items()}
+        norm = float(torch.nn.utils.clip_grad_norm_(list(params.values()), clip)) if clip else None
+        opt.step()
+        log.append({"loss": losses, "grads": grads, "grad_norm": norm})
+    final = {k: v.detach().clone() for k, v in params.items()}
+    final.update({k: v.clone() for k, v in buffers.items()})
+    return log, final

@@ -44,3 +44,33 @@ def test_scatter_gather_world2():
         port = _free_port()
         mp.spawn(_worker, args=(2, port, n_total, ret), nprocs=2, join=True)
         assert ret.get("ok") is True
+
+
+def _grad_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from mon_amd.sharding import allreduce_gradients
+    g = torch.arange(10, dtype=torch.float32) * (rank + 1)       # rank r holds (r+1) * [0..9]
+    scale = allreduce_gradients(g)
+    mean = g * scale
+    expect = torch.arange(10, dtype=torch.float32) * (sum(range(1, world + 1)) / world)
+    ret[rank] = bool(torch.allclose(mean, expect)) and scale == 1.0 / world
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_mean_world2():
+    """Training path: the flat-buffer sum all-reduce + 1/world factor equals DDP's gradient mean."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_grad_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    assert ret.get(0) is True and ret.get(1) is True
+
+
+def test_gradient_allreduce_without_group_is_identity():
+    from mon_amd.sharding import allreduce_gradients
+    g = torch.ones(4)
+    assert allreduce_gradients(g) == 1.0 and torch.equal(g, torch.ones(4))

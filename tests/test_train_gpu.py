@@ -1,0 +1,361 @@
+"""GPU parity of the training path: every backward kernel against torch.autograd on the CPU, the
+L1/SSIM losses against oracle/train.py, and whole optimiser steps of U-Net (loss, per-parameter gradients, post-step
+weights, BatchNorm running statistics) against the torch-CPU restatement."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import mon_amd
+from mon_amd import capi, ops, losses
+from oracle import train as otrain
+from tests.helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+CL = torch.channels_last
+
+
+def dev(t):
+    return ops.to_nhwc(t.cuda())
+
+
+def host(t):
+    return t.cpu().contiguous()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+# ---- losses ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+def test_l1_loss_value_and_grad(layout):
+    x, y = torch.rand(2, 3, 19, 23, generator=torch.Generator().manual_seed(1)), torch.rand(2, 3, 19, 23, generator=torch.Generator().manual_seed(2))
+    xr = x.clone().requires_grad_(True)
+    ref = otrain.l1_loss(xr, y, 0.7)
+    ref.backward()
+    xd = x.cuda().contiguous(memory_format=CL) if layout == "nhwc" else x.cuda()
+    res = losses.L1Loss(loss_weight=0.7)(xd, y.cuda())
+    assert abs(float(res) - float(ref)) < 1e-6
+    g = torch.empty_like(xd)
+    res.backward_into(g)
+    assert torch.equal(host(g), xr.grad)
+
+
+@pytest.mark.parametrize("layout,data_range,nonneg,shape", [("nchw", 1.0, False, (2, 3, 40, 56)), ("nhwc", 1.0, True, (1, 3, 33, 47)),
+                                                            ("nhwc", 255.0, False, (2, 3, 16, 75)), ("nchw", 1.0, False, (1, 1, 11, 11))])
+def test_ssim_loss_value_and_grad(layout, data_range, nonneg, shape):
+    g = torch.Generator().manual_seed(3)
+    y = torch.rand(*shape, generator=g)
+    x = (y + 0.25 * torch.randn(*shape, generator=g)).clamp(0, 1)     # correlated pair, like prediction vs target
+    if data_range == 255.0:
+        x, y = x * 255, y * 255
+    xr = x.clone().requires_grad_(True)
+    ref = otrain.ssim_loss(xr, y, data_range, nonneg)
+    ref.backward()
+    xd = x.cuda().contiguous(memory_format=CL) if layout == "nhwc" else x.cuda()
+    res = losses.SSIMLoss(data_range=data_range, non_negative_ssim=nonneg)(xd, y.cuda())
+    assert abs(float(res) - float(ref)) < 2e-5, (float(res), float(ref))
+    gd = torch.empty_like(xd)
+    res.backward_into(gd)
+    assert rel_err(host(gd), xr.grad) < 2e-4
+
+
+def test_ssim_non_negative_masks_gradient():
+    x = torch.rand(1, 3, 24, 24, generator=torch.Generator().manual_seed(5))
+    y = 1.0 - x                                                        # anti-correlated -> negative SSIM
+    xr = x.clone().requires_grad_(True)
+    ref = otrain.ssim_loss(xr, y, 1.0, True)
+    ref.backward()
+    res = losses.SSIMLoss(data_range=1.0, non_negative_ssim=True)(x.cuda(), y.cuda())
+    assert abs(float(res) - float(ref)) < 1e-5
+    gd = torch.ones(1, 3, 24, 24, device="cuda")
+    res.backward_into(gd)
+    assert float(xr.grad.abs().max()) == 0.0 and float(gd.abs().max()) == 0.0
+
+
+def test_loss_errors():
+    with pytest.raises(ValueError):
+        losses.SSIMLoss(data_range=1.0)(torch.zeros(1, 3, 16, 16, device="cuda"), torch.zeros(1, 3, 16, 17, device="cuda"))
+    with pytest.raises(capi.IEError):
+        losses.SSIMLoss(data_range=1.0)(torch.zeros(1, 3, 8, 16, device="cuda"), torch.zeros(1, 3, 8, 16, device="cuda"))
+    with pytest.raises(ValueError):
+        losses.L1Loss(reduction="avg")
+    assert set(mon_amd.LOSSES) >= {"l1_loss", "ssim_loss", "l1_ssim_loss"}
+
+
+# ---- norm layers -----------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("per_sample,c,act,c_begin,c_count", [(False, 16, "relu", 0, None), (True, 24, "lrelu", 0, None),
+                                                              (True, 32, "lrelu", 0, 16), (False, 300, "none", 0, None)])
+def test_norm_forward_backward(per_sample, c, act, c_begin, c_count):
+    n, h, w = 3, 13, 17
+    cc = c - c_begin if c_count is None else c_count
+    x = rnd(n, c, h, w, seed=1) * 2 + 0.5
+    gamma, beta = 1 + 0.2 * rnd(cc, seed=2), 0.1 * rnd(cc, seed=3)
+    dy = rnd(n, c, h, w, seed=4)
+    rm, rv = 0.1 * rnd(cc, seed=5), 1 + 0.1 * rnd(cc, seed=6).abs()
+    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    part = xr[:, c_begin:c_begin + cc]
+    if per_sample:
+        yn = F.instance_norm(part, weight=gr, bias=br, eps=1e-5)
+    else:
+        yn = F.batch_norm(part, rm_ref, rv_ref, gr, br, True, 0.1, 1e-5)
+    full = torch.cat([xr[:, :c_begin], yn, xr[:, c_begin + cc:]], 1)
+    yref = {"relu": F.relu, "lrelu": lambda t: F.leaky_relu(t, 0.2), "none": lambda t: t}[act](full)
+    yref.backward(dy)
+    xd, gd, bd = dev(x), gamma.cuda(), beta.cuda()
+    rmd, rvd = (None, None) if per_sample else (rm.cuda(), rv.cuda())
+    y, mean, inv = ops.norm_forward(xd, gd, bd, per_sample, rmd, rvd, 0.1, 1e-5, act, 0.2, c_begin, c_count)
+    assert rel_err(host(y), yref.detach()) < 1e-5
+    if not per_sample:
+        assert rel_err(host(rmd), rm_ref) < 1e-5 and rel_err(host(rvd), rv_ref) < 1e-5
+    dg, db = torch.empty(cc, device="cuda"), torch.empty(cc, device="cuda")
+    dx = ops.norm_backward(xd, dev(dy), y, gd, mean, inv, per_sample, dg, db, False, act, 0.2, c_begin, c_count)
+    assert rel_err(host(dx), xr.grad) < 2e-5
+    assert rel_err(host(dg), gr.grad) < 2e-5 and rel_err(host(db), br.grad) < 2e-5
+
+
+# ---- conv gradients ------------------------------------------------------------------------------------------------------
+CONV_CASES = [
+    dict(cs=[16], co=16, k=3, s=1, p=1),
+    dict(cs=[3], co=8, k=3, s=1, p=1, no_dx=True),          # first layer: no data gradient
+    dict(cs=[8, 24], co=20, k=3, s=1, p=1),                 # decoder concat [skip, up]
+    dict(cs=[72, 5, 64], co=70, k=3, s=1, p=1),             # tiles straddling 64, ragged channels
+    dict(cs=[16], co=3, k=1, s=1, p=0, bias=True),          # outc (unet.py:104-112)
+    dict(cs=[32], co=32, k=4, s=2, p=1),                    # HINet down conv (hinet.py:65)
+    dict(cs=[12], co=12, k=3, s=2, p=1),
+    dict(cs=[130], co=132, k=1, s=1, p=0, bias=True),
+]
+
+
+@pytest.mark.parametrize("c", CONV_CASES, ids=lambda c: f"{'+'.join(map(str, c['cs']))}-{c['co']}-k{c['k']}s{c['s']}p{c['p']}")
+def test_conv_wgrad_dgrad(c):
+    n, h, w = 2, 18, 27
+    g = torch.Generator().manual_seed(7)
+    xs = [torch.randn(n, ci, h, w, generator=g).requires_grad_(True) for ci in c["cs"]]
+    cin = sum(c["cs"])
+    wt = (torch.randn(c["co"], cin, c["k"], c["k"], generator=g) / (cin * c["k"] ** 2) ** 0.5).requires_grad_(True)
+    b = torch.randn(c["co"], generator=g).requires_grad_(True) if c.get("bias") else None
+    yref = F.conv2d(torch.cat(xs, 1), wt, b, stride=c["s"], padding=c["p"])
+    dy = torch.randn(yref.shape, generator=g)
+    yref.backward(dy)
+    cw = ops.ConvWeights(wt.detach(), None if b is None else b.detach(), "cuda")
+    xd = [dev(x.detach()) for x in xs]
+    dyd = dev(dy)
+    dw = torch.full((c["k"] * c["k"] * cin * c["co"],), 7.0, device="cuda")      # must be overwritten, not accumulated
+    db = torch.full((c["co"],), 7.0, device="cuda") if b is not None else None
+    ops.conv2d_wgrad(xd, dyd, cw, dw, db, c["s"], c["p"])
+    dw_oihw = host(dw.reshape(c["k"], c["k"], cin, c["co"]).permute(3, 2, 0, 1))
+    assert rel_err(dw_oihw, wt.grad) < 2e-5
+    if b is not None:
+        assert rel_err(host(db), b.grad) < 2e-5
+    ops.conv2d_wgrad(xd, dyd, cw, dw, db, c["s"], c["p"], accumulate=True)
+    assert rel_err(host(dw.reshape(c["k"], c["k"], cin, c["co"]).permute(3, 2, 0, 1)), 2 * wt.grad) < 2e-5
+    if c.get("no_dx"):
+        ops.conv2d_dgrad(dyd, cw, [tuple(x.shape) for x in xs], [None] * len(xs), [0] * len(xs), c["s"], c["p"])
+        return
+    dsts = [torch.full_like(x, 3.0, memory_format=CL) for x in xd]
+    acc = [i % 2 for i in range(len(xs))]                    # odd sources accumulate onto the 3.0
+    ops.conv2d_dgrad(dyd, cw, [tuple(x.shape) for x in xs], dsts, acc, c["s"], c["p"])
+    for i, x in enumerate(xs):
+        ref = x.grad + (3.0 if acc[i] else 0.0)
+        assert rel_err(host(dsts[i]), ref) < 2e-5
+
+
+def test_dgrad_rejects_replicate():
+    cw = ops.ConvWeights(torch.zeros(4, 4, 3, 3), None, "cuda")
+    dy = torch.zeros(1, 4, 8, 8, device="cuda").contiguous(memory_format=CL)
+    with pytest.raises(capi.IEError):
+        ops.conv2d_dgrad(dy, cw, [(1, 4, 8, 8)], [torch.empty_like(dy)], [0], 1, 1, "replicate")
+
+
+# ---- streaming backward ops ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("h,w", [(12, 16), (13, 17)])
+def test_maxpool_backward(h, w):
+    x = F.relu(rnd(2, 6, h, w, seed=1)).requires_grad_(True)            # ReLU output: ties at zero, like in the network
+    y = F.max_pool2d(x, 2)
+    dy = rnd(*y.shape, seed=2)
+    y.backward(dy)
+    xd = dev(x.detach())
+    dx = torch.full_like(xd, 1.0, memory_format=CL)
+    ops.maxpool2x2_backward(xd, dev(dy), dx, 1)
+    assert rel_err(host(dx), x.grad + 1.0) == 0.0
+    ops.maxpool2x2_backward(xd, dev(dy), dx, 0)
+    assert torch.equal(host(dx), x.grad)
+
+
+@pytest.mark.parametrize("mode,hi,wi,ho,wo", [("bilinear_align", 5, 7, 10, 14), ("bilinear_align", 67, 9, 134, 18), ("bilinear_align", 1, 3, 2, 6),
+                                              ("bilinear", 8, 12, 16, 24), ("bilinear", 17, 11, 9, 20), ("nearest", 5, 6, 20, 24),
+                                              ("nearest", 9, 14, 4, 5), ("bilinear_align", 12, 10, 5, 4)])
+def test_resize_backward(mode, hi, wi, ho, wo):
+    x = rnd(2, 5, hi, wi, seed=1).requires_grad_(True)
+    if mode == "nearest":
+        y = F.interpolate(x, size=(ho, wo))
+    else:
+        y = F.interpolate(x, size=(ho, wo), mode="bilinear", align_corners=(mode == "bilinear_align"))
+    dy = rnd(*y.shape, seed=2)
+    y.backward(dy)
+    assert rel_err(host(ops.resize(dev(x.detach()), (ho, wo), mode)), y.detach()) < 1e-5
+    dx = torch.full((2, 5, hi, wi), 2.0, device="cuda").contiguous(memory_format=CL)
+    ops.resize_backward(dev(dy), dx, mode, 1)
+    assert rel_err(host(dx), x.grad + 2.0) < 1e-5
+    ops.resize_backward(dev(dy), dx, mode, 0)
+    assert rel_err(host(dx), x.grad) < 1e-5
+
+
+def test_crop_unshuffle_act_backward():
+    dy = rnd(2, 4, 11, 13, seed=1)
+    dx = torch.empty(2, 4, 8, 9, device="cuda").contiguous(memory_format=CL)
+    ops.crop_into(dev(dy), dx, 2, 1, 0)
+    assert torch.equal(host(dx), dy[:, :, 2:10, 1:10])
+    x = rnd(2, 12, 5, 6, seed=2).requires_grad_(True)
+    y = F.pixel_shuffle(x, 2)
+    g = rnd(*y.shape, seed=3)
+    y.backward(g)
+    dx = torch.empty(2, 12, 5, 6, device="cuda").contiguous(memory_format=CL)
+    ops.pixel_unshuffle_into(dev(g), dx, 2, 0)
+    assert torch.equal(host(dx), x.grad)
+    for act, fn in (("relu", F.relu), ("lrelu", lambda t: F.leaky_relu(t, 0.2)), ("tanh", torch.tanh), ("sigmoid", torch.sigmoid)):
+        x = rnd(1, 3, 9, 10, seed=4).requires_grad_(True)
+        y = fn(x)
+        y.backward(g[:1, :3, :9, :10].contiguous())
+        dx = torch.empty(1, 3, 9, 10, device="cuda").contiguous(memory_format=CL)
+        ops.act_backward_into(dev(g[:1, :3, :9, :10].contiguous()), dev(y.detach()), dx, act, 0.2)
+        assert rel_err(host(dx), x.grad) < 1e-5, act
+    x = (rnd(1, 3, 9, 10, seed=5) * 0.8 + 0.5).requires_grad_(True)
+    y = torch.clamp(x, 0, 1)
+    y.backward(g[:1, :3, :9, :10].contiguous())
+    ops.act_backward_into(dev(g[:1, :3, :9, :10].contiguous()), dev(x.detach()), dx, "clamp", 0.0, 0.0, 1.0)
+    assert torch.equal(host(dx), x.grad)
+
+
+# ---- optimiser -------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("clip,wd,gscale", [(0.1, 0.0, 1.0), (0.0, 0.01, 1.0), (5.0, 0.0, 0.5)])
+def test_adam_with_clip(clip, wd, gscale):
+    n = 10007
+    p0, L = rnd(n, seed=1), capi.lib()
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd)
+    pd, m, v = p0.cuda(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    acc = torch.zeros(1, device="cuda", dtype=torch.float64)
+    ws = torch.zeros(capi.SUMSQ_WS_DOUBLES, device="cuda", dtype=torch.float64)
+    for step in range(1, 4):
+        g = rnd(n, seed=10 + step, scale=0.05 * step)
+        pr.grad = (g * gscale).clone()
+        norm = float(torch.nn.utils.clip_grad_norm_([pr], clip)) if clip else None
+        opt.step()
+        gd = g.cuda()
+        capi.check(L.ie_sumsq_f32(capi.ptr(gd), n, gscale, capi.ptr(acc), capi.ptr(ws), 1, capi.current_stream()))
+        if clip:
+            assert abs(float(acc.item()) ** 0.5 - norm) < 1e-5 * max(1.0, norm)
+        capi.check(L.ie_adam_step_f32(capi.ptr(pd), capi.ptr(gd), capi.ptr(m), capi.ptr(v), n, step, 1e-2, 0.9, 0.999, 1e-8, wd, gscale,
+                                      capi.ptr(acc) if clip else None, clip, capi.current_stream()))
+        assert rel_err(host(pd), pr.detach()) < 2e-6, step
+
+
+# ---- whole training steps of U-Net ---------------------------------------------------------------------------------------------
+def _unet(upsampler, seed=11):
+    return mon_amd.MODELS.build(name="unet", in_channels=3, num_classes=3, base_channels=8, upsampler=upsampler, enhance=True,
+                                seed=seed).to("cuda")
+
+
+def _batches(n, h, w, steps, seed):
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for _ in range(steps):
+        tgt = torch.rand(n, 3, h, w, generator=g)
+        out.append(((tgt ** 2.2 * 0.4).contiguous(), tgt))              # dark input, bright target
+    return out
+
+
+@pytest.mark.parametrize("upsampler,h,w", [("bilinear", 48, 64), ("bilinear", 44, 60), ("pixelshuffle", 32, 48)])
+def test_unet_training_steps_match_torch(upsampler, h, w):
+    """Two optimiser steps.  Adam's default eps (1e-8) makes the update sign-like -- lr * g/(|g|+eps) -- so rounding-sized
+    gradient differences on near-zero gradients change a few weights by a fraction of lr and the second step then starts
+    from (slightly) different weights.  The chained comparison therefore uses eps = 1e-3, where the update is smooth in g;
+    the eps = 1e-8 arithmetic itself is pinned by test_adam_with_clip."""
+    model = _unet(upsampler)
+    sd0 = model.state_dict()
+    batches = _batches(2, h, w, 2, seed=3)
+    lr, clip, eps = 1e-3, 0.1, 1e-3
+    # The oracle runs in float64: torch's own fp32 CPU backward is ~5e-3 away from the fp64 result on this network (fp32
+    # partial sums in its BatchNorm backward; tools/train_diag.py prints both), the HIP path (fp64 channel sums) ~5e-6.
+    fwd = lambda p, b, x: otrain.unet_forward_train(p, b, x, upsampler, True)
+    log, final = otrain.training_steps({k: v.double() for k, v in sd0.items()}, [(a.double(), b.double()) for a, b in batches], fwd,
+                                       lambda a, b: otrain.l1_ssim_loss(a, b), lr=lr, clip=clip, eps=eps)
+    log32, _ = otrain.training_steps(sd0, batches[:1], fwd, lambda a, b: otrain.l1_ssim_loss(a, b), lr=lr, clip=clip, eps=eps)
+    assert abs(log32[0]["loss"][0] - log[0]["loss"][0]) < 1e-5
+    tr = mon_amd.Trainer(model, optimizer={"name": "adam", "lr": lr, "eps": eps}, loss={"name": "l1_ssim_loss"}, gradient_clip_val=clip)
+    for step, (img, tgt) in enumerate(batches):
+        out = tr.training_step({"image": img, "ref_image": tgt})
+        assert list(out)[:2] == ["enhanced", "loss"]
+        assert abs(float(out["loss"]) - log[step]["loss"][0]) < 2e-5, (step, float(out["loss"]), log[step]["loss"])
+        grads = tr.gradients()
+        gmax = max(float(v.abs().max()) for v in log[step]["grads"].values())
+        for k, ref in log[step]["grads"].items():
+            err = float((grads[k] - ref).abs().max())
+            assert err < 2e-4 * max(float(ref.abs().max()), 0.02 * gmax), (step, k, err, float(ref.abs().max()))
+        assert abs(tr.grad_norm() - log[step]["grad_norm"]) < 1e-4 * log[step]["grad_norm"]
+    sd1 = tr.state_dict()
+    for k, ref in final.items():
+        d = float((sd1[k] - ref).abs().max())
+        assert d < (1e-4 * max(1.0, float(ref.abs().max())) if "running_" in k else 0.01 * lr), (k, d)
+    moved = max(float((sd1[k] - sd0[k]).abs().max()) for k in sd0 if "running_" not in k)
+    assert moved > 0.5 * lr                                              # the steps really updated the weights
+    model2 = tr.sync_to_model().eval()
+    model2.predicting = True
+    out = model2.forward({"image": batches[0][0].cuda()})
+    assert out["enhanced"].shape == (2, 3, h, w)
+
+
+def test_trainer_requires_target_and_graph():
+    model = _unet("bilinear")
+    tr = mon_amd.Trainer(model)
+    with pytest.raises(ValueError):
+        tr.training_step({"image": torch.rand(1, 3, 32, 32)})
+    zd = mon_amd.MODELS.build(name="zero_dce_re").to("cuda")
+    with pytest.raises(capi.IEError):
+        mon_amd.Trainer(zd)
+
+
+# ---- data-parallel step: 2 ranks on the one GPU of the test box, gloo carries the flat gradient buffer ---------------------
+def _ddp_worker(rank, world, port, ret):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model = _unet("bilinear")
+    batches = _batches(4, 32, 48, 2, seed=9)
+    tr = mon_amd.Trainer(model, optimizer={"lr": 1e-3, "eps": 1e-3}, loss={"name": "l1_ssim_loss"}, gradient_clip_val=0.1)
+    norms = []
+    for img, tgt in batches:
+        lo, hi = mon_amd.sharding.shard_range(img.shape[0], rank, world)
+        tr.training_step({"image": img[lo:hi], "ref_image": tgt[lo:hi]})
+        norms.append(tr.grad_norm())
+    sd = tr.state_dict()
+    ret[rank] = ({k: v for k, v in sd.items() if "running_" not in k}, norms)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_unet_ddp_two_ranks_match_torch_mean_of_shard_gradients():
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ret = mp.Manager().dict()
+    mp.spawn(_ddp_worker, args=(2, port, ret), nprocs=2, join=True)
+    model = mon_amd.MODELS.build(name="unet", in_channels=3, num_classes=3, base_channels=8, enhance=True, seed=11)
+    sd0 = {k: v.double() for k, v in model.state_dict().items()}
+    batches = [(a.double(), b.double()) for a, b in _batches(4, 32, 48, 2, seed=9)]
+    shards = [[(a[:2], b[:2]), (a[2:], b[2:])] for a, b in batches]
+    log, final = otrain.training_steps(sd0, batches, lambda p, b, x: otrain.unet_forward_train(p, b, x, "bilinear", True),
+                                       lambda a, b: otrain.l1_ssim_loss(a, b), lr=1e-3, clip=0.1, eps=1e-3, world_batches=shards)
+    (sd_a, norms_a), (sd_b, norms_b) = ret[0], ret[1]
+    for k in sd_a:
+        assert torch.equal(sd_a[k], sd_b[k]), k                         # replicas stay bit-identical
+        d = (sd_a[k] - final[k]).abs()
+        assert float(d.max()) < 1e-5, k
+    for step in range(2):
+        assert abs(norms_a[step] - log[step]["grad_norm"]) < 1e-4 * log[step]["grad_norm"]
+        assert norms_a[step] == norms_b[step]
