@@ -532,3 +532,136 @@ class RetinexNet(_GraphModel):
         out["illumination_delta"] = ops.to_nchw(i_delta)
         out["enhanced"] = ops.to_nchw(s)
         return out
+
+
+# ----------------------------------------------------------------------------------------------------------------
+@MODELS.register(name="hinet_re", arch="hinet")
+class HINet_RE(_GraphModel):
+    """HINet (hinet.py:204-362): two U-Net stages of ``UNetConvBlock`` (hinet.py:34-87: Conv3x3 -> InstanceNorm on the
+    first half of the channels -> LeakyReLU -> Conv3x3 -> LeakyReLU, + Conv1x1 identity, + cross-stage feature fusion,
+    Conv4x4 stride-2 down-sampling), ``UNetUpBlock`` (ConvTranspose 2x2 + cat + block, :90-119), supervised attention
+    between the stages (:122-198).  Outputs ``stage1`` and ``enhanced`` (last).
+
+    The reference's ``if enc and dec:`` (hinet.py:80) raises on multi-element tensors, so stage 2 cannot run as shipped;
+    the intended test (``enc is not None and dec is not None``, as in the original HINet) is implemented.
+    Checkpoint keys are the reference module names (``down_path_1.0.conv_1.weight`` ... ``sam12.conv3.bias``, ``last``)."""
+
+    arch = "hinet"
+    tasks = [Task.DEBLUR, Task.DENOISE, Task.DERAIN, Task.DESNOW, Task.LES]
+    schemes = [Scheme.SUPERVISED]
+
+    def __init__(self, in_channels: int = 3, num_channels: int = 64, depth: int = 5, relu_slope: float = 0.2, in_pos_left: int = 0,
+                 in_pos_right: int = 4, weights: Any = None, seed: int = None, *args, **kwargs):
+        kwargs.pop("name", None)
+        super().__init__(name="hinet_re", in_channels=in_channels, weights=weights, *args, **kwargs)
+        if isinstance(self.weights, dict):
+            in_channels = self.weights.get("in_channels", in_channels)
+            num_channels = self.weights.get("num_channels", num_channels)
+            depth = self.weights.get("depth", depth)
+            relu_slope = self.weights.get("relu_slope", relu_slope)
+            in_pos_left = self.weights.get("in_pos_left", in_pos_left)
+            in_pos_right = self.weights.get("in_pos_right", in_pos_right)
+        self.in_channels, self.num_channels, self.depth, self.relu_slope = in_channels, num_channels, depth, relu_slope
+        self.in_pos_left, self.in_pos_right = in_pos_left, in_pos_right
+        self.predicting = True
+        P = self._params
+
+        def conv(name, ci, co, k, bias=True):
+            P[f"{name}.weight"] = torch.zeros(co, ci, k, k)
+            if bias:
+                P[f"{name}.bias"] = torch.zeros(co)
+
+        def block(name, ci, co, down, csff, hin):
+            conv(f"{name}.identity", ci, co, 1); conv(f"{name}.conv_1", ci, co, 3); conv(f"{name}.conv_2", co, co, 3)
+            if down and csff:
+                conv(f"{name}.csff_enc", co, co, 3); conv(f"{name}.csff_dec", co, co, 3)
+            if hin:
+                P[f"{name}.norm.weight"], P[f"{name}.norm.bias"] = torch.ones(co // 2), torch.zeros(co // 2)
+            if down:
+                conv(f"{name}.downsample", co, co, 4, bias=False)
+
+        c = num_channels
+        conv("conv_01", in_channels, c, 3); conv("conv_02", in_channels, c, 3)
+        self._hin, prev = [], c
+        for i in range(depth):
+            hin, down = in_pos_left <= i <= in_pos_right, (i + 1) < depth
+            self._hin.append(hin)
+            block(f"down_path_1.{i}", prev, (2 ** i) * c, down, False, hin)
+            block(f"down_path_2.{i}", prev, (2 ** i) * c, down, down, hin)
+            prev = (2 ** i) * c
+        for j, i in enumerate(reversed(range(depth - 1))):
+            for s in (1, 2):
+                P[f"up_path_{s}.{j}.up.weight"], P[f"up_path_{s}.{j}.up.bias"] = torch.zeros(prev, (2 ** i) * c, 2, 2), torch.zeros((2 ** i) * c)
+                block(f"up_path_{s}.{j}.conv_block", prev, (2 ** i) * c, False, False, False)
+                conv(f"skip_conv_{s}.{j}", (2 ** i) * c, (2 ** i) * c, 3)
+            prev = (2 ** i) * c
+        conv("sam12.conv1", prev, prev, 3); conv("sam12.conv2", prev, 3, 3); conv("sam12.conv3", 3, prev, 3)
+        conv("cat12", prev * 2, prev, 1); conv("last", prev, in_channels, 3)
+        self._finish_init(seed)
+
+    def init_weights(self, seed: int = None):
+        # hinet.py:301-308 only touches modules that have a ``.conv`` attribute (none of these), i.e. torch's default
+        # Conv2d / ConvTranspose2d init stays: U(+-1/sqrt(fan_in)); ConvTranspose2d's fan_in is Cout*k*k (weight dim 1).
+        g = self._gen(seed)
+        for k in list(self._params):
+            if k.endswith(".weight") and self._params[k].dim() == 4:
+                self._init_conv(k[:-7], g)
+        self._on_params_change()
+
+    def _ct(self, name):
+        if self._dev_cache is None:
+            self._dev_cache = {}
+        if name not in self._dev_cache:
+            self._dev_cache[name] = ops.ConvT2x2Weights(self._params[f"{name}.weight"], self._params[f"{name}.bias"], self.device)
+        return self._dev_cache[name]
+
+    def _block(self, name, srcs, hin, down, enc=None, dec=None):
+        s = self.relu_slope
+        idn = ops.conv2d(srcs, self._cw(f"{name}.identity"), pad=0)
+        if hin:
+            y = ops.conv2d(srcs, self._cw(f"{name}.conv_1"))
+            half = y.shape[1] // 2
+            y = ops.instance_norm(y, self._vec(f"{name}.norm.weight"), self._vec(f"{name}.norm.bias"), 1e-5, "lrelu", s, 0, half)
+        else:
+            y = ops.conv2d(srcs, self._cw(f"{name}.conv_1"), act="lrelu", slope=s)
+        y = ops.conv2d(y, self._cw(f"{name}.conv_2"), act="lrelu", slope=s, residual=idn)
+        if enc is not None and dec is not None:
+            y = ops.conv2d(enc, self._cw(f"{name}.csff_enc"), residual=y)
+            y = ops.conv2d(dec, self._cw(f"{name}.csff_dec"), residual=y)
+        if down:
+            return ops.conv2d(y, self._cw(f"{name}.downsample"), stride=2, pad=1), y
+        return y
+
+    def _stage(self, s, x, encs=None, decs=None):
+        d = self.depth
+        ups, outs = [], []
+        for i in range(d):
+            name = f"down_path_{s}.{i}"
+            if i + 1 < d:
+                e, dd = (encs[i], decs[-i - 1]) if encs is not None else (None, None)
+                x, x_up = self._block(name, [x], self._hin[i], True, e, dd)
+                ups.append(x_up)
+            else:
+                x = self._block(name, [x], self._hin[i], False)
+        for j in range(d - 1):
+            bridge = ops.conv2d(ups[-j - 1], self._cw(f"skip_conv_{s}.{j}"))
+            x = self._block(f"up_path_{s}.{j}.conv_block", [ops.conv_transpose2x2(x, self._ct(f"up_path_{s}.{j}.up")), bridge], False, False)
+            outs.append(x)
+        return x, ups, outs
+
+    def forward(self, datapoint: dict, *args, **kwargs) -> dict:
+        x = self._input(datapoint)
+        m = 2 ** (self.depth - 1)
+        if x.shape[2] % m or x.shape[3] % m:
+            raise ValueError(f"HINet needs H and W divisible by {m} (got {x.shape[2]}x{x.shape[3]}); use infer(), which resizes "
+                             f"to a multiple of 32 like the reference (vision/model.py:106).")
+        x1, encs, decs = self._stage(1, ops.conv2d(x, self._cw("conv_01")))
+        # supervised attention (hinet.py:192-197)
+        f1 = ops.conv2d(x1, self._cw("sam12.conv1"))
+        img = ops.conv2d(x1, self._cw("sam12.conv2"), residual=x)
+        att = ops.conv2d(img, self._cw("sam12.conv3"), act="sigmoid")
+        sam = ops.add(ops.mul(f1, att), x1)
+        x2 = ops.conv2d([ops.conv2d(x, self._cw("conv_02")), sam], self._cw("cat12"), pad=0)
+        x2, _, _ = self._stage(2, x2, encs, decs)
+        y2 = ops.conv2d(x2, self._cw("last"), residual=x)
+        return OrderedDict(stage1=ops.to_nchw(img), enhanced=ops.to_nchw(y2))

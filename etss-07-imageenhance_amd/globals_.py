@@ -7,6 +7,8 @@ class Task(Enum):
     DENOISE = "denoise"
     DERAIN = "derain"
     DEBLUR = "deblur"
+    DESNOW = "desnow"
+    LES = "les"
     SEGMENT = "segment"
 
 

@@ -154,3 +154,47 @@ def retinexnet_forward(sd: dict, x: torch.Tensor) -> dict:
     fus = _c(sd, "net2_fusion", feats, padding=1, mode=R)
     i_delta = _c(sd, "net2_output", fus, padding=0)
     return {"reflectance": r_low, "illumination": i_low, "illumination_delta": i_delta, "enhanced": r_low * i_delta}
+
+
+# ---- HINet -------------------------------------------------------------------------------------------------------
+def hinet_forward(sd: dict, x: torch.Tensor, depth: int = 5, relu_slope: float = 0.2, in_pos_left: int = 0, in_pos_right: int = 4) -> dict:
+    """src/mon/vision/enhance/multitask/hinet/hinet.py:34-198, 322-362 with hinet.py:80's ``if enc and dec`` read as
+    ``enc is not None and dec is not None`` (as shipped it raises on tensors).  parity unpinned (mon not importable)."""
+    lr = lambda t: F.leaky_relu(t, relu_slope)
+
+    def block(n, t, hin, down, enc=None, dec=None):
+        y = _c(sd, f"{n}.conv_1", t)
+        if hin:
+            y1, y2 = torch.chunk(y, 2, dim=1)
+            y = torch.cat([F.instance_norm(y1, weight=sd[f"{n}.norm.weight"], bias=sd[f"{n}.norm.bias"], eps=1e-5), y2], 1)
+        y = lr(_c(sd, f"{n}.conv_2", lr(y))) + _c(sd, f"{n}.identity", t, padding=0)
+        if enc is not None and dec is not None:
+            y = y + _c(sd, f"{n}.csff_enc", enc) + _c(sd, f"{n}.csff_dec", dec)
+        if down:
+            return F.conv2d(y, sd[f"{n}.downsample.weight"], None, stride=2, padding=1), y
+        return y
+
+    def stage(s, t, encs=None, decs=None):
+        ups, outs = [], []
+        for i in range(depth):
+            hin = in_pos_left <= i <= in_pos_right
+            if i + 1 < depth:
+                e, d = (encs[i], decs[-i - 1]) if encs is not None else (None, None)
+                t, up = block(f"down_path_{s}.{i}", t, hin, True, e, d)
+                ups.append(up)
+            else:
+                t = block(f"down_path_{s}.{i}", t, hin, False)
+        for j in range(depth - 1):
+            bridge = _c(sd, f"skip_conv_{s}.{j}", ups[-j - 1])
+            u = F.conv_transpose2d(t, sd[f"up_path_{s}.{j}.up.weight"], sd[f"up_path_{s}.{j}.up.bias"], stride=2)
+            t = block(f"up_path_{s}.{j}.conv_block", torch.cat([u, bridge], 1), False, False)
+            outs.append(t)
+        return t, ups, outs
+
+    x1, encs, decs = stage(1, _c(sd, "conv_01", x))
+    f1 = _c(sd, "sam12.conv1", x1)
+    img = _c(sd, "sam12.conv2", x1) + x
+    sam = f1 * torch.sigmoid(_c(sd, "sam12.conv3", img)) + x1
+    x2 = _c(sd, "cat12", torch.cat([_c(sd, "conv_02", x), sam], 1), padding=0)
+    x2, _, _ = stage(2, x2, encs, decs)
+    return {"stage1": img, "enhanced": _c(sd, "last", x2) + x}

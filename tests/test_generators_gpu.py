@@ -138,3 +138,26 @@ def test_building_blocks_against_torch():
     assert torch.equal(ops.to_nchw(ops.clamp(xn, -0.5, 0.25)).cpu(), x.clamp(-0.5, 0.25))
     assert torch.equal(ops.to_nchw(ops.max_concat(xn)).cpu(), torch.cat([x.max(1, keepdim=True)[0], x], 1))
     assert torch.equal(ops.to_nchw(ops.mul_prefix(xn, ops.to_nhwc(one.cuda()))).cpu(), x[:, :23] * one)
+
+
+@pytest.mark.parametrize("cfg", [dict(num_channels=16, hw=(32, 48), n=2), dict(num_channels=8, depth=3, in_pos_left=1, in_pos_right=1, hw=(20, 28), n=1),
+                                 dict(num_channels=64, hw=(16, 32), n=1)], ids=["c16-d5", "c8-d3-hin1", "c64-default"])
+def test_hinet_vs_oracle(cfg):
+    """HINet (hinet.py:204-362): half instance norm, Conv4x4 stride 2, ConvTranspose 2x2, CSFF, SAM."""
+    hw, n = cfg.pop("hw"), cfg.pop("n")
+    m = mon_amd.MODELS.build(name="hinet_re", seed=5, **cfg).to("cuda")
+    x = torch.rand(n, 3, *hw, generator=torch.Generator().manual_seed(4))
+    out = m.forward({"image": x.cuda()})
+    assert list(out.keys()) == ["stage1", "enhanced"]
+    ref = og.hinet_forward(m.state_dict(), x, depth=cfg.get("depth", 5), in_pos_left=cfg.get("in_pos_left", 0), in_pos_right=cfg.get("in_pos_right", 4))
+    for k in ("stage1", "enhanced"):
+        assert rel_err(out[k].cpu(), ref[k]) <= TOL, k
+    with pytest.raises(ValueError):
+        m.forward({"image": torch.rand(1, 3, hw[0] + 2, hw[1]).cuda()})
+    if cfg["num_channels"] == 16:                           # infer(): resize to a multiple of 32 and back (vision/model.py:97-127)
+        y = torch.rand(1, 3, 40, 56, generator=torch.Generator().manual_seed(1))
+        got = m.infer({"image": y.clone()})
+        assert list(got.keys())[-2:] == ["enhanced", "time"] and tuple(got["enhanced"].shape) == (1, 3, 40, 56)
+        yr = F.interpolate(y, size=(64, 64), mode="bilinear", align_corners=False)
+        r = F.interpolate(og.hinet_forward(m.state_dict(), yr)["enhanced"], size=(40, 56), mode="bilinear", align_corners=False)
+        assert rel_err(got["enhanced"].cpu(), r) <= TOL

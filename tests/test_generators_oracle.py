@@ -67,3 +67,23 @@ def test_bn_folding_is_exact_in_fp64():
     ref = F.batch_norm(F.conv2d(x, w, b, padding=1), mean, var, gamma, beta, False, 0.1, 1e-5)
     w2, b2 = fold_bn(w, b, gamma, beta, mean, var)
     assert (F.conv2d(x, w2, b2, padding=1) - ref).abs().max() < 2e-5
+
+
+def test_hinet_structure_and_oracle_runs():
+    """hinet.py:204-304: 88.67 M parameters at the default width (the figure the HINet authors publish), reference
+    state_dict key names, and the CPU restatement runs the two stages with CSFF + SAM."""
+    m = mon_amd.MODELS.build(name="hinet_re", seed=0)
+    assert m.params == 88_669_702
+    keys = set(m.state_dict())
+    for k in ("conv_01.weight", "down_path_1.0.norm.weight", "down_path_1.3.downsample.weight", "down_path_2.0.csff_enc.bias",
+              "up_path_1.0.up.weight", "up_path_2.3.conv_block.identity.weight", "skip_conv_2.1.bias", "sam12.conv3.weight",
+              "cat12.weight", "last.bias"):
+        assert k in keys, k
+    assert "down_path_1.4.downsample.weight" not in keys and "down_path_1.0.csff_enc.weight" not in keys
+    assert tuple(m.state_dict()["up_path_1.0.up.weight"].shape) == (1024, 512, 2, 2)
+    small = mon_amd.MODELS.build(name="hinet_re", num_channels=8, seed=1)
+    x = torch.rand(1, 3, 32, 48, generator=torch.Generator().manual_seed(0))
+    out = og.hinet_forward(small.state_dict(), x)
+    assert list(out) == ["stage1", "enhanced"] and out["enhanced"].shape == x.shape
+    with pytest.raises(mon_amd.capi.IEError):
+        small.forward({"image": x})            # no CPU execution path
