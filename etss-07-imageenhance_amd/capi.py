@@ -29,6 +29,7 @@ SYMBOLS = [
     "ie_conv2d_nhwc_f32", "ie_pack_weight_hwio_f32", "ie_le_curve",
     "ie_convn_nhwc_f32", "ie_instnorm_nhwc_f32", "ie_maxpool2x2_nhwc_f32", "ie_resize_nhwc_f32", "ie_pixel_shuffle_nhwc_f32",
     "ie_conv_transpose2x2_nhwc_f32", "ie_pad_nhwc_f32", "ie_eltwise_nhwc_f32", "ie_max_concat_nhwc_f32",
+    "ie_mconv_packed_bytes", "ie_mconv_pack_weights", "ie_mconv_nhwc",
     "ie_norm_forward_nhwc_f32", "ie_norm_backward_nhwc_f32", "ie_convn_wgrad_nhwc_f32", "ie_convn_dgrad_nhwc_f32",
     "ie_maxpool2x2_backward_nhwc_f32", "ie_resize_backward_nhwc_f32", "ie_crop_nhwc_f32", "ie_pixel_unshuffle_nhwc_f32",
     "ie_act_backward_f32", "ie_l1_loss_f32", "ie_ssim_forward_f32", "ie_ssim_backward_f32", "ie_sumsq_f32", "ie_adam_step_f32",
@@ -59,6 +60,13 @@ class ConvNDesc(C.Structure):
                 ("kw", C.c_int), ("stride", C.c_int), ("pad", C.c_int), ("pad_mode", C.c_int), ("act", C.c_int),
                 ("slope", C.c_float), ("clamp", C.c_int), ("clamp_lo", C.c_float), ("clamp_hi", C.c_float),
                 ("Ho", C.c_int), ("Wo", C.c_int)]
+
+
+class MConvDesc(C.Structure):
+    _fields_ = [("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("nsrc", C.c_int), ("Cout", C.c_int), ("kh", C.c_int),
+                ("kw", C.c_int), ("stride", C.c_int), ("pad", C.c_int), ("pad_mode", C.c_int), ("act", C.c_int),
+                ("slope", C.c_float), ("clamp", C.c_int), ("clamp_lo", C.c_float), ("clamp_hi", C.c_float),
+                ("in_dtype", C.c_int), ("out_dtype", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int)]
 
 
 _lib = None
@@ -95,6 +103,10 @@ def lib():
     L.ie_eltwise_nhwc_f32.argtypes = [ip, vp, vp, vp, C.c_size_t, ip, ip, fp, fp, vp]
     L.ie_max_concat_nhwc_f32.argtypes = [vp, vp, C.c_size_t, ip, vp]
     i64, sz = C.c_int64, C.c_size_t
+    L.ie_mconv_packed_bytes.argtypes = [C.POINTER(ip), ip, ip, ip, ip]
+    L.ie_mconv_packed_bytes.restype = C.c_size_t
+    L.ie_mconv_pack_weights.argtypes = [vp, C.POINTER(ip), ip, ip, ip, ip, ip, vp, vp]
+    L.ie_mconv_nhwc.argtypes = [C.POINTER(MConvDesc), C.POINTER(vp), C.POINTER(ip), vp, vp, vp, vp, vp]
     L.ie_norm_forward_nhwc_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, fp, ip, ip, ip, ip, ip, ip, ip, fp, ip, fp, vp]
     L.ie_norm_backward_nhwc_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ip, ip, ip, ip, ip, ip, ip, ip, ip, fp, vp]
     L.ie_convn_wgrad_nhwc_f32.argtypes = [C.POINTER(ConvNDesc), C.POINTER(vp), C.POINTER(ip), vp, vp, vp, ip, vp, vp]

@@ -377,3 +377,91 @@ def act_backward_into(dy, ref, dx, act, slope=0.0, lo=0.0, hi=0.0, accumulate=Fa
     with torch.cuda.device(dy.device):
         capi.check(capi.lib().ie_act_backward_f32(capi.ptr(dy), capi.ptr(ref), capi.ptr(dx), dy.numel(), code, slope, lo, hi,
                                                   int(accumulate), capi.current_stream()), "ie_act_backward_f32")
+
+
+# ---- 16-bit matrix-core path (ie_mconv_*) ------------------------------------------------------------------------------
+TORCH_DT = {"f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32}
+IE_DT = {torch.float16: capi.IE_F16, torch.bfloat16: capi.IE_BF16, torch.float32: capi.IE_F32}
+
+
+def _chk16(t: torch.Tensor) -> torch.Tensor:
+    if not t.is_cuda or t.dtype not in (torch.float16, torch.bfloat16) or t.dim() != 4:
+        raise capi.IEError(f"expected a cuda fp16/bf16 (N,C,H,W) tensor, got {tuple(t.shape)} {t.dtype} {t.device}")
+    if not t.is_contiguous(memory_format=CL):
+        raise capi.IEError("expected channels_last (NHWC) memory")
+    return t
+
+
+def to_nhwc16(x: torch.Tensor, dtype, cpad: int = 8) -> torch.Tensor:
+    """NCHW fp32 image -> channels_last 16-bit with the channel count padded to a multiple of ``cpad`` (zeros)."""
+    x = x.to(torch.float32).contiguous()
+    n, c, h, w = x.shape
+    cp = (c + cpad - 1) // cpad * cpad
+    y = torch.empty((n, cp, h, w), device=x.device, dtype=dtype, memory_format=CL)
+    with torch.cuda.device(x.device):
+        capi.check(capi.lib().ie_nchw_f32_to_nhwc(capi.ptr(x), capi.ptr(y), IE_DT[dtype], n, c, h, w, cp, capi.current_stream()),
+                   "ie_nchw_f32_to_nhwc")
+    return y
+
+
+class MConvWeights:
+    """Weights of one Conv2d repacked for ie_mconv_nhwc: MFMA A-operand fragments per (cout tile, K chunk, tap), K chunked
+    per source of the virtual concat.  ``split``: channel counts of the sources as they will be passed (each a multiple
+    of 8; weights of padded input channels are zero).  ``cin_map``: for every source, the indices (into the checkpoint's
+    Cin) its channels correspond to, or -1 for padding channels."""
+
+    def __init__(self, w_oihw: torch.Tensor, bias, split, dtype, device, cin_map=None):
+        w = w_oihw.detach().to("cpu", torch.float32)
+        self.cout, cin, self.kh, self.kw = w.shape
+        self.split = [int(s) for s in split]
+        if cin_map is not None:
+            idx = torch.as_tensor(cin_map, dtype=torch.long)
+            wz = torch.zeros(self.cout, idx.numel(), self.kh, self.kw)
+            wz[:, idx >= 0] = w[:, idx[idx >= 0]]
+            w = wz
+        if w.shape[1] != sum(self.split):
+            raise capi.IEError(f"MConvWeights: weights carry {w.shape[1]} input channels, sources {sum(self.split)}")
+        w = w.contiguous()
+        self.dtype = dtype
+        chans = (C.c_int * len(self.split))(*self.split)
+        L = capi.lib()
+        nbytes = L.ie_mconv_packed_bytes(chans, len(self.split), self.cout, self.kh, self.kw)
+        if nbytes == 0:
+            capi.check(-1, "ie_mconv_packed_bytes")
+        self.w = torch.empty(nbytes, device=device, dtype=torch.uint8)
+        with torch.cuda.device(device):
+            capi.check(L.ie_mconv_pack_weights(capi.ptr(w), chans, len(self.split), self.cout, self.kh, self.kw, IE_DT[dtype],
+                                               capi.ptr(self.w), capi.current_stream()), "ie_mconv_pack_weights")
+        self.b = None if bias is None else bias.detach().to(device, torch.float32).contiguous()
+
+
+def mconv2d(srcs, mw: MConvWeights, stride=1, pad=1, pad_mode="zeros", act="none", slope=0.0, residual=None, clamp=None,
+            out_f32=False) -> torch.Tensor:
+    """16-bit Conv2d over the channel concat of ``srcs`` on the matrix cores."""
+    if isinstance(srcs, torch.Tensor):
+        srcs = [srcs]
+    for s in srcs:
+        _chk16(s)
+        if s.dtype != mw.dtype:
+            raise capi.IEError("mconv2d: source dtype differs from the packed weights")
+    cs = [int(s.shape[1]) for s in srcs]
+    if cs != mw.split:
+        raise capi.IEError(f"mconv2d: sources carry channels {cs}, weights were packed for {mw.split}")
+    n, _, h, w = srcs[0].shape
+    odt = torch.float32 if out_f32 else mw.dtype
+    d = capi.MConvDesc(n, h, w, len(srcs), mw.cout, mw.kh, mw.kw, stride, pad, capi.PAD[pad_mode], capi.ACT[act], slope,
+                       0 if clamp is None else 1, 0.0 if clamp is None else clamp[0], 0.0 if clamp is None else clamp[1],
+                       IE_DT[mw.dtype], IE_DT[odt], 0, 0)
+    ho = (h + 2 * pad - mw.kh) // stride + 1
+    wo = (w + 2 * pad - mw.kw) // stride + 1
+    out = torch.empty((n, mw.cout, ho, wo), device=srcs[0].device, dtype=odt, memory_format=CL)
+    if residual is not None:
+        _chk16(residual)
+        if tuple(residual.shape) != tuple(out.shape):
+            raise capi.IEError("mconv2d: residual shape mismatch")
+    ptrs = (C.c_void_p * len(srcs))(*[s.data_ptr() for s in srcs])
+    chans = (C.c_int * len(srcs))(*cs)
+    with torch.cuda.device(out.device):
+        capi.check(capi.lib().ie_mconv_nhwc(C.byref(d), ptrs, chans, capi.ptr(mw.w), capi.ptr(mw.b), capi.ptr(residual), capi.ptr(out),
+                                            capi.current_stream()), "ie_mconv_nhwc")
+    return out

@@ -136,6 +136,29 @@ int ie_eltwise_nhwc_f32(int op, const float* a_dev, const float* b_dev, float* y
 /* [max_c(x), x] channel concat (retinexnet/model.py:45-46). */
 int ie_max_concat_nhwc_f32(const float* x_dev, float* y_dev, size_t npix, int C, void* stream);
 
+/* ---- 16-bit matrix-core convolution for the generators (fast path of nn.Conv2d on the U-Net / RetinexNet / LLUnet++ /
+ * HINet graphs; same semantics as ie_convn_nhwc_f32) ---------------------------------------------------------------
+ * Activations NHWC fp16 or bf16 (channel counts multiples of 8), fp32 accumulate on v_mfma_f32_16x16x32; stride 1, or
+ * stride 2 computed as the stride-1 result sub-sampled in the epilogue; zero / replicate padding; virtual concat;
+ * fused bias + activation, then residual add (residual in in_dtype, stored shape), then clamp; output in_dtype or fp32.
+ * Weights are repacked once per layer AND per source split (K is chunked per source) by ie_mconv_pack_weights. */
+typedef struct ie_mconv_desc {
+    int N, H, W, nsrc, Cout, kh, kw, stride, pad;
+    int pad_mode;          /* ie_pad_mode */
+    int act;               /* ie_act */
+    float slope;
+    int clamp;             /* 0/1 */
+    float clamp_lo, clamp_hi;
+    int in_dtype;          /* IE_F16 | IE_BF16 */
+    int out_dtype;         /* in_dtype | IE_F32 */
+    int Ho, Wo;            /* out */
+} ie_mconv_desc;
+size_t ie_mconv_packed_bytes(const int* channels, int nsrc, int Cout, int kh, int kw);
+int ie_mconv_pack_weights(const float* w_oihw_host, const int* channels, int nsrc, int Cout, int kh, int kw, int dtype,
+                          void* dst_dev, void* stream);
+int ie_mconv_nhwc(ie_mconv_desc* d, const void* const* srcs_dev, const int* channels, const void* packed_w_dev,
+                  const float* bias_dev, const void* residual_dev, void* dst_dev, void* stream);
+
 /* ---- training path, fp32 NHWC: what torch.autograd does behind Model.training_step ---------
  * (src/mon/nn/model.py:701-746) for the layers above, the L1 + SSIM losses and Adam with gradient-norm clipping. */
 /* Forward of nn.InstanceNorm2d (per_sample=1) or of nn.BatchNorm2d in training mode (per_sample=0: batch

@@ -1,0 +1,84 @@
+"""GPU parity of the 16-bit matrix-core convolution (ie_mconv_nhwc) against torch CPU fp32 on the SAME 16-bit-rounded
+inputs and weights: the only differences left are fp32 accumulation order and the rounding of the stored result."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from mon_amd import capi, ops
+from tests.helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+CL = torch.channels_last
+
+CASES = [
+    dict(cs=[32], co=32, k=3, p=1),
+    dict(cs=[64], co=64, k=3, p=1, act="relu"),                       # unet.py:43-48 (BN folded)
+    dict(cs=[8], co=32, k=3, p=1, act="relu"),                        # first layer: RGB padded to 8 channels
+    dict(cs=[64, 64], co=64, k=3, p=1, act="relu"),                   # decoder concat [skip, up] (unet.py:97)
+    dict(cs=[32, 32, 32, 32, 64], co=32, k=3, p=1, act="lrelu"),      # LLUnet++ conv0_4 (llunetpp.py:239)
+    dict(cs=[40, 24], co=72, k=3, p=1, bias=False),                   # short chunks, ragged Cout tile
+    dict(cs=[256], co=128, k=3, p=1, act="relu"),                     # two cout tiles, 8 K chunks
+    dict(cs=[32], co=3, k=1, p=0, clamp=(0.0, 1.0), out_f32=True),    # outc + clamp, fp32 result (llunetpp.py:241)
+    dict(cs=[64], co=24, k=3, p=1, act="tanh"),
+    dict(cs=[8], co=64, k=9, p=4, mode="replicate"),                  # retinexnet/model.py:26 (4 -> padded 8)
+    dict(cs=[64], co=64, k=3, p=1, s=2, mode="replicate", act="relu"),  # retinexnet/model.py:60
+    dict(cs=[192], co=64, k=1, p=1, mode="replicate"),                # retinexnet/model.py:66 (grows the map)
+    dict(cs=[64], co=1, k=3, p=0),                                    # retinexnet/model.py:67
+    dict(cs=[32], co=32, k=4, p=1, s=2, bias=False),                  # hinet.py:65
+    dict(cs=[64], co=64, k=3, p=1, act="lrelu", residual=True),       # hinet.py:77 (+ identity)
+    dict(cs=[16], co=3, k=3, p=1, act="sigmoid"),                     # zero_ig.py:331
+]
+
+
+def _id(c):
+    return f"{'+'.join(map(str, c['cs']))}-{c['co']}-k{c['k']}s{c.get('s', 1)}p{c['p']}{c.get('mode', 'zeros')[0]}-{c.get('act', 'none')}"
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("c", CASES, ids=_id)
+def test_mconv_vs_torch(c, dt):
+    tdt = ops.TORCH_DT[dt]
+    n, h, w = 2, 37, 45                                                # ragged tiles in both directions
+    g = torch.Generator().manual_seed(11)
+    xs = [torch.randn(n, ci, h, w, generator=g).to(tdt) for ci in c["cs"]]
+    cin, k, s, p = sum(c["cs"]), c["k"], c.get("s", 1), c["p"]
+    wt = (torch.randn(c["co"], cin, k, k, generator=g) / (cin * k * k) ** 0.5).to(tdt).float()
+    b = None if c.get("bias") is False else torch.randn(c["co"], generator=g)
+    mode = c.get("mode", "zeros")
+    xcat = torch.cat([x.float() for x in xs], 1)
+    xp = F.pad(xcat, (p,) * 4, mode="replicate") if mode == "replicate" and p > 0 else xcat
+    ref = F.conv2d(xp, wt, b, stride=s, padding=0 if mode == "replicate" else p)
+    act = c.get("act", "none")
+    ref = {"none": lambda t: t, "relu": F.relu, "lrelu": lambda t: F.leaky_relu(t, 0.2), "tanh": torch.tanh, "sigmoid": torch.sigmoid}[act](ref)
+    res = None
+    if c.get("residual"):
+        res = torch.randn(ref.shape, generator=g).to(tdt)
+        ref = ref + res.float()
+    if c.get("clamp"):
+        ref = ref.clamp(*c["clamp"])
+    mw = ops.MConvWeights(wt, b, c["cs"], tdt, "cuda")
+    out = ops.mconv2d([x.cuda().contiguous(memory_format=CL) for x in xs], mw, stride=s, pad=p, pad_mode=mode, act=act, slope=0.2,
+                      residual=None if res is None else res.cuda().contiguous(memory_format=CL), clamp=c.get("clamp"),
+                      out_f32=c.get("out_f32", False))
+    assert tuple(out.shape) == tuple(ref.shape)
+    assert out.dtype == (torch.float32 if c.get("out_f32") else tdt)
+    tol = 2e-5 if c.get("out_f32") else (1.5e-3 if dt == "f16" else 1e-2)     # stored-result rounding: 2^-11 / 2^-8 relative
+    assert rel_err(out.float().cpu(), ref) <= tol
+
+
+def test_mconv_input_channel_map_and_errors():
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(16, 3, 3, 3, generator=g).half().float()
+    x = torch.rand(1, 3, 20, 24, generator=g)
+    x16 = ops.to_nhwc16(x.cuda(), torch.float16)                       # RGB -> 8 channels, zeros appended
+    assert x16.shape[1] == 8 and float(x16[:, 3:].abs().max()) == 0.0
+    mw = ops.MConvWeights(w, None, [8], torch.float16, "cuda", cin_map=[0, 1, 2, -1, -1, -1, -1, -1])
+    out = ops.mconv2d(x16, mw)
+    ref = F.conv2d(x.half().float(), w, None, padding=1)
+    assert rel_err(out.float().cpu(), ref) <= 1.5e-3
+    with pytest.raises(capi.IEError):
+        ops.MConvWeights(w, None, [3], torch.float16, "cuda")          # channel counts must be multiples of 8
+    with pytest.raises(capi.IEError):
+        ops.mconv2d(x16.to(torch.bfloat16), mw)
+    with pytest.raises(capi.IEError):
+        ops.mconv2d([x16, x16], mw)
