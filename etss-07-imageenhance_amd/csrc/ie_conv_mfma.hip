@@ -38,11 +38,92 @@ struct MConvParams {
     float slope, lo, hi;
 };
 
-template <typename T, int NF>
+// activation with the hardware exp2/rcp forms (|err| <= 3e-7): one code path per template instance keeps the epilogue small
+template <int ACT> __device__ __forceinline__ float act_fast(float v, float slope) {
+    if constexpr (ACT == IE_ACT_RELU) return fmaxf(v, 0.f);
+    else if constexpr (ACT == IE_ACT_LRELU) return v > 0.f ? v : v * slope;
+    else if constexpr (ACT == IE_ACT_TANH) return ie_tanh_fast(v);
+    else if constexpr (ACT == IE_ACT_SIGMOID) return ie_sigmoid_fast(v);
+    else return v;
+}
+
+template <typename T, int NF, int ACT>
+__device__ __forceinline__ void mconv_epilogue(const MConvParams& p, ie_f32x4 (&acc)[8][NF], int n, int ct, int oy0, int ox0, int wave, int kc,
+                                            int l16) {
+    float bv[NF][4];
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int co = (ct * NF + f) * 16 + kc * 4 + j;
+            bv[f][j] = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
+        }
+    const bool quad = (p.Cout & 3) == 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int oy = oy0 + wave * 4 + (i >> 1), ox = ox0 + (i & 1) * 16 + l16;
+        bool live = oy < p.Ho && ox < p.Wo;
+        int sy = oy, sx = ox;
+        if (p.sub > 1) {
+            live = live && !(oy % p.sub) && !(ox % p.sub);
+            sy = oy / p.sub; sx = ox / p.sub;
+        }
+        if (!live) continue;
+        const size_t opix = ((size_t)n * p.Hs + sy) * p.Ws + sx;
+        float v[NF][4];
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[f][j] = act_fast<ACT>(acc[i][f][j] + bv[f][j], p.slope);
+        if (p.res) {
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const int co = (ct * NF + f) * 16 + kc * 4;
+                const T* rp = (const T*)p.res + opix * p.Cout + co;
+                if (quad && co + 3 < p.Cout) {
+                    typedef __attribute__((ext_vector_type(4))) T t4;
+                    const t4 r4 = *(const t4*)rp;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[f][j] += (float)r4[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (co + j < p.Cout) v[f][j] += (float)rp[j];
+                }
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            const int co = (ct * NF + f) * 16 + kc * 4;
+            if (co >= p.Cout) continue;
+            if (p.clamp) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[f][j] = fminf(fmaxf(v[f][j], p.lo), p.hi);
+            }
+            const size_t o = opix * p.Cout + co;
+            const bool full = quad && (co + 3 < p.Cout);
+            if (p.out_f32) {
+                float* dp = (float*)p.dst + o;
+                if (full) *(ie_f32x4*)dp = ie_f32x4{v[f][0], v[f][1], v[f][2], v[f][3]};
+                else
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (co + j < p.Cout) dp[j] = v[f][j];
+            } else {
+                T* dp = (T*)p.dst + o;
+                if (full) *(ie_u32x2*)dp = ie_u32x2{ie_pack2<T>(v[f][0], v[f][1]), ie_pack2<T>(v[f][2], v[f][3])};
+                else
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (co + j < p.Cout) dp[j] = (T)v[f][j];
+            }
+        }
+    }
+}
+
+template <typename T, int NF, bool K3>
 __global__ __launch_bounds__(256, 2) void mconv_kernel(MConvParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using frag = typename ie_elem<T>::frag;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // XCD-aware block order: physical id -> logical id so that consecutive logical ids (the cout tiles of one pixel tile,
     // then the neighbouring pixel tile) share an XCD and therefore an L2
     const int pb = blockIdx.x;
@@ -54,9 +135,11 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(MConvParams p) {
     const int n = lb / p.tiles_y;
     if (n >= p.N) return;                      // padding blocks (uniform over the workgroup)
     const int oy0 = ty * TH, ox0 = tx * TW;
-    const int TWH = TW + p.kw - 1, THH = TH + p.kh - 1, TPX = TWH * THH;
+    const int KH = K3 ? 3 : p.kh, KW = K3 ? 3 : p.kw;
+    const int TWH = TW + KW - 1, THH = TH + KH - 1, TPX = TWH * THH;
+    const int ND = (TPX + 15) >> 4;            // 1-KB (16-pixel) LDS-DMA instructions that fill the input tile
     unsigned char* in_lds = smem;
-    unsigned char* w_lds = smem + (size_t)TPX * 64;
+    unsigned char* w_lds = smem + (size_t)ND * 1024;
     const int kc = lane >> 4, l16 = lane & 15;
 
     ie_f32x4 acc[8][NF];
@@ -65,104 +148,97 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(MConvParams p) {
 #pragma unroll
         for (int f = 0; f < NF; ++f) acc[i][f] = ie_f32x4{0.f, 0.f, 0.f, 0.f};
 
-    int q0[8];                                  // LDS pixel index of each of the wave's 8 pixel fragments at tap (0,0)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) q0[i] = (wave * 4 + (i >> 1)) * TWH + (i & 1) * 16 + l16;
-
-    const size_t w_stage_bytes = (size_t)p.taps_stage * 16 * NF * 64;
+    const unsigned w_stage_bytes = (unsigned)p.taps_stage * 16 * NF * 64;
     const unsigned char* wpk = (const unsigned char*)p.wpk + (size_t)ct * p.nchunks * p.nstages * w_stage_bytes;
+    constexpr unsigned OOB = 0xFFFFFFF0u;      // beyond every buffer range (host-checked): the load returns zeros
 
     for (int ch = 0; ch < p.nchunks; ++ch) {
         const int s = p.chunk_src[ch], c0 = p.chunk_c0[ch], Cs = p.cs[s];
-        const T* sp = (const T*)p.src[s] + (size_t)n * p.H * p.W * Cs + c0;
+        const size_t frame_b = (size_t)p.H * p.W * Cs * sizeof(T);
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.src[s] + (size_t)n * frame_b), 0, (int)frame_b, 0x00020000);
         __syncthreads();                        // the previous chunk's fragments have been read
-        for (int i = tid; i < TPX * 4; i += 256) {
-            const int q = i >> 2, j = i & 3;
+        // input halo tile by LDS-DMA: lane -> (pixel q, 16-byte slot); the slot holds channel piece slot ^ ((q>>1)&3).
+        // Zero padding, the tile's overhang and the zero fill of a short chunk are all "out-of-range offset -> zeros".
+        for (int d = wave; d < ND; d += 4) {
+            const int q = d * 16 + (lane >> 2);
+            const int j = (lane & 3) ^ ((q >> 1) & 3);
             const int r = q / TWH, c = q - r * TWH;
             int iy = oy0 + r - p.pad, ix = ox0 + c - p.pad;
-            bool ok = c0 + j * 8 < Cs;
+            bool ok = (c0 + j * 8 < Cs) && (q < TPX);
             if (p.pad_mode == IE_PAD_REPLICATE) { iy = min(max(iy, 0), p.H - 1); ix = min(max(ix, 0), p.W - 1); }
             else ok = ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            ie_u32x4 v = {0u, 0u, 0u, 0u};
-            if (ok) v = *(const ie_u32x4*)(sp + ((size_t)iy * p.W + ix) * Cs + j * 8);
-            *(ie_u32x4*)(in_lds + (size_t)q * 64 + ((j ^ ((q >> 1) & 3)) << 4)) = v;
+            const unsigned off = ok ? (unsigned)(((unsigned)(iy * p.W + ix) * (unsigned)Cs + (unsigned)(c0 + j * 8)) * sizeof(T)) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(in_lds + d * 1024), 16, (int)off, 0, 0, 0);
         }
         for (int st = 0; st < p.nstages; ++st) {
             if (st > 0) __syncthreads();        // previous stage's weights have been read
-            const ie_u32x4* wsrc = (const ie_u32x4*)(wpk + ((size_t)ch * p.nstages + st) * w_stage_bytes);
-            for (int i = tid; i < (int)(w_stage_bytes >> 4); i += 256) ((ie_u32x4*)w_lds)[i] = wsrc[i];
+            const auto rw = __builtin_amdgcn_make_buffer_rsrc((void*)(wpk + ((size_t)ch * p.nstages + st) * w_stage_bytes), 0,
+                                                              (int)w_stage_bytes, 0x00020000);
+            for (int d = wave; d < p.taps_stage * NF; d += 4)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(w_lds + d * 1024), 16, d * 1024 + lane * 16, 0, 0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            const int tap0 = st * p.taps_stage;
-            for (int t = 0; t < p.taps_stage; ++t) {
-                const int tap = tap0 + t;
-                if (tap >= p.kh * p.kw) break;
-                const int ky = tap / p.kw, kx = tap - ky * p.kw;
-                frag a[NF];
+            if constexpr (K3) {
+                // 3x3: every pixel fragment (input row, column half, kx) feeds the MFMAs of up to three output rows (ky = 0,1,2)
+#pragma unroll 1
+                for (int kx = 0; kx < 3; ++kx) {
+                    frag a[3][NF];
 #pragma unroll
-                for (int f = 0; f < NF; ++f) {
-                    const int row = (t * NF + f) * 16 + l16;
-                    a[f] = *(const frag*)(w_lds + (size_t)row * 64 + ((kc ^ ((l16 >> 1) & 3)) << 4));
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int f = 0; f < NF; ++f) {
+                            const int row = ((ky * 3 + kx) * NF + f) * 16 + l16;
+                            a[ky][f] = *(const frag*)(w_lds + (size_t)row * 64 + ((kc ^ ((l16 >> 1) & 3)) << 4));
+                        }
+#pragma unroll
+                    for (int ir = 0; ir < 6; ++ir) {
+#pragma unroll
+                        for (int hf = 0; hf < 2; ++hf) {
+                            const int q = (wave * 4 + ir) * TWH + hf * 16 + l16 + kx;
+                            const frag b = *(const frag*)(in_lds + (size_t)q * 64 + ((kc ^ ((q >> 1) & 3)) << 4));
+#pragma unroll
+                            for (int ky = 0; ky < 3; ++ky) {
+                                const int orow = ir - ky;
+                                if (orow < 0 || orow > 3) continue;
+#pragma unroll
+                                for (int f = 0; f < NF; ++f) acc[orow * 2 + hf][f] = ie_elem<T>::mfma16(a[ky][f], b, acc[orow * 2 + hf][f]);
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);      // keep the fragment reads of later rows from being hoisted (VGPR budget)
+                    }
                 }
-                const int dq = ky * TWH + kx;
+            } else {
+                const int tap0 = st * p.taps_stage;
+                for (int t = 0; t < p.taps_stage; ++t) {
+                    const int tap = tap0 + t;
+                    if (tap >= KH * KW) break;
+                    const int ky = tap / KW, kx = tap - ky * KW;
+                    frag a[NF];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int q = q0[i] + dq;
-                    const frag b = *(const frag*)(in_lds + (size_t)q * 64 + ((kc ^ ((q >> 1) & 3)) << 4));
+                    for (int f = 0; f < NF; ++f) {
+                        const int row = (t * NF + f) * 16 + l16;
+                        a[f] = *(const frag*)(w_lds + (size_t)row * 64 + ((kc ^ ((l16 >> 1) & 3)) << 4));
+                    }
+                    const int dq = ky * TWH + kx;
 #pragma unroll
-                    for (int f = 0; f < NF; ++f) acc[i][f] = ie_elem<T>::mfma16(a[f], b, acc[i][f]);
+                    for (int i = 0; i < 8; ++i) {
+                        const int q = (wave * 4 + (i >> 1)) * TWH + (i & 1) * 16 + l16 + dq;
+                        const frag b = *(const frag*)(in_lds + (size_t)q * 64 + ((kc ^ ((q >> 1) & 3)) << 4));
+#pragma unroll
+                        for (int f = 0; f < NF; ++f) acc[i][f] = ie_elem<T>::mfma16(a[f], b, acc[i][f]);
+                    }
                 }
             }
         }
     }
 
     // epilogue: lane holds couts co0 + 4*kc + {0..3} of pixel (row, col + l16) for each (i, f)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int oy = oy0 + wave * 4 + (i >> 1), ox = ox0 + (i & 1) * 16 + l16;
-        if (oy >= p.Ho || ox >= p.Wo) continue;
-        int sy = oy, sx = ox;
-        if (p.sub > 1) {
-            if ((oy % p.sub) || (ox % p.sub)) continue;
-            sy = oy / p.sub; sx = ox / p.sub;
-        }
-        const size_t opix = ((size_t)n * p.Hs + sy) * p.Ws + sx;
-#pragma unroll
-        for (int f = 0; f < NF; ++f) {
-            const int co = (ct * NF + f) * 16 + kc * 4;
-            if (co >= p.Cout) continue;
-            float v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float x = acc[i][f][j];
-                if (p.bias && co + j < p.Cout) x += p.bias[co + j];
-                x = ie_act_apply(x, p.act, p.slope);
-                v[j] = x;
-            }
-            const size_t o = opix * p.Cout + co;
-            const bool full = (co + 3 < p.Cout) && ((p.Cout & 3) == 0);
-            if (p.res) {
-                const T* rp = (const T*)p.res + o;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) if (co + j < p.Cout) v[j] += (float)rp[j];
-            }
-            if (p.clamp) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = fminf(fmaxf(v[j], p.lo), p.hi);
-            }
-            if (p.out_f32) {
-                float* dp = (float*)p.dst + o;
-                if (full) *(ie_f32x4*)dp = ie_f32x4{v[0], v[1], v[2], v[3]};
-                else
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) if (co + j < p.Cout) dp[j] = v[j];
-            } else {
-                T* dp = (T*)p.dst + o;
-                if (full) *(ie_u32x2*)dp = ie_u32x2{ie_pack2<T>(v[0], v[1]), ie_pack2<T>(v[2], v[3])};
-                else
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) if (co + j < p.Cout) dp[j] = (T)v[j];
-            }
-        }
+    switch (p.act) {
+    case IE_ACT_RELU: mconv_epilogue<T, NF, IE_ACT_RELU>(p, acc, n, ct, oy0, ox0, wave, kc, l16); break;
+    case IE_ACT_LRELU: mconv_epilogue<T, NF, IE_ACT_LRELU>(p, acc, n, ct, oy0, ox0, wave, kc, l16); break;
+    case IE_ACT_TANH: mconv_epilogue<T, NF, IE_ACT_TANH>(p, acc, n, ct, oy0, ox0, wave, kc, l16); break;
+    case IE_ACT_SIGMOID: mconv_epilogue<T, NF, IE_ACT_SIGMOID>(p, acc, n, ct, oy0, ox0, wave, kc, l16); break;
+    default: mconv_epilogue<T, NF, IE_ACT_NONE>(p, acc, n, ct, oy0, ox0, wave, kc, l16); break;
     }
 }
 
@@ -282,18 +358,24 @@ IE_EXPORT int ie_mconv_nhwc(ie_mconv_desc* d, const void* const* srcs, const int
     const long logical = (long)p.tiles_x * p.tiles_y * p.cout_tiles * d->N;
     p.total_blocks = (int)((logical + 7) / 8 * 8);
     p.taps_stage = pl.taps_stage; p.nstages = pl.nstages;
-    const size_t lds = (size_t)(TH + d->kh - 1) * (TW + d->kw - 1) * 64 + pl.stage_bytes;
+    const size_t lds = (size_t)(((TH + d->kh - 1) * (TW + d->kw - 1) + 15) / 16) * 1024 + pl.stage_bytes;
+    for (int s = 0; s < d->nsrc; ++s)
+        if ((double)d->H * d->W * channels[s] * 2.0 >= 4294967040.0) IE_FAIL(IE_ERR_UNSUPPORTED, "ie_mconv_nhwc: a frame of source %d exceeds 4 GiB", s);
     if (lds > 160 * 1024) IE_FAIL(IE_ERR_UNSUPPORTED, "ie_mconv_nhwc: %dx%d kernel needs %zu bytes of LDS", d->kh, d->kw, lds);
     void (*fn)(MConvParams) = nullptr;
     const bool h = d->in_dtype == IE_F16;
-    switch (pl.nf) {
-    case 1: fn = h ? mconv_kernel<_Float16, 1> : mconv_kernel<__bf16, 1>; break;
-    case 2: fn = h ? mconv_kernel<_Float16, 2> : mconv_kernel<__bf16, 2>; break;
-    default: fn = h ? mconv_kernel<_Float16, 4> : mconv_kernel<__bf16, 4>; break;
+    const bool k3 = d->kh == 3 && d->kw == 3;
+    switch (pl.nf * 2 + (k3 ? 1 : 0)) {
+    case 2: fn = h ? mconv_kernel<_Float16, 1, false> : mconv_kernel<__bf16, 1, false>; break;
+    case 3: fn = h ? mconv_kernel<_Float16, 1, true> : mconv_kernel<__bf16, 1, true>; break;
+    case 4: fn = h ? mconv_kernel<_Float16, 2, false> : mconv_kernel<__bf16, 2, false>; break;
+    case 5: fn = h ? mconv_kernel<_Float16, 2, true> : mconv_kernel<__bf16, 2, true>; break;
+    case 8: fn = h ? mconv_kernel<_Float16, 4, false> : mconv_kernel<__bf16, 4, false>; break;
+    default: fn = h ? mconv_kernel<_Float16, 4, true> : mconv_kernel<__bf16, 4, true>; break;
     }
     if (lds > 64 * 1024) {       // opt in to > 64 KB of dynamic LDS once per kernel (raised monotonically)
-        static size_t granted[6] = {0, 0, 0, 0, 0, 0};
-        const int slot = (h ? 0 : 3) + (pl.nf == 1 ? 0 : (pl.nf == 2 ? 1 : 2));
+        static size_t granted[12] = {0};
+        const int slot = (h ? 0 : 6) + (pl.nf == 1 ? 0 : (pl.nf == 2 ? 1 : 2)) * 2 + (k3 ? 1 : 0);
         if (granted[slot] < lds) {
             IE_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             granted[slot] = 160 * 1024;
