@@ -1,0 +1,312 @@
+// 16-bit (fp16 / bf16) NHWC streaming ops that sit between the matrix-core convolutions of the generators: 2x2 max-pool,
+// resize (nearest / bilinear), zero pad, pixel shuffle, element-wise add / multiply, instance norm, dtype / channel-count
+// casts.  All are HBM-bound single passes; a thread moves 8 channels (16 bytes) so every access is a full dwordx4 and
+// a wave covers 1 KB of contiguous NHWC memory.  Arithmetic is fp32 on the loaded values, one rounding on store.
+// Semantics are those of the fp32 kernels in ie_ops.hip / ie_norm.hip (reference call sites cited in include/ie_hip.h).
+#include "ie_common.h"
+#include <math.h>
+
+namespace {
+
+inline unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }
+
+template <typename T> __device__ __forceinline__ void unpack8(const ie_u32x4& r, float (&f)[8]) {
+    typedef __attribute__((ext_vector_type(8))) T t8;
+    const t8 v = __builtin_bit_cast(t8, r);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] = (float)v[k];
+}
+template <typename T> __device__ __forceinline__ ie_u32x4 pack8(const float (&f)[8]) {
+    return ie_u32x4{ie_pack2<T>(f[0], f[1]), ie_pack2<T>(f[2], f[3]), ie_pack2<T>(f[4], f[5]), ie_pack2<T>(f[6], f[7])};
+}
+template <typename T> __device__ __forceinline__ ie_u32x4 ld8(const T* p) { return *(const ie_u32x4*)p; }
+template <typename T> __device__ __forceinline__ void st8(T* p, const ie_u32x4& v) { *(ie_u32x4*)p = v; }
+
+// index decomposition of thread i over (n, h, w, c8)
+struct Idx { size_t n; int h, w, c; };
+__device__ __forceinline__ Idx split(size_t i, int H, int W, int C8) {
+    Idx r;
+    r.c = (int)(i % C8) * 8; i /= C8;
+    r.w = (int)(i % W); i /= W;
+    r.h = (int)(i % H);
+    r.n = i / H;
+    return r;
+}
+
+template <typename T>
+__global__ void maxpool2_v8(const T* __restrict__ x, T* __restrict__ y, int H, int W, int C, int Ho, int Wo, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const Idx o = split(i, Ho, Wo, C / 8);
+    const T* p = x + ((o.n * H + 2 * o.h) * W + 2 * o.w) * C + o.c;
+    float a[8], b[8], c[8], d[8], r[8];
+    unpack8<T>(ld8(p), a); unpack8<T>(ld8(p + C), b); unpack8<T>(ld8(p + (size_t)W * C), c); unpack8<T>(ld8(p + (size_t)W * C + C), d);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r[k] = fmaxf(fmaxf(a[k], b[k]), fmaxf(c[k], d[k]));
+    st8(y + ((o.n * Ho + o.h) * Wo + o.w) * C + o.c, pack8<T>(r));
+}
+
+template <typename T>
+__global__ void resize_v8(const T* __restrict__ x, T* __restrict__ y, int Hi, int Wi, int C, int Ho, int Wo, int mode, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const Idx o = split(i, Ho, Wo, C / 8);
+    const T* p = x + o.n * (size_t)Hi * Wi * C + o.c;
+    T* q = y + ((o.n * Ho + o.h) * Wo + o.w) * C + o.c;
+    if (mode == 0) {
+        const int ys = min((int)floorf(o.h * ((float)Hi / (float)Ho)), Hi - 1);
+        const int xs = min((int)floorf(o.w * ((float)Wi / (float)Wo)), Wi - 1);
+        st8(q, ld8(p + ((size_t)ys * Wi + xs) * C));
+        return;
+    }
+    float sy, sx;
+    if (mode == 2) {
+        sy = (Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f) * o.h;
+        sx = (Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f) * o.w;
+    } else {
+        sy = fmaxf((float)Hi / (float)Ho * (o.h + 0.5f) - 0.5f, 0.f);
+        sx = fmaxf((float)Wi / (float)Wo * (o.w + 0.5f) - 0.5f, 0.f);
+    }
+    const int y0 = min((int)sy, Hi - 1), x0 = min((int)sx, Wi - 1);
+    const int y1 = min(y0 + 1, Hi - 1), x1 = min(x0 + 1, Wi - 1);
+    const float ly = sy - (float)y0, lx = sx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+    float a[8], b[8], c[8], d[8], r[8];
+    unpack8<T>(ld8(p + ((size_t)y0 * Wi + x0) * C), a); unpack8<T>(ld8(p + ((size_t)y0 * Wi + x1) * C), b);
+    unpack8<T>(ld8(p + ((size_t)y1 * Wi + x0) * C), c); unpack8<T>(ld8(p + ((size_t)y1 * Wi + x1) * C), d);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r[k] = hy * (hx * a[k] + lx * b[k]) + ly * (hx * c[k] + lx * d[k]);
+    st8(q, pack8<T>(r));
+}
+
+template <typename T>
+__global__ void pad_v8(const T* __restrict__ x, T* __restrict__ y, int H, int W, int C, int top, int left, int Ho, int Wo, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const Idx o = split(i, Ho, Wo, C / 8);
+    const int h = o.h - top, w = o.w - left;
+    ie_u32x4 v = {0u, 0u, 0u, 0u};
+    if (h >= 0 && h < H && w >= 0 && w < W) v = ld8(x + ((o.n * H + h) * W + w) * C + o.c);
+    st8(y + ((o.n * Ho + o.h) * Wo + o.w) * C + o.c, v);
+}
+
+// y[n, h*r+i, w*r+j, c] = x[n, h, w, c*r*r + i*r + j]; thread = 8 output channels of one output pixel
+template <typename T>
+__global__ void pixel_shuffle_v8(const T* __restrict__ x, T* __restrict__ y, int H, int W, int Co, int r, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const Idx o = split(i, H * r, W * r, Co / 8);
+    const int h = o.h / r, ii = o.h % r, w = o.w / r, jj = o.w % r;
+    const T* p = x + ((o.n * H + h) * W + w) * (size_t)(Co * r * r) + ii * r + jj;
+    typedef __attribute__((ext_vector_type(8))) T t8;
+    t8 v;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = p[(size_t)(o.c + k) * r * r];
+    *(t8*)(y + ((o.n * H * r + o.h) * (size_t)(W * r) + o.w) * Co + o.c) = v;
+}
+
+// op 0: a + b; 1: a * b (b with C channels or 1 channel)
+template <typename T>
+__global__ void eltwise_v8(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ y, int C, int Cb, int op, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const size_t e = i * 8;
+    float fa[8], fb[8], r[8];
+    unpack8<T>(ld8(a + e), fa);
+    if (Cb == C) unpack8<T>(ld8(b + e), fb);
+    else {
+        const float s = (float)b[e / C];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) fb[k] = s;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r[k] = op == 0 ? fa[k] + fb[k] : fa[k] * fb[k];
+    st8(y + e, pack8<T>(r));
+}
+
+// generic dtype / channel-count cast: dst[p][c] = c < Cs ? src[p][c] : 0 for c < Cd
+template <typename S, typename D>
+__global__ void cast_kernel(const S* __restrict__ src, D* __restrict__ dst, int Cs, int Cd, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % Cd);
+    const size_t px = i / Cd;
+    dst[i] = c < Cs ? (D)(float)src[px * Cs + c] : (D)0.f;
+}
+
+// instance-norm statistics of a 16-bit tensor: thread = (pixel slot, 8 channels); fp64 partials + atomics
+template <typename T>
+__global__ void norm16_stats(const T* __restrict__ x, double* __restrict__ stats, int HW, int C, int c0, int cn) {
+    const int n = blockIdx.y;
+    const int g8 = cn / 8;                          // channel groups
+    const int tpc = max(1, 256 / g8);
+    const int cg = threadIdx.x % g8, ps = threadIdx.x / g8;
+    double s[8], ss[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { s[k] = 0.0; ss[k] = 0.0; }
+    if (ps < tpc) {
+        const T* xp = x + (size_t)n * HW * C + c0 + cg * 8;
+        for (int pix = blockIdx.x * tpc + ps; pix < HW; pix += gridDim.x * tpc) {
+            float v[8];
+            unpack8<T>(ld8(xp + (size_t)pix * C), v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { s[k] += v[k]; ss[k] += (double)v[k] * v[k]; }
+        }
+    }
+    __shared__ double sh[16][256];                  // block partials first: one atomic per (block, channel, statistic)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sh[k][threadIdx.x] = s[k]; sh[8 + k][threadIdx.x] = ss[k]; }
+    __syncthreads();
+    if (ps == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            double a = s[k], b = ss[k];
+            for (int j = 1; j < tpc; ++j) { a += sh[k][j * g8 + cg]; b += sh[8 + k][j * g8 + cg]; }
+            atomicAdd(&stats[((size_t)n * cn + cg * 8 + k) * 2 + 0], a);
+            atomicAdd(&stats[((size_t)n * cn + cg * 8 + k) * 2 + 1], b);
+        }
+    }
+}
+__global__ void norm16_finalize(const double* __restrict__ stats, float* __restrict__ mean, float* __restrict__ inv, int total, double count,
+                                float eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const double m = stats[2 * (size_t)i] / count;
+    const double var = fmax(stats[2 * (size_t)i + 1] / count - m * m, 0.0);
+    mean[i] = (float)m;
+    inv[i] = (float)(1.0 / sqrt(var + (double)eps));
+}
+template <typename T>
+__global__ void norm16_apply(const T* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ inv,
+                             const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ y, int HW, int C, int c0,
+                             int cn, int act, float slope, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const size_t e = i * 8;
+    const int c = (int)(e % C);
+    const size_t n = e / ((size_t)HW * C);
+    float v[8];
+    unpack8<T>(ld8(x + e), v);
+    if (c >= c0 && c < c0 + cn) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int cc = c - c0 + k;
+            float t = (v[k] - mean[n * cn + cc]) * inv[n * cn + cc];
+            if (gamma) t = t * gamma[cc] + beta[cc];
+            v[k] = t;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = ie_act_apply(v[k], act, slope);
+    st8(y + e, pack8<T>(v));
+}
+
+bool is16(int dt) { return dt == IE_F16 || dt == IE_BF16; }
+
+}  // namespace
+
+IE_EXPORT int ie_maxpool2x2_nhwc(const void* x, void* y, int dtype, int N, int H, int W, int C, void* stream) {
+    if (dtype == IE_F32) return ie_maxpool2x2_nhwc_f32((const float*)x, (float*)y, N, H, W, C, stream);
+    if (!x || !y || !is16(dtype) || N <= 0 || H < 2 || W < 2 || C <= 0 || (C & 7)) IE_FAIL(IE_ERR_INVALID, "ie_maxpool2x2_nhwc: bad args (C %% 8 == 0 on the 16-bit path)");
+    const int Ho = H / 2, Wo = W / 2;
+    const size_t total = (size_t)N * Ho * Wo * (C / 8);
+    if (dtype == IE_F16) hipLaunchKernelGGL(maxpool2_v8<_Float16>, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, (_Float16*)y, H, W, C, Ho, Wo, total);
+    else hipLaunchKernelGGL(maxpool2_v8<__bf16>, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, (__bf16*)y, H, W, C, Ho, Wo, total);
+    IE_LAUNCH_CHECK();
+    return IE_OK;
+}
+
+IE_EXPORT int ie_resize_nhwc(const void* x, void* y, int dtype, int N, int Hi, int Wi, int C, int Ho, int Wo, int mode, void* stream) {
+    if (dtype == IE_F32) return ie_resize_nhwc_f32((const float*)x, (float*)y, N, Hi, Wi, C, Ho, Wo, mode, stream);
+    if (!x || !y || !is16(dtype) || N <= 0 || Hi <= 0 || Wi <= 0 || C <= 0 || (C & 7) || Ho <= 0 || Wo <= 0 || mode < 0 || mode > 2)
+        IE_FAIL(IE_ERR_INVALID, "ie_resize_nhwc: bad args (C %% 8 == 0 on the 16-bit path)");
+    const size_t total = (size_t)N * Ho * Wo * (C / 8);
+    if (dtype == IE_F16) hipLaunchKernelGGL(resize_v8<_Float16>, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, (_Float16*)y, Hi, Wi, C, Ho, Wo, mode, total);
+    else hipLaunchKernelGGL(resize_v8<__bf16>, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, (__bf16*)y, Hi, Wi, C, Ho, Wo, mode, total);
+    IE_LAUNCH_CHECK();
+    return IE_OK;
+}
+
+IE_EXPORT int ie_pad_nhwc(const void* x, void* y, int dtype, int N, int H, int W, int C, int top, int bottom, int left, int right, void* stream) {
+    if (dtype == IE_F32) return ie_pad_nhwc_f32((const float*)x, (float*)y, N, H, W, C, top, bottom, left, right, stream);
+    if (!x || !y || !is16(dtype) || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7) || top < 0 || bottom < 0 || left < 0 || right < 0)
+        IE_FAIL(IE_ERR_INVALID, "ie_pad_nhwc: bad args (C %% 8 == 0 on the 16-bit path)");
+    const int Ho = H + top + bottom, Wo = W + left + right;
+    const size_t total = (size_t)N * Ho * Wo * (C / 8);
+    if (dtype == IE_F16) hipLaunchKernelGGL(pad_v8<_Float16>, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, (_Float16*)y, H, W, C, top, left, Ho, Wo, total);
+    else hipLaunchKernelGGL(pad_v8<__bf16>, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, (__bf16*)y, H, W, C, top, left, Ho, Wo, total);
+    IE_LAUNCH_CHECK();
+    return IE_OK;
+}
+
+IE_EXPORT int ie_pixel_shuffle_nhwc(const void* x, void* y, int dtype, int N, int H, int W, int Cout, int r, void* stream) {
+    if (dtype == IE_F32) return ie_pixel_shuffle_nhwc_f32((const float*)x, (float*)y, N, H, W, Cout, r, stream);
+    if (!x || !y || !is16(dtype) || N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || (Cout & 7) || r <= 0)
+        IE_FAIL(IE_ERR_INVALID, "ie_pixel_shuffle_nhwc: bad args (Cout %% 8 == 0 on the 16-bit path)");
+    const size_t total = (size_t)N * H * r * W * r * (Cout / 8);
+    if (dtype == IE_F16) hipLaunchKernelGGL(pixel_shuffle_v8<_Float16>, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, (_Float16*)y, H, W, Cout, r, total);
+    else hipLaunchKernelGGL(pixel_shuffle_v8<__bf16>, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, (__bf16*)y, H, W, Cout, r, total);
+    IE_LAUNCH_CHECK();
+    return IE_OK;
+}
+
+IE_EXPORT int ie_eltwise_nhwc(int op, const void* a, const void* b, void* y, int dtype, size_t npix, int C, int Cb, void* stream) {
+    if (!a || !b || !y || !is16(dtype) || npix == 0 || C <= 0 || (C & 7) || (op != 0 && op != 1) || (Cb != C && Cb != 1))
+        IE_FAIL(IE_ERR_INVALID, "ie_eltwise_nhwc: bad args (16-bit add / multiply, C %% 8 == 0)");
+    const size_t total = npix * (C / 8);
+    if (dtype == IE_F16) hipLaunchKernelGGL(eltwise_v8<_Float16>, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)a, (const _Float16*)b, (_Float16*)y, C, Cb, op, total);
+    else hipLaunchKernelGGL(eltwise_v8<__bf16>, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)a, (const __bf16*)b, (__bf16*)y, C, Cb, op, total);
+    IE_LAUNCH_CHECK();
+    return IE_OK;
+}
+
+template <typename S>
+static int cast_from(const S* src, void* dst, int ddt, int Cs, int Cd, size_t total, hipStream_t st) {
+    switch (ddt) {
+    case IE_F32: hipLaunchKernelGGL((cast_kernel<S, float>), dim3(nblk(total)), dim3(256), 0, st, src, (float*)dst, Cs, Cd, total); break;
+    case IE_F16: hipLaunchKernelGGL((cast_kernel<S, _Float16>), dim3(nblk(total)), dim3(256), 0, st, src, (_Float16*)dst, Cs, Cd, total); break;
+    case IE_BF16: hipLaunchKernelGGL((cast_kernel<S, __bf16>), dim3(nblk(total)), dim3(256), 0, st, src, (__bf16*)dst, Cs, Cd, total); break;
+    default: IE_FAIL(IE_ERR_INVALID, "ie_cast_nhwc: bad destination dtype");
+    }
+    IE_LAUNCH_CHECK();
+    return IE_OK;
+}
+
+IE_EXPORT int ie_cast_nhwc(const void* src, int src_dtype, int Cs, void* dst, int dst_dtype, int Cd, size_t npix, void* stream) {
+    if (!src || !dst || npix == 0 || Cs <= 0 || Cd <= 0) IE_FAIL(IE_ERR_INVALID, "ie_cast_nhwc: bad args");
+    const size_t total = npix * Cd;
+    hipStream_t st = (hipStream_t)stream;
+    switch (src_dtype) {
+    case IE_F32: return cast_from((const float*)src, dst, dst_dtype, Cs, Cd, total, st);
+    case IE_F16: return cast_from((const _Float16*)src, dst, dst_dtype, Cs, Cd, total, st);
+    case IE_BF16: return cast_from((const __bf16*)src, dst, dst_dtype, Cs, Cd, total, st);
+    default: IE_FAIL(IE_ERR_INVALID, "ie_cast_nhwc: bad source dtype");
+    }
+}
+
+IE_EXPORT int ie_instnorm_nhwc(const void* x, const float* gamma, const float* beta, void* y, int dtype, double* stats_ws, int N, int H, int W,
+                               int C, int c_begin, int c_count, float eps, int act, float slope, void* stream) {
+    if (dtype == IE_F32) return ie_instnorm_nhwc_f32((const float*)x, gamma, beta, (float*)y, stats_ws, N, H, W, C, c_begin, c_count, eps, act, slope, stream);
+    if (!x || !y || !stats_ws || !is16(dtype) || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7) || c_begin < 0 || (c_begin & 7) || c_count <= 0 ||
+        (c_count & 7) || c_count > 2048 || c_begin + c_count > C || (gamma == nullptr) != (beta == nullptr))
+        IE_FAIL(IE_ERR_INVALID, "ie_instnorm_nhwc: bad args (channel counts multiples of 8 on the 16-bit path)");
+    hipStream_t st = (hipStream_t)stream;
+    const int HW = H * W;
+    IE_HIP_CHECK(hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * (size_t)N * c_count, st));
+    float* mean = (float*)(stats_ws + 2 * (size_t)N * c_count);
+    float* inv = mean + (size_t)N * c_count;
+    const int g8 = c_count / 8;
+    const int tpc = 256 / g8 > 0 ? 256 / g8 : 1;
+    int chunks = ie_cdiv(HW, tpc * 32);
+    if (chunks > 512) chunks = 512;
+    if (chunks < 1) chunks = 1;
+    if (dtype == IE_F16) hipLaunchKernelGGL(norm16_stats<_Float16>, dim3(chunks, N), dim3(256), 0, st, (const _Float16*)x, stats_ws, HW, C, c_begin, c_count);
+    else hipLaunchKernelGGL(norm16_stats<__bf16>, dim3(chunks, N), dim3(256), 0, st, (const __bf16*)x, stats_ws, HW, C, c_begin, c_count);
+    IE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(norm16_finalize, dim3(nblk((size_t)N * c_count)), dim3(256), 0, st, stats_ws, mean, inv, N * c_count, (double)HW, eps);
+    IE_LAUNCH_CHECK();
+    const size_t total = (size_t)N * HW * (C / 8);
+    if (dtype == IE_F16) hipLaunchKernelGGL(norm16_apply<_Float16>, dim3(nblk(total)), dim3(256), 0, st, (const _Float16*)x, mean, inv, gamma, beta, (_Float16*)y, HW, C, c_begin, c_count, act, slope, total);
+    else hipLaunchKernelGGL(norm16_apply<__bf16>, dim3(nblk(total)), dim3(256), 0, st, (const __bf16*)x, mean, inv, gamma, beta, (__bf16*)y, HW, C, c_begin, c_count, act, slope, total);
+    IE_LAUNCH_CHECK();
+    return IE_OK;
+}

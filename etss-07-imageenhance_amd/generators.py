@@ -28,8 +28,55 @@ class _GraphModel(ImageEnhancementModel):
     """Host fp32 parameters + per-device repacked weights, rebuilt lazily."""
 
     def __init__(self, *args, **kwargs):
+        # engine extra: "f32" = parity path (VALU fp32 kernels), "f16" / "bf16" = matrix-core path (16-bit NHWC activations,
+        # fp32 accumulate) for the models that implement it
+        cd = str(kwargs.pop("compute_dtype", "f32")).lower()
+        if cd not in capi.DTYPES:
+            raise ValueError(f"`compute_dtype` must be one of f32/f16/bf16, but got {cd}.")
+        self.compute_dtype = {capi.IE_F32: "f32", capi.IE_F16: "f16", capi.IE_BF16: "bf16"}[capi.DTYPES[cd]]
         super().__init__(*args, **kwargs)
         self._dev_cache = None
+
+    @property
+    def _tdt(self) -> torch.dtype:
+        return ops.TORCH_DT[self.compute_dtype]
+
+    def _input_any(self, datapoint: dict):
+        """Image as the compute dtype's NHWC tensor: fp32 with C channels, or 16-bit zero-padded to 8 channels."""
+        x = self._input(datapoint)
+        return x if self.compute_dtype == "f32" else ops.cast(x, self._tdt, 8)
+
+    def _conv(self, srcs, name, bn=None, stride=1, pad=1, pad_mode="zeros", act="none", slope=0.0, residual=None, clamp=None,
+              out_f32=False, cout_pad=None):
+        """Conv2d ``name`` (+ folded eval BatchNorm ``bn``) over the channel concat of ``srcs`` in the model's compute dtype.
+        On the 16-bit path sources may carry zero-padded channels (a 3-channel image stored as 8): the weights of the missing
+        input channels are zero; ``cout_pad`` pads the output channels the same way (zero weights and bias)."""
+        if isinstance(srcs, torch.Tensor):
+            srcs = [srcs]
+        if self.compute_dtype == "f32":
+            return ops.conv2d(srcs, self._cw(name, bn), stride=stride, pad=pad, pad_mode=pad_mode, act=act, slope=slope,
+                              residual=residual, clamp=clamp)
+        split = tuple(int(t.shape[1]) for t in srcs)
+        key = ("mconv", name, bn, split, cout_pad)
+        if self._dev_cache is None:
+            self._dev_cache = {}
+        if key not in self._dev_cache:
+            w, b = self._params[f"{name}.weight"], self._params.get(f"{name}.bias")
+            if bn is not None:
+                w, b = ops.fold_bn(w, b, self._params[f"{bn}.weight"], self._params[f"{bn}.bias"],
+                                   self._params[f"{bn}.running_mean"], self._params[f"{bn}.running_var"])
+            cin_map = None
+            if sum(split) != w.shape[1]:
+                if len(split) != 1 or split[0] < w.shape[1]:
+                    raise capi.IEError(f"{name}: sources carry {split} channels, weights expect {w.shape[1]}")
+                cin_map = list(range(w.shape[1])) + [-1] * (split[0] - w.shape[1])
+            if cout_pad is not None and cout_pad > w.shape[0]:
+                extra = cout_pad - w.shape[0]
+                w = torch.cat([w, torch.zeros(extra, *w.shape[1:])], 0)
+                b = None if b is None else torch.cat([b, torch.zeros(extra)], 0)
+            self._dev_cache[key] = ops.MConvWeights(w, b, split, self._tdt, self.device, cin_map)
+        return ops.mconv2d(srcs, self._dev_cache[key], stride=stride, pad=pad, pad_mode=pad_mode, act=act, slope=slope,
+                           residual=residual, clamp=clamp, out_f32=out_f32)
 
     def _on_params_change(self):
         self._dev_cache = None
@@ -335,20 +382,20 @@ class UNet(_GraphModel):
         self._on_params_change()
 
     def _dc(self, name, srcs):
-        x = ops.conv2d(srcs, self._cw(f"{name}.conv1", f"{name}.norm1"), act="relu")
-        return ops.conv2d(x, self._cw(f"{name}.conv2", f"{name}.norm2"), act="relu")
+        x = self._conv(srcs, f"{name}.conv1", f"{name}.norm1", act="relu")
+        return self._conv(x, f"{name}.conv2", f"{name}.norm2", act="relu")
 
     def _up(self, k, x1, x2):
         if self.upsampler == "bilinear":
             x1 = ops.upsample2x_bilinear(x1)
         else:
-            x1 = ops.pixel_shuffle(ops.conv2d(x1, self._cw(f"up{k}.up.0")), 2)
+            x1 = ops.pixel_shuffle(self._conv(x1, f"up{k}.up.0"), 2)
         dy, dx = x2.shape[2] - x1.shape[2], x2.shape[3] - x1.shape[3]
         x1 = ops.pad(x1, dy // 2, dy - dy // 2, dx // 2, dx - dx // 2)
         return self._dc(f"up{k}.conv", [x2, x1])
 
     def forward(self, datapoint: dict, *args, **kwargs) -> dict:
-        x = self._input(datapoint)
+        x = self._input_any(datapoint)
         x1 = self._dc("inc", [x])
         x2 = self._dc("down1.conv", [ops.maxpool2x2(x1)])
         x3 = self._dc("down2.conv", [ops.maxpool2x2(x2)])
@@ -358,7 +405,7 @@ class UNet(_GraphModel):
         y = self._up(2, y, x3)
         y = self._up(3, y, x2)
         y = self._up(4, y, x1)
-        y = ops.conv2d(y, self._cw("outc.conv"), pad=0, clamp=(0.0, 1.0) if self.enhance else None)
+        y = self._conv(y, "outc.conv", pad=0, clamp=(0.0, 1.0) if self.enhance else None, out_f32=True)
         out = OrderedDict()
         out["enhanced" if self.enhance else "semantic"] = ops.to_nchw(y)
         return out
@@ -499,31 +546,37 @@ class RetinexNet(_GraphModel):
         self._on_params_change()
 
     def decom(self, x):
-        R = "replicate"
-        f = ops.conv2d(ops.max_concat(x), self._cw("net1_conv0"), pad=4, pad_mode=R)
+        """x: fp32 NHWC image.  Returns DecomNet's sigmoid output: channels 0-2 = R, 3 = L (16-bit path: padded to 8)."""
+        R, c = "replicate", self._conv
+        xin = ops.max_concat(x)                                                    # [max_c(x), x], model.py:45-46
+        if self.compute_dtype != "f32":
+            xin = ops.cast(xin, self._tdt, 8)
+        f = c(xin, "net1_conv0", pad=4, pad_mode=R)
         for i in (0, 2, 4, 6, 8):
-            f = ops.conv2d(f, self._cw(f"net1_convs.{i}"), pad_mode=R, act="relu")
-        return ops.conv2d(f, self._cw("net1_recon"), pad_mode=R, act="sigmoid")     # channels 0-2 = R, 3 = L
+            f = c(f, f"net1_convs.{i}", pad_mode=R, act="relu")
+        return c(f, "net1_recon", pad_mode=R, act="sigmoid", cout_pad=None if self.compute_dtype == "f32" else 8)
 
     def relight(self, rl):
         """rl: cat(R, L) == the 4-channel sigmoid output of DecomNet (model.py:72)."""
-        R = "replicate"
-        out0 = ops.conv2d(rl, self._cw("net2_conv0_1"), pad_mode=R)
-        out1 = ops.conv2d(out0, self._cw("net2_conv1_1"), stride=2, pad_mode=R, act="relu")
-        out2 = ops.conv2d(out1, self._cw("net2_conv1_2"), stride=2, pad_mode=R, act="relu")
-        out3 = ops.conv2d(out2, self._cw("net2_conv1_3"), stride=2, pad_mode=R, act="relu")
+        R, c = "replicate", self._conv
+        out0 = c(rl, "net2_conv0_1", pad_mode=R)
+        out1 = c(out0, "net2_conv1_1", stride=2, pad_mode=R, act="relu")
+        out2 = c(out1, "net2_conv1_2", stride=2, pad_mode=R, act="relu")
+        out3 = c(out2, "net2_conv1_3", stride=2, pad_mode=R, act="relu")
         sz = lambda t: (t.shape[2], t.shape[3])
-        d1 = ops.conv2d([ops.resize(out3, sz(out2), "nearest"), out2], self._cw("net2_deconv1_1"), pad_mode=R, act="relu")
-        d2 = ops.conv2d([ops.resize(d1, sz(out1), "nearest"), out1], self._cw("net2_deconv1_2"), pad_mode=R, act="relu")
-        d3 = ops.conv2d([ops.resize(d2, sz(out0), "nearest"), out0], self._cw("net2_deconv1_3"), pad_mode=R, act="relu")
-        fus = ops.conv2d([ops.resize(d1, sz(rl), "nearest"), ops.resize(d2, sz(rl), "nearest"), d3], self._cw("net2_fusion"),
-                         pad=1, pad_mode=R)                                        # 1x1 with replicate padding 1: (H+2, W+2)
-        return ops.conv2d(fus, self._cw("net2_output"), pad=0)                      # 3x3 valid -> (H, W)
+        d1 = c([ops.resize(out3, sz(out2), "nearest"), out2], "net2_deconv1_1", pad_mode=R, act="relu")
+        d2 = c([ops.resize(d1, sz(out1), "nearest"), out1], "net2_deconv1_2", pad_mode=R, act="relu")
+        d3 = c([ops.resize(d2, sz(out0), "nearest"), out0], "net2_deconv1_3", pad_mode=R, act="relu")
+        fus = c([ops.resize(d1, sz(rl), "nearest"), ops.resize(d2, sz(rl), "nearest"), d3], "net2_fusion",
+                pad=1, pad_mode=R)                                                 # 1x1 with replicate padding 1: (H+2, W+2)
+        return c(fus, "net2_output", pad=0, out_f32=True)                          # 3x3 valid -> (H, W), fp32
 
     def forward(self, datapoint: dict, *args, **kwargs) -> dict:
         x = self._input(datapoint)
         rl = self.decom(x)
         i_delta = self.relight(rl)
+        if self.compute_dtype != "f32":
+            rl = ops.cast(rl, torch.float32, 4)                                    # drop the padding channels, back to fp32
         rl_nchw = ops.to_nchw(rl)
         s = ops.mul_prefix(rl, i_delta)
         out = OrderedDict()

@@ -24,8 +24,21 @@ def _chk(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
-def empty_nhwc(n, c, h, w, device) -> torch.Tensor:
-    return torch.empty((n, c, h, w), device=device, dtype=torch.float32, memory_format=CL)
+def _chk_any(t: torch.Tensor) -> torch.Tensor:
+    """fp32 or 16-bit channels_last tensor (the streaming ops dispatch on dtype)."""
+    if not t.is_cuda or t.dtype not in (torch.float32, torch.float16, torch.bfloat16) or t.dim() != 4:
+        raise capi.IEError(f"expected a cuda fp32/fp16/bf16 (N,C,H,W) tensor, got {tuple(t.shape)} {t.dtype} {t.device}")
+    if not t.is_contiguous(memory_format=CL):
+        raise capi.IEError("expected channels_last (NHWC) memory; use ops.to_nhwc()")
+    return t
+
+
+def _dt(t: torch.Tensor) -> int:
+    return {torch.float32: capi.IE_F32, torch.float16: capi.IE_F16, torch.bfloat16: capi.IE_BF16}[t.dtype]
+
+
+def empty_nhwc(n, c, h, w, device, dtype=torch.float32) -> torch.Tensor:
+    return torch.empty((n, c, h, w), device=device, dtype=dtype, memory_format=CL)
 
 
 def to_nhwc(x: torch.Tensor) -> torch.Tensor:
@@ -119,24 +132,24 @@ def depthwise_conv2d(x, cw: ConvWeights, stride=1, pad=1, act="none") -> torch.T
 
 
 def instance_norm(x, gamma=None, beta=None, eps=1e-5, act="none", slope=0.0, c_begin=0, c_count=None) -> torch.Tensor:
-    _chk(x)
+    _chk_any(x)
     n, c, h, w = x.shape
     c_count = c - c_begin if c_count is None else c_count
     y = torch.empty_like(x, memory_format=CL)
     ws = torch.empty(3 * n * c_count, device=x.device, dtype=torch.float64)
     with torch.cuda.device(x.device):
-        capi.check(capi.lib().ie_instnorm_nhwc_f32(capi.ptr(x), capi.ptr(gamma), capi.ptr(beta), capi.ptr(y), capi.ptr(ws), n, h, w,
-                                                   c, c_begin, c_count, eps, capi.ACT[act], slope, capi.current_stream()),
-                   "ie_instnorm_nhwc_f32")
+        capi.check(capi.lib().ie_instnorm_nhwc(capi.ptr(x), capi.ptr(gamma), capi.ptr(beta), capi.ptr(y), _dt(x), capi.ptr(ws), n, h, w,
+                                               c, c_begin, c_count, eps, capi.ACT[act], slope, capi.current_stream()),
+                   "ie_instnorm_nhwc")
     return y
 
 
 def maxpool2x2(x) -> torch.Tensor:
-    _chk(x)
+    _chk_any(x)
     n, c, h, w = x.shape
-    y = empty_nhwc(n, c, h // 2, w // 2, x.device)
+    y = empty_nhwc(n, c, h // 2, w // 2, x.device, x.dtype)
     with torch.cuda.device(x.device):
-        capi.check(capi.lib().ie_maxpool2x2_nhwc_f32(capi.ptr(x), capi.ptr(y), n, h, w, c, capi.current_stream()), "ie_maxpool2x2_nhwc_f32")
+        capi.check(capi.lib().ie_maxpool2x2_nhwc(capi.ptr(x), capi.ptr(y), _dt(x), n, h, w, c, capi.current_stream()), "ie_maxpool2x2_nhwc")
     return y
 
 
@@ -144,12 +157,12 @@ _RESIZE = {"nearest": 0, "bilinear": 1, "bilinear_align": 2}
 
 
 def resize(x, size, mode="bilinear_align") -> torch.Tensor:
-    _chk(x)
+    _chk_any(x)
     n, c, h, w = x.shape
-    y = empty_nhwc(n, c, size[0], size[1], x.device)
+    y = empty_nhwc(n, c, size[0], size[1], x.device, x.dtype)
     with torch.cuda.device(x.device):
-        capi.check(capi.lib().ie_resize_nhwc_f32(capi.ptr(x), capi.ptr(y), n, h, w, c, size[0], size[1], _RESIZE[mode],
-                                                 capi.current_stream()), "ie_resize_nhwc_f32")
+        capi.check(capi.lib().ie_resize_nhwc(capi.ptr(x), capi.ptr(y), _dt(x), n, h, w, c, size[0], size[1], _RESIZE[mode],
+                                             capi.current_stream()), "ie_resize_nhwc")
     return y
 
 
@@ -158,13 +171,24 @@ def upsample2x_bilinear(x) -> torch.Tensor:
 
 
 def pixel_shuffle(x, r=2) -> torch.Tensor:
-    _chk(x)
+    _chk_any(x)
     n, c, h, w = x.shape
     co = c // (r * r)
-    y = empty_nhwc(n, co, h * r, w * r, x.device)
+    y = empty_nhwc(n, co, h * r, w * r, x.device, x.dtype)
     with torch.cuda.device(x.device):
-        capi.check(capi.lib().ie_pixel_shuffle_nhwc_f32(capi.ptr(x), capi.ptr(y), n, h, w, co, r, capi.current_stream()),
-                   "ie_pixel_shuffle_nhwc_f32")
+        capi.check(capi.lib().ie_pixel_shuffle_nhwc(capi.ptr(x), capi.ptr(y), _dt(x), n, h, w, co, r, capi.current_stream()),
+                   "ie_pixel_shuffle_nhwc")
+    return y
+
+
+def cast(x, dtype, channels=None) -> torch.Tensor:
+    """Convert dtype and pad (zeros) / crop the channel count in one pass (ie_cast_nhwc)."""
+    _chk_any(x)
+    n, c, h, w = x.shape
+    cd = c if channels is None else int(channels)
+    y = empty_nhwc(n, cd, h, w, x.device, dtype)
+    with torch.cuda.device(x.device):
+        capi.check(capi.lib().ie_cast_nhwc(capi.ptr(x), _dt(x), c, capi.ptr(y), _dt(y), cd, n * h * w, capi.current_stream()), "ie_cast_nhwc")
     return y
 
 
@@ -187,18 +211,26 @@ def conv_transpose2x2(x, cw: ConvT2x2Weights) -> torch.Tensor:
 
 
 def pad(x, top, bottom, left, right) -> torch.Tensor:
-    _chk(x)
+    _chk_any(x)
     if top == bottom == left == right == 0:
         return x
     n, c, h, w = x.shape
-    y = empty_nhwc(n, c, h + top + bottom, w + left + right, x.device)
+    y = empty_nhwc(n, c, h + top + bottom, w + left + right, x.device, x.dtype)
     with torch.cuda.device(x.device):
-        capi.check(capi.lib().ie_pad_nhwc_f32(capi.ptr(x), capi.ptr(y), n, h, w, c, top, bottom, left, right, capi.current_stream()),
-                   "ie_pad_nhwc_f32")
+        capi.check(capi.lib().ie_pad_nhwc(capi.ptr(x), capi.ptr(y), _dt(x), n, h, w, c, top, bottom, left, right, capi.current_stream()),
+                   "ie_pad_nhwc")
     return y
 
 
 def _elt(op, a, b, lo=0.0, hi=0.0):
+    if a.dtype != torch.float32:
+        _chk16(a); _chk16(b)
+        n, c, h, w = a.shape
+        y = torch.empty_like(a, memory_format=CL)
+        with torch.cuda.device(a.device):
+            capi.check(capi.lib().ie_eltwise_nhwc(op, capi.ptr(a), capi.ptr(b), capi.ptr(y), _dt(a), n * h * w, c, int(b.shape[1]),
+                                                  capi.current_stream()), "ie_eltwise_nhwc")
+        return y
     _chk(a)
     n, c, h, w = a.shape
     cb = c

@@ -159,6 +159,22 @@ int ie_mconv_pack_weights(const float* w_oihw_host, const int* channels, int nsr
 int ie_mconv_nhwc(ie_mconv_desc* d, const void* const* srcs_dev, const int* channels, const void* packed_w_dev,
                   const float* bias_dev, const void* residual_dev, void* dst_dev, void* stream);
 
+/* ---- 16-bit (IE_F16 / IE_BF16) NHWC streaming ops between the matrix-core convolutions; IE_F32 forwards to the *_f32
+ * entry points above.  On the 16-bit path channel counts are multiples of 8 (a thread moves 8 channels = 16 bytes). */
+int ie_maxpool2x2_nhwc(const void* x_dev, void* y_dev, int dtype, int N, int H, int W, int C, void* stream);
+int ie_resize_nhwc(const void* x_dev, void* y_dev, int dtype, int N, int Hi, int Wi, int C, int Ho, int Wo, int mode, void* stream);
+int ie_pad_nhwc(const void* x_dev, void* y_dev, int dtype, int N, int H, int W, int C, int top, int bottom, int left, int right, void* stream);
+int ie_pixel_shuffle_nhwc(const void* x_dev, void* y_dev, int dtype, int N, int H, int W, int Cout, int r, void* stream);
+/* op 0: a + b, 1: a * b; b has C channels or one (broadcast). */
+int ie_eltwise_nhwc(int op, const void* a_dev, const void* b_dev, void* y_dev, int dtype, size_t npix, int C, int Cb, void* stream);
+/* dst[p][c] = c < Cs ? (dst type) src[p][c] : 0 for c < Cd: dtype conversion and channel padding / cropping in one pass
+ * (e.g. DecomNet's 4-channel fp32 input -> 8-channel bf16; a 16-bit map -> the fp32 tensor handed back to the caller). */
+int ie_cast_nhwc(const void* src_dev, int src_dtype, int Cs, void* dst_dev, int dst_dtype, int Cd, size_t npix, void* stream);
+/* ie_instnorm_nhwc_f32 for 16-bit tensors (statistics in fp64 from the 16-bit values, one rounding on store);
+ * stats_ws_dev: >= 3*N*c_count doubles; c_begin and c_count multiples of 8. */
+int ie_instnorm_nhwc(const void* x_dev, const float* gamma_dev, const float* beta_dev, void* y_dev, int dtype, double* stats_ws_dev,
+                     int N, int H, int W, int C, int c_begin, int c_count, float eps, int act, float slope, void* stream);
+
 /* ---- training path, fp32 NHWC: what torch.autograd does behind Model.training_step ---------
  * (src/mon/nn/model.py:701-746) for the layers above, the L1 + SSIM losses and Adam with gradient-norm clipping. */
 /* Forward of nn.InstanceNorm2d (per_sample=1) or of nn.BatchNorm2d in training mode (per_sample=0: batch

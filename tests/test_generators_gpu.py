@@ -161,3 +161,69 @@ def test_hinet_vs_oracle(cfg):
         yr = F.interpolate(y, size=(64, 64), mode="bilinear", align_corners=False)
         r = F.interpolate(og.hinet_forward(m.state_dict(), yr)["enhanced"], size=(40, 56), mode="bilinear", align_corners=False)
         assert rel_err(got["enhanced"].cpu(), r) <= TOL
+
+
+# ---- 16-bit matrix-core path (compute_dtype f16 / bf16): same graphs, ie_mconv_nhwc + the 16-bit streaming ops ----------
+TOL16 = {"f16": 1.5e-3, "bf16": 1.5e-2}       # measured 4e-4 / 6e-3 (tools/gen16_diag.py); BASELINE bound for fp32 parity is 1e-3
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("cfg", [dict(base_channels=32, num_classes=3, enhance=True, upsampler="bilinear", hw=(135, 70)),
+                                 dict(base_channels=32, num_classes=3, enhance=True, upsampler="pixelshuffle", hw=(48, 64)),
+                                 dict(base_channels=64, num_classes=34, enhance=False, upsampler="bilinear", hw=(33, 47))],
+                         ids=["unet32-enh-odd", "unet32-pixelshuffle", "unet64-seg-odd"])
+def test_unet_16bit_vs_oracle(cfg, dt):
+    cfg = dict(cfg)
+    hw = cfg.pop("hw")
+    m = mon_amd.MODELS.build(name="unet", seed=3, compute_dtype=dt, **cfg).to("cuda")
+    assert m.compute_dtype == dt
+    x = torch.rand(2, 3, *hw, generator=torch.Generator().manual_seed(2))
+    out = m.forward({"image": x.cuda()})
+    key = "enhanced" if cfg["enhance"] else "semantic"
+    ref = og.unet_forward(m.state_dict(), x, cfg["upsampler"], cfg["enhance"])[key]
+    assert out[key].dtype == torch.float32 and tuple(out[key].shape) == tuple(ref.shape)
+    assert rel_err(out[key].cpu(), ref) <= TOL16[dt]
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+def test_retinexnet_16bit_vs_oracle(dt):
+    m = mon_amd.MODELS.build(name="retinexnet", seed=3, compute_dtype=dt).to("cuda")
+    x = torch.rand(2, 3, 45, 67, generator=torch.Generator().manual_seed(2))
+    out = m.forward({"image": x.cuda()})
+    ref = og.retinexnet_forward(m.state_dict(), x)
+    assert list(out.keys()) == ["reflectance", "illumination", "illumination_delta", "enhanced"]
+    for k in out:
+        assert rel_err(out[k].cpu(), ref[k]) <= TOL16[dt], k
+
+
+def test_compute_dtype_is_validated():
+    with pytest.raises(ValueError):
+        mon_amd.MODELS.build(name="unet", compute_dtype="int8")
+
+
+def test_16bit_streaming_ops_against_torch():
+    g = torch.Generator().manual_seed(0)
+    for tdt, tol in ((torch.float16, 1e-3), (torch.bfloat16, 8e-3)):
+        x = torch.randn(2, 16, 11, 14, generator=g).to(tdt)
+        xd = x.cuda().contiguous(memory_format=torch.channels_last)
+        xf = x.float()
+        assert torch.equal(ops.maxpool2x2(xd).float().cpu(), F.max_pool2d(xf, 2))
+        for mode, kw in (("nearest", dict(mode="nearest")), ("bilinear", dict(mode="bilinear", align_corners=False)),
+                         ("bilinear_align", dict(mode="bilinear", align_corners=True))):
+            assert rel_err(ops.resize(xd, (22, 28), mode).float().cpu(), F.interpolate(xf, size=(22, 28), **kw)) <= tol, mode
+        assert torch.equal(ops.pad(xd, 1, 2, 0, 3).float().cpu(), F.pad(xf, [0, 3, 1, 2]))
+        x4 = torch.randn(2, 32, 5, 6, generator=g).to(tdt)
+        assert torch.equal(ops.pixel_shuffle(x4.cuda().contiguous(memory_format=torch.channels_last), 2).float().cpu(), F.pixel_shuffle(x4.float(), 2))
+        y = torch.randn(2, 16, 11, 14, generator=g).to(tdt)
+        yd = y.cuda().contiguous(memory_format=torch.channels_last)
+        assert rel_err(ops.add(xd, yd).float().cpu(), xf + y.float()) <= tol
+        assert rel_err(ops.mul(xd, yd).float().cpu(), xf * y.float()) <= tol
+        assert rel_err(ops.mul(xd, yd[:, :1].contiguous(memory_format=torch.channels_last)).float().cpu(), xf * y.float()[:, :1]) <= tol
+        gam, bet = torch.randn(8, generator=g), torch.randn(8, generator=g)
+        ref = torch.cat([F.instance_norm(xf[:, :8], weight=gam, bias=bet, eps=1e-5), xf[:, 8:]], 1)
+        got = ops.instance_norm(xd, gam.cuda(), bet.cuda(), 1e-5, "lrelu", 0.2, 0, 8)
+        assert rel_err(got.float().cpu(), F.leaky_relu(ref, 0.2)) <= tol
+        c = ops.cast(ops.to_nhwc(torch.rand(1, 3, 6, 7, generator=g).cuda()), tdt, 8)
+        assert c.shape[1] == 8 and float(c[:, 3:].float().abs().max()) == 0.0
+        back = ops.cast(c, torch.float32, 3)
+        assert back.dtype == torch.float32 and back.shape[1] == 3

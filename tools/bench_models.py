@@ -21,20 +21,26 @@ CASES = [
     ("retinexnet", dict(name="retinexnet", seed=1), 2, (1080, 1920)),
     ("llunet++", dict(name="llunet++_re", seed=1), 1, (1088, 1920)),
 ]
-only = sys.argv[1:]
+cdt = "f32"
+args = sys.argv[1:]
+if args and args[0] in ("f32", "f16", "bf16"):
+    cdt = args.pop(0)
+only = args
 for tag, cfg, n, hw in CASES:
     if only and tag not in only:
         continue
-    m = mon_amd.MODELS.build(**cfg).to("cuda")
+    if cdt != "f32" and tag in ("zero_dce++", "llunet++"):
+        continue                      # no 16-bit graph yet
+    m = mon_amd.MODELS.build(compute_dtype=cdt, **cfg).to("cuda") if cdt != "f32" else mon_amd.MODELS.build(**cfg).to("cuda")
     x = torch.rand(n, 3, *hw, device="cuda")
     m.forward({"image": x}); torch.cuda.synchronize()
     t0 = time.perf_counter()
-    reps = 2
+    reps = 2 if cdt == "f32" else 5
     for _ in range(reps):
         out = m.forward({"image": x})
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
-    rec = {"model": tag, "frames": n, "hw": hw, "ms_per_frame": round(dt / n * 1e3, 2), "frames_per_s": round(n / dt, 3)}
+    rec = {"model": tag, "dtype": cdt, "frames": n, "hw": hw, "ms_per_frame": round(dt / n * 1e3, 2), "frames_per_s": round(n / dt, 3)}
     if GFLOP.get(tag):
         rec["tflops"] = round(GFLOP[tag] * n / dt / 1e3, 2)
     print(json.dumps(rec), flush=True)
