@@ -47,7 +47,7 @@ class _GraphModel(ImageEnhancementModel):
         return x if self.compute_dtype == "f32" else ops.cast(x, self._tdt, 8)
 
     def _conv(self, srcs, name, bn=None, stride=1, pad=1, pad_mode="zeros", act="none", slope=0.0, residual=None, clamp=None,
-              out_f32=False, cout_pad=None):
+              out_f32=False, cout_pad=None, valid=None):
         """Conv2d ``name`` (+ folded eval BatchNorm ``bn``) over the channel concat of ``srcs`` in the model's compute dtype.
         On the 16-bit path sources may carry zero-padded channels (a 3-channel image stored as 8): the weights of the missing
         input channels are zero; ``cout_pad`` pads the output channels the same way (zero weights and bias)."""
@@ -57,7 +57,7 @@ class _GraphModel(ImageEnhancementModel):
             return ops.conv2d(srcs, self._cw(name, bn), stride=stride, pad=pad, pad_mode=pad_mode, act=act, slope=slope,
                               residual=residual, clamp=clamp)
         split = tuple(int(t.shape[1]) for t in srcs)
-        key = ("mconv", name, bn, split, cout_pad)
+        key = ("mconv", name, bn, split, cout_pad, None if valid is None else tuple(valid))
         if self._dev_cache is None:
             self._dev_cache = {}
         if key not in self._dev_cache:
@@ -67,9 +67,13 @@ class _GraphModel(ImageEnhancementModel):
                                    self._params[f"{bn}.running_mean"], self._params[f"{bn}.running_var"])
             cin_map = None
             if sum(split) != w.shape[1]:
-                if len(split) != 1 or split[0] < w.shape[1]:
+                real = list(valid) if valid is not None else ([w.shape[1]] if len(split) == 1 else None)
+                if real is None or len(real) != len(split) or sum(real) != w.shape[1] or any(r > c for r, c in zip(real, split)):
                     raise capi.IEError(f"{name}: sources carry {split} channels, weights expect {w.shape[1]}")
-                cin_map = list(range(w.shape[1])) + [-1] * (split[0] - w.shape[1])
+                cin_map, base = [], 0
+                for r, c in zip(real, split):
+                    cin_map += list(range(base, base + r)) + [-1] * (c - r)
+                    base += r
             if cout_pad is not None and cout_pad > w.shape[0]:
                 extra = cout_pad - w.shape[0]
                 w = torch.cat([w, torch.zeros(extra, *w.shape[1:])], 0)
@@ -127,6 +131,36 @@ class _GraphModel(ImageEnhancementModel):
         if name not in self._dev_cache:
             self._dev_cache[name] = self._params[name].to(self.device, torch.float32).contiguous()
         return self._dev_cache[name]
+
+    def _vec_pad(self, name: str, n: int) -> torch.Tensor:
+        """Per-channel vector zero-padded to ``n`` entries (norm affine of zero-padded channels)."""
+        if self._dev_cache is None:
+            self._dev_cache = {}
+        key = ("vecpad", name, n)
+        if key not in self._dev_cache:
+            v = self._params[name].to(torch.float32)
+            self._dev_cache[key] = torch.cat([v, torch.zeros(n - v.numel())]).to(self.device).contiguous()
+        return self._dev_cache[key]
+
+    def _conv_transpose2x2(self, x, name):
+        """nn.ConvTranspose2d(k=2, s=2).  16-bit path: a 1x1 matrix-core conv to 4*Cout channels (o*4 + i*2 + j) + pixel shuffle."""
+        if self.compute_dtype == "f32":
+            if self._dev_cache is None:
+                self._dev_cache = {}
+            if ("ct", name) not in self._dev_cache:
+                self._dev_cache[("ct", name)] = ops.ConvT2x2Weights(self._params[f"{name}.weight"], self._params[f"{name}.bias"], self.device)
+            return ops.conv_transpose2x2(x, self._dev_cache[("ct", name)])
+        key = ("mconvT", name)
+        if self._dev_cache is None:
+            self._dev_cache = {}
+        if key not in self._dev_cache:
+            w = self._params[f"{name}.weight"]                            # (Cin, Cout, 2, 2)
+            b = self._params.get(f"{name}.bias")
+            ci, co = w.shape[0], w.shape[1]
+            w1 = w.permute(1, 2, 3, 0).reshape(co * 4, ci, 1, 1).contiguous()
+            b1 = None if b is None else b.repeat_interleave(4)
+            self._dev_cache[key] = ops.MConvWeights(w1, b1, [ci], self._tdt, self.device)
+        return ops.pixel_shuffle(ops.mconv2d(x, self._dev_cache[key], pad=0), 2)
 
     def _input(self, datapoint: dict) -> torch.Tensor:
         self.assert_datapoint(datapoint)
@@ -282,15 +316,22 @@ class LLUnetpp_RE(_GraphModel):
         self._on_params_change()
 
     def _block(self, b: str, srcs):
-        x12 = ops.conv2d(srcs, self._cw(f"{b}.conv1_2"), pad=0)
-        x1 = ops.conv2d(srcs, self._cw(f"{b}.conv1"))
-        x1 = ops.instance_norm(x1, self._vec(f"{b}.norm1.weight"), self._vec(f"{b}.norm1.bias"), 1e-5, "lrelu", 0.2)
-        x23 = ops.conv2d([x1, x12], self._cw(f"{b}.conv2_3"), pad=0)
-        x2 = ops.conv2d([x1, x12], self._cw(f"{b}.conv2"), act="lrelu", slope=0.2)
-        return ops.conv2d(x2, self._cw(f"{b}.conv3"), act="lrelu", slope=0.2, residual=x23)
+        c, ci = self._conv, self._io[b][0]
+        f32 = self.compute_dtype == "f32"
+        cp = None if f32 or ci % 8 == 0 else (ci + 7) // 8 * 8        # conv0_0: 3 channels carried as 8 on the 16-bit path
+        x12 = c(srcs, f"{b}.conv1_2", pad=0, cout_pad=cp)
+        x1 = c(srcs, f"{b}.conv1", cout_pad=cp)
+        if cp is None:
+            x1 = ops.instance_norm(x1, self._vec(f"{b}.norm1.weight"), self._vec(f"{b}.norm1.bias"), 1e-5, "lrelu", 0.2)
+        else:
+            x1 = ops.instance_norm(x1, self._vec_pad(f"{b}.norm1.weight", cp), self._vec_pad(f"{b}.norm1.bias", cp), 1e-5, "lrelu", 0.2)
+        v = None if cp is None else [ci, ci]
+        x23 = c([x1, x12], f"{b}.conv2_3", pad=0, valid=v)
+        x2 = c([x1, x12], f"{b}.conv2", act="lrelu", slope=0.2, valid=v)
+        return c(x2, f"{b}.conv3", act="lrelu", slope=0.2, residual=x23)
 
     def forward(self, datapoint: dict, *args, **kwargs) -> dict:
-        x = self._input(datapoint)
+        x = self._input_any(datapoint)
         if x.shape[2] % 16 or x.shape[3] % 16:
             raise ValueError(f"LLUnet++ needs H and W divisible by 16 (got {x.shape[2]}x{x.shape[3]}); use infer(), which "
                              f"resizes to a multiple of 32 like the reference (vision/model.py:106).")
@@ -310,7 +351,7 @@ class LLUnetpp_RE(_GraphModel):
         x2_2 = B("conv2_2", [x2_0, x2_1, up(x3_1)])
         x1_3 = B("conv1_3", [x1_0, x1_1, x1_2, up(x2_2)])
         x0_4 = B("conv0_4", [x0_0, x0_1, x0_2, x0_3, up(x1_3)])
-        y = ops.conv2d(x0_4, self._cw("final"), pad=0, clamp=(0.0, 1.0))
+        y = self._conv(x0_4, "final", pad=0, clamp=(0.0, 1.0), out_f32=True)
         return OrderedDict(enhanced=ops.to_nchw(y))
 
 
@@ -487,11 +528,11 @@ class ZeroIGEnhance(_GraphModel):
         self._on_params_change()
 
     def forward(self, datapoint: dict, *args, **kwargs) -> dict:
-        x = self._input(datapoint)
-        fea = ops.conv2d(x, self._cw("in_conv.0"), act="relu")
+        x = self._input_any(datapoint)
+        fea = self._conv(x, "in_conv.0", act="relu")
         for _ in range(self.layers):
-            fea = ops.conv2d(fea, self._cw("conv.0", "conv.1"), act="relu", residual=fea)
-        y = ops.conv2d(fea, self._cw("out_conv.0"), act="sigmoid", clamp=(0.0001, 1.0))
+            fea = self._conv(fea, "conv.0", "conv.1", act="relu", residual=fea)
+        y = self._conv(fea, "out_conv.0", act="sigmoid", clamp=(0.0001, 1.0), out_f32=True)
         return OrderedDict(enhanced=ops.to_nchw(y))
 
 
@@ -661,28 +702,21 @@ class HINet_RE(_GraphModel):
                 self._init_conv(k[:-7], g)
         self._on_params_change()
 
-    def _ct(self, name):
-        if self._dev_cache is None:
-            self._dev_cache = {}
-        if name not in self._dev_cache:
-            self._dev_cache[name] = ops.ConvT2x2Weights(self._params[f"{name}.weight"], self._params[f"{name}.bias"], self.device)
-        return self._dev_cache[name]
-
     def _block(self, name, srcs, hin, down, enc=None, dec=None):
-        s = self.relu_slope
-        idn = ops.conv2d(srcs, self._cw(f"{name}.identity"), pad=0)
+        s, c = self.relu_slope, self._conv
+        idn = c(srcs, f"{name}.identity", pad=0)
         if hin:
-            y = ops.conv2d(srcs, self._cw(f"{name}.conv_1"))
+            y = c(srcs, f"{name}.conv_1")
             half = y.shape[1] // 2
             y = ops.instance_norm(y, self._vec(f"{name}.norm.weight"), self._vec(f"{name}.norm.bias"), 1e-5, "lrelu", s, 0, half)
         else:
-            y = ops.conv2d(srcs, self._cw(f"{name}.conv_1"), act="lrelu", slope=s)
-        y = ops.conv2d(y, self._cw(f"{name}.conv_2"), act="lrelu", slope=s, residual=idn)
+            y = c(srcs, f"{name}.conv_1", act="lrelu", slope=s)
+        y = c(y, f"{name}.conv_2", act="lrelu", slope=s, residual=idn)
         if enc is not None and dec is not None:
-            y = ops.conv2d(enc, self._cw(f"{name}.csff_enc"), residual=y)
-            y = ops.conv2d(dec, self._cw(f"{name}.csff_dec"), residual=y)
+            y = c(enc, f"{name}.csff_enc", residual=y)
+            y = c(dec, f"{name}.csff_dec", residual=y)
         if down:
-            return ops.conv2d(y, self._cw(f"{name}.downsample"), stride=2, pad=1), y
+            return c(y, f"{name}.downsample", stride=2, pad=1), y
         return y
 
     def _stage(self, s, x, encs=None, decs=None):
@@ -697,8 +731,8 @@ class HINet_RE(_GraphModel):
             else:
                 x = self._block(name, [x], self._hin[i], False)
         for j in range(d - 1):
-            bridge = ops.conv2d(ups[-j - 1], self._cw(f"skip_conv_{s}.{j}"))
-            x = self._block(f"up_path_{s}.{j}.conv_block", [ops.conv_transpose2x2(x, self._ct(f"up_path_{s}.{j}.up")), bridge], False, False)
+            bridge = self._conv(ups[-j - 1], f"skip_conv_{s}.{j}")
+            x = self._block(f"up_path_{s}.{j}.conv_block", [self._conv_transpose2x2(x, f"up_path_{s}.{j}.up"), bridge], False, False)
             outs.append(x)
         return x, ups, outs
 
@@ -708,13 +742,22 @@ class HINet_RE(_GraphModel):
         if x.shape[2] % m or x.shape[3] % m:
             raise ValueError(f"HINet needs H and W divisible by {m} (got {x.shape[2]}x{x.shape[3]}); use infer(), which resizes "
                              f"to a multiple of 32 like the reference (vision/model.py:106).")
-        x1, encs, decs = self._stage(1, ops.conv2d(x, self._cw("conv_01")))
+        f32 = self.compute_dtype == "f32"
+        if not f32:
+            if self.num_channels % 16:
+                raise capi.IEError("hinet_re: the 16-bit path needs num_channels to be a multiple of 16")
+            x = ops.cast(x, self._tdt, 8)                                   # RGB carried as 8 channels (zeros appended)
+        cp = None if f32 else 8
+        c = self._conv
+        x1, encs, decs = self._stage(1, c(x, "conv_01"))
         # supervised attention (hinet.py:192-197)
-        f1 = ops.conv2d(x1, self._cw("sam12.conv1"))
-        img = ops.conv2d(x1, self._cw("sam12.conv2"), residual=x)
-        att = ops.conv2d(img, self._cw("sam12.conv3"), act="sigmoid")
+        f1 = c(x1, "sam12.conv1")
+        img = c(x1, "sam12.conv2", residual=x, cout_pad=cp)
+        att = c(img, "sam12.conv3", act="sigmoid")
         sam = ops.add(ops.mul(f1, att), x1)
-        x2 = ops.conv2d([ops.conv2d(x, self._cw("conv_02")), sam], self._cw("cat12"), pad=0)
+        x2 = c([c(x, "conv_02"), sam], "cat12", pad=0)
         x2, _, _ = self._stage(2, x2, encs, decs)
-        y2 = ops.conv2d(x2, self._cw("last"), residual=x)
+        y2 = c(x2, "last", residual=x, cout_pad=cp)
+        if not f32:
+            img, y2 = ops.cast(img, torch.float32, 3), ops.cast(y2, torch.float32, 3)
         return OrderedDict(stage1=ops.to_nchw(img), enhanced=ops.to_nchw(y2))

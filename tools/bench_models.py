@@ -20,6 +20,8 @@ CASES = [
     ("unet32_ps", dict(name="unet", seed=1, base_channels=32, num_classes=3, enhance=True, upsampler="pixelshuffle"), 2, (1080, 1920)),
     ("retinexnet", dict(name="retinexnet", seed=1), 2, (1080, 1920)),
     ("llunet++", dict(name="llunet++_re", seed=1), 1, (1088, 1920)),
+    ("hinet64", dict(name="hinet_re", seed=1), 1, (1088, 1920)),
+    ("unet64", dict(name="unet", seed=1, base_channels=64, num_classes=3, enhance=True), 2, (1080, 1920)),
 ]
 cdt = "f32"
 args = sys.argv[1:]
@@ -29,7 +31,7 @@ only = args
 for tag, cfg, n, hw in CASES:
     if only and tag not in only:
         continue
-    if cdt != "f32" and tag in ("zero_dce++", "llunet++"):
+    if cdt != "f32" and tag in ("zero_dce++",):
         continue                      # no 16-bit graph yet
     m = mon_amd.MODELS.build(compute_dtype=cdt, **cfg).to("cuda") if cdt != "f32" else mon_amd.MODELS.build(**cfg).to("cuda")
     x = torch.rand(n, 3, *hw, device="cuda")

@@ -20,3 +20,8 @@ x = torch.rand(2, 3, 48, 64, generator=g)
 run("unet32ps", dict(name="unet", seed=3, base_channels=32, num_classes=3, enhance=True, upsampler="pixelshuffle"), lambda sd, t: og.unet_forward(sd, t, "pixelshuffle", True), x, ["enhanced"])
 x = torch.rand(2, 3, 45, 67, generator=g)
 run("retinex", dict(name="retinexnet", seed=3), lambda sd, t: og.retinexnet_forward(sd, t), x, ["reflectance", "illumination", "illumination_delta", "enhanced"])
+x = torch.rand(1, 3, 32, 48, generator=g)
+run("llunet++", dict(name="llunet++_re", seed=31), lambda sd, t: og.llunetpp_forward(sd, t), x, ["enhanced"])
+x = torch.rand(2, 3, 32, 48, generator=g)
+run("hinet16", dict(name="hinet_re", seed=5, num_channels=16), lambda sd, t: og.hinet_forward(sd, t), x, ["stage1", "enhanced"])
+run("zero_ig", dict(name="zero_ig_enhance", seed=5), lambda sd, t: og.zero_ig_enhance_forward(sd, t), x, ["enhanced"])
