@@ -15,6 +15,7 @@
 // machine balance -> the kernel is MFMA-bound only if the input tile is shared through L2 by the cout tiles of the same
 // pixels; the block index is therefore XCD-swizzled so that those workgroups run on the same XCD.
 #include "ie_common.h"
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -26,8 +27,9 @@ constexpr int MAX_CHUNKS = 96;
 struct MConvParams {
     const void* src[IE_CONV_MAX_SRC];
     int cs[IE_CONV_MAX_SRC];
-    unsigned char chunk_src[MAX_CHUNKS];
-    unsigned short chunk_c0[MAX_CHUNKS];
+    int chunk_tab[MAX_CHUNKS];   // (source << 16) | first channel; dwords so that the wave-uniform lookups are scalar loads
+    const void* cd_base[MAX_CHUNKS];     // per chunk, flattened (one scalar load, no dependent lookups): source tensor ...
+    unsigned cd_info[MAX_CHUNKS];        // ... and (bytes per pixel of that source) | (byte offset of the chunk's first channel << 16)
     int nchunks;
     const void* wpk; const float* bias; const void* res; void* dst;
     int N, H, W, Cout, kh, kw, pad, pad_mode, sub, act, clamp, out_f32;
@@ -36,7 +38,16 @@ struct MConvParams {
     int tiles_x, tiles_y, cout_tiles, total_blocks;
     int taps_stage, nstages;     // weight staging: taps per LDS stage
     float slope, lo, hi;
+#ifdef IE_MSTAMP
+    unsigned long long* stamps;  // diagnostic build only: 64 s_memtime stamps per workgroup
+#endif
 };
+
+#ifdef IE_MSTAMP
+#define MST(i) do { if (p.stamps && tid == 0) p.stamps[(size_t)blockIdx.x * 64 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define MST(i) do { } while (0)
+#endif
 
 // activation with the hardware exp2/rcp forms (|err| <= 3e-7): one code path per template instance keeps the epilogue small
 template <int ACT> __device__ __forceinline__ float act_fast(float v, float slope) {
@@ -153,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(MConvParams p) {
     constexpr unsigned OOB = 0xFFFFFFF0u;      // beyond every buffer range (host-checked): the load returns zeros
 
     for (int ch = 0; ch < p.nchunks; ++ch) {
-        const int s = p.chunk_src[ch], c0 = p.chunk_c0[ch], Cs = p.cs[s];
+        const int s = p.chunk_tab[ch] >> 16, c0 = p.chunk_tab[ch] & 0xffff, Cs = p.cs[s];
         const size_t frame_b = (size_t)p.H * p.W * Cs * sizeof(T);
         const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.src[s] + (size_t)n * frame_b), 0, (int)frame_b, 0x00020000);
         __syncthreads();                        // the previous chunk's fragments have been read
@@ -242,6 +253,301 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(MConvParams p) {
     }
 }
 
+// ---- 3x3, weights in registers, double-buffered input tile ---------------------------------------------------------
+// The workgroup's 4 waves are CW cout fragments x RW row groups (CW*RW = 4, CW = 16-cout fragments of the cout tile = NF of
+// the packing).  A wave keeps its 9 weight fragments of the current K chunk in registers (loaded straight from the packed
+// image in L2, the next chunk's prefetched during the MFMAs), so LDS holds only the input tile -- twice: the LDS-DMA of chunk
+// ch+1 runs under the MFMAs of chunk ch, one barrier per chunk, two workgroups per CU.  Every pixel fragment read from LDS
+// (input row, column half, kx) feeds up to three MFMAs (ky = 0,1,2).
+template <typename T, int ACT, int NT>
+__device__ __forceinline__ void mconv3_epilogue(const MConvParams& p, ie_f32x4 (&acc)[NT], const float (&bv)[4], int n, int co0, int oy0, int ox0,
+                                                int r0, int kc, int l16) {
+    const int co = co0 + kc * 4;
+    if (co >= p.Cout) return;
+    const bool full = ((p.Cout & 3) == 0) && (co + 3 < p.Cout);
+    if constexpr (ACT == IE_ACT_RELU || ACT == IE_ACT_NONE) {
+        // interior tile of a plain Conv(+BN)+ReLU layer -- nearly all of the work: no masks; per accumulator tile 2 packed adds,
+        // 2 cvt_pk (+ 2 packed max), one store through a wave-uniform base pointer and a 32-bit lane offset
+        if (p.sub == 1 && full && !p.res && !p.clamp && !p.out_f32 && oy0 + TH <= p.Ho && ox0 + TW <= p.Wo) {
+            const char* tile = (const char*)((T*)p.dst + (((size_t)n * p.Hs + oy0 + r0) * p.Ws + ox0) * p.Cout);
+            const unsigned lane_off = (unsigned)((l16 * p.Cout + co) * (int)sizeof(T));
+            const unsigned row_b = (unsigned)p.Ws * (unsigned)p.Cout * (unsigned)sizeof(T), half_b = 16u * (unsigned)p.Cout * (unsigned)sizeof(T);
+            const ie_f32x2 b01 = {bv[0], bv[1]}, b23 = {bv[2], bv[3]};
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const ie_f32x2 v01 = ie_f32x2{acc[t][0], acc[t][1]} + b01, v23 = ie_f32x2{acc[t][2], acc[t][3]} + b23;
+                ie_u32x2 o;
+                if constexpr (ACT == IE_ACT_RELU) o = ie_u32x2{ie_pack2_relu<T>(v01[0], v01[1]), ie_pack2_relu<T>(v23[0], v23[1])};
+                else o = ie_u32x2{ie_pack2<T>(v01[0], v01[1]), ie_pack2<T>(v23[0], v23[1])};
+                *(ie_u32x2*)(const_cast<char*>(tile) + ((unsigned)(t >> 1) * row_b + (unsigned)(t & 1) * half_b) + lane_off) = o;
+            }
+            return;
+        }
+    }
+    if (p.sub == 1 && full && !p.res && !p.clamp && !p.out_f32) {
+        // fast path (every hot layer): one 64-bit base per lane, wave-uniform row / half offsets, 8 VALU + 1 store per tile
+        const int ox_a = ox0 + l16;
+        const bool live_x[2] = {ox_a < p.Wo, ox_a + 16 < p.Wo};
+        T* dst = (T*)p.dst + ((((size_t)n * p.Hs + oy0 + r0) * p.Ws + ox_a) * p.Cout + co);
+        const float slope = p.slope;
+        const unsigned row_stride = (unsigned)p.Ws * (unsigned)p.Cout;       // elements
+        const unsigned half_stride = 16u * (unsigned)p.Cout;
+        const int rows_live = p.Ho - (oy0 + r0);                             // wave-uniform
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if ((t >> 1) >= rows_live || !live_x[t & 1]) continue;
+            const unsigned o = (unsigned)(t >> 1) * row_stride + (unsigned)(t & 1) * half_stride;
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = act_fast<ACT>(acc[t][j] + bv[j], slope);
+            *(ie_u32x2*)(dst + o) = ie_u32x2{ie_pack2<T>(v[0], v[1]), ie_pack2<T>(v[2], v[3])};
+        }
+        return;
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {             // general path (stride 2, residual, ragged Cout)
+        const int oy = oy0 + r0 + (t >> 1), ox = ox0 + (t & 1) * 16 + l16;
+        bool live = oy < p.Ho && ox < p.Wo;
+        int sy = oy, sx = ox;
+        if (p.sub > 1) {
+            live = live && !(oy % p.sub) && !(ox % p.sub);
+            sy = oy / p.sub; sx = ox / p.sub;
+        }
+        if (!live) continue;
+        const size_t o = (((size_t)n * p.Hs + sy) * p.Ws + sx) * p.Cout + co;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = act_fast<ACT>(acc[t][j] + bv[j], p.slope);
+        if (p.res) {
+            const T* rp = (const T*)p.res + o;
+            if (full) {
+                typedef __attribute__((ext_vector_type(4))) T t4;
+                const t4 r4 = *(const t4*)rp;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += (float)r4[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (co + j < p.Cout) v[j] += (float)rp[j];
+            }
+        }
+        if (p.clamp) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fminf(fmaxf(v[j], p.lo), p.hi);
+        }
+        if (p.out_f32) {
+            float* dp = (float*)p.dst + o;
+            if (full) *(ie_f32x4*)dp = ie_f32x4{v[0], v[1], v[2], v[3]};
+            else
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (co + j < p.Cout) dp[j] = v[j];
+        } else {
+            T* dp = (T*)p.dst + o;
+            if (full) *(ie_u32x2*)dp = ie_u32x2{ie_pack2<T>(v[0], v[1]), ie_pack2<T>(v[2], v[3])};
+            else
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (co + j < p.Cout) dp[j] = (T)v[j];
+        }
+    }
+}
+
+template <typename T, int RW>
+__global__ __launch_bounds__(256, 2) void mconv3_kernel(MConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using frag = typename ie_elem<T>::frag;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    constexpr int CW = 4 / RW;                 // cout fragments per workgroup (= NF of the weight packing)
+    constexpr int R = TH / RW;                 // output rows per wave
+    constexpr int NT = 2 * R;                  // accumulator tiles per wave
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cw = wave % CW, rw = wave / CW;
+    constexpr int TWH = TW + 2, THH = TH + 2, TPX = TWH * THH;
+    constexpr int ND = ((TPX + 15) / 16 + 3) / 4 * 4;    // 1-KB DMA instructions per tile, padded so every wave issues ND/4
+    constexpr unsigned BUF_B = ND * 1024;
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    const int kc = lane >> 4, l16 = lane & 15;
+    const int r0 = rw * R;
+
+    // Persistent workgroup: tiles pos, pos + G, pos + 2G, ... of the logical order (cout tile fastest, then x, y, frame).
+    // pos is XCD-swizzled: the G/8 workgroups of one XCD work on G/8 consecutive logical tiles at any time, so the cout
+    // tiles of a pixel tile and its neighbours share that XCD's L2.
+    const int G = gridDim.x;
+    const int pos = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+    const int ntiles = p.tiles_x * p.tiles_y * p.cout_tiles * p.N;
+    if (pos >= ntiles) return;
+    struct Tile { int ct, n, oy0, ox0; };
+    auto decode = [&](int id) __attribute__((always_inline)) {
+        Tile t;
+        t.ct = id % p.cout_tiles; id /= p.cout_tiles;
+        const int tx = id % p.tiles_x; id /= p.tiles_x;
+        t.oy0 = (id % p.tiles_y) * TH; t.ox0 = tx * TW;
+        t.n = id / p.tiles_y;
+        return t;
+    };
+
+    ie_f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = ie_f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const unsigned w_chunk_bytes = 9u * 16 * CW * 64;
+    // this lane's 16 bytes of fragment (tap, cw) inside a chunk's packed image (same swizzled image the LDS path uses)
+    const unsigned w_lane_off = (unsigned)((cw * 16 + l16) * 64 + ((kc ^ ((l16 >> 1) & 3)) << 4));
+    frag w[9];                                  // w[ky*3+kx]
+    auto load_w_kx = [&](const Tile& t, int ch, int kx) __attribute__((always_inline)) {
+        const unsigned char* base = (const unsigned char*)p.wpk + ((size_t)t.ct * p.nchunks + ch) * w_chunk_bytes + w_lane_off;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) w[ky * 3 + kx] = *(const frag*)(base + (ky * 3 + kx) * (16 * CW * 64));
+    };
+    // LDS-DMA addressing: structured buffer (stride = one pixel of the source, index = pixel of the frame), so the per-chunk
+    // work of a DMA instruction is nil: vindex (pixel or "out of range" -> zeros) is computed once per tile, the channel
+    // piece offset once per kernel, the chunk's first channel goes into the scalar offset.
+    constexpr int NDW = ND / 4;                 // DMA instructions per wave per tile
+    constexpr bool IL_DMA = RW > 1;             // interleave the DMA issue with the MFMAs (the 128-accumulator variant has no VGPRs to spare)
+    // per tile and DMA slot: bits 0-27 = pixel index in the frame (replicate: clamped; all ones = out of range -> zeros),
+    // bits 28-29 = the column swizzle (c>>1)&3 of the halo pixel this lane fills
+    unsigned slot[NDW];
+    auto set_tile_pixels = [&](const Tile& t) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < NDW; ++k) {
+            const int q = (wave + 4 * k) * 16 + (lane >> 2);
+            const int r = q / TWH, c = q - r * TWH;
+            int iy = t.oy0 + r - p.pad, ix = t.ox0 + c - p.pad;
+            bool ok = q < TPX;
+            if (p.pad_mode == IE_PAD_REPLICATE) { iy = min(max(iy, 0), p.H - 1); ix = min(max(ix, 0), p.W - 1); }
+            else ok = ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            slot[k] = (ok ? (unsigned)(iy * p.W + ix) : 0x0fffffffu) | ((unsigned)((c >> 1) & 3) << 28);
+        }
+    };
+    struct CDesc { const char* base; unsigned info; };
+    auto fetch_desc = [&](int ch) __attribute__((always_inline)) { return CDesc{(const char*)p.cd_base[ch], p.cd_info[ch]}; };
+    const unsigned frame_px = (unsigned)p.H * (unsigned)p.W;
+    // one DMA instruction (slot k of this wave) of the tile described by (frame, d) into buffer bufsel
+    auto dma_one = [&](int k, int frame, const CDesc& d, unsigned bufsel) __attribute__((always_inline)) {
+        const unsigned cs_b = d.info & 0xffffu, c0_b = d.info >> 16;
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(d.base + (size_t)frame * frame_px * cs_b), (short)cs_b, (int)frame_px, 0x00020000);
+        unsigned char* buf = smem + bufsel * BUF_B + wave * 1024;
+        const int rem = (int)(cs_b - c0_b);                     // bytes of this chunk that exist in the source (>= 64: whole chunk)
+        const int voff = (int)(((lane & 3) ^ (slot[k] >> 28)) << 4);         // this lane's channel piece of the pixel (column swizzle)
+        const int vi = voff < rem ? (int)(slot[k] & 0x0fffffffu) : 0x0fffffff;   // short chunk: missing channel pieces read as zeros
+        __builtin_amdgcn_struct_ptr_buffer_load_lds(rs, (lds_ptr)(buf + k * 4096), 16, vi, voff, (int)c0_b, 0, 0);
+    };
+    auto issue_dma = [&](int frame, const CDesc& d, unsigned bufsel) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < NDW; ++k) dma_one(k, frame, d, bufsel);
+    };
+    // The 16-byte pieces of a pixel are swizzled by its COLUMN, (c>>1)&3 (not by the linear pixel index): a fragment's lane
+    // address is then lane_base[kx] + (ir*TWH*64 + hf*1024), a compile-time immediate of the ds_read -- three address
+    // registers instead of one per (row, half, kx).  Bank behaviour is that of the linear rule (a per-row phase only).
+    unsigned lane_base[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) lane_base[kx] = (unsigned)((r0 * TWH + l16 + kx) * 64 + ((kc ^ (((l16 + kx) >> 1) & 3)) << 4));
+    auto compute_kx = [&](unsigned bufsel, int kx, bool dma, int dframe, const CDesc& dd) __attribute__((always_inline)) {
+        const unsigned char* pk = smem + bufsel * BUF_B + lane_base[kx];
+        // fragment reads run one input row (6 MFMAs) ahead of their use; sched_group_barrier pins "the 2 reads first, then this
+        // row's MFMAs" inside every step (a second row of look-ahead changed nothing measurable and costs 8 VGPRs)
+        frag cur[2], nxt[2];
+        cur[0] = *(const frag*)(pk);
+        cur[1] = *(const frag*)(pk + 1024);
+#pragma unroll
+        for (int ir = 0; ir < R + 2; ++ir) {
+            if (ir + 1 < R + 2) {
+                nxt[0] = *(const frag*)(pk + (ir + 1) * (TWH * 64));
+                nxt[1] = *(const frag*)(pk + (ir + 1) * (TWH * 64) + 1024);
+            }
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int orow = ir - ky;
+                    if (orow < 0 || orow >= R) continue;
+                    acc[orow * 2 + hf] = ie_elem<T>::mfma16(w[ky * 3 + kx], cur[hf], acc[orow * 2 + hf]);
+                }
+            if (ir + 1 < R + 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // the next tile's LDS-DMA instructions ride in the shadow of the MFMAs, one per row step (issuing them in a block
+            // costs ~270 cycles each with the matrix pipe idle)
+            if (IL_DMA && kx == 0 && dma) {
+#pragma unroll
+                for (int k = ir; k < NDW; k += R + 2) dma_one(k, dframe, dd, bufsel ^ 1);
+            }
+            cur[0] = nxt[0]; cur[1] = nxt[1];
+        }
+    };
+
+    // Flat software pipeline over (tile, chunk): the LDS-DMA of the NEXT (tile, chunk) -- which may be chunk 0 of the next
+    // tile -- and its weights are issued under the MFMAs of the current one; one barrier per chunk.  VMEM order per chunk:
+    // [DMA of the next input tile: ND/4 per wave] [3 weight loads after each kx].  Inside a tile the 6 youngest loads
+    // (weights of kx = 1, 2) may still be in flight at the top (the compiler waits for those registers itself); after an
+    // epilogue the stores are in the queue too (loads and stores retire out of order with each other): wait for all.
+    int id = pos;
+    Tile cur = decode(id);
+    unsigned bufsel = 0;
+    set_tile_pixels(cur);
+    CDesc dn = fetch_desc(0);
+    issue_dma(cur.n, dn, 0);
+    dn = fetch_desc(p.nchunks > 1 ? 1 : 0);     // descriptor of the NEXT (tile, chunk): its scalar loads never sit on the critical path
+    load_w_kx(cur, 0, 0); load_w_kx(cur, 0, 1); load_w_kx(cur, 0, 2);
+    bool fresh = true;                          // first chunk of the kernel or after an epilogue
+    while (true) {
+        const int nid = id + G;
+        const bool has_next_tile = nid < ntiles;
+        Tile nxt_tile = cur;
+        if (has_next_tile) nxt_tile = decode(nid);
+        float bv[4];                            // this lane's 4 biases of the tile: loaded now, used in the epilogue
+        {
+            const int co = (cur.ct * CW + cw) * 16 + kc * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[j] = (p.bias && co + j < p.Cout) ? p.bias[co + j] : 0.f;
+        }
+        for (int ch = 0; ch < p.nchunks; ++ch) {
+            const int sb = (id == pos && ch < 6) ? ch * 8 : 56;
+            MST(sb + 0);
+            if (fresh) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // this wave's part of the tile (and the kx = 0 weights) has landed
+            fresh = false;
+            MST(sb + 1);
+            __syncthreads();                                    // ... everyone's; and everyone is done with the other buffer
+            MST(sb + 2);
+            const bool last = ch + 1 == p.nchunks;
+            const bool more = !last || has_next_tile;
+            const Tile& nt = last ? nxt_tile : cur;
+            const int nch = last ? 0 : ch + 1;
+            if (last && has_next_tile) set_tile_pixels(nxt_tile);
+            if (!IL_DMA && more) issue_dma(nt.n, dn, bufsel ^ 1);
+            MST(sb + 3);
+            compute_kx(bufsel, 0, more, nt.n, dn);
+            {
+                int c2 = ch + 2;
+                if (c2 >= p.nchunks) c2 -= p.nchunks;
+                if (c2 >= p.nchunks) c2 = 0;
+                dn = fetch_desc(c2);
+            }
+            MST(sb + 4);
+            if (more) load_w_kx(nt, nch, 0);
+            compute_kx(bufsel, 1, false, 0, dn);
+            MST(sb + 5);
+            if (more) load_w_kx(nt, nch, 1);
+            compute_kx(bufsel, 2, false, 0, dn);
+            MST(sb + 6);
+            if (more) load_w_kx(nt, nch, 2);
+            bufsel ^= 1;
+        }
+        const int co0 = (cur.ct * CW + cw) * 16;
+        switch (p.act) {
+        case IE_ACT_RELU: mconv3_epilogue<T, IE_ACT_RELU, NT>(p, acc, bv, cur.n, co0, cur.oy0, cur.ox0, r0, kc, l16); break;
+        case IE_ACT_LRELU: mconv3_epilogue<T, IE_ACT_LRELU, NT>(p, acc, bv, cur.n, co0, cur.oy0, cur.ox0, r0, kc, l16); break;
+        case IE_ACT_TANH: mconv3_epilogue<T, IE_ACT_TANH, NT>(p, acc, bv, cur.n, co0, cur.oy0, cur.ox0, r0, kc, l16); break;
+        case IE_ACT_SIGMOID: mconv3_epilogue<T, IE_ACT_SIGMOID, NT>(p, acc, bv, cur.n, co0, cur.oy0, cur.ox0, r0, kc, l16); break;
+        default: mconv3_epilogue<T, IE_ACT_NONE, NT>(p, acc, bv, cur.n, co0, cur.oy0, cur.ox0, r0, kc, l16); break;
+        }
+        if (id == pos) MST(48);
+        if (!has_next_tile) break;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = ie_f32x4{0.f, 0.f, 0.f, 0.f};
+        cur = nxt_tile; id = nid; fresh = true;
+    }
+}
+
 int pick_nf(int Cout) { return Cout > 32 ? 4 : (Cout > 16 ? 2 : 1); }
 
 struct Plan {
@@ -283,6 +589,11 @@ unsigned short f32_to_16(float v, int dtype) {
 }
 
 }  // namespace
+
+#ifdef IE_MSTAMP
+static unsigned long long* g_mconv_stamps = nullptr;
+IE_EXPORT void ie_debug_mconv_stamps(void* dev) { g_mconv_stamps = (unsigned long long*)dev; }
+#endif
 
 IE_EXPORT size_t ie_mconv_packed_bytes(const int* channels, int nsrc, int Cout, int kh, int kw) {
     Plan pl;
@@ -344,8 +655,14 @@ IE_EXPORT int ie_mconv_nhwc(ie_mconv_desc* d, const void* const* srcs, const int
         if (!srcs[s]) IE_FAIL(IE_ERR_INVALID, "ie_mconv_nhwc: source %d is null", s);
         p.src[s] = srcs[s]; p.cs[s] = channels[s];
     }
-    memcpy(p.chunk_src, pl.chunk_src, sizeof(p.chunk_src));
-    memcpy(p.chunk_c0, pl.chunk_c0, sizeof(p.chunk_c0));
+#ifdef IE_MSTAMP
+    p.stamps = g_mconv_stamps;
+#endif
+    for (int c = 0; c < pl.nchunks; ++c) {
+        p.chunk_tab[c] = ((int)pl.chunk_src[c] << 16) | (int)pl.chunk_c0[c];
+        p.cd_base[c] = srcs[pl.chunk_src[c]];
+        p.cd_info[c] = (unsigned)(channels[pl.chunk_src[c]] * 2) | ((unsigned)(pl.chunk_c0[c] * 2) << 16);
+    }
     p.nchunks = pl.nchunks; p.wpk = packed_w; p.bias = bias; p.res = residual; p.dst = dst;
     p.N = d->N; p.H = d->H; p.W = d->W; p.Cout = d->Cout; p.kh = d->kh; p.kw = d->kw; p.pad = d->pad; p.pad_mode = d->pad_mode;
     p.sub = d->stride; p.act = d->act; p.clamp = d->clamp; p.out_f32 = d->out_dtype == IE_F32; p.slope = d->slope; p.lo = d->clamp_lo;
@@ -360,28 +677,47 @@ IE_EXPORT int ie_mconv_nhwc(ie_mconv_desc* d, const void* const* srcs, const int
     p.taps_stage = pl.taps_stage; p.nstages = pl.nstages;
     const size_t lds = (size_t)(((TH + d->kh - 1) * (TW + d->kw - 1) + 15) / 16) * 1024 + pl.stage_bytes;
     for (int s = 0; s < d->nsrc; ++s)
-        if ((double)d->H * d->W * channels[s] * 2.0 >= 4294967040.0) IE_FAIL(IE_ERR_UNSUPPORTED, "ie_mconv_nhwc: a frame of source %d exceeds 4 GiB", s);
+        if ((double)d->H * d->W * channels[s] * 2.0 >= 4294967040.0 || (double)d->H * d->W >= 268435455.0)
+            IE_FAIL(IE_ERR_UNSUPPORTED, "ie_mconv_nhwc: a frame of source %d exceeds 4 GiB / 2^28 pixels", s);
     if (lds > 160 * 1024) IE_FAIL(IE_ERR_UNSUPPORTED, "ie_mconv_nhwc: %dx%d kernel needs %zu bytes of LDS", d->kh, d->kw, lds);
     void (*fn)(MConvParams) = nullptr;
     const bool h = d->in_dtype == IE_F16;
     const bool k3 = d->kh == 3 && d->kw == 3;
-    switch (pl.nf * 2 + (k3 ? 1 : 0)) {
-    case 2: fn = h ? mconv_kernel<_Float16, 1, false> : mconv_kernel<__bf16, 1, false>; break;
-    case 3: fn = h ? mconv_kernel<_Float16, 1, true> : mconv_kernel<__bf16, 1, true>; break;
-    case 4: fn = h ? mconv_kernel<_Float16, 2, false> : mconv_kernel<__bf16, 2, false>; break;
-    case 5: fn = h ? mconv_kernel<_Float16, 2, true> : mconv_kernel<__bf16, 2, true>; break;
-    case 8: fn = h ? mconv_kernel<_Float16, 4, false> : mconv_kernel<__bf16, 4, false>; break;
-    default: fn = h ? mconv_kernel<_Float16, 4, true> : mconv_kernel<__bf16, 4, true>; break;
+    static const int use_v1 = getenv("IE_MCONV_V1") ? atoi(getenv("IE_MCONV_V1")) : 0;     // A/B switch: single-buffered LDS-weights kernel
+    size_t lds_bytes = lds;
+    int slot;
+    if (k3 && !use_v1) {
+        switch (pl.nf) {
+        case 1: fn = h ? mconv3_kernel<_Float16, 4> : mconv3_kernel<__bf16, 4>; break;
+        case 2: fn = h ? mconv3_kernel<_Float16, 2> : mconv3_kernel<__bf16, 2>; break;
+        default: fn = h ? mconv3_kernel<_Float16, 1> : mconv3_kernel<__bf16, 1>; break;
+        }
+        lds_bytes = 2 * (size_t)((((TH + 2) * (TW + 2) + 15) / 16 + 3) / 4 * 4) * 1024;
+        slot = 12 + (h ? 0 : 3) + (pl.nf == 1 ? 0 : (pl.nf == 2 ? 1 : 2));
+    } else {
+        switch (pl.nf * 2 + (k3 ? 1 : 0)) {
+        case 2: fn = h ? mconv_kernel<_Float16, 1, false> : mconv_kernel<__bf16, 1, false>; break;
+        case 3: fn = h ? mconv_kernel<_Float16, 1, true> : mconv_kernel<__bf16, 1, true>; break;
+        case 4: fn = h ? mconv_kernel<_Float16, 2, false> : mconv_kernel<__bf16, 2, false>; break;
+        case 5: fn = h ? mconv_kernel<_Float16, 2, true> : mconv_kernel<__bf16, 2, true>; break;
+        case 8: fn = h ? mconv_kernel<_Float16, 4, false> : mconv_kernel<__bf16, 4, false>; break;
+        default: fn = h ? mconv_kernel<_Float16, 4, true> : mconv_kernel<__bf16, 4, true>; break;
+        }
+        slot = (h ? 0 : 6) + (pl.nf == 1 ? 0 : (pl.nf == 2 ? 1 : 2)) * 2 + (k3 ? 1 : 0);
     }
-    if (lds > 64 * 1024) {       // opt in to > 64 KB of dynamic LDS once per kernel (raised monotonically)
-        static size_t granted[12] = {0};
-        const int slot = (h ? 0 : 6) + (pl.nf == 1 ? 0 : (pl.nf == 2 ? 1 : 2)) * 2 + (k3 ? 1 : 0);
-        if (granted[slot] < lds) {
+    if (lds_bytes > 64 * 1024) {       // opt in to > 64 KB of dynamic LDS once per kernel
+        static bool granted[18] = {false};
+        if (!granted[slot]) {
             IE_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            granted[slot] = 160 * 1024;
+            granted[slot] = true;
         }
     }
-    hipLaunchKernelGGL(fn, dim3(p.total_blocks), dim3(256), lds, (hipStream_t)stream, p);
+    int grid = p.total_blocks;
+    if (k3 && !use_v1) {                   // persistent: two workgroups per CU (LDS 2 x 80 KB), each walks its share of the tiles
+        static const int wg_cap = getenv("IE_MCONV_WGS") ? atoi(getenv("IE_MCONV_WGS")) : 512;
+        if (grid > wg_cap) grid = wg_cap;
+    }
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds_bytes, (hipStream_t)stream, p);
     IE_LAUNCH_CHECK();
     return IE_OK;
 }

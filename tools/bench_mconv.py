@@ -23,7 +23,10 @@ SHAPES = [  # (name, N, H, W, [cin...], cout, k)
     ("64->3 1x1", 4, 1080, 1920, [64], 3, 1),
     ("8->64 9x9", 2, 1080, 1920, [8], 64, 9),
 ]
+only = sys.argv[2:]
 for name, n, h, w, cs, co, k in SHAPES:
+    if only and not any(o in name for o in only):
+        continue
     g = torch.Generator().manual_seed(0)
     xs = [torch.randn(n, c, h, w, device="cuda", dtype=dt).contiguous(memory_format=CL) for c in cs]
     wt = torch.randn(co, sum(cs), k, k) / (sum(cs) * k * k) ** 0.5
