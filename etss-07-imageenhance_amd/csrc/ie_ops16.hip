@@ -200,6 +200,41 @@ __global__ void norm16_apply(const T* __restrict__ x, const float* __restrict__ 
     st8(y + e, pack8<T>(v));
 }
 
+
+// depthwise 3x3 (groups = C, zero padding, stride 1) + bias + activation: thread = 8 channels of one output pixel,
+// weights [9][C] fp32 staged in LDS once per block (nn/modules/conv/dsconv.py:122-134)
+template <typename T>
+__global__ void dwconv3x3_v8(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, T* __restrict__ y, int H,
+                             int W, int C, int act, float slope, size_t total) {
+    extern __shared__ float wl[];                  // [9][C] + [C]
+    for (int i = threadIdx.x; i < 10 * C; i += blockDim.x) wl[i] = i < 9 * C ? w[i] : (bias ? bias[i - 9 * C] : 0.f);
+    __syncthreads();
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const Idx o = split(i, H, W, C / 8);
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = wl[9 * C + o.c + k];
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+        const int yy = o.h + dy;
+        if (yy < 0 || yy >= H) continue;
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int xx = o.w + dx;
+            if (xx < 0 || xx >= W) continue;
+            float v[8];
+            unpack8<T>(ld8(x + ((o.n * H + yy) * W + xx) * C + o.c), v);
+            const float* wt = wl + ((dy + 1) * 3 + (dx + 1)) * C + o.c;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] = fmaf(v[k], wt[k], acc[k]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = ie_act_apply(acc[k], act, slope);
+    st8(y + i * 8, pack8<T>(acc));
+}
+
 bool is16(int dt) { return dt == IE_F16 || dt == IE_BF16; }
 
 }  // namespace
@@ -307,6 +342,18 @@ IE_EXPORT int ie_instnorm_nhwc(const void* x, const float* gamma, const float* b
     const size_t total = (size_t)N * HW * (C / 8);
     if (dtype == IE_F16) hipLaunchKernelGGL(norm16_apply<_Float16>, dim3(nblk(total)), dim3(256), 0, st, (const _Float16*)x, mean, inv, gamma, beta, (_Float16*)y, HW, C, c_begin, c_count, act, slope, total);
     else hipLaunchKernelGGL(norm16_apply<__bf16>, dim3(nblk(total)), dim3(256), 0, st, (const __bf16*)x, mean, inv, gamma, beta, (__bf16*)y, HW, C, c_begin, c_count, act, slope, total);
+    IE_LAUNCH_CHECK();
+    return IE_OK;
+}
+
+IE_EXPORT int ie_dwconv3x3_nhwc(const void* x, const float* w_tap_c, const float* bias, void* y, int dtype, int N, int H, int W, int C, int act,
+                                float slope, void* stream) {
+    if (!x || !w_tap_c || !y || !is16(dtype) || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7) || C > 1024)
+        IE_FAIL(IE_ERR_INVALID, "ie_dwconv3x3_nhwc: bad args (16-bit, C %% 8 == 0, C <= 1024)");
+    const size_t total = (size_t)N * H * W * (C / 8);
+    const size_t lds = sizeof(float) * 10 * C;
+    if (dtype == IE_F16) hipLaunchKernelGGL(dwconv3x3_v8<_Float16>, dim3(nblk(total)), dim3(256), lds, (hipStream_t)stream, (const _Float16*)x, w_tap_c, bias, (_Float16*)y, H, W, C, act, slope, total);
+    else hipLaunchKernelGGL(dwconv3x3_v8<__bf16>, dim3(nblk(total)), dim3(256), lds, (hipStream_t)stream, (const __bf16*)x, w_tap_c, bias, (__bf16*)y, H, W, C, act, slope, total);
     IE_LAUNCH_CHECK();
     return IE_OK;
 }

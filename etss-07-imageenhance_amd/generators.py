@@ -219,20 +219,33 @@ class ZeroDCEpp_RE(_GraphModel):
             self._init_conv(f"e_conv{k}.pw_conv", g, std=0.02)
         self._on_params_change()
 
-    def _ds(self, k, srcs, act):
+    def _ds(self, k, srcs, act, out_f32=False):
         # depthwise over the concat == depthwise per source with the matching weight slice
-        outs, off = [], 0
+        outs, off, valid = [], 0, []
+        f32 = self.compute_dtype == "f32"
+        if self._dev_cache is None:
+            self._dev_cache = {}
+        wdw, bdw = self._params[f"e_conv{k}.dw_conv.weight"], self._params[f"e_conv{k}.dw_conv.bias"]
         for s in srcs:
             c = s.shape[1]
-            key = ("dw", k, off)
-            if self._dev_cache is None:
-                self._dev_cache = {}
+            real = min(c, wdw.shape[0] - off)         # 16-bit path: the RGB input is carried as 8 channels
+            key = ("dw", k, off, c)
             if key not in self._dev_cache:
-                self._dev_cache[key] = ops.ConvWeights(self._params[f"e_conv{k}.dw_conv.weight"][off:off + c],
-                                                       self._params[f"e_conv{k}.dw_conv.bias"][off:off + c], self.device)
-            outs.append(ops.depthwise_conv2d(s, self._dev_cache[key]))
-            off += c
-        return ops.conv2d(outs, self._cw(f"e_conv{k}.pw_conv"), pad=0, act=act)
+                if f32:
+                    self._dev_cache[key] = ops.ConvWeights(wdw[off:off + c], bdw[off:off + c], self.device)
+                else:
+                    wt = torch.zeros(9, c)
+                    wt[:, :real] = wdw[off:off + real, 0].reshape(real, 9).t()
+                    bt = torch.zeros(c)
+                    bt[:real] = bdw[off:off + real]
+                    self._dev_cache[key] = (wt.contiguous().to(self.device), bt.to(self.device))
+            if f32:
+                outs.append(ops.depthwise_conv2d(s, self._dev_cache[key]))
+            else:
+                outs.append(ops.depthwise3x3_16(s, *self._dev_cache[key]))
+            valid.append(real)
+            off += real
+        return self._conv(outs, f"e_conv{k}.pw_conv", pad=0, act=act, out_f32=out_f32, valid=None if f32 or valid == [t.shape[1] for t in outs] else valid)
 
     def forward(self, datapoint: dict, *args, **kwargs) -> dict:
         x = self._input(datapoint)
@@ -241,13 +254,15 @@ class ZeroDCEpp_RE(_GraphModel):
             h, w = x.shape[2], x.shape[3]
             # F.interpolate(scale_factor=1/s, mode="bilinear"): out = floor(in * (1/s)), align_corners=False
             xd = ops.resize(x, (int(math.floor(h * (1 / self.scale_factor))), int(math.floor(w * (1 / self.scale_factor)))), "bilinear")
+        if self.compute_dtype != "f32":
+            xd = ops.cast(xd, self._tdt, 8)
         x1 = self._ds(1, [xd], "relu")
         x2 = self._ds(2, [x1], "relu")
         x3 = self._ds(3, [x2], "relu")
         x4 = self._ds(4, [x3], "relu")
         x5 = self._ds(5, [x3, x4], "relu")
         x6 = self._ds(6, [x2, x5], "relu")
-        xr = self._ds(7, [x1, x6], "tanh")
+        xr = self._ds(7, [x1, x6], "tanh", out_f32=True)          # 3-channel map, fp32 on every path
         if self.scale_factor != 1:
             # nn.UpsamplingBilinear2d(scale_factor): align_corners=True, out = floor(in * s)
             xr = ops.resize(xr, (int(math.floor(xr.shape[2] * self.scale_factor)), int(math.floor(xr.shape[3] * self.scale_factor))),

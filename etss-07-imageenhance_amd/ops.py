@@ -497,3 +497,14 @@ def mconv2d(srcs, mw: MConvWeights, stride=1, pad=1, pad_mode="zeros", act="none
         capi.check(capi.lib().ie_mconv_nhwc(C.byref(d), ptrs, chans, capi.ptr(mw.w), capi.ptr(mw.b), capi.ptr(residual), capi.ptr(out),
                                             capi.current_stream()), "ie_mconv_nhwc")
     return out
+
+
+def depthwise3x3_16(x, w_tap_c: torch.Tensor, bias, act="none", slope=0.0) -> torch.Tensor:
+    """16-bit depthwise 3x3 (zero padding 1): ``w_tap_c`` fp32 device tensor [9, C]."""
+    _chk16(x)
+    n, c, h, w = x.shape
+    y = torch.empty_like(x, memory_format=CL)
+    with torch.cuda.device(x.device):
+        capi.check(capi.lib().ie_dwconv3x3_nhwc(capi.ptr(x), capi.ptr(w_tap_c), capi.ptr(bias), capi.ptr(y), _dt(x), n, h, w, c, capi.ACT[act], slope,
+                                                capi.current_stream()), "ie_dwconv3x3_nhwc")
+    return y

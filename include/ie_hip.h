@@ -167,6 +167,11 @@ int ie_pad_nhwc(const void* x_dev, void* y_dev, int dtype, int N, int H, int W, 
 int ie_pixel_shuffle_nhwc(const void* x_dev, void* y_dev, int dtype, int N, int H, int W, int Cout, int r, void* stream);
 /* op 0: a + b, 1: a * b; b has C channels or one (broadcast). */
 int ie_eltwise_nhwc(int op, const void* a_dev, const void* b_dev, void* y_dev, int dtype, size_t npix, int C, int Cb, void* stream);
+/* Depthwise 3x3 (groups = C, zero padding 1, stride 1) + bias + activation on a 16-bit tensor: the first half of
+ * DepthwiseSeparableConv2d (nn/modules/conv/dsconv.py:122-134); the pointwise half is ie_mconv_nhwc with a 1x1 kernel.
+ * w_tap_c_dev: fp32 [9][C] (tap-major); bias_dev may be NULL. */
+int ie_dwconv3x3_nhwc(const void* x_dev, const float* w_tap_c_dev, const float* bias_dev, void* y_dev, int dtype, int N, int H, int W, int C,
+                      int act, float slope, void* stream);
 /* dst[p][c] = c < Cs ? (dst type) src[p][c] : 0 for c < Cd: dtype conversion and channel padding / cropping in one pass
  * (e.g. DecomNet's 4-channel fp32 input -> 8-channel bf16; a 16-bit map -> the fp32 tensor handed back to the caller). */
 int ie_cast_nhwc(const void* src_dev, int src_dtype, int Cs, void* dst_dev, int dst_dtype, int Cd, size_t npix, void* stream);

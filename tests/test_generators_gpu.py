@@ -251,3 +251,28 @@ def test_llunetpp_hinet_zero_ig_16bit_vs_oracle(dt, tol_ll, tol_hi):
 
 def capi_err():
     return mon_amd.capi.IEError
+
+
+@pytest.mark.parametrize("dt,tol", [("f16", 1e-3), ("bf16", 6e-3)])
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "zero_dcepp_*.npz"))), ids=lambda p: os.path.basename(p)[11:-4])
+def test_zero_dcepp_16bit_golden(path, dt, tol):
+    """Zero-DCE++ on the 16-bit path: depthwise 3x3 (ie_dwconv3x3_nhwc) + 1x1 matrix-core conv per layer, against the
+    reference-generated goldens (measured 1.8e-4 / 1.2e-3)."""
+    g = np.load(path)
+    sd = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w.")}
+    m = mon_amd.MODELS.build(name="zero_dce++_re", scale_factor=float(g["scale_factor"]), weights=sd, compute_dtype=dt).to("cuda")
+    out = m.forward({"image": torch.from_numpy(g["image"]).cuda()})
+    assert list(out.keys()) == ["adjust", "enhanced"]
+    assert rel_err(out["enhanced"].cpu(), g["enhanced"]) <= tol
+    assert rel_err(out["adjust"].cpu(), g["adjust"]) <= tol
+
+
+def test_depthwise3x3_16bit_against_torch():
+    g = torch.Generator().manual_seed(4)
+    for tdt, tol in ((torch.float16, 1e-3), (torch.bfloat16, 8e-3)):
+        x = torch.randn(2, 24, 13, 19, generator=g).to(tdt)
+        w = torch.randn(24, 1, 3, 3, generator=g) * 0.3
+        b = torch.randn(24, generator=g)
+        ref = F.relu(F.conv2d(x.float(), w, b, padding=1, groups=24))
+        got = ops.depthwise3x3_16(x.cuda().contiguous(memory_format=torch.channels_last), w[:, 0].reshape(24, 9).t().contiguous().cuda(), b.cuda(), "relu")
+        assert rel_err(got.float().cpu(), ref) <= tol

@@ -25,3 +25,6 @@ run("llunet++", dict(name="llunet++_re", seed=31), lambda sd, t: og.llunetpp_for
 x = torch.rand(2, 3, 32, 48, generator=g)
 run("hinet16", dict(name="hinet_re", seed=5, num_channels=16), lambda sd, t: og.hinet_forward(sd, t), x, ["stage1", "enhanced"])
 run("zero_ig", dict(name="zero_ig_enhance", seed=5), lambda sd, t: og.zero_ig_enhance_forward(sd, t), x, ["enhanced"])
+x = torch.rand(2, 3, 40, 56, generator=g)
+run("zero_dce++", dict(name="zero_dce++_re", seed=5), lambda sd, t: og.zero_dcepp_forward(sd, t), x, ["adjust", "enhanced"])
+run("zero_dce++s2", dict(name="zero_dce++_re", seed=5, scale_factor=2.0), lambda sd, t: og.zero_dcepp_forward(sd, t, 8, 2.0), x, ["adjust", "enhanced"])
