@@ -1,0 +1,18 @@
+// Shared between ie_ops.hip (forward) and ie_train.hip (data gradient = a forward conv with transposed, flipped weights).
+#pragma once
+#include "ie_common.h"
+
+struct ConvNParams {
+    const float* src[IE_CONV_MAX_SRC];
+    int cs[IE_CONV_MAX_SRC];
+    int nsrc;
+    const float* w; const float* bias; const float* res; float* dst;
+    int N, H, W, Cin, Cout, kh, kw, stride, pad, pad_mode, act, Ho, Wo, clamp;
+    float slope, lo, hi;
+    int w_ld;          // row pitch of the HWIO weight matrix (>= Cout; > Cout when only a column slice is used)
+    int accumulate;    // dst += result (data gradients landing on a tensor with several consumers)
+};
+
+// Launch the fp32 convolution described by p (fields Ho/Wo already set): LDS-tiled GEMM kernel for wide layers,
+// direct kernel for thin ones.  Returns an ie_status.
+int ie_convn_launch(const ConvNParams& p, hipStream_t stream);

@@ -6,7 +6,10 @@
 // src/mon/nn/metric/image.py:90-237 (custom_ssim); optimiser: torch.optim.Adam + clip_grad_norm_
 // (src/mon/nn/model.py:498-615, zero_dce_re_sice_mix.py:46-51,106).
 #include "ie_common.h"
+#include "ie_conv_internal.h"
 #include <math.h>
+#include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -150,6 +153,17 @@ __global__ __launch_bounds__(256) void conv_dgrad_kernel(DgradParams p) {
     float* o = p.dx + (((size_t)n * p.H + hi) * p.W + wi) * p.Cs + ci0;
 #pragma unroll
     for (int k = 0; k < DG_CT; ++k) if (k < nci) o[k] = (p.accumulate ? o[k] : 0.f) + acc[k];
+}
+
+// W'[(kh-1-i)*kw + (kw-1-j)][co][ci] = W[i*kw + j][ci][co]: the data gradient of a stride-1 conv is a conv of dY with W'
+__global__ void flip_transpose_hwio_kernel(const float* __restrict__ w, float* __restrict__ wt, int taps, int Cin, int Cout, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int ci = (int)(i % Cin);
+    size_t r = i / Cin;
+    const int co = (int)(r % Cout);
+    const int tp = (int)(r / Cout);
+    wt[i] = w[((size_t)(taps - 1 - tp) * Cin + ci) * Cout + co];
 }
 
 // per-channel sum over pixels (bias gradient): same thread layout as the norm statistics pass
@@ -546,6 +560,34 @@ IE_EXPORT int ie_convn_dgrad_nhwc_f32(ie_convn_desc* d, const float* dy, const f
     d->Ho = (d->H + 2 * d->pad - d->kh) / d->stride + 1;
     d->Wo = (d->W + 2 * d->pad - d->kw) / d->stride + 1;
     if (d->Ho <= 0 || d->Wo <= 0) IE_FAIL(IE_ERR_INVALID, "ie_convn_dgrad_nhwc_f32: empty output");
+    hipStream_t st = (hipStream_t)stream;
+    static const int force_gather = getenv("IE_DGRAD_GATHER") ? atoi(getenv("IE_DGRAD_GATHER")) : 0;     // A/B switch
+    if (d->stride == 1 && d->kh - 1 - d->pad >= 0 && d->kw - 1 - d->pad >= 0 && d->kh - 1 - d->pad == d->kw - 1 - d->pad && !force_gather) {
+        // stride 1: dX = conv(dY, W') with W' = W flipped and transposed -> the LDS-tiled forward kernel (3x the gather kernel)
+        const int taps = d->kh * d->kw;
+        const size_t wn = (size_t)taps * Cin * d->Cout;
+        float* wt = nullptr;
+        IE_HIP_CHECK(hipMallocAsync((void**)&wt, wn * sizeof(float), st));
+        hipLaunchKernelGGL(flip_transpose_hwio_kernel, dim3(nblk(wn)), dim3(256), 0, st, w_hwio, wt, taps, Cin, d->Cout, wn);
+        IE_LAUNCH_CHECK();
+        int cb = 0;
+        for (int s = 0; s < d->nsrc; ++s) {
+            if (dsrcs[s]) {
+                ConvNParams q;
+                memset(&q, 0, sizeof(q));
+                q.src[0] = dy; q.cs[0] = d->Cout; q.nsrc = 1; q.Cin = d->Cout;
+                q.w = wt + cb; q.w_ld = Cin; q.Cout = cs[s]; q.dst = dsrcs[s];
+                q.N = d->N; q.H = d->Ho; q.W = d->Wo; q.kh = d->kh; q.kw = d->kw; q.stride = 1; q.pad = d->kh - 1 - d->pad;
+                q.pad_mode = IE_PAD_ZEROS; q.act = IE_ACT_NONE; q.Ho = d->H; q.Wo = d->W;
+                q.accumulate = accumulate ? accumulate[s] : 0;
+                rc = ie_convn_launch(q, st);
+                if (rc != IE_OK) { hipFreeAsync(wt, st); return rc; }
+            }
+            cb += cs[s];
+        }
+        IE_HIP_CHECK(hipFreeAsync(wt, st));
+        return IE_OK;
+    }
     int cbase = 0;
     for (int s = 0; s < d->nsrc; ++s) {
         if (dsrcs[s]) {                    // NULL = this source needs no gradient (e.g. the input image)
@@ -554,7 +596,7 @@ IE_EXPORT int ie_convn_dgrad_nhwc_f32(ie_convn_desc* d, const float* dy, const f
             p.N = d->N; p.H = d->H; p.W = d->W; p.Cs = cs[s]; p.Cout = d->Cout; p.Cin_total = Cin; p.cbase = cbase; p.kh = d->kh;
             p.kw = d->kw; p.stride = d->stride; p.pad = d->pad; p.Ho = d->Ho; p.Wo = d->Wo; p.accumulate = accumulate ? accumulate[s] : 0;
             dim3 grid(ie_cdiv(d->H * d->W, 64), ie_cdiv(cs[s], 4 * DG_CT), d->N);
-            hipLaunchKernelGGL(conv_dgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+            hipLaunchKernelGGL(conv_dgrad_kernel, grid, dim3(256), 0, st, p);
             IE_LAUNCH_CHECK();
         }
         cbase += cs[s];

