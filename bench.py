@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
     ap.add_argument("--output", default="f32", choices=["f32", "u8"], help="enhanced as fp32 NCHW or uint8 NHWC")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the short side measurements of the other BASELINE configs")
     args = ap.parse_args()
 
     import torch
@@ -186,6 +187,43 @@ def main():
             parity = {"max_rel_err": float(f"{err:.3e}"), "psnr_db_vs_cpu_fp32": round(10 * math.log10(1.0 / mse), 2) if mse > 0 else None,
                       "u8_exact_match": round(float((d == 0).float().mean()), 5), "u8_max_abs_diff": int(d.max())}
 
+        # ---- side measurements (N=1 only, a few seconds): the other BASELINE.json configs, NOT part of `value` ----------------
+        extras = None
+        if world == 1 and not args.no_extras:
+            extras = {}
+            del x
+            torch.cuda.empty_cache()
+
+            def timed(fn, reps):
+                fn(); fn(); torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    fn()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0) / reps
+
+            for tag, cfg, nfr in (("unet32_bf16_1080p_frames_per_s", dict(name="unet", base_channels=32, num_classes=3, enhance=True), 4),
+                                  ("unet32_pixelshuffle_bf16_1080p_frames_per_s", dict(name="unet", base_channels=32, num_classes=3, enhance=True, upsampler="pixelshuffle"), 4),
+                                  ("retinexnet_bf16_1080p_frames_per_s", dict(name="retinexnet"), 4)):
+                try:
+                    m2 = mon_amd.MODELS.build(seed=1, compute_dtype="bf16", **cfg).to(dev)
+                    xi = torch.rand(nfr, 3, H, W, device=dev)
+                    extras[tag] = round(nfr / timed(lambda: m2.forward({"image": xi}), 5), 1)
+                    del m2, xi
+                except Exception as e:                       # a side measurement must never take the headline line down
+                    extras[tag] = f"failed: {e}"[:200]
+                torch.cuda.empty_cache()
+            try:
+                m3 = mon_amd.MODELS.build(name="unet", base_channels=64, num_classes=3, enhance=True, seed=1).to(dev)
+                tr = mon_amd.Trainer(m3, optimizer={"name": "adam", "lr": 1e-4}, loss={"name": "l1_ssim_loss"}, gradient_clip_val=0.1)
+                tgt = torch.rand(2, 3, H, W, device=dev)
+                img = (tgt ** 2.2 * 0.4).contiguous()
+                extras["unet64_train_l1ssim_fp32_1080p_frames_per_s"] = round(2 / timed(lambda: tr.training_step({"image": img, "ref_image": tgt}), 2), 2)
+                del m3, tr, tgt, img
+            except Exception as e:
+                extras["unet64_train_l1ssim_fp32_1080p_frames_per_s"] = f"failed: {e}"[:200]
+            torch.cuda.empty_cache()
+
         line = {
             "metric": "enhanced_images_per_sec_1080p", "value": round(value, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -196,6 +234,8 @@ def main():
                        "parallelism": f"frames sharded over {world} GPU(s), no collective", "tflops_per_gpu": round(value / world * H * W * FLOP_PER_PX / 1e12, 1)},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,
         }
+        if extras is not None:
+            line["extras"] = extras
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
