@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(MConvParams p) {
 // image in L2, the next chunk's prefetched during the MFMAs), so LDS holds only the input tile -- twice: the LDS-DMA of chunk
 // ch+1 runs under the MFMAs of chunk ch, one barrier per chunk, two workgroups per CU.  Every pixel fragment read from LDS
 // (input row, column half, kx) feeds up to three MFMAs (ky = 0,1,2).
-template <typename T, int ACT, int NT>
+template <typename T, int ACT, int NT, int TH3>
 __device__ __forceinline__ void mconv3_epilogue(const MConvParams& p, ie_f32x4 (&acc)[NT], const float (&bv)[4], int n, int co0, int oy0, int ox0,
                                                 int r0, int kc, int l16) {
     const int co = co0 + kc * 4;
@@ -268,7 +268,7 @@ __device__ __forceinline__ void mconv3_epilogue(const MConvParams& p, ie_f32x4 (
     if constexpr (ACT == IE_ACT_RELU || ACT == IE_ACT_NONE) {
         // interior tile of a plain Conv(+BN)+ReLU layer -- nearly all of the work: no masks; per accumulator tile 2 packed adds,
         // 2 cvt_pk (+ 2 packed max), one store through a wave-uniform base pointer and a 32-bit lane offset
-        if (p.sub == 1 && full && !p.res && !p.clamp && !p.out_f32 && oy0 + TH <= p.Ho && ox0 + TW <= p.Wo) {
+        if (p.sub == 1 && full && !p.res && !p.clamp && !p.out_f32 && oy0 + TH3 <= p.Ho && ox0 + TW <= p.Wo) {
             const char* tile = (const char*)((T*)p.dst + (((size_t)n * p.Hs + oy0 + r0) * p.Ws + ox0) * p.Cout);
             const unsigned lane_off = (unsigned)((l16 * p.Cout + co) * (int)sizeof(T));
             const unsigned row_b = (unsigned)p.Ws * (unsigned)p.Cout * (unsigned)sizeof(T), half_b = 16u * (unsigned)p.Cout * (unsigned)sizeof(T);
@@ -350,17 +350,17 @@ __device__ __forceinline__ void mconv3_epilogue(const MConvParams& p, ie_f32x4 (
     }
 }
 
-template <typename T, int RW>
-__global__ __launch_bounds__(256, 2) void mconv3_kernel(MConvParams p) {
+template <typename T, int RW, int TH3>
+__global__ __launch_bounds__(256, TH3 == 16 ? 2 : 3) void mconv3_kernel(MConvParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using frag = typename ie_elem<T>::frag;
     typedef __attribute__((address_space(3))) void* lds_ptr;
     constexpr int CW = 4 / RW;                 // cout fragments per workgroup (= NF of the weight packing)
-    constexpr int R = TH / RW;                 // output rows per wave
+    constexpr int R = TH3 / RW;                // output rows per wave
     constexpr int NT = 2 * R;                  // accumulator tiles per wave
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cw = wave % CW, rw = wave / CW;
-    constexpr int TWH = TW + 2, THH = TH + 2, TPX = TWH * THH;
+    constexpr int TWH = TW + 2, THH = TH3 + 2, TPX = TWH * THH;
     constexpr int ND = ((TPX + 15) / 16 + 3) / 4 * 4;    // 1-KB DMA instructions per tile, padded so every wave issues ND/4
     constexpr unsigned BUF_B = ND * 1024;
     constexpr unsigned OOB = 0xFFFFFFF0u;
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256, 2) void mconv3_kernel(MConvParams p) {
         Tile t;
         t.ct = id % p.cout_tiles; id /= p.cout_tiles;
         const int tx = id % p.tiles_x; id /= p.tiles_x;
-        t.oy0 = (id % p.tiles_y) * TH; t.ox0 = tx * TW;
+        t.oy0 = (id % p.tiles_y) * TH3; t.ox0 = tx * TW;
         t.n = id / p.tiles_y;
         return t;
     };
@@ -534,11 +534,11 @@ __global__ __launch_bounds__(256, 2) void mconv3_kernel(MConvParams p) {
         }
         const int co0 = (cur.ct * CW + cw) * 16;
         switch (p.act) {
-        case IE_ACT_RELU: mconv3_epilogue<T, IE_ACT_RELU, NT>(p, acc, bv, cur.n, co0, cur.oy0, cur.ox0, r0, kc, l16); break;
-        case IE_ACT_LRELU: mconv3_epilogue<T, IE_ACT_LRELU, NT>(p, acc, bv, cur.n, co0, cur.oy0, cur.ox0, r0, kc, l16); break;
-        case IE_ACT_TANH: mconv3_epilogue<T, IE_ACT_TANH, NT>(p, acc, bv, cur.n, co0, cur.oy0, cur.ox0, r0, kc, l16); break;
-        case IE_ACT_SIGMOID: mconv3_epilogue<T, IE_ACT_SIGMOID, NT>(p, acc, bv, cur.n, co0, cur.oy0, cur.ox0, r0, kc, l16); break;
-        default: mconv3_epilogue<T, IE_ACT_NONE, NT>(p, acc, bv, cur.n, co0, cur.oy0, cur.ox0, r0, kc, l16); break;
+        case IE_ACT_RELU: mconv3_epilogue<T, IE_ACT_RELU, NT, TH3>(p, acc, bv, cur.n, co0, cur.oy0, cur.ox0, r0, kc, l16); break;
+        case IE_ACT_LRELU: mconv3_epilogue<T, IE_ACT_LRELU, NT, TH3>(p, acc, bv, cur.n, co0, cur.oy0, cur.ox0, r0, kc, l16); break;
+        case IE_ACT_TANH: mconv3_epilogue<T, IE_ACT_TANH, NT, TH3>(p, acc, bv, cur.n, co0, cur.oy0, cur.ox0, r0, kc, l16); break;
+        case IE_ACT_SIGMOID: mconv3_epilogue<T, IE_ACT_SIGMOID, NT, TH3>(p, acc, bv, cur.n, co0, cur.oy0, cur.ox0, r0, kc, l16); break;
+        default: mconv3_epilogue<T, IE_ACT_NONE, NT, TH3>(p, acc, bv, cur.n, co0, cur.oy0, cur.ox0, r0, kc, l16); break;
         }
         if (id == pos) MST(48);
         if (!has_next_tile) break;
@@ -686,14 +686,24 @@ IE_EXPORT int ie_mconv_nhwc(ie_mconv_desc* d, const void* const* srcs, const int
     static const int use_v1 = getenv("IE_MCONV_V1") ? atoi(getenv("IE_MCONV_V1")) : 0;     // A/B switch: single-buffered LDS-weights kernel
     size_t lds_bytes = lds;
     int slot;
+    int th3 = TH, wgs_per_cu = 2;
     if (k3 && !use_v1) {
+        // 64-cout tiles (one cout fragment per wave, 16-row tile = 128 accumulator VGPRs) leave room for only two workgroups per
+        // CU; an 8-row tile (64 accumulator VGPRs, 2 x 22 KB of LDS) runs three and overlaps the per-tile serial work better
+        static const int th_nf4 = getenv("IE_MCONV_TH") ? atoi(getenv("IE_MCONV_TH")) : 16;   // measured: 8-row tiles x 3 workgroups are ~7 % slower (582 vs 624 TFLOP/s on 64->64)
+        if (pl.nf == 4 && th_nf4 == 8) { th3 = 8; wgs_per_cu = 3; }
         switch (pl.nf) {
-        case 1: fn = h ? mconv3_kernel<_Float16, 4> : mconv3_kernel<__bf16, 4>; break;
-        case 2: fn = h ? mconv3_kernel<_Float16, 2> : mconv3_kernel<__bf16, 2>; break;
-        default: fn = h ? mconv3_kernel<_Float16, 1> : mconv3_kernel<__bf16, 1>; break;
+        case 1: fn = h ? mconv3_kernel<_Float16, 4, 16> : mconv3_kernel<__bf16, 4, 16>; break;
+        case 2: fn = h ? mconv3_kernel<_Float16, 2, 16> : mconv3_kernel<__bf16, 2, 16>; break;
+        default:
+            if (th3 == 8) fn = h ? mconv3_kernel<_Float16, 1, 8> : mconv3_kernel<__bf16, 1, 8>;
+            else fn = h ? mconv3_kernel<_Float16, 1, 16> : mconv3_kernel<__bf16, 1, 16>;
+            break;
         }
-        lds_bytes = 2 * (size_t)((((TH + 2) * (TW + 2) + 15) / 16 + 3) / 4 * 4) * 1024;
+        p.tiles_y = ie_cdiv(p.Ho, th3);
+        lds_bytes = 2 * (size_t)((((th3 + 2) * (TW + 2) + 15) / 16 + 3) / 4 * 4) * 1024;
         slot = 12 + (h ? 0 : 3) + (pl.nf == 1 ? 0 : (pl.nf == 2 ? 1 : 2));
+        if (th3 == 8) slot = 18 + (h ? 0 : 1);
     } else {
         switch (pl.nf * 2 + (k3 ? 1 : 0)) {
         case 2: fn = h ? mconv_kernel<_Float16, 1, false> : mconv_kernel<__bf16, 1, false>; break;
@@ -706,7 +716,7 @@ IE_EXPORT int ie_mconv_nhwc(ie_mconv_desc* d, const void* const* srcs, const int
         slot = (h ? 0 : 6) + (pl.nf == 1 ? 0 : (pl.nf == 2 ? 1 : 2)) * 2 + (k3 ? 1 : 0);
     }
     if (lds_bytes > 64 * 1024) {       // opt in to > 64 KB of dynamic LDS once per kernel
-        static bool granted[18] = {false};
+        static bool granted[20] = {false};
         if (!granted[slot]) {
             IE_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             granted[slot] = true;
@@ -714,7 +724,10 @@ IE_EXPORT int ie_mconv_nhwc(ie_mconv_desc* d, const void* const* srcs, const int
     }
     int grid = p.total_blocks;
     if (k3 && !use_v1) {                   // persistent: two workgroups per CU (LDS 2 x 80 KB), each walks its share of the tiles
-        static const int wg_cap = getenv("IE_MCONV_WGS") ? atoi(getenv("IE_MCONV_WGS")) : 512;
+        static const int wg_cap_env = getenv("IE_MCONV_WGS") ? atoi(getenv("IE_MCONV_WGS")) : 0;
+        const int wg_cap = wg_cap_env ? wg_cap_env : 256 * wgs_per_cu;
+        const long logical3 = (long)p.tiles_x * p.tiles_y * p.cout_tiles * d->N;
+        grid = (int)((logical3 + 7) / 8 * 8);
         if (grid > wg_cap) grid = wg_cap;
     }
     hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds_bytes, (hipStream_t)stream, p);
