@@ -363,7 +363,6 @@ __global__ __launch_bounds__(256, TH3 == 16 ? 2 : 3) void mconv3_kernel(MConvPar
     constexpr int TWH = TW + 2, THH = TH3 + 2, TPX = TWH * THH;
     constexpr int ND = ((TPX + 15) / 16 + 3) / 4 * 4;    // 1-KB DMA instructions per tile, padded so every wave issues ND/4
     constexpr unsigned BUF_B = ND * 1024;
-    constexpr unsigned OOB = 0xFFFFFFF0u;
     const int kc = lane >> 4, l16 = lane & 15;
     const int r0 = rw * R;
 
@@ -500,7 +499,8 @@ __global__ __launch_bounds__(256, TH3 == 16 ? 2 : 3) void mconv3_kernel(MConvPar
             for (int j = 0; j < 4; ++j) bv[j] = (p.bias && co + j < p.Cout) ? p.bias[co + j] : 0.f;
         }
         for (int ch = 0; ch < p.nchunks; ++ch) {
-            const int sb = (id == pos && ch < 6) ? ch * 8 : 56;
+            const int sb = (id == pos && ch < 6) ? ch * 8 : 56;      // stamp slot (diagnostic build)
+            (void)sb;
             MST(sb + 0);
             if (fresh) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // this wave's part of the tile (and the kx = 0 weights) has landed
