@@ -253,6 +253,86 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(MConvParams p) {
     }
 }
 
+// ---- thin inputs (one source of 8 channels: an RGB / RGB+max image carried as 8) ---------------------------------------
+// A 32-channel K chunk would be three quarters zeros.  Here K runs over (kx, channel): a K step of 32 = 4 neighbouring pixels
+// of an input row x 8 channels = 64 contiguous bytes of the LDS tile [row][col][8 ch] (16 bytes per pixel, no swizzle: a
+// fragment's 16 lanes read 256 contiguous bytes).  A kh x kw kernel costs kh * ceil(kw/4) MFMA steps instead of kh * kw
+// (9x9: 27 instead of 81; 3x3: 3 instead of 9).  Weights are staged one kernel row (ky) at a time.
+template <typename T, int NF>
+__global__ __launch_bounds__(256, 2) void mconv_thin_kernel(MConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using frag = typename ie_elem<T>::frag;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pb = blockIdx.x;
+    const int per_xcd = p.total_blocks >> 3;
+    int lb = (pb & 7) * per_xcd + (pb >> 3);
+    const int ct = lb % p.cout_tiles; lb /= p.cout_tiles;
+    const int tx = lb % p.tiles_x; lb /= p.tiles_x;
+    const int ty = lb % p.tiles_y;
+    const int n = lb / p.tiles_y;
+    if (n >= p.N) return;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int KXG = (p.kw + 3) >> 2;                          // groups of 4 taps along kx
+    const int TWH = TW + 4 * KXG - 1, THH = TH + p.kh - 1, TPX = TWH * THH;
+    const int ND = (TPX + 63) >> 6;                           // 1-KB DMA instructions (64 pixels of 16 bytes)
+    unsigned char* in_lds = smem;
+    unsigned char* w_lds = smem + (size_t)ND * 1024;
+    const int kc = lane >> 4, l16 = lane & 15;
+
+    ie_f32x4 acc[8][NF];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int f = 0; f < NF; ++f) acc[i][f] = ie_f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const size_t frame_b = (size_t)p.H * p.W * 8 * sizeof(T);
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.src[0] + (size_t)n * frame_b), 0, (int)frame_b, 0x00020000);
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    for (int d = wave; d < ND; d += 4) {                      // whole halo tile: lane = one pixel (16 bytes)
+        const int q = d * 64 + lane;
+        const int r = q / TWH, c = q - r * TWH;
+        int iy = oy0 + r - p.pad, ix = ox0 + c - p.pad;
+        bool ok = q < TPX;
+        if (p.pad_mode == IE_PAD_REPLICATE) { iy = min(max(iy, 0), p.H - 1); ix = min(max(ix, 0), p.W - 1); }
+        else ok = ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        const unsigned off = ok ? (unsigned)((iy * p.W + ix) * 8 * (int)sizeof(T)) : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(in_lds + d * 1024), 16, (int)off, 0, 0, 0);
+    }
+    const unsigned w_stage_bytes = (unsigned)KXG * 16 * NF * 64;
+    const unsigned char* wpk = (const unsigned char*)p.wpk + (size_t)ct * p.kh * w_stage_bytes;
+    for (int ky = 0; ky < p.kh; ++ky) {
+        if (ky > 0) __syncthreads();                          // previous row's weights have been read
+        const auto rw = __builtin_amdgcn_make_buffer_rsrc((void*)(wpk + (size_t)ky * w_stage_bytes), 0, (int)w_stage_bytes, 0x00020000);
+        for (int d = wave; d < KXG * NF; d += 4)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(w_lds + d * 1024), 16, d * 1024 + lane * 16, 0, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int g = 0; g < KXG; ++g) {
+            frag a[NF];
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const int row = (g * NF + f) * 16 + l16;
+                a[f] = *(const frag*)(w_lds + (size_t)row * 64 + ((kc ^ ((l16 >> 1) & 3)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int q = (wave * 4 + (i >> 1) + ky) * TWH + (i & 1) * 16 + l16 + g * 4 + kc;   // K quarter kc = pixel +kc
+                const frag b = *(const frag*)(in_lds + (size_t)q * 16);
+#pragma unroll
+                for (int f = 0; f < NF; ++f) acc[i][f] = ie_elem<T>::mfma16(a[f], b, acc[i][f]);
+            }
+        }
+    }
+    switch (p.act) {
+    case IE_ACT_RELU: mconv_epilogue<T, NF, IE_ACT_RELU>(p, acc, n, ct, oy0, ox0, wave, kc, l16); break;
+    case IE_ACT_LRELU: mconv_epilogue<T, NF, IE_ACT_LRELU>(p, acc, n, ct, oy0, ox0, wave, kc, l16); break;
+    case IE_ACT_TANH: mconv_epilogue<T, NF, IE_ACT_TANH>(p, acc, n, ct, oy0, ox0, wave, kc, l16); break;
+    case IE_ACT_SIGMOID: mconv_epilogue<T, NF, IE_ACT_SIGMOID>(p, acc, n, ct, oy0, ox0, wave, kc, l16); break;
+    default: mconv_epilogue<T, NF, IE_ACT_NONE>(p, acc, n, ct, oy0, ox0, wave, kc, l16); break;
+    }
+}
+
 // ---- 3x3, weights in registers, double-buffered input tile ---------------------------------------------------------
 // The workgroup's 4 waves are CW cout fragments x RW row groups (CW*RW = 4, CW = 16-cout fragments of the cout tile = NF of
 // the packing).  A wave keeps its 9 weight fragments of the current K chunk in registers (loaded straight from the packed
@@ -552,6 +632,7 @@ int pick_nf(int Cout) { return Cout > 32 ? 4 : (Cout > 16 ? 2 : 1); }
 
 struct Plan {
     int nf, cout_tiles, nchunks, taps, taps_stage, nstages;
+    int thin, kxg;               // thin: one 8-channel source, K = (4 kx taps x 8 channels) per step, one stage per kernel row
     unsigned char chunk_src[MAX_CHUNKS];
     unsigned short chunk_c0[MAX_CHUNKS];
     size_t stage_bytes, total_bytes;
@@ -573,6 +654,15 @@ int make_plan(const int* cs, int nsrc, int Cout, int kh, int kw, Plan* pl, const
         }
     }
     pl->taps = kh * kw;
+    static const int no_thin = getenv("IE_MCONV_NO_THIN") ? atoi(getenv("IE_MCONV_NO_THIN")) : 0;     // A/B switch (packing + kernel)
+    pl->thin = (nsrc == 1 && cs[0] == 8 && !no_thin) ? 1 : 0;
+    pl->kxg = (kw + 3) / 4;
+    if (pl->thin) {
+        pl->taps_stage = pl->kxg; pl->nstages = kh;
+        pl->stage_bytes = (size_t)pl->kxg * 16 * pl->nf * 64;
+        pl->total_bytes = (size_t)pl->cout_tiles * kh * pl->stage_bytes;
+        return IE_OK;
+    }
     pl->taps_stage = pl->taps <= 9 ? pl->taps : kw;          // all taps at once for <= 3x3, else one kernel row per stage
     pl->nstages = ie_cdiv(pl->taps, pl->taps_stage);
     pl->stage_bytes = (size_t)pl->taps_stage * 16 * pl->nf * 64;
@@ -611,6 +701,25 @@ IE_EXPORT int ie_mconv_pack_weights(const float* w_oihw_host, const int* channel
     for (int s = 0; s < nsrc; ++s) { cbase[s] = Cin; Cin += channels[s]; }
     std::vector<unsigned short> host(pl.total_bytes / 2, 0);
     const int rows = 16 * pl.nf;
+    if (pl.thin) {                                           // [ct][ky][kx group][row][k = kxo*8 + ci], rows swizzled like the LDS image
+        for (int ct = 0; ct < pl.cout_tiles; ++ct)
+            for (int ky = 0; ky < kh; ++ky)
+                for (int g = 0; g < pl.kxg; ++g)
+                    for (int r = 0; r < rows; ++r) {
+                        const int co = ct * rows + r;
+                        if (co >= Cout) continue;
+                        unsigned short* row = host.data() + ((((size_t)ct * kh + ky) * pl.kxg + g) * rows + r) * 32;
+                        const int sw = ((r & 15) >> 1) & 3;
+                        for (int k = 0; k < 32; ++k) {
+                            const int kx = g * 4 + (k >> 3), ci = k & 7;
+                            if (kx >= kw || ci >= Cin) continue;
+                            row[(((k >> 3) ^ sw) << 3) + (k & 7)] = f32_to_16(w_oihw_host[(((size_t)co * Cin + ci) * kh + ky) * kw + kx], dtype);
+                        }
+                    }
+        IE_HIP_CHECK(hipMemcpyAsync(dst_dev, host.data(), pl.total_bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+        IE_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+        return IE_OK;
+    }
     for (int ct = 0; ct < pl.cout_tiles; ++ct)
         for (int ch = 0; ch < pl.nchunks; ++ch) {
             const int s = pl.chunk_src[ch], c0 = pl.chunk_c0[ch];
@@ -687,7 +796,16 @@ IE_EXPORT int ie_mconv_nhwc(ie_mconv_desc* d, const void* const* srcs, const int
     size_t lds_bytes = lds;
     int slot;
     int th3 = TH, wgs_per_cu = 2;
-    if (k3 && !use_v1) {
+    if (pl.thin) {
+        switch (pl.nf) {
+        case 1: fn = h ? mconv_thin_kernel<_Float16, 1> : mconv_thin_kernel<__bf16, 1>; break;
+        case 2: fn = h ? mconv_thin_kernel<_Float16, 2> : mconv_thin_kernel<__bf16, 2>; break;
+        default: fn = h ? mconv_thin_kernel<_Float16, 4> : mconv_thin_kernel<__bf16, 4>; break;
+        }
+        const int twh = TW + 4 * pl.kxg - 1, thh = TH + d->kh - 1;
+        lds_bytes = (size_t)((twh * thh + 63) / 64) * 1024 + pl.stage_bytes;
+        slot = 20 + (h ? 0 : 3) + (pl.nf == 1 ? 0 : (pl.nf == 2 ? 1 : 2));
+    } else if (k3 && !use_v1) {
         // 64-cout tiles (one cout fragment per wave, 16-row tile = 128 accumulator VGPRs) leave room for only two workgroups per
         // CU; an 8-row tile (64 accumulator VGPRs, 2 x 22 KB of LDS) runs three and overlaps the per-tile serial work better
         static const int th_nf4 = getenv("IE_MCONV_TH") ? atoi(getenv("IE_MCONV_TH")) : 16;   // measured: 8-row tiles x 3 workgroups are ~7 % slower (582 vs 624 TFLOP/s on 64->64)
@@ -716,14 +834,14 @@ IE_EXPORT int ie_mconv_nhwc(ie_mconv_desc* d, const void* const* srcs, const int
         slot = (h ? 0 : 6) + (pl.nf == 1 ? 0 : (pl.nf == 2 ? 1 : 2)) * 2 + (k3 ? 1 : 0);
     }
     if (lds_bytes > 64 * 1024) {       // opt in to > 64 KB of dynamic LDS once per kernel
-        static bool granted[20] = {false};
+        static bool granted[26] = {false};
         if (!granted[slot]) {
             IE_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             granted[slot] = true;
         }
     }
     int grid = p.total_blocks;
-    if (k3 && !use_v1) {                   // persistent: two workgroups per CU (LDS 2 x 80 KB), each walks its share of the tiles
+    if (k3 && !use_v1 && !pl.thin) {     // persistent: two workgroups per CU (LDS 2 x 80 KB), each walks its share of the tiles
         static const int wg_cap_env = getenv("IE_MCONV_WGS") ? atoi(getenv("IE_MCONV_WGS")) : 0;
         const int wg_cap = wg_cap_env ? wg_cap_env : 256 * wgs_per_cu;
         const long logical3 = (long)p.tiles_x * p.tiles_y * p.cout_tiles * d->N;
