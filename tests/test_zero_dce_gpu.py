@@ -8,6 +8,8 @@ Tolerances (max |a-b| / max |b|, the 'relative fp32' measure of the north star):
 uint8 (save_image rule): f32 mode must differ from the reference in <= 0.1 % of bytes and by at
 most 1 LSB (an fp32 reordering can flip x*255+0.5 across an integer); f16/bf16 <= 1 / 2 LSB.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -176,3 +178,36 @@ def test_error_behaviour_on_gpu():
         mon_amd.ZeroDCE_RE(compute_dtype="int8")
     with pytest.raises(capi.IEError):
         mon_amd.ZeroDCE_RE(num_channels=16, seed=1).to("cuda").forward({"image": torch.rand(1, 3, 8, 8).cuda()})
+
+
+def test_predict_driver_png_roundtrip(tmp_path):
+    """predict.py:23-125 flow: files -> read_image -> infer (resize to /32 and back) -> save_image rule -> <stem>.png."""
+    import numpy as np
+    from PIL import Image
+    import torch.nn.functional as F
+    from mon_amd import image as ie_image
+    src = tmp_path / "lowlight"
+    src.mkdir()
+    g = torch.Generator().manual_seed(0)
+    frames = {}
+    for stem, (h, w) in (("a", (40, 56)), ("b", (33, 47))):
+        arr = (torch.rand(h, w, 3, generator=g) ** 2.2 * 90).to(torch.uint8).numpy()
+        Image.fromarray(arr).save(src / f"{stem}.png")
+        frames[stem] = arr
+    sd = o_zdce.init_state_dict(seed=2, gain=4.0)
+    torch.save(sd, tmp_path / "w.pt")
+    res = ie_image.predict({"name": "zero_dce_re", "weights": str(tmp_path / "w.pt"), "compute_dtype": "f32"}, src, tmp_path / "out")
+    assert [os.path.basename(f) for f in res["files"]] == ["a.png", "b.png"] and res["avg_time"] > 0
+    for stem, arr in frames.items():
+        x = torch.from_numpy(arr).permute(2, 0, 1)[None].float() / 255.0
+        h, w = x.shape[2:]
+        hp, wp = (h + 31) // 32 * 32, (w + 31) // 32 * 32
+        ref = o_zdce.forward(sd, F.interpolate(x, size=(hp, wp), mode="bilinear", align_corners=False))["enhanced"]
+        ref = F.interpolate(ref, size=(h, w), mode="bilinear", align_corners=False)
+        want = o_zdce.to_uint8_save_image(ref)[0].numpy()
+        got = np.asarray(Image.open(os.path.join(res["save_dir"], f"{stem}.png")))
+        assert got.shape == want.shape
+        assert int(np.abs(got.astype(int) - want.astype(int)).max()) <= 1      # resize rounding at .5 boundaries
+        assert float((got == want).mean()) > 0.99
+    with pytest.raises(ValueError):
+        ie_image.list_images(tmp_path / "nope")
