@@ -4,6 +4,9 @@
   ssim_loss   SSIMLoss   src/mon/nn/loss/image.py:834-866         1 - custom_ssim(...)  (loss_weight is NOT applied, as in
                                                                     the reference's forward); CustomSSIM: nn/metric/image.py:316-346
   l1_ssim_loss  L1SSIMLoss  engine composite for BASELINE config 5: l1_weight * L1 + ssim_weight * SSIMLoss
+  zero_dce_loss ZeroDCELoss src/mon/vision/enhance/llie/zero_dce/zero_dce.py:34-79: spa + 10 exp + 5 col + 200 tvA (zero-reference;
+                            SpatialConsistencyLoss nn/loss/image.py:905-1270, ExposureControlLoss :534-568, ColorConstancyLoss
+                            :191-217, TotalVariationLoss :1355-1392); called as loss(input, adjust, enhance)
 
 Each loss is called as ``loss(input, target)`` and returns a ``LossResult``: ``float(result)`` is the value (one device
 sync); ``result.backward_into(grad)`` enqueues d(loss)/d(input) into ``grad`` (same memory layout as ``input``).
@@ -35,8 +38,9 @@ def _same_layout(input: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
 
 
 class LossResult:
-    def __init__(self, value_fn, backward_fn):
+    def __init__(self, value_fn, backward_fn, seed_fn=None):
         self._value_fn, self._backward_fn, self._value = value_fn, backward_fn, None
+        self.seed_fn = seed_fn        # multi-input losses: seed_fn(tape, scale) puts the gradients of their inputs on the tape
 
     def __float__(self):
         if self._value is None:
@@ -142,3 +146,65 @@ class L1SSIMLoss(Loss):
             a.backward_into(grad, accumulate, scale * self.loss_weight * self.l1_weight)
             b.backward_into(grad, True, scale * self.loss_weight * self.ssim_weight)
         return LossResult(lambda: self.loss_weight * (self.l1_weight * float(a) + self.ssim_weight * float(b)), backward)
+
+
+@LOSSES.register(name="zero_dce_loss")
+class ZeroDCELoss(Loss):
+    """zero_dce.py:34-79.  ``input``/``enhance``: NCHW fp32 (N,3,H,W); ``adjust``: the curve maps, logical (N,3*iters,H,W) in
+    channels_last memory (NHWC), as the training graph produces them."""
+
+    zero_reference = True
+
+    def __init__(self, spa_weight: float = 1.0, exp_patch_size: int = 16, exp_mean_val: float = 0.6, exp_weight: float = 10.0,
+                 col_weight: float = 5.0, tva_weight: float = 200.0, reduction: str = "mean", loss_weight: float = 1.0):
+        super().__init__(loss_weight, reduction)
+        if exp_patch_size != 16 or reduction != "mean":
+            raise capi.IEError("zero_dce_loss: the kernels implement the reference defaults (exposure patch 16, reduction 'mean')")
+        self.spa_weight, self.exp_weight, self.col_weight, self.tva_weight, self.exp_mean_val = spa_weight, exp_weight, col_weight, tva_weight, exp_mean_val
+
+    def forward(self, input: torch.Tensor, adjust: torch.Tensor, enhance: torch.Tensor) -> LossResult:
+        for t in (input, enhance):
+            if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 4 or t.shape[1] != 3 or not t.is_contiguous():
+                raise capi.IEError("zero_dce_loss: `input` and `enhance` must be contiguous cuda float32 (N,3,H,W) tensors")
+        if tuple(input.shape) != tuple(enhance.shape):
+            raise ValueError(f"`input` and `enhance` must have the same dimensions, but got {tuple(input.shape)} and {tuple(enhance.shape)}.")
+        if not adjust.is_cuda or adjust.dtype != torch.float32 or not adjust.is_contiguous(memory_format=torch.channels_last):
+            raise capi.IEError("zero_dce_loss: `adjust` must be a channels_last cuda float32 tensor")
+        n, _, h, w = enhance.shape
+        c = adjust.shape[1]
+        L = capi.lib()
+        sums = torch.empty(3 + 3 * n, device=enhance.device, dtype=torch.float64)
+        tv = torch.empty(2, device=enhance.device, dtype=torch.float64)
+        ws = torch.empty(L.ie_zref_workspace_floats(n, h, w), device=enhance.device, dtype=torch.float32)
+        g_enh = torch.empty_like(enhance)
+        g_adj = torch.empty_like(adjust, memory_format=torch.channels_last)
+        k = self.loss_weight
+        with torch.cuda.device(enhance.device):
+            capi.check(L.ie_zref_image_losses_f32(capi.ptr(enhance), capi.ptr(input), n, h, w, self.exp_mean_val, k * self.spa_weight,
+                                                  k * self.exp_weight, k * self.col_weight, capi.ptr(sums), capi.ptr(ws), capi.ptr(g_enh), 0,
+                                                  capi.current_stream()), "ie_zref_image_losses_f32")
+            capi.check(L.ie_tv_loss_nhwc_f32(capi.ptr(adjust), n, h, w, c, k * self.tva_weight, capi.ptr(tv), capi.ptr(g_adj), 0,
+                                             capi.current_stream()), "ie_tv_loss_nhwc_f32")
+
+        def terms():
+            s, t = sums[:3].cpu(), tv.cpu()
+            return {"spa": float(s[0]) / (n * (h // 4) * (w // 4)), "exp": float(s[1]) / (n * (h // 16) * (w // 16)), "col": float(s[2]) / n,
+                    "tva": 2.0 * (float(t[0]) / (c * (h - 1) * w) + float(t[1]) / (c * h * (w - 1))) / n}
+
+        def value():
+            t = terms()
+            self.last_terms = t
+            return k * (self.spa_weight * t["spa"] + self.exp_weight * t["exp"] + self.col_weight * t["col"] + self.tva_weight * t["tva"])
+
+        def seed(tape, scale=1.0):
+            if scale != 1.0:
+                raise capi.IEError("zero_dce_loss: gradient scaling is folded into loss_weight")
+            tape.seed(enhance, g_enh)
+            tape.seed(adjust, g_adj)
+
+        def backward(grad, accumulate, scale):
+            raise capi.IEError("zero_dce_loss has two differentiable inputs: use result.seed_fn(tape)")
+        return LossResult(value, backward, seed)
+
+    def __call__(self, input, adjust, enhance):
+        return self.forward(input, adjust, enhance)

@@ -250,6 +250,29 @@ def t_clamp(tape, x, lo, hi):
     return y
 
 
+def t_curve(tape, image_nchw, adjust, iters):
+    """LE curve (zero_dce.py:186-188): image NCHW fp32 (no gradient) + curve maps NHWC -> enhanced NCHW fp32."""
+    n, _, h, w = image_nchw.shape
+    cp = int(adjust.shape[1])
+    y = torch.empty_like(image_nchw)
+    L = capi.lib()
+    with torch.cuda.device(image_nchw.device):
+        capi.check(L.ie_le_curve(capi.ptr(image_nchw), capi.ptr(adjust), cp, capi.ptr(y), n, h, w, iters, capi.current_stream()), "ie_le_curve")
+
+    def bwd():
+        g = tape.grad(y)
+        if g is None:
+            return
+        buf, acc = tape.slot(adjust)
+        if buf is not None:
+            with torch.cuda.device(g.device):
+                capi.check(L.ie_le_curve_backward(capi.ptr(image_nchw), capi.ptr(adjust), cp, capi.ptr(g), capi.ptr(buf), n, h, w, iters, int(acc),
+                                                  capi.current_stream()), "ie_le_curve_backward")
+        tape.release(y)
+    tape.record(bwd)
+    return y
+
+
 # ---- trainer -------------------------------------------------------------------------------------------------------------
 class Trainer:
     """One-model fit driver: ``training_step(batch)`` = forward_loss + backward + all-reduce + clip + Adam.
@@ -275,7 +298,9 @@ class Trainer:
         self.clip = float(gradient_clip_val) if gradient_clip_val else 0.0
         if isinstance(loss, dict):
             loss = LOSSES.build(config=loss)
-        self.loss = loss if loss is not None else LOSSES.build(name="l1_ssim_loss")
+        from .globals_ import Scheme
+        zero_ref = Scheme.ZERO_REFERENCE in getattr(model, "schemes", [])
+        self.loss = loss if loss is not None else LOSSES.build(name="zero_dce_loss" if zero_ref else "l1_ssim_loss")
         if not isinstance(self.loss, Loss):
             raise TypeError("`loss` must be a mon_amd.losses.Loss or its config dict")
         self.group = process_group
@@ -303,19 +328,29 @@ class Trainer:
         x = ops.to_nhwc(datapoint["image"].to(self.device, torch.float32))
         tape = tape or Tape()
         tape.no_grad(x)
-        pred = m.forward_train(x, self.store, tape)
-        outputs = OrderedDict(enhanced=pred)
-        m.assert_outputs(outputs)
-        target = datapoint.get("ref_image")
-        outputs["loss"] = self.loss(pred, target.to(self.device, torch.float32))
+        res = m.forward_train(x, self.store, tape)
+        if isinstance(res, dict):                 # zero-reference models: loss(input, adjust, enhance) (zero_dce.py:160-171)
+            outputs = OrderedDict(res)
+            m.assert_outputs(outputs)
+            image = outputs.pop("_image")
+            adjust = outputs.pop("adjust")        # zero_dce.py:168: the loss consumes it, the step output does not carry it
+            outputs["loss"] = self.loss(image, adjust, outputs["enhanced"])
+        else:
+            outputs = OrderedDict(enhanced=res)
+            m.assert_outputs(outputs)
+            target = datapoint.get("ref_image")
+            outputs["loss"] = self.loss(res, target.to(self.device, torch.float32))
         outputs["_tape"] = tape
         return outputs
 
     def backward(self, outputs: dict):
         tape, pred, loss = outputs["_tape"], outputs["enhanced"], outputs["loss"]
-        g = torch.empty_like(pred, memory_format=CL)
-        loss.backward_into(g, False, 1.0)
-        tape.seed(pred, g)
+        if loss.seed_fn is not None:
+            loss.seed_fn(tape)
+        else:
+            g = torch.empty_like(pred, memory_format=CL)
+            loss.backward_into(g, False, 1.0)
+            tape.seed(pred, g)
         tape.backward()
 
     def optimizer_step(self):

@@ -173,6 +173,30 @@ class ZeroDCE_RE(ImageEnhancementModel):
         outputs["enhanced"] = res["enhanced"]
         return outputs
 
+    def _require_cuda(self):
+        if self.device.type != "cuda":
+            raise capi.IEError(f"{self.__class__.__name__} runs on the HIP device only (model.device = {self.device}); call .to('cuda').")
+
+    def forward_train(self, x, store, tape):
+        """Training graph (zero_dce.py:173-191) on the fp32 building blocks with saved activations: the fused matrix-core plan
+        keeps x1/x4/x6 in LDS and cannot be differentiated, so training runs the layers one by one (the parity-grade fp32
+        path); returns ``adjust`` (NHWC), ``enhanced`` (NCHW, last) and the NCHW image for the zero-reference loss."""
+        from . import ops, train as T
+
+        def conv(k, srcs, act):
+            name = f"e_conv{k}"
+            return T.t_conv(tape, srcs, store.conv(name), *store.conv_grads(name), act=act)
+        x1 = conv(1, [x], "relu")
+        x2 = conv(2, [x1], "relu")
+        x3 = conv(3, [x2], "relu")
+        x4 = conv(4, [x3], "relu")
+        x5 = conv(5, [x3, x4], "relu")
+        x6 = conv(6, [x2, x5], "relu")
+        xr = conv(7, [x1, x6], "tanh")
+        image = ops.to_nchw(x)
+        enhanced = T.t_curve(tape, image, xr, self.num_iters)
+        return {"adjust": xr, "enhanced": enhanced, "_image": image}
+
     def feature(self, idx: int) -> torch.Tensor:
         """Intermediate x{idx} (1..6) of the last forward as NCHW fp32 (unit parity / debugging)."""
         plan = self._ensure_plan()

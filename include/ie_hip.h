@@ -246,6 +246,26 @@ int ie_adam_step_f32(float* param_dev, const float* grad_dev, float* exp_avg_dev
                      float beta1, float beta2, float eps, float weight_decay, float grad_scale, const double* sumsq_dev,
                      float max_norm, void* stream);
 
+/* ---- zero-reference training of Zero-DCE: the losses of zero_dce.py:34-79 and the LE-curve backward --------- */
+/* floats of scratch ie_zref_image_losses_f32 needs for an (N,3,H,W) batch. */
+size_t ie_zref_workspace_floats(int N, int H, int W);
+/* SpatialConsistencyLoss(num_regions=4, patch 4) (nn/loss/image.py:905-1270), ExposureControlLoss(patch 16, mean exp_mean)
+ * (:534-568) and ColorConstancyLoss (:191-217) of `enhanced` against `image`, both NCHW fp32 (N,3,H,W), H,W >= 16.
+ * sums_dev (>= 3 + 3N doubles): [0] = sum over pooled cells of the spatial term (mean = /(N*(H/4)*(W/4))), [1] = sum of the
+ * exposure term (/(N*(H/16)*(W/16))), [2] = sum over frames of the colour term (/N).  grad_enhanced_dev (may be NULL)
+ * (+)= d(w_spa*L_spa + w_exp*L_exp + w_col*L_col)/d enhanced. */
+int ie_zref_image_losses_f32(const float* enhanced_dev, const float* image_dev, int N, int H, int W, float exp_mean, float w_spa,
+                             float w_exp, float w_col, double* sums_dev, float* ws_dev, float* grad_enhanced_dev, int accumulate,
+                             void* stream);
+/* TotalVariationLoss (nn/loss/image.py:1355-1392) on NHWC fp32 maps (the 24 curve maps): sums_dev[0] / [1] = sums of squared
+ * vertical / horizontal differences; loss = weight * 2 * (s0/(C*(H-1)*W) + s1/(C*H*(W-1))) / N; grad_dev (may be NULL). */
+int ie_tv_loss_nhwc_f32(const float* a_dev, int N, int H, int W, int C, float weight, double* sums_dev, float* grad_dev, int accumulate,
+                        void* stream);
+/* Backward of ie_le_curve with respect to the curve maps: grad_adjust (NHWC, Cp channels) (+)= d enhanced / d adjust applied to
+ * grad_enhanced (NCHW).  The image receives no gradient (it is the network input). */
+int ie_le_curve_backward(const float* img_dev, const float* adjust_nhwc_dev, int Cp, const float* grad_enhanced_dev,
+                         float* grad_adjust_nhwc_dev, int N, int H, int W, int iters, int accumulate, void* stream);
+
 /* ---- LE curve (zero_dce.py:186-188) ------------------------------------ */
 /* y <- y + r_i (y^2 - y), i < iters; img NCHW fp32 (N,3,H,W); adjust NHWC fp32
  * with Cp channels (first 3*iters used, already tanh'ed; 3 <= Cp < 3*iters: one

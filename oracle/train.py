@@ -106,3 +106,57 @@ def training_steps(state_dict: dict, batches, forward_train, loss_fn, lr=1e-4, b
     final = {k: v.detach().clone() for k, v in params.items()}
     final.update({k: v.clone() for k, v in buffers.items()})
     return log, final
+
+
+# ---- Zero-DCE zero-reference training (zero_dce.py:34-79, 160-191) ------------------------------------------------------------
+def spatial_consistency_loss(input, target, patch: int = 4):
+    """nn/loss/image.py:905-1270 with num_regions = 4: contrasts of the pooled channel means against the 4 neighbours
+    (conv2d with the +1/-1 kernels, zero padding 1), squared difference between the two images, mean."""
+    org, enh = F.avg_pool2d(input.mean(1, keepdim=True), patch), F.avg_pool2d(target.mean(1, keepdim=True), patch)
+    k = torch.zeros(4, 1, 3, 3, dtype=input.dtype)
+    k[:, 0, 1, 1] = 1
+    k[0, 0, 1, 0] = -1; k[1, 0, 1, 2] = -1; k[2, 0, 0, 1] = -1; k[3, 0, 2, 1] = -1          # left, right, up, down
+    d = F.conv2d(org, k, padding=1) - F.conv2d(enh, k, padding=1)
+    return (d ** 2).sum(1, keepdim=True).mean()
+
+
+def exposure_control_loss(input, patch: int = 16, mean_val: float = 0.6):
+    """nn/loss/image.py:534-568."""
+    return ((F.avg_pool2d(input.mean(1, keepdim=True), patch) - mean_val) ** 2).mean()
+
+
+def color_constancy_loss(input):
+    """nn/loss/image.py:191-217 (d_* are already squared differences, squared again under the root)."""
+    m = input.mean((2, 3), keepdim=True)
+    mr, mg, mb = torch.split(m, 1, dim=1)
+    drg, drb, dgb = (mr - mg) ** 2, (mr - mb) ** 2, (mb - mg) ** 2
+    return torch.pow(drg ** 2 + drb ** 2 + dgb ** 2, 0.5).mean()
+
+
+def total_variation_loss(x):
+    """nn/loss/image.py:1355-1392."""
+    b, c, h, w = x.shape
+    count_h, count_w = c * (h - 1) * w, c * h * (w - 1)
+    h_tv = ((x[:, :, 1:, :] - x[:, :, :h - 1, :]) ** 2).sum()
+    w_tv = ((x[:, :, :, 1:] - x[:, :, :, :w - 1]) ** 2).sum()
+    return 2 * (h_tv / count_h + w_tv / count_w) / b
+
+
+def zero_dce_loss(input, adjust, enhance, spa_weight=1.0, exp_weight=10.0, col_weight=5.0, tva_weight=200.0, exp_mean_val=0.6):
+    """zero_dce.py:65-79: spa(input=enhance, target=input) + exp(enhance) + col(enhance) + tva(adjust)."""
+    return (spa_weight * spatial_consistency_loss(enhance, input) + exp_weight * exposure_control_loss(enhance, 16, exp_mean_val)
+            + col_weight * color_constancy_loss(enhance) + tva_weight * total_variation_loss(adjust))
+
+
+def zero_dce_forward_train(p: dict, buffers: dict, x, num_iters: int = 8):
+    """zero_dce.py:173-191; returns (adjust, enhanced)."""
+    c = lambda k, t: F.conv2d(t, p[f"e_conv{k}.weight"], p[f"e_conv{k}.bias"], padding=1)
+    x1 = F.relu(c(1, x)); x2 = F.relu(c(2, x1)); x3 = F.relu(c(3, x2)); x4 = F.relu(c(4, x3))
+    x5 = F.relu(c(5, torch.cat([x3, x4], 1)))
+    x6 = F.relu(c(6, torch.cat([x2, x5], 1)))
+    xr = torch.tanh(c(7, torch.cat([x1, x6], 1)))
+    y = x
+    for i in range(num_iters):
+        r = xr[:, 3 * i:3 * i + 3]
+        y = y + r * (torch.pow(y, 2) - y)
+    return xr, y
