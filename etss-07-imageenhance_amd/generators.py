@@ -345,6 +345,46 @@ class LLUnetpp_RE(_GraphModel):
         x2 = c([x1, x12], f"{b}.conv2", act="lrelu", slope=0.2, valid=v)
         return c(x2, f"{b}.conv3", act="lrelu", slope=0.2, residual=x23)
 
+    def forward_train(self, x, store, tape):
+        """Training graph of llunetpp.py:97-137, 218-243 on the fp32 taped ops (instance statistics are per sample in training
+        and in inference alike).  Returns the clamped NHWC prediction; the reference's own loss needs a VGG-19 that cannot be
+        fetched offline, so the trainer pairs it with L1 / SSIM."""
+        from . import train as T
+        if x.shape[2] % 16 or x.shape[3] % 16:
+            raise ValueError(f"LLUnet++ needs H and W divisible by 16 (got {x.shape[2]}x{x.shape[3]}).")
+        g = store.grads
+
+        def conv(name, srcs, pad=1, act="none"):
+            return T.t_conv(tape, srcs, store.conv(name), *store.conv_grads(name), pad=pad, act=act, slope=0.2)
+
+        def block(b, srcs):
+            x12 = conv(f"{b}.conv1_2", srcs, pad=0)
+            x1 = conv(f"{b}.conv1", srcs)
+            x1 = T.t_norm(tape, x1, store.view(f"{b}.norm1.weight"), store.view(f"{b}.norm1.bias"), store.view(f"{b}.norm1.weight", g),
+                          store.view(f"{b}.norm1.bias", g), per_sample=True, eps=1e-5, act="lrelu", slope=0.2)
+            x23 = conv(f"{b}.conv2_3", [x1, x12], pad=0)
+            x2 = conv(f"{b}.conv2", [x1, x12], act="lrelu")
+            return T.t_add(tape, conv(f"{b}.conv3", [x2], act="lrelu"), x23)
+
+        pool = lambda t: T.t_maxpool(tape, t)
+        up = lambda t: T.t_resize(tape, t, (t.shape[2] * 2, t.shape[3] * 2), "bilinear_align")
+        x0_0 = block("conv0_0", [x])
+        x1_0 = block("conv1_0", [pool(x0_0)])
+        x0_1 = block("conv0_1", [x0_0, up(x1_0)])
+        x2_0 = block("conv2_0", [pool(x1_0)])
+        x1_1 = block("conv1_1", [x1_0, up(x2_0)])
+        x0_2 = block("conv0_2", [x0_0, x0_1, up(x1_1)])
+        x3_0 = block("conv3_0", [pool(x2_0)])
+        x2_1 = block("conv2_1", [x2_0, up(x3_0)])
+        x1_2 = block("conv1_2", [x1_0, x1_1, up(x2_1)])
+        x0_3 = block("conv0_3", [x0_0, x0_1, x0_2, up(x1_2)])
+        x4_0 = block("conv4_0", [pool(x3_0)])
+        x3_1 = block("conv3_1", [x3_0, up(x4_0)])
+        x2_2 = block("conv2_2", [x2_0, x2_1, up(x3_1)])
+        x1_3 = block("conv1_3", [x1_0, x1_1, x1_2, up(x2_2)])
+        x0_4 = block("conv0_4", [x0_0, x0_1, x0_2, x0_3, up(x1_3)])
+        return T.t_clamp(tape, conv("final", [x0_4], pad=0), 0.0, 1.0)
+
     def forward(self, datapoint: dict, *args, **kwargs) -> dict:
         x = self._input_any(datapoint)
         if x.shape[2] % 16 or x.shape[3] % 16:

@@ -250,6 +250,28 @@ def t_clamp(tape, x, lo, hi):
     return y
 
 
+def t_add(tape, a, b):
+    """a + b (residual connection): the gradient goes to both operands unchanged."""
+    y = ops.add(a, b)
+
+    def bwd():
+        g = tape.grad(y)
+        if g is None:
+            return
+        for t in (a, b):
+            if tape.is_no_grad(t):
+                continue
+            if tape.grad(t) is not None:
+                _accumulate(tape.grad(t), g)
+            elif t is a and not tape.is_no_grad(b) and tape.grad(b) is None:
+                tape.seed(t, g.clone(memory_format=torch.preserve_format))   # the other operand will own `g` itself
+            else:
+                tape.seed(t, g)
+        tape.release(y)
+    tape.record(bwd)
+    return y
+
+
 def t_curve(tape, image_nchw, adjust, iters):
     """LE curve (zero_dce.py:186-188): image NCHW fp32 (no gradient) + curve maps NHWC -> enhanced NCHW fp32."""
     n, _, h, w = image_nchw.shape
