@@ -90,101 +90,149 @@ __global__ __launch_bounds__(256) void convn_direct_kernel(ConvNParams p) {
 // Workgroup = 64 consecutive output pixels of one frame x 64 output channels; thread = 4 pixels x 4 channels; K = (tap, 16
 // input channels of one source) staged through LDS: X tile [64 px][16 ci], W tile [16 ci][64 co].  16 FMAs per pair of
 // ds_read_b128 -- about 3x the direct kernel on the 32..1024-channel layers of the U-Nets (same arithmetic, fp32 FMA).
-constexpr int TP = 64, TC = 64, TK = 16;
+constexpr int TK = 16;
+// PT x CT outputs per thread (pixels x couts): the workgroup tile is 16*PT pixels x 16*CT couts.  4x4 reads 2 ds_read_b128 per
+// 16 FMAs; 8x8 reads 4 per 64, halving the LDS traffic per FLOP (the kernel is LDS-bound, not FMA-bound).
+template <int PT, int CT>
 __global__ __launch_bounds__(256) void convn_tiled_kernel(ConvNParams p) {
+    constexpr int TP = 16 * PT, TC = 16 * CT, NLP = PT / 4, NLW = CT / 4;
     __shared__ float xs[TP][TK + 4];
     __shared__ float wsh[TK][TC + 4];
     const int t = threadIdx.x;
     const int n = blockIdx.z;
     const int pix0 = blockIdx.x * TP, co_t = blockIdx.y * TC;
     const int npix = p.Ho * p.Wo;
-    // loader roles
-    const int lp = t >> 2, lc = (t & 3) * 4;            // X: pixel, first of 4 channels of the chunk
-    const int wk = t >> 4, wc = (t & 15) * 4;           // W: chunk row (input channel), first of 4 output channels
-    const int lpix = pix0 + lp;
-    const bool lp_live = lpix < npix;
-    const int lho = lp_live ? lpix / p.Wo : 0, lwo = lp_live ? lpix % p.Wo : 0;
-    // compute roles
-    const int tpx = (t >> 4) * 4, tco = (t & 15) * 4;
-    float acc[4][4];
+    const int lc = (t & 3) * 4;                         // X loader: first of 4 channels of the chunk; pixels (t >> 2) + 64 i
+    const int wk = t >> 4, wc = (t & 15) * 4;           // W loader: chunk row (input channel); couts wc + 64 i
+    int lho[NLP], lwo[NLP];
+    bool llive[NLP];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int i = 0; i < NLP; ++i) {
+        const int lpix = pix0 + (t >> 2) + 64 * i;
+        llive[i] = lpix < npix;
+        lho[i] = llive[i] ? lpix / p.Wo : 0;
+        lwo[i] = llive[i] ? lpix % p.Wo : 0;
+    }
+    const int tpx = (t >> 4) * PT, tco = (t & 15) * 4;   // thread's pixels tpx..tpx+PT-1; couts tco + 64 j + {0..3}
+    ie_f32x2 acc[PT][NLW][2];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
+    for (int a = 0; a < PT; ++a)
+#pragma unroll
+        for (int j = 0; j < NLW; ++j) { acc[a][j][0] = ie_f32x2{0.f, 0.f}; acc[a][j][1] = ie_f32x2{0.f, 0.f}; }
     const bool vec_w = (p.w_ld & 3) == 0;
-    for (int i = 0; i < p.kh; ++i)
-        for (int j = 0; j < p.kw; ++j) {
-            int hi = lho * p.stride + i - p.pad, wi = lwo * p.stride + j - p.pad;
-            bool inb = lp_live;
+    // K steps = (tap, source, 16-channel chunk), flattened so that the global loads of step k+1 are issued before the FMAs of
+    // step k (register double buffering): without it every step exposes a full global-load latency between two barriers.
+    int ti = 0, tj = 0, ts = 0, tc0 = 0, cbase = 0;     // iterator state of the step being LOADED
+    size_t ipix[NLP];
+    bool inb[NLP];
+    auto set_tap = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < NLP; ++u) {
+            int hi = lho[u] * p.stride + ti - p.pad, wi = lwo[u] * p.stride + tj - p.pad;
+            inb[u] = llive[u];
             if (p.pad_mode == IE_PAD_REPLICATE) { hi = min(max(hi, 0), p.H - 1); wi = min(max(wi, 0), p.W - 1); }
-            else inb = inb && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
-            const size_t ipix = ((size_t)n * p.H + (inb ? hi : 0)) * p.W + (inb ? wi : 0);
-            const float* wtap = p.w + (size_t)(i * p.kw + j) * p.Cin * p.w_ld;
-            int cbase = 0;
-            for (int s = 0; s < p.nsrc; ++s) {
-                const int Cs = p.cs[s];
-                const float* sp = p.src[s] + ipix * Cs;
-                for (int c0 = 0; c0 < Cs; c0 += TK) {
-                    ie_f32x4 vx = {0.f, 0.f, 0.f, 0.f}, vw = {0.f, 0.f, 0.f, 0.f};
-                    if (inb) {
-                        const float* q = sp + c0 + lc;
-                        if ((Cs & 3) == 0 && c0 + lc + 3 < Cs) vx = *(const ie_f32x4*)q;
-                        else
+            else inb[u] = inb[u] && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+            ipix[u] = ((size_t)n * p.H + (inb[u] ? hi : 0)) * p.W + (inb[u] ? wi : 0);
+        }
+    };
+    ie_f32x4 vx[NLP], vw[NLW];
+    auto load_step = [&]() __attribute__((always_inline)) {
+        const int Cs = p.cs[ts];
+        const float* wtap = p.w + (size_t)(ti * p.kw + tj) * p.Cin * p.w_ld;
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) if (c0 + lc + k < Cs) vx[k] = q[k];
-                    }
-                    if (c0 + wk < Cs) {
-                        const float* q = wtap + (size_t)(cbase + c0 + wk) * p.w_ld + co_t + wc;
-                        if (vec_w && co_t + wc + 3 < p.Cout) vw = *(const ie_f32x4*)q;
-                        else
+        for (int u = 0; u < NLP; ++u) {
+            vx[u] = ie_f32x4{0.f, 0.f, 0.f, 0.f};
+            if (inb[u]) {
+                const float* q = p.src[ts] + ipix[u] * Cs + tc0 + lc;
+                if ((Cs & 3) == 0 && tc0 + lc + 3 < Cs) vx[u] = *(const ie_f32x4*)q;
+                else
 #pragma unroll
-                            for (int k = 0; k < 4; ++k) if (co_t + wc + k < p.Cout) vw[k] = q[k];
-                    }
-                    __syncthreads();
-                    *(ie_f32x4*)&xs[lp][lc] = vx;
-                    *(ie_f32x4*)&wsh[wk][wc] = vw;
-                    __syncthreads();
-#pragma unroll
-                    for (int kk = 0; kk < TK; kk += 4) {
-                        ie_f32x4 a[4];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) a[q] = *(const ie_f32x4*)&xs[tpx + q][kk];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const ie_f32x4 b = *(const ie_f32x4*)&wsh[kk + r][tco];
-#pragma unroll
-                            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                                for (int c = 0; c < 4; ++c) acc[q][c] = fmaf(a[q][r], b[c], acc[q][c]);
-                        }
-                    }
-                }
-                cbase += Cs;
+                    for (int k = 0; k < 4; ++k) if (tc0 + lc + k < Cs) vx[u][k] = q[k];
             }
         }
-    const int co = co_t + tco;
-    if (co >= p.Cout) return;
-    const bool full = ((p.Cout & 3) == 0) && co + 3 < p.Cout;
-    float bv[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) bv[c] = (p.bias && co + c < p.Cout) ? p.bias[co + c] : 0.f;
+        for (int u = 0; u < NLW; ++u) {
+            vw[u] = ie_f32x4{0.f, 0.f, 0.f, 0.f};
+            const int co = co_t + wc + 64 * u;
+            if (tc0 + wk < Cs) {
+                const float* q = wtap + (size_t)(cbase + tc0 + wk) * p.w_ld + co;
+                if (vec_w && co + 3 < p.Cout) vw[u] = *(const ie_f32x4*)q;
+                else
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int pix = pix0 + tpx + q;
-        if (pix >= npix) continue;
-        const size_t ob = ((size_t)n * npix + pix) * p.Cout + co;
-        float v[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            v[c] = act_f(acc[q][c] + bv[c], p.act, p.slope);
-            if (p.res && co + c < p.Cout) v[c] += p.res[ob + c];
-            if (p.clamp) v[c] = fminf(fmaxf(v[c], p.lo), p.hi);
-            if (p.accumulate && co + c < p.Cout) v[c] += p.dst[ob + c];
+                    for (int k = 0; k < 4; ++k) if (co + k < p.Cout) vw[u][k] = q[k];
+            }
         }
-        if (full) *(ie_f32x4*)(p.dst + ob) = ie_f32x4{v[0], v[1], v[2], v[3]};
-        else
+    };
+    auto advance = [&]() __attribute__((always_inline)) {   // returns false after the last step
+        tc0 += TK;
+        if (tc0 < p.cs[ts]) return true;
+        tc0 = 0; cbase += p.cs[ts]; ++ts;
+        if (ts < p.nsrc) return true;
+        ts = 0; cbase = 0; ++tj;
+        if (tj == p.kw) { tj = 0; ++ti; }
+        if (ti == p.kh) return false;
+        set_tap();
+        return true;
+    };
+    set_tap();
+    load_step();
+    bool more = true;
+    while (more) {
+        __syncthreads();                                  // the previous step's tiles have been read
 #pragma unroll
-            for (int c = 0; c < 4; ++c) if (co + c < p.Cout) p.dst[ob + c] = v[c];
+        for (int u = 0; u < NLP; ++u) *(ie_f32x4*)&xs[(t >> 2) + 64 * u][lc] = vx[u];
+#pragma unroll
+        for (int u = 0; u < NLW; ++u) *(ie_f32x4*)&wsh[wk][wc + 64 * u] = vw[u];
+        __syncthreads();
+        more = advance();
+        if (more) load_step();                            // in flight during the FMAs below
+#pragma unroll
+        for (int kk = 0; kk < TK; kk += 4) {
+            ie_f32x4 a[PT];
+#pragma unroll
+            for (int q = 0; q < PT; ++q) a[q] = *(const ie_f32x4*)&xs[tpx + q][kk];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int u = 0; u < NLW; ++u) {
+                    const ie_f32x4 bq = *(const ie_f32x4*)&wsh[kk + r][tco + 64 * u];
+                    const ie_f32x2 b01 = {bq[0], bq[1]}, b23 = {bq[2], bq[3]};
+#pragma unroll
+                    for (int q = 0; q < PT; ++q) {
+                        const ie_f32x2 av = {a[q][r], a[q][r]};
+                        acc[q][u][0] = __builtin_elementwise_fma(av, b01, acc[q][u][0]);
+                        acc[q][u][1] = __builtin_elementwise_fma(av, b23, acc[q][u][1]);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NLW; ++u) {
+        const int co = co_t + tco + 64 * u;
+        if (co >= p.Cout) continue;
+        const bool full = ((p.Cout & 3) == 0) && co + 3 < p.Cout;
+        float bv[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bv[c] = (p.bias && co + c < p.Cout) ? p.bias[co + c] : 0.f;
+#pragma unroll
+        for (int q = 0; q < PT; ++q) {
+            const int pix = pix0 + tpx + q;
+            if (pix >= npix) continue;
+            const size_t ob = ((size_t)n * npix + pix) * p.Cout + co;
+            float v[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                v[c] = act_f(acc[q][u][c >> 1][c & 1] + bv[c], p.act, p.slope);
+                if (p.res && co + c < p.Cout) v[c] += p.res[ob + c];
+                if (p.clamp) v[c] = fminf(fmaxf(v[c], p.lo), p.hi);
+                if (p.accumulate && co + c < p.Cout) v[c] += p.dst[ob + c];
+            }
+            if (full) *(ie_f32x4*)(p.dst + ob) = ie_f32x4{v[0], v[1], v[2], v[3]};
+            else
+#pragma unroll
+                for (int c = 0; c < 4; ++c) if (co + c < p.Cout) p.dst[ob + c] = v[c];
+        }
     }
 }
 
@@ -333,9 +381,18 @@ IE_EXPORT int ie_convn_nhwc_f32(ie_convn_desc* d, const float* const* srcs, cons
 
 int ie_convn_launch(const ConvNParams& p, hipStream_t stream) {
     static const int force_direct = getenv("IE_CONV_DIRECT") ? atoi(getenv("IE_CONV_DIRECT")) : 0;     // A/B switch
+    static const int tile_sel = getenv("IE_CONV_TILE") ? atoi(getenv("IE_CONV_TILE")) : 0;             // 44 / 84 / 88 force a tile
     if (!force_direct && p.Cin >= 8 && p.Cout >= 16) {
-        dim3 grid(ie_cdiv(p.Ho * p.Wo, TP), ie_cdiv(p.Cout, TC), p.N);
-        hipLaunchKernelGGL(convn_tiled_kernel, grid, dim3(256), 0, stream, p);
+        const long npix = (long)p.Ho * p.Wo;
+        const bool big_px = npix * p.N >= 128L * 1024;                 // enough pixels to fill the chip with 128-pixel tiles
+        int sel = tile_sel ? tile_sel : (big_px ? (p.Cout > 64 ? 88 : 84) : 44);
+        if (sel == 88) {
+            hipLaunchKernelGGL((convn_tiled_kernel<8, 8>), dim3(ie_cdiv((int)npix, 128), ie_cdiv(p.Cout, 128), p.N), dim3(256), 0, stream, p);
+        } else if (sel == 84) {
+            hipLaunchKernelGGL((convn_tiled_kernel<8, 4>), dim3(ie_cdiv((int)npix, 128), ie_cdiv(p.Cout, 64), p.N), dim3(256), 0, stream, p);
+        } else {
+            hipLaunchKernelGGL((convn_tiled_kernel<4, 4>), dim3(ie_cdiv((int)npix, 64), ie_cdiv(p.Cout, 64), p.N), dim3(256), 0, stream, p);
+        }
     } else {
         dim3 grid(ie_cdiv(p.Ho * p.Wo, 64), ie_cdiv(p.Cout, 4 * CT), p.N);
         hipLaunchKernelGGL(convn_direct_kernel, grid, dim3(256), 0, stream, p);
