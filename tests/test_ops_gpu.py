@@ -146,3 +146,16 @@ def test_le_curve_matches_reference_order_bitwise():
     adj = r.permute(0, 2, 3, 1).contiguous().cuda()
     capi.check(capi.lib().ie_le_curve(capi.ptr(x.cuda()), capi.ptr(adj), 24, capi.ptr(out), 2, 17, 19, 8, capi.current_stream()))
     assert torch.equal(out.cpu(), ref)    # same fp32 association order, no FMA contraction
+
+
+@pytest.mark.parametrize("co,cs", [(64, [32]), (136, [24, 16])], ids=["tile8x4", "tile8x8-ragged"])
+def test_conv_f32_large_tiles(co, cs):
+    """>= 128K output pixels select the 8x4 / 8x8 register tiles of the LDS-tiled fp32 conv (small cases use 4x4)."""
+    from mon_amd import ops
+    g = torch.Generator().manual_seed(3)
+    xs = [torch.randn(2, c, 260, 270, generator=g) for c in cs]
+    w = torch.randn(co, sum(cs), 3, 3, generator=g) / (9 * sum(cs)) ** 0.5
+    b = torch.randn(co, generator=g)
+    ref = F.relu(F.conv2d(torch.cat(xs, 1), w, b, padding=1))
+    out = ops.conv2d([ops.to_nhwc(x.cuda()) for x in xs], ops.ConvWeights(w, b, "cuda"), act="relu")
+    assert rel_err(ops.to_nchw(out).cpu(), ref) <= 2e-5
