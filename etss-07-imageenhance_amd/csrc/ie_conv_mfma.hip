@@ -253,6 +253,119 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(MConvParams p) {
     }
 }
 
+// ---- fused depthwise 3x3 + pointwise 1x1 (DepthwiseSeparableConv2d, nn/modules/conv/dsconv.py:106-149) --------------------
+// Per 32-channel chunk of a source: the halo tile arrives by LDS-DMA as in mconv_kernel; the 256 threads run the depthwise
+// 3x3 on it (thread = 8 channels of a pixel: 9 ds_read_b128 + 72 fp32 FMAs, weights [9][32] + bias staged in LDS) and write
+// the 16-bit result as a second LDS tile in MFMA-fragment layout; the pointwise conv is then one MFMA step per pixel fragment.
+// The depthwise result never goes to HBM: a Zero-DCE++ layer moves 128 B/px instead of 256.  VALU-bound (the MFMAs are ~5 %).
+struct DsParams {
+    MConvParams m;
+    const float* dw_w;       // [Cin_total][9] fp32 (the checkpoint's (Cin,1,3,3) flattened)
+    const float* dw_b;       // [Cin_total] or NULL
+};
+
+template <typename T, int NF>
+__global__ __launch_bounds__(256, 2) void dsconv_kernel(DsParams dp) {
+    const MConvParams& p = dp.m;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using frag = typename ie_elem<T>::frag;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pb = blockIdx.x;
+    const int per_xcd = p.total_blocks >> 3;
+    int lb = (pb & 7) * per_xcd + (pb >> 3);
+    const int ct = lb % p.cout_tiles; lb /= p.cout_tiles;
+    const int tx = lb % p.tiles_x; lb /= p.tiles_x;
+    const int ty = lb % p.tiles_y;
+    const int n = lb / p.tiles_y;
+    if (n >= p.N) return;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    constexpr int TWH = TW + 2, THH = TH + 2, TPX = TWH * THH, ND = (TPX + 15) >> 4;
+    unsigned char* in_lds = smem;                                   // [18 x 34 px][64 B], pieces swizzled by (q>>1)&3
+    unsigned char* dw_lds = smem + ND * 1024;                       // [16 x 32 px][64 B], same rule on the tile-linear pixel index
+    unsigned char* w_lds = dw_lds + TH * TW * 64;                   // pointwise weights of the chunk [16*NF][64 B]
+    float* dww = (float*)(w_lds + 16 * NF * 64);                    // depthwise weights [9][32] + bias [32]
+    const int kc = lane >> 4, l16 = lane & 15;
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+
+    ie_f32x4 acc[8][NF];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int f = 0; f < NF; ++f) acc[i][f] = ie_f32x4{0.f, 0.f, 0.f, 0.f};
+    const unsigned w_chunk_bytes = 16u * NF * 64;
+    const unsigned char* wpk = (const unsigned char*)p.wpk + (size_t)ct * p.nchunks * w_chunk_bytes;
+
+    int cin_base = 0, prev_src = 0;
+    for (int ch = 0; ch < p.nchunks; ++ch) {
+        const int s = p.chunk_tab[ch] >> 16, c0 = p.chunk_tab[ch] & 0xffff, Cs = p.cs[s];
+        if (s != prev_src) { cin_base += p.cs[prev_src]; prev_src = s; }
+        const size_t frame_b = (size_t)p.H * p.W * Cs * sizeof(T);
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.src[s] + (size_t)n * frame_b), 0, (int)frame_b, 0x00020000);
+        __syncthreads();                                            // previous chunk: fragments and weights have been read
+        for (int d = wave; d < ND; d += 4) {
+            const int q = d * 16 + (lane >> 2);
+            const int j = (lane & 3) ^ ((q >> 1) & 3);
+            const int r = q / TWH, c = q - r * TWH;
+            const int iy = oy0 + r - 1, ix = ox0 + c - 1;
+            const bool ok = (c0 + j * 8 < Cs) && (q < TPX) && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            const unsigned off = ok ? (unsigned)(((unsigned)(iy * p.W + ix) * (unsigned)Cs + (unsigned)(c0 + j * 8)) * sizeof(T)) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(in_lds + d * 1024), 16, (int)off, 0, 0, 0);
+        }
+        {
+            const auto rw = __builtin_amdgcn_make_buffer_rsrc((void*)(wpk + (size_t)ch * w_chunk_bytes), 0, (int)w_chunk_bytes, 0x00020000);
+            for (int d = wave; d < NF; d += 4)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(w_lds + d * 1024), 16, d * 1024 + lane * 16, 0, 0, 0);
+            for (int i = tid; i < 10 * 32; i += 256) {              // depthwise weights of the chunk's channels (zeros beyond the source)
+                const int t = i >> 5, k = i & 31;
+                const bool live = c0 + k < Cs;
+                dww[i] = !live ? 0.f : (t < 9 ? dp.dw_w[(size_t)(cin_base + c0 + k) * 9 + t] : (dp.dw_b ? dp.dw_b[cin_base + c0 + k] : 0.f));
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // depthwise: item = (tile pixel, 8-channel piece)
+        for (int i = tid; i < TH * TW * 4; i += 256) {
+            const int px = i >> 2, j = i & 3;
+            const int r = px >> 5, c = px & 31;
+            float a8[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a8[k] = dww[9 * 32 + j * 8 + k];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int q = (r + ky) * TWH + c + kx;
+                    typedef __attribute__((ext_vector_type(8))) T t8;
+                    const t8 v = *(const t8*)(in_lds + (size_t)q * 64 + ((j ^ ((q >> 1) & 3)) << 4));
+                    const float* wt = dww + (ky * 3 + kx) * 32 + j * 8;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) a8[k] = fmaf((float)v[k], wt[k], a8[k]);
+                }
+            *(ie_u32x4*)(dw_lds + (size_t)px * 64 + ((j ^ ((px >> 1) & 3)) << 4)) =
+                ie_u32x4{ie_pack2<T>(a8[0], a8[1]), ie_pack2<T>(a8[2], a8[3]), ie_pack2<T>(a8[4], a8[5]), ie_pack2<T>(a8[6], a8[7])};
+        }
+        __syncthreads();
+        frag a[NF];
+#pragma unroll
+        for (int f = 0; f < NF; ++f) a[f] = *(const frag*)(w_lds + (size_t)(f * 16 + l16) * 64 + ((kc ^ ((l16 >> 1) & 3)) << 4));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int q = (wave * 4 + (i >> 1)) * TW + (i & 1) * 16 + l16;
+            const frag b = *(const frag*)(dw_lds + (size_t)q * 64 + ((kc ^ ((q >> 1) & 3)) << 4));
+#pragma unroll
+            for (int f = 0; f < NF; ++f) acc[i][f] = ie_elem<T>::mfma16(a[f], b, acc[i][f]);
+        }
+    }
+    switch (p.act) {
+    case IE_ACT_RELU: mconv_epilogue<T, NF, IE_ACT_RELU>(p, acc, n, ct, oy0, ox0, wave, kc, l16); break;
+    case IE_ACT_LRELU: mconv_epilogue<T, NF, IE_ACT_LRELU>(p, acc, n, ct, oy0, ox0, wave, kc, l16); break;
+    case IE_ACT_TANH: mconv_epilogue<T, NF, IE_ACT_TANH>(p, acc, n, ct, oy0, ox0, wave, kc, l16); break;
+    case IE_ACT_SIGMOID: mconv_epilogue<T, NF, IE_ACT_SIGMOID>(p, acc, n, ct, oy0, ox0, wave, kc, l16); break;
+    default: mconv_epilogue<T, NF, IE_ACT_NONE>(p, acc, n, ct, oy0, ox0, wave, kc, l16); break;
+    }
+}
+
 // ---- thin inputs (one source of 8 channels: an RGB / RGB+max image carried as 8) ---------------------------------------
 // A 32-channel K chunk would be three quarters zeros.  Here K runs over (kx, channel): a K step of 32 = 4 neighbouring pixels
 // of an input row x 8 channels = 64 contiguous bytes of the LDS tile [row][col][8 ch] (16 bytes per pixel, no swizzle: a
@@ -849,6 +962,56 @@ IE_EXPORT int ie_mconv_nhwc(ie_mconv_desc* d, const void* const* srcs, const int
         if (grid > wg_cap) grid = wg_cap;
     }
     hipLaunchKernelGGL(fn, dim3(grid), dim3(256), lds_bytes, (hipStream_t)stream, p);
+    IE_LAUNCH_CHECK();
+    return IE_OK;
+}
+
+
+IE_EXPORT int ie_dsconv_nhwc(ie_mconv_desc* d, const void* const* srcs, const int* channels, const float* dw_w_dev, const float* dw_b_dev,
+                             const void* packed_pw, const float* pw_bias, void* dst, void* stream) {
+    if (!d || !srcs || !channels || !dw_w_dev || !packed_pw || !dst) IE_FAIL(IE_ERR_INVALID, "ie_dsconv_nhwc: null pointer");
+    if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->pad_mode != IE_PAD_ZEROS)
+        IE_FAIL(IE_ERR_UNSUPPORTED, "ie_dsconv_nhwc: depthwise 3x3, stride 1, zero padding 1 only");
+    if ((d->in_dtype != IE_F16 && d->in_dtype != IE_BF16) || (d->out_dtype != d->in_dtype && d->out_dtype != IE_F32))
+        IE_FAIL(IE_ERR_UNSUPPORTED, "ie_dsconv_nhwc: in_dtype must be f16/bf16 and out_dtype the same or f32");
+    Plan pl;
+    int rc = make_plan(channels, d->nsrc, d->Cout, 1, 1, &pl, "ie_dsconv_nhwc");
+    if (rc != IE_OK) return rc;
+    if (pl.thin) IE_FAIL(IE_ERR_UNSUPPORTED, "ie_dsconv_nhwc: a single 8-channel source takes the unfused path (ie_dwconv3x3_nhwc + ie_mconv_nhwc)");
+    DsParams dp;
+    memset(&dp, 0, sizeof(dp));
+    MConvParams& p = dp.m;
+    for (int s = 0; s < d->nsrc; ++s) {
+        if (!srcs[s]) IE_FAIL(IE_ERR_INVALID, "ie_dsconv_nhwc: source %d is null", s);
+        if ((double)d->H * d->W * channels[s] * 2.0 >= 4294967040.0) IE_FAIL(IE_ERR_UNSUPPORTED, "ie_dsconv_nhwc: a frame of source %d exceeds 4 GiB", s);
+        p.src[s] = srcs[s]; p.cs[s] = channels[s];
+    }
+    for (int c = 0; c < pl.nchunks; ++c) p.chunk_tab[c] = ((int)pl.chunk_src[c] << 16) | (int)pl.chunk_c0[c];
+    p.nchunks = pl.nchunks; p.wpk = packed_pw; p.bias = pw_bias; p.res = nullptr; p.dst = dst;
+    p.N = d->N; p.H = d->H; p.W = d->W; p.Cout = d->Cout; p.kh = 1; p.kw = 1; p.pad = 0; p.pad_mode = IE_PAD_ZEROS;
+    p.sub = 1; p.act = d->act; p.clamp = d->clamp; p.out_f32 = d->out_dtype == IE_F32; p.slope = d->slope; p.lo = d->clamp_lo; p.hi = d->clamp_hi;
+    p.Ho = p.Hs = d->H; p.Wo = p.Ws = d->W;
+    d->Ho = d->H; d->Wo = d->W;
+    p.tiles_x = ie_cdiv(p.Wo, TW); p.tiles_y = ie_cdiv(p.Ho, TH); p.cout_tiles = pl.cout_tiles;
+    const long logical = (long)p.tiles_x * p.tiles_y * p.cout_tiles * d->N;
+    p.total_blocks = (int)((logical + 7) / 8 * 8);
+    p.taps_stage = 1; p.nstages = 1;
+    dp.dw_w = dw_w_dev; dp.dw_b = dw_b_dev;
+    const size_t lds = (size_t)((((TH + 2) * (TW + 2)) + 15) / 16) * 1024 + (size_t)TH * TW * 64 + 16 * pl.nf * 64 + 10 * 32 * sizeof(float);
+    void (*fn)(DsParams) = nullptr;
+    const bool h = d->in_dtype == IE_F16;
+    switch (pl.nf) {
+    case 1: fn = h ? dsconv_kernel<_Float16, 1> : dsconv_kernel<__bf16, 1>; break;
+    case 2: fn = h ? dsconv_kernel<_Float16, 2> : dsconv_kernel<__bf16, 2>; break;
+    default: fn = h ? dsconv_kernel<_Float16, 4> : dsconv_kernel<__bf16, 4>; break;
+    }
+    static bool granted[6] = {false};
+    const int slot = (h ? 0 : 3) + (pl.nf == 1 ? 0 : (pl.nf == 2 ? 1 : 2));
+    if (!granted[slot]) {
+        IE_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        granted[slot] = true;
+    }
+    hipLaunchKernelGGL(fn, dim3(p.total_blocks), dim3(256), lds, (hipStream_t)stream, dp);
     IE_LAUNCH_CHECK();
     return IE_OK;
 }

@@ -226,6 +226,15 @@ class ZeroDCEpp_RE(_GraphModel):
         if self._dev_cache is None:
             self._dev_cache = {}
         wdw, bdw = self._params[f"e_conv{k}.dw_conv.weight"], self._params[f"e_conv{k}.dw_conv.bias"]
+        split = tuple(int(t.shape[1]) for t in srcs)
+        if not f32 and sum(split) == wdw.shape[0] and split != (8,):
+            # fused depthwise + pointwise kernel (the depthwise result stays in LDS); the 8-channel RGB input takes the unfused path
+            key = ("dsfused", k, split)
+            if key not in self._dev_cache:
+                pw = ops.MConvWeights(self._params[f"e_conv{k}.pw_conv.weight"], self._params[f"e_conv{k}.pw_conv.bias"], list(split), self._tdt, self.device)
+                self._dev_cache[key] = (wdw[:, 0].reshape(wdw.shape[0], 9).contiguous().to(self.device), bdw.to(self.device).contiguous(), pw)
+            dw_w, dw_b, pw = self._dev_cache[key]
+            return ops.dsconv2d(list(srcs), dw_w, dw_b, pw, act=act, out_f32=out_f32)
         for s in srcs:
             c = s.shape[1]
             real = min(c, wdw.shape[0] - off)         # 16-bit path: the RGB input is carried as 8 channels

@@ -508,3 +508,25 @@ def depthwise3x3_16(x, w_tap_c: torch.Tensor, bias, act="none", slope=0.0) -> to
         capi.check(capi.lib().ie_dwconv3x3_nhwc(capi.ptr(x), capi.ptr(w_tap_c), capi.ptr(bias), capi.ptr(y), _dt(x), n, h, w, c, capi.ACT[act], slope,
                                                 capi.current_stream()), "ie_dwconv3x3_nhwc")
     return y
+
+
+def dsconv2d(srcs, dw_w: torch.Tensor, dw_b, pw: MConvWeights, act="none", slope=0.0, out_f32=False) -> torch.Tensor:
+    """Fused depthwise 3x3 + pointwise 1x1 over the channel concat of ``srcs`` (16-bit): ``dw_w`` fp32 device [Cin, 9],
+    ``pw`` = MConvWeights of the 1x1 conv packed for the same channel split."""
+    if isinstance(srcs, torch.Tensor):
+        srcs = [srcs]
+    for s in srcs:
+        _chk16(s)
+    cs = [int(s.shape[1]) for s in srcs]
+    if cs != pw.split or pw.kh != 1 or pw.kw != 1:
+        raise capi.IEError(f"dsconv2d: sources {cs} do not match the packed 1x1 weights {pw.split}")
+    n, _, h, w = srcs[0].shape
+    odt = torch.float32 if out_f32 else pw.dtype
+    d = capi.MConvDesc(n, h, w, len(srcs), pw.cout, 3, 3, 1, 1, 0, capi.ACT[act], slope, 0, 0.0, 0.0, IE_DT[pw.dtype], IE_DT[odt], 0, 0)
+    out = torch.empty((n, pw.cout, h, w), device=srcs[0].device, dtype=odt, memory_format=CL)
+    ptrs = (C.c_void_p * len(srcs))(*[s.data_ptr() for s in srcs])
+    chans = (C.c_int * len(srcs))(*cs)
+    with torch.cuda.device(out.device):
+        capi.check(capi.lib().ie_dsconv_nhwc(C.byref(d), ptrs, chans, capi.ptr(dw_w), capi.ptr(dw_b), capi.ptr(pw.w), capi.ptr(pw.b), capi.ptr(out),
+                                             capi.current_stream()), "ie_dsconv_nhwc")
+    return out

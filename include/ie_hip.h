@@ -158,6 +158,13 @@ int ie_mconv_pack_weights(const float* w_oihw_host, const int* channels, int nsr
                           void* dst_dev, void* stream);
 int ie_mconv_nhwc(ie_mconv_desc* d, const void* const* srcs_dev, const int* channels, const void* packed_w_dev,
                   const float* bias_dev, const void* residual_dev, void* dst_dev, void* stream);
+/* Fused DepthwiseSeparableConv2d (nn/modules/conv/dsconv.py:106-149; zero_dcepp.py:140-146): depthwise 3x3 (zero padding 1,
+ * bias) of the virtual concat, then pointwise 1x1 (bias, activation) on the matrix cores; the depthwise result stays in LDS.
+ * d: kh = kw = 3, stride 1, pad 1; dw_w_dev: fp32 [Cin_total][9] (the checkpoint's (Cin,1,3,3)); packed_pw_dev: the 1x1 weights
+ * from ie_mconv_pack_weights(kh = kw = 1) for the same channel split.  A single 8-channel source is refused (use
+ * ie_dwconv3x3_nhwc + ie_mconv_nhwc). */
+int ie_dsconv_nhwc(ie_mconv_desc* d, const void* const* srcs_dev, const int* channels, const float* dw_w_dev, const float* dw_b_dev,
+                   const void* packed_pw_dev, const float* pw_bias_dev, void* dst_dev, void* stream);
 
 /* ---- 16-bit (IE_F16 / IE_BF16) NHWC streaming ops between the matrix-core convolutions; IE_F32 forwards to the *_f32
  * entry points above.  On the 16-bit path channel counts are multiples of 8 (a thread moves 8 channels = 16 bytes). */

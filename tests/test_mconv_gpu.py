@@ -82,3 +82,30 @@ def test_mconv_input_channel_map_and_errors():
         ops.mconv2d(x16.to(torch.bfloat16), mw)
     with pytest.raises(capi.IEError):
         ops.mconv2d([x16, x16], mw)
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("cs,co,act", [([32], 32, "relu"), ([32, 32], 32, "relu"), ([40, 24], 3, "tanh"), ([16], 72, "none")])
+def test_fused_depthwise_pointwise(cs, co, act, dt):
+    """ie_dsconv_nhwc (dsconv.py:106-149): depthwise 3x3 of the virtual concat, result rounded to the 16-bit type in LDS,
+    pointwise 1x1 on the matrix cores.  Reference: the same two steps in torch with the intermediate rounded the same way."""
+    tdt = ops.TORCH_DT[dt]
+    g = torch.Generator().manual_seed(5)
+    n, h, w = 2, 37, 45
+    xs = [torch.randn(n, c, h, w, generator=g).to(tdt) for c in cs]
+    cin = sum(cs)
+    wd = torch.randn(cin, 1, 3, 3, generator=g) * 0.3
+    bd = torch.randn(cin, generator=g) * 0.1
+    wp = (torch.randn(co, cin, 1, 1, generator=g) / cin ** 0.5).to(tdt).float()
+    bp = torch.randn(co, generator=g)
+    mid = F.conv2d(torch.cat([x.float() for x in xs], 1), wd, bd, padding=1, groups=cin).to(tdt).float()
+    ref = F.conv2d(mid, wp, bp)
+    ref = {"relu": F.relu, "tanh": torch.tanh, "none": lambda t: t}[act](ref)
+    pw = ops.MConvWeights(wp, bp, cs, tdt, "cuda")
+    out = ops.dsconv2d([x.cuda().contiguous(memory_format=CL) for x in xs], wd[:, 0].reshape(cin, 9).contiguous().cuda(), bd.cuda(), pw, act=act,
+                       out_f32=(co == 3))
+    tol = 3e-3 if dt == "f16" else 2e-2          # a 1-ulp difference in the rounded intermediate is amplified by the 1x1 contraction
+    assert tuple(out.shape) == tuple(ref.shape) and rel_err(out.float().cpu(), ref) <= tol
+    with pytest.raises(capi.IEError):
+        ops.dsconv2d([xs[0].cuda().contiguous(memory_format=CL)[:, :8].contiguous(memory_format=CL)], wd[:8, 0].reshape(8, 9).cuda(), None,
+                     ops.MConvWeights(wp[:, :8].contiguous(), bp, [8], tdt, "cuda"))
