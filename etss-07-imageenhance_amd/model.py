@@ -193,6 +193,35 @@ class VisionModel(Model, ABC):
     def assert_outputs(self, outputs: dict):
         pass
 
+    def capture_graph(self, image: torch.Tensor, warmup: int = 3):
+        """Serving path: capture ``forward`` for one input shape into a HIP graph (one ``hipGraphLaunch`` per call instead of
+        the ~50-150 kernel launches a generator enqueues from Python; the launch-bound case is small batches).  Returns
+        ``run(image) -> outputs``: the input is copied into the captured buffer, the graph replayed, and the SAME output
+        tensors returned on every call (consume or clone them before the next call).  Weights are baked in: capture again
+        after ``load_state_dict``.  The reference has no counterpart (it relies on eager PyTorch)."""
+        if self.device.type != "cuda":
+            raise capi.IEError("capture_graph needs the model on the HIP device")
+        static_in = image.to(self.device, torch.float32).contiguous().clone()
+        stream = torch.cuda.Stream(device=self.device)
+        stream.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(stream):                  # warm-up on a side stream: weight packing, plan workspaces, attributes
+            for _ in range(max(1, warmup)):
+                self.forward({"image": static_in})
+        torch.cuda.current_stream(self.device).wait_stream(stream)
+        torch.cuda.synchronize(self.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            outputs = self.forward({"image": static_in})
+
+        def run(x: torch.Tensor) -> dict:
+            if tuple(x.shape) != tuple(static_in.shape):
+                raise ValueError(f"the graph was captured for {tuple(static_in.shape)}, but got {tuple(x.shape)}.")
+            static_in.copy_(x, non_blocking=True)
+            graph.replay()
+            return outputs
+        run.graph, run.static_input = graph, static_in
+        return run
+
     def _resize(self, v: torch.Tensor, size: tuple[int, int]) -> torch.Tensor:
         """core.resize on tensors == F.interpolate(bilinear, align_corners=False)
         (core/image/geometry/transform.py:216-223), run by the HIP kernel."""

@@ -276,3 +276,25 @@ def test_depthwise3x3_16bit_against_torch():
         ref = F.relu(F.conv2d(x.float(), w, b, padding=1, groups=24))
         got = ops.depthwise3x3_16(x.cuda().contiguous(memory_format=torch.channels_last), w[:, 0].reshape(24, 9).t().contiguous().cuda(), b.cuda(), "relu")
         assert rel_err(got.float().cpu(), ref) <= tol
+
+
+def test_capture_graph_is_bit_identical_and_shape_checked():
+    """Serving path: forward captured into a HIP graph replays to the same bits as the eager launches."""
+    g = torch.Generator().manual_seed(8)
+    for cfg in (dict(name="unet", base_channels=32, num_classes=3, enhance=True, compute_dtype="bf16"), dict(name="zero_dce_re", compute_dtype="f16"),
+                dict(name="retinexnet")):
+        m = mon_amd.MODELS.build(seed=2, **cfg).to("cuda")
+        x = torch.rand(2, 3, 48, 64, generator=g).cuda()
+        ref = {k: v.clone() for k, v in m.forward({"image": x}).items()}
+        run = m.capture_graph(x)
+        y = torch.rand(2, 3, 48, 64, generator=g).cuda()
+        ref_y = {k: v.clone() for k, v in m.forward({"image": y}).items()}
+        out = run(x)
+        assert list(out.keys()) == list(ref.keys())
+        for k in ref:
+            assert torch.equal(out[k], ref[k]), (cfg["name"], k)
+        out = run(y)                                   # new input through the same graph
+        for k in ref_y:
+            assert torch.equal(out[k], ref_y[k]), (cfg["name"], k)
+        with pytest.raises(ValueError):
+            run(torch.rand(1, 3, 48, 64).cuda())
