@@ -410,6 +410,43 @@ class Trainer:
     def gradients(self):
         return self.store.export(self.store.grads)
 
+    # ---- checkpoint / resume (Lightning's ModelCheckpoint writes {"state_dict", "optimizer_states", "global_step", ...};
+    #      nn/callback/model_checkpoint.py:35-185 -- the same top-level keys are used so mon's loaders find "state_dict") ----
+    def save_checkpoint(self, path) -> str:
+        st = self.store
+        ckpt = {"state_dict": self.state_dict(), "global_step": self.step,
+                "optimizer_states": [{"name": "adam", "lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay,
+                                      "exp_avg": self.store.export(st.exp_avg), "exp_avg_sq": self.store.export(st.exp_avg_sq)}],
+                "gradient_clip_val": self.clip, "model": self.model.name}
+        import os
+        os.makedirs(os.path.dirname(os.path.abspath(str(path))) or ".", exist_ok=True)
+        torch.save(ckpt, str(path))
+        return str(path)
+
+    def load_checkpoint(self, path):
+        """Resume: parameters, BatchNorm buffers, Adam moments and the step counter; the next step continues bit-identically."""
+        ckpt = torch.load(str(path), map_location="cpu", weights_only=False)
+        st = self.store
+        opt = ckpt["optimizer_states"][0]
+
+        def put(flat, tensors):
+            for k, (o, n, shape, is_conv) in st.index.items():
+                t = tensors[k].to(torch.float32)
+                if tuple(t.shape) != tuple(shape):
+                    raise RuntimeError(f"checkpoint entry {k} has shape {tuple(t.shape)}, expected {shape}")
+                if is_conv:
+                    ops.pack_hwio_into(t, flat[o:o + n])
+                else:
+                    flat[o:o + n].copy_(t.reshape(-1))
+        put(st.params, ckpt["state_dict"])
+        put(st.exp_avg, opt["exp_avg"])
+        put(st.exp_avg_sq, opt["exp_avg_sq"])
+        for k in st.buffers:
+            st.buffers[k].copy_(ckpt["state_dict"][k])
+        self.step = int(ckpt["global_step"])
+        self.lr, self.betas, self.eps, self.weight_decay = float(opt["lr"]), tuple(opt["betas"]), float(opt["eps"]), float(opt["weight_decay"])
+        return self
+
     def sync_to_model(self):
         """Write the trained parameters back into the model object (for inference / checkpointing)."""
         sd = self.state_dict()

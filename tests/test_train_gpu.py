@@ -479,3 +479,25 @@ def test_llunetpp_training_step_matches_torch():
     sd1 = tr.state_dict()
     for k, ref in final.items():
         assert float((sd1[k] - ref).abs().max()) < 0.1 * lr, k
+
+
+def test_checkpoint_resume_continues_bit_identically(tmp_path):
+    """save_checkpoint after step 1, resume in a fresh Trainer: step 2 produces the same weights as the uninterrupted run
+    (deterministic kernels only on this path? the weight gradient uses fp32 atomics, so "same" is to rounding)."""
+    batches = _batches(2, 32, 48, 2, seed=12)
+    def fresh():
+        return mon_amd.Trainer(_unet("bilinear", seed=21), optimizer={"lr": 1e-3, "eps": 1e-3}, loss={"name": "l1_ssim_loss"}, gradient_clip_val=0.1)
+    a = fresh()
+    a.training_step({"image": batches[0][0], "ref_image": batches[0][1]})
+    path = a.save_checkpoint(tmp_path / "ckpt" / "last.pt")            # .pt: what mon accepts as a weights file (nn/model.py:401-405)
+    a.training_step({"image": batches[1][0], "ref_image": batches[1][1]})
+    b = fresh().load_checkpoint(path)
+    assert b.step == 1
+    b.training_step({"image": batches[1][0], "ref_image": batches[1][1]})
+    sa, sb = a.state_dict(), b.state_dict()
+    for k in sa:
+        assert float((sa[k] - sb[k]).abs().max()) < 2e-5, k
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    assert set(ck) >= {"state_dict", "optimizer_states", "global_step"} and ck["global_step"] == 1
+    m = mon_amd.MODELS.build(name="unet", base_channels=8, num_classes=3, enhance=True, weights=str(path)).to("cuda")   # mon-style loader
+    assert torch.equal(m.state_dict()["inc.conv1.weight"], ck["state_dict"]["inc.conv1.weight"])
