@@ -162,6 +162,7 @@ def main():
         roofline["model_bytes_per_px"] = sum(KERNEL_WORK[k][1] for k in layer_ms)
         roofline["model_mfma_frac"] = round(value / world * H * W * FLOP_PER_PX / (PEAK_MFMA_TFLOPS * 1e12), 4)
 
+        ref = xs = None
         # ---- parity of this very configuration on one frame + CPU baseline (oracle, "port") ----
         if world == 1 and not args.no_cpu_baseline:
             xs = x[:1].cpu()
@@ -202,6 +203,18 @@ def main():
                 torch.cuda.synchronize()
                 return (time.perf_counter() - t0) / reps
 
+            try:      # the same workload with fp16 storage: the configuration that meets the 1e-3 parity bound (bf16 cannot, 8-bit mantissa)
+                m16 = mon_amd.MODELS.build(name="zero_dce_re", weights=dict(sd), compute_dtype="f16").to(dev).eval()
+                x16 = torch.rand(n, 3, H, W, device=dev, generator=torch.Generator(device=dev).manual_seed(0))
+                t16 = timed(lambda: m16.enhance(x16, want_enhanced=True), 3)
+                extras["zero_dce_f16_1080p_frames_per_s"] = round(n / t16, 1)
+                if ref is not None:
+                    e16 = m16.enhance(xs.to(dev), want_enhanced=True)["enhanced"].cpu()
+                    extras["zero_dce_f16_max_rel_err"] = float(f"{float((e16 - ref).abs().max() / ref.abs().max()):.3e}")
+                del m16, x16
+            except Exception as e:
+                extras["zero_dce_f16_1080p_frames_per_s"] = f"failed: {e}"[:200]
+            torch.cuda.empty_cache()
             for tag, cfg, nfr in (("unet32_bf16_1080p_frames_per_s", dict(name="unet", base_channels=32, num_classes=3, enhance=True), 4),
                                   ("unet32_pixelshuffle_bf16_1080p_frames_per_s", dict(name="unet", base_channels=32, num_classes=3, enhance=True, upsampler="pixelshuffle"), 4),
                                   ("retinexnet_bf16_1080p_frames_per_s", dict(name="retinexnet"), 4)):
