@@ -193,6 +193,33 @@ class VisionModel(Model, ABC):
     def assert_outputs(self, outputs: dict):
         pass
 
+    def compute_efficiency_score(self, image_size: int | Sequence[int] = 512, channels: int = 3, runs: int = 100, verbose: bool = False):
+        """vision/model.py:36-70: (FLOPs, params, average seconds per forward) on one random ``image_size`` frame.  FLOPs follow
+        the reference's thop convention (one multiply-accumulate of a convolution = 1): counted by the conv wrappers during one
+        forward (``macs_per_pixel`` for models whose forward is one fused plan); time = ``runs`` forwards bracketed by device syncs."""
+        from . import ops
+        h, w = get_image_size(image_size)
+        datapoint = {"image": torch.rand(1, channels, h, w).to(self.device)}
+        ops._mac_counter = [0]
+        try:
+            self.forward(dict(datapoint))
+            flops = float(ops._mac_counter[0])
+        finally:
+            ops._mac_counter = None
+        if flops == 0 and hasattr(self, "macs_per_pixel"):
+            flops = float(self.macs_per_pixel) * h * w
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        t0 = time.perf_counter()
+        for _ in range(runs):
+            self.forward(dict(datapoint))
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        avg_time = (time.perf_counter() - t0) / max(1, runs)
+        if verbose:
+            print(f"FLOPs (G) : {flops / 1e9:.4f}\nParams (M): {self.params / 1e6:.4f}\nTime (s)  : {avg_time:.17f}")
+        return flops, self.params, avg_time
+
     def capture_graph(self, image: torch.Tensor, warmup: int = 3):
         """Serving path: capture ``forward`` for one input shape into a HIP graph (one ``hipGraphLaunch`` per call instead of
         the ~50-150 kernel launches a generator enqueues from Python; the launch-bound case is small batches).  Returns

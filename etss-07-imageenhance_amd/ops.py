@@ -15,6 +15,15 @@ from . import capi
 
 CL = torch.channels_last
 
+# MAC counter used by VisionModel.compute_efficiency_score (the reference profiles with thop, which counts one multiply-accumulate
+# per "FLOP"): a list with one running total, or None when no profile is being taken
+_mac_counter = None
+
+
+def _count_macs(n, ho, wo, cout, cin_per_group, kh, kw):
+    if _mac_counter is not None:
+        _mac_counter[0] += n * ho * wo * cout * cin_per_group * kh * kw
+
 
 def _chk(t: torch.Tensor) -> torch.Tensor:
     if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 4:
@@ -106,6 +115,7 @@ def conv2d(srcs, cw: ConvWeights, stride=1, pad=1, pad_mode="zeros", act="none",
     ho = (h + 2 * pad - cw.kh) // stride + 1
     wo = (w + 2 * pad - cw.kw) // stride + 1
     out = empty_nhwc(n, cw.cout, ho, wo, srcs[0].device)
+    _count_macs(n, ho, wo, cw.cout, cw.cin_g, cw.kh, cw.kw)
     if residual is not None:
         _chk(residual)
         if tuple(residual.shape) != tuple(out.shape):
@@ -125,6 +135,7 @@ def depthwise_conv2d(x, cw: ConvWeights, stride=1, pad=1, act="none") -> torch.T
     ho = (h + 2 * pad - cw.kh) // stride + 1
     wo = (w + 2 * pad - cw.kw) // stride + 1
     out = empty_nhwc(n, c, ho, wo, x.device)
+    _count_macs(n, ho, wo, c, 1, cw.kh, cw.kw)
     with torch.cuda.device(x.device):
         capi.check(capi.lib().ie_conv2d_nhwc_f32(C.byref(d), capi.ptr(x), None, capi.ptr(cw.w), capi.ptr(cw.b), capi.ptr(out),
                                                  capi.current_stream()), "ie_conv2d_nhwc_f32(depthwise)")
@@ -487,6 +498,7 @@ def mconv2d(srcs, mw: MConvWeights, stride=1, pad=1, pad_mode="zeros", act="none
     ho = (h + 2 * pad - mw.kh) // stride + 1
     wo = (w + 2 * pad - mw.kw) // stride + 1
     out = torch.empty((n, mw.cout, ho, wo), device=srcs[0].device, dtype=odt, memory_format=CL)
+    _count_macs(n, ho, wo, mw.cout, sum(cs), mw.kh, mw.kw)
     if residual is not None:
         _chk16(residual)
         if tuple(residual.shape) != tuple(out.shape):
@@ -504,6 +516,7 @@ def depthwise3x3_16(x, w_tap_c: torch.Tensor, bias, act="none", slope=0.0) -> to
     _chk16(x)
     n, c, h, w = x.shape
     y = torch.empty_like(x, memory_format=CL)
+    _count_macs(n, h, w, c, 1, 3, 3)
     with torch.cuda.device(x.device):
         capi.check(capi.lib().ie_dwconv3x3_nhwc(capi.ptr(x), capi.ptr(w_tap_c), capi.ptr(bias), capi.ptr(y), _dt(x), n, h, w, c, capi.ACT[act], slope,
                                                 capi.current_stream()), "ie_dwconv3x3_nhwc")
@@ -524,6 +537,8 @@ def dsconv2d(srcs, dw_w: torch.Tensor, dw_b, pw: MConvWeights, act="none", slope
     odt = torch.float32 if out_f32 else pw.dtype
     d = capi.MConvDesc(n, h, w, len(srcs), pw.cout, 3, 3, 1, 1, 0, capi.ACT[act], slope, 0, 0.0, 0.0, IE_DT[pw.dtype], IE_DT[odt], 0, 0)
     out = torch.empty((n, pw.cout, h, w), device=srcs[0].device, dtype=odt, memory_format=CL)
+    _count_macs(n, h, w, sum(cs), 1, 3, 3)
+    _count_macs(n, h, w, pw.cout, sum(cs), 1, 1)
     ptrs = (C.c_void_p * len(srcs))(*[s.data_ptr() for s in srcs])
     chans = (C.c_int * len(srcs))(*cs)
     with torch.cuda.device(out.device):

@@ -173,6 +173,12 @@ class ZeroDCE_RE(ImageEnhancementModel):
         outputs["enhanced"] = res["enhanced"]
         return outputs
 
+    @property
+    def macs_per_pixel(self) -> int:
+        """Multiply-accumulates per pixel of the seven convolutions (79,200 at the default widths)."""
+        c, ci, co = self.num_channels, self.in_channels, self.in_channels * self.num_iters
+        return 9 * (ci * c + 3 * c * c + 2 * 2 * c * c + 2 * c * co)
+
     def _require_cuda(self):
         if self.device.type != "cuda":
             raise capi.IEError(f"{self.__class__.__name__} runs on the HIP device only (model.device = {self.device}); call .to('cuda').")

@@ -298,3 +298,19 @@ def test_capture_graph_is_bit_identical_and_shape_checked():
             assert torch.equal(out[k], ref_y[k]), (cfg["name"], k)
         with pytest.raises(ValueError):
             run(torch.rand(1, 3, 48, 64).cuda())
+
+
+def test_compute_efficiency_score_matches_survey_counts():
+    """vision/model.py:36-70.  MACs: Zero-DCE 79,200/px, U-Net-32 634.5 GFLOP/2 per 1080p frame -> checked at 512x512
+    through the ratio, RetinexNet 1374.5/2 GMAC per 1080p frame."""
+    zd = mon_amd.MODELS.build(name="zero_dce_re", seed=1).to("cuda")
+    flops, params, t = zd.compute_efficiency_score(image_size=512, runs=3)
+    assert flops == 79200 * 512 * 512 and params == 79416 and t > 0
+    u = mon_amd.MODELS.build(name="unet", base_channels=32, num_classes=3, enhance=True, seed=1, compute_dtype="bf16").to("cuda")
+    flops, params, t = u.compute_efficiency_score(image_size=512, runs=2)
+    per_px_1080 = 634.5e9 / 2 / (1080 * 1920)
+    assert abs(flops / (512 * 512) - per_px_1080) / per_px_1080 < 0.03          # 1080 rows pad at one level; 8-channel input padding
+    r = mon_amd.MODELS.build(name="retinexnet", seed=1).to("cuda")
+    flops, _, _ = r.compute_efficiency_score(image_size=256, runs=1)
+    per_px = 1374.5e9 / 2 / (1080 * 1920)
+    assert abs(flops / (256 * 256) - per_px) / per_px < 0.03
