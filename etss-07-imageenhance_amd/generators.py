@@ -783,6 +783,62 @@ class HINet_RE(_GraphModel):
             return c(y, f"{name}.downsample", stride=2, pad=1), y
         return y
 
+    def conv_transpose_keys(self):
+        return [k for k in self._params if k.endswith(".up.weight")]
+
+    def forward_train(self, x, store, tape):
+        """Training graph of hinet.py:34-198, 322-362 on the fp32 taped ops; returns ``stage1`` and ``enhanced`` (NHWC), whose
+        losses the trainer sums (hinet.py:311-320)."""
+        from . import train as T
+        m = 2 ** (self.depth - 1)
+        if x.shape[2] % m or x.shape[3] % m:
+            raise ValueError(f"HINet needs H and W divisible by {m} (got {x.shape[2]}x{x.shape[3]}).")
+        s_ = self.relu_slope
+        g = store.grads
+
+        def conv(name, srcs, pad=1, act="none", stride=1):
+            return T.t_conv(tape, srcs, store.conv(name), *store.conv_grads(name), stride=stride, pad=pad, act=act, slope=s_)
+
+        def block(name, srcs, hin, down, enc=None, dec=None):
+            idn = conv(f"{name}.identity", srcs, pad=0)
+            y = conv(f"{name}.conv_1", srcs, act="none" if hin else "lrelu")
+            if hin:
+                half = y.shape[1] // 2
+                y = T.t_norm(tape, y, store.view(f"{name}.norm.weight"), store.view(f"{name}.norm.bias"), store.view(f"{name}.norm.weight", g),
+                             store.view(f"{name}.norm.bias", g), per_sample=True, eps=1e-5, act="lrelu", slope=s_, c_begin=0, c_count=half)
+            y = T.t_add(tape, conv(f"{name}.conv_2", [y], act="lrelu"), idn)
+            if enc is not None and dec is not None:
+                y = T.t_add(tape, T.t_add(tape, y, conv(f"{name}.csff_enc", [enc])), conv(f"{name}.csff_dec", [dec]))
+            if down:
+                return conv(f"{name}.downsample", [y], stride=2, pad=1), y
+            return y
+
+        def stage(s, t, encs=None, decs=None):
+            ups, outs = [], []
+            for i in range(self.depth):
+                name = f"down_path_{s}.{i}"
+                if i + 1 < self.depth:
+                    e, dd = (encs[i], decs[-i - 1]) if encs is not None else (None, None)
+                    t, t_up = block(name, [t], self._hin[i], True, e, dd)
+                    ups.append(t_up)
+                else:
+                    t = block(name, [t], self._hin[i], False)
+            for j in range(self.depth - 1):
+                bridge = conv(f"skip_conv_{s}.{j}", [ups[-j - 1]])
+                t = block(f"up_path_{s}.{j}.conv_block", [T.t_conv_transpose2x2(tape, t, store, f"up_path_{s}.{j}.up"), bridge], False, False)
+                outs.append(t)
+            return t, ups, outs
+
+        x1, encs, decs = stage(1, conv("conv_01", [x]))
+        f1 = conv("sam12.conv1", [x1])
+        img = T.t_add(tape, conv("sam12.conv2", [x1]), x)
+        att = conv("sam12.conv3", [img], act="sigmoid")
+        sam = T.t_add(tape, T.t_mul(tape, f1, att), x1)
+        x2 = conv("cat12", [conv("conv_02", [x]), sam], pad=0)
+        x2, _, _ = stage(2, x2, encs, decs)
+        y2 = T.t_add(tape, conv("last", [x2]), x)
+        return OrderedDict(stage1=img, enhanced=y2)
+
     def _stage(self, s, x, encs=None, decs=None):
         d = self.depth
         ups, outs = [], []

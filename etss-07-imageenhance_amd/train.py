@@ -74,6 +74,9 @@ class ParamStore:
         self.device = device
         self.index = OrderedDict()            # name -> (offset, numel, shape, is_conv)
         self.buffers = OrderedDict()          # running_mean / running_var
+        # ConvTranspose2d(k=2, s=2) weights (Cin, Cout, 2, 2) are kept as they are: read as [Cin][4*Cout] that IS the HWIO matrix of
+        # the 1x1 conv to channels o*4 + i*2 + j that, followed by a pixel shuffle, equals the transposed conv
+        self.convT = set(getattr(model, "conv_transpose_keys", lambda: [])())
         off = 0
         for k, v in model._params.items():
             if k.endswith("running_mean") or k.endswith("running_var"):
@@ -81,7 +84,7 @@ class ParamStore:
                 continue
             if any(s in k for s in ("loss", "train/", "val/", "test/")):      # nn/factory.py:70-77
                 continue
-            self.index[k] = (off, v.numel(), tuple(v.shape), v.dim() == 4)
+            self.index[k] = (off, v.numel(), tuple(v.shape), v.dim() == 4 and k not in self.convT)
             off += (v.numel() + 3) // 4 * 4                                    # keep every view 16-byte aligned
         self.numel = off
         self.params = torch.zeros(off, device=device, dtype=torch.float32)
@@ -102,6 +105,13 @@ class ParamStore:
         _, _, (co, ci, kh, kw), _ = self.index[f"{name}.weight"]
         b = self.view(f"{name}.bias") if f"{name}.bias" in self.index else None
         return ops.ConvWeightsView(self.view(f"{name}.weight"), b, co, ci, kh, kw)
+
+    def conv_transpose(self, name):
+        """(weights view of the equivalent 1x1 conv, its weight-gradient view) of ConvTranspose2d ``name``; the bias (Cout) is tied
+        over the 4 sub-pixels: ``expand_bias`` / ``reduce_bias_grad`` move between the (Cout) parameter and the 4*Cout conv bias."""
+        _, n, (ci, co, kh, kw), _ = self.index[f"{name}.weight"]
+        w = ops.ConvWeightsView(self.view(f"{name}.weight"), None, co * 4, ci, 1, 1)
+        return w, self.view(f"{name}.weight", self.grads)
 
     def conv_grads(self, name):
         db = self.view(f"{name}.bias", self.grads) if f"{name}.bias" in self.index else None
@@ -272,6 +282,44 @@ def t_add(tape, a, b):
     return y
 
 
+def t_mul(tape, a, b):
+    """a * b (same shape): ga = g * b, gb = g * a."""
+    y = ops.mul(a, b)
+
+    def bwd():
+        g = tape.grad(y)
+        if g is None:
+            return
+        for t, other in ((a, b), (b, a)):
+            if tape.is_no_grad(t):
+                continue
+            gt = ops.mul(g, other)
+            if tape.grad(t) is not None:
+                _accumulate(tape.grad(t), gt)
+            else:
+                tape.seed(t, gt)
+        tape.release(y)
+    tape.record(bwd)
+    return y
+
+
+def t_conv_transpose2x2(tape, x, store, name):
+    """nn.ConvTranspose2d(k=2, s=2) = 1x1 conv to 4*Cout channels (o*4 + i*2 + j) + pixel shuffle; the bias is tied over the 4
+    sub-pixels (expanded for the forward, its gradient summed back)."""
+    cw, dw = store.conv_transpose(name)
+    has_b = f"{name}.bias" in store.index
+    b4 = store.view(f"{name}.bias").repeat_interleave(4).contiguous() if has_b else None     # parameter plumbing, Cout values
+    cw.b = b4
+    db4 = torch.empty_like(b4) if has_b else None
+    y = t_pixel_shuffle(tape, t_conv(tape, x, cw, dw, db4, pad=0), 2)
+    if has_b:
+        def bwd():
+            store.view(f"{name}.bias", store.grads).copy_(db4.view(-1, 4).sum(1))
+        # the tape runs in reverse order of recording: placed BEFORE the conv node, the reduction executes right after it
+        tape._fns.insert(len(tape._fns) - 2, bwd)
+    return y
+
+
 def t_curve(tape, image_nchw, adjust, iters):
     """LE curve (zero_dce.py:186-188): image NCHW fp32 (no gradient) + curve maps NHWC -> enhanced NCHW fp32."""
     n, _, h, w = image_nchw.shape
@@ -351,7 +399,21 @@ class Trainer:
         tape = tape or Tape()
         tape.no_grad(x)
         res = m.forward_train(x, self.store, tape)
-        if isinstance(res, dict):                 # zero-reference models: loss(input, adjust, enhance) (zero_dce.py:160-171)
+        if isinstance(res, dict) and "adjust" not in res:
+            # supervised models with several predictions (hinet.py:311-320): loss = sum over the outputs of loss(p, target)
+            outputs = OrderedDict(res)
+            m.assert_outputs(outputs)
+            target = datapoint.get("ref_image").to(self.device, torch.float32)
+            parts = [(p_, self.loss(p_, target)) for p_ in outputs.values()]
+
+            def seed(tape_, scale=1.0):
+                for p_, r_ in parts:
+                    g_ = torch.empty_like(p_, memory_format=CL)
+                    r_.backward_into(g_, False, scale)
+                    tape_.seed(p_, g_)
+            from .losses import LossResult
+            outputs["loss"] = LossResult(lambda: sum(float(r_) for _, r_ in parts), None, seed)
+        elif isinstance(res, dict):               # zero-reference models: loss(input, adjust, enhance) (zero_dce.py:160-171)
             outputs = OrderedDict(res)
             m.assert_outputs(outputs)
             image = outputs.pop("_image")

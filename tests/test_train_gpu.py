@@ -501,3 +501,34 @@ def test_checkpoint_resume_continues_bit_identically(tmp_path):
     assert set(ck) >= {"state_dict", "optimizer_states", "global_step"} and ck["global_step"] == 1
     m = mon_amd.MODELS.build(name="unet", base_channels=8, num_classes=3, enhance=True, weights=str(path)).to("cuda")   # mon-style loader
     assert torch.equal(m.state_dict()["inc.conv1.weight"], ck["state_dict"]["inc.conv1.weight"])
+
+
+def test_hinet_training_step_matches_torch():
+    """HINet (half instance norm, Conv4x4 stride 2 and ConvTranspose 2x2 gradients, cross-stage fusion, supervised attention):
+    loss = sum over (stage1, enhanced) of L1+SSIM (hinet.py:311-320); one optimiser step vs torch float64 autograd."""
+    from oracle import generators as og
+    model = mon_amd.MODELS.build(name="hinet_re", num_channels=16, depth=3, in_pos_right=2, seed=7).to("cuda")
+    sd0 = model.state_dict()
+    g = torch.Generator().manual_seed(8)
+    tgt = torch.rand(2, 3, 48, 64, generator=g)
+    img = (tgt * 0.8 + 0.1 * torch.randn(2, 3, 48, 64, generator=g)).clamp(0, 1).contiguous()
+    lr, clip, eps = 1e-4, 0.1, 1e-3
+
+    def fwd(p, b, x):
+        o = og.hinet_forward(p, x, depth=3, in_pos_left=0, in_pos_right=2)
+        return o["stage1"], o["enhanced"]
+    log, final = otrain.training_steps({k: v.double() for k, v in sd0.items()}, [(img.double(), tgt.double())], fwd,
+                                       lambda pred, t: otrain.l1_ssim_loss(pred[0], t) + otrain.l1_ssim_loss(pred[1], t), lr=lr, clip=clip, eps=eps)
+    tr = mon_amd.Trainer(model, optimizer={"name": "adam", "lr": lr, "eps": eps}, loss={"name": "l1_ssim_loss"}, gradient_clip_val=clip)
+    out = tr.training_step({"image": img, "ref_image": tgt})
+    assert list(out) == ["stage1", "enhanced", "loss"]
+    assert abs(float(out["loss"]) - log[0]["loss"][0]) < 5e-5
+    grads = tr.gradients()
+    gmax = max(float(v.abs().max()) for v in log[0]["grads"].values())
+    for k, ref in log[0]["grads"].items():
+        assert tuple(grads[k].shape) == tuple(ref.shape), k
+        err = float((grads[k] - ref).abs().max())
+        assert err < 5e-4 * max(float(ref.abs().max()), 0.05 * gmax), (k, err, float(ref.abs().max()), gmax)
+    sd1 = tr.state_dict()
+    for k, ref in final.items():
+        assert float((sd1[k] - ref).abs().max()) < 0.05 * lr, k
