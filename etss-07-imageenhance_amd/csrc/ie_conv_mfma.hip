@@ -741,6 +741,42 @@ __global__ __launch_bounds__(256, TH3 == 16 ? 2 : 3) void mconv3_kernel(MConvPar
     }
 }
 
+
+// ---- device-side weight packing (training: the fp32 master weights change every step) ---------------------------------------
+// One thread per 16-bit element of the packed image (layout of ie_mconv_pack_weights, non-thin).  The source is the trainer's
+// HWIO fp32 matrix W[tap][ci][co]; mode 1 packs the weights of the DATA-GRADIENT conv of source slice [cb, cb+Cs): the conv of dY
+// (K runs over the original couts) with W'[tap][co][ci] = W[taps-1-tap][cb+ci][co] (output channels = the slice's cins).
+struct PackDevParams {
+    const float* w; void* dst;
+    int nf, cout_tiles, nchunks, nstages, taps_stage, taps, Cout_p, dtype;
+    int s_tap, s_k, s_o, off, flip;          // element strides of W for (tap, K index, output index), base offset, tap flip
+    int chunk_k0[MAX_CHUNKS];                 // first K index of the chunk
+    int chunk_valid[MAX_CHUNKS];              // K indices that exist in the chunk (<= 32)
+    size_t total;
+};
+__global__ void mconv_pack_dev_kernel(PackDevParams q) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= q.total) return;
+    const int rows = 16 * q.nf;
+    size_t r = e;
+    const int kk = (int)(r & 31); r >>= 5;
+    const int row = (int)(r % rows); r /= rows;
+    const int t = (int)(r % q.taps_stage); r /= q.taps_stage;
+    const int st = (int)(r % q.nstages); r /= q.nstages;
+    const int ch = (int)(r % q.nchunks);
+    const int ct = (int)(r / q.nchunks);
+    const int sw = ((row & 15) >> 1) & 3;
+    const int k = (((kk >> 3) ^ sw) << 3) + (kk & 7);
+    const int tap = st * q.taps_stage + t, co = ct * rows + row;
+    float v = 0.f;
+    if (tap < q.taps && co < q.Cout_p && k < q.chunk_valid[ch]) {
+        const int tp = q.flip ? q.taps - 1 - tap : tap;
+        v = q.w[(size_t)tp * q.s_tap + (size_t)(q.chunk_k0[ch] + k) * q.s_k + (size_t)co * q.s_o + q.off];
+    }
+    if (q.dtype == IE_F16) ((_Float16*)q.dst)[e] = (_Float16)v;
+    else ((__bf16*)q.dst)[e] = (__bf16)v;
+}
+
 int pick_nf(int Cout) { return Cout > 32 ? 4 : (Cout > 16 ? 2 : 1); }
 
 struct Plan {
@@ -1012,6 +1048,42 @@ IE_EXPORT int ie_dsconv_nhwc(ie_mconv_desc* d, const void* const* srcs, const in
         granted[slot] = true;
     }
     hipLaunchKernelGGL(fn, dim3(p.total_blocks), dim3(256), lds, (hipStream_t)stream, dp);
+    IE_LAUNCH_CHECK();
+    return IE_OK;
+}
+
+
+IE_EXPORT int ie_mconv_pack_weights_dev(const float* w_hwio_dev, const int* channels, int nsrc, int Cout, int kh, int kw, int dtype, int mode,
+                                        int src_index, void* dst_dev, void* stream) {
+    if (!w_hwio_dev || !channels || !dst_dev || (dtype != IE_F16 && dtype != IE_BF16) || (mode != 0 && mode != 1) || nsrc < 1 || nsrc > IE_CONV_MAX_SRC)
+        IE_FAIL(IE_ERR_INVALID, "ie_mconv_pack_weights_dev: bad args");
+    int Cin = 0, cbase[IE_CONV_MAX_SRC];
+    for (int s = 0; s < nsrc; ++s) { cbase[s] = Cin; Cin += channels[s]; }
+    Plan pl;
+    PackDevParams q;
+    memset(&q, 0, sizeof(q));
+    int rc;
+    if (mode == 0) {
+        rc = make_plan(channels, nsrc, Cout, kh, kw, &pl, "ie_mconv_pack_weights_dev");
+        if (rc != IE_OK) return rc;
+        q.Cout_p = Cout; q.s_tap = Cin * Cout; q.s_k = Cout; q.s_o = 1; q.off = 0; q.flip = 0;
+        for (int c = 0; c < pl.nchunks; ++c) {
+            const int s = pl.chunk_src[c], c0 = pl.chunk_c0[c];
+            q.chunk_k0[c] = cbase[s] + c0;
+            q.chunk_valid[c] = channels[s] - c0 < KC ? channels[s] - c0 : KC;
+        }
+    } else {
+        if (src_index < 0 || src_index >= nsrc) IE_FAIL(IE_ERR_INVALID, "ie_mconv_pack_weights_dev: bad source index");
+        const int one[1] = {Cout};                       // the gradient conv reads dY: one source of Cout channels
+        rc = make_plan(one, 1, channels[src_index], kh, kw, &pl, "ie_mconv_pack_weights_dev");
+        if (rc != IE_OK) return rc;
+        q.Cout_p = channels[src_index]; q.s_tap = Cin * Cout; q.s_k = 1; q.s_o = Cout; q.off = cbase[src_index] * Cout; q.flip = 1;
+        for (int c = 0; c < pl.nchunks; ++c) { q.chunk_k0[c] = pl.chunk_c0[c]; q.chunk_valid[c] = Cout - pl.chunk_c0[c] < KC ? Cout - pl.chunk_c0[c] : KC; }
+    }
+    if (pl.thin) IE_FAIL(IE_ERR_UNSUPPORTED, "ie_mconv_pack_weights_dev: 8-channel (thin) sources are packed on the host only");
+    q.w = w_hwio_dev; q.dst = dst_dev; q.nf = pl.nf; q.cout_tiles = pl.cout_tiles; q.nchunks = pl.nchunks; q.nstages = pl.nstages;
+    q.taps_stage = pl.taps_stage; q.taps = pl.taps; q.dtype = dtype; q.total = pl.total_bytes / 2;
+    hipLaunchKernelGGL(mconv_pack_dev_kernel, dim3((unsigned)((q.total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, q);
     IE_LAUNCH_CHECK();
     return IE_OK;
 }

@@ -545,3 +545,31 @@ def dsconv2d(srcs, dw_w: torch.Tensor, dw_b, pw: MConvWeights, act="none", slope
         capi.check(capi.lib().ie_dsconv_nhwc(C.byref(d), ptrs, chans, capi.ptr(dw_w), capi.ptr(dw_b), capi.ptr(pw.w), capi.ptr(pw.b), capi.ptr(out),
                                              capi.current_stream()), "ie_dsconv_nhwc")
     return out
+
+
+class MConvWeightsDev:
+    """Packed weights for ie_mconv_nhwc produced ON THE DEVICE from the trainer's HWIO fp32 master weights (``repack()`` after every
+    optimiser step).  ``mode="forward"``: the conv over sources ``split``; ``mode="dgrad"``: the data-gradient conv of source
+    ``src_index`` (input = dY with ``cout`` channels, output = that source's channels)."""
+
+    def __init__(self, w_hwio_flat: torch.Tensor, bias, split, cout: int, kh: int, kw: int, dtype, mode="forward", src_index=0):
+        self._src, self._split, self._cout_fwd, self._mode, self._si = w_hwio_flat, [int(c) for c in split], int(cout), mode, int(src_index)
+        self.kh, self.kw, self.dtype = kh, kw, dtype
+        L = capi.lib()
+        if mode == "forward":
+            self.split, self.cout, self.b = list(self._split), int(cout), bias
+        else:
+            self.split, self.cout, self.b = [int(cout)], self._split[src_index], None
+        chans = (C.c_int * len(self.split))(*self.split)
+        nbytes = L.ie_mconv_packed_bytes(chans, len(self.split), self.cout, kh, kw)
+        if nbytes == 0:
+            capi.check(-1, "ie_mconv_packed_bytes")
+        self.w = torch.empty(nbytes, device=w_hwio_flat.device, dtype=torch.uint8)
+        self.repack()
+
+    def repack(self):
+        chans = (C.c_int * len(self._split))(*self._split)
+        with torch.cuda.device(self.w.device):
+            capi.check(capi.lib().ie_mconv_pack_weights_dev(capi.ptr(self._src), chans, len(self._split), self._cout_fwd, self.kh, self.kw,
+                                                            IE_DT[self.dtype], 0 if self._mode == "forward" else 1, self._si, capi.ptr(self.w),
+                                                            capi.current_stream()), "ie_mconv_pack_weights_dev")

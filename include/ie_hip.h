@@ -156,6 +156,12 @@ typedef struct ie_mconv_desc {
 size_t ie_mconv_packed_bytes(const int* channels, int nsrc, int Cout, int kh, int kw);
 int ie_mconv_pack_weights(const float* w_oihw_host, const int* channels, int nsrc, int Cout, int kh, int kw, int dtype,
                           void* dst_dev, void* stream);
+/* Device-side packing from the trainer's HWIO fp32 master weights (they change every step).  mode 0: the forward conv over the
+ * sources `channels`; mode 1: the DATA-GRADIENT conv of source `src_index` -- a conv of dY (one source of Cout channels) with the
+ * flipped, transposed weights, output channels = channels[src_index]; its packed size is
+ * ie_mconv_packed_bytes({Cout}, 1, channels[src_index], kh, kw).  8-channel (thin) sources are not supported here. */
+int ie_mconv_pack_weights_dev(const float* w_hwio_dev, const int* channels, int nsrc, int Cout, int kh, int kw, int dtype, int mode,
+                              int src_index, void* dst_dev, void* stream);
 int ie_mconv_nhwc(ie_mconv_desc* d, const void* const* srcs_dev, const int* channels, const void* packed_w_dev,
                   const float* bias_dev, const void* residual_dev, void* dst_dev, void* stream);
 /* Fused DepthwiseSeparableConv2d (nn/modules/conv/dsconv.py:106-149; zero_dcepp.py:140-146): depthwise 3x3 (zero padding 1,

@@ -109,3 +109,25 @@ def test_fused_depthwise_pointwise(cs, co, act, dt):
     with pytest.raises(capi.IEError):
         ops.dsconv2d([xs[0].cuda().contiguous(memory_format=CL)[:, :8].contiguous(memory_format=CL)], wd[:8, 0].reshape(8, 9).cuda(), None,
                      ops.MConvWeights(wp[:, :8].contiguous(), bp, [8], tdt, "cuda"))
+
+
+@pytest.mark.parametrize("cs,co,k", [([64], 64, 3), ([32, 40], 72, 3), ([128], 24, 1), ([16, 16, 16], 16, 3)])
+def test_device_weight_packing_matches_host(cs, co, k):
+    """ie_mconv_pack_weights_dev (training: master weights change every step) produces the bytes of the host packer, for the forward
+    conv and for the data-gradient conv of every source (flipped, transposed weights)."""
+    g = torch.Generator().manual_seed(9)
+    cin = sum(cs)
+    w = torch.randn(co, cin, k, k, generator=g)
+    hwio = ops.ConvWeights(w, None, "cuda").w                       # [k][k][cin][co] fp32 on the device
+    for tdt in (torch.float16, torch.bfloat16):
+        host = ops.MConvWeights(w, None, cs, tdt, "cuda")
+        dev = ops.MConvWeightsDev(hwio, None, cs, co, k, k, tdt)
+        assert torch.equal(host.w, dev.w)
+        base = 0
+        for si, c in enumerate(cs):
+            wt = w[:, base:base + c].flip(2, 3).permute(1, 0, 2, 3).contiguous()     # OIHW of the gradient conv: (c, co, k, k)
+            host_g = ops.MConvWeights(wt, None, [co], tdt, "cuda") if co % 8 == 0 else None
+            if host_g is not None:
+                dev_g = ops.MConvWeightsDev(hwio, None, cs, co, k, k, tdt, mode="dgrad", src_index=si)
+                assert dev_g.cout == c and dev_g.split == [co] and torch.equal(host_g.w, dev_g.w)
+            base += c
