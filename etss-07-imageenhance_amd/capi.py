@@ -34,6 +34,7 @@ SYMBOLS = [
     "ie_norm_forward_nhwc_f32", "ie_norm_backward_nhwc_f32", "ie_convn_wgrad_nhwc_f32", "ie_convn_dgrad_nhwc_f32",
     "ie_maxpool2x2_backward_nhwc_f32", "ie_resize_backward_nhwc_f32", "ie_crop_nhwc_f32", "ie_pixel_unshuffle_nhwc_f32",
     "ie_act_backward_f32", "ie_l1_loss_f32", "ie_ssim_forward_f32", "ie_ssim_backward_f32", "ie_sumsq_f32", "ie_adam_step_f32",
+    "ie_norm_forward_nhwc", "ie_norm_backward_nhwc", "ie_convn_wgrad_nhwc", "ie_maxpool2x2_backward_nhwc", "ie_resize_backward_nhwc", "ie_crop_nhwc",
     "ie_zref_workspace_floats", "ie_zref_image_losses_f32", "ie_tv_loss_nhwc_f32", "ie_le_curve_backward",
     "ie_zdce_create", "ie_zdce_set_layer", "ie_zdce_finalize", "ie_zdce_reserve", "ie_zdce_forward",
     "ie_zdce_get_feature", "ie_zdce_workspace_bytes", "ie_zdce_destroy", "ie_zdce_time_forward",
@@ -133,6 +134,12 @@ def lib():
     L.ie_ssim_backward_f32.argtypes = [vp, vp, vp, vp, vp, ip, ip, ip, ip, i64, i64, i64, i64, fp, fp, ip, ip, vp]
     L.ie_sumsq_f32.argtypes = [vp, sz, fp, vp, vp, ip, vp]
     L.ie_adam_step_f32.argtypes = [vp, vp, vp, vp, sz, ip, fp, fp, fp, fp, fp, fp, vp, fp, vp]
+    L.ie_norm_forward_nhwc.argtypes = [vp, vp, vp, vp, ip, vp, vp, vp, vp, vp, fp, ip, ip, ip, ip, ip, ip, ip, fp, ip, fp, vp]
+    L.ie_norm_backward_nhwc.argtypes = [vp, vp, vp, ip, vp, vp, vp, vp, vp, vp, vp, ip, ip, ip, ip, ip, ip, ip, ip, ip, fp, vp]
+    L.ie_convn_wgrad_nhwc.argtypes = [C.POINTER(ConvNDesc), C.POINTER(vp), C.POINTER(ip), vp, ip, vp, vp, ip, vp, vp]
+    L.ie_maxpool2x2_backward_nhwc.argtypes = [vp, vp, vp, ip, ip, ip, ip, ip, ip, vp]
+    L.ie_resize_backward_nhwc.argtypes = [vp, vp, ip, ip, ip, ip, ip, ip, ip, ip, ip, vp]
+    L.ie_crop_nhwc.argtypes = [vp, vp, ip, ip, ip, ip, ip, ip, ip, ip, ip, ip, vp]
     L.ie_zref_workspace_floats.argtypes = [ip, ip, ip]
     L.ie_zref_workspace_floats.restype = C.c_size_t
     L.ie_zref_image_losses_f32.argtypes = [vp, vp, ip, ip, ip, fp, fp, fp, fp, vp, vp, vp, ip, vp]

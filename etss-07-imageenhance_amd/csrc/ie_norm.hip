@@ -11,8 +11,8 @@ namespace {
 inline unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }
 
 // thread = (pixel slot, channel); accumulates sum / sum of squares of x, or of g and g*xhat (backward)
-template <bool BWD>
-__global__ void norm_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ yact,
+template <bool BWD, typename T>
+__global__ void norm_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ yact,
                                    const float* __restrict__ mean, const float* __restrict__ inv, double* __restrict__ stats,
                                    int HW, int C, int c0, int cn, int cn_total, int c_off, int n_mul, int act, float slope) {
     const int n = blockIdx.y;
@@ -27,12 +27,12 @@ __global__ void norm_reduce_kernel(const float* __restrict__ x, const float* __r
         for (int pix = blockIdx.x * tpc + ps; pix < HW; pix += gridDim.x * tpc) {
             const size_t i = base + (size_t)pix * C;
             if (BWD) {
-                float gr = dy[i];
-                if (act != IE_ACT_NONE) gr *= ie_act_grad_from_output(yact[i], act, slope);
-                const float xh = (x[i] - m) * iv;
+                float gr = (float)dy[i];
+                if (act != IE_ACT_NONE) gr *= ie_act_grad_from_output((float)yact[i], act, slope);
+                const float xh = ((float)x[i] - m) * iv;
                 s += gr; ss += (double)gr * xh;
             } else {
-                const float v = x[i];
+                const float v = (float)x[i];
                 s += v; ss += (double)v * v;
             }
         }
@@ -63,39 +63,41 @@ __global__ void norm_finalize_kernel(const double* __restrict__ stats, float* __
     }
 }
 
-__global__ void norm_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ inv,
-                                  const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y, int HW,
+template <typename T>
+__global__ void norm_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ inv,
+                                  const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ y, int HW,
                                   int C, int c0, int cn, int n_mul, int act, float slope, size_t total) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int c = (int)(i % C);
-    float v = x[i];
+    float v = (float)x[i];
     if (c >= c0 && c < c0 + cn) {
         const size_t g = (i / ((size_t)HW * C)) * n_mul;
         v = (v - mean[g * cn + (c - c0)]) * inv[g * cn + (c - c0)];
         if (gamma) v = v * gamma[c - c0] + beta[c - c0];
     }
-    y[i] = ie_act_apply(v, act, slope);
+    y[i] = (T)ie_act_apply(v, act, slope);
 }
 
 // dx = gamma * inv * (g - mean(g) - xhat * mean(g * xhat)); channels outside the range: dx = g
-__global__ void norm_backward_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ yact,
+template <typename T>
+__global__ void norm_backward_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ yact,
                                            const float* __restrict__ mean, const float* __restrict__ inv,
-                                           const float* __restrict__ gamma, const double* __restrict__ stats, float* __restrict__ dx,
+                                           const float* __restrict__ gamma, const double* __restrict__ stats, T* __restrict__ dx,
                                            int HW, int C, int c0, int cn, int n_mul, double count, int act, float slope, size_t total) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int c = (int)(i % C);
-    float gr = dy[i];
-    if (act != IE_ACT_NONE) gr *= ie_act_grad_from_output(yact[i], act, slope);
+    float gr = (float)dy[i];
+    if (act != IE_ACT_NONE) gr *= ie_act_grad_from_output((float)yact[i], act, slope);
     if (c >= c0 && c < c0 + cn) {
         const size_t k = (i / ((size_t)HW * C)) * n_mul * cn + (c - c0);
         const float iv = inv[k];
-        const float xh = (x[i] - mean[k]) * iv;
+        const float xh = ((float)x[i] - mean[k]) * iv;
         const float m1 = (float)(stats[2 * k] / count), m2 = (float)(stats[2 * k + 1] / count);
         gr = (gamma ? gamma[c - c0] : 1.f) * iv * (gr - m1 - xh * m2);
     }
-    dx[i] = gr;
+    dx[i] = (T)gr;
 }
 
 // dgamma[c] = sum over groups of sum(g * xhat), dbeta[c] = sum over groups of sum(g)
@@ -108,8 +110,8 @@ __global__ void norm_param_grad_kernel(const double* __restrict__ stats, float* 
     dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
 }
 
-template <bool BWD>
-int launch_reduce(const float* x, const float* dy, const float* yact, const float* mean, const float* inv, double* ws, int N, int HW,
+template <bool BWD, typename T>
+int launch_reduce(const T* x, const T* dy, const T* yact, const float* mean, const float* inv, double* ws, int N, int HW,
                   int C, int c_begin, int c_count, int n_mul, int act, float slope, hipStream_t st) {
     const int groups = n_mul ? N : 1;
     IE_HIP_CHECK(hipMemsetAsync(ws, 0, sizeof(double) * 2 * (size_t)groups * c_count, st));
@@ -120,7 +122,7 @@ int launch_reduce(const float* x, const float* dy, const float* yact, const floa
         const int cap = n_mul ? 1024 : (N >= 16 ? 64 : 1024 / N);
         if (chunks > cap) chunks = cap;
         if (chunks < 1) chunks = 1;
-        hipLaunchKernelGGL(norm_reduce_kernel<BWD>, dim3(chunks, N), dim3(256), 0, st, x, dy, yact, mean, inv, ws, HW, C, c_begin + off,
+        hipLaunchKernelGGL((norm_reduce_kernel<BWD, T>), dim3(chunks, N), dim3(256), 0, st, x, dy, yact, mean, inv, ws, HW, C, c_begin + off,
                            cn, c_count, off, n_mul, act, slope);
         IE_LAUNCH_CHECK();
     }
@@ -129,27 +131,81 @@ int launch_reduce(const float* x, const float* dy, const float* yact, const floa
 
 }  // namespace
 
-IE_EXPORT int ie_norm_forward_nhwc_f32(const float* x, const float* gamma, const float* beta, float* y, double* ws, float* save_mean,
-                                       float* save_invstd, float* running_mean, float* running_var, float momentum, int per_sample,
-                                       int N, int H, int W, int C, int c_begin, int c_count, float eps, int act, float slope,
-                                       void* stream) {
+template <typename T>
+static int norm_forward_impl(const T* x, const float* gamma, const float* beta, T* y, double* ws, float* save_mean, float* save_invstd,
+                             float* running_mean, float* running_var, float momentum, int per_sample, int N, int H, int W, int C, int c_begin,
+                             int c_count, float eps, int act, float slope, void* stream) {
     if (!x || !y || !ws || !save_mean || !save_invstd || N <= 0 || H <= 0 || W <= 0 || C <= 0 || c_begin < 0 || c_count <= 0 ||
         c_begin + c_count > C || (gamma == nullptr) != (beta == nullptr) || (running_mean == nullptr) != (running_var == nullptr) ||
         (per_sample && running_mean))
-        IE_FAIL(IE_ERR_INVALID, "ie_norm_forward_nhwc_f32: bad args");
+        IE_FAIL(IE_ERR_INVALID, "ie_norm_forward_nhwc: bad args");
     hipStream_t st = (hipStream_t)stream;
     const int HW = H * W, n_mul = per_sample ? 1 : 0, groups = per_sample ? N : 1;
-    int rc = launch_reduce<false>(x, nullptr, nullptr, nullptr, nullptr, ws, N, HW, C, c_begin, c_count, n_mul, 0, 0.f, st);
+    int rc = launch_reduce<false, T>(x, nullptr, nullptr, nullptr, nullptr, ws, N, HW, C, c_begin, c_count, n_mul, 0, 0.f, st);
     if (rc != IE_OK) return rc;
     const double count = per_sample ? (double)HW : (double)N * HW;
     hipLaunchKernelGGL(norm_finalize_kernel, dim3(nblk((size_t)groups * c_count)), dim3(256), 0, st, ws, save_mean, save_invstd,
                        groups * c_count, count, eps, running_mean, running_var, momentum);
     IE_LAUNCH_CHECK();
     const size_t total = (size_t)N * HW * C;
-    hipLaunchKernelGGL(norm_apply_kernel, dim3(nblk(total)), dim3(256), 0, st, x, save_mean, save_invstd, gamma, beta, y, HW, C, c_begin,
+    hipLaunchKernelGGL(norm_apply_kernel<T>, dim3(nblk(total)), dim3(256), 0, st, x, save_mean, save_invstd, gamma, beta, y, HW, C, c_begin,
                        c_count, n_mul, act, slope, total);
     IE_LAUNCH_CHECK();
     return IE_OK;
+}
+
+template <typename T>
+static int norm_backward_impl(const T* x, const T* dy, const T* y, const float* gamma, const float* save_mean, const float* save_invstd, double* ws,
+                              T* dx, float* dgamma, float* dbeta, int accumulate_param_grads, int per_sample, int N, int H, int W, int C,
+                              int c_begin, int c_count, int act, float slope, void* stream) {
+    if (!x || !dy || !save_mean || !save_invstd || !ws || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || c_begin < 0 || c_count <= 0 ||
+        c_begin + c_count > C || (act != IE_ACT_NONE && !y) || (dgamma == nullptr) != (dbeta == nullptr))
+        IE_FAIL(IE_ERR_INVALID, "ie_norm_backward_nhwc: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    const int HW = H * W, n_mul = per_sample ? 1 : 0, groups = per_sample ? N : 1;
+    int rc = launch_reduce<true, T>(x, dy, y, save_mean, save_invstd, ws, N, HW, C, c_begin, c_count, n_mul, act, slope, st);
+    if (rc != IE_OK) return rc;
+    const double count = per_sample ? (double)HW : (double)N * HW;
+    const size_t total = (size_t)N * HW * C;
+    hipLaunchKernelGGL(norm_backward_apply_kernel<T>, dim3(nblk(total)), dim3(256), 0, st, x, dy, y, save_mean, save_invstd, gamma, ws, dx,
+                       HW, C, c_begin, c_count, n_mul, count, act, slope, total);
+    IE_LAUNCH_CHECK();
+    if (dgamma) {
+        hipLaunchKernelGGL(norm_param_grad_kernel, dim3(nblk(c_count)), dim3(256), 0, st, ws, dgamma, dbeta, groups, c_count,
+                           accumulate_param_grads);
+        IE_LAUNCH_CHECK();
+    }
+    return IE_OK;
+}
+
+IE_EXPORT int ie_norm_forward_nhwc(const void* x, const float* gamma, const float* beta, void* y, int dtype, double* ws, float* save_mean,
+                                   float* save_invstd, float* running_mean, float* running_var, float momentum, int per_sample, int N, int H,
+                                   int W, int C, int c_begin, int c_count, float eps, int act, float slope, void* stream) {
+    switch (dtype) {
+    case IE_F32: return norm_forward_impl((const float*)x, gamma, beta, (float*)y, ws, save_mean, save_invstd, running_mean, running_var, momentum, per_sample, N, H, W, C, c_begin, c_count, eps, act, slope, stream);
+    case IE_F16: return norm_forward_impl((const _Float16*)x, gamma, beta, (_Float16*)y, ws, save_mean, save_invstd, running_mean, running_var, momentum, per_sample, N, H, W, C, c_begin, c_count, eps, act, slope, stream);
+    case IE_BF16: return norm_forward_impl((const __bf16*)x, gamma, beta, (__bf16*)y, ws, save_mean, save_invstd, running_mean, running_var, momentum, per_sample, N, H, W, C, c_begin, c_count, eps, act, slope, stream);
+    default: IE_FAIL(IE_ERR_INVALID, "ie_norm_forward_nhwc: bad dtype");
+    }
+}
+
+IE_EXPORT int ie_norm_backward_nhwc(const void* x, const void* dy, const void* y, int dtype, const float* gamma, const float* save_mean,
+                                    const float* save_invstd, double* ws, void* dx, float* dgamma, float* dbeta, int accumulate_param_grads,
+                                    int per_sample, int N, int H, int W, int C, int c_begin, int c_count, int act, float slope, void* stream) {
+    switch (dtype) {
+    case IE_F32: return norm_backward_impl((const float*)x, (const float*)dy, (const float*)y, gamma, save_mean, save_invstd, ws, (float*)dx, dgamma, dbeta, accumulate_param_grads, per_sample, N, H, W, C, c_begin, c_count, act, slope, stream);
+    case IE_F16: return norm_backward_impl((const _Float16*)x, (const _Float16*)dy, (const _Float16*)y, gamma, save_mean, save_invstd, ws, (_Float16*)dx, dgamma, dbeta, accumulate_param_grads, per_sample, N, H, W, C, c_begin, c_count, act, slope, stream);
+    case IE_BF16: return norm_backward_impl((const __bf16*)x, (const __bf16*)dy, (const __bf16*)y, gamma, save_mean, save_invstd, ws, (__bf16*)dx, dgamma, dbeta, accumulate_param_grads, per_sample, N, H, W, C, c_begin, c_count, act, slope, stream);
+    default: IE_FAIL(IE_ERR_INVALID, "ie_norm_backward_nhwc: bad dtype");
+    }
+}
+
+IE_EXPORT int ie_norm_forward_nhwc_f32(const float* x, const float* gamma, const float* beta, float* y, double* ws, float* save_mean,
+                                       float* save_invstd, float* running_mean, float* running_var, float momentum, int per_sample,
+                                       int N, int H, int W, int C, int c_begin, int c_count, float eps, int act, float slope,
+                                       void* stream) {
+    return ie_norm_forward_nhwc(x, gamma, beta, y, IE_F32, ws, save_mean, save_invstd, running_mean, running_var, momentum, per_sample, N, H, W, C,
+                                c_begin, c_count, eps, act, slope, stream);
 }
 
 IE_EXPORT int ie_instnorm_nhwc_f32(const float* x, const float* gamma, const float* beta, float* y, double* stats_ws, int N, int H,
@@ -164,22 +220,6 @@ IE_EXPORT int ie_norm_backward_nhwc_f32(const float* x, const float* dy, const f
                                         const float* save_invstd, double* ws, float* dx, float* dgamma, float* dbeta,
                                         int accumulate_param_grads, int per_sample, int N, int H, int W, int C, int c_begin,
                                         int c_count, int act, float slope, void* stream) {
-    if (!x || !dy || !save_mean || !save_invstd || !ws || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || c_begin < 0 || c_count <= 0 ||
-        c_begin + c_count > C || (act != IE_ACT_NONE && !y) || (dgamma == nullptr) != (dbeta == nullptr))
-        IE_FAIL(IE_ERR_INVALID, "ie_norm_backward_nhwc_f32: bad args");
-    hipStream_t st = (hipStream_t)stream;
-    const int HW = H * W, n_mul = per_sample ? 1 : 0, groups = per_sample ? N : 1;
-    int rc = launch_reduce<true>(x, dy, y, save_mean, save_invstd, ws, N, HW, C, c_begin, c_count, n_mul, act, slope, st);
-    if (rc != IE_OK) return rc;
-    const double count = per_sample ? (double)HW : (double)N * HW;
-    const size_t total = (size_t)N * HW * C;
-    hipLaunchKernelGGL(norm_backward_apply_kernel, dim3(nblk(total)), dim3(256), 0, st, x, dy, y, save_mean, save_invstd, gamma, ws, dx,
-                       HW, C, c_begin, c_count, n_mul, count, act, slope, total);
-    IE_LAUNCH_CHECK();
-    if (dgamma) {
-        hipLaunchKernelGGL(norm_param_grad_kernel, dim3(nblk(c_count)), dim3(256), 0, st, ws, dgamma, dbeta, groups, c_count,
-                           accumulate_param_grads);
-        IE_LAUNCH_CHECK();
-    }
-    return IE_OK;
+    return ie_norm_backward_nhwc(x, dy, y, IE_F32, gamma, save_mean, save_invstd, ws, dx, dgamma, dbeta, accumulate_param_grads, per_sample, N, H, W,
+                                 C, c_begin, c_count, act, slope, stream);
 }

@@ -22,10 +22,21 @@ inline unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }
 constexpr int WG_T = 64, WG_K = 16;
 
 struct WgradParams {
-    const float* x; const float* dy; float* dw;
+    const void* x; const void* dy; float* dw;
     int N, H, W, Cs, Cout, Cin_total, cbase, kh, kw, stride, pad, pad_mode, Ho, Wo, rows_per_wg, ci_tiles;
 };
 
+// 4 consecutive channels of an fp32 / 16-bit NHWC tensor as fp32
+template <typename T> __device__ __forceinline__ ie_f32x4 ld4(const T* q) {
+    if constexpr (sizeof(T) == 4) return *(const ie_f32x4*)q;
+    else {
+        typedef __attribute__((ext_vector_type(4))) T t4;
+        const t4 v = *(const t4*)q;
+        return ie_f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    }
+}
+
+template <typename T>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
     __shared__ float xs[WG_K][WG_T + 4];
     __shared__ float ds[WG_K][WG_T + 4];
@@ -49,8 +60,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
         int hi = ho * p.stride + ti - p.pad;
         if (p.pad_mode == IE_PAD_REPLICATE) hi = min(max(hi, 0), p.H - 1);
         else if (hi < 0 || hi >= p.H) continue;          // uniform over the workgroup
-        const float* xrow = p.x + ((size_t)n * p.H + hi) * p.W * p.Cs;
-        const float* drow = p.dy + ((size_t)n * p.Ho + ho) * p.Wo * p.Cout;
+        const T* xrow = (const T*)p.x + ((size_t)n * p.H + hi) * p.W * p.Cs;
+        const T* drow = (const T*)p.dy + ((size_t)n * p.Ho + ho) * p.Wo * p.Cout;
         for (int w0 = 0; w0 < p.Wo; w0 += WG_K) {
             const int wo = w0 + lk;
             int wi = wo * p.stride + tj - p.pad;
@@ -59,18 +70,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
             else okx = okx && wi >= 0 && wi < p.W;
             ie_f32x4 vx = {0.f, 0.f, 0.f, 0.f}, vd = {0.f, 0.f, 0.f, 0.f};
             if (okx) {
-                const float* q = xrow + (size_t)wi * p.Cs + ci_t + lc;
-                if (vec_x && ci_t + lc + 3 < p.Cs) vx = *(const ie_f32x4*)q;
+                const T* q = xrow + (size_t)wi * p.Cs + ci_t + lc;
+                if (vec_x && ci_t + lc + 3 < p.Cs) vx = ld4<T>(q);
                 else
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) if (ci_t + lc + k < p.Cs) vx[k] = q[k];
+                    for (int k = 0; k < 4; ++k) if (ci_t + lc + k < p.Cs) vx[k] = (float)q[k];
             }
             if (wo < p.Wo) {
-                const float* q = drow + (size_t)wo * p.Cout + co_t + lc;
-                if (vec_d && co_t + lc + 3 < p.Cout) vd = *(const ie_f32x4*)q;
+                const T* q = drow + (size_t)wo * p.Cout + co_t + lc;
+                if (vec_d && co_t + lc + 3 < p.Cout) vd = ld4<T>(q);
                 else
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) if (co_t + lc + k < p.Cout) vd[k] = q[k];
+                    for (int k = 0; k < 4; ++k) if (co_t + lc + k < p.Cout) vd[k] = (float)q[k];
             }
             __syncthreads();
             *(ie_f32x4*)&xs[lk][lc] = vx;
@@ -167,12 +178,13 @@ __global__ void flip_transpose_hwio_kernel(const float* __restrict__ w, float* _
 }
 
 // per-channel sum over pixels (bias gradient): same thread layout as the norm statistics pass
-__global__ void channel_sum_kernel(const float* __restrict__ x, double* __restrict__ acc, size_t npix, int C, int c0, int cn) {
+template <typename T>
+__global__ void channel_sum_kernel(const T* __restrict__ x, double* __restrict__ acc, size_t npix, int C, int c0, int cn) {
     const int tpc = max(1, 256 / cn);
     const int c = threadIdx.x % cn, ps = threadIdx.x / cn;
     double s = 0.0;
     if (ps < tpc)
-        for (size_t pix = (size_t)blockIdx.x * tpc + ps; pix < npix; pix += (size_t)gridDim.x * tpc) s += x[pix * C + c0 + c];
+        for (size_t pix = (size_t)blockIdx.x * tpc + ps; pix < npix; pix += (size_t)gridDim.x * tpc) s += (float)x[pix * C + c0 + c];
     __shared__ double sh[256];
     sh[threadIdx.x] = s;
     __syncthreads();
@@ -188,7 +200,8 @@ __global__ void store_f64_as_f32_kernel(const double* __restrict__ a, float* y, 
 
 // ---- streaming backward ops ---------------------------------------------------------------------------------------
 // MaxPool2d(2,2): gradient to the first maximum of the window in scan order (torch keeps the first index)
-__global__ void maxpool2_backward_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, int H,
+template <typename T>
+__global__ void maxpool2_backward_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, int H,
                                          int W, int C, int Ho, int Wo, int accumulate, size_t total) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
@@ -200,14 +213,14 @@ __global__ void maxpool2_backward_kernel(const float* __restrict__ x, const floa
     float g = 0.f;
     const int ho = h >> 1, wo = w >> 1;
     if (ho < Ho && wo < Wo) {
-        const float* p = x + ((n * H + 2 * ho) * W + 2 * wo) * C + c;
-        const float v[4] = {p[0], p[C], p[(size_t)W * C], p[(size_t)W * C + C]};
+        const T* p = x + ((n * H + 2 * ho) * W + 2 * wo) * C + c;
+        const float v[4] = {(float)p[0], (float)p[C], (float)p[(size_t)W * C], (float)p[(size_t)W * C + C]};
         int best = 0;
 #pragma unroll
         for (int k = 1; k < 4; ++k) if (v[k] > v[best] || (v[k] != v[k] && v[best] == v[best])) best = k;
-        if (best == ((h & 1) * 2 + (w & 1))) g = dy[((n * Ho + ho) * Wo + wo) * C + c];
+        if (best == ((h & 1) * 2 + (w & 1))) g = (float)dy[((n * Ho + ho) * Wo + wo) * C + c];
     }
-    dx[i] = (accumulate ? dx[i] : 0.f) + g;
+    dx[i] = (T)((accumulate ? (float)dx[i] : 0.f) + g);
 }
 
 // source coordinates of destination index o (same float expressions as the forward kernel in ie_ops.hip)
@@ -226,7 +239,8 @@ __device__ __forceinline__ void resize_candidates(int i, int In, int Out, int& l
     hi = min(Out - 1, (int)ceilf((i + 2) * sc) + 2);
 }
 // gather form of the resize adjoint: dx[i] = sum over the outputs that read input i of weight * dy[o]
-__global__ void resize_backward_kernel(const float* __restrict__ dy, float* __restrict__ dx, int Hi, int Wi, int C, int Ho, int Wo,
+template <typename T>
+__global__ void resize_backward_kernel(const T* __restrict__ dy, T* __restrict__ dx, int Hi, int Wi, int C, int Ho, int Wo,
                                        int mode, int accumulate, size_t total) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
@@ -238,7 +252,7 @@ __global__ void resize_backward_kernel(const float* __restrict__ dy, float* __re
     int ylo, yhi, xlo, xhi;
     resize_candidates(yi, Hi, Ho, ylo, yhi);
     resize_candidates(xi, Wi, Wo, xlo, xhi);
-    const float* p = dy + n * (size_t)Ho * Wo * C + c;
+    const T* p = dy + n * (size_t)Ho * Wo * C + c;
     float g = 0.f;
     for (int yo = ylo; yo <= yhi; ++yo) {
         int a0, a1; float ly;
@@ -254,15 +268,16 @@ __global__ void resize_backward_kernel(const float* __restrict__ dy, float* __re
             float wx = 0.f;
             if (mode == 0) wx = (b0 == xi) ? 1.f : 0.f;
             else { if (b0 == xi) wx += 1.f - lx; if (b1 == xi) wx += lx; }
-            if (wx != 0.f) rowacc = fmaf(wx, p[((size_t)yo * Wo + xo) * C], rowacc);
+            if (wx != 0.f) rowacc = fmaf(wx, (float)p[((size_t)yo * Wo + xo) * C], rowacc);
         }
         g = fmaf(wy, rowacc, g);
     }
-    dx[i] = (accumulate ? dx[i] : 0.f) + g;
+    dx[i] = (T)((accumulate ? (float)dx[i] : 0.f) + g);
 }
 
 // adjoint of zero padding: dx[h,w] = dy[h+top, w+left]
-__global__ void crop_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int Hs, int Ws, int C, int top, int left,
+template <typename T>
+__global__ void crop_nhwc_kernel(const T* __restrict__ src, T* __restrict__ dst, int Hs, int Ws, int C, int top, int left,
                                  int H, int W, int accumulate, size_t total) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
@@ -271,7 +286,7 @@ __global__ void crop_nhwc_kernel(const float* __restrict__ src, float* __restric
     const int w = (int)(q % W); q /= W;
     const int h = (int)(q % H);
     const size_t n = q / H;
-    dst[i] = (accumulate ? dst[i] : 0.f) + src[((n * Hs + h + top) * Ws + w + left) * C + c];
+    dst[i] = (T)((accumulate ? (float)dst[i] : 0.f) + (float)src[((n * Hs + h + top) * Ws + w + left) * C + c]);
 }
 
 // adjoint of pixel shuffle: dx[n,h,w,c*r*r+i*r+j] = dy[n,h*r+i,w*r+j,c]
@@ -500,17 +515,18 @@ static int check_conv(const ie_convn_desc* d, const char* who) {
     return IE_OK;
 }
 
-IE_EXPORT int ie_convn_wgrad_nhwc_f32(ie_convn_desc* d, const float* const* srcs, const int* cs, const float* dy, float* dw_hwio,
-                                      float* dbias, int accumulate, double* ws, void* stream) {
-    int rc = check_conv(d, "ie_convn_wgrad_nhwc_f32");
+template <typename T>
+static int wgrad_impl(ie_convn_desc* d, const void* const* srcs, const int* cs, const void* dy, float* dw_hwio, float* dbias, int accumulate,
+                      double* ws, void* stream) {
+    int rc = check_conv(d, "ie_convn_wgrad_nhwc");
     if (rc != IE_OK) return rc;
-    if (!srcs || !cs || !dy || !dw_hwio || (dbias && !ws)) IE_FAIL(IE_ERR_INVALID, "ie_convn_wgrad_nhwc_f32: null pointer");
+    if (!srcs || !cs || !dy || !dw_hwio || (dbias && !ws)) IE_FAIL(IE_ERR_INVALID, "ie_convn_wgrad_nhwc: null pointer");
     hipStream_t st = (hipStream_t)stream;
     int Cin = 0;
-    for (int s = 0; s < d->nsrc; ++s) { if (!srcs[s] || cs[s] <= 0) IE_FAIL(IE_ERR_INVALID, "ie_convn_wgrad_nhwc_f32: source %d invalid", s); Cin += cs[s]; }
+    for (int s = 0; s < d->nsrc; ++s) { if (!srcs[s] || cs[s] <= 0) IE_FAIL(IE_ERR_INVALID, "ie_convn_wgrad_nhwc: source %d invalid", s); Cin += cs[s]; }
     d->Ho = (d->H + 2 * d->pad - d->kh) / d->stride + 1;
     d->Wo = (d->W + 2 * d->pad - d->kw) / d->stride + 1;
-    if (d->Ho <= 0 || d->Wo <= 0) IE_FAIL(IE_ERR_INVALID, "ie_convn_wgrad_nhwc_f32: empty output");
+    if (d->Ho <= 0 || d->Wo <= 0) IE_FAIL(IE_ERR_INVALID, "ie_convn_wgrad_nhwc: empty output");
     const int taps = d->kh * d->kw;
     if (!accumulate) IE_HIP_CHECK(hipMemsetAsync(dw_hwio, 0, sizeof(float) * (size_t)taps * Cin * d->Cout, st));
     int cbase = 0;
@@ -528,7 +544,7 @@ IE_EXPORT int ie_convn_wgrad_nhwc_f32(ie_convn_desc* d, const float* const* srcs
         if (chunks > total_rows) chunks = total_rows;
         p.rows_per_wg = ie_cdiv(total_rows, chunks);
         chunks = ie_cdiv(total_rows, p.rows_per_wg);
-        hipLaunchKernelGGL(conv_wgrad_kernel, dim3(co_tiles, p.ci_tiles * taps, chunks), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(conv_wgrad_kernel<T>, dim3(co_tiles, p.ci_tiles * taps, chunks), dim3(256), 0, st, p);
         IE_LAUNCH_CHECK();
         cbase += cs[s];
     }
@@ -540,13 +556,28 @@ IE_EXPORT int ie_convn_wgrad_nhwc_f32(ie_convn_desc* d, const float* const* srcs
             size_t blocks = (npix + (size_t)(256 / cn) * 64 - 1) / ((size_t)(256 / cn) * 64);
             if (blocks > 1024) blocks = 1024;
             if (blocks < 1) blocks = 1;
-            hipLaunchKernelGGL(channel_sum_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dy, ws, npix, d->Cout, off, cn);
+            hipLaunchKernelGGL(channel_sum_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, st, (const T*)dy, ws, npix, d->Cout, off, cn);
             IE_LAUNCH_CHECK();
         }
         hipLaunchKernelGGL(store_f64_as_f32_kernel, dim3(nblk(d->Cout)), dim3(256), 0, st, ws, dbias, d->Cout, accumulate);
         IE_LAUNCH_CHECK();
     }
     return IE_OK;
+}
+
+IE_EXPORT int ie_convn_wgrad_nhwc(ie_convn_desc* d, const void* const* srcs, const int* cs, const void* dy, int dtype, float* dw_hwio, float* dbias,
+                                  int accumulate, double* ws, void* stream) {
+    switch (dtype) {
+    case IE_F32: return wgrad_impl<float>(d, srcs, cs, dy, dw_hwio, dbias, accumulate, ws, stream);
+    case IE_F16: return wgrad_impl<_Float16>(d, srcs, cs, dy, dw_hwio, dbias, accumulate, ws, stream);
+    case IE_BF16: return wgrad_impl<__bf16>(d, srcs, cs, dy, dw_hwio, dbias, accumulate, ws, stream);
+    default: IE_FAIL(IE_ERR_INVALID, "ie_convn_wgrad_nhwc: bad dtype");
+    }
+}
+
+IE_EXPORT int ie_convn_wgrad_nhwc_f32(ie_convn_desc* d, const float* const* srcs, const int* cs, const float* dy, float* dw_hwio,
+                                      float* dbias, int accumulate, double* ws, void* stream) {
+    return wgrad_impl<float>(d, (const void* const*)srcs, cs, dy, dw_hwio, dbias, accumulate, ws, stream);
 }
 
 IE_EXPORT int ie_convn_dgrad_nhwc_f32(ie_convn_desc* d, const float* dy, const float* w_hwio, float* const* dsrcs, const int* cs,
@@ -604,36 +635,74 @@ IE_EXPORT int ie_convn_dgrad_nhwc_f32(ie_convn_desc* d, const float* dy, const f
     return IE_OK;
 }
 
+template <typename T>
+static int maxpool_bwd_impl(const void* x, const void* dy, void* dx, int N, int H, int W, int C, int accumulate, void* stream) {
+    if (!x || !dy || !dx || N <= 0 || H < 2 || W < 2 || C <= 0) IE_FAIL(IE_ERR_INVALID, "ie_maxpool2x2_backward_nhwc: bad args");
+    const size_t total = (size_t)N * H * W * C;
+    hipLaunchKernelGGL(maxpool2_backward_kernel<T>, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)dy, (T*)dx, H, W, C,
+                       H / 2, W / 2, accumulate, total);
+    IE_LAUNCH_CHECK();
+    return IE_OK;
+}
+IE_EXPORT int ie_maxpool2x2_backward_nhwc(const void* x, const void* dy, void* dx, int dtype, int N, int H, int W, int C, int accumulate, void* stream) {
+    switch (dtype) {
+    case IE_F32: return maxpool_bwd_impl<float>(x, dy, dx, N, H, W, C, accumulate, stream);
+    case IE_F16: return maxpool_bwd_impl<_Float16>(x, dy, dx, N, H, W, C, accumulate, stream);
+    case IE_BF16: return maxpool_bwd_impl<__bf16>(x, dy, dx, N, H, W, C, accumulate, stream);
+    default: IE_FAIL(IE_ERR_INVALID, "ie_maxpool2x2_backward_nhwc: bad dtype");
+    }
+}
 IE_EXPORT int ie_maxpool2x2_backward_nhwc_f32(const float* x, const float* dy, float* dx, int N, int H, int W, int C, int accumulate,
                                               void* stream) {
-    if (!x || !dy || !dx || N <= 0 || H < 2 || W < 2 || C <= 0) IE_FAIL(IE_ERR_INVALID, "ie_maxpool2x2_backward_nhwc_f32: bad args");
-    const size_t total = (size_t)N * H * W * C;
-    hipLaunchKernelGGL(maxpool2_backward_kernel, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, H, W, C, H / 2, W / 2,
+    return maxpool_bwd_impl<float>(x, dy, dx, N, H, W, C, accumulate, stream);
+}
+
+template <typename T>
+static int resize_bwd_impl(const void* dy, void* dx, int N, int Hi, int Wi, int C, int Ho, int Wo, int mode, int accumulate, void* stream) {
+    if (!dy || !dx || N <= 0 || Hi <= 0 || Wi <= 0 || C <= 0 || Ho <= 0 || Wo <= 0 || mode < 0 || mode > 2)
+        IE_FAIL(IE_ERR_INVALID, "ie_resize_backward_nhwc: bad args");
+    const size_t total = (size_t)N * Hi * Wi * C;
+    hipLaunchKernelGGL(resize_backward_kernel<T>, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, (const T*)dy, (T*)dx, Hi, Wi, C, Ho, Wo, mode,
                        accumulate, total);
     IE_LAUNCH_CHECK();
     return IE_OK;
 }
-
+IE_EXPORT int ie_resize_backward_nhwc(const void* dy, void* dx, int dtype, int N, int Hi, int Wi, int C, int Ho, int Wo, int mode, int accumulate,
+                                      void* stream) {
+    switch (dtype) {
+    case IE_F32: return resize_bwd_impl<float>(dy, dx, N, Hi, Wi, C, Ho, Wo, mode, accumulate, stream);
+    case IE_F16: return resize_bwd_impl<_Float16>(dy, dx, N, Hi, Wi, C, Ho, Wo, mode, accumulate, stream);
+    case IE_BF16: return resize_bwd_impl<__bf16>(dy, dx, N, Hi, Wi, C, Ho, Wo, mode, accumulate, stream);
+    default: IE_FAIL(IE_ERR_INVALID, "ie_resize_backward_nhwc: bad dtype");
+    }
+}
 IE_EXPORT int ie_resize_backward_nhwc_f32(const float* dy, float* dx, int N, int Hi, int Wi, int C, int Ho, int Wo, int mode,
                                           int accumulate, void* stream) {
-    if (!dy || !dx || N <= 0 || Hi <= 0 || Wi <= 0 || C <= 0 || Ho <= 0 || Wo <= 0 || mode < 0 || mode > 2)
-        IE_FAIL(IE_ERR_INVALID, "ie_resize_backward_nhwc_f32: bad args");
-    const size_t total = (size_t)N * Hi * Wi * C;
-    hipLaunchKernelGGL(resize_backward_kernel, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, dy, dx, Hi, Wi, C, Ho, Wo, mode,
+    return resize_bwd_impl<float>(dy, dx, N, Hi, Wi, C, Ho, Wo, mode, accumulate, stream);
+}
+
+template <typename T>
+static int crop_impl(const void* src, void* dst, int N, int Hs, int Ws, int C, int top, int left, int H, int W, int accumulate, void* stream) {
+    if (!src || !dst || N <= 0 || C <= 0 || top < 0 || left < 0 || H <= 0 || W <= 0 || top + H > Hs || left + W > Ws)
+        IE_FAIL(IE_ERR_INVALID, "ie_crop_nhwc: bad args");
+    const size_t total = (size_t)N * H * W * C;
+    hipLaunchKernelGGL(crop_nhwc_kernel<T>, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, (const T*)src, (T*)dst, Hs, Ws, C, top, left, H, W,
                        accumulate, total);
     IE_LAUNCH_CHECK();
     return IE_OK;
 }
-
+IE_EXPORT int ie_crop_nhwc(const void* src, void* dst, int dtype, int N, int Hs, int Ws, int C, int top, int left, int H, int W, int accumulate,
+                           void* stream) {
+    switch (dtype) {
+    case IE_F32: return crop_impl<float>(src, dst, N, Hs, Ws, C, top, left, H, W, accumulate, stream);
+    case IE_F16: return crop_impl<_Float16>(src, dst, N, Hs, Ws, C, top, left, H, W, accumulate, stream);
+    case IE_BF16: return crop_impl<__bf16>(src, dst, N, Hs, Ws, C, top, left, H, W, accumulate, stream);
+    default: IE_FAIL(IE_ERR_INVALID, "ie_crop_nhwc: bad dtype");
+    }
+}
 IE_EXPORT int ie_crop_nhwc_f32(const float* src, float* dst, int N, int Hs, int Ws, int C, int top, int left, int H, int W,
                                int accumulate, void* stream) {
-    if (!src || !dst || N <= 0 || C <= 0 || top < 0 || left < 0 || H <= 0 || W <= 0 || top + H > Hs || left + W > Ws)
-        IE_FAIL(IE_ERR_INVALID, "ie_crop_nhwc_f32: bad args");
-    const size_t total = (size_t)N * H * W * C;
-    hipLaunchKernelGGL(crop_nhwc_kernel, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, src, dst, Hs, Ws, C, top, left, H, W,
-                       accumulate, total);
-    IE_LAUNCH_CHECK();
-    return IE_OK;
+    return crop_impl<float>(src, dst, N, Hs, Ws, C, top, left, H, W, accumulate, stream);
 }
 
 IE_EXPORT int ie_pixel_unshuffle_nhwc_f32(const float* dy, float* dx, int N, int H, int W, int Cout, int r, int accumulate, void* stream) {

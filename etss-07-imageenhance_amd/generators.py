@@ -515,10 +515,17 @@ class UNet(_GraphModel):
         out["enhanced" if self.enhance else "semantic"] = ops.to_nchw(y)
         return out
 
+    supports_mixed_training = True
+
     def forward_train(self, x, store, tape):
         """Training-mode graph (BatchNorm on batch statistics, running stats updated; activations kept on ``tape``):
         what ``model.train(); model(x)`` runs in the reference (unet.py:35-197).  Returns the NHWC prediction."""
         from . import train as T
+
+        mixed = store.compute_dtype != "f32"
+        tdt = ops.TORCH_DT[store.compute_dtype]
+        if mixed and self.upsampler != "bilinear":
+            raise capi.IEError("unet: the 16-bit training graph covers the bilinear decoder (the PixelShuffle adjoint is fp32 only)")
 
         def dc(name, srcs):
             y = None
@@ -528,6 +535,8 @@ class UNet(_GraphModel):
                 y = T.t_norm(tape, z, store.view(f"{nn_}.weight"), store.view(f"{nn_}.bias"), store.view(f"{nn_}.weight", store.grads),
                              store.view(f"{nn_}.bias", store.grads), per_sample=False, running_mean=store.buffers[f"{nn_}.running_mean"],
                              running_var=store.buffers[f"{nn_}.running_var"], momentum=0.1, eps=1e-5, act="relu")
+                if mixed and y.dtype == torch.float32:
+                    y = T.t_cast(tape, y, tdt)         # the RGB edge runs in fp32; everything after the first Conv-BN-ReLU is 16-bit
                 srcs = [y]
             return y
 
@@ -546,6 +555,8 @@ class UNet(_GraphModel):
         x4 = dc("down3.conv", [T.t_maxpool(tape, x3)])
         x5 = dc("down4.conv", [T.t_maxpool(tape, x4)])
         y = up(1, x5, x4); y = up(2, y, x3); y = up(3, y, x2); y = up(4, y, x1)
+        if mixed:
+            y = T.t_cast(tape, y, torch.float32)       # the 3-channel head, the clamp and the loss run in fp32
         y = T.t_conv(tape, y, store.conv("outc.conv"), *store.conv_grads("outc.conv"), pad=0)
         return T.t_clamp(tape, y, 0.0, 1.0) if self.enhance else y
 

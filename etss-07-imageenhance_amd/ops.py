@@ -311,7 +311,7 @@ def pack_hwio_into(w_oihw: torch.Tensor, dst_flat: torch.Tensor):
 def norm_forward(x, gamma, beta, per_sample: bool, running_mean=None, running_var=None, momentum=0.1, eps=1e-5, act="none",
                  slope=0.0, c_begin=0, c_count=None):
     """InstanceNorm2d (per_sample) / training-mode BatchNorm2d; returns (y, save_mean, save_invstd)."""
-    _chk(x)
+    _chk_any(x)
     n, c, h, w = x.shape
     c_count = c - c_begin if c_count is None else c_count
     g = n if per_sample else 1
@@ -320,26 +320,28 @@ def norm_forward(x, gamma, beta, per_sample: bool, running_mean=None, running_va
     mean = torch.empty(g * c_count, device=x.device, dtype=torch.float32)
     inv = torch.empty_like(mean)
     with torch.cuda.device(x.device):
-        capi.check(capi.lib().ie_norm_forward_nhwc_f32(capi.ptr(x), capi.ptr(gamma), capi.ptr(beta), capi.ptr(y), capi.ptr(ws),
-                                                       capi.ptr(mean), capi.ptr(inv), capi.ptr(running_mean), capi.ptr(running_var),
-                                                       momentum, int(per_sample), n, h, w, c, c_begin, c_count, eps, capi.ACT[act],
-                                                       slope, capi.current_stream()), "ie_norm_forward_nhwc_f32")
+        capi.check(capi.lib().ie_norm_forward_nhwc(capi.ptr(x), capi.ptr(gamma), capi.ptr(beta), capi.ptr(y), _dt(x), capi.ptr(ws),
+                                                   capi.ptr(mean), capi.ptr(inv), capi.ptr(running_mean), capi.ptr(running_var),
+                                                   momentum, int(per_sample), n, h, w, c, c_begin, c_count, eps, capi.ACT[act],
+                                                   slope, capi.current_stream()), "ie_norm_forward_nhwc")
     return y, mean, inv
 
 
 def norm_backward(x, dy, y, gamma, mean, inv, per_sample: bool, dgamma=None, dbeta=None, accumulate=False, act="none", slope=0.0,
                   c_begin=0, c_count=None):
-    _chk(x); _chk(dy)
+    _chk_any(x); _chk_any(dy)
+    if dy.dtype != x.dtype:
+        raise capi.IEError("norm_backward: x and dy must have the same dtype")
     n, c, h, w = x.shape
     c_count = c - c_begin if c_count is None else c_count
     g = n if per_sample else 1
     dx = torch.empty_like(x, memory_format=CL)
     ws = torch.empty(2 * g * c_count, device=x.device, dtype=torch.float64)
     with torch.cuda.device(x.device):
-        capi.check(capi.lib().ie_norm_backward_nhwc_f32(capi.ptr(x), capi.ptr(dy), capi.ptr(y), capi.ptr(gamma), capi.ptr(mean),
-                                                        capi.ptr(inv), capi.ptr(ws), capi.ptr(dx), capi.ptr(dgamma), capi.ptr(dbeta),
-                                                        int(accumulate), int(per_sample), n, h, w, c, c_begin, c_count,
-                                                        capi.ACT[act], slope, capi.current_stream()), "ie_norm_backward_nhwc_f32")
+        capi.check(capi.lib().ie_norm_backward_nhwc(capi.ptr(x), capi.ptr(dy), capi.ptr(y), _dt(x), capi.ptr(gamma), capi.ptr(mean),
+                                                    capi.ptr(inv), capi.ptr(ws), capi.ptr(dx), capi.ptr(dgamma), capi.ptr(dbeta),
+                                                    int(accumulate), int(per_sample), n, h, w, c, c_begin, c_count,
+                                                    capi.ACT[act], slope, capi.current_stream()), "ie_norm_backward_nhwc")
     return dx
 
 
@@ -353,8 +355,10 @@ def conv2d_wgrad(srcs, dy, cw: ConvWeights, dw: torch.Tensor, dbias=None, stride
     if isinstance(srcs, torch.Tensor):
         srcs = [srcs]
     for s in srcs:
-        _chk(s)
-    _chk(dy)
+        _chk_any(s)
+        if s.dtype != dy.dtype:
+            raise capi.IEError("conv2d_wgrad: sources and dy must have the same dtype")
+    _chk_any(dy)
     d = _convn_desc(srcs, cw, stride, pad, pad_mode)
     cs = [int(s.shape[1]) for s in srcs]
     if dw.numel() != cw.kh * cw.kw * sum(cs) * cw.cout:
@@ -363,8 +367,8 @@ def conv2d_wgrad(srcs, dy, cw: ConvWeights, dw: torch.Tensor, dbias=None, stride
     chans = (C.c_int * len(srcs))(*cs)
     ws = torch.empty(cw.cout, device=dy.device, dtype=torch.float64) if dbias is not None else None
     with torch.cuda.device(dy.device):
-        capi.check(capi.lib().ie_convn_wgrad_nhwc_f32(C.byref(d), ptrs, chans, capi.ptr(dy), capi.ptr(dw), capi.ptr(dbias),
-                                                      int(accumulate), capi.ptr(ws), capi.current_stream()), "ie_convn_wgrad_nhwc_f32")
+        capi.check(capi.lib().ie_convn_wgrad_nhwc(C.byref(d), ptrs, chans, capi.ptr(dy), _dt(dy), capi.ptr(dw), capi.ptr(dbias),
+                                                  int(accumulate), capi.ptr(ws), capi.current_stream()), "ie_convn_wgrad_nhwc")
 
 
 def conv2d_dgrad(dy, cw: ConvWeights, src_shapes, dsts, accumulate, stride=1, pad=1, pad_mode="zeros"):
@@ -382,28 +386,28 @@ def conv2d_dgrad(dy, cw: ConvWeights, src_shapes, dsts, accumulate, stride=1, pa
 
 
 def maxpool2x2_backward(x, dy, dx, accumulate):
-    _chk(x); _chk(dy); _chk(dx)
+    _chk_any(x); _chk_any(dy); _chk_any(dx)
     n, c, h, w = x.shape
     with torch.cuda.device(x.device):
-        capi.check(capi.lib().ie_maxpool2x2_backward_nhwc_f32(capi.ptr(x), capi.ptr(dy), capi.ptr(dx), n, h, w, c, int(accumulate),
-                                                              capi.current_stream()), "ie_maxpool2x2_backward_nhwc_f32")
+        capi.check(capi.lib().ie_maxpool2x2_backward_nhwc(capi.ptr(x), capi.ptr(dy), capi.ptr(dx), _dt(x), n, h, w, c, int(accumulate),
+                                                          capi.current_stream()), "ie_maxpool2x2_backward_nhwc")
 
 
 def resize_backward(dy, dx, mode, accumulate):
-    _chk(dy); _chk(dx)
+    _chk_any(dy); _chk_any(dx)
     n, c, hi, wi = dx.shape
     with torch.cuda.device(dy.device):
-        capi.check(capi.lib().ie_resize_backward_nhwc_f32(capi.ptr(dy), capi.ptr(dx), n, hi, wi, c, dy.shape[2], dy.shape[3],
-                                                          _RESIZE[mode], int(accumulate), capi.current_stream()),
-                   "ie_resize_backward_nhwc_f32")
+        capi.check(capi.lib().ie_resize_backward_nhwc(capi.ptr(dy), capi.ptr(dx), _dt(dy), n, hi, wi, c, dy.shape[2], dy.shape[3],
+                                                      _RESIZE[mode], int(accumulate), capi.current_stream()),
+                   "ie_resize_backward_nhwc")
 
 
 def crop_into(src, dst, top, left, accumulate):
-    _chk(src); _chk(dst)
+    _chk_any(src); _chk_any(dst)
     n, c, h, w = dst.shape
     with torch.cuda.device(src.device):
-        capi.check(capi.lib().ie_crop_nhwc_f32(capi.ptr(src), capi.ptr(dst), n, src.shape[2], src.shape[3], c, top, left, h, w,
-                                               int(accumulate), capi.current_stream()), "ie_crop_nhwc_f32")
+        capi.check(capi.lib().ie_crop_nhwc(capi.ptr(src), capi.ptr(dst), _dt(src), n, src.shape[2], src.shape[3], c, top, left, h, w,
+                                           int(accumulate), capi.current_stream()), "ie_crop_nhwc")
 
 
 def pixel_unshuffle_into(dy, dx, r, accumulate):

@@ -70,8 +70,10 @@ class Tape:
 class ParamStore:
     """Flat device storage of a model's trainable parameters (+ gradient and Adam moments) and its buffers."""
 
-    def __init__(self, model, device):
+    def __init__(self, model, device, compute_dtype="f32"):
         self.device = device
+        self.compute_dtype = compute_dtype        # "f32", or "bf16"/"f16": activations between the convolutions are 16-bit
+        self._c16 = {}                            # (name, split) -> (forward MConvWeightsDev, [data-gradient MConvWeightsDev per source])
         self.index = OrderedDict()            # name -> (offset, numel, shape, is_conv)
         self.buffers = OrderedDict()          # running_mean / running_var
         # ConvTranspose2d(k=2, s=2) weights (Cin, Cout, 2, 2) are kept as they are: read as [Cin][4*Cout] that IS the HWIO matrix of
@@ -104,7 +106,29 @@ class ParamStore:
     def conv(self, name) -> ops.ConvWeightsView:
         _, _, (co, ci, kh, kw), _ = self.index[f"{name}.weight"]
         b = self.view(f"{name}.bias") if f"{name}.bias" in self.index else None
-        return ops.ConvWeightsView(self.view(f"{name}.weight"), b, co, ci, kh, kw)
+        cw = ops.ConvWeightsView(self.view(f"{name}.weight"), b, co, ci, kh, kw)
+        cw.store, cw.name = self, name
+        return cw
+
+    def conv16(self, name, split):
+        """Packed 16-bit weights of conv ``name`` over sources ``split`` for the matrix-core forward and for the data gradient of
+        every source, produced on the device from the fp32 master weights and refreshed by ``repack16()`` after every step."""
+        key = (name, tuple(split))
+        if key not in self._c16:
+            _, _, (co, ci, kh, kw), _ = self.index[f"{name}.weight"]
+            dt = ops.TORCH_DT[self.compute_dtype]
+            b = self.view(f"{name}.bias") if f"{name}.bias" in self.index else None
+            w = self.view(f"{name}.weight")
+            fwd = ops.MConvWeightsDev(w, b, list(split), co, kh, kw, dt)
+            dg = [ops.MConvWeightsDev(w, None, list(split), co, kh, kw, dt, mode="dgrad", src_index=i) for i in range(len(split))]
+            self._c16[key] = (fwd, dg)
+        return self._c16[key]
+
+    def repack16(self):
+        for fwd, dg in self._c16.values():
+            fwd.repack()
+            for g in dg:
+                g.repack()
 
     def conv_transpose(self, name):
         """(weights view of the equivalent 1x1 conv, its weight-gradient view) of ConvTranspose2d ``name``; the bias (Cout) is tied
@@ -133,9 +157,55 @@ class ParamStore:
 
 
 # ---- taped ops ---------------------------------------------------------------------------------------------------------
+def t_cast(tape, x, dtype, channels=None):
+    """dtype (and channel count) change between the fp32 edges and the 16-bit interior of the mixed-precision graph."""
+    y = ops.cast(x, dtype, channels)
+
+    def bwd():
+        g = tape.grad(y)
+        if g is None or tape.is_no_grad(x):
+            return
+        gx = ops.cast(g, x.dtype, x.shape[1])
+        if tape.grad(x) is not None:
+            _accumulate(tape.grad(x), gx)
+        else:
+            tape.seed(x, gx)
+        tape.release(y)
+    tape.record(bwd)
+    return y
+
+
+def t_conv16(tape, srcs, cw, dw, db, pad=1):
+    """16-bit conv (stride 1, zero padding, no fused activation): forward and data gradient on the matrix cores with weights
+    packed on the device from the fp32 master copy, weight gradient by the fp32-accumulating kernel on the 16-bit tensors."""
+    fwd, dgw = cw.store.conv16(cw.name, [int(s.shape[1]) for s in srcs])
+    y = ops.mconv2d(srcs, fwd, pad=pad)
+
+    def bwd():
+        dy = tape.grad(y)
+        if dy is None:
+            return
+        ops.conv2d_wgrad(srcs, dy, cw, dw, db, 1, pad, "zeros")
+        for i, src in enumerate(srcs):
+            if tape.is_no_grad(src):
+                continue
+            g = ops.mconv2d([dy], dgw[i], pad=cw.kh - 1 - pad)
+            if tape.grad(src) is not None:
+                _accumulate(tape.grad(src), g)
+            else:
+                tape.seed(src, g)
+        tape.release(y)
+    tape.record(bwd)
+    return y
+
+
 def t_conv(tape, srcs, cw, dw, db, stride=1, pad=1, pad_mode="zeros", act="none", slope=0.0):
     if isinstance(srcs, torch.Tensor):
         srcs = [srcs]
+    if srcs[0].dtype != torch.float32:
+        if stride != 1 or pad_mode != "zeros" or act != "none":
+            raise capi.IEError("the 16-bit training conv supports stride 1, zero padding and no fused activation")
+        return t_conv16(tape, srcs, cw, dw, db, pad)
     y = ops.conv2d(srcs, cw, stride=stride, pad=pad, pad_mode=pad_mode, act=act, slope=slope)
 
     def bwd():
@@ -178,6 +248,11 @@ def t_norm(tape, x, gamma, beta, dgamma, dbeta, per_sample, running_mean=None, r
 def _accumulate(buf, dx):
     """buf += dx through the library's eltwise kernel (no torch arithmetic on the data path)."""
     n, c, h, w = buf.shape
+    if buf.dtype != torch.float32:
+        with torch.cuda.device(buf.device):
+            capi.check(capi.lib().ie_eltwise_nhwc(0, capi.ptr(buf), capi.ptr(dx), capi.ptr(buf), ops._dt(buf), n * h * w, c, c,
+                                                  capi.current_stream()), "ie_eltwise_nhwc")
+        return
     with torch.cuda.device(buf.device):
         capi.check(capi.lib().ie_eltwise_nhwc_f32(0, capi.ptr(buf), capi.ptr(dx), capi.ptr(buf), n * h * w, c, c, 0.0, 0.0,
                                                   capi.current_stream()), "ie_eltwise_nhwc_f32")
@@ -352,7 +427,8 @@ class Trainer:
     ``optimizers[0]["optimizer"]``; ``gradient_clip_val`` like the Lightning trainer config (norm clipping).
     ``process_group``: torch.distributed group for data parallelism (default group when initialised)."""
 
-    def __init__(self, model, optimizer: dict | None = None, loss=None, gradient_clip_val: float | None = 0.1, process_group=None):
+    def __init__(self, model, optimizer: dict | None = None, loss=None, gradient_clip_val: float | None = 0.1, process_group=None,
+                 compute_dtype: str = "f32"):
         if not hasattr(model, "forward_train"):
             raise capi.IEError(f"{model.__class__.__name__} has no training graph (forward_train)")
         model._require_cuda()
@@ -375,7 +451,11 @@ class Trainer:
             raise TypeError("`loss` must be a mon_amd.losses.Loss or its config dict")
         self.group = process_group
         self.step = 0
-        self.store = ParamStore(model, self.device)
+        cd = {capi.IE_F32: "f32", capi.IE_F16: "f16", capi.IE_BF16: "bf16"}[capi.DTYPES[str(compute_dtype).lower()]]
+        if cd != "f32" and not getattr(model, "supports_mixed_training", False):
+            raise capi.IEError(f"{model.__class__.__name__} has no 16-bit training graph")
+        self.compute_dtype = cd
+        self.store = ParamStore(model, self.device, cd)
         self._sumsq = torch.zeros(1, device=self.device, dtype=torch.float64)
         self._sumsq_ws = torch.zeros(capi.SUMSQ_WS_DOUBLES, device=self.device, dtype=torch.float64)
         model.predicting = False
@@ -453,6 +533,7 @@ class Trainer:
             capi.check(L.ie_adam_step_f32(capi.ptr(st.params), capi.ptr(st.grads), capi.ptr(st.exp_avg), capi.ptr(st.exp_avg_sq), st.numel,
                                           self.step, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, scale,
                                           capi.ptr(sumsq), self.clip, capi.current_stream()), "ie_adam_step_f32")
+        st.repack16()                             # 16-bit copies of the weights for the next step's matrix-core convolutions
 
     def training_step(self, batch: dict, batch_idx: int = 0) -> dict:
         """nn/model.py:701-746 (+ the optimiser step Lightning runs right after it)."""

@@ -259,6 +259,25 @@ int ie_adam_step_f32(float* param_dev, const float* grad_dev, float* exp_avg_dev
                      float beta1, float beta2, float eps, float weight_decay, float grad_scale, const double* sumsq_dev,
                      float max_norm, void* stream);
 
+/* ---- dtype-generic twins of the training entry points (dtype = IE_F32 / IE_F16 / IE_BF16 of the activation tensors; parameter
+ * gradients, statistics and saved mean / invstd stay fp32 / fp64): the 16-bit training path keeps activations and their gradients in
+ * 16 bits between the matrix-core convolutions (forward ie_mconv_nhwc, data gradient ie_mconv_nhwc with ie_mconv_pack_weights_dev
+ * mode 1) and fp32 master weights. */
+int ie_norm_forward_nhwc(const void* x_dev, const float* gamma_dev, const float* beta_dev, void* y_dev, int dtype, double* ws_dev,
+                         float* save_mean_dev, float* save_invstd_dev, float* running_mean_dev, float* running_var_dev, float momentum,
+                         int per_sample, int N, int H, int W, int C, int c_begin, int c_count, float eps, int act, float slope, void* stream);
+int ie_norm_backward_nhwc(const void* x_dev, const void* dy_dev, const void* y_dev, int dtype, const float* gamma_dev, const float* save_mean_dev,
+                          const float* save_invstd_dev, double* ws_dev, void* dx_dev, float* dgamma_dev, float* dbeta_dev,
+                          int accumulate_param_grads, int per_sample, int N, int H, int W, int C, int c_begin, int c_count, int act, float slope,
+                          void* stream);
+int ie_convn_wgrad_nhwc(ie_convn_desc* d, const void* const* srcs_dev, const int* channels, const void* dy_dev, int dtype, float* dw_hwio_dev,
+                        float* dbias_dev, int accumulate, double* ws_dev, void* stream);
+int ie_maxpool2x2_backward_nhwc(const void* x_dev, const void* dy_dev, void* dx_dev, int dtype, int N, int H, int W, int C, int accumulate, void* stream);
+int ie_resize_backward_nhwc(const void* dy_dev, void* dx_dev, int dtype, int N, int Hi, int Wi, int C, int Ho, int Wo, int mode, int accumulate,
+                            void* stream);
+int ie_crop_nhwc(const void* src_dev, void* dst_dev, int dtype, int N, int Hs, int Ws, int C, int top, int left, int H, int W, int accumulate,
+                 void* stream);
+
 /* ---- zero-reference training of Zero-DCE: the losses of zero_dce.py:34-79 and the LE-curve backward --------- */
 /* floats of scratch ie_zref_image_losses_f32 needs for an (N,3,H,W) batch. */
 size_t ie_zref_workspace_floats(int N, int H, int W);
