@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")"
 OUT=${IE_OUT:-../libie_hip.so}
-SRCS="ie_core.hip ie_conv_direct.hip ie_ops.hip ie_conv_mfma.hip ie_ops16.hip ie_norm.hip ie_train.hip ie_zref.hip ie_zdce_kernels.hip ie_zdce_fused.hip ie_zdce_plan.hip"
+SRCS="ie_core.hip ie_conv_direct.hip ie_ops.hip ie_conv_mfma.hip ie_ops16.hip ie_norm.hip ie_train.hip ie_wgrad_mfma.hip ie_zref.hip ie_zdce_kernels.hip ie_zdce_fused.hip ie_zdce_plan.hip"
 OBJ=$(mktemp -d)
 trap 'rm -rf "$OBJ"' EXIT
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno-unused-function $*"

@@ -529,8 +529,17 @@ static int wgrad_impl(ie_convn_desc* d, const void* const* srcs, const int* cs, 
     if (d->Ho <= 0 || d->Wo <= 0) IE_FAIL(IE_ERR_INVALID, "ie_convn_wgrad_nhwc: empty output");
     const int taps = d->kh * d->kw;
     if (!accumulate) IE_HIP_CHECK(hipMemsetAsync(dw_hwio, 0, sizeof(float) * (size_t)taps * Cin * d->Cout, st));
+    static const int force_fma = getenv("IE_WGRAD_FMA") ? atoi(getenv("IE_WGRAD_FMA")) : 0;      // A/B switch: skip the matrix-core kernel
     int cbase = 0;
     for (int s = 0; s < d->nsrc; ++s) {
+        if constexpr (sizeof(T) == 2) {
+            if (!force_fma && ie_wgrad_mfma_applicable(d->kh, d->kw, d->stride, d->pad, d->pad_mode, cs[s], d->Cout)) {
+                rc = ie_wgrad_mfma_launch(srcs[s], dy, ie_elem<T>::dtype, dw_hwio, d->N, d->H, d->W, cs[s], d->Cout, Cin, cbase, st);
+                if (rc != IE_OK) return rc;
+                cbase += cs[s];
+                continue;
+            }
+        }
         WgradParams p;
         p.x = srcs[s]; p.dy = dy; p.dw = dw_hwio;
         p.N = d->N; p.H = d->H; p.W = d->W; p.Cs = cs[s]; p.Cout = d->Cout; p.Cin_total = Cin; p.cbase = cbase; p.kh = d->kh; p.kw = d->kw;

@@ -1,0 +1,184 @@
+// Matrix-core weight gradient of a 3x3 / stride-1 / zero-padded convolution over 16-bit NHWC tensors (SURVEY 8 a13:
+// torch.autograd's conv2d weight gradient inside the reference's training step, src/mon/nn/model.py:498-615).
+//
+//   dW[ky][kx][ci][co] += sum over pixels (y,x) of X[y+ky-1][x+kx-1][ci] * dY[y][x][co]
+//
+// GEMM view per tap: D[ci][co] = A[ci][k] * B[k][co] with k = 32 consecutive pixels of one image row, on
+// v_mfma_f32_16x16x32_{f16,bf16}.  Both operands are k-strided in NHWC memory (k = pixel, the contiguous axis is
+// the channel), so the LDS image keeps the NHWC order ([pixel][64 channels], 128 B per pixel) and the fragments are
+// gathered with ds_read_b64_tr_b16 (4 pixels x 16 channels per 16-lane group, delivered channel-major).
+//
+// Workgroup = 64 ci x 64 co x 9 taps of one source over a column strip (32 pixels wide) of `rows_per_wg` image rows;
+// wave w owns ci block 16w..16w+15 -> 9 x 4 accumulators of 16x16 (144 VGPRs).  Walking down the strip, each step
+// stages ONE new input row (34 pixels) and one dY row (32 pixels) - the three input rows a step needs live in a
+// 4-slot ring - so X and dY are read once per (ci tile, co tile) pair.  dY fragments are shared by the 9 taps; the
+// tap's horizontal shift is a pixel offset of the transposed read.  Partial sums land in dW with fp32 atomics
+// (split-K over strips), like the fp32 kernel in ie_train.hip.
+//
+// LDS bank swizzle: pixel stride 128 B = 32 banks, so the 8 pixels a 32-lane half reads in one ds_read_b64_tr_b16
+// would share 16 banks (4-way).  The 8-byte unit u of pixel p is stored at unit u ^ (s(p) << 2),
+// s(p) = bit1(p) | bit3(p) << 1: the 8 pixels {c..c+3, c+8..c+11} of a half then cover all 8 (p & 1, s) pairs.
+#include "ie_common.h"
+#include "ie_conv_internal.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) short wm_s16x4;
+typedef __attribute__((address_space(3))) wm_s16x4* wm_lds_ptr;
+
+constexpr int WM_PX = 32;                 // pixels per step = K of one MFMA
+constexpr int WM_XP = WM_PX + 2;          // staged input pixels per row (one halo pixel each side)
+constexpr int WM_ROWB = WM_XP * 128;      // bytes of one staged input row
+constexpr int WM_DYB = WM_PX * 128;       // bytes of one staged dY row
+constexpr int WM_LDS = 4 * WM_ROWB + 2 * WM_DYB;
+
+struct WgradMParams {
+    const void* x; const void* dy; float* dw;
+    int N, H, W, Cs, Cout, Cin_total, cbase, rows_per_wg, co_tiles, xchunks;
+};
+
+__device__ __forceinline__ int wm_swz(int pix) { return ((pix >> 1) & 1) | (((pix >> 3) & 1) << 1); }
+// byte offset of 16-byte chunk c (8 channels) of staged pixel pix
+__device__ __forceinline__ int wm_chunk_off(int pix, int c) { return pix * 128 + ((c ^ (wm_swz(pix) << 1)) << 4); }
+// byte offset of 8-byte unit u (4 channels) of staged pixel pix
+__device__ __forceinline__ int wm_unit_off(int pix, int u) { return pix * 128 + ((u ^ (wm_swz(pix) << 2)) << 3); }
+
+template <typename T>
+__device__ __forceinline__ typename ie_elem<T>::frag wm_frag(const unsigned char* base, int off_lo, int off_hi) {
+    struct { wm_s16x4 lo, hi; } v;
+    v.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wm_lds_ptr)(base + off_lo));
+    v.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wm_lds_ptr)(base + off_hi));
+    return __builtin_bit_cast(typename ie_elem<T>::frag, v);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_kernel(WgradMParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[WM_LDS];
+    const int t = threadIdx.x, lane = t & 63;
+    const int cb = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int co_t = (blockIdx.x % p.co_tiles) * 64, ci_t = (blockIdx.x / p.co_tiles) * 64;
+    const int n = blockIdx.y / p.xchunks, x0 = (blockIdx.y % p.xchunks) * WM_PX;
+    const int y0 = blockIdx.z * p.rows_per_wg, y1 = min(y0 + p.rows_per_wg, p.H);
+    const T* xn = (const T*)p.x + (size_t)n * p.H * p.W * p.Cs;
+    const T* dn = (const T*)p.dy + (size_t)n * p.H * p.W * p.Cout;
+
+    // loader slots: 16-byte chunk (t & 7) of staged pixel (t >> 3); threads 0..15 also take pixels 32, 33 of the input row
+    const int lpix = t >> 3, lch = t & 7;
+    const bool x_ch_ok = ci_t + lch * 8 < p.Cs, d_ch_ok = co_t + lch * 8 < p.Cout;
+    const int gx_a = x0 - 1 + lpix, gx_b = x0 + 31 + lpix;      // input columns of the two loader slots
+    const bool xa_ok = x_ch_ok && gx_a >= 0 && gx_a < p.W;
+    const bool xb_ok = t < 16 && x_ch_ok && gx_b < p.W;
+    const bool d_ok = d_ch_ok && x0 + lpix < p.W;
+    const int xoff_a = wm_chunk_off(lpix, lch), xoff_b = wm_chunk_off(32 + lpix, lch), doff = 4 * WM_ROWB + wm_chunk_off(lpix, lch);
+    const ie_u32x4 zero4 = {0u, 0u, 0u, 0u};
+    auto ld_x = [&](int y, bool ok, int gx) -> ie_u32x4 {
+        return (ok && y >= 0 && y < p.H) ? *(const ie_u32x4*)(xn + ((size_t)y * p.W + gx) * p.Cs + ci_t + lch * 8) : zero4;
+    };
+    auto ld_d = [&](int y) -> ie_u32x4 {
+        return d_ok ? *(const ie_u32x4*)(dn + ((size_t)y * p.W + x0 + lpix) * p.Cout + co_t + lch * 8) : zero4;
+    };
+    auto st_x = [&](int rr, ie_u32x4 a, ie_u32x4 b) {
+        unsigned char* row = lds + (rr & 3) * WM_ROWB;
+        *(ie_u32x4*)(row + xoff_a) = a;
+        if (t < 16) *(ie_u32x4*)(row + xoff_b) = b;
+    };
+
+    // fragment read offsets
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    int aoff[3][2], boff[4][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) aoff[kx][h] = wm_unit_off(kx + g * 8 + h * 4 + q, cb * 4 + pp);
+#pragma unroll
+        for (int cob = 0; cob < 4; ++cob) boff[cob][h] = wm_unit_off(g * 8 + h * 4 + q, cob * 4 + pp);
+    }
+    const bool wave_live = ci_t + cb * 16 < p.Cs;
+    const int ncob = min(4, (p.Cout - co_t + 15) >> 4);
+
+    ie_f32x4 acc[9][4];
+#pragma unroll
+    for (int a = 0; a < 9; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = ie_f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // prologue: input rows y0-1, y0, y0+1 -> ring slots 0, 1, 2; dY row y0 -> slot 0
+#pragma unroll
+    for (int r = 0; r < 3; ++r) st_x(r, ld_x(y0 - 1 + r, xa_ok, gx_a), ld_x(y0 - 1 + r, xb_ok, gx_b));
+    *(ie_u32x4*)(lds + doff) = ld_d(y0);
+
+    for (int y = y0; y < y1; ++y) {
+        __syncthreads();
+        const int rr = y - y0;                      // ring index of input row y-1
+        const bool more = y + 1 < y1;
+        ie_u32x4 nxa = zero4, nxb = zero4, nd = zero4;
+        if (more) { nxa = ld_x(y + 2, xa_ok, gx_a); nxb = ld_x(y + 2, xb_ok, gx_b); nd = ld_d(y + 1); }
+        if (wave_live) {
+            const unsigned char* dyb = lds + 4 * WM_ROWB + (rr & 1) * WM_DYB;
+            typename ie_elem<T>::frag b[4];
+#pragma unroll
+            for (int cob = 0; cob < 4; ++cob) b[cob] = wm_frag<T>(dyb, boff[cob][0], boff[cob][1]);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const unsigned char* xb = lds + ((rr + ky) & 3) * WM_ROWB;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const typename ie_elem<T>::frag a = wm_frag<T>(xb, aoff[kx][0], aoff[kx][1]);
+#pragma unroll
+                    for (int cob = 0; cob < 4; ++cob)
+                        if (cob < ncob) acc[ky * 3 + kx][cob] = ie_elem<T>::mfma16(a, b[cob], acc[ky * 3 + kx][cob]);
+                }
+            }
+        }
+        if (more) {
+            st_x(rr + 3, nxa, nxb);
+            *(ie_u32x4*)(lds + doff + ((rr + 1) & 1) * WM_DYB) = nd;
+        }
+    }
+
+    if (!wave_live) return;
+    const int co_l = lane & 15;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int cob = 0; cob < 4; ++cob) {
+            const int co = co_t + cob * 16 + co_l;
+            if (cob >= ncob || co >= p.Cout) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ci = ci_t + cb * 16 + g * 4 + j;
+                if (ci < p.Cs) atomicAdd(p.dw + ((size_t)tap * p.Cin_total + p.cbase + ci) * p.Cout + co, acc[tap][cob][j]);
+            }
+        }
+}
+
+}  // namespace
+
+// One source of a 3x3 / stride 1 / pad 1 / zero-padded layer: dw_hwio[tap][cbase + ci][co] += X (*) dY.  dtype IE_F16 / IE_BF16,
+// cs % 8 == 0 and Cout % 8 == 0 (16-byte channel chunks); the caller checked applicability with ie_wgrad_mfma_applicable.
+bool ie_wgrad_mfma_applicable(int kh, int kw, int stride, int pad, int pad_mode, int cs, int cout) {
+    return kh == 3 && kw == 3 && stride == 1 && pad == 1 && pad_mode == IE_PAD_ZEROS && (cs & 7) == 0 && (cout & 7) == 0;
+}
+
+int ie_wgrad_mfma_launch(const void* x, const void* dy, int dtype, float* dw_hwio, int N, int H, int W, int cs, int cout, int cin_total, int cbase,
+                         hipStream_t stream) {
+    WgradMParams p;
+    p.x = x; p.dy = dy; p.dw = dw_hwio; p.N = N; p.H = H; p.W = W; p.Cs = cs; p.Cout = cout; p.Cin_total = cin_total; p.cbase = cbase;
+    p.co_tiles = ie_cdiv(cout, 64);
+    const int ci_tiles = ie_cdiv(cs, 64);
+    p.xchunks = ie_cdiv(W, WM_PX);
+    const long tiles = (long)p.co_tiles * ci_tiles, strips = (long)N * p.xchunks;
+    if (tiles > 0x7fffffffL || strips > 65535) IE_FAIL(IE_ERR_UNSUPPORTED, "ie_convn_wgrad_nhwc: grid too large (%ld tiles, %ld strips)", tiles, strips);
+    // split the rows so that ~1024 workgroups exist, but keep >= 16 rows per workgroup to amortise the 36K atomics
+    long ychunks = (1024 + tiles * strips - 1) / (tiles * strips);
+    if (ychunks > (H + 15) / 16) ychunks = (H + 15) / 16;
+    if (ychunks < 1) ychunks = 1;
+    p.rows_per_wg = ie_cdiv(H, (int)ychunks);
+    ychunks = ie_cdiv(H, p.rows_per_wg);
+    const dim3 grid((unsigned)tiles, (unsigned)strips, (unsigned)ychunks);
+    if (dtype == IE_F16) hipLaunchKernelGGL(conv_wgrad_mfma_kernel<_Float16>, grid, dim3(256), 0, stream, p);
+    else if (dtype == IE_BF16) hipLaunchKernelGGL(conv_wgrad_mfma_kernel<__bf16>, grid, dim3(256), 0, stream, p);
+    else IE_FAIL(IE_ERR_INVALID, "ie_convn_wgrad_nhwc: matrix-core path needs a 16-bit dtype");
+    IE_LAUNCH_CHECK();
+    return IE_OK;
+}

@@ -162,6 +162,43 @@ def test_conv_wgrad_dgrad(c):
         assert rel_err(host(dsts[i]), ref) < 2e-5
 
 
+WGRAD16_CASES = [
+    dict(cs=[64], co=64, n=2, h=19, w=70),        # full 64x64 tile, 3 column strips (last one ragged)
+    dict(cs=[16], co=32, n=1, h=5, w=32),         # one ci block live, two co blocks
+    dict(cs=[8, 24], co=24, n=2, h=9, w=33),      # decoder concat, half-filled 16-channel blocks
+    dict(cs=[72, 128], co=136, n=1, h=40, w=31),  # tiles straddling 64 on both sides
+    dict(cs=[64], co=64, n=1, h=67, w=120),       # several row chunks per strip
+    dict(cs=[12], co=20, n=1, h=6, w=9),          # channels not multiples of 8 -> scalar kernel
+]
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("c", WGRAD16_CASES, ids=lambda c: f"{'+'.join(map(str, c['cs']))}-{c['co']}-{c['h']}x{c['w']}")
+def test_conv_wgrad_16bit_matrix_core(c, dtype):
+    """16-bit weight gradient (matrix-core kernel where it applies) against float64 autograd on the SAME rounded inputs."""
+    tdt = ops.TORCH_DT[dtype]
+    n, h, w = c["n"], c["h"], c["w"]
+    g = torch.Generator().manual_seed(11)
+    xs16 = [torch.randn(n, ci, h, w, generator=g).to(tdt) for ci in c["cs"]]
+    cin = sum(c["cs"])
+    dy16 = torch.randn(n, c["co"], h, w, generator=g).to(tdt)
+    wt = torch.zeros(c["co"], cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    b = torch.zeros(c["co"], dtype=torch.float64, requires_grad=True)
+    F.conv2d(torch.cat([x.double() for x in xs16], 1), wt, b, padding=1).backward(dy16.double())
+    cw = ops.ConvWeights(wt.detach().float(), b.detach().float(), "cuda")
+    xd = [x.cuda().contiguous(memory_format=CL) for x in xs16]
+    dyd = dy16.cuda().contiguous(memory_format=CL)
+    dw = torch.full((9 * cin * c["co"],), 7.0, device="cuda")
+    db = torch.full((c["co"],), 7.0, device="cuda")
+    ops.conv2d_wgrad(xd, dyd, cw, dw, db, 1, 1)
+    got = host(dw.reshape(3, 3, cin, c["co"]).permute(3, 2, 0, 1)).double()
+    # products of 16-bit values are exact in fp32; only the fp32 summation order differs
+    assert rel_err(got, wt.grad) < 2e-5
+    assert rel_err(host(db).double(), b.grad) < 2e-5
+    ops.conv2d_wgrad(xd, dyd, cw, dw, None, 1, 1, accumulate=True)
+    assert rel_err(host(dw.reshape(3, 3, cin, c["co"]).permute(3, 2, 0, 1)).double(), 2 * wt.grad) < 2e-5
+
+
 def test_dgrad_rejects_replicate():
     cw = ops.ConvWeights(torch.zeros(4, 4, 3, 3), None, "cuda")
     dy = torch.zeros(1, 4, 8, 8, device="cuda").contiguous(memory_format=CL)
