@@ -110,9 +110,162 @@ __global__ void norm_param_grad_kernel(const double* __restrict__ stats, float* 
     dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
 }
 
+// ---- 16-bit fast path: one thread = 8 consecutive channels (16 bytes) of one pixel -------------------------------------
+// Used when C, c_begin and c_count are multiples of 8, so every 16-byte chunk is wholly inside or outside the
+// normalised range.  Per-thread partial sums are fp32 over a bounded number of pixels (<= ~512, see launch_reduce_v8),
+// combined in double like the scalar kernels.
+template <typename T> struct ie_vec8 { typedef __attribute__((ext_vector_type(8))) T type; };
+
+template <bool BWD, typename T>
+__global__ __launch_bounds__(256) void norm_reduce_v8_kernel(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ yact,
+                                                             const float* __restrict__ mean, const float* __restrict__ inv,
+                                                             double* __restrict__ stats, int HW, int C, int c0, int nch, int cn_total, int c_off,
+                                                             int n_mul, int act, float slope) {
+    typedef typename ie_vec8<T>::type V;
+    const int n = blockIdx.y;
+    const int tpc = 256 / nch;
+    const int ch = threadIdx.x % nch, ps = threadIdx.x / nch;
+    const int g = n * n_mul;
+    float s[8], ss[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { s[k] = 0.f; ss[k] = 0.f; }
+    if (ps < tpc) {
+        const size_t base = (size_t)n * HW * C + c0 + ch * 8;
+        float m[8], iv[8];
+        if (BWD) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                m[k] = mean[(size_t)g * cn_total + c_off + ch * 8 + k];
+                iv[k] = inv[(size_t)g * cn_total + c_off + ch * 8 + k];
+            }
+        }
+        for (int pix = blockIdx.x * tpc + ps; pix < HW; pix += gridDim.x * tpc) {
+            const size_t i = base + (size_t)pix * C;
+            const V xv = *(const V*)(x + i);
+            if (BWD) {
+                const V dv = *(const V*)(dy + i);
+                V yv = xv;
+                if (act != IE_ACT_NONE) yv = *(const V*)(yact + i);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    float gr = (float)dv[k];
+                    if (act != IE_ACT_NONE) gr *= ie_act_grad_from_output((float)yv[k], act, slope);
+                    s[k] += gr;
+                    ss[k] = fmaf(gr, ((float)xv[k] - m[k]) * iv[k], ss[k]);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { const float v = (float)xv[k]; s[k] += v; ss[k] = fmaf(v, v, ss[k]); }
+            }
+        }
+    }
+    __shared__ float sh[16][256];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { sh[k][threadIdx.x] = s[k]; sh[8 + k][threadIdx.x] = ss[k]; }
+    __syncthreads();
+    for (int o = threadIdx.x; o < nch * 16; o += 256) {
+        const int stat = o / (nch * 8), cc = o % (nch * 8);
+        double a = 0.0;
+        for (int q = 0; q < tpc; ++q) a += (double)sh[stat * 8 + (cc & 7)][q * nch + (cc >> 3)];
+        atomicAdd(&stats[((size_t)g * cn_total + c_off + cc) * 2 + stat], a);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void norm_apply_v8_kernel(const T* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ inv,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ y,
+                                                            int HW, int C8, int c0, int cn, int n_mul, int act, float slope, size_t total8) {
+    typedef typename ie_vec8<T>::type V;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total8) return;
+    const int c = (int)(i % C8) * 8;
+    const V xv = *(const V*)(x + i * 8);
+    V out;
+    if (c >= c0 && c < c0 + cn) {
+        const size_t g = (i / ((size_t)HW * C8)) * n_mul;
+        const float* mp = mean + g * cn + (c - c0);
+        const float* ip = inv + g * cn + (c - c0);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float v = ((float)xv[k] - mp[k]) * ip[k];
+            if (gamma) v = v * gamma[c - c0 + k] + beta[c - c0 + k];
+            out[k] = (T)ie_act_apply(v, act, slope);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) out[k] = (T)ie_act_apply((float)xv[k], act, slope);
+    }
+    *(V*)(y + i * 8) = out;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void norm_backward_apply_v8_kernel(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ yact,
+                                                                     const float* __restrict__ mean, const float* __restrict__ inv,
+                                                                     const float* __restrict__ gamma, const double* __restrict__ stats,
+                                                                     T* __restrict__ dx, int HW, int C8, int c0, int cn, int n_mul, double count,
+                                                                     int act, float slope, size_t total8) {
+    typedef typename ie_vec8<T>::type V;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total8) return;
+    const int c = (int)(i % C8) * 8;
+    const V dv = *(const V*)(dy + i * 8);
+    float gr[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) gr[k] = (float)dv[k];
+    if (act != IE_ACT_NONE) {
+        const V yv = *(const V*)(yact + i * 8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) gr[k] *= ie_act_grad_from_output((float)yv[k], act, slope);
+    }
+    V out;
+    if (c >= c0 && c < c0 + cn) {
+        const V xv = *(const V*)(x + i * 8);
+        const size_t kb = (i / ((size_t)HW * C8)) * n_mul * cn + (c - c0);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float iv = inv[kb + k];
+            const float xh = ((float)xv[k] - mean[kb + k]) * iv;
+            const float m1 = (float)(stats[2 * (kb + k)] / count), m2 = (float)(stats[2 * (kb + k) + 1] / count);
+            out[k] = (T)((gamma ? gamma[c - c0 + k] : 1.f) * iv * (gr[k] - m1 - xh * m2));
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) out[k] = (T)gr[k];
+    }
+    *(V*)(dx + i * 8) = out;
+}
+
+template <typename T> constexpr bool norm_v8_ok(int C, int c_begin, int c_count) {
+    return sizeof(T) == 2 && (C & 7) == 0 && (c_begin & 7) == 0 && (c_count & 7) == 0;
+}
+
+template <bool BWD, typename T>
+int launch_reduce_v8(const T* x, const T* dy, const T* yact, const float* mean, const float* inv, double* ws, int N, int HW,
+                     int C, int c_begin, int c_count, int n_mul, int act, float slope, hipStream_t st) {
+    const int groups = n_mul ? N : 1;
+    IE_HIP_CHECK(hipMemsetAsync(ws, 0, sizeof(double) * 2 * (size_t)groups * c_count, st));
+    for (int off = 0; off < c_count; off += 2048) {      // <= 256 chunks of 8 channels per launch
+        const int cn = (c_count - off) < 2048 ? (c_count - off) : 2048;
+        const int nch = cn / 8, tpc = 256 / nch;
+        int chunks = ie_cdiv(HW, tpc * 16);
+        const int cap = n_mul ? 1024 : (N >= 16 ? 64 : 1024 / N);
+        if (chunks > cap) chunks = cap;
+        const int min_chunks = ie_cdiv(HW, tpc * 512);      // bound the fp32 partial sums to <= 512 terms per thread
+        if (chunks < min_chunks) chunks = min_chunks;
+        if (chunks < 1) chunks = 1;
+        hipLaunchKernelGGL((norm_reduce_v8_kernel<BWD, T>), dim3(chunks, N), dim3(256), 0, st, x, dy, yact, mean, inv, ws, HW, C, c_begin + off,
+                           nch, c_count, off, n_mul, act, slope);
+        IE_LAUNCH_CHECK();
+    }
+    return IE_OK;
+}
+
 template <bool BWD, typename T>
 int launch_reduce(const T* x, const T* dy, const T* yact, const float* mean, const float* inv, double* ws, int N, int HW,
                   int C, int c_begin, int c_count, int n_mul, int act, float slope, hipStream_t st) {
+    if constexpr (sizeof(T) == 2) {
+        if (norm_v8_ok<T>(C, c_begin, c_count)) return launch_reduce_v8<BWD, T>(x, dy, yact, mean, inv, ws, N, HW, C, c_begin, c_count, n_mul, act, slope, st);
+    }
     const int groups = n_mul ? N : 1;
     IE_HIP_CHECK(hipMemsetAsync(ws, 0, sizeof(double) * 2 * (size_t)groups * c_count, st));
     for (int off = 0; off < c_count; off += 256) {     // <= 256 channels per launch (one thread column each)
@@ -148,6 +301,14 @@ static int norm_forward_impl(const T* x, const float* gamma, const float* beta, 
                        groups * c_count, count, eps, running_mean, running_var, momentum);
     IE_LAUNCH_CHECK();
     const size_t total = (size_t)N * HW * C;
+    if constexpr (sizeof(T) == 2) {
+        if (norm_v8_ok<T>(C, c_begin, c_count)) {
+            hipLaunchKernelGGL(norm_apply_v8_kernel<T>, dim3(nblk(total / 8)), dim3(256), 0, st, x, save_mean, save_invstd, gamma, beta, y, HW, C / 8,
+                               c_begin, c_count, n_mul, act, slope, total / 8);
+            IE_LAUNCH_CHECK();
+            return IE_OK;
+        }
+    }
     hipLaunchKernelGGL(norm_apply_kernel<T>, dim3(nblk(total)), dim3(256), 0, st, x, save_mean, save_invstd, gamma, beta, y, HW, C, c_begin,
                        c_count, n_mul, act, slope, total);
     IE_LAUNCH_CHECK();
@@ -167,8 +328,14 @@ static int norm_backward_impl(const T* x, const T* dy, const T* y, const float* 
     if (rc != IE_OK) return rc;
     const double count = per_sample ? (double)HW : (double)N * HW;
     const size_t total = (size_t)N * HW * C;
-    hipLaunchKernelGGL(norm_backward_apply_kernel<T>, dim3(nblk(total)), dim3(256), 0, st, x, dy, y, save_mean, save_invstd, gamma, ws, dx,
-                       HW, C, c_begin, c_count, n_mul, count, act, slope, total);
+    bool v8 = false;
+    if constexpr (sizeof(T) == 2) v8 = norm_v8_ok<T>(C, c_begin, c_count);
+    if (v8)
+        hipLaunchKernelGGL(norm_backward_apply_v8_kernel<T>, dim3(nblk(total / 8)), dim3(256), 0, st, x, dy, y, save_mean, save_invstd, gamma, ws, dx,
+                           HW, C / 8, c_begin, c_count, n_mul, count, act, slope, total / 8);
+    else
+        hipLaunchKernelGGL(norm_backward_apply_kernel<T>, dim3(nblk(total)), dim3(256), 0, st, x, dy, y, save_mean, save_invstd, gamma, ws, dx,
+                           HW, C, c_begin, c_count, n_mul, count, act, slope, total);
     IE_LAUNCH_CHECK();
     if (dgamma) {
         hipLaunchKernelGGL(norm_param_grad_kernel, dim3(nblk(c_count)), dim3(256), 0, st, ws, dgamma, dbeta, groups, c_count,

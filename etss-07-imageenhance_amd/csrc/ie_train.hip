@@ -199,28 +199,52 @@ __global__ void store_f64_as_f32_kernel(const double* __restrict__ a, float* y, 
 }
 
 // ---- streaming backward ops ---------------------------------------------------------------------------------------
-// MaxPool2d(2,2): gradient to the first maximum of the window in scan order (torch keeps the first index)
-template <typename T>
+// MaxPool2d(2,2): gradient to the first maximum of the window in scan order (torch keeps the first index).
+// V consecutive channels per thread (8 for 16-bit tensors whose channel count allows: 16-byte accesses).
+template <typename T, int V>
 __global__ void maxpool2_backward_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, int H,
                                          int W, int C, int Ho, int Wo, int accumulate, size_t total) {
+    typedef __attribute__((ext_vector_type(V))) T TV;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    const int c = (int)(i % C);
-    size_t r = i / C;
+    const int CV = C / V;
+    const int c = (int)(i % CV) * V;
+    size_t r = i / CV;
     const int w = (int)(r % W); r /= W;
     const int h = (int)(r % H);
     const size_t n = r / H;
-    float g = 0.f;
+    float g[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) g[k] = 0.f;
     const int ho = h >> 1, wo = w >> 1;
     if (ho < Ho && wo < Wo) {
         const T* p = x + ((n * H + 2 * ho) * W + 2 * wo) * C + c;
-        const float v[4] = {(float)p[0], (float)p[C], (float)p[(size_t)W * C], (float)p[(size_t)W * C + C]};
-        int best = 0;
+        TV v[4];
+        v[0] = *(const TV*)p; v[1] = *(const TV*)(p + C); v[2] = *(const TV*)(p + (size_t)W * C); v[3] = *(const TV*)(p + (size_t)W * C + C);
+        const TV d = *(const TV*)(dy + ((n * Ho + ho) * Wo + wo) * C + c);
+        const int me = (h & 1) * 2 + (w & 1);
 #pragma unroll
-        for (int k = 1; k < 4; ++k) if (v[k] > v[best] || (v[k] != v[k] && v[best] == v[best])) best = k;
-        if (best == ((h & 1) * 2 + (w & 1))) g = (float)dy[((n * Ho + ho) * Wo + wo) * C + c];
+        for (int e = 0; e < V; ++e) {
+            float f[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) f[k] = (float)v[k][e];
+            int best = 0;
+#pragma unroll
+            for (int k = 1; k < 4; ++k) if (f[k] > f[best] || (f[k] != f[k] && f[best] == f[best])) best = k;
+            if (best == me) g[e] = (float)d[e];
+        }
     }
-    dx[i] = (T)((accumulate ? (float)dx[i] : 0.f) + g);
+    T* o = dx + ((n * H + h) * W + w) * C + c;
+    TV out;
+    if (accumulate) {
+        const TV old = *(const TV*)o;
+#pragma unroll
+        for (int e = 0; e < V; ++e) out[e] = (T)((float)old[e] + g[e]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < V; ++e) out[e] = (T)g[e];
+    }
+    *(TV*)o = out;
 }
 
 // source coordinates of destination index o (same float expressions as the forward kernel in ie_ops.hip)
@@ -238,14 +262,16 @@ __device__ __forceinline__ void resize_candidates(int i, int In, int Out, int& l
     lo = max(0, (int)floorf((i - 1) * sc) - 2);
     hi = min(Out - 1, (int)ceilf((i + 2) * sc) + 2);
 }
-// gather form of the resize adjoint: dx[i] = sum over the outputs that read input i of weight * dy[o]
-template <typename T>
+// gather form of the resize adjoint: dx[i] = sum over the outputs that read input i of weight * dy[o]; V channels per thread
+template <typename T, int V>
 __global__ void resize_backward_kernel(const T* __restrict__ dy, T* __restrict__ dx, int Hi, int Wi, int C, int Ho, int Wo,
                                        int mode, int accumulate, size_t total) {
+    typedef __attribute__((ext_vector_type(V))) T TV;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    const int c = (int)(i % C);
-    size_t r = i / C;
+    const int CV = C / V;
+    const int c = (int)(i % CV) * V;
+    size_t r = i / CV;
     const int xi = (int)(r % Wi); r /= Wi;
     const int yi = (int)(r % Hi);
     const size_t n = r / Hi;
@@ -253,7 +279,9 @@ __global__ void resize_backward_kernel(const T* __restrict__ dy, T* __restrict__
     resize_candidates(yi, Hi, Ho, ylo, yhi);
     resize_candidates(xi, Wi, Wo, xlo, xhi);
     const T* p = dy + n * (size_t)Ho * Wo * C + c;
-    float g = 0.f;
+    float g[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) g[e] = 0.f;
     for (int yo = ylo; yo <= yhi; ++yo) {
         int a0, a1; float ly;
         resize_src(yo, Hi, Ho, mode, a0, a1, ly);
@@ -261,18 +289,36 @@ __global__ void resize_backward_kernel(const T* __restrict__ dy, T* __restrict__
         if (mode == 0) wy = (a0 == yi) ? 1.f : 0.f;
         else { if (a0 == yi) wy += 1.f - ly; if (a1 == yi) wy += ly; }
         if (wy == 0.f) continue;
-        float rowacc = 0.f;
+        float rowacc[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) rowacc[e] = 0.f;
         for (int xo = xlo; xo <= xhi; ++xo) {
             int b0, b1; float lx;
             resize_src(xo, Wi, Wo, mode, b0, b1, lx);
             float wx = 0.f;
             if (mode == 0) wx = (b0 == xi) ? 1.f : 0.f;
             else { if (b0 == xi) wx += 1.f - lx; if (b1 == xi) wx += lx; }
-            if (wx != 0.f) rowacc = fmaf(wx, (float)p[((size_t)yo * Wo + xo) * C], rowacc);
+            if (wx != 0.f) {
+                const T* q = p + ((size_t)yo * Wo + xo) * C;
+                const TV d = *(const TV*)q;
+#pragma unroll
+                for (int e = 0; e < V; ++e) rowacc[e] = fmaf(wx, (float)d[e], rowacc[e]);
+            }
         }
-        g = fmaf(wy, rowacc, g);
+#pragma unroll
+        for (int e = 0; e < V; ++e) g[e] = fmaf(wy, rowacc[e], g[e]);
     }
-    dx[i] = (T)((accumulate ? (float)dx[i] : 0.f) + g);
+    T* o = dx + ((n * Hi + yi) * Wi + xi) * C + c;
+    TV out;
+    if (accumulate) {
+        const TV old = *(const TV*)o;
+#pragma unroll
+        for (int e = 0; e < V; ++e) out[e] = (T)((float)old[e] + g[e]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < V; ++e) out[e] = (T)g[e];
+    }
+    *(TV*)o = out;
 }
 
 // adjoint of zero padding: dx[h,w] = dy[h+top, w+left]
@@ -648,8 +694,12 @@ template <typename T>
 static int maxpool_bwd_impl(const void* x, const void* dy, void* dx, int N, int H, int W, int C, int accumulate, void* stream) {
     if (!x || !dy || !dx || N <= 0 || H < 2 || W < 2 || C <= 0) IE_FAIL(IE_ERR_INVALID, "ie_maxpool2x2_backward_nhwc: bad args");
     const size_t total = (size_t)N * H * W * C;
-    hipLaunchKernelGGL(maxpool2_backward_kernel<T>, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)dy, (T*)dx, H, W, C,
-                       H / 2, W / 2, accumulate, total);
+    if (sizeof(T) == 2 && (C & 7) == 0)
+        hipLaunchKernelGGL((maxpool2_backward_kernel<T, 8>), dim3(nblk(total / 8)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)dy, (T*)dx,
+                           H, W, C, H / 2, W / 2, accumulate, total / 8);
+    else
+        hipLaunchKernelGGL((maxpool2_backward_kernel<T, 1>), dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)dy, (T*)dx,
+                           H, W, C, H / 2, W / 2, accumulate, total);
     IE_LAUNCH_CHECK();
     return IE_OK;
 }
@@ -671,8 +721,12 @@ static int resize_bwd_impl(const void* dy, void* dx, int N, int Hi, int Wi, int 
     if (!dy || !dx || N <= 0 || Hi <= 0 || Wi <= 0 || C <= 0 || Ho <= 0 || Wo <= 0 || mode < 0 || mode > 2)
         IE_FAIL(IE_ERR_INVALID, "ie_resize_backward_nhwc: bad args");
     const size_t total = (size_t)N * Hi * Wi * C;
-    hipLaunchKernelGGL(resize_backward_kernel<T>, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, (const T*)dy, (T*)dx, Hi, Wi, C, Ho, Wo, mode,
-                       accumulate, total);
+    if (sizeof(T) == 2 && (C & 7) == 0)
+        hipLaunchKernelGGL((resize_backward_kernel<T, 8>), dim3(nblk(total / 8)), dim3(256), 0, (hipStream_t)stream, (const T*)dy, (T*)dx, Hi, Wi, C, Ho,
+                           Wo, mode, accumulate, total / 8);
+    else
+        hipLaunchKernelGGL((resize_backward_kernel<T, 1>), dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, (const T*)dy, (T*)dx, Hi, Wi, C, Ho,
+                           Wo, mode, accumulate, total);
     IE_LAUNCH_CHECK();
     return IE_OK;
 }

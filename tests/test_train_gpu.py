@@ -115,6 +115,43 @@ def test_norm_forward_backward(per_sample, c, act, c_begin, c_count):
     assert rel_err(host(dg), gr.grad) < 2e-5 and rel_err(host(db), br.grad) < 2e-5
 
 
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("per_sample,c,act,c_begin,c_count", [(False, 64, "relu", 0, None), (True, 32, "lrelu", 0, 16), (True, 32, "lrelu", 16, 16),
+                                                              (False, 2056, "none", 0, None), (True, 24, "relu", 0, None),
+                                                              (False, 20, "relu", 0, None)])
+def test_norm_forward_backward_16bit(per_sample, c, act, c_begin, c_count, dtype):
+    """16-bit norm kernels (8-channel vector path where the channel counts allow, scalar otherwise) vs float64 on the same inputs."""
+    tdt = ops.TORCH_DT[dtype]
+    tol = 1.5e-3 if dtype == "f16" else 1.2e-2
+    n, h, w = 2, 23, 37
+    cc = c - c_begin if c_count is None else c_count
+    x = (rnd(n, c, h, w, seed=1) * 2 + 0.5).to(tdt)
+    dy = rnd(n, c, h, w, seed=4).to(tdt)
+    gamma, beta = 1 + 0.2 * rnd(cc, seed=2), 0.1 * rnd(cc, seed=3)
+    xr, gr, br = x.double().requires_grad_(True), gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    part = xr[:, c_begin:c_begin + cc]
+    yn = F.instance_norm(part, weight=gr, bias=br, eps=1e-5) if per_sample else F.batch_norm(part, None, None, gr, br, True, 0.1, 1e-5)
+    full = torch.cat([xr[:, :c_begin], yn, xr[:, c_begin + cc:]], 1)
+    yref = {"relu": F.relu, "lrelu": lambda t: F.leaky_relu(t, 0.2), "none": lambda t: t}[act](full)
+    xd = x.cuda().contiguous(memory_format=CL)
+    dyd = dy.cuda().contiguous(memory_format=CL)
+    gd, bd = gamma.cuda(), beta.cuda()
+    y, mean, inv = ops.norm_forward(xd, gd, bd, per_sample, None, None, 0.1, 1e-5, act, 0.2, c_begin, c_count)
+    assert y.dtype == tdt
+    dims = (2, 3) if per_sample else (0, 2, 3)
+    mref = part.detach().mean(dims)
+    iref = 1.0 / torch.sqrt(part.detach().var(dims, unbiased=False) + 1e-5)
+    assert rel_err(host(mean).reshape(mref.shape), mref) < 1e-5 and rel_err(host(inv).reshape(iref.shape), iref) < 1e-5
+    assert rel_err(host(y), yref.detach()) < tol
+    # backward from the device's own (rounded) activation output, as the training tape does
+    yref.backward(dy.double())
+    dg, db = torch.empty(cc, device="cuda"), torch.empty(cc, device="cuda")
+    dx = ops.norm_backward(xd, dyd, y, gd, mean, inv, per_sample, dg, db, False, act, 0.2, c_begin, c_count)
+    assert dx.dtype == tdt
+    assert rel_err(host(dx), xr.grad) < tol
+    assert rel_err(host(dg), gr.grad) < tol and rel_err(host(db), br.grad) < tol
+
+
 # ---- conv gradients ------------------------------------------------------------------------------------------------------
 CONV_CASES = [
     dict(cs=[16], co=16, k=3, s=1, p=1),
@@ -238,6 +275,37 @@ def test_resize_backward(mode, hi, wi, ho, wo):
     assert rel_err(host(dx), x.grad + 2.0) < 1e-5
     ops.resize_backward(dev(dy), dx, mode, 0)
     assert rel_err(host(dx), x.grad) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("c", [16, 40, 6])            # multiples of 8 -> 16-byte vector kernels, 6 -> scalar
+def test_maxpool_resize_backward_16bit(c, dtype):
+    tdt = ops.TORCH_DT[dtype]
+    tol = 1e-3 if dtype == "f16" else 8e-3
+    x = F.relu(rnd(2, c, 11, 14, seed=1)).to(tdt)
+    xr = x.double().requires_grad_(True)
+    y = F.max_pool2d(xr, 2)
+    dy = rnd(*y.shape, seed=2).to(tdt)
+    y.backward(dy.double())
+    xd = x.cuda().contiguous(memory_format=CL)
+    dyd = dy.cuda().contiguous(memory_format=CL)
+    dx = torch.empty_like(xd, memory_format=CL)
+    ops.maxpool2x2_backward(xd, dyd, dx, 0)
+    assert torch.equal(host(dx).double(), xr.grad)                       # routing only: exact
+    ops.maxpool2x2_backward(xd, dyd, dx, 1)
+    assert rel_err(host(dx), 2 * xr.grad) < tol
+    for mode, (hi, wi, ho, wo) in (("bilinear_align", (7, 9, 14, 18)), ("bilinear", (8, 12, 16, 24)), ("nearest", (5, 6, 20, 24))):
+        xr = torch.zeros(2, c, hi, wi, dtype=torch.float64, requires_grad=True)
+        yr = F.interpolate(xr, size=(ho, wo)) if mode == "nearest" else F.interpolate(xr, size=(ho, wo), mode="bilinear",
+                                                                                      align_corners=(mode == "bilinear_align"))
+        g = rnd(*yr.shape, seed=3).to(tdt)
+        yr.backward(g.double())
+        gd = g.cuda().contiguous(memory_format=CL)
+        dx = torch.empty(2, c, hi, wi, device="cuda", dtype=tdt).contiguous(memory_format=CL)
+        ops.resize_backward(gd, dx, mode, 0)
+        assert rel_err(host(dx), xr.grad) < tol
+        ops.resize_backward(gd, dx, mode, 1)
+        assert rel_err(host(dx), 2 * xr.grad) < 2 * tol
 
 
 def test_crop_unshuffle_act_backward():
