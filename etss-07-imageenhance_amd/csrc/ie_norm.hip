@@ -171,68 +171,106 @@ __global__ __launch_bounds__(256) void norm_reduce_v8_kernel(const T* __restrict
     }
 }
 
+// Apply passes: thread = (pixel slot, 8-channel chunk) walking down the image, so the per-channel coefficients are
+// fetched once per thread and the loop body is one 16-byte load (three in the backward pass), a few FMAs and one
+// 16-byte store.  Grid: (pixel chunks, N, channel blocks of <= 256 chunks); nchb = chunks per channel block.
 template <typename T>
 __global__ __launch_bounds__(256) void norm_apply_v8_kernel(const T* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ inv,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ y,
-                                                            int HW, int C8, int c0, int cn, int n_mul, int act, float slope, size_t total8) {
+                                                            int HW, int C, int c0, int cn, int n_mul, int act, float slope, int nchb) {
     typedef typename ie_vec8<T>::type V;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total8) return;
-    const int c = (int)(i % C8) * 8;
-    const V xv = *(const V*)(x + i * 8);
-    V out;
-    if (c >= c0 && c < c0 + cn) {
-        const size_t g = (i / ((size_t)HW * C8)) * n_mul;
-        const float* mp = mean + g * cn + (c - c0);
-        const float* ip = inv + g * cn + (c - c0);
+    const int n = blockIdx.y;
+    const int tpc = 256 / nchb;
+    const int c = (blockIdx.z * nchb + threadIdx.x % nchb) * 8, ps = threadIdx.x / nchb;
+    if (ps >= tpc || c >= C) return;
+    const bool in = c >= c0 && c < c0 + cn;
+    float m[8], iv[8], ga[8], be[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        m[k] = 0.f; iv[k] = 1.f; ga[k] = 1.f; be[k] = 0.f;
+        if (in) {
+            const size_t idx = (size_t)n * n_mul * cn + (c - c0) + k;
+            m[k] = mean[idx]; iv[k] = inv[idx];
+            if (gamma) { ga[k] = gamma[c - c0 + k]; be[k] = beta[c - c0 + k]; }
+        }
+    }
+    const size_t base = (size_t)n * HW * C + c;
+    for (int pix = blockIdx.x * tpc + ps; pix < HW; pix += gridDim.x * tpc) {
+        const size_t i = base + (size_t)pix * C;
+        const V xv = *(const V*)(x + i);
+        V out;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            float v = ((float)xv[k] - mp[k]) * ip[k];
-            if (gamma) v = v * gamma[c - c0 + k] + beta[c - c0 + k];
+            float v = (float)xv[k];
+            if (in) { v = (v - m[k]) * iv[k]; if (gamma) v = v * ga[k] + be[k]; }
             out[k] = (T)ie_act_apply(v, act, slope);
         }
-    } else {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) out[k] = (T)ie_act_apply((float)xv[k], act, slope);
+        *(V*)(y + i) = out;
     }
-    *(V*)(y + i * 8) = out;
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void norm_backward_apply_v8_kernel(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ yact,
+__global__ __launch_bounds__(256, 4) void norm_backward_apply_v8_kernel(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ yact,
                                                                      const float* __restrict__ mean, const float* __restrict__ inv,
                                                                      const float* __restrict__ gamma, const double* __restrict__ stats,
-                                                                     T* __restrict__ dx, int HW, int C8, int c0, int cn, int n_mul, double count,
-                                                                     int act, float slope, size_t total8) {
+                                                                     T* __restrict__ dx, int HW, int C, int c0, int cn, int n_mul, double count,
+                                                                     int act, float slope, int nchb) {
     typedef typename ie_vec8<T>::type V;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total8) return;
-    const int c = (int)(i % C8) * 8;
-    const V dv = *(const V*)(dy + i * 8);
-    float gr[8];
+    const int n = blockIdx.y;
+    const int tpc = 256 / nchb;
+    const int c = (blockIdx.z * nchb + threadIdx.x % nchb) * 8, ps = threadIdx.x / nchb;
+    if (ps >= tpc || c >= C) return;
+    const bool in = c >= c0 && c < c0 + cn;
+    float m[8], iv[8], gi[8], m1[8], m2[8];
+    const double rcount = 1.0 / count;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) gr[k] = (float)dv[k];
-    if (act != IE_ACT_NONE) {
-        const V yv = *(const V*)(yact + i * 8);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) gr[k] *= ie_act_grad_from_output((float)yv[k], act, slope);
-    }
-    V out;
-    if (c >= c0 && c < c0 + cn) {
-        const V xv = *(const V*)(x + i * 8);
-        const size_t kb = (i / ((size_t)HW * C8)) * n_mul * cn + (c - c0);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float iv = inv[kb + k];
-            const float xh = ((float)xv[k] - mean[kb + k]) * iv;
-            const float m1 = (float)(stats[2 * (kb + k)] / count), m2 = (float)(stats[2 * (kb + k) + 1] / count);
-            out[k] = (T)((gamma ? gamma[c - c0 + k] : 1.f) * iv * (gr[k] - m1 - xh * m2));
+    for (int k = 0; k < 8; ++k) {
+        m[k] = 0.f; iv[k] = 1.f; gi[k] = 1.f; m1[k] = 0.f; m2[k] = 0.f;
+        if (in) {
+            const size_t idx = (size_t)n * n_mul * cn + (c - c0) + k;
+            m[k] = mean[idx]; iv[k] = inv[idx];
+            gi[k] = (gamma ? gamma[c - c0 + k] : 1.f) * iv[k];
+            m1[k] = (float)(stats[2 * idx] * rcount); m2[k] = (float)(stats[2 * idx + 1] * rcount);
         }
-    } else {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) out[k] = (T)gr[k];
     }
-    *(V*)(dx + i * 8) = out;
+    const size_t base = (size_t)n * HW * C + c;
+    for (int pix = blockIdx.x * tpc + ps; pix < HW; pix += gridDim.x * tpc) {
+        const size_t i = base + (size_t)pix * C;
+        const V dv = *(const V*)(dy + i);
+        float gr[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) gr[k] = (float)dv[k];
+        if (act != IE_ACT_NONE) {
+            const V yv = *(const V*)(yact + i);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) gr[k] *= ie_act_grad_from_output((float)yv[k], act, slope);
+        }
+        V out;
+        if (in) {
+            const V xv = *(const V*)(x + i);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float xh = ((float)xv[k] - m[k]) * iv[k];
+                out[k] = (T)(gi[k] * (gr[k] - m1[k] - xh * m2[k]));
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) out[k] = (T)gr[k];
+        }
+        *(V*)(dx + i) = out;
+    }
+}
+
+// grid of the apply passes: ~8 pixels per thread, at most ~8192 workgroups
+inline dim3 norm_apply_v8_grid(int N, int HW, int C, int& nchb) {
+    const int C8 = C / 8;
+    nchb = C8 < 256 ? C8 : 256;
+    const int tpc = 256 / nchb;
+    int chunks = ie_cdiv(HW, tpc * 8);
+    const int cap = ie_cdiv(8192, N);
+    if (chunks > cap) chunks = cap;
+    if (chunks < 1) chunks = 1;
+    return dim3(chunks, N, ie_cdiv(C8, nchb));
 }
 
 template <typename T> constexpr bool norm_v8_ok(int C, int c_begin, int c_count) {
@@ -303,8 +341,10 @@ static int norm_forward_impl(const T* x, const float* gamma, const float* beta, 
     const size_t total = (size_t)N * HW * C;
     if constexpr (sizeof(T) == 2) {
         if (norm_v8_ok<T>(C, c_begin, c_count)) {
-            hipLaunchKernelGGL(norm_apply_v8_kernel<T>, dim3(nblk(total / 8)), dim3(256), 0, st, x, save_mean, save_invstd, gamma, beta, y, HW, C / 8,
-                               c_begin, c_count, n_mul, act, slope, total / 8);
+            int nchb;
+            const dim3 grid = norm_apply_v8_grid(N, HW, C, nchb);
+            hipLaunchKernelGGL(norm_apply_v8_kernel<T>, grid, dim3(256), 0, st, x, save_mean, save_invstd, gamma, beta, y, HW, C, c_begin, c_count,
+                               n_mul, act, slope, nchb);
             IE_LAUNCH_CHECK();
             return IE_OK;
         }
@@ -330,10 +370,14 @@ static int norm_backward_impl(const T* x, const T* dy, const T* y, const float* 
     const size_t total = (size_t)N * HW * C;
     bool v8 = false;
     if constexpr (sizeof(T) == 2) v8 = norm_v8_ok<T>(C, c_begin, c_count);
-    if (v8)
-        hipLaunchKernelGGL(norm_backward_apply_v8_kernel<T>, dim3(nblk(total / 8)), dim3(256), 0, st, x, dy, y, save_mean, save_invstd, gamma, ws, dx,
-                           HW, C / 8, c_begin, c_count, n_mul, count, act, slope, total / 8);
-    else
+    if (v8) {
+        if constexpr (sizeof(T) == 2) {
+            int nchb;
+            const dim3 grid = norm_apply_v8_grid(N, HW, C, nchb);
+            hipLaunchKernelGGL(norm_backward_apply_v8_kernel<T>, grid, dim3(256), 0, st, x, dy, y, save_mean, save_invstd, gamma, ws, dx, HW, C,
+                               c_begin, c_count, n_mul, count, act, slope, nchb);
+        }
+    } else
         hipLaunchKernelGGL(norm_backward_apply_kernel<T>, dim3(nblk(total)), dim3(256), 0, st, x, dy, y, save_mean, save_invstd, gamma, ws, dx,
                            HW, C, c_begin, c_count, n_mul, count, act, slope, total);
     IE_LAUNCH_CHECK();
