@@ -535,8 +535,6 @@ class UNet(_GraphModel):
                 y = T.t_norm(tape, z, store.view(f"{nn_}.weight"), store.view(f"{nn_}.bias"), store.view(f"{nn_}.weight", store.grads),
                              store.view(f"{nn_}.bias", store.grads), per_sample=False, running_mean=store.buffers[f"{nn_}.running_mean"],
                              running_var=store.buffers[f"{nn_}.running_var"], momentum=0.1, eps=1e-5, act="relu")
-                if mixed and y.dtype == torch.float32:
-                    y = T.t_cast(tape, y, tdt)         # the RGB edge runs in fp32; everything after the first Conv-BN-ReLU is 16-bit
                 srcs = [y]
             return y
 
@@ -549,15 +547,19 @@ class UNet(_GraphModel):
             a = T.t_pad(tape, a, dy // 2, dy - dy // 2, dx // 2, dx - dx // 2)
             return dc(f"up{k}.conv", [skip, a])
 
+        if mixed:
+            x = T.t_cast(tape, x, tdt, channels=16)    # RGB carried as 16 channels: the first layer runs on the matrix cores too
         x1 = dc("inc", [x])
         x2 = dc("down1.conv", [T.t_maxpool(tape, x1)])
         x3 = dc("down2.conv", [T.t_maxpool(tape, x2)])
         x4 = dc("down3.conv", [T.t_maxpool(tape, x3)])
         x5 = dc("down4.conv", [T.t_maxpool(tape, x4)])
         y = up(1, x5, x4); y = up(2, y, x3); y = up(3, y, x2); y = up(4, y, x1)
-        if mixed:
-            y = T.t_cast(tape, y, torch.float32)       # the 3-channel head, the clamp and the loss run in fp32
-        y = T.t_conv(tape, y, store.conv("outc.conv"), *store.conv_grads("outc.conv"), pad=0)
+        if mixed:                                      # head computed as 16 output channels; the clamp and the loss run in fp32
+            y = T.t_conv(tape, y, store.conv("outc.conv"), *store.conv_grads("outc.conv"), pad=0, cout_pad=16)
+            y = T.t_cast(tape, y, torch.float32, channels=self.out_channels)
+        else:
+            y = T.t_conv(tape, y, store.conv("outc.conv"), *store.conv_grads("outc.conv"), pad=0)
         return T.t_clamp(tape, y, 0.0, 1.0) if self.enhance else y
 
     def assert_outputs(self, outputs: dict):

@@ -110,22 +110,34 @@ class ParamStore:
         cw.store, cw.name = self, name
         return cw
 
-    def conv16(self, name, split):
+    def conv16(self, name, split, cout_pad=None):
         """Packed 16-bit weights of conv ``name`` over sources ``split`` for the matrix-core forward and for the data gradient of
-        every source, produced on the device from the fp32 master weights and refreshed by ``repack16()`` after every step."""
-        key = (name, tuple(split))
+        every source, produced on the device from the fp32 master weights and refreshed by ``repack16()`` after every step.
+
+        Channel-padded edges (the RGB input carried as 16 channels, the 3-channel head computed as 16): ``sum(split)`` may exceed the
+        layer's Cin (single source) and ``cout_pad`` its Cout; the packers then read a zero-padded fp32 scratch copy of the master
+        weights (``pad`` in the returned triple: scratch weights / bias and their gradient twins), refreshed before every repack."""
+        key = (name, tuple(split), cout_pad)
         if key not in self._c16:
             _, _, (co, ci, kh, kw), _ = self.index[f"{name}.weight"]
             dt = ops.TORCH_DT[self.compute_dtype]
             b = self.view(f"{name}.bias") if f"{name}.bias" in self.index else None
             w = self.view(f"{name}.weight")
-            fwd = ops.MConvWeightsDev(w, b, list(split), co, kh, kw, dt)
-            dg = [ops.MConvWeightsDev(w, None, list(split), co, kh, kw, dt, mode="dgrad", src_index=i) for i in range(len(split))]
-            self._c16[key] = (fwd, dg)
+            cin_p, co_p, pad = sum(split), cout_pad or co, None
+            if cin_p != ci or co_p != co:
+                if cin_p < ci or co_p < co or (cin_p != ci and len(split) != 1):
+                    raise capi.IEError(f"conv16 {name}: cannot pad {ci}->{co} to {list(split)}->{co_p}")
+                pad = _PaddedEdge(w, b, kh * kw, ci, co, cin_p, co_p)
+                w, b = pad.w, pad.b
+            fwd = ops.MConvWeightsDev(w, b, list(split), co_p, kh, kw, dt)
+            dg = [ops.MConvWeightsDev(w, None, list(split), co_p, kh, kw, dt, mode="dgrad", src_index=i) for i in range(len(split))]
+            self._c16[key] = (fwd, dg, pad)
         return self._c16[key]
 
     def repack16(self):
-        for fwd, dg in self._c16.values():
+        for fwd, dg, pad in self._c16.values():
+            if pad is not None:
+                pad.refresh()
             fwd.repack()
             for g in dg:
                 g.repack()
@@ -156,10 +168,37 @@ class ParamStore:
         return out
 
 
+class _PaddedEdge:
+    """Zero-padded fp32 scratch copy [taps][cin_p][co_p] of a conv's master weights [taps][ci][co] (and bias), plus gradient scratch of
+    the same shape: device-to-device slice copies only, the arithmetic stays in the kernels."""
+
+    def __init__(self, w, b, taps, ci, co, cin_p, co_p):
+        self.src_w, self.src_b, self.dims = w, b, (taps, ci, co, cin_p, co_p)
+        self.w = torch.zeros(taps * cin_p * co_p, device=w.device, dtype=torch.float32)
+        self.b = None if b is None else torch.zeros(co_p, device=w.device, dtype=torch.float32)
+        self.dw = torch.zeros_like(self.w)
+        self.db = None if b is None else torch.zeros_like(self.b)
+        self.refresh()
+
+    def refresh(self):
+        taps, ci, co, cin_p, co_p = self.dims
+        self.w.view(taps, cin_p, co_p)[:, :ci, :co].copy_(self.src_w.view(taps, ci, co))
+        if self.b is not None:
+            self.b[:co].copy_(self.src_b)
+
+    def scatter_grads(self, dw, db):
+        taps, ci, co, cin_p, co_p = self.dims
+        dw.view(taps, ci, co).copy_(self.dw.view(taps, cin_p, co_p)[:, :ci, :co])
+        if db is not None:
+            db.copy_(self.db[:co])
+
+
 # ---- taped ops ---------------------------------------------------------------------------------------------------------
 def t_cast(tape, x, dtype, channels=None):
     """dtype (and channel count) change between the fp32 edges and the 16-bit interior of the mixed-precision graph."""
     y = ops.cast(x, dtype, channels)
+    if tape.is_no_grad(x):
+        return tape.no_grad(y)
 
     def bwd():
         g = tape.grad(y)
@@ -175,17 +214,23 @@ def t_cast(tape, x, dtype, channels=None):
     return y
 
 
-def t_conv16(tape, srcs, cw, dw, db, pad=1):
-    """16-bit conv (stride 1, zero padding, no fused activation): forward and data gradient on the matrix cores with weights
-    packed on the device from the fp32 master copy, weight gradient by the fp32-accumulating kernel on the 16-bit tensors."""
-    fwd, dgw = cw.store.conv16(cw.name, [int(s.shape[1]) for s in srcs])
+def t_conv16(tape, srcs, cw, dw, db, pad=1, cout_pad=None):
+    """16-bit conv (stride 1, zero padding, no fused activation): forward, data gradient and (3x3) weight gradient on the matrix
+    cores, weights packed on the device from the fp32 master copy; fp32 gradient accumulation.  ``cout_pad`` / sources wider than
+    the layer's Cin: channel-padded edges (``ParamStore.conv16``)."""
+    fwd, dgw, edge = cw.store.conv16(cw.name, [int(s.shape[1]) for s in srcs], cout_pad)
     y = ops.mconv2d(srcs, fwd, pad=pad)
 
     def bwd():
         dy = tape.grad(y)
         if dy is None:
             return
-        ops.conv2d_wgrad(srcs, dy, cw, dw, db, 1, pad, "zeros")
+        if edge is None:
+            ops.conv2d_wgrad(srcs, dy, cw, dw, db, 1, pad, "zeros")
+        else:
+            ev = ops.ConvWeightsView(edge.w, edge.b, fwd.cout, sum(fwd.split), cw.kh, cw.kw)
+            ops.conv2d_wgrad(srcs, dy, ev, edge.dw, edge.db if db is not None else None, 1, pad, "zeros")
+            edge.scatter_grads(dw, db)
         for i, src in enumerate(srcs):
             if tape.is_no_grad(src):
                 continue
@@ -199,13 +244,13 @@ def t_conv16(tape, srcs, cw, dw, db, pad=1):
     return y
 
 
-def t_conv(tape, srcs, cw, dw, db, stride=1, pad=1, pad_mode="zeros", act="none", slope=0.0):
+def t_conv(tape, srcs, cw, dw, db, stride=1, pad=1, pad_mode="zeros", act="none", slope=0.0, cout_pad=None):
     if isinstance(srcs, torch.Tensor):
         srcs = [srcs]
     if srcs[0].dtype != torch.float32:
         if stride != 1 or pad_mode != "zeros" or act != "none":
             raise capi.IEError("the 16-bit training conv supports stride 1, zero padding and no fused activation")
-        return t_conv16(tape, srcs, cw, dw, db, pad)
+        return t_conv16(tape, srcs, cw, dw, db, pad, cout_pad)
     y = ops.conv2d(srcs, cw, stride=stride, pad=pad, pad_mode=pad_mode, act=act, slope=slope)
 
     def bwd():
