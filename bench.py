@@ -226,16 +226,19 @@ def main():
                 except Exception as e:                       # a side measurement must never take the headline line down
                     extras[tag] = f"failed: {e}"[:200]
                 torch.cuda.empty_cache()
-            try:
-                m3 = mon_amd.MODELS.build(name="unet", base_channels=64, num_classes=3, enhance=True, seed=1).to(dev)
-                tr = mon_amd.Trainer(m3, optimizer={"name": "adam", "lr": 1e-4}, loss={"name": "l1_ssim_loss"}, gradient_clip_val=0.1)
-                tgt = torch.rand(2, 3, H, W, device=dev)
-                img = (tgt ** 2.2 * 0.4).contiguous()
-                extras["unet64_train_l1ssim_fp32_1080p_frames_per_s"] = round(2 / timed(lambda: tr.training_step({"image": img, "ref_image": tgt}), 2), 2)
-                del m3, tr, tgt, img
-            except Exception as e:
-                extras["unet64_train_l1ssim_fp32_1080p_frames_per_s"] = f"failed: {e}"[:200]
-            torch.cuda.empty_cache()
+            # BASELINE.json configs[4]'s step (U-Net-64, L1+SSIM, Adam + clip) at 2 frames: the fp32 parity graph and the 16-bit graph
+            for tag, cdt in (("unet64_train_l1ssim_fp32_1080p_frames_per_s", "f32"), ("unet64_train_l1ssim_bf16_1080p_frames_per_s", "bf16")):
+                try:
+                    m3 = mon_amd.MODELS.build(name="unet", base_channels=64, num_classes=3, enhance=True, seed=1).to(dev)
+                    tr = mon_amd.Trainer(m3, optimizer={"name": "adam", "lr": 1e-4}, loss={"name": "l1_ssim_loss"}, gradient_clip_val=0.1,
+                                         compute_dtype=cdt)
+                    tgt = torch.rand(2, 3, H, W, device=dev)
+                    img = (tgt ** 2.2 * 0.4).contiguous()
+                    extras[tag] = round(2 / timed(lambda: tr.training_step({"image": img, "ref_image": tgt}), 2), 2)
+                    del m3, tr, tgt, img
+                except Exception as e:
+                    extras[tag] = f"failed: {e}"[:200]
+                torch.cuda.empty_cache()
 
         line = {
             "metric": "enhanced_images_per_sec_1080p", "value": round(value, 2), "unit": "images/s",

@@ -539,7 +539,11 @@ __global__ void adam_kernel(float* __restrict__ param, const float* __restrict__
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     float coef = 1.f;
-    if (sumsq && max_norm > 0.f) coef = fminf(1.f, max_norm / ((float)sqrt(*sumsq) + 1e-6f));
+    if (sumsq) {
+        const double ss = *sumsq;
+        if (!(ss < INFINITY)) return;            // overflowed 16-bit gradients (inf / NaN norm): skip the step, as AMP's GradScaler does
+        if (max_norm > 0.f) coef = fminf(1.f, max_norm / ((float)sqrt(ss) + 1e-6f));
+    }
     float g = grad[i] * grad_scale * coef;
     const float w = param[i];
     if (wd != 0.f) g = fmaf(wd, w, g);

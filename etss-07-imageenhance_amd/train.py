@@ -473,7 +473,7 @@ class Trainer:
     ``process_group``: torch.distributed group for data parallelism (default group when initialised)."""
 
     def __init__(self, model, optimizer: dict | None = None, loss=None, gradient_clip_val: float | None = 0.1, process_group=None,
-                 compute_dtype: str = "f32"):
+                 compute_dtype: str = "f32", loss_scale: float | None = None):
         if not hasattr(model, "forward_train"):
             raise capi.IEError(f"{model.__class__.__name__} has no training graph (forward_train)")
         model._require_cuda()
@@ -500,6 +500,10 @@ class Trainer:
         if cd != "f32" and not getattr(model, "supports_mixed_training", False):
             raise capi.IEError(f"{model.__class__.__name__} has no 16-bit training graph")
         self.compute_dtype = cd
+        # Static loss scale (AMP): the seed gradient is multiplied by it and the optimiser divides it out again.  fp16 needs it --
+        # a mean-reduced loss over a 1080p batch seeds ~1e-7 per element, below fp16's normal range; bf16 / fp32 do not.  With
+        # clipping on, a step whose scaled gradients overflowed (non-finite norm) is skipped by ie_adam_step_f32.
+        self.loss_scale = float(loss_scale) if loss_scale else (8192.0 if cd == "f16" else 1.0)
         self.store = ParamStore(model, self.device, cd)
         self._sumsq = torch.zeros(1, device=self.device, dtype=torch.float64)
         self._sumsq_ws = torch.zeros(capi.SUMSQ_WS_DOUBLES, device=self.device, dtype=torch.float64)
@@ -555,10 +559,10 @@ class Trainer:
     def backward(self, outputs: dict):
         tape, pred, loss = outputs["_tape"], outputs["enhanced"], outputs["loss"]
         if loss.seed_fn is not None:
-            loss.seed_fn(tape)
+            loss.seed_fn(tape, self.loss_scale) if self.loss_scale != 1.0 else loss.seed_fn(tape)
         else:
             g = torch.empty_like(pred, memory_format=CL)
-            loss.backward_into(g, False, 1.0)
+            loss.backward_into(g, False, self.loss_scale)
             tape.seed(pred, g)
         tape.backward()
 
@@ -566,7 +570,7 @@ class Trainer:
         """DDP mean of the gradients (one flat all-reduce over RCCL) -> clip_grad_norm_ -> Adam, three launches."""
         from .sharding import allreduce_gradients
         st = self.store
-        scale = allreduce_gradients(st.grads, self.group)
+        scale = allreduce_gradients(st.grads, self.group) / self.loss_scale
         self.step += 1
         L = capi.lib()
         with torch.cuda.device(self.device):
@@ -596,7 +600,12 @@ class Trainer:
         return self.store.export()
 
     def gradients(self):
-        return self.store.export(self.store.grads)
+        """Checkpoint-layout gradients of the last backward pass (loss scale divided out)."""
+        g = self.store.export(self.store.grads)
+        if self.loss_scale != 1.0:
+            for k in g:
+                g[k] /= self.loss_scale
+        return g
 
     # ---- checkpoint / resume (Lightning's ModelCheckpoint writes {"state_dict", "optimizer_states", "global_step", ...};
     #      nn/callback/model_checkpoint.py:35-185 -- the same top-level keys are used so mon's loaders find "state_dict") ----

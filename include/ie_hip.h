@@ -254,7 +254,8 @@ int ie_ssim_backward_f32(const float* x_dev, const float* y_dev, const float* d_
 #define IE_SUMSQ_WS_DOUBLES 2048
 int ie_sumsq_f32(const float* a_dev, size_t n, float scale, double* acc_dev, double* ws_dev, int zero_first, void* stream);
 /* torch.optim.Adam step t=`step` (>=1) on a flat buffer: g = grad*grad_scale*min(1, max_norm/(sqrt(*sumsq_dev)+1e-6))
- * (+ weight_decay*p); sumsq_dev NULL or max_norm <= 0 disables clipping. */
+ * (+ weight_decay*p); sumsq_dev NULL or max_norm <= 0 disables clipping.  A non-finite *sumsq_dev (overflowed fp16 gradients under
+ * loss scaling) leaves parameters and moments untouched -- torch.cuda.amp.GradScaler's skipped step. */
 int ie_adam_step_f32(float* param_dev, const float* grad_dev, float* exp_avg_dev, float* exp_avg_sq_dev, size_t n, int step, float lr,
                      float beta1, float beta2, float eps, float weight_decay, float grad_scale, const double* sumsq_dev,
                      float max_norm, void* stream);

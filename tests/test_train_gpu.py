@@ -1,6 +1,8 @@
 """GPU parity of the training path: every backward kernel against torch.autograd on the CPU, the
 L1/SSIM losses against oracle/train.py, and whole optimiser steps of U-Net (loss, per-parameter gradients, post-step
 weights, BatchNorm running statistics) against the torch-CPU restatement."""
+import math
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -673,3 +675,26 @@ def test_unet_mixed_precision_training_step(dt, min_cos):
             assert float((sd1[k] - ref).abs().max()) < 2e-2 * max(1.0, float(ref.abs().max())), k
     with pytest.raises(capi.IEError):
         mon_amd.Trainer(mon_amd.MODELS.build(name="zero_dce_re", seed=1).to("cuda"), compute_dtype="bf16")
+
+
+def test_fp16_loss_scale_and_skipped_step():
+    """fp16 graph: the default static loss scale is divided out of the reported gradients and of the update; a scale that overflows
+    the 16-bit gradients gives a non-finite norm and the optimiser leaves parameters and moments untouched (GradScaler semantics)."""
+    batches = _batches(2, 48, 64, 1, seed=14)
+    batch = {"image": batches[0][0], "ref_image": batches[0][1]}
+    mk = lambda **kw: mon_amd.Trainer(_unet("bilinear", seed=13, base=16), optimizer={"name": "adam", "lr": 1e-3, "eps": 1e-3},
+                                      loss={"name": "l1_ssim_loss"}, gradient_clip_val=0.1, compute_dtype="f16", **kw)
+    t1, t2 = mk(), mk(loss_scale=64.0)
+    assert t1.loss_scale == 8192.0 and t2.loss_scale == 64.0
+    t1.training_step(batch); t2.training_step(batch)
+    g1, g2 = t1.gradients(), t2.gradients()
+    a = torch.cat([g1[k].double().reshape(-1) for k in g1]); b = torch.cat([g2[k].double().reshape(-1) for k in g2])
+    assert float((a * b).sum() / (a.norm() * b.norm())) > 0.995 and abs(float(a.norm() / b.norm()) - 1.0) < 0.02
+    assert abs(t1.grad_norm() / t2.grad_norm() - 1.0) < 0.02
+    t3 = mk(loss_scale=1e12)
+    sd0 = t3.state_dict()
+    t3.training_step(batch)
+    assert not math.isfinite(t3.grad_norm())
+    sd1 = t3.state_dict()
+    assert all(torch.equal(sd0[k], sd1[k]) for k in sd0 if "running_" not in k)
+    assert float(t3.store.exp_avg.abs().max()) == 0.0
