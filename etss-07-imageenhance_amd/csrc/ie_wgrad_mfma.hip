@@ -94,7 +94,6 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_kernel(WgradMParams p)
         for (int cob = 0; cob < 4; ++cob) boff[cob][h] = wm_unit_off(g * 8 + h * 4 + q, cob * 4 + pp);
     }
     const bool wave_live = ci_t + cb * 16 < p.Cs;
-    const int ncob = min(4, (p.Cout - co_t + 15) >> 4);
 
     ie_f32x4 acc[9][4];
 #pragma unroll
@@ -107,33 +106,45 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_kernel(WgradMParams p)
     for (int r = 0; r < 3; ++r) st_x(r, ld_x(y0 - 1 + r, xa_ok, gx_a), ld_x(y0 - 1 + r, xb_ok, gx_b));
     *(ie_u32x4*)(lds + doff) = ld_d(y0);
 
-    for (int y = y0; y < y1; ++y) {
+    // Global loads run TWO steps ahead of their use (two register sets, the loop is unrolled by two): a step's MFMA work
+    // (36 per wave, ~0.3 us) is shorter than the HBM latency, one step of look-ahead left the matrix cores idle ~75 %.
+    struct Pf { ie_u32x4 xa, xb, d; };
+    auto fetch = [&](int yx, int yd, bool on) -> Pf {
+        Pf f = {zero4, zero4, zero4};
+        if (on) { f.xa = ld_x(yx, xa_ok, gx_a); f.xb = ld_x(yx, xb_ok, gx_b); f.d = ld_d(yd); }
+        return f;
+    };
+    auto step = [&](int y, const Pf& wr, Pf& ld) {
         __syncthreads();
         const int rr = y - y0;                      // ring index of input row y-1
-        const bool more = y + 1 < y1;
-        ie_u32x4 nxa = zero4, nxb = zero4, nd = zero4;
-        if (more) { nxa = ld_x(y + 2, xa_ok, gx_a); nxb = ld_x(y + 2, xb_ok, gx_b); nd = ld_d(y + 1); }
+        ld = fetch(y + 3, y + 2, y + 2 < y1);
         if (wave_live) {
             const unsigned char* dyb = lds + 4 * WM_ROWB + (rr & 1) * WM_DYB;
             typename ie_elem<T>::frag b[4];
 #pragma unroll
             for (int cob = 0; cob < 4; ++cob) b[cob] = wm_frag<T>(dyb, boff[cob][0], boff[cob][1]);
+            // A fragments run two taps ahead of the MFMAs that consume them (3 rotating register sets); output channels past
+            // Cout see zero dY fragments, so all four MFMAs of a tap issue unconditionally (no branches inside the chain)
+            const unsigned char* xr[3] = {lds + (rr & 3) * WM_ROWB, lds + ((rr + 1) & 3) * WM_ROWB, lds + ((rr + 2) & 3) * WM_ROWB};
+            typename ie_elem<T>::frag a[3];
+            a[0] = wm_frag<T>(xr[0], aoff[0][0], aoff[0][1]);
+            a[1] = wm_frag<T>(xr[0], aoff[1][0], aoff[1][1]);
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const unsigned char* xb = lds + ((rr + ky) & 3) * WM_ROWB;
+            for (int tap = 0; tap < 9; ++tap) {
+                if (tap + 2 < 9) a[(tap + 2) % 3] = wm_frag<T>(xr[(tap + 2) / 3], aoff[(tap + 2) % 3][0], aoff[(tap + 2) % 3][1]);
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const typename ie_elem<T>::frag a = wm_frag<T>(xb, aoff[kx][0], aoff[kx][1]);
-#pragma unroll
-                    for (int cob = 0; cob < 4; ++cob)
-                        if (cob < ncob) acc[ky * 3 + kx][cob] = ie_elem<T>::mfma16(a, b[cob], acc[ky * 3 + kx][cob]);
-                }
+                for (int cob = 0; cob < 4; ++cob) acc[tap][cob] = ie_elem<T>::mfma16(a[tap % 3], b[cob], acc[tap][cob]);
             }
         }
-        if (more) {
-            st_x(rr + 3, nxa, nxb);
-            *(ie_u32x4*)(lds + doff + ((rr + 1) & 1) * WM_DYB) = nd;
+        if (y + 1 < y1) {                           // rows fetched during the previous step: input row y+2, dY row y+1
+            st_x(rr + 3, wr.xa, wr.xb);
+            *(ie_u32x4*)(lds + doff + ((rr + 1) & 1) * WM_DYB) = wr.d;
         }
+    };
+    Pf pa = fetch(y0 + 2, y0 + 1, y0 + 1 < y1), pb = {zero4, zero4, zero4};
+    for (int y = y0; y < y1; y += 2) {
+        step(y, pa, pb);
+        if (y + 1 < y1) step(y + 1, pb, pa);
     }
 
     if (!wave_live) return;
@@ -143,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_kernel(WgradMParams p)
 #pragma unroll
         for (int cob = 0; cob < 4; ++cob) {
             const int co = co_t + cob * 16 + co_l;
-            if (cob >= ncob || co >= p.Cout) continue;
+            if (co >= p.Cout) continue;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int ci = ci_t + cb * 16 + g * 4 + j;
