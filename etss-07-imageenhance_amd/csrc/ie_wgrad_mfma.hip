@@ -71,12 +71,19 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_kernel(WgradMParams p)
     const bool d_ok = d_ch_ok && x0 + lpix < p.W;
     const int xoff_a = wm_chunk_off(lpix, lch), xoff_b = wm_chunk_off(32 + lpix, lch), doff = 4 * WM_ROWB + wm_chunk_off(lpix, lch);
     const ie_u32x4 zero4 = {0u, 0u, 0u, 0u};
+    // Loads are unconditional and RAW (a masked slot reads the tensor's first 16 bytes); the zero-select of masked slots happens
+    // where the value is stored to LDS, a step later.  With the same number of loads in flight on every path and no use of the
+    // value near the load, the compiler waits for the OLDER prefetch set with a counted vmcnt and the newer set stays in flight.
     auto ld_x = [&](int y, bool ok, int gx) -> ie_u32x4 {
-        return (ok && y >= 0 && y < p.H) ? *(const ie_u32x4*)(xn + ((size_t)y * p.W + gx) * p.Cs + ci_t + lch * 8) : zero4;
+        const bool v = ok && y >= 0 && y < p.H;
+        return *(const ie_u32x4*)(v ? xn + ((size_t)y * p.W + gx) * p.Cs + ci_t + lch * 8 : xn);
     };
     auto ld_d = [&](int y) -> ie_u32x4 {
-        return d_ok ? *(const ie_u32x4*)(dn + ((size_t)y * p.W + x0 + lpix) * p.Cout + co_t + lch * 8) : zero4;
+        const bool v = d_ok && y < p.H;
+        return *(const ie_u32x4*)(v ? dn + ((size_t)y * p.W + x0 + lpix) * p.Cout + co_t + lch * 8 : dn);
     };
+    auto sel = [&](ie_u32x4 r, bool v) -> ie_u32x4 { return v ? r : zero4; };
+    auto row_ok = [&](int y) -> bool { return y >= 0 && y < p.H; };
     auto st_x = [&](int rr, ie_u32x4 a, ie_u32x4 b) {
         unsigned char* row = lds + (rr & 3) * WM_ROWB;
         *(ie_u32x4*)(row + xoff_a) = a;
@@ -103,21 +110,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_kernel(WgradMParams p)
 
     // prologue: input rows y0-1, y0, y0+1 -> ring slots 0, 1, 2; dY row y0 -> slot 0
 #pragma unroll
-    for (int r = 0; r < 3; ++r) st_x(r, ld_x(y0 - 1 + r, xa_ok, gx_a), ld_x(y0 - 1 + r, xb_ok, gx_b));
-    *(ie_u32x4*)(lds + doff) = ld_d(y0);
+    for (int r = 0; r < 3; ++r)
+        st_x(r, sel(ld_x(y0 - 1 + r, xa_ok, gx_a), xa_ok && row_ok(y0 - 1 + r)), sel(ld_x(y0 - 1 + r, xb_ok, gx_b), xb_ok && row_ok(y0 - 1 + r)));
+    *(ie_u32x4*)(lds + doff) = sel(ld_d(y0), d_ok);
 
     // Global loads run TWO steps ahead of their use (two register sets, the loop is unrolled by two): a step's MFMA work
     // (36 per wave, ~0.3 us) is shorter than the HBM latency, one step of look-ahead left the matrix cores idle ~75 %.
     struct Pf { ie_u32x4 xa, xb, d; };
-    auto fetch = [&](int yx, int yd, bool on) -> Pf {
-        Pf f = {zero4, zero4, zero4};
-        if (on) { f.xa = ld_x(yx, xa_ok, gx_a); f.xb = ld_x(yx, xb_ok, gx_b); f.d = ld_d(yd); }
-        return f;
-    };
+    auto fetch = [&](int yx, int yd) -> Pf { return Pf{ld_x(yx, xa_ok, gx_a), ld_x(yx, xb_ok, gx_b), ld_d(yd)}; };
     auto step = [&](int y, const Pf& wr, Pf& ld) {
         __syncthreads();
         const int rr = y - y0;                      // ring index of input row y-1
-        ld = fetch(y + 3, y + 2, y + 2 < y1);
+        ld = fetch(y + 3, y + 2);               // rows past the chunk / image: loaded (or zeroed) and never stored
         if (wave_live) {
             const unsigned char* dyb = lds + 4 * WM_ROWB + (rr & 1) * WM_DYB;
             typename ie_elem<T>::frag b[4];
@@ -137,11 +141,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_kernel(WgradMParams p)
             }
         }
         if (y + 1 < y1) {                           // rows fetched during the previous step: input row y+2, dY row y+1
-            st_x(rr + 3, wr.xa, wr.xb);
-            *(ie_u32x4*)(lds + doff + ((rr + 1) & 1) * WM_DYB) = wr.d;
+            const bool rok = row_ok(y + 2);
+            st_x(rr + 3, sel(wr.xa, xa_ok && rok), sel(wr.xb, xb_ok && rok));
+            *(ie_u32x4*)(lds + doff + ((rr + 1) & 1) * WM_DYB) = sel(wr.d, d_ok);
         }
     };
-    Pf pa = fetch(y0 + 2, y0 + 1, y0 + 1 < y1), pb = {zero4, zero4, zero4};
+    Pf pa = fetch(y0 + 2, y0 + 1), pb = {zero4, zero4, zero4};
     for (int y = y0; y < y1; y += 2) {
         step(y, pa, pb);
         if (y + 1 < y1) step(y + 1, pb, pa);
@@ -180,12 +185,19 @@ int ie_wgrad_mfma_launch(const void* x, const void* dy, int dtype, float* dw_hwi
     p.xchunks = ie_cdiv(W, WM_PX);
     const long tiles = (long)p.co_tiles * ci_tiles, strips = (long)N * p.xchunks;
     if (tiles > 0x7fffffffL || strips > 65535) IE_FAIL(IE_ERR_UNSUPPORTED, "ie_convn_wgrad_nhwc: grid too large (%ld tiles, %ld strips)", tiles, strips);
-    // split the rows so that ~1024 workgroups exist, but keep >= 16 rows per workgroup to amortise the 36K atomics
-    long ychunks = (1024 + tiles * strips - 1) / (tiles * strips);
-    if (ychunks > (H + 15) / 16) ychunks = (H + 15) / 16;
-    if (ychunks < 1) ychunks = 1;
-    p.rows_per_wg = ie_cdiv(H, (int)ychunks);
-    ychunks = ie_cdiv(H, p.rows_per_wg);
+    // Split the rows into `ychunks` per strip.  Two workgroups fit a CU (512 slots on the chip) and every workgroup costs its rows
+    // plus a fixed ~12 rows' worth of prologue and 36K atomics, so pick the split that minimises rounds x (rows + 12): a grid of
+    // 1080 workgroups (2.1 rounds) ran 30 % slower than 960.
+    const long slots = 512;
+    long best = 1, best_cost = -1;
+    const long max_chunks = H >= 32 ? H / 16 : 1;
+    for (long c = 1; c <= max_chunks && c <= 64; ++c) {
+        const long rows = (H + c - 1) / c, wgs = tiles * strips * ((H + rows - 1) / rows);
+        const long cost = ((wgs + slots - 1) / slots) * (rows + 12);
+        if (best_cost < 0 || cost < best_cost) { best = c; best_cost = cost; }
+    }
+    p.rows_per_wg = ie_cdiv(H, (int)best);
+    const long ychunks = ie_cdiv(H, p.rows_per_wg);
     const dim3 grid((unsigned)tiles, (unsigned)strips, (unsigned)ychunks);
     if (dtype == IE_F16) hipLaunchKernelGGL(conv_wgrad_mfma_kernel<_Float16>, grid, dim3(256), 0, stream, p);
     else if (dtype == IE_BF16) hipLaunchKernelGGL(conv_wgrad_mfma_kernel<__bf16>, grid, dim3(256), 0, stream, p);
