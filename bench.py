@@ -215,8 +215,8 @@ def main():
             except Exception as e:
                 extras["zero_dce_f16_1080p_frames_per_s"] = f"failed: {e}"[:200]
             torch.cuda.empty_cache()
-            for tag, cfg, nfr in (("unet32_bf16_1080p_frames_per_s", dict(name="unet", base_channels=32, num_classes=3, enhance=True), 4),
-                                  ("unet32_pixelshuffle_bf16_1080p_frames_per_s", dict(name="unet", base_channels=32, num_classes=3, enhance=True, upsampler="pixelshuffle"), 4),
+            for tag, cfg, nfr in (("unet32_bf16_1080p_frames_per_s", dict(name="unet", base_channels=32, num_classes=3, enhance=True), 8),
+                                  ("unet32_pixelshuffle_bf16_1080p_frames_per_s", dict(name="unet", base_channels=32, num_classes=3, enhance=True, upsampler="pixelshuffle"), 8),
                                   ("retinexnet_bf16_1080p_frames_per_s", dict(name="retinexnet"), 4)):
                 try:
                     m2 = mon_amd.MODELS.build(seed=1, compute_dtype="bf16", **cfg).to(dev)

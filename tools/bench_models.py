@@ -16,12 +16,12 @@ from oracle import generators as og
 GFLOP = {"unet32": 634.5, "unet32_ps": None, "unet64": 2530.0, "llunet++": 11495.7, "retinexnet": 1374.5, "zero_dce++": 41.8}
 CASES = [
     ("zero_dce++", dict(name="zero_dce++_re", seed=1), 4, (1080, 1920)),
-    ("unet32", dict(name="unet", seed=1, base_channels=32, num_classes=3, enhance=True), 2, (1080, 1920)),
-    ("unet32_ps", dict(name="unet", seed=1, base_channels=32, num_classes=3, enhance=True, upsampler="pixelshuffle"), 2, (1080, 1920)),
+    ("unet32", dict(name="unet", seed=1, base_channels=32, num_classes=3, enhance=True), 8, (1080, 1920)),
+    ("unet32_ps", dict(name="unet", seed=1, base_channels=32, num_classes=3, enhance=True, upsampler="pixelshuffle"), 8, (1080, 1920)),
     ("retinexnet", dict(name="retinexnet", seed=1), 2, (1080, 1920)),
     ("llunet++", dict(name="llunet++_re", seed=1), 1, (1088, 1920)),
     ("hinet64", dict(name="hinet_re", seed=1), 1, (1088, 1920)),
-    ("unet64", dict(name="unet", seed=1, base_channels=64, num_classes=3, enhance=True), 2, (1080, 1920)),
+    ("unet64", dict(name="unet", seed=1, base_channels=64, num_classes=3, enhance=True), 8, (1080, 1920)),
 ]
 cdt = "f32"
 args = sys.argv[1:]
