@@ -349,14 +349,25 @@ __global__ void pixel_unshuffle_kernel(const float* __restrict__ dy, float* __re
     dx[i] = (accumulate ? dx[i] : 0.f) + dy[((n * H * r + h * r + ii) * (size_t)(W * r) + w * r + jj) * Co + c];
 }
 
-// dx = dy * act'(.) from the activation OUTPUT y; mode 5: clamp(x, lo, hi) from its INPUT x (pass where lo <= x <= hi)
-__global__ void act_backward_kernel(const float* __restrict__ dy, const float* __restrict__ ref, float* __restrict__ dx, int act,
-                                    float slope, float lo, float hi, int accumulate, size_t total) {
+// dx = dy * act'(.) from the activation OUTPUT y; mode 5: clamp(x, lo, hi) from its INPUT x (pass where lo <= x <= hi).
+// V elements per thread (8 for 16-bit tensors whose length allows: 16-byte accesses); dx may alias dy.
+template <typename T, int V>
+__global__ void act_backward_kernel(const T* dy, const T* __restrict__ ref, T* dx, int act, float slope, float lo, float hi, int accumulate,
+                                    size_t total) {
+    typedef __attribute__((ext_vector_type(V))) T TV;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    const float v = ref[i];
-    const float d = act == 5 ? ((v >= lo && v <= hi) ? 1.f : 0.f) : ie_act_grad_from_output(v, act, slope);
-    dx[i] = (accumulate ? dx[i] : 0.f) + dy[i] * d;
+    const TV g = *(const TV*)(dy + i * V), r = *(const TV*)(ref + i * V);
+    TV old;
+    if (accumulate) old = *(const TV*)(dx + i * V);
+    TV out;
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+        const float v = (float)r[e];
+        const float d = act == 5 ? ((v >= lo && v <= hi) ? 1.f : 0.f) : ie_act_grad_from_output(v, act, slope);
+        out[e] = (T)((accumulate ? (float)old[e] : 0.f) + (float)g[e] * d);
+    }
+    *(TV*)(dx + i * V) = out;
 }
 
 // ---- losses ---------------------------------------------------------------------------------------------------------
@@ -780,12 +791,30 @@ IE_EXPORT int ie_pixel_unshuffle_nhwc_f32(const float* dy, float* dx, int N, int
     return IE_OK;
 }
 
-IE_EXPORT int ie_act_backward_f32(const float* dy, const float* ref, float* dx, size_t n, int act, float slope, float lo, float hi,
-                                  int accumulate, void* stream) {
-    if (!dy || !ref || !dx || n == 0 || act < 0 || act > 5) IE_FAIL(IE_ERR_INVALID, "ie_act_backward_f32: bad args");
-    hipLaunchKernelGGL(act_backward_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, dy, ref, dx, act, slope, lo, hi, accumulate, n);
+template <typename T>
+static int act_bwd_impl(const void* dy, const void* ref, void* dx, size_t n, int act, float slope, float lo, float hi, int accumulate, void* stream) {
+    if (!dy || !ref || !dx || n == 0 || act < 0 || act > 5) IE_FAIL(IE_ERR_INVALID, "ie_act_backward: bad args");
+    if (sizeof(T) == 2 && (n & 7) == 0)
+        hipLaunchKernelGGL((act_backward_kernel<T, 8>), dim3(nblk(n / 8)), dim3(256), 0, (hipStream_t)stream, (const T*)dy, (const T*)ref, (T*)dx, act,
+                           slope, lo, hi, accumulate, n / 8);
+    else
+        hipLaunchKernelGGL((act_backward_kernel<T, 1>), dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, (const T*)dy, (const T*)ref, (T*)dx, act,
+                           slope, lo, hi, accumulate, n);
     IE_LAUNCH_CHECK();
     return IE_OK;
+}
+IE_EXPORT int ie_act_backward(const void* dy, const void* ref, void* dx, int dtype, size_t n, int act, float slope, float lo, float hi,
+                              int accumulate, void* stream) {
+    switch (dtype) {
+    case IE_F32: return act_bwd_impl<float>(dy, ref, dx, n, act, slope, lo, hi, accumulate, stream);
+    case IE_F16: return act_bwd_impl<_Float16>(dy, ref, dx, n, act, slope, lo, hi, accumulate, stream);
+    case IE_BF16: return act_bwd_impl<__bf16>(dy, ref, dx, n, act, slope, lo, hi, accumulate, stream);
+    default: IE_FAIL(IE_ERR_INVALID, "ie_act_backward: bad dtype");
+    }
+}
+IE_EXPORT int ie_act_backward_f32(const float* dy, const float* ref, float* dx, size_t n, int act, float slope, float lo, float hi,
+                                  int accumulate, void* stream) {
+    return act_bwd_impl<float>(dy, ref, dx, n, act, slope, lo, hi, accumulate, stream);
 }
 
 IE_EXPORT int ie_l1_loss_f32(const float* pred, const float* target, size_t n, double* sum_dev, float* grad, float grad_scale,

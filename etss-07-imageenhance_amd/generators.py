@@ -354,6 +354,8 @@ class LLUnetpp_RE(_GraphModel):
         x2 = c([x1, x12], f"{b}.conv2", act="lrelu", slope=0.2, valid=v)
         return c(x2, f"{b}.conv3", act="lrelu", slope=0.2, residual=x23)
 
+    supports_mixed_training = True
+
     def forward_train(self, x, store, tape):
         """Training graph of llunetpp.py:97-137, 218-243 on the fp32 taped ops (instance statistics are per sample in training
         and in inference alike).  Returns the clamped NHWC prediction; the reference's own loss needs a VGG-19 that cannot be
@@ -362,13 +364,18 @@ class LLUnetpp_RE(_GraphModel):
         if x.shape[2] % 16 or x.shape[3] % 16:
             raise ValueError(f"LLUnet++ needs H and W divisible by 16 (got {x.shape[2]}x{x.shape[3]}).")
         g = store.grads
+        mixed = store.compute_dtype != "f32"
+        if mixed:      # 16-bit graph: RGB carried as 16 channels, the 3-channel head computed as 16; clamp and loss in fp32
+            x = T.t_cast(tape, x, ops.TORCH_DT[store.compute_dtype], channels=16)
 
-        def conv(name, srcs, pad=1, act="none"):
-            return T.t_conv(tape, srcs, store.conv(name), *store.conv_grads(name), pad=pad, act=act, slope=0.2)
+        def conv(name, srcs, pad=1, act="none", cout_pad=None):
+            return T.t_conv(tape, srcs, store.conv(name), *store.conv_grads(name), pad=pad, act=act, slope=0.2, cout_pad=cout_pad)
 
         def block(b, srcs):
-            x12 = conv(f"{b}.conv1_2", srcs, pad=0)
-            x1 = conv(f"{b}.conv1", srcs)
+            ci = self._io[b][0]
+            cp = 16 if (mixed and ci % 8) else None        # conv0_0 works on the 3 RGB channels: carried as 16 in the 16-bit graph
+            x12 = conv(f"{b}.conv1_2", srcs, pad=0, cout_pad=cp)
+            x1 = conv(f"{b}.conv1", srcs, cout_pad=cp)
             x1 = T.t_norm(tape, x1, store.view(f"{b}.norm1.weight"), store.view(f"{b}.norm1.bias"), store.view(f"{b}.norm1.weight", g),
                           store.view(f"{b}.norm1.bias", g), per_sample=True, eps=1e-5, act="lrelu", slope=0.2)
             x23 = conv(f"{b}.conv2_3", [x1, x12], pad=0)
@@ -392,7 +399,11 @@ class LLUnetpp_RE(_GraphModel):
         x2_2 = block("conv2_2", [x2_0, x2_1, up(x3_1)])
         x1_3 = block("conv1_3", [x1_0, x1_1, x1_2, up(x2_2)])
         x0_4 = block("conv0_4", [x0_0, x0_1, x0_2, x0_3, up(x1_3)])
-        return T.t_clamp(tape, conv("final", [x0_4], pad=0), 0.0, 1.0)
+        if mixed:
+            y = T.t_cast(tape, conv("final", [x0_4], pad=0, cout_pad=16), torch.float32, channels=self.out_channels)
+        else:
+            y = conv("final", [x0_4], pad=0)
+        return T.t_clamp(tape, y, 0.0, 1.0)
 
     def forward(self, datapoint: dict, *args, **kwargs) -> dict:
         x = self._input_any(datapoint)

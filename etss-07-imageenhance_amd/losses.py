@@ -154,6 +154,7 @@ class ZeroDCELoss(Loss):
     channels_last memory (NHWC), as the training graph produces them."""
 
     zero_reference = True
+    grad_scale = 1.0          # set by the Trainer (its AMP loss scale) before the forward pass
 
     def __init__(self, spa_weight: float = 1.0, exp_patch_size: int = 16, exp_mean_val: float = 0.6, exp_weight: float = 10.0,
                  col_weight: float = 5.0, tva_weight: float = 200.0, reduction: str = "mean", loss_weight: float = 1.0):
@@ -179,11 +180,12 @@ class ZeroDCELoss(Loss):
         g_enh = torch.empty_like(enhance)
         g_adj = torch.empty_like(adjust, memory_format=torch.channels_last)
         k = self.loss_weight
+        gs = float(self.grad_scale)           # AMP loss scale of the trainer: folded into the gradient weights, not into the value
         with torch.cuda.device(enhance.device):
-            capi.check(L.ie_zref_image_losses_f32(capi.ptr(enhance), capi.ptr(input), n, h, w, self.exp_mean_val, k * self.spa_weight,
-                                                  k * self.exp_weight, k * self.col_weight, capi.ptr(sums), capi.ptr(ws), capi.ptr(g_enh), 0,
+            capi.check(L.ie_zref_image_losses_f32(capi.ptr(enhance), capi.ptr(input), n, h, w, self.exp_mean_val, gs * k * self.spa_weight,
+                                                  gs * k * self.exp_weight, gs * k * self.col_weight, capi.ptr(sums), capi.ptr(ws), capi.ptr(g_enh), 0,
                                                   capi.current_stream()), "ie_zref_image_losses_f32")
-            capi.check(L.ie_tv_loss_nhwc_f32(capi.ptr(adjust), n, h, w, c, k * self.tva_weight, capi.ptr(tv), capi.ptr(g_adj), 0,
+            capi.check(L.ie_tv_loss_nhwc_f32(capi.ptr(adjust), n, h, w, c, gs * k * self.tva_weight, capi.ptr(tv), capi.ptr(g_adj), 0,
                                              capi.current_stream()), "ie_tv_loss_nhwc_f32")
 
         def terms():
@@ -197,8 +199,8 @@ class ZeroDCELoss(Loss):
             return k * (self.spa_weight * t["spa"] + self.exp_weight * t["exp"] + self.col_weight * t["col"] + self.tva_weight * t["tva"])
 
         def seed(tape, scale=1.0):
-            if scale != 1.0:
-                raise capi.IEError("zero_dce_loss: gradient scaling is folded into loss_weight")
+            if scale != gs:
+                raise capi.IEError("zero_dce_loss: the gradients were computed with grad_scale %g, not %g (set loss.grad_scale before forward)" % (gs, scale))
             tape.seed(enhance, g_enh)
             tape.seed(adjust, g_adj)
 

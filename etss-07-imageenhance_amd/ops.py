@@ -421,9 +421,11 @@ def pixel_unshuffle_into(dy, dx, r, accumulate):
 def act_backward_into(dy, ref, dx, act, slope=0.0, lo=0.0, hi=0.0, accumulate=False):
     """dx (+)= dy * act'(ref); act in ACT names (ref = activation output) or "clamp" (ref = clamp input)."""
     code = 5 if act == "clamp" else capi.ACT[act]
+    if not (dy.dtype == ref.dtype == dx.dtype):
+        raise capi.IEError("act_backward_into: dy, ref and dx must share a dtype")
     with torch.cuda.device(dy.device):
-        capi.check(capi.lib().ie_act_backward_f32(capi.ptr(dy), capi.ptr(ref), capi.ptr(dx), dy.numel(), code, slope, lo, hi,
-                                                  int(accumulate), capi.current_stream()), "ie_act_backward_f32")
+        capi.check(capi.lib().ie_act_backward(capi.ptr(dy), capi.ptr(ref), capi.ptr(dx), _dt(dy), dy.numel(), code, slope, lo, hi,
+                                              int(accumulate), capi.current_stream()), "ie_act_backward")
 
 
 # ---- 16-bit matrix-core path (ie_mconv_*) ------------------------------------------------------------------------------

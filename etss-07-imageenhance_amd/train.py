@@ -110,27 +110,30 @@ class ParamStore:
         cw.store, cw.name = self, name
         return cw
 
-    def conv16(self, name, split, cout_pad=None):
+    def conv16(self, name, split, cout_pad=None, real_split=None):
         """Packed 16-bit weights of conv ``name`` over sources ``split`` for the matrix-core forward and for the data gradient of
         every source, produced on the device from the fp32 master weights and refreshed by ``repack16()`` after every step.
 
-        Channel-padded edges (the RGB input carried as 16 channels, the 3-channel head computed as 16): ``sum(split)`` may exceed the
-        layer's Cin (single source) and ``cout_pad`` its Cout; the packers then read a zero-padded fp32 scratch copy of the master
-        weights (``pad`` in the returned triple: scratch weights / bias and their gradient twins), refreshed before every repack."""
-        key = (name, tuple(split), cout_pad)
+        Channel-padded edges (RGB carried as 16 channels, a 3-channel head computed as 16): ``real_split`` gives the channels of
+        each source that exist in the layer's weight matrix (the rest of the source is zero padding) and ``cout_pad`` the padded
+        Cout; the packers then read a zero-padded fp32 scratch copy of the master weights (``pad`` in the returned triple: scratch
+        weights / bias and their gradient twins), refreshed before every repack."""
+        split = [int(c) for c in split]
+        real = [int(c) for c in (real_split or split)]
+        key = (name, tuple(split), cout_pad, tuple(real))
         if key not in self._c16:
             _, _, (co, ci, kh, kw), _ = self.index[f"{name}.weight"]
             dt = ops.TORCH_DT[self.compute_dtype]
             b = self.view(f"{name}.bias") if f"{name}.bias" in self.index else None
             w = self.view(f"{name}.weight")
-            cin_p, co_p, pad = sum(split), cout_pad or co, None
-            if cin_p != ci or co_p != co:
-                if cin_p < ci or co_p < co or (cin_p != ci and len(split) != 1):
-                    raise capi.IEError(f"conv16 {name}: cannot pad {ci}->{co} to {list(split)}->{co_p}")
-                pad = _PaddedEdge(w, b, kh * kw, ci, co, cin_p, co_p)
+            co_p, pad = cout_pad or co, None
+            if sum(real) != ci or co_p < co or any(r > c for r, c in zip(real, split)):
+                raise capi.IEError(f"conv16 {name}: sources {split} (real {real}) / cout {co_p} do not fit the layer {ci}->{co}")
+            if real != split or co_p != co:
+                pad = _PaddedEdge(w, b, kh * kw, real, split, co, co_p)
                 w, b = pad.w, pad.b
-            fwd = ops.MConvWeightsDev(w, b, list(split), co_p, kh, kw, dt)
-            dg = [ops.MConvWeightsDev(w, None, list(split), co_p, kh, kw, dt, mode="dgrad", src_index=i) for i in range(len(split))]
+            fwd = ops.MConvWeightsDev(w, b, split, co_p, kh, kw, dt)
+            dg = [ops.MConvWeightsDev(w, None, split, co_p, kh, kw, dt, mode="dgrad", src_index=i) for i in range(len(split))]
             self._c16[key] = (fwd, dg, pad)
         return self._c16[key]
 
@@ -169,34 +172,49 @@ class ParamStore:
 
 
 class _PaddedEdge:
-    """Zero-padded fp32 scratch copy [taps][cin_p][co_p] of a conv's master weights [taps][ci][co] (and bias), plus gradient scratch of
-    the same shape: device-to-device slice copies only, the arithmetic stays in the kernels."""
+    """Zero-padded fp32 scratch copy [taps][sum(split)][co_p] of a conv's master weights [taps][sum(real)][co] (and bias), plus
+    gradient scratch of the same shape: source s owns rows [sum(split[:s]), +real[s]) of the padded matrix.  Device-to-device
+    slice copies only, the arithmetic stays in the kernels."""
 
-    def __init__(self, w, b, taps, ci, co, cin_p, co_p):
-        self.src_w, self.src_b, self.dims = w, b, (taps, ci, co, cin_p, co_p)
-        self.w = torch.zeros(taps * cin_p * co_p, device=w.device, dtype=torch.float32)
+    def __init__(self, w, b, taps, real, split, co, co_p):
+        self.src_w, self.src_b, self.taps, self.co, self.co_p = w, b, taps, co, co_p
+        self.ci, self.cin_p = sum(real), sum(split)
+        self.rows, r0, p0 = [], 0, 0
+        for r, c in zip(real, split):
+            self.rows.append((p0, r0, r))
+            r0 += r; p0 += c
+        self.w = torch.zeros(taps * self.cin_p * co_p, device=w.device, dtype=torch.float32)
         self.b = None if b is None else torch.zeros(co_p, device=w.device, dtype=torch.float32)
         self.dw = torch.zeros_like(self.w)
         self.db = None if b is None else torch.zeros_like(self.b)
         self.refresh()
 
     def refresh(self):
-        taps, ci, co, cin_p, co_p = self.dims
-        self.w.view(taps, cin_p, co_p)[:, :ci, :co].copy_(self.src_w.view(taps, ci, co))
+        wp, ws = self.w.view(self.taps, self.cin_p, self.co_p), self.src_w.view(self.taps, self.ci, self.co)
+        for p0, r0, r in self.rows:
+            wp[:, p0:p0 + r, :self.co].copy_(ws[:, r0:r0 + r, :])
         if self.b is not None:
-            self.b[:co].copy_(self.src_b)
+            self.b[:self.co].copy_(self.src_b)
 
     def scatter_grads(self, dw, db):
-        taps, ci, co, cin_p, co_p = self.dims
-        dw.view(taps, ci, co).copy_(self.dw.view(taps, cin_p, co_p)[:, :ci, :co])
+        gp, gs = self.dw.view(self.taps, self.cin_p, self.co_p), dw.view(self.taps, self.ci, self.co)
+        for p0, r0, r in self.rows:
+            gs[:, r0:r0 + r, :].copy_(gp[:, p0:p0 + r, :self.co])
         if db is not None:
-            db.copy_(self.db[:co])
+            db.copy_(self.db[:self.co])
 
 
-# ---- taped ops ---------------------------------------------------------------------------------------------------------
+def _real_c(t):
+    """Channels of ``t`` that carry data (16-bit tensors of the padded edges hold zeros behind them)."""
+    return int(getattr(t, "_ie_real", t.shape[1]))
+
+
+# ---- taped ops ----# ---- taped ops ---------------------------------------------------------------------------------------------------------
 def t_cast(tape, x, dtype, channels=None):
     """dtype (and channel count) change between the fp32 edges and the 16-bit interior of the mixed-precision graph."""
     y = ops.cast(x, dtype, channels)
+    if y.shape[1] > x.shape[1] or _real_c(x) < x.shape[1]:
+        y._ie_real = min(_real_c(x), int(y.shape[1]))
     if tape.is_no_grad(x):
         return tape.no_grad(y)
 
@@ -214,17 +232,21 @@ def t_cast(tape, x, dtype, channels=None):
     return y
 
 
-def t_conv16(tape, srcs, cw, dw, db, pad=1, cout_pad=None):
-    """16-bit conv (stride 1, zero padding, no fused activation): forward, data gradient and (3x3) weight gradient on the matrix
-    cores, weights packed on the device from the fp32 master copy; fp32 gradient accumulation.  ``cout_pad`` / sources wider than
-    the layer's Cin: channel-padded edges (``ParamStore.conv16``)."""
-    fwd, dgw, edge = cw.store.conv16(cw.name, [int(s.shape[1]) for s in srcs], cout_pad)
-    y = ops.mconv2d(srcs, fwd, pad=pad)
+def t_conv16(tape, srcs, cw, dw, db, pad=1, cout_pad=None, act="none", slope=0.0):
+    """16-bit conv (stride 1, zero padding, activation fused into the forward epilogue): forward, data gradient and (3x3) weight
+    gradient on the matrix cores, weights packed on the device from the fp32 master copy; fp32 gradient accumulation.
+    ``cout_pad`` / sources wider than the layer's Cin: channel-padded edges (``ParamStore.conv16``)."""
+    fwd, dgw, edge = cw.store.conv16(cw.name, [int(s.shape[1]) for s in srcs], cout_pad, [_real_c(s) for s in srcs])
+    y = ops.mconv2d(srcs, fwd, pad=pad, act=act, slope=slope)
+    if cout_pad and cout_pad != cw.cout:
+        y._ie_real = cw.cout
 
     def bwd():
         dy = tape.grad(y)
         if dy is None:
             return
+        if act != "none":
+            ops.act_backward_into(dy, y, dy, act, slope)          # in place: this op owns the gradient buffer of its output
         if edge is None:
             ops.conv2d_wgrad(srcs, dy, cw, dw, db, 1, pad, "zeros")
         else:
@@ -248,9 +270,9 @@ def t_conv(tape, srcs, cw, dw, db, stride=1, pad=1, pad_mode="zeros", act="none"
     if isinstance(srcs, torch.Tensor):
         srcs = [srcs]
     if srcs[0].dtype != torch.float32:
-        if stride != 1 or pad_mode != "zeros" or act != "none":
-            raise capi.IEError("the 16-bit training conv supports stride 1, zero padding and no fused activation")
-        return t_conv16(tape, srcs, cw, dw, db, pad, cout_pad)
+        if stride != 1 or pad_mode != "zeros":
+            raise capi.IEError("the 16-bit training conv supports stride 1 and zero padding")
+        return t_conv16(tape, srcs, cw, dw, db, pad, cout_pad, act, slope)
     y = ops.conv2d(srcs, cw, stride=stride, pad=pad, pad_mode=pad_mode, act=act, slope=slope)
 
     def bwd():
@@ -272,7 +294,11 @@ def t_conv(tape, srcs, cw, dw, db, stride=1, pad=1, pad_mode="zeros", act="none"
 
 def t_norm(tape, x, gamma, beta, dgamma, dbeta, per_sample, running_mean=None, running_var=None, momentum=0.1, eps=1e-5,
            act="none", slope=0.0, c_begin=0, c_count=None):
+    if c_count is None and _real_c(x) < x.shape[1]:        # channel-padded 16-bit tensor: normalise the real channels only
+        c_count = _real_c(x) - c_begin
     y, mean, inv = ops.norm_forward(x, gamma, beta, per_sample, running_mean, running_var, momentum, eps, act, slope, c_begin, c_count)
+    if _real_c(x) < x.shape[1]:
+        y._ie_real = _real_c(x)
 
     def bwd():
         dy = tape.grad(y)
@@ -504,6 +530,8 @@ class Trainer:
         # a mean-reduced loss over a 1080p batch seeds ~1e-7 per element, below fp16's normal range; bf16 / fp32 do not.  With
         # clipping on, a step whose scaled gradients overflowed (non-finite norm) is skipped by ie_adam_step_f32.
         self.loss_scale = float(loss_scale) if loss_scale else (8192.0 if cd == "f16" else 1.0)
+        if getattr(self.loss, "zero_reference", False):
+            self.loss.grad_scale = self.loss_scale          # this loss computes its gradients in the forward pass
         self.store = ParamStore(model, self.device, cd)
         self._sumsq = torch.zeros(1, device=self.device, dtype=torch.float64)
         self._sumsq_ws = torch.zeros(capi.SUMSQ_WS_DOUBLES, device=self.device, dtype=torch.float64)

@@ -183,6 +183,8 @@ class ZeroDCE_RE(ImageEnhancementModel):
         if self.device.type != "cuda":
             raise capi.IEError(f"{self.__class__.__name__} runs on the HIP device only (model.device = {self.device}); call .to('cuda').")
 
+    supports_mixed_training = True
+
     def forward_train(self, x, store, tape):
         """Training graph (zero_dce.py:173-191) on the fp32 building blocks with saved activations: the fused matrix-core plan
         keeps x1/x4/x6 in LDS and cannot be differentiated, so training runs the layers one by one (the parity-grade fp32
@@ -192,6 +194,11 @@ class ZeroDCE_RE(ImageEnhancementModel):
         def conv(k, srcs, act):
             name = f"e_conv{k}"
             return T.t_conv(tape, srcs, store.conv(name), *store.conv_grads(name), act=act)
+        image_nhwc = x
+        if store.compute_dtype != "f32":
+            # 16-bit graph: the seven layers (forward, data and weight gradients) on the generic matrix-core kernels, RGB carried
+            # as 16 channels; the curve maps return to fp32 for the LE curve and the zero-reference loss
+            x = T.t_cast(tape, x, ops.TORCH_DT[store.compute_dtype], channels=16)
         x1 = conv(1, [x], "relu")
         x2 = conv(2, [x1], "relu")
         x3 = conv(3, [x2], "relu")
@@ -199,7 +206,9 @@ class ZeroDCE_RE(ImageEnhancementModel):
         x5 = conv(5, [x3, x4], "relu")
         x6 = conv(6, [x2, x5], "relu")
         xr = conv(7, [x1, x6], "tanh")
-        image = ops.to_nchw(x)
+        if xr.dtype != torch.float32:
+            xr = T.t_cast(tape, xr, torch.float32)
+        image = ops.to_nchw(image_nhwc)
         enhanced = T.t_curve(tape, image, xr, self.num_iters)
         return {"adjust": xr, "enhanced": enhanced, "_image": image}
 

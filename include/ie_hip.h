@@ -233,6 +233,9 @@ int ie_pixel_unshuffle_nhwc_f32(const float* dy_dev, float* dx_dev, int N, int H
  * (gradient passes where lo <= ref <= hi, like torch.clamp). */
 int ie_act_backward_f32(const float* dy_dev, const float* ref_dev, float* dx_dev, size_t n, int act, float slope, float lo, float hi,
                         int accumulate, void* stream);
+/* dtype-generic twin (IE_F32 / IE_F16 / IE_BF16; all three tensors share the dtype; dx may alias dy). */
+int ie_act_backward(const void* dy_dev, const void* ref_dev, void* dx_dev, int dtype, size_t n, int act, float slope, float lo, float hi,
+                    int accumulate, void* stream);
 /* L1Loss (nn/loss/base.py:164-178): *sum_dev = sum |pred - target| (caller divides by n for reduction="mean");
  * grad_dev (may be NULL) (+)= grad_scale * sign(pred - target). */
 int ie_l1_loss_f32(const float* pred_dev, const float* target_dev, size_t n, double* sum_dev, float* grad_dev, float grad_scale,

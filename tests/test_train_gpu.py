@@ -674,7 +674,82 @@ def test_unet_mixed_precision_training_step(dt, min_cos):
         if "running_" in k:
             assert float((sd1[k] - ref).abs().max()) < 2e-2 * max(1.0, float(ref.abs().max())), k
     with pytest.raises(capi.IEError):
-        mon_amd.Trainer(mon_amd.MODELS.build(name="zero_dce_re", seed=1).to("cuda"), compute_dtype="bf16")
+        mon_amd.Trainer(mon_amd.MODELS.build(name="retinexnet", seed=1).to("cuda"), compute_dtype="bf16")
+
+
+@pytest.mark.parametrize("dt,min_cos", [("f16", 0.995), ("bf16", 0.97)])
+def test_zero_dce_mixed_precision_training_step(dt, min_cos):
+    """Zero-DCE's zero-reference step on the 16-bit graph (seven matrix-core layers with fused ReLU / tanh, RGB carried as 16 channels,
+    curve and loss in fp32) against torch float64: no norm layers, so the gradient direction holds to 16-bit accuracy."""
+    model = mon_amd.MODELS.build(name="zero_dce_re", seed=4).to("cuda")
+    sd0 = model.state_dict()
+    g = torch.Generator().manual_seed(5)
+    img = (torch.rand(2, 3, 48, 64, generator=g) ** 2.2 * 0.4).contiguous()
+    kw = dict(lr=5e-5, betas=(0.9, 0.99), eps=1e-3, weight_decay=1e-5, clip=0.1)
+    log, final = otrain.training_steps({k: v.double() for k, v in sd0.items()}, [(img.double(), img.double())],
+                                       lambda p, b, x: otrain.zero_dce_forward_train(p, b, x),
+                                       lambda pred, im: otrain.zero_dce_loss(im, pred[0], pred[1]), **kw)
+    tr = mon_amd.Trainer(model, optimizer={"name": "adam", "lr": 5e-5, "betas": (0.9, 0.99), "eps": 1e-3, "weight_decay": 1e-5},
+                         gradient_clip_val=0.1, compute_dtype=dt)
+    out = tr.training_step({"image": img})
+    assert list(out) == ["enhanced", "loss"] and out["enhanced"].dtype == torch.float32
+    assert abs(float(out["loss"]) - log[0]["loss"][0]) < (2e-3 if dt == "f16" else 1e-2) * max(1.0, log[0]["loss"][0])
+    grads = tr.gradients()
+    a = torch.cat([grads[k].double().reshape(-1) for k in log[0]["grads"]])
+    b = torch.cat([log[0]["grads"][k].reshape(-1) for k in log[0]["grads"]])
+    cos = float((a * b).sum() / (a.norm() * b.norm()))
+    assert cos > min_cos, cos
+    assert abs(float(a.norm()) / float(b.norm()) - 1.0) < 0.05
+    sd1 = tr.state_dict()
+    assert max(float((sd1[k] - sd0[k]).abs().max()) for k in sd0) > 0.2 * 5e-5
+
+
+@pytest.mark.parametrize("dt,min_cos", [("f16", 0.98), ("bf16", 0.80)])
+def test_llunetpp_mixed_precision_training_step(dt, min_cos):
+    """LLUnet++ on the 16-bit graph: the RGB block (3->3 convs, 3-channel instance norm, 6-channel concat) runs channel-padded to 16,
+    fused LeakyReLU epilogues, 16-bit residual adds and 5-way concats; loss and gradient direction against torch float64."""
+    from oracle import generators as og
+    model = mon_amd.MODELS.build(name="llunet++_re", seed=31).to("cuda")
+    sd0 = model.state_dict()
+    g = torch.Generator().manual_seed(6)
+    tgt = torch.rand(1, 3, 96, 96, generator=g)
+    img = (tgt ** 2.2 * 0.4).contiguous()
+    lr, clip, eps = 1e-4, 0.1, 1e-3
+    log, final = otrain.training_steps({k: v.double() for k, v in sd0.items()}, [(img.double(), tgt.double())],
+                                       lambda p, b, x: og.llunetpp_forward(p, x)["enhanced"], lambda a, b: otrain.l1_ssim_loss(a, b),
+                                       lr=lr, clip=clip, eps=eps)
+    tr = mon_amd.Trainer(model, optimizer={"name": "adam", "lr": lr, "eps": eps}, loss={"name": "l1_ssim_loss"}, gradient_clip_val=clip,
+                         compute_dtype=dt)
+    out = tr.training_step({"image": img, "ref_image": tgt})
+    assert out["enhanced"].dtype == torch.float32 and tuple(out["enhanced"].shape) == (1, 3, 96, 96)
+    assert abs(float(out["loss"]) - log[0]["loss"][0]) < (3e-3 if dt == "f16" else 2e-2)
+    grads = tr.gradients()
+    a = torch.cat([grads[k].double().reshape(-1) for k in log[0]["grads"]])
+    b = torch.cat([log[0]["grads"][k].reshape(-1) for k in log[0]["grads"]])
+    cos = float((a * b).sum() / (a.norm() * b.norm()))
+    assert cos > min_cos, cos
+    assert abs(float(a.norm()) / float(b.norm()) - 1.0) < 0.1
+    ga, gb = grads["final.weight"].double().reshape(-1), log[0]["grads"]["final.weight"].reshape(-1)
+    assert float((ga * gb).sum() / (ga.norm() * gb.norm())) > 0.999
+    sd1 = tr.state_dict()
+    assert max(float((sd1[k] - sd0[k]).abs().max()) for k in sd0) > 0.5 * lr
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_act_backward_16bit(dtype):
+    tdt = ops.TORCH_DT[dtype]
+    tol = 1e-3 if dtype == "f16" else 8e-3
+    for act, fn in (("relu", F.relu), ("lrelu", lambda t: F.leaky_relu(t, 0.2)), ("tanh", torch.tanh), ("sigmoid", torch.sigmoid)):
+        for shape in ((2, 16, 9, 10), (1, 3, 7, 5)):                       # vector kernel (n % 8 == 0) and scalar kernel
+            x = rnd(*shape, seed=4).double().requires_grad_(True)
+            y = fn(x)
+            g = rnd(*shape, seed=5).to(tdt)
+            y.backward(g.double())
+            yd = y.detach().to(tdt).cuda().contiguous(memory_format=CL)
+            gd = g.cuda().contiguous(memory_format=CL)
+            ref = x.grad if act in ("relu", "lrelu") else g.double() * {"tanh": lambda t: 1 - t * t, "sigmoid": lambda t: t * (1 - t)}[act](yd.cpu().double())
+            ops.act_backward_into(gd, yd, gd, act, 0.2)                    # in place, as the 16-bit conv's backward uses it
+            assert rel_err(host(gd), ref) < tol, (act, shape)
 
 
 def test_fp16_loss_scale_and_skipped_step():

@@ -23,7 +23,7 @@ ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--hw", type=int, nargs=2, default=[1080, 1920])
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--warmup", type=int, default=1)
-ap.add_argument("--dtype", default="f32", choices=["f32", "f16", "bf16"], help="activation dtype of the training graph (unet)")
+ap.add_argument("--dtype", default="f32", choices=["f32", "f16", "bf16"], help="activation dtype of the training graph")
 a = ap.parse_args()
 world = int(os.environ.get("WORLD_SIZE", "1"))
 rank = int(os.environ.get("RANK", "0"))
@@ -36,10 +36,11 @@ if a.model == "unet":
     tr = mon_amd.Trainer(model, optimizer={"name": "adam", "lr": 1e-4}, loss={"name": "l1_ssim_loss"}, gradient_clip_val=0.1, compute_dtype=a.dtype)
 elif a.model == "llunetpp":
     model = mon_amd.MODELS.build(name="llunet++_re", seed=1).to(f"cuda:{local}")
-    tr = mon_amd.Trainer(model, optimizer={"name": "adam", "lr": 1e-4}, loss={"name": "l1_ssim_loss"}, gradient_clip_val=0.1)
+    tr = mon_amd.Trainer(model, optimizer={"name": "adam", "lr": 1e-4}, loss={"name": "l1_ssim_loss"}, gradient_clip_val=0.1, compute_dtype=a.dtype)
 else:       # zero-reference training of Zero-DCE with the reference's optimiser config (zero_dce_re_sice_mix.py:46-51,106)
     model = mon_amd.MODELS.build(name="zero_dce_re", seed=1).to(f"cuda:{local}")
-    tr = mon_amd.Trainer(model, optimizer={"name": "adam", "lr": 5e-5, "betas": (0.9, 0.99), "weight_decay": 1e-5}, gradient_clip_val=0.1)
+    tr = mon_amd.Trainer(model, optimizer={"name": "adam", "lr": 5e-5, "betas": (0.9, 0.99), "weight_decay": 1e-5}, gradient_clip_val=0.1,
+                         compute_dtype=a.dtype)
 g = torch.Generator().manual_seed(2 + rank)
 tgt = torch.rand(a.batch, 3, *a.hw, generator=g).cuda()
 img = (tgt ** 2.2 * 0.4).contiguous()
@@ -59,7 +60,7 @@ if world > 1:
 fwd_gflop = {64: 2530.0, 32: 634.5}.get(a.base)
 if rank == 0:
     wl = {"unet": f"unet{a.base} train L1+SSIM", "llunetpp": "llunet++ train L1+SSIM", "zero_dce": "zero_dce train zero-reference loss"}[a.model]
-    rec = {"workload": f"{wl} batch={a.batch}/GPU {a.hw[0]}x{a.hw[1]} {a.dtype if a.model == 'unet' else 'f32'}", "n_gpus": world, "s_per_step": round(dt.item(), 4),
+    rec = {"workload": f"{wl} batch={a.batch}/GPU {a.hw[0]}x{a.hw[1]} {a.dtype}", "n_gpus": world, "s_per_step": round(dt.item(), 4),
            "images_per_s": round(a.batch * world / dt.item(), 3), "loss_first_last": [round(losses[0], 5), round(losses[-1], 5)],
            "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
     if a.model == "unet" and fwd_gflop and tuple(a.hw) == (1080, 1920):
