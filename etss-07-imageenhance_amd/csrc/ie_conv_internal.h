@@ -17,7 +17,8 @@ struct ConvNParams {
 // direct kernel for thin ones.  Returns an ie_status.
 int ie_convn_launch(const ConvNParams& p, hipStream_t stream);
 
-// Matrix-core weight gradient (ie_wgrad_mfma.hip): 16-bit NHWC, 3x3 / stride 1 / pad 1 / zero padding, channel counts multiples of 8.
+// Matrix-core weight gradient (ie_wgrad_mfma.hip): 16-bit NHWC, 3x3 / stride 1 / pad 1 / zero padding or 1x1 / pad 0, channel counts
+// multiples of 8.
 bool ie_wgrad_mfma_applicable(int kh, int kw, int stride, int pad, int pad_mode, int cs, int cout);
 int ie_wgrad_mfma_launch(const void* x, const void* dy, int dtype, float* dw_hwio, int N, int H, int W, int cs, int cout, int cin_total, int cbase,
-                         hipStream_t stream);
+                         int ksize, hipStream_t stream);

@@ -193,6 +193,32 @@ __global__ void channel_sum_kernel(const T* __restrict__ x, double* __restrict__
         atomicAdd(&acc[c0 + c], s);
     }
 }
+// 16-bit tensors with C % 8 == 0: thread = (pixel slot, 8-channel chunk), 16-byte loads; fp32 partial sums over a bounded number
+// of pixels per thread (launch: <= ~512), combined in double
+template <typename T>
+__global__ __launch_bounds__(256) void channel_sum_v8_kernel(const T* __restrict__ x, double* __restrict__ acc, size_t npix, int C, int c0, int nch) {
+    typedef __attribute__((ext_vector_type(8))) T V;
+    const int tpc = 256 / nch;
+    const int ch = threadIdx.x % nch, ps = threadIdx.x / nch;
+    float s[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s[k] = 0.f;
+    if (ps < tpc)
+        for (size_t pix = (size_t)blockIdx.x * tpc + ps; pix < npix; pix += (size_t)gridDim.x * tpc) {
+            const V v = *(const V*)(x + pix * C + c0 + ch * 8);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s[k] += (float)v[k];
+        }
+    __shared__ float sh[8][256];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sh[k][threadIdx.x] = s[k];
+    __syncthreads();
+    for (int o = threadIdx.x; o < nch * 8; o += 256) {
+        double a = 0.0;
+        for (int q = 0; q < tpc; ++q) a += (double)sh[o & 7][q * nch + (o >> 3)];
+        atomicAdd(&acc[c0 + o], a);
+    }
+}
 __global__ void store_f64_as_f32_kernel(const double* __restrict__ a, float* y, int n, int accumulate) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) y[i] = (accumulate ? y[i] : 0.f) + (float)a[i];
@@ -595,7 +621,7 @@ static int wgrad_impl(ie_convn_desc* d, const void* const* srcs, const int* cs, 
     for (int s = 0; s < d->nsrc; ++s) {
         if constexpr (sizeof(T) == 2) {
             if (!force_fma && ie_wgrad_mfma_applicable(d->kh, d->kw, d->stride, d->pad, d->pad_mode, cs[s], d->Cout)) {
-                rc = ie_wgrad_mfma_launch(srcs[s], dy, ie_elem<T>::dtype, dw_hwio, d->N, d->H, d->W, cs[s], d->Cout, Cin, cbase, st);
+                rc = ie_wgrad_mfma_launch(srcs[s], dy, ie_elem<T>::dtype, dw_hwio, d->N, d->H, d->W, cs[s], d->Cout, Cin, cbase, d->kh, st);
                 if (rc != IE_OK) return rc;
                 cbase += cs[s];
                 continue;
@@ -621,7 +647,19 @@ static int wgrad_impl(ie_convn_desc* d, const void* const* srcs, const int* cs, 
     if (dbias) {
         IE_HIP_CHECK(hipMemsetAsync(ws, 0, sizeof(double) * d->Cout, st));
         const size_t npix = (size_t)d->N * d->Ho * d->Wo;
-        for (int off = 0; off < d->Cout; off += 256) {
+        const bool sum_v8 = sizeof(T) == 2 && (d->Cout & 7) == 0;
+        for (int off = 0; sum_v8 && off < d->Cout; off += 2048) {
+            const int cn = d->Cout - off < 2048 ? d->Cout - off : 2048;
+            const int nch = cn / 8, tpc = 256 / nch;
+            size_t blocks = (npix + (size_t)tpc * 16 - 1) / ((size_t)tpc * 16);
+            if (blocks > 2048) blocks = 2048;
+            const size_t min_blocks = (npix + (size_t)tpc * 512 - 1) / ((size_t)tpc * 512);
+            if (blocks < min_blocks) blocks = min_blocks;
+            if constexpr (sizeof(T) == 2)
+                hipLaunchKernelGGL(channel_sum_v8_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, st, (const T*)dy, ws, npix, d->Cout, off, nch);
+            IE_LAUNCH_CHECK();
+        }
+        for (int off = 0; !sum_v8 && off < d->Cout; off += 256) {
             const int cn = d->Cout - off < 256 ? d->Cout - off : 256;
             size_t blocks = (npix + (size_t)(256 / cn) * 64 - 1) / ((size_t)(256 / cn) * 64);
             if (blocks > 1024) blocks = 1024;

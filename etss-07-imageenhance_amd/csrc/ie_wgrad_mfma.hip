@@ -51,8 +51,11 @@ __device__ __forceinline__ typename ie_elem<T>::frag wm_frag(const unsigned char
     return __builtin_bit_cast(typename ie_elem<T>::frag, v);
 }
 
-template <typename T>
+// KS = 3: 3x3 / pad 1 (9 taps).  KS = 1: 1x1 / pad 0 -- the same staging (the halo rows and pixels are loaded and unused; the
+// layer is HBM-bound either way), one tap: the centre position of the 3x3 window.
+template <typename T, int KS>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_kernel(WgradMParams p) {
+    constexpr int NT = KS * KS;
     __shared__ __attribute__((aligned(16))) unsigned char lds[WM_LDS];
     const int t = threadIdx.x, lane = t & 63;
     const int cb = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -102,9 +105,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_kernel(WgradMParams p)
     }
     const bool wave_live = ci_t + cb * 16 < p.Cs;
 
-    ie_f32x4 acc[9][4];
+    ie_f32x4 acc[NT][4];
 #pragma unroll
-    for (int a = 0; a < 9; ++a)
+    for (int a = 0; a < NT; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = ie_f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -131,13 +134,19 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_kernel(WgradMParams p)
             // Cout see zero dY fragments, so all four MFMAs of a tap issue unconditionally (no branches inside the chain)
             const unsigned char* xr[3] = {lds + (rr & 3) * WM_ROWB, lds + ((rr + 1) & 3) * WM_ROWB, lds + ((rr + 2) & 3) * WM_ROWB};
             typename ie_elem<T>::frag a[3];
-            a[0] = wm_frag<T>(xr[0], aoff[0][0], aoff[0][1]);
-            a[1] = wm_frag<T>(xr[0], aoff[1][0], aoff[1][1]);
+            if constexpr (KS == 3) {
+                a[0] = wm_frag<T>(xr[0], aoff[0][0], aoff[0][1]);
+                a[1] = wm_frag<T>(xr[0], aoff[1][0], aoff[1][1]);
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                if (tap + 2 < 9) a[(tap + 2) % 3] = wm_frag<T>(xr[(tap + 2) / 3], aoff[(tap + 2) % 3][0], aoff[(tap + 2) % 3][1]);
+                for (int tap = 0; tap < 9; ++tap) {
+                    if (tap + 2 < 9) a[(tap + 2) % 3] = wm_frag<T>(xr[(tap + 2) / 3], aoff[(tap + 2) % 3][0], aoff[(tap + 2) % 3][1]);
 #pragma unroll
-                for (int cob = 0; cob < 4; ++cob) acc[tap][cob] = ie_elem<T>::mfma16(a[tap % 3], b[cob], acc[tap][cob]);
+                    for (int cob = 0; cob < 4; ++cob) acc[tap][cob] = ie_elem<T>::mfma16(a[tap % 3], b[cob], acc[tap][cob]);
+                }
+            } else {
+                a[0] = wm_frag<T>(xr[1], aoff[1][0], aoff[1][1]);
+#pragma unroll
+                for (int cob = 0; cob < 4; ++cob) acc[0][cob] = ie_elem<T>::mfma16(a[0], b[cob], acc[0][cob]);
             }
         }
         if (y + 1 < y1) {                           // rows fetched during the previous step: input row y+2, dY row y+1
@@ -155,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_kernel(WgradMParams p)
     if (!wave_live) return;
     const int co_l = lane & 15;
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap)
+    for (int tap = 0; tap < NT; ++tap)
 #pragma unroll
         for (int cob = 0; cob < 4; ++cob) {
             const int co = co_t + cob * 16 + co_l;
@@ -170,14 +179,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_kernel(WgradMParams p)
 
 }  // namespace
 
-// One source of a 3x3 / stride 1 / pad 1 / zero-padded layer: dw_hwio[tap][cbase + ci][co] += X (*) dY.  dtype IE_F16 / IE_BF16,
+// One source of a 3x3 / stride 1 / pad 1 / zero-padded layer (ksize 3) or of a 1x1 / pad 0 layer (ksize 1):
+// dw_hwio[tap][cbase + ci][co] += X (*) dY.  dtype IE_F16 / IE_BF16,
 // cs % 8 == 0 and Cout % 8 == 0 (16-byte channel chunks); the caller checked applicability with ie_wgrad_mfma_applicable.
 bool ie_wgrad_mfma_applicable(int kh, int kw, int stride, int pad, int pad_mode, int cs, int cout) {
-    return kh == 3 && kw == 3 && stride == 1 && pad == 1 && pad_mode == IE_PAD_ZEROS && (cs & 7) == 0 && (cout & 7) == 0;
+    const bool k3 = kh == 3 && kw == 3 && pad == 1 && pad_mode == IE_PAD_ZEROS, k1 = kh == 1 && kw == 1 && pad == 0;
+    return (k3 || k1) && stride == 1 && (cs & 7) == 0 && (cout & 7) == 0;
 }
 
 int ie_wgrad_mfma_launch(const void* x, const void* dy, int dtype, float* dw_hwio, int N, int H, int W, int cs, int cout, int cin_total, int cbase,
-                         hipStream_t stream) {
+                         int ksize, hipStream_t stream) {
     WgradMParams p;
     p.x = x; p.dy = dy; p.dw = dw_hwio; p.N = N; p.H = H; p.W = W; p.Cs = cs; p.Cout = cout; p.Cin_total = cin_total; p.cbase = cbase;
     p.co_tiles = ie_cdiv(cout, 64);
@@ -199,9 +210,15 @@ int ie_wgrad_mfma_launch(const void* x, const void* dy, int dtype, float* dw_hwi
     p.rows_per_wg = ie_cdiv(H, (int)best);
     const long ychunks = ie_cdiv(H, p.rows_per_wg);
     const dim3 grid((unsigned)tiles, (unsigned)strips, (unsigned)ychunks);
-    if (dtype == IE_F16) hipLaunchKernelGGL(conv_wgrad_mfma_kernel<_Float16>, grid, dim3(256), 0, stream, p);
-    else if (dtype == IE_BF16) hipLaunchKernelGGL(conv_wgrad_mfma_kernel<__bf16>, grid, dim3(256), 0, stream, p);
-    else IE_FAIL(IE_ERR_INVALID, "ie_convn_wgrad_nhwc: matrix-core path needs a 16-bit dtype");
+    if (dtype != IE_F16 && dtype != IE_BF16) IE_FAIL(IE_ERR_INVALID, "ie_convn_wgrad_nhwc: matrix-core path needs a 16-bit dtype");
+    const bool h = dtype == IE_F16;
+    if (ksize == 3) {
+        if (h) hipLaunchKernelGGL((conv_wgrad_mfma_kernel<_Float16, 3>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((conv_wgrad_mfma_kernel<__bf16, 3>), grid, dim3(256), 0, stream, p);
+    } else {
+        if (h) hipLaunchKernelGGL((conv_wgrad_mfma_kernel<_Float16, 1>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((conv_wgrad_mfma_kernel<__bf16, 1>), grid, dim3(256), 0, stream, p);
+    }
     IE_LAUNCH_CHECK();
     return IE_OK;
 }

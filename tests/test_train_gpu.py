@@ -208,11 +208,13 @@ WGRAD16_CASES = [
     dict(cs=[72, 128], co=136, n=1, h=40, w=31),  # tiles straddling 64 on both sides
     dict(cs=[64], co=64, n=1, h=67, w=120),       # several row chunks per strip
     dict(cs=[12], co=20, n=1, h=6, w=9),          # channels not multiples of 8 -> scalar kernel
+    dict(cs=[64, 32, 8], co=40, n=2, h=21, w=45, k=1),   # 1x1 / pad 0 (LLUnet++ skip convs): the single-tap form of the kernel
+    dict(cs=[16], co=16, n=1, h=4, w=100, k=1),
 ]
 
 
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
-@pytest.mark.parametrize("c", WGRAD16_CASES, ids=lambda c: f"{'+'.join(map(str, c['cs']))}-{c['co']}-{c['h']}x{c['w']}")
+@pytest.mark.parametrize("c", WGRAD16_CASES, ids=lambda c: f"{'+'.join(map(str, c['cs']))}-{c['co']}-{c['h']}x{c['w']}-k{c.get('k', 3)}")
 def test_conv_wgrad_16bit_matrix_core(c, dtype):
     """16-bit weight gradient (matrix-core kernel where it applies) against float64 autograd on the SAME rounded inputs."""
     tdt = ops.TORCH_DT[dtype]
@@ -221,21 +223,22 @@ def test_conv_wgrad_16bit_matrix_core(c, dtype):
     xs16 = [torch.randn(n, ci, h, w, generator=g).to(tdt) for ci in c["cs"]]
     cin = sum(c["cs"])
     dy16 = torch.randn(n, c["co"], h, w, generator=g).to(tdt)
-    wt = torch.zeros(c["co"], cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    k = c.get("k", 3)
+    wt = torch.zeros(c["co"], cin, k, k, dtype=torch.float64, requires_grad=True)
     b = torch.zeros(c["co"], dtype=torch.float64, requires_grad=True)
-    F.conv2d(torch.cat([x.double() for x in xs16], 1), wt, b, padding=1).backward(dy16.double())
+    F.conv2d(torch.cat([x.double() for x in xs16], 1), wt, b, padding=k // 2).backward(dy16.double())
     cw = ops.ConvWeights(wt.detach().float(), b.detach().float(), "cuda")
     xd = [x.cuda().contiguous(memory_format=CL) for x in xs16]
     dyd = dy16.cuda().contiguous(memory_format=CL)
-    dw = torch.full((9 * cin * c["co"],), 7.0, device="cuda")
+    dw = torch.full((k * k * cin * c["co"],), 7.0, device="cuda")
     db = torch.full((c["co"],), 7.0, device="cuda")
-    ops.conv2d_wgrad(xd, dyd, cw, dw, db, 1, 1)
-    got = host(dw.reshape(3, 3, cin, c["co"]).permute(3, 2, 0, 1)).double()
+    ops.conv2d_wgrad(xd, dyd, cw, dw, db, 1, k // 2)
+    got = host(dw.reshape(k, k, cin, c["co"]).permute(3, 2, 0, 1)).double()
     # products of 16-bit values are exact in fp32; only the fp32 summation order differs
     assert rel_err(got, wt.grad) < 2e-5
     assert rel_err(host(db).double(), b.grad) < 2e-5
-    ops.conv2d_wgrad(xd, dyd, cw, dw, None, 1, 1, accumulate=True)
-    assert rel_err(host(dw.reshape(3, 3, cin, c["co"]).permute(3, 2, 0, 1)).double(), 2 * wt.grad) < 2e-5
+    ops.conv2d_wgrad(xd, dyd, cw, dw, None, 1, k // 2, accumulate=True)
+    assert rel_err(host(dw.reshape(k, k, cin, c["co"]).permute(3, 2, 0, 1)).double(), 2 * wt.grad) < 2e-5
 
 
 def test_dgrad_rejects_replicate():
