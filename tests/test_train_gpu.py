@@ -505,22 +505,28 @@ def test_zero_dce_loss_terms_and_gradients(n, h, w):
     assert rel_err(host(tape.g[id(a_dev)]), ar.grad) < 2e-5
 
 
-def test_le_curve_backward_matches_autograd():
+@pytest.mark.parametrize("iters,shared", [(8, False), (4, False), (8, True)])       # 8 x 3 maps: the six-vector fast path; others: generic kernel
+def test_le_curve_backward_matches_autograd(iters, shared):
     g = torch.Generator().manual_seed(2)
     n, h, w = 2, 19, 23
+    cp = 3 if shared else 3 * iters
     img = torch.rand(n, 3, h, w, generator=g)
-    adj = torch.tanh(torch.randn(n, 24, h, w, generator=g)).double().requires_grad_(True)
+    adj = torch.tanh(torch.randn(n, cp, h, w, generator=g)).double().requires_grad_(True)
     y = img.double()
-    for i in range(8):
-        y = y + adj[:, 3 * i:3 * i + 3] * (y ** 2 - y)
+    for i in range(iters):
+        y = y + (adj if shared else adj[:, 3 * i:3 * i + 3]) * (y ** 2 - y)
     gy = torch.randn(n, 3, h, w, generator=g)
     y.backward(gy.double())
     L = capi.lib()
     a_dev = adj.detach().float().cuda().contiguous(memory_format=CL)
     out = torch.full_like(a_dev, 0.5, memory_format=CL)
     img_dev, gy_dev = img.cuda(), gy.cuda()          # keep the device tensors alive across the asynchronous call
-    capi.check(L.ie_le_curve_backward(capi.ptr(img_dev), capi.ptr(a_dev), 24, capi.ptr(gy_dev), capi.ptr(out), n, h, w, 8, 1, capi.current_stream()))
+    capi.check(L.ie_le_curve_backward(capi.ptr(img_dev), capi.ptr(a_dev), cp, capi.ptr(gy_dev), capi.ptr(out), n, h, w, iters, 1,
+                                      capi.current_stream()))
     assert rel_err(host(out), adj.grad + 0.5) < 1e-5
+    capi.check(L.ie_le_curve_backward(capi.ptr(img_dev), capi.ptr(a_dev), cp, capi.ptr(gy_dev), capi.ptr(out), n, h, w, iters, 0,
+                                      capi.current_stream()))
+    assert rel_err(host(out), adj.grad) < 1e-5
 
 
 def test_zero_dce_training_steps_match_torch():
