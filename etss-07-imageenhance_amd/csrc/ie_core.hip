@@ -90,6 +90,27 @@ __global__ void le_curve_kernel(const float* __restrict__ img, const float* __re
     }
 }
 
+// 8 iterations x 3 maps, not shared (the reference configuration): the pixel's 24 curve values as six 16-byte loads
+__global__ void le_curve8_kernel(const float* __restrict__ img, const float* __restrict__ adj, float* __restrict__ out, size_t plane,
+                                 size_t total_px) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total_px) return;
+    const size_t n = i / plane, pix = i % plane;
+    float r[24];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const ie_f32x4 v = *(const ie_f32x4*)(adj + i * 24 + j * 4);
+        r[4 * j] = v[0]; r[4 * j + 1] = v[1]; r[4 * j + 2] = v[2]; r[4 * j + 3] = v[3];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float y = img[(n * 3 + c) * plane + pix];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) y = ie_curve_step(y, r[3 * k + c]);
+        out[(n * 3 + c) * plane + pix] = y;
+    }
+}
+
 // Bilinear resize, NCHW fp32, F.interpolate(mode="bilinear") semantics (what kornia's resize
 // inside VisionModel.infer reduces to, core/image/geometry/transform.py:216-223, and
 // nn.Upsample(bilinear, align_corners=True), llunetpp.py:182).
@@ -176,8 +197,11 @@ IE_EXPORT int ie_le_curve(const float* img, const float* adjust_nhwc, int Cp, fl
     if (!img || !adjust_nhwc || !enhanced || N <= 0 || H <= 0 || W <= 0 || iters <= 0 || Cp < 3)
         IE_FAIL(IE_ERR_INVALID, "ie_le_curve: bad args");
     const size_t plane = (size_t)H * W, total = plane * N;
-    hipLaunchKernelGGL(le_curve_kernel, grid_for(total, 256), 256, 0, (hipStream_t)stream, img, adjust_nhwc, Cp, enhanced,
-                       plane, total, iters, shared);
+    if (iters == 8 && Cp == 24 && !shared)
+        hipLaunchKernelGGL(le_curve8_kernel, grid_for(total, 256), 256, 0, (hipStream_t)stream, img, adjust_nhwc, enhanced, plane, total);
+    else
+        hipLaunchKernelGGL(le_curve_kernel, grid_for(total, 256), 256, 0, (hipStream_t)stream, img, adjust_nhwc, Cp, enhanced,
+                           plane, total, iters, shared);
     IE_LAUNCH_CHECK();
     return IE_OK;
 }
