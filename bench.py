@@ -244,7 +244,7 @@ def main():
             "metric": "enhanced_images_per_sec_1080p", "value": round(value, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "zero_dce_re batch=64/GPU 1920x1080 (BASELINE.json configs[1])", "frames_per_gpu": n,
+            "config": {"workload": f"zero_dce_re batch={n}/GPU {W}x{H} (BASELINE.json configs[1])", "frames_per_gpu": n,
                        "global_batch": n * world, "height": H, "width": W, "input": "NCHW fp32 in HBM",
                        "output": "enhanced NCHW fp32" if args.output == "f32" else "enhanced NHWC uint8",
                        "parallelism": f"frames sharded over {world} GPU(s), no collective", "tflops_per_gpu": round(value / world * H * W * FLOP_PER_PX / 1e12, 1)},
