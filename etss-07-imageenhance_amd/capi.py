@@ -33,7 +33,7 @@ SYMBOLS = [
     "ie_mconv_packed_bytes", "ie_mconv_pack_weights", "ie_mconv_pack_weights_dev", "ie_mconv_nhwc", "ie_dsconv_nhwc",
     "ie_norm_forward_nhwc_f32", "ie_norm_backward_nhwc_f32", "ie_convn_wgrad_nhwc_f32", "ie_convn_dgrad_nhwc_f32",
     "ie_maxpool2x2_backward_nhwc_f32", "ie_resize_backward_nhwc_f32", "ie_crop_nhwc_f32", "ie_pixel_unshuffle_nhwc_f32",
-    "ie_act_backward_f32", "ie_act_backward", "ie_l1_loss_f32", "ie_ssim_forward_f32", "ie_ssim_backward_f32", "ie_sumsq_f32", "ie_adam_step_f32",
+    "ie_act_backward_f32", "ie_act_backward", "ie_pixel_unshuffle_nhwc", "ie_l1_loss_f32", "ie_ssim_forward_f32", "ie_ssim_backward_f32", "ie_sumsq_f32", "ie_adam_step_f32",
     "ie_norm_forward_nhwc", "ie_norm_backward_nhwc", "ie_convn_wgrad_nhwc", "ie_maxpool2x2_backward_nhwc", "ie_resize_backward_nhwc", "ie_crop_nhwc",
     "ie_zref_workspace_floats", "ie_zref_image_losses_f32", "ie_tv_loss_nhwc_f32", "ie_le_curve_backward",
     "ie_zdce_create", "ie_zdce_set_layer", "ie_zdce_finalize", "ie_zdce_reserve", "ie_zdce_forward",
@@ -130,6 +130,7 @@ def lib():
     L.ie_pixel_unshuffle_nhwc_f32.argtypes = [vp, vp, ip, ip, ip, ip, ip, ip, vp]
     L.ie_act_backward_f32.argtypes = [vp, vp, vp, sz, ip, fp, fp, fp, ip, vp]
     L.ie_act_backward.argtypes = [vp, vp, vp, ip, sz, ip, fp, fp, fp, ip, vp]
+    L.ie_pixel_unshuffle_nhwc.argtypes = [vp, vp, ip, ip, ip, ip, ip, ip, ip, vp]
     L.ie_l1_loss_f32.argtypes = [vp, vp, sz, vp, vp, fp, ip, vp]
     L.ie_ssim_forward_f32.argtypes = [vp, vp, ip, ip, ip, ip, i64, i64, i64, i64, fp, fp, fp, fp, vp, vp, vp]
     L.ie_ssim_backward_f32.argtypes = [vp, vp, vp, vp, vp, ip, ip, ip, ip, i64, i64, i64, i64, fp, fp, ip, ip, vp]

@@ -362,7 +362,8 @@ __global__ void crop_nhwc_kernel(const T* __restrict__ src, T* __restrict__ dst,
 }
 
 // adjoint of pixel shuffle: dx[n,h,w,c*r*r+i*r+j] = dy[n,h*r+i,w*r+j,c]
-__global__ void pixel_unshuffle_kernel(const float* __restrict__ dy, float* __restrict__ dx, int H, int W, int Co, int r,
+template <typename T>
+__global__ void pixel_unshuffle_kernel(const T* __restrict__ dy, T* __restrict__ dx, int H, int W, int Co, int r,
                                        int accumulate, size_t total) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
@@ -372,7 +373,7 @@ __global__ void pixel_unshuffle_kernel(const float* __restrict__ dy, float* __re
     const int h = (int)(q % H);
     const size_t n = q / H;
     const int c = ch / (r * r), ii = (ch / r) % r, jj = ch % r;
-    dx[i] = (accumulate ? dx[i] : 0.f) + dy[((n * H * r + h * r + ii) * (size_t)(W * r) + w * r + jj) * Co + c];
+    dx[i] = (T)((accumulate ? (float)dx[i] : 0.f) + (float)dy[((n * H * r + h * r + ii) * (size_t)(W * r) + w * r + jj) * Co + c]);
 }
 
 // dx = dy * act'(.) from the activation OUTPUT y; mode 5: clamp(x, lo, hi) from its INPUT x (pass where lo <= x <= hi).
@@ -821,12 +822,25 @@ IE_EXPORT int ie_crop_nhwc_f32(const float* src, float* dst, int N, int Hs, int 
     return crop_impl<float>(src, dst, N, Hs, Ws, C, top, left, H, W, accumulate, stream);
 }
 
-IE_EXPORT int ie_pixel_unshuffle_nhwc_f32(const float* dy, float* dx, int N, int H, int W, int Cout, int r, int accumulate, void* stream) {
-    if (!dy || !dx || N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || r <= 0) IE_FAIL(IE_ERR_INVALID, "ie_pixel_unshuffle_nhwc_f32: bad args");
+template <typename T>
+static int unshuffle_impl(const void* dy, void* dx, int N, int H, int W, int Cout, int r, int accumulate, void* stream) {
+    if (!dy || !dx || N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || r <= 0) IE_FAIL(IE_ERR_INVALID, "ie_pixel_unshuffle_nhwc: bad args");
     const size_t total = (size_t)N * H * W * Cout * r * r;
-    hipLaunchKernelGGL(pixel_unshuffle_kernel, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, dy, dx, H, W, Cout, r, accumulate, total);
+    hipLaunchKernelGGL(pixel_unshuffle_kernel<T>, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, (const T*)dy, (T*)dx, H, W, Cout, r, accumulate,
+                       total);
     IE_LAUNCH_CHECK();
     return IE_OK;
+}
+IE_EXPORT int ie_pixel_unshuffle_nhwc(const void* dy, void* dx, int dtype, int N, int H, int W, int Cout, int r, int accumulate, void* stream) {
+    switch (dtype) {
+    case IE_F32: return unshuffle_impl<float>(dy, dx, N, H, W, Cout, r, accumulate, stream);
+    case IE_F16: return unshuffle_impl<_Float16>(dy, dx, N, H, W, Cout, r, accumulate, stream);
+    case IE_BF16: return unshuffle_impl<__bf16>(dy, dx, N, H, W, Cout, r, accumulate, stream);
+    default: IE_FAIL(IE_ERR_INVALID, "ie_pixel_unshuffle_nhwc: bad dtype");
+    }
+}
+IE_EXPORT int ie_pixel_unshuffle_nhwc_f32(const float* dy, float* dx, int N, int H, int W, int Cout, int r, int accumulate, void* stream) {
+    return unshuffle_impl<float>(dy, dx, N, H, W, Cout, r, accumulate, stream);
 }
 
 template <typename T>

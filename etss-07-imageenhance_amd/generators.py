@@ -535,8 +535,6 @@ class UNet(_GraphModel):
 
         mixed = store.compute_dtype != "f32"
         tdt = ops.TORCH_DT[store.compute_dtype]
-        if mixed and self.upsampler != "bilinear":
-            raise capi.IEError("unet: the 16-bit training graph covers the bilinear decoder (the PixelShuffle adjoint is fp32 only)")
 
         def dc(name, srcs):
             y = None

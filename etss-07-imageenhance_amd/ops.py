@@ -411,11 +411,13 @@ def crop_into(src, dst, top, left, accumulate):
 
 
 def pixel_unshuffle_into(dy, dx, r, accumulate):
-    _chk(dy); _chk(dx)
+    _chk_any(dy); _chk_any(dx)
+    if dy.dtype != dx.dtype:
+        raise capi.IEError("pixel_unshuffle_into: dy and dx must share a dtype")
     n, c, h, w = dx.shape
     with torch.cuda.device(dy.device):
-        capi.check(capi.lib().ie_pixel_unshuffle_nhwc_f32(capi.ptr(dy), capi.ptr(dx), n, h, w, c // (r * r), r, int(accumulate),
-                                                          capi.current_stream()), "ie_pixel_unshuffle_nhwc_f32")
+        capi.check(capi.lib().ie_pixel_unshuffle_nhwc(capi.ptr(dy), capi.ptr(dx), _dt(dy), n, h, w, c // (r * r), r, int(accumulate),
+                                                      capi.current_stream()), "ie_pixel_unshuffle_nhwc")
 
 
 def act_backward_into(dy, ref, dx, act, slope=0.0, lo=0.0, hi=0.0, accumulate=False):

@@ -229,6 +229,7 @@ int ie_crop_nhwc_f32(const float* src_dev, float* dst_dev, int N, int Hs, int Ws
                      int accumulate, void* stream);
 /* Adjoint of ie_pixel_shuffle_nhwc_f32: dy (N,H*r,W*r,Cout) -> dx (N,H,W,Cout*r*r). */
 int ie_pixel_unshuffle_nhwc_f32(const float* dy_dev, float* dx_dev, int N, int H, int W, int Cout, int r, int accumulate, void* stream);
+int ie_pixel_unshuffle_nhwc(const void* dy_dev, void* dx_dev, int dtype, int N, int H, int W, int Cout, int r, int accumulate, void* stream);
 /* dx (+)= dy * act'(ref): act = ie_act with ref = the activation's OUTPUT, or act = 5: clamp with ref = its INPUT
  * (gradient passes where lo <= ref <= hi, like torch.clamp). */
 int ie_act_backward_f32(const float* dy_dev, const float* ref_dev, float* dx_dev, size_t n, int act, float slope, float lo, float hi,

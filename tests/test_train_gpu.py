@@ -325,6 +325,11 @@ def test_crop_unshuffle_act_backward():
     dx = torch.empty(2, 12, 5, 6, device="cuda").contiguous(memory_format=CL)
     ops.pixel_unshuffle_into(dev(g), dx, 2, 0)
     assert torch.equal(host(dx), x.grad)
+    for tdt in (torch.float16, torch.bfloat16):              # 16-bit twin: a pure permutation, exact
+        g16 = g.to(tdt)
+        dx16 = torch.empty(2, 12, 5, 6, device="cuda", dtype=tdt).contiguous(memory_format=CL)
+        ops.pixel_unshuffle_into(g16.cuda().contiguous(memory_format=CL), dx16, 2, 0)
+        assert torch.equal(host(dx16), F.pixel_unshuffle(g16.float(), 2).to(tdt))
     for act, fn in (("relu", F.relu), ("lrelu", lambda t: F.leaky_relu(t, 0.2)), ("tanh", torch.tanh), ("sigmoid", torch.sigmoid)):
         x = rnd(1, 3, 9, 10, seed=4).requires_grad_(True)
         y = fn(x)
@@ -650,17 +655,18 @@ def test_hinet_training_step_matches_torch():
         assert float((sd1[k] - ref).abs().max()) < 0.05 * lr, k
 
 
-@pytest.mark.parametrize("dt,min_cos", [("f16", 0.98), ("bf16", 0.85)])
-def test_unet_mixed_precision_training_step(dt, min_cos):
+@pytest.mark.parametrize("dt,min_cos,upsampler", [("f16", 0.98, "bilinear"), ("bf16", 0.85, "bilinear"), ("f16", 0.98, "pixelshuffle"),
+                                                  ("bf16", 0.85, "pixelshuffle")])
+def test_unet_mixed_precision_training_step(dt, min_cos, upsampler):
     """compute_dtype f16 / bf16: 16-bit activations and gradients between matrix-core convolutions (forward and data gradient), fp32
     master weights / statistics / weight gradients / Adam.  Against torch float64 the loss agrees to 16-bit accuracy; the gradient
     direction degrades with back-propagation depth because BatchNorm's backward subtracts the mean of a 16-bit-rounded gradient
     (measured cosine 0.99 with fp16, 0.90 with bf16 on this 23-layer net, 0.9995 at the last layer; tools/mixed_diag.py)."""
-    model = _unet("bilinear", seed=13, base=16)          # 16-bit sources need >= 16 channels on the device-packed path
+    model = _unet(upsampler, seed=13, base=16)           # 16-bit sources need >= 16 channels on the device-packed path
     sd0 = model.state_dict()
     batches = _batches(2, 48, 64, 1, seed=14)
     lr, clip, eps = 1e-3, 0.1, 1e-3
-    fwd = lambda p, b, x: otrain.unet_forward_train(p, b, x, "bilinear", True)
+    fwd = lambda p, b, x: otrain.unet_forward_train(p, b, x, upsampler, True)
     log, final = otrain.training_steps({k: v.double() for k, v in sd0.items()}, [(a.double(), b.double()) for a, b in batches], fwd,
                                        lambda a, b: otrain.l1_ssim_loss(a, b), lr=lr, clip=clip, eps=eps)
     tr = mon_amd.Trainer(model, optimizer={"name": "adam", "lr": lr, "eps": eps}, loss={"name": "l1_ssim_loss"}, gradient_clip_val=clip,
