@@ -34,7 +34,7 @@ constexpr int WM_LDS = 4 * WM_ROWB + 2 * WM_DYB;
 
 struct WgradMParams {
     const void* x; const void* dy; float* dw;
-    int N, H, W, Cs, Cout, Cin_total, cbase, rows_per_wg, co_tiles, xchunks;
+    int N, H, W, Cs, Cout, Cin_total, cbase, rows_per_wg, co_tiles, xchunks, nci;
 };
 
 __device__ __forceinline__ int wm_swz(int pix) { return ((pix >> 1) & 1) | (((pix >> 3) & 1) << 1); }
@@ -53,12 +53,17 @@ __device__ __forceinline__ typename ie_elem<T>::frag wm_frag(const unsigned char
 
 // KS = 3: 3x3 / pad 1 (9 taps).  KS = 1: 1x1 / pad 0 -- the same staging (the halo rows and pixels are loaded and unused; the
 // layer is HBM-bound either way), one tap: the centre position of the 3x3 window.
-template <typename T, int KS>
+// NCO = cout blocks (of 16) per wave.  4: wave w owns cin block w and all four cout blocks (64-wide tiles).  Narrow layers split the
+// waves over cout instead so that none idles: p.nci = live cin blocks of the tile rounded up to a power of two (1, 2, 4), wave w owns
+// cin block w % nci and cout blocks (w / nci) * NCO ... + NCO - 1 (32 -> 32: 2 x 2 waves with one cout block each; 16 -> 64, the RGB
+// edge: one cin block, four waves with one cout block each).
+template <typename T, int KS, int NCO>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_kernel(WgradMParams p) {
     constexpr int NT = KS * KS;
     __shared__ __attribute__((aligned(16))) unsigned char lds[WM_LDS];
     const int t = threadIdx.x, lane = t & 63;
-    const int cb = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int cb = wave % p.nci, cob0 = (wave / p.nci) * NCO;
     const int co_t = (blockIdx.x % p.co_tiles) * 64, ci_t = (blockIdx.x / p.co_tiles) * 64;
     const int n = blockIdx.y / p.xchunks, x0 = (blockIdx.y % p.xchunks) * WM_PX;
     const int y0 = blockIdx.z * p.rows_per_wg, y1 = min(y0 + p.rows_per_wg, p.H);
@@ -95,21 +100,21 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_kernel(WgradMParams p)
 
     // fragment read offsets
     const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
-    int aoff[3][2], boff[4][2];
+    int aoff[3][2], boff[NCO][2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) aoff[kx][h] = wm_unit_off(kx + g * 8 + h * 4 + q, cb * 4 + pp);
 #pragma unroll
-        for (int cob = 0; cob < 4; ++cob) boff[cob][h] = wm_unit_off(g * 8 + h * 4 + q, cob * 4 + pp);
+        for (int cob = 0; cob < NCO; ++cob) boff[cob][h] = wm_unit_off(g * 8 + h * 4 + q, (cob0 + cob) * 4 + pp);
     }
-    const bool wave_live = ci_t + cb * 16 < p.Cs;
+    const bool wave_live = ci_t + cb * 16 < p.Cs && cob0 < 4 && co_t + cob0 * 16 < p.Cout;
 
-    ie_f32x4 acc[NT][4];
+    ie_f32x4 acc[NT][NCO];
 #pragma unroll
     for (int a = 0; a < NT; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = ie_f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < NCO; ++b) acc[a][b] = ie_f32x4{0.f, 0.f, 0.f, 0.f};
 
     // prologue: input rows y0-1, y0, y0+1 -> ring slots 0, 1, 2; dY row y0 -> slot 0
 #pragma unroll
@@ -127,9 +132,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_kernel(WgradMParams p)
         ld = fetch(y + 3, y + 2);               // rows past the chunk / image: loaded (or zeroed) and never stored
         if (wave_live) {
             const unsigned char* dyb = lds + 4 * WM_ROWB + (rr & 1) * WM_DYB;
-            typename ie_elem<T>::frag b[4];
+            typename ie_elem<T>::frag b[NCO];
 #pragma unroll
-            for (int cob = 0; cob < 4; ++cob) b[cob] = wm_frag<T>(dyb, boff[cob][0], boff[cob][1]);
+            for (int cob = 0; cob < NCO; ++cob) b[cob] = wm_frag<T>(dyb, boff[cob][0], boff[cob][1]);
             // A fragments run two taps ahead of the MFMAs that consume them (3 rotating register sets); output channels past
             // Cout see zero dY fragments, so all four MFMAs of a tap issue unconditionally (no branches inside the chain)
             const unsigned char* xr[3] = {lds + (rr & 3) * WM_ROWB, lds + ((rr + 1) & 3) * WM_ROWB, lds + ((rr + 2) & 3) * WM_ROWB};
@@ -141,12 +146,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_kernel(WgradMParams p)
                 for (int tap = 0; tap < 9; ++tap) {
                     if (tap + 2 < 9) a[(tap + 2) % 3] = wm_frag<T>(xr[(tap + 2) / 3], aoff[(tap + 2) % 3][0], aoff[(tap + 2) % 3][1]);
 #pragma unroll
-                    for (int cob = 0; cob < 4; ++cob) acc[tap][cob] = ie_elem<T>::mfma16(a[tap % 3], b[cob], acc[tap][cob]);
+                    for (int cob = 0; cob < NCO; ++cob) acc[tap][cob] = ie_elem<T>::mfma16(a[tap % 3], b[cob], acc[tap][cob]);
                 }
             } else {
                 a[0] = wm_frag<T>(xr[1], aoff[1][0], aoff[1][1]);
 #pragma unroll
-                for (int cob = 0; cob < 4; ++cob) acc[0][cob] = ie_elem<T>::mfma16(a[0], b[cob], acc[0][cob]);
+                for (int cob = 0; cob < NCO; ++cob) acc[0][cob] = ie_elem<T>::mfma16(a[0], b[cob], acc[0][cob]);
             }
         }
         if (y + 1 < y1) {                           // rows fetched during the previous step: input row y+2, dY row y+1
@@ -166,9 +171,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_kernel(WgradMParams p)
 #pragma unroll
     for (int tap = 0; tap < NT; ++tap)
 #pragma unroll
-        for (int cob = 0; cob < 4; ++cob) {
-            const int co = co_t + cob * 16 + co_l;
-            if (co >= p.Cout) continue;
+        for (int cob = 0; cob < NCO; ++cob) {
+            const int co = co_t + (cob0 + cob) * 16 + co_l;
+            if (cob0 + cob >= 4 || co >= p.Cout) continue;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int ci = ci_t + cb * 16 + g * 4 + j;
@@ -211,14 +216,23 @@ int ie_wgrad_mfma_launch(const void* x, const void* dy, int dtype, float* dw_hwi
     const long ychunks = ie_cdiv(H, p.rows_per_wg);
     const dim3 grid((unsigned)tiles, (unsigned)strips, (unsigned)ychunks);
     if (dtype != IE_F16 && dtype != IE_BF16) IE_FAIL(IE_ERR_INVALID, "ie_convn_wgrad_nhwc: matrix-core path needs a 16-bit dtype");
+    // wave layout (see the kernel): nci cin blocks x (4 / nci) cout groups of NCO blocks
+    p.nci = cs <= 16 ? 1 : (cs <= 32 ? 2 : 4);
+    const int live_cob = ie_cdiv(cout < 64 ? cout : 64, 16), cow = 4 / p.nci;
+    int nco = ie_cdiv(live_cob, cow);
+    if (nco == 3) nco = 4;
     const bool h = dtype == IE_F16;
+#define WM_LAUNCH(KS_, NCO_)                                                                                              \
+    do {                                                                                                                  \
+        if (h) hipLaunchKernelGGL((conv_wgrad_mfma_kernel<_Float16, KS_, NCO_>), grid, dim3(256), 0, stream, p);          \
+        else hipLaunchKernelGGL((conv_wgrad_mfma_kernel<__bf16, KS_, NCO_>), grid, dim3(256), 0, stream, p);              \
+    } while (0)
     if (ksize == 3) {
-        if (h) hipLaunchKernelGGL((conv_wgrad_mfma_kernel<_Float16, 3>), grid, dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL((conv_wgrad_mfma_kernel<__bf16, 3>), grid, dim3(256), 0, stream, p);
+        if (nco == 1) WM_LAUNCH(3, 1); else if (nco == 2) WM_LAUNCH(3, 2); else WM_LAUNCH(3, 4);
     } else {
-        if (h) hipLaunchKernelGGL((conv_wgrad_mfma_kernel<_Float16, 1>), grid, dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL((conv_wgrad_mfma_kernel<__bf16, 1>), grid, dim3(256), 0, stream, p);
+        if (nco == 1) WM_LAUNCH(1, 1); else if (nco == 2) WM_LAUNCH(1, 2); else WM_LAUNCH(1, 4);
     }
+#undef WM_LAUNCH
     IE_LAUNCH_CHECK();
     return IE_OK;
 }
