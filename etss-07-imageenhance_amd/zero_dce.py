@@ -186,9 +186,10 @@ class ZeroDCE_RE(ImageEnhancementModel):
     supports_mixed_training = True
 
     def forward_train(self, x, store, tape):
-        """Training graph (zero_dce.py:173-191) on the fp32 building blocks with saved activations: the fused matrix-core plan
-        keeps x1/x4/x6 in LDS and cannot be differentiated, so training runs the layers one by one (the parity-grade fp32
-        path); returns ``adjust`` (NHWC), ``enhanced`` (NCHW, last) and the NCHW image for the zero-reference loss."""
+        """Training graph (zero_dce.py:173-191) on the taped building blocks with saved activations: the fused inference plan
+        keeps x1/x4/x6 in LDS and cannot be differentiated, so training runs the layers one by one -- fp32 kernels (parity
+        grade) or, with the trainer's ``compute_dtype`` bf16 / f16, the generic 16-bit matrix-core kernels; returns ``adjust``
+        (NHWC), ``enhanced`` (NCHW, last) and the NCHW image for the zero-reference loss."""
         from . import ops, train as T
 
         def conv(k, srcs, act):
