@@ -670,6 +670,7 @@ class Trainer:
             st.buffers[k].copy_(ckpt["state_dict"][k])
         self.step = int(ckpt["global_step"])
         self.lr, self.betas, self.eps, self.weight_decay = float(opt["lr"]), tuple(opt["betas"]), float(opt["eps"]), float(opt["weight_decay"])
+        st.repack16()                             # 16-bit graph: packed weight images made before the load are stale
         return self
 
     def sync_to_model(self):

@@ -624,6 +624,25 @@ def test_checkpoint_resume_continues_bit_identically(tmp_path):
     assert torch.equal(m.state_dict()["inc.conv1.weight"], ck["state_dict"]["inc.conv1.weight"])
 
 
+def test_checkpoint_load_refreshes_16bit_weights(tmp_path):
+    """Loading a checkpoint into a trainer that has already stepped on the 16-bit graph must refresh the packed weight images: its
+    next forward equals that of a fresh trainer loaded from the same file."""
+    batches = _batches(2, 32, 48, 2, seed=12)
+    mk = lambda seed: mon_amd.Trainer(_unet("bilinear", seed=seed, base=16), optimizer={"lr": 1e-2, "eps": 1e-3}, loss={"name": "l1_ssim_loss"},
+                                      gradient_clip_val=0.1, compute_dtype="bf16")
+    a = mk(21)
+    a.training_step({"image": batches[0][0], "ref_image": batches[0][1]})
+    path = a.save_checkpoint(tmp_path / "mixed.pt")
+    b = mk(22)                                                   # different weights, packed images built by its own first step
+    b.training_step({"image": batches[0][0], "ref_image": batches[0][1]})
+    b.load_checkpoint(path)
+    c = mk(23).load_checkpoint(path)
+    lb = float(b.forward_loss({"image": batches[1][0], "ref_image": batches[1][1]})["loss"])
+    lc = float(c.forward_loss({"image": batches[1][0], "ref_image": batches[1][1]})["loss"])
+    la = float(a.forward_loss({"image": batches[1][0], "ref_image": batches[1][1]})["loss"])
+    assert lb == lc and abs(lb - la) < 1e-6
+
+
 def test_hinet_training_step_matches_torch():
     """HINet (half instance norm, Conv4x4 stride 2 and ConvTranspose 2x2 gradients, cross-stage fusion, supervised attention):
     loss = sum over (stage1, enhanced) of L1+SSIM (hinet.py:311-320); one optimiser step vs torch float64 autograd."""
