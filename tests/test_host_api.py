@@ -113,3 +113,42 @@ def test_sharding_ranges():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         shard_range(4, 2, 2)
+
+
+def test_padded_edge_row_maps_and_tape_bookkeeping():
+    """Host logic of the 16-bit training graph that needs no GPU: the zero-padded weight scratch of channel-padded layers (per-source
+    row maps, gradient scatter back into the master layout) and the tape's no-grad / real-channel bookkeeping."""
+    from mon_amd import train as T
+    taps, real, split, co, co_p = 2, [3, 3], [16, 8], 5, 8
+    w = torch.arange(taps * sum(real) * co, dtype=torch.float32) + 1.0
+    b = torch.arange(co, dtype=torch.float32) + 100.0
+    e = T._PaddedEdge(w, b, taps, real, split, co, co_p)
+    wp = e.w.view(taps, sum(split), co_p)
+    ws = w.view(taps, sum(real), co)
+    assert torch.equal(wp[:, 0:3, :co], ws[:, 0:3]) and torch.equal(wp[:, 16:19, :co], ws[:, 3:6])
+    mask = torch.ones_like(wp, dtype=torch.bool)
+    mask[:, 0:3, :co] = False
+    mask[:, 16:19, :co] = False
+    assert float(wp[mask].abs().max()) == 0.0                       # everything outside the two real row ranges / real couts is zero
+    assert torch.equal(e.b[:co], b) and float(e.b[co:].abs().max()) == 0.0
+    w += 1.0                                                        # master weights change (optimiser step) -> refresh picks them up
+    e.refresh()
+    assert torch.equal(e.w.view(taps, sum(split), co_p)[:, 16:19, :co], w.view(taps, sum(real), co)[:, 3:6])
+    e.dw.copy_(torch.arange(e.dw.numel(), dtype=torch.float32))
+    e.db.copy_(torch.arange(co_p, dtype=torch.float32))
+    dw, db = torch.zeros_like(w), torch.zeros_like(b)
+    e.scatter_grads(dw, db)
+    gp = e.dw.view(taps, sum(split), co_p)
+    assert torch.equal(dw.view(taps, sum(real), co)[:, 0:3], gp[:, 0:3, :co]) and torch.equal(dw.view(taps, sum(real), co)[:, 3:6], gp[:, 16:19, :co])
+    assert torch.equal(db, e.db[:co])
+    # tape: no-grad tensors have no slot, a second producer accumulates, real-channel marks default to the tensor's channels
+    tape = T.Tape()
+    x = torch.zeros(1, 16, 2, 2)
+    tape.no_grad(x)
+    assert tape.is_no_grad(x) and tape.slot(x) == (None, 0)
+    y = torch.zeros(1, 16, 2, 2)
+    buf, acc = tape.slot(y)
+    assert acc == 0 and tape.slot(y)[1] == 1 and tape.grad(y) is buf
+    assert T._real_c(y) == 16
+    y._ie_real = 3
+    assert T._real_c(y) == 3
