@@ -273,6 +273,9 @@ inline dim3 norm_apply_v8_grid(int N, int HW, int C, int& nchb) {
     return dim3(chunks, N, ie_cdiv(C8, nchb));
 }
 
+// the apply passes take the 8-channel form for fp32 tensors too (two 16-byte accesses per thread; same arithmetic as the scalar
+// kernels); the statistics passes keep their per-element double accumulation for fp32 (the parity path)
+inline bool norm_apply_v8_ok(int C, int c_begin, int c_count) { return (C & 7) == 0 && (c_begin & 7) == 0 && (c_count & 7) == 0; }
 template <typename T> constexpr bool norm_v8_ok(int C, int c_begin, int c_count) {
     return sizeof(T) == 2 && (C & 7) == 0 && (c_begin & 7) == 0 && (c_count & 7) == 0;
 }
@@ -339,15 +342,13 @@ static int norm_forward_impl(const T* x, const float* gamma, const float* beta, 
                        groups * c_count, count, eps, running_mean, running_var, momentum);
     IE_LAUNCH_CHECK();
     const size_t total = (size_t)N * HW * C;
-    if constexpr (sizeof(T) == 2) {
-        if (norm_v8_ok<T>(C, c_begin, c_count)) {
-            int nchb;
-            const dim3 grid = norm_apply_v8_grid(N, HW, C, nchb);
-            hipLaunchKernelGGL(norm_apply_v8_kernel<T>, grid, dim3(256), 0, st, x, save_mean, save_invstd, gamma, beta, y, HW, C, c_begin, c_count,
-                               n_mul, act, slope, nchb);
-            IE_LAUNCH_CHECK();
-            return IE_OK;
-        }
+    if (norm_apply_v8_ok(C, c_begin, c_count)) {
+        int nchb;
+        const dim3 grid = norm_apply_v8_grid(N, HW, C, nchb);
+        hipLaunchKernelGGL(norm_apply_v8_kernel<T>, grid, dim3(256), 0, st, x, save_mean, save_invstd, gamma, beta, y, HW, C, c_begin, c_count,
+                           n_mul, act, slope, nchb);
+        IE_LAUNCH_CHECK();
+        return IE_OK;
     }
     hipLaunchKernelGGL(norm_apply_kernel<T>, dim3(nblk(total)), dim3(256), 0, st, x, save_mean, save_invstd, gamma, beta, y, HW, C, c_begin,
                        c_count, n_mul, act, slope, total);
@@ -368,15 +369,11 @@ static int norm_backward_impl(const T* x, const T* dy, const T* y, const float* 
     if (rc != IE_OK) return rc;
     const double count = per_sample ? (double)HW : (double)N * HW;
     const size_t total = (size_t)N * HW * C;
-    bool v8 = false;
-    if constexpr (sizeof(T) == 2) v8 = norm_v8_ok<T>(C, c_begin, c_count);
-    if (v8) {
-        if constexpr (sizeof(T) == 2) {
-            int nchb;
-            const dim3 grid = norm_apply_v8_grid(N, HW, C, nchb);
-            hipLaunchKernelGGL(norm_backward_apply_v8_kernel<T>, grid, dim3(256), 0, st, x, dy, y, save_mean, save_invstd, gamma, ws, dx, HW, C,
-                               c_begin, c_count, n_mul, count, act, slope, nchb);
-        }
+    if (norm_apply_v8_ok(C, c_begin, c_count)) {
+        int nchb;
+        const dim3 grid = norm_apply_v8_grid(N, HW, C, nchb);
+        hipLaunchKernelGGL(norm_backward_apply_v8_kernel<T>, grid, dim3(256), 0, st, x, dy, y, save_mean, save_invstd, gamma, ws, dx, HW, C,
+                           c_begin, c_count, n_mul, count, act, slope, nchb);
     } else
         hipLaunchKernelGGL(norm_backward_apply_kernel<T>, dim3(nblk(total)), dim3(256), 0, st, x, dy, y, save_mean, save_invstd, gamma, ws, dx,
                            HW, C, c_begin, c_count, n_mul, count, act, slope, total);
