@@ -807,3 +807,23 @@ def test_fp16_loss_scale_and_skipped_step():
     sd1 = t3.state_dict()
     assert all(torch.equal(sd0[k], sd1[k]) for k in sd0 if "running_" not in k)
     assert float(t3.store.exp_avg.abs().max()) == 0.0
+
+
+def test_unet64_training_full_size_fp32_vs_bf16():
+    """BASELINE config 5 at full frame size (U-Net-64, 2 x 1080p, L1+SSIM, Adam + clip): size-independent properties -- the fp32 and
+    the 16-bit graph start from the same loss (to 16-bit accuracy), both decrease it over three steps and end within 2e-3 of each other."""
+    g = torch.Generator().manual_seed(3)
+    tgt = torch.rand(2, 3, 1080, 1920, generator=g).cuda()
+    img = (tgt ** 2.2 * 0.4).contiguous()
+    traj = {}
+    for dt in ("f32", "bf16"):
+        model = mon_amd.MODELS.build(name="unet", in_channels=3, num_classes=3, base_channels=64, enhance=True, seed=1).to("cuda")
+        tr = mon_amd.Trainer(model, optimizer={"name": "adam", "lr": 1e-4}, loss={"name": "l1_ssim_loss"}, gradient_clip_val=0.1, compute_dtype=dt)
+        traj[dt] = [float(tr.training_step({"image": img, "ref_image": tgt})["loss"]) for _ in range(3)]
+        assert all(math.isfinite(v) for v in traj[dt]) and math.isfinite(tr.grad_norm())
+        del tr, model
+        torch.cuda.empty_cache()
+    assert abs(traj["f32"][0] - traj["bf16"][0]) < 1e-3
+    for dt in traj:
+        assert traj[dt][2] < traj[dt][1] < traj[dt][0]
+    assert abs(traj["f32"][2] - traj["bf16"][2]) < 2e-3
