@@ -133,6 +133,20 @@ __global__ void cast_kernel(const S* __restrict__ src, D* __restrict__ dst, int 
     dst[i] = c < Cs ? (D)(float)src[px * Cs + c] : (D)0.f;
 }
 
+// pure dtype conversion (same channel count): 8 elements per thread, vector loads and stores, no index arithmetic
+template <typename S, typename D>
+__global__ void cast8_kernel(const S* __restrict__ src, D* __restrict__ dst, size_t total8) {
+    typedef __attribute__((ext_vector_type(8))) S SV;
+    typedef __attribute__((ext_vector_type(8))) D DV;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total8) return;
+    const SV v = *(const SV*)(src + i * 8);
+    DV o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (D)(float)v[k];
+    *(DV*)(dst + i * 8) = o;
+}
+
 // instance-norm statistics of a 16-bit tensor: thread = (pixel slot, 8 channels); fp64 partials + atomics
 template <typename T>
 __global__ void norm16_stats(const T* __restrict__ x, double* __restrict__ stats, int HW, int C, int c0, int cn) {
@@ -312,6 +326,17 @@ IE_EXPORT int ie_eltwise_nhwc(int op, const void* a, const void* b, void* y, int
 
 template <typename S>
 static int cast_from(const S* src, void* dst, int ddt, int Cs, int Cd, size_t total, hipStream_t st) {
+    if (Cs == Cd && (total & 7) == 0) {
+        const size_t t8 = total / 8;
+        switch (ddt) {
+        case IE_F32: hipLaunchKernelGGL((cast8_kernel<S, float>), dim3(nblk(t8)), dim3(256), 0, st, src, (float*)dst, t8); break;
+        case IE_F16: hipLaunchKernelGGL((cast8_kernel<S, _Float16>), dim3(nblk(t8)), dim3(256), 0, st, src, (_Float16*)dst, t8); break;
+        case IE_BF16: hipLaunchKernelGGL((cast8_kernel<S, __bf16>), dim3(nblk(t8)), dim3(256), 0, st, src, (__bf16*)dst, t8); break;
+        default: IE_FAIL(IE_ERR_INVALID, "ie_cast_nhwc: bad destination dtype");
+        }
+        IE_LAUNCH_CHECK();
+        return IE_OK;
+    }
     switch (ddt) {
     case IE_F32: hipLaunchKernelGGL((cast_kernel<S, float>), dim3(nblk(total)), dim3(256), 0, st, src, (float*)dst, Cs, Cd, total); break;
     case IE_F16: hipLaunchKernelGGL((cast_kernel<S, _Float16>), dim3(nblk(total)), dim3(256), 0, st, src, (_Float16*)dst, Cs, Cd, total); break;
