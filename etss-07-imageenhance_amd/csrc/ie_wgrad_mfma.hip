@@ -202,10 +202,18 @@ int ie_wgrad_mfma_launch(const void* x, const void* dy, int dtype, float* dw_hwi
     p.xchunks = ie_cdiv(W, WM_PX);
     const long tiles = (long)p.co_tiles * ci_tiles, strips = (long)N * p.xchunks;
     if (tiles > 0x7fffffffL || strips > 65535) IE_FAIL(IE_ERR_UNSUPPORTED, "ie_convn_wgrad_nhwc: grid too large (%ld tiles, %ld strips)", tiles, strips);
-    // Split the rows into `ychunks` per strip.  Two workgroups fit a CU (512 slots on the chip) and every workgroup costs its rows
-    // plus a fixed ~12 rows' worth of prologue and 36K atomics, so pick the split that minimises rounds x (rows + 12): a grid of
-    // 1080 workgroups (2.1 rounds) ran 30 % slower than 960.
-    const long slots = 512;
+    if (dtype != IE_F16 && dtype != IE_BF16) IE_FAIL(IE_ERR_INVALID, "ie_convn_wgrad_nhwc: matrix-core path needs a 16-bit dtype");
+    // wave layout (see the kernel): nci cin blocks x (4 / nci) cout groups of NCO blocks
+    p.nci = cs <= 16 ? 1 : (cs <= 32 ? 2 : 4);
+    const int live_cob = ie_cdiv(cout < 64 ? cout : 64, 16), cow = 4 / p.nci;
+    int nco = ie_cdiv(live_cob, cow);
+    if (nco == 3) nco = 4;
+    // Split the rows into `ychunks` per strip.  A CU holds 2 workgroups of the NCO = 4 kernel (219 VGPRs; 3 at NCO = 2, 5 at NCO = 1
+    // for 3x3; the 1x1 kernels are lighter still) and every workgroup costs its rows plus a fixed ~12 rows' worth of prologue and
+    // atomics, so pick the split that minimises rounds x (rows + 12): a grid of 1080 workgroups on 512 slots (2.1 rounds) ran 30 %
+    // slower than 960.
+    const long per_cu = ksize == 3 ? (nco == 4 ? 2 : (nco == 2 ? 3 : 5)) : 5;
+    const long slots = 256 * per_cu;
     long best = 1, best_cost = -1;
     const long max_chunks = H >= 32 ? H / 16 : 1;
     for (long c = 1; c <= max_chunks && c <= 64; ++c) {
@@ -216,12 +224,6 @@ int ie_wgrad_mfma_launch(const void* x, const void* dy, int dtype, float* dw_hwi
     p.rows_per_wg = ie_cdiv(H, (int)best);
     const long ychunks = ie_cdiv(H, p.rows_per_wg);
     const dim3 grid((unsigned)tiles, (unsigned)strips, (unsigned)ychunks);
-    if (dtype != IE_F16 && dtype != IE_BF16) IE_FAIL(IE_ERR_INVALID, "ie_convn_wgrad_nhwc: matrix-core path needs a 16-bit dtype");
-    // wave layout (see the kernel): nci cin blocks x (4 / nci) cout groups of NCO blocks
-    p.nci = cs <= 16 ? 1 : (cs <= 32 ? 2 : 4);
-    const int live_cob = ie_cdiv(cout < 64 ? cout : 64, 16), cow = 4 / p.nci;
-    int nco = ie_cdiv(live_cob, cow);
-    if (nco == 3) nco = 4;
     const bool h = dtype == IE_F16;
 #define WM_LAUNCH(KS_, NCO_)                                                                                              \
     do {                                                                                                                  \
