@@ -240,6 +240,17 @@ def main():
                     extras[tag] = f"failed: {e}"[:200]
                 torch.cuda.empty_cache()
 
+            try:      # zero-reference training of the headline model itself, 16-bit graph, reference optimiser config
+                m4 = mon_amd.MODELS.build(name="zero_dce_re", seed=1).to(dev)
+                tr4 = mon_amd.Trainer(m4, optimizer={"name": "adam", "lr": 5e-5, "betas": (0.9, 0.99), "weight_decay": 1e-5}, gradient_clip_val=0.1,
+                                      compute_dtype="bf16")
+                im4 = (torch.rand(8, 3, H, W, device=dev) ** 2.2 * 0.4).contiguous()
+                extras["zero_dce_train_zeroref_bf16_1080p_frames_per_s"] = round(8 / timed(lambda: tr4.training_step({"image": im4}), 2), 1)
+                del m4, tr4, im4
+            except Exception as e:
+                extras["zero_dce_train_zeroref_bf16_1080p_frames_per_s"] = f"failed: {e}"[:200]
+            torch.cuda.empty_cache()
+
         line = {
             "metric": "enhanced_images_per_sec_1080p", "value": round(value, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
