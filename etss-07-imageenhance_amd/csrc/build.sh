@@ -1,13 +1,27 @@
 #!/bin/bash
 # Build libie_hip.so (gfx950) in-tree: one hipcc per source in parallel, then link.
 # Usage: build.sh [extra hipcc flags];  IE_OUT=path overrides the output, IE_JOBS the parallelism.
+# Objects are cached in csrc/_obj/<flags-hash>/ and rebuilt only when the source, a header or the flags changed.
 set -e
 cd "$(dirname "$0")"
 OUT=${IE_OUT:-../libie_hip.so}
-SRCS="ie_core.hip ie_conv_direct.hip ie_ops.hip ie_conv_mfma.hip ie_ops16.hip ie_norm.hip ie_train.hip ie_wgrad_mfma.hip ie_zref.hip ie_zdce_kernels.hip ie_zdce_fused.hip ie_zdce_plan.hip"
-OBJ=$(mktemp -d)
-trap 'rm -rf "$OBJ"' EXIT
+SRCS=$(ls ie_*.hip)
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno-unused-function $*"
-printf '%s\n' $SRCS | xargs -P "${IE_JOBS:-8}" -I{} sh -c "hipcc $FLAGS -c {} -o $OBJ/{}.o"
-hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" $OBJ/*.o
-echo "built $(readlink -f $OUT)"
+KEY=$(printf '%s' "$FLAGS" | md5sum | cut -c1-10)
+OBJ=_obj/$KEY
+mkdir -p "$OBJ"
+HDR_STAMP=$(cat ie_*.h | md5sum | cut -c1-16)
+todo=""
+for s in $SRCS; do
+    sig="$(md5sum < "$s" | cut -c1-16)-$HDR_STAMP"
+    if [ ! -f "$OBJ/$s.o" ] || [ "$(cat "$OBJ/$s.sig" 2>/dev/null)" != "$sig" ]; then
+        todo="$todo $s"; rm -f "$OBJ/$s.sig"; echo "$sig" > "$OBJ/$s.sig.new"   # the signature of what is compiled NOW (edits during the build re-trigger)
+    fi
+done
+if [ -n "$todo" ]; then
+    printf '%s\n' $todo | xargs -P "${IE_JOBS:-8}" -I{} sh -c "cp {} $OBJ/{}.src.hip && hipcc $FLAGS -I. -c $OBJ/{}.src.hip -o $OBJ/{}.o.tmp && mv $OBJ/{}.o.tmp $OBJ/{}.o && mv $OBJ/{}.sig.new $OBJ/{}.sig"
+fi
+objs=""
+for s in $SRCS; do objs="$objs $OBJ/$s.o"; done
+hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" $objs
+echo "built $(readlink -f $OUT) (recompiled:${todo:- nothing})"

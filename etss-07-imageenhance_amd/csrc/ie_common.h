@@ -55,6 +55,14 @@ template <> struct ie_elem<__bf16> {
     }
 };
 
+// MFMA on raw 16-byte fragments: kernels whose operands mix fp16 and bf16 sources (the Zero-DCE "bf16" schedule
+// keeps the precision-critical tensors in fp16) hold every fragment as four dwords and name the
+// element type at the instruction.
+template <typename T> __device__ __forceinline__ ie_f32x4 ie_mfma16_raw(ie_u32x4 a, ie_u32x4 b, ie_f32x4 c) {
+    using frag = typename ie_elem<T>::frag;
+    return ie_elem<T>::mfma16(__builtin_bit_cast(frag, a), __builtin_bit_cast(frag, b), c);
+}
+
 // Pack two floats into one dword of 2 x T: one v_cvt_pk_{bf16,f16}_f32 (round-to-nearest-even).
 typedef __attribute__((ext_vector_type(2))) float ie_f32x2;
 typedef __attribute__((ext_vector_type(2))) short ie_s16x2;

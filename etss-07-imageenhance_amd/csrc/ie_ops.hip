@@ -327,7 +327,9 @@ __global__ void pad_nhwc_kernel(const float* __restrict__ x, float* __restrict__
     y[i] = (h >= 0 && h < H && w >= 0 && w < W) ? x[((n * H + h) * W + w) * C + c] : 0.f;
 }
 
-// op 0: a + b, 1: a * b, 2: clamp(a, lo, hi); b may have 1 channel (broadcast) or C channels
+// op 0: a + b, 1: a * b, 2: clamp(a, lo, hi), 3: a[:, :C] * b (a has C+1 channels), 4: a - b, 5: clamp(a / b, lo, hi),
+// 6: a * lo + hi, 7: pow(a, lo), 8: a / max_all where b points at ONE float (a device-side reduction result);
+// b may have 1 channel (broadcast) or C channels
 __global__ void eltwise_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, int C, int Cb,
                                int op, float lo, float hi, size_t total) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -335,8 +337,19 @@ __global__ void eltwise_kernel(const float* __restrict__ a, const float* __restr
     if (op == 3) { y[i] = a[(i / C) * (C + 1) + (i % C)] * b[i / C]; return; }
     const float va = a[i];
     float vb = 0.f;
-    if (b) vb = (Cb == C) ? b[i] : b[i / C];
-    y[i] = op == 0 ? va + vb : (op == 1 ? va * vb : fminf(fmaxf(va, lo), hi));
+    if (b && op != 8) vb = (Cb == C) ? b[i] : b[i / C];
+    float r;
+    switch (op) {
+    case 0: r = va + vb; break;
+    case 1: r = va * vb; break;
+    case 2: r = fminf(fmaxf(va, lo), hi); break;
+    case 4: r = va - vb; break;
+    case 5: r = fminf(fmaxf(va / vb, lo), hi); break;
+    case 6: r = va * lo + hi; break;
+    case 7: r = powf(va, lo); break;
+    default: r = va / b[0]; break;       // 8
+    }
+    y[i] = r;
 }
 
 // RetinexNet DecomNet input (mon_extra/.../retinexnet/model.py:45-46): [max_c(x), x] -> 4 channels
@@ -447,8 +460,10 @@ IE_EXPORT int ie_pad_nhwc_f32(const float* x, float* y, int N, int H, int W, int
 }
 
 IE_EXPORT int ie_eltwise_nhwc_f32(int op, const float* a, const float* b, float* y, size_t npix, int C, int Cb, float lo, float hi, void* stream) {
-    if (!a || !y || npix == 0 || C <= 0 || op < 0 || op > 3 || (op != 2 && (!b || (Cb != C && Cb != 1))) || (op == 3 && Cb != 1))
+    const bool unary = op == 2 || op == 6 || op == 7;
+    if (!a || !y || npix == 0 || C <= 0 || op < 0 || op > 8 || (!unary && (!b || (Cb != C && Cb != 1))) || ((op == 3 || op == 8) && Cb != 1))
         IE_FAIL(IE_ERR_INVALID, "ie_eltwise_nhwc_f32: bad args");
+    if (unary) b = nullptr;
     const size_t total = npix * C;
     hipLaunchKernelGGL(eltwise_kernel, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, a, b, y, C, Cb, op, lo, hi, total);
     IE_LAUNCH_CHECK();

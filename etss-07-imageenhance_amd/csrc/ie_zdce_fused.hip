@@ -71,12 +71,17 @@ __device__ __forceinline__ void wait_vm(int n) {
 #define IE_T(var) do { } while (0)
 #endif
 
-template <typename T, int KIND>
+template <typename T> struct ie_tag { using type = T; };
+
+// Element types (all 16-bit): TA0 / TA1 = stage A's HBM sources and their weights (K45: x3; K67: x2, x5);
+// TH = the LDS hand-off (x1 / x4 / x6), stage B's weights on it and K67's P seed (K12: also e_conv1's operands);
+// TO = stage B's HBM outputs (K12: x2 and P, K45: x5).  They differ only in the "bf16" schedule of the plan,
+// which keeps the precision-critical tensors x1, x2, x6 and P in fp16.
+template <typename TA0, typename TA1, typename TH, typename TO, int KIND>
 __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
-    using E = ie_elem<T>;
-    using frag = typename E::frag;
+    using frag = ie_u32x4;
     constexpr int PF = (KIND == K67) ? 3 : PF_DEFAULT;
-    constexpr int PXB = 32 * sizeof(T);                     // 64 B per pixel per tensor
+    constexpr int PXB = 32 * 2;                             // 64 B per pixel per tensor
     constexpr int ROW_B = ROW_PX * PXB;                     // one ring row of one tensor
     constexpr int NSA = (KIND == K67) ? 2 : (KIND == K45 ? 1 : 0);   // stage A HBM sources (K12: image)
     constexpr int NFB = (KIND == K45 || KIND == K12) ? 18 : 9;       // stage B weight fragments (K12: e_conv2 + e_conv7a)
@@ -256,16 +261,17 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     }
 
     // one source row into the three live accumulator sets
-    auto src_mfma = [&](const char* row, int wbase, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4], int x1_row) __attribute__((always_inline)) {
+    auto src_mfma = [&](auto tg, const char* row, int wbase, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4], int x1_row) __attribute__((always_inline)) {
+        using TT = typename decltype(tg)::type;
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 const int off = (kx == 0 && nt == 0) ? rd_first : (kx == 2 && nt == 3) ? rd_last : rd_base[kx] + 1024 * nt;
                 const frag bx = *(const frag*)(row + off);
-                accN[nt] = E::mfma16(wv[wbase + 0 * 3 + kx], bx, accN[nt]);
-                accM[nt] = E::mfma16(wv[wbase + 1 * 3 + kx], bx, accM[nt]);
-                accO[nt] = E::mfma16(wv[wbase + 2 * 3 + kx], bx, accO[nt]);
+                accN[nt] = ie_mfma16_raw<TT>(wv[wbase + 0 * 3 + kx], bx, accN[nt]);
+                accM[nt] = ie_mfma16_raw<TT>(wv[wbase + 1 * 3 + kx], bx, accM[nt]);
+                accO[nt] = ie_mfma16_raw<TT>(wv[wbase + 2 * 3 + kx], bx, accO[nt]);
             }
 #ifndef IE_LDS_DEPTH
 #define IE_LDS_DEPTH 3
@@ -288,12 +294,12 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
             for (int nt = 0; nt < 4; ++nt) {
                 const int off = (kx == 0 && nt == 0) ? rd_first : (kx == 2 && nt == 3) ? rd_last : rd_base[kx] + 1024 * nt;
                 const frag bx = *(const frag*)(row + off);
-                accN[nt] = E::mfma16(wv[0 * 3 + kx], bx, accN[nt]);
-                accM[nt] = E::mfma16(wv[1 * 3 + kx], bx, accM[nt]);
-                accO[nt] = E::mfma16(wv[2 * 3 + kx], bx, accO[nt]);
-                pN[nt] = E::mfma16(wv[(NW > 9 ? 9 : 0) + 0 * 3 + kx], bx, pN[nt]);
-                pM[nt] = E::mfma16(wv[(NW > 9 ? 9 : 0) + 1 * 3 + kx], bx, pM[nt]);
-                pO[nt] = E::mfma16(wv[(NW > 9 ? 9 : 0) + 2 * 3 + kx], bx, pO[nt]);
+                accN[nt] = ie_mfma16_raw<TH>(wv[0 * 3 + kx], bx, accN[nt]);
+                accM[nt] = ie_mfma16_raw<TH>(wv[1 * 3 + kx], bx, accM[nt]);
+                accO[nt] = ie_mfma16_raw<TH>(wv[2 * 3 + kx], bx, accO[nt]);
+                pN[nt] = ie_mfma16_raw<TH>(wv[(NW > 9 ? 9 : 0) + 0 * 3 + kx], bx, pN[nt]);
+                pM[nt] = ie_mfma16_raw<TH>(wv[(NW > 9 ? 9 : 0) + 1 * 3 + kx], bx, pM[nt]);
+                pO[nt] = ie_mfma16_raw<TH>(wv[(NW > 9 ? 9 : 0) + 2 * 3 + kx], bx, pO[nt]);
             }
         __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
 #pragma unroll
@@ -315,8 +321,8 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
             const int x = xc0 + q;
             const bool in_img = row_in && x >= 0 && x < W;
             ie_u32x2 pk;
-            pk[0] = in_img ? ie_pack2_relu<T>(acc[nt][0], acc[nt][1]) : 0u;
-            pk[1] = in_img ? ie_pack2_relu<T>(acc[nt][2], acc[nt][3]) : 0u;
+            pk[0] = in_img ? ie_pack2_relu<TH>(acc[nt][0], acc[nt][1]) : 0u;
+            pk[1] = in_img ? ie_pack2_relu<TH>(acc[nt][2], acc[nt][3]) : 0u;
             const int c = 2 * ch + (kq >> 1);      // 16-byte chunk holding couts 16ch+4kq .. +3
             *(ie_u32x2*)(slot + q * PXB + ((c ^ ((q >> 1) & 3)) << 4) + (kq & 1) * 8) = pk;
         }
@@ -329,8 +335,8 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
         const bool row_ok_ = (yo_ >= ys) && (yo_ < ye);                                                                   \
         ie_u32x2 pk_[4];                                                                                                  \
         _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                                                \
-            pk_[nt][0] = (RELU) ? ie_pack2_relu<T>(ACC[nt][0], ACC[nt][1]) : ie_pack2<T>(ACC[nt][0], ACC[nt][1]);         \
-            pk_[nt][1] = (RELU) ? ie_pack2_relu<T>(ACC[nt][2], ACC[nt][3]) : ie_pack2<T>(ACC[nt][2], ACC[nt][3]);         \
+            pk_[nt][0] = (RELU) ? ie_pack2_relu<TO>(ACC[nt][0], ACC[nt][1]) : ie_pack2<TO>(ACC[nt][0], ACC[nt][1]);       \
+            pk_[nt][1] = (RELU) ? ie_pack2_relu<TO>(ACC[nt][2], ACC[nt][3]) : ie_pack2<TO>(ACC[nt][2], ACC[nt][3]);       \
         }                                                                                                                 \
         const unsigned row_b_ = (unsigned)yo_ * (unsigned)W * PXB;                                                        \
         _Pragma("unroll") for (int nt = 0; nt < 4; nt += 2) {                                                             \
@@ -340,7 +346,7 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
             const int q_ = 64 * ph + 16 * (nt + (kq & 1)) + p16;                                                          \
             const int xo_ = xc0 + q_;                                                                                     \
             const bool ok_ = row_ok_ && q_ >= 1 && q_ < TW - 1 && xo_ < W;                                                \
-            const unsigned off_ = ok_ ? row_b_ + (unsigned)xo_ * PXB + (unsigned)((16 * ch + 4 * (kq & 2)) * sizeof(T)) : OOB; \
+            const unsigned off_ = ok_ ? row_b_ + (unsigned)xo_ * PXB + (unsigned)((16 * ch + 4 * (kq & 2)) * 2) : OOB;         \
             __builtin_amdgcn_raw_buffer_store_b128(v_, RS, (int)off_, 0, 0);                                              \
         }                                                                                                                 \
     } while (0)
@@ -352,7 +358,7 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
         for (int nt = 0; nt < 4; ++nt) {
             const int q = 64 * ph + 16 * nt + p16;
             const int c = 2 * ch + (kq >> 1);
-            typedef __attribute__((ext_vector_type(4))) T t4;
+            typedef __attribute__((ext_vector_type(4))) TH t4;
             const t4 v = *(const t4*)(slot + q * PXB + ((c ^ ((q >> 1) & 3)) << 4) + (kq & 1) * 8);
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[nt][i] = (float)v[i];
@@ -415,12 +421,12 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
             const float* ip = (const float*)(smem + OFF_IMG + (t % NRI) * IMG_SLOT_B) + px;
             const bool real = px < 130;
             const float r = real ? ip[0] : 0.f, g = real ? ip[132] : 0.f, bl = real ? ip[264] : 0.f;
-            const T hr = (T)r, hg = (T)g, hb = (T)bl;
+            const TH hr = (TH)r, hg = (TH)g, hb = (TH)bl;
             ie_u32x2 hi, lo;
-            hi[0] = ie_pack2<T>(r, g);
-            hi[1] = ie_pack2<T>(bl, 0.f);
-            lo[0] = ie_pack2<T>(r - (float)hr, g - (float)hg);
-            lo[1] = ie_pack2<T>(bl - (float)hb, 0.f);
+            hi[0] = ie_pack2<TH>(r, g);
+            hi[1] = ie_pack2<TH>(bl, 0.f);
+            lo[0] = ie_pack2<TH>(r - (float)hr, g - (float)hg);
+            lo[1] = ie_pack2<TH>(bl - (float)hb, 0.f);
             char* cv = smem + OFF_CV + (t % NRC) * CV_SLOT_B + px * 8;
             *(ie_u32x2*)cv = hi;
             *(ie_u32x2*)(cv + CV_PLANE_B) = lo;
@@ -435,7 +441,7 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) acc[nt] = bias4;
 #pragma unroll
-        for (int part = 0; part < (ie_elem<T>::dtype == IE_BF16 ? 2 : 1); ++part) {
+        for (int part = 0; part < (ie_elem<TH>::dtype == IE_BF16 ? 2 : 1); ++part) {
             ie_u32x4 b0[4], b1[4];
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {       // all loads first: the four tiles are independent MFMA chains
@@ -447,9 +453,9 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
                 b1[nt] = ie_u32x4{b1a[0], b1a[1], b1b[0], b1b[1]};
             }
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc[nt] = E::mfma16(wv[0], __builtin_bit_cast(frag, b0[nt]), acc[nt]);
+            for (int nt = 0; nt < 4; ++nt) acc[nt] = ie_mfma16_raw<TH>(wv[0], b0[nt], acc[nt]);
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc[nt] = E::mfma16(wv[1], __builtin_bit_cast(frag, b1[nt]), acc[nt]);
+            for (int nt = 0; nt < 4; ++nt) acc[nt] = ie_mfma16_raw<TH>(wv[1], b1[nt], acc[nt]);
         }
     };
 
@@ -479,8 +485,8 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
             } else {
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) accN[nt] = bias4;
-                src_mfma(smem + (t % NRA) * ROW_B, 0, accN, accM, accO, 0);
-                if constexpr (NSA == 2) src_mfma(smem + NRA * ROW_B + (t % NRA) * ROW_B, 9, accN, accM, accO, 0);
+                src_mfma(ie_tag<TA0>{}, smem + (t % NRA) * ROW_B, 0, accN, accM, accO, 0);
+                if constexpr (NSA == 2) src_mfma(ie_tag<TA1>{}, smem + NRA * ROW_B + (t % NRA) * ROW_B, 9, accN, accM, accO, 0);
                 IE_T(ts2);
                 issue(t + PF);
                 if (t >= 2) a_emit(accO, t);
@@ -507,11 +513,11 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
             } else if constexpr (KIND == K45) {
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) accN[nt] = bias4;
-                src_mfma(smem + ((t + NRA - 2) % NRA) * ROW_B, 0, accN, accM, accO, 0);   // x3 row ys-4+t
-                src_mfma(ra_row, 9, accN, accM, accO, 0);                                  // x4 row ys-4+t
+                src_mfma(ie_tag<TA0>{}, smem + ((t + NRA - 2) % NRA) * ROW_B, 0, accN, accM, accO, 0);   // x3 row ys-4+t
+                src_mfma(ie_tag<TH>{}, ra_row, 9, accN, accM, accO, 0);                                   // x4 row ys-4+t
             } else {
                 seed_from_p(t, accN);                                                      // P row ys-3+t = W7a*x1 + bias7
-                src_mfma(ra_row, 0, accN, accM, accO, 0);                                  // x6 row ys-4+t
+                src_mfma(ie_tag<TH>{}, ra_row, 0, accN, accM, accO, 0);                    // x6 row ys-4+t
             }
         }
 #ifdef IE_STAMP
@@ -544,28 +550,22 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
 
 // Concrete kernels (readable names in rocprof traces; hipcc/ROCm 7.2 emitted the host stub of only
 // the first instantiation when the __global__ function itself was a template on KIND).
-#define IE_DEF_FUSED(NAME, T, KIND) \
-    __global__ __launch_bounds__(512, 2) void NAME(FusedParams p) { zdce_fused2_body<T, KIND>(p); }
-IE_DEF_FUSED(zdce_k12_conv1_conv2_f16, _Float16, K12)
-IE_DEF_FUSED(zdce_k45_conv4_conv5_f16, _Float16, K45)
-IE_DEF_FUSED(zdce_k67_conv6_conv7_curve_f16, _Float16, K67)
-IE_DEF_FUSED(zdce_k12_conv1_conv2_bf16, __bf16, K12)
-IE_DEF_FUSED(zdce_k45_conv4_conv5_bf16, __bf16, K45)
-IE_DEF_FUSED(zdce_k67_conv6_conv7_curve_bf16, __bf16, K67)
+#define IE_DEF_FUSED(NAME, TA0, TA1, TH, TO, KIND) \
+    __global__ __launch_bounds__(512, 2) void NAME(FusedParams p) { zdce_fused2_body<TA0, TA1, TH, TO, KIND>(p); }
+IE_DEF_FUSED(zdce_k12_conv1_conv2_f16, _Float16, _Float16, _Float16, _Float16, K12)
+IE_DEF_FUSED(zdce_k45_conv4_conv5_f16, _Float16, _Float16, _Float16, _Float16, K45)
+IE_DEF_FUSED(zdce_k67_conv6_conv7_curve_f16, _Float16, _Float16, _Float16, _Float16, K67)
+IE_DEF_FUSED(zdce_k12_conv1_conv2_bf16, __bf16, __bf16, __bf16, __bf16, K12)
+IE_DEF_FUSED(zdce_k45_conv4_conv5_bf16, __bf16, __bf16, __bf16, __bf16, K45)
+IE_DEF_FUSED(zdce_k67_conv6_conv7_curve_bf16, __bf16, __bf16, __bf16, __bf16, K67)
+// the "bf16" schedule's last kernel: x2 (fp16) and x5 (bf16) in, x6 / P / e_conv7b in fp16
+IE_DEF_FUSED(zdce_k67_conv6_conv7_curve_mix, _Float16, __bf16, _Float16, _Float16, K67)
 #undef IE_DEF_FUSED
 
-template <typename T, int KIND> struct FusedKernel;
-#define IE_BIND(T, KIND, NAME) template <> struct FusedKernel<T, KIND> { static constexpr void (*fn)(FusedParams) = NAME; };
-IE_BIND(_Float16, K12, zdce_k12_conv1_conv2_f16)
-IE_BIND(_Float16, K45, zdce_k45_conv4_conv5_f16)
-IE_BIND(_Float16, K67, zdce_k67_conv6_conv7_curve_f16)
-IE_BIND(__bf16, K12, zdce_k12_conv1_conv2_bf16)
-IE_BIND(__bf16, K45, zdce_k45_conv4_conv5_bf16)
-IE_BIND(__bf16, K67, zdce_k67_conv6_conv7_curve_bf16)
-#undef IE_BIND
+typedef void (*FusedFn)(FusedParams);
 
-template <typename T, int KIND>
-static int launch_fused_t(const ZdceFusedLaunch& a, hipStream_t st) {
+template <int KIND>
+static int launch_fused_t(FusedFn fn, const ZdceFusedLaunch& a, hipStream_t st) {
     FusedParams p;
     p.a_src0 = a.a_src0; p.a_src1 = a.a_src1; p.b_src = a.b_src; p.img = a.img;
     p.a_w = a.a_w; p.a_bias = a.a_bias; p.b_w = a.b_w; p.b_bias = a.b_bias; p.b2_bias = a.b2_bias; p.a_dst = a.a_dst; p.b_dst = a.b_dst;
@@ -577,32 +577,41 @@ static int launch_fused_t(const ZdceFusedLaunch& a, hipStream_t st) {
     p.chunks = ie_cdiv(a.y_end - a.y_begin, a.rows_per_block);
     const long long blocks = (long long)p.strips * p.chunks * a.n_count;
     if (blocks <= 0 || blocks > 0x7fffffffLL) IE_FAIL(IE_ERR_INVALID, "zdce fused: bad grid %lld", blocks);
-    if ((size_t)a.H * a.W * 32 * sizeof(T) >= 0x7fffffffull) IE_FAIL(IE_ERR_UNSUPPORTED, "zdce fused: frame too large for 31-bit offsets");
+    if ((size_t)a.H * a.W * 32 * 2 >= 0x7fffffffull) IE_FAIL(IE_ERR_UNSUPPORTED, "zdce fused: frame too large for 31-bit offsets");
     constexpr int PF = (KIND == K67) ? 3 : PF_DEFAULT;
-    constexpr int ROW_B = ROW_PX * 32 * (int)sizeof(T);
+    constexpr int ROW_B = ROW_PX * 32 * 2;
     constexpr int NSA = (KIND == K67) ? 2 : (KIND == K45 ? 1 : 0);
     constexpr int NRA = (KIND == K45) ? PF + 3 : PF + 1;
     constexpr int NRI = (KIND == K12) ? PF + 1 : PF + 3;
     const size_t lds = (size_t)NSA * NRA * ROW_B + (KIND == K67 ? (PF + 1) * ROW_B : 0) + 2 * ROW_B +
                        (KIND == K45 ? 0 : NRI * 2048) + (KIND == K12 ? 4 * 2 * 1088 : 0) + (KIND == K67 ? 2 * 24 * TW * 4 : 0);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)FusedKernel<T, KIND>::fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // the dynamic-LDS limit is a per-function attribute: set it once per kernel
+    static FusedFn attr_done[8] = {nullptr};
+    bool done = false;
+    for (FusedFn f : attr_done) done = done || (f == fn);
+    if (!done) {
+        hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) IE_FAIL(IE_ERR_HIP, "hipFuncSetAttribute(lds=%zu): %s", lds, hipGetErrorString(e));
-        attr_set = true;
+        for (FusedFn& f : attr_done) if (!f) { f = fn; break; }
     }
     void* args[] = {(void*)&p};
-    IE_HIP_CHECK(hipLaunchKernel((const void*)FusedKernel<T, KIND>::fn, dim3((unsigned)blocks), dim3(512), args, lds, st));
+    IE_HIP_CHECK(hipLaunchKernel((const void*)fn, dim3((unsigned)blocks), dim3(512), args, lds, st));
     return IE_OK;
 }
 
 int ie_zdce_launch_fused(const ZdceFusedLaunch& a, hipStream_t st) {
-#define IE_DISPATCH(T)                                           \
-    if (a.kind == 12) return launch_fused_t<T, K12>(a, st);      \
-    if (a.kind == 45) return launch_fused_t<T, K45>(a, st);      \
-    if (a.kind == 67) return launch_fused_t<T, K67>(a, st);
-    if (a.dtype == IE_F16) { IE_DISPATCH(_Float16) }
-    else if (a.dtype == IE_BF16) { IE_DISPATCH(__bf16) }
-#undef IE_DISPATCH
-    IE_FAIL(IE_ERR_UNSUPPORTED, "zdce fused: kind=%d dtype=%d", a.kind, a.dtype);
+    const bool h_all = a.dt_h == IE_F16 && a.dt_o == IE_F16 && a.dt_a0 == IE_F16 && a.dt_a1 == IE_F16;
+    const bool b_all = a.dt_h == IE_BF16 && a.dt_o == IE_BF16 && a.dt_a0 == IE_BF16 && a.dt_a1 == IE_BF16;
+    if (a.kind == 12) {
+        if (h_all) return launch_fused_t<K12>(zdce_k12_conv1_conv2_f16, a, st);
+        if (b_all) return launch_fused_t<K12>(zdce_k12_conv1_conv2_bf16, a, st);
+    } else if (a.kind == 45) {
+        if (h_all) return launch_fused_t<K45>(zdce_k45_conv4_conv5_f16, a, st);
+        if (b_all) return launch_fused_t<K45>(zdce_k45_conv4_conv5_bf16, a, st);
+    } else if (a.kind == 67) {
+        if (h_all) return launch_fused_t<K67>(zdce_k67_conv6_conv7_curve_f16, a, st);
+        if (b_all) return launch_fused_t<K67>(zdce_k67_conv6_conv7_curve_bf16, a, st);
+        if (a.dt_a0 == IE_F16 && a.dt_a1 == IE_BF16 && a.dt_h == IE_F16) return launch_fused_t<K67>(zdce_k67_conv6_conv7_curve_mix, a, st);
+    }
+    IE_FAIL(IE_ERR_UNSUPPORTED, "zdce fused: kind=%d dtypes a0=%d a1=%d h=%d o=%d", a.kind, a.dt_a0, a.dt_a1, a.dt_h, a.dt_o);
 }

@@ -6,7 +6,8 @@ struct ZdceConvLaunch {
     const void* src0; const void* src1; const void* wpk; const float* bias; void* dst;
     const float* img; float* enhanced; float* adjust; unsigned char* u8;
     int N, H, W, y_begin, y_end, n_begin, n_count, rows_per_block;
-    int nsrc, epi, dtype, variant;
+    int nsrc, epi, variant;
+    int dt0, dt1, dto;   // element types (IE_F16 / IE_BF16) of source 0, source 1 and the ReLU output
 };
 int ie_zdce_launch_mfma(const ZdceConvLaunch& a, hipStream_t st);
 int ie_zdce_launch_conv1(const float* img, const float* wk, const float* bias, void* dst, int dtype, int N, int H,
@@ -14,7 +15,10 @@ int ie_zdce_launch_conv1(const float* img, const float* wk, const float* bias, v
 
 // two-stage fused strip kernels (ie_zdce_fused.hip); kind = 12, 45 or 67
 struct ZdceFusedLaunch {
-    int kind, dtype;
+    int kind;
+    int dt_a0, dt_a1;    // element types of stage A's HBM sources (K45: x3; K67: x2, x5)
+    int dt_h;            // element type of the LDS hand-off (x1 / x4 / x6), of stage B's weights and of K67's P
+    int dt_o;            // element type of the HBM outputs (K12: x2 and P; K45: x5)
     const void* a_src0; const void* a_src1; const void* b_src; const float* img;
     const void* a_w; const float* a_bias; const void* b_w; const float* b_bias; const float* b2_bias;
     void* a_dst; void* b_dst; float* enhanced; float* adjust; unsigned char* u8;

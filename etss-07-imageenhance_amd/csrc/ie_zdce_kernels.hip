@@ -71,13 +71,14 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
     }
 }
 
-template <typename T, int NSRC, int EPI, bool DMA, bool SYNC, bool WIDE>
+// T0 / T1: element types of source 0 / 1 (and of their weight fragments), TO: element type of the ReLU output.
+// All three are 16-bit; they differ only in the "bf16" schedule of the plan, which holds x1, x2, x6 and P in fp16.
+template <typename T0, typename T1, typename TO, int NSRC, int EPI, bool DMA, bool SYNC, bool WIDE>
 __global__ __launch_bounds__(NWAVE * 64, (NSRC == 1 ? 3 : 2)) void zdce_conv3x3_mfma(ConvParams p) {
-    using E = ie_elem<T>;
-    using frag = typename E::frag;
+    using frag = ie_u32x4;
     constexpr int NR = (EPI == EPI_CURVE) ? 3 : 4;      // ring slots (input rows resident in LDS)
     constexpr int PF = NR - 1;                          // rows of DMA prefetch issued ahead
-    constexpr int PXB = 32 * sizeof(T);                 // bytes per pixel per source (64)
+    constexpr int PXB = 32 * 2;                         // bytes per pixel per source (64)
     constexpr int SRC_ROW_B = ROW_PX * PXB;             // bytes per ring row per source
     constexpr int SLOT_B = SRC_ROW_B * NSRC;            // bytes per ring slot
     constexpr int RING_B = SLOT_B * NR;
@@ -246,8 +247,8 @@ __global__ __launch_bounds__(NWAVE * 64, (NSRC == 1 ? 3 : 2)) void zdce_conv3x3_
         ie_u32x2 pk[4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-            pk[nt][0] = ie_pack2_relu<T>(acc[nt][0], acc[nt][1]);
-            pk[nt][1] = ie_pack2_relu<T>(acc[nt][2], acc[nt][3]);
+            pk[nt][0] = ie_pack2_relu<TO>(acc[nt][0], acc[nt][1]);
+            pk[nt][1] = ie_pack2_relu<TO>(acc[nt][2], acc[nt][3]);
         }
         const unsigned row_b = (unsigned)yo * (unsigned)W * PXB;
         if constexpr (WIDE) {
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(NWAVE * 64, (NSRC == 1 ? 3 : 2)) void zdce_conv3x3_
                 ie_u32x4 v = {sx[0], sy[0], sx[1], sy[1]};
                 const int xo = x0 + 64 * ph + 16 * (nt + (kq & 1)) + p16;
                 const unsigned off = (row_ok && xo < W)
-                                         ? row_b + (unsigned)xo * PXB + (unsigned)((16 * ch + 4 * (kq & 2)) * sizeof(T))
+                                         ? row_b + (unsigned)xo * PXB + (unsigned)((16 * ch + 4 * (kq & 2)) * 2)
                                          : OOB;
                 __builtin_amdgcn_raw_buffer_store_b128(v, rsd, (int)off, 0, 0);
             }
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(NWAVE * 64, (NSRC == 1 ? 3 : 2)) void zdce_conv3x3_
             for (int nt = 0; nt < 4; ++nt) {
                 const int xo = x0 + 64 * ph + 16 * nt + p16;
                 const unsigned off = (row_ok && xo < W)
-                                         ? row_b + (unsigned)xo * PXB + (unsigned)((16 * ch + 4 * kq) * sizeof(T))
+                                         ? row_b + (unsigned)xo * PXB + (unsigned)((16 * ch + 4 * kq) * 2)
                                          : OOB;
                 __builtin_amdgcn_raw_buffer_store_b64(pk[nt], rsd, (int)off, 0, 0);
             }
@@ -337,9 +338,15 @@ __global__ __launch_bounds__(NWAVE * 64, (NSRC == 1 ? 3 : 2)) void zdce_conv3x3_
                 for (int nt = 0; nt < 4; ++nt) {
                     const int off = (kx == 0 && nt == 0) ? rd_first : (kx == 2 && nt == 3) ? rd_last : rd_base[kx] + 1024 * nt;
                     const frag bx = *(const frag*)(slot + s * SRC_ROW_B + off);
-                    accN[nt] = E::mfma16(wA[s * 9 + 0 * 3 + kx], bx, accN[nt]);
-                    accM[nt] = E::mfma16(wA[s * 9 + 1 * 3 + kx], bx, accM[nt]);
-                    accO[nt] = E::mfma16(wA[s * 9 + 2 * 3 + kx], bx, accO[nt]);
+                    if (s == 0) {
+                        accN[nt] = ie_mfma16_raw<T0>(wA[0 * 3 + kx], bx, accN[nt]);
+                        accM[nt] = ie_mfma16_raw<T0>(wA[1 * 3 + kx], bx, accM[nt]);
+                        accO[nt] = ie_mfma16_raw<T0>(wA[2 * 3 + kx], bx, accO[nt]);
+                    } else {
+                        accN[nt] = ie_mfma16_raw<T1>(wA[(NSRC - 1) * 9 + 0 * 3 + kx], bx, accN[nt]);
+                        accM[nt] = ie_mfma16_raw<T1>(wA[(NSRC - 1) * 9 + 1 * 3 + kx], bx, accM[nt]);
+                        accO[nt] = ie_mfma16_raw<T1>(wA[(NSRC - 1) * 9 + 2 * 3 + kx], bx, accO[nt]);
+                    }
                 }
         // software pipeline: keep 3 LDS reads in flight ahead of their MFMAs
         __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
@@ -431,7 +438,7 @@ __global__ __launch_bounds__(256) void zdce_conv1_kernel(const float* __restrict
 // ------------------------------------------------------------------------------------
 // host-side launchers (called from ie_zdce_plan.hip)
 // ------------------------------------------------------------------------------------
-template <typename T, int NSRC, int EPI>
+template <typename T0, typename T1, typename TO, int NSRC, int EPI>
 static int launch_mfma_t(const ZdceConvLaunch& a, hipStream_t st) {
     ConvParams p;
     p.src0 = a.src0; p.src1 = a.src1; p.wpk = a.wpk; p.bias = a.bias; p.dst = a.dst;
@@ -442,14 +449,14 @@ static int launch_mfma_t(const ZdceConvLaunch& a, hipStream_t st) {
     p.chunks = ie_cdiv(a.y_end - a.y_begin, a.rows_per_block);
     const long long blocks = (long long)p.strips * p.chunks * a.n_count;
     if (blocks <= 0 || blocks > 0x7fffffffLL) IE_FAIL(IE_ERR_INVALID, "zdce conv: bad grid %lld", blocks);
-    if ((size_t)a.H * a.W * 32 * sizeof(T) >= 0x7fffffffull) IE_FAIL(IE_ERR_UNSUPPORTED, "zdce conv: frame too large for 31-bit offsets");
+    if ((size_t)a.H * a.W * 32 * 2 >= 0x7fffffffull) IE_FAIL(IE_ERR_UNSUPPORTED, "zdce conv: frame too large for 31-bit offsets");
     constexpr int NR = (EPI == EPI_CURVE) ? 3 : 4;
-    const size_t lds = (size_t)NR * ROW_PX * 32 * sizeof(T) * NSRC + (EPI == EPI_CURVE ? (24 * TW * 4 + NR * 3 * TW * 4) : 0);
+    const size_t lds = (size_t)NR * ROW_PX * 32 * 2 * NSRC + (EPI == EPI_CURVE ? (24 * TW * 4 + NR * 3 * TW * 4) : 0);
     const bool sync = a.variant & IE_ZDCE_VAR_SYNC_STAGE;
     const bool narrow = a.variant & IE_ZDCE_VAR_NARROW_STORE;
     const bool nodma = a.variant & IE_ZDCE_VAR_NO_DMA;
     dim3 grid((unsigned)blocks), block(NWAVE * 64);
-#define IE_GO(DMA, SYNC, WIDE) hipLaunchKernelGGL((zdce_conv3x3_mfma<T, NSRC, EPI, DMA, SYNC, WIDE>), grid, block, lds, st, p)
+#define IE_GO(DMA, SYNC, WIDE) hipLaunchKernelGGL((zdce_conv3x3_mfma<T0, T1, TO, NSRC, EPI, DMA, SYNC, WIDE>), grid, block, lds, st, p)
     if (nodma) { if (narrow) IE_GO(false, true, false); else IE_GO(false, true, true); }
     else if (sync) { if (narrow) IE_GO(true, true, false); else IE_GO(true, true, true); }
     else { if (narrow) IE_GO(true, false, false); else IE_GO(true, false, true); }
@@ -459,14 +466,20 @@ static int launch_mfma_t(const ZdceConvLaunch& a, hipStream_t st) {
 }
 
 int ie_zdce_launch_mfma(const ZdceConvLaunch& a, hipStream_t st) {
-#define IE_DISPATCH(T)                                                                   \
-    if (a.nsrc == 1 && a.epi == EPI_RELU) return launch_mfma_t<T, 1, EPI_RELU>(a, st);  \
-    if (a.nsrc == 2 && a.epi == EPI_RELU) return launch_mfma_t<T, 2, EPI_RELU>(a, st);  \
-    if (a.nsrc == 2 && a.epi == EPI_CURVE) return launch_mfma_t<T, 2, EPI_CURVE>(a, st);
-    if (a.dtype == IE_F16) { IE_DISPATCH(_Float16) }
-    else if (a.dtype == IE_BF16) { IE_DISPATCH(__bf16) }
+    // element types: source 0, source 1 (nsrc == 2), ReLU output (epi == RELU)
+    const int d0 = a.dt0, d1 = a.nsrc == 2 ? a.dt1 : a.dt0, dO = a.epi == EPI_RELU ? a.dto : a.dt0;
+#define IE_DISPATCH(T0, T1, TO)                                                                  \
+    if (a.nsrc == 1 && a.epi == EPI_RELU) return launch_mfma_t<T0, T1, TO, 1, EPI_RELU>(a, st);  \
+    if (a.nsrc == 2 && a.epi == EPI_RELU) return launch_mfma_t<T0, T1, TO, 2, EPI_RELU>(a, st);  \
+    if (a.nsrc == 2 && a.epi == EPI_CURVE) return launch_mfma_t<T0, T1, TO, 2, EPI_CURVE>(a, st);
+    if (d0 == IE_F16 && d1 == IE_F16 && dO == IE_F16) { IE_DISPATCH(_Float16, _Float16, _Float16) }
+    else if (d0 == IE_BF16 && d1 == IE_BF16 && dO == IE_BF16) { IE_DISPATCH(__bf16, __bf16, __bf16) }
 #undef IE_DISPATCH
-    IE_FAIL(IE_ERR_UNSUPPORTED, "zdce mfma conv: nsrc=%d epi=%d dtype=%d", a.nsrc, a.epi, a.dtype);
+    // the two mixed layers of the "bf16" schedule run one at a time only on the unfused (diagnostic) schedule and as
+    // e_conv3 of the fused one: x2 (fp16) -> x3 (bf16), and [x2 (fp16), x5 (bf16)] -> x6 (fp16)
+    else if (d0 == IE_F16 && dO == IE_BF16 && a.nsrc == 1 && a.epi == EPI_RELU) return launch_mfma_t<_Float16, _Float16, __bf16, 1, EPI_RELU>(a, st);
+    else if (d0 == IE_F16 && d1 == IE_BF16 && dO == IE_F16 && a.nsrc == 2 && a.epi == EPI_RELU) return launch_mfma_t<_Float16, __bf16, _Float16, 2, EPI_RELU>(a, st);
+    IE_FAIL(IE_ERR_UNSUPPORTED, "zdce mfma conv: nsrc=%d epi=%d dtypes=%d,%d->%d", a.nsrc, a.epi, d0, d1, dO);
 }
 
 int ie_zdce_launch_conv1(const float* img, const float* wk, const float* bias, void* dst, int dtype, int N, int H,

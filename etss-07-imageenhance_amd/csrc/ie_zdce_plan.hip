@@ -35,6 +35,11 @@ int env_int(const char* name, int dflt) { const char* v = getenv(name); return (
 
 struct ie_zdce_plan {
     ie_zdce_config cfg;
+    // element type of every 16-bit intermediate x1..x6 (index 1..6; x1's slot holds P on the fused schedule).
+    // compute_dtype F16: all fp16.  BF16 + IE_ZDCE_VAR_PURE_BF16: all bf16 (2e-3 of the fp32 result: bf16's 8-bit
+    // mantissa on the WEIGHTS alone costs 1.3e-3, tools/bf16_attrib.py).  BF16 (default): the tensors that carry
+    // the error -- x1, x2, x6, P and the weights contracted with them -- are fp16, x3/x4/x5 and theirs stay bf16.
+    int xdt[7] = {0, 0, 0, 0, 0, 0, 0};
     std::vector<float> w[NL], b[NL];
     bool set[NL] = {false, false, false, false, false, false, false};
     bool finalized = false;
@@ -96,6 +101,11 @@ IE_EXPORT int ie_zdce_create(const ie_zdce_config* cfg, ie_zdce_plan** out) {
     ie_zdce_plan* p = new (std::nothrow) ie_zdce_plan();
     if (!p) IE_FAIL(IE_ERR_NOMEM, "ie_zdce_create: out of host memory");
     p->cfg = *cfg;
+    {
+        const bool mixed = cfg->compute_dtype == IE_BF16 && !(cfg->variant & IE_ZDCE_VAR_PURE_BF16);
+        for (int k = 1; k <= 6; ++k) p->xdt[k] = cfg->compute_dtype;
+        if (mixed) { p->xdt[1] = p->xdt[2] = p->xdt[6] = IE_F16; }
+    }
     p->rows_per_block = env_int("IE_ZDCE_RB", 0);
     p->band_rows = env_int("IE_ZDCE_BAND", 0);
     p->group_frames = env_int("IE_ZDCE_GROUP", 0);
@@ -132,6 +142,7 @@ IE_EXPORT int ie_zdce_finalize(ie_zdce_plan* p, void* stream) {
     const int nc = 32;
     std::vector<char> host;
     auto align = [&](size_t a) { while (host.size() % a) host.push_back(0); };
+    const int s0x[NL] = {0, 1, 2, 3, 3, 2, 1}, s1x[NL] = {0, 0, 0, 0, 4, 5, 6};   // source tensors of each layer
     for (int l = 0; l < NL; ++l) {
         const int Co = l == 6 ? 24 : nc;
         const int Ci = l == 0 ? 3 : (l >= 4 ? 64 : 32);
@@ -165,7 +176,8 @@ IE_EXPORT int ie_zdce_finalize(ie_zdce_plan* p, void* stream) {
                     const int co = 16 * hc + (lane & 15);
                     const int ci = s * 32 + 8 * (lane >> 4) + j;
                     const float v = co < Co ? w[((size_t)co * Ci + ci) * 9 + t] : 0.f;
-                    hw[(((size_t)hc * nsrc * 9 + f) * 64 + lane) * 8 + j] = dt == IE_F16 ? f32_to_f16_bits(v) : f32_to_bf16_bits(v);
+                    const int sdt = p->xdt[s == 0 ? s0x[l] : s1x[l]];      // the weights take their source tensor's element type
+                    hw[(((size_t)hc * nsrc * 9 + f) * 64 + lane) * 8 + j] = sdt == IE_F16 ? f32_to_f16_bits(v) : f32_to_bf16_bits(v);
                 }
             const char* q = (const char*)hw.data();
             host.insert(host.end(), q, q + hw.size() * 2);
@@ -189,7 +201,7 @@ IE_EXPORT int ie_zdce_finalize(ie_zdce_plan* p, void* stream) {
             const int kq = lane >> 4, ky = 2 * m + (kq >> 1), kx = 2 * (kq & 1) + (j >> 2), c = j & 3;
             float v = 0.f;
             if (ky < 3 && kx < 3 && c < 3) v = w[((size_t)(16 * hc + (lane & 15)) * 3 + c) * 9 + ky * 3 + kx];
-            hw[(((size_t)hc * 2 + m) * 64 + lane) * 8 + j] = dt == IE_F16 ? f32_to_f16_bits(v) : f32_to_bf16_bits(v);
+            hw[(((size_t)hc * 2 + m) * 64 + lane) * 8 + j] = p->xdt[1] == IE_F16 ? f32_to_f16_bits(v) : f32_to_bf16_bits(v);
         }
         const char* q = (const char*)hw.data();
         host.insert(host.end(), q, q + hw.size() * 2);
@@ -197,12 +209,12 @@ IE_EXPORT int ie_zdce_finalize(ie_zdce_plan* p, void* stream) {
     if (dt != IE_F32) {
         // e_conv7([x1, x6]) = W7a * x1 + W7b * x6.  K12 computes P = W7a*x1 + bias7 next to e_conv2 (one fragment
         // buffer [hc][e_conv2 9 | e_conv7a 9]), K67 adds W7b * x6.  Same fragment order as above.
-        auto pack9 = [&](std::vector<unsigned short>& hw, size_t base, int hc, const float* w, int Co, int Ci, int ci0) {
+        auto pack9 = [&](std::vector<unsigned short>& hw, size_t base, int hc, const float* w, int Co, int Ci, int ci0, int sdt) {
             for (int t = 0; t < 9; ++t) for (int lane = 0; lane < 64; ++lane) for (int j = 0; j < 8; ++j) {
                 const int co = 16 * hc + (lane & 15);
                 const int ci = ci0 + 8 * (lane >> 4) + j;
                 const float v = co < Co ? w[((size_t)co * Ci + ci) * 9 + t] : 0.f;
-                hw[base + ((size_t)t * 64 + lane) * 8 + j] = dt == IE_F16 ? f32_to_f16_bits(v) : f32_to_bf16_bits(v);
+                hw[base + ((size_t)t * 64 + lane) * 8 + j] = sdt == IE_F16 ? f32_to_f16_bits(v) : f32_to_bf16_bits(v);
             }
         };
         align(256);
@@ -210,8 +222,8 @@ IE_EXPORT int ie_zdce_finalize(ie_zdce_plan* p, void* stream) {
         {
             std::vector<unsigned short> hw((size_t)2 * 18 * 64 * 8, 0);
             for (int hc = 0; hc < 2; ++hc) {
-                pack9(hw, ((size_t)hc * 18 + 0) * 64 * 8, hc, p->w[1].data(), 32, 32, 0);
-                pack9(hw, ((size_t)hc * 18 + 9) * 64 * 8, hc, p->w[6].data(), 24, 64, 0);
+                pack9(hw, ((size_t)hc * 18 + 0) * 64 * 8, hc, p->w[1].data(), 32, 32, 0, p->xdt[1]);
+                pack9(hw, ((size_t)hc * 18 + 9) * 64 * 8, hc, p->w[6].data(), 24, 64, 0, p->xdt[1]);
             }
             const char* q = (const char*)hw.data();
             host.insert(host.end(), q, q + hw.size() * 2);
@@ -220,7 +232,7 @@ IE_EXPORT int ie_zdce_finalize(ie_zdce_plan* p, void* stream) {
         p->off_w7b = host.size();
         {
             std::vector<unsigned short> hw((size_t)2 * 9 * 64 * 8, 0);
-            for (int hc = 0; hc < 2; ++hc) pack9(hw, (size_t)hc * 9 * 64 * 8, hc, p->w[6].data(), 24, 64, 32);
+            for (int hc = 0; hc < 2; ++hc) pack9(hw, (size_t)hc * 9 * 64 * 8, hc, p->w[6].data(), 24, 64, 32, p->xdt[6]);
             const char* q = (const char*)hw.data();
             host.insert(host.end(), q, q + hw.size() * 2);
         }
@@ -311,7 +323,6 @@ static int forward_f32(ie_zdce_plan* p, const float* image, float* enhanced, flo
 
 static int forward_mfma(ie_zdce_plan* p, const float* image, float* enhanced, float* adjust, uint8_t* u8, int N, int H,
                         int W, hipStream_t st, int group, int band, int rb) {
-    const int dt = p->cfg.compute_dtype;
     const size_t fb = frame_elems(H, W, 32) * elem_size(p);   // bytes per frame of one intermediate
     for (int n0 = 0; n0 < N; n0 += group) {
         const int g = (N - n0) < group ? (N - n0) : group;
@@ -333,7 +344,8 @@ static int forward_mfma(ie_zdce_plan* p, const float* image, float* enhanced, fl
                 a.src0 = x[s0i[l]]; a.src1 = s1i[l] >= 0 ? x[s1i[l]] : nullptr;
                 a.wpk = W_(l); a.bias = B_(l);
                 a.N = N; a.H = H; a.W = W; a.n_begin = n0; a.n_count = g; a.rows_per_block = rb;
-                a.nsrc = s1i[l] >= 0 ? 2 : 1; a.dtype = dt; a.variant = p->cfg.variant;
+                a.nsrc = s1i[l] >= 0 ? 2 : 1; a.variant = p->cfg.variant;
+                a.dt0 = p->xdt[s0i[l]]; a.dt1 = s1i[l] >= 0 ? p->xdt[s1i[l]] : a.dt0; a.dto = l < 6 ? p->xdt[l + 1] : a.dt0;
                 if (l < 6) { a.epi = 0; a.dst = x[l + 1]; a.y_begin = lo(l + 1); a.y_end = hi(l + 1); }
                 else { a.epi = 1; a.img = image; a.enhanced = enhanced; a.adjust = adjust; a.u8 = u8; a.y_begin = b0; a.y_end = b1; }
                 return ie_zdce_launch_mfma(a, st);
@@ -342,18 +354,21 @@ static int forward_mfma(ie_zdce_plan* p, const float* image, float* enhanced, fl
                 ProfScope ps(p, prof_layer, st);
                 ZdceFusedLaunch a;
                 memset(&a, 0, sizeof(a));
-                a.kind = kind; a.dtype = dt; a.N = N; a.H = H; a.W = W; a.n_begin = n0; a.n_count = g; a.rows_per_block = rb;
+                a.kind = kind; a.N = N; a.H = H; a.W = W; a.n_begin = n0; a.n_count = g; a.rows_per_block = rb;
                 a.img = image;
                 a.stamps = g_ie_stamps ? (void*)((unsigned long long*)g_ie_stamps + (size_t)(kind == 12 ? 0 : kind == 45 ? 1 : 2) * (1u << 20)) : nullptr;
                 if (kind == 12) {
                     a.a_w = p->d_w + p->off_w1m; a.a_bias = B_(0); a.b_w = p->d_w + p->off_w27; a.b_bias = B_(1); a.b2_bias = B_(6);
                     a.a_dst = x[1]; a.b_dst = x[2]; a.y_begin = lo(2); a.y_end = hi(2);   // x[1] holds P = W7a*x1 + bias7, not x1
+                    a.dt_h = a.dt_a0 = a.dt_a1 = p->xdt[1]; a.dt_o = p->xdt[2];            // (P takes x2's element type = x6's)
                 } else if (kind == 45) {
                     a.a_src0 = x[3]; a.a_w = W_(3); a.a_bias = B_(3); a.b_w = W_(4); a.b_bias = B_(4);
                     a.b_dst = x[5]; a.y_begin = lo(5); a.y_end = hi(5);
+                    a.dt_a0 = a.dt_a1 = p->xdt[3]; a.dt_h = p->xdt[4]; a.dt_o = p->xdt[5];
                 } else {
                     a.a_src0 = x[2]; a.a_src1 = x[5]; a.b_src = x[1]; a.a_w = W_(5); a.a_bias = B_(5); a.b_w = p->d_w + p->off_w7b; a.b_bias = B_(6);
                     a.enhanced = enhanced; a.adjust = adjust; a.u8 = u8; a.y_begin = b0; a.y_end = b1;
+                    a.dt_a0 = p->xdt[2]; a.dt_a1 = p->xdt[5]; a.dt_h = a.dt_o = p->xdt[6];
                 }
                 return ie_zdce_launch_fused(a, st);
             };
@@ -361,7 +376,7 @@ static int forward_mfma(ie_zdce_plan* p, const float* image, float* enhanced, fl
             if (p->cfg.variant & IE_ZDCE_VAR_UNFUSED) {
                 {
                     ProfScope ps(p, 0, st);
-                    rc = ie_zdce_launch_conv1(image, (const float*)W_(0), B_(0), x[1], dt, N, H, W, lo(1), hi(1), n0, g, st);
+                    rc = ie_zdce_launch_conv1(image, (const float*)W_(0), B_(0), x[1], p->xdt[1], N, H, W, lo(1), hi(1), n0, g, st);
                 }
                 for (int l = 1; l < NL && rc == IE_OK; ++l) rc = single(l);
             } else {
@@ -408,7 +423,7 @@ IE_EXPORT int ie_zdce_get_feature(ie_zdce_plan* p, int idx, float* dst, void* st
         return ie_nhwc_to_nchw_f32(xk, IE_F32, dst, N, 32, H, W, 32, stream);
     }
     const size_t fb = frame_elems(H, W, 32) * elem_size(p);
-    return ie_nhwc_to_nchw_f32(p->ws + fb * g * (idx - 1), (ie_dtype)p->cfg.compute_dtype, dst, N, 32, H, W, 32, stream);
+    return ie_nhwc_to_nchw_f32(p->ws + fb * g * (idx - 1), (ie_dtype)p->xdt[idx], dst, N, 32, H, W, 32, stream);
 }
 
 IE_EXPORT int ie_zdce_destroy(ie_zdce_plan* p) {

@@ -4,6 +4,9 @@
   llunet++_re     LLUnetpp_RE    src/mon/vision/enhance/llie/llunetpp/llunetpp.py:97-243
   unet            UNet           src/mon/vision/segment/unet/unet.py:35-197  (+ ``upsampler="pixelshuffle"``: nn/modules/encoder/edsr.py:88-123)
   zero_ig_enhance Enhance        src/mon/vision/enhance/llie/zero_ig/zero_ig.py:307-348
+  zero_ig_re      ZeroIG         src/mon/vision/enhance/llie/zero_ig/zero_ig.py:257-304, 355-452 (predicting branch)
+  rrdnet_re       RRDNet_RE      src/mon/vision/enhance/llie/rrdnet/rrdnet.py:183-289
+  zsn2n           ZSN2N          src/mon/vision/enhance/denoise/zsn2n/zsn2n.py:40-124
   retinexnet      RetinexNet     src/mon_extra/vision/enhance/llie/retinexnet/model.py:21-90, 199-238
 
 Same registry names, constructor hyper-parameters, checkpoint key names and output dicts as the reference
@@ -46,25 +49,35 @@ class _GraphModel(ImageEnhancementModel):
         x = self._input(datapoint)
         return x if self.compute_dtype == "f32" else ops.cast(x, self._tdt, 8)
 
+    def _wb(self, name, bn=None, negate=False, cout=None):
+        """Host (weight, bias) of conv ``name``: eval BatchNorm ``bn`` folded in, optionally only the first ``cout`` output
+        channels and/or negated (``x - conv(x)`` then runs as one conv with a fused residual: -(W*x + b) = (-W)*x + (-b) exactly)."""
+        w, b = self._params[f"{name}.weight"], self._params.get(f"{name}.bias")
+        if bn is not None:
+            w, b = ops.fold_bn(w, b, self._params[f"{bn}.weight"], self._params[f"{bn}.bias"],
+                               self._params[f"{bn}.running_mean"], self._params[f"{bn}.running_var"])
+        if cout is not None:
+            w, b = w[:cout], None if b is None else b[:cout]
+        if negate:
+            w, b = -w, None if b is None else -b
+        return w, b
+
     def _conv(self, srcs, name, bn=None, stride=1, pad=1, pad_mode="zeros", act="none", slope=0.0, residual=None, clamp=None,
-              out_f32=False, cout_pad=None, valid=None):
+              out_f32=False, cout_pad=None, valid=None, negate=False, cout=None):
         """Conv2d ``name`` (+ folded eval BatchNorm ``bn``) over the channel concat of ``srcs`` in the model's compute dtype.
         On the 16-bit path sources may carry zero-padded channels (a 3-channel image stored as 8): the weights of the missing
         input channels are zero; ``cout_pad`` pads the output channels the same way (zero weights and bias)."""
         if isinstance(srcs, torch.Tensor):
             srcs = [srcs]
         if self.compute_dtype == "f32":
-            return ops.conv2d(srcs, self._cw(name, bn), stride=stride, pad=pad, pad_mode=pad_mode, act=act, slope=slope,
+            return ops.conv2d(srcs, self._cw(name, bn, negate, cout), stride=stride, pad=pad, pad_mode=pad_mode, act=act, slope=slope,
                               residual=residual, clamp=clamp)
         split = tuple(int(t.shape[1]) for t in srcs)
-        key = ("mconv", name, bn, split, cout_pad, None if valid is None else tuple(valid))
+        key = ("mconv", name, bn, split, cout_pad, None if valid is None else tuple(valid), negate, cout)
         if self._dev_cache is None:
             self._dev_cache = {}
         if key not in self._dev_cache:
-            w, b = self._params[f"{name}.weight"], self._params.get(f"{name}.bias")
-            if bn is not None:
-                w, b = ops.fold_bn(w, b, self._params[f"{bn}.weight"], self._params[f"{bn}.bias"],
-                                   self._params[f"{bn}.running_mean"], self._params[f"{bn}.running_var"])
+            w, b = self._wb(name, bn, negate, cout)
             cin_map = None
             if sum(split) != w.shape[1]:
                 real = list(valid) if valid is not None else ([w.shape[1]] if len(split) == 1 else None)
@@ -111,18 +124,13 @@ class _GraphModel(ImageEnhancementModel):
         g.manual_seed(int(seed)) if seed is not None else g.seed()
         return g
 
-    def _cw(self, name: str, bn: str | None = None) -> ops.ConvWeights:
+    def _cw(self, name: str, bn: str | None = None, negate: bool = False, cout: int | None = None) -> ops.ConvWeights:
         """ConvWeights of conv ``name`` (optionally with eval-mode BatchNorm ``bn`` folded in), cached per device."""
         if self._dev_cache is None:
             self._dev_cache = {}
-        key = (name, bn)
+        key = (name, bn, negate, cout)
         if key not in self._dev_cache:
-            w = self._params[f"{name}.weight"]
-            b = self._params.get(f"{name}.bias")
-            if bn is not None:
-                w, b = ops.fold_bn(w, b, self._params[f"{bn}.weight"], self._params[f"{bn}.bias"],
-                                   self._params[f"{bn}.running_mean"], self._params[f"{bn}.running_var"])
-            self._dev_cache[key] = ops.ConvWeights(w, b, self.device)
+            self._dev_cache[key] = ops.ConvWeights(*self._wb(name, bn, negate, cout), self.device)
         return self._dev_cache[key]
 
     def _vec(self, name: str) -> torch.Tensor:
@@ -619,6 +627,181 @@ class ZeroIGEnhance(_GraphModel):
         for _ in range(self.layers):
             fea = self._conv(fea, "conv.0", "conv.1", act="relu", residual=fea)
         y = self._conv(fea, "out_conv.0", act="sigmoid", clamp=(0.0001, 1.0), out_f32=True)
+        return OrderedDict(enhanced=ops.to_nchw(y))
+
+
+# ----------------------------------------------------------------------------------------------------------------
+@MODELS.register(name="zero_ig_re", arch="zero_ig")
+class ZeroIG(_GraphModel):
+    """Zero-IG (zero_ig.py:355-452), predicting branch of ``forward`` (:434-452 == ``Finetunemodel.forward`` of the original
+    repository, mon_extra/.../zero_ig/model.py:188-199):
+
+        image += 1e-4;  L2 = clamp(image - Denoise1(image), 1e-4, 1);  s2 = Enhance(L2);  H2 = clamp(image / s2, 1e-4, 1)
+        H3 = clamp(cat[H2, s2] - Denoise2(cat[H2, s2]), 1e-4, 1)[:, :3]          -> {"denoise": H3, "enhanced": H2}
+
+    ``Enhance`` (:307-348) is the graph of ``zero_ig_enhance``; ``Denoise1/2`` (:257-304) are Conv3x3 + LeakyReLU(0.2) twice and
+    a Conv1x1.  ``x - conv(x)`` runs as ONE convolution with negated weights and the fused residual add + clamp.
+    Checkpoint keys ``enhance.*``, ``denoise1.*``, ``denoise2.*`` (the original's ``denoise_1`` / ``denoise_2`` are accepted;
+    the ``enhance.blocks.i.*`` aliases of the shared block are dropped)."""
+
+    arch = "zero_ig"
+    tasks = [Task.LLIE]
+    schemes = [Scheme.UNSUPERVISED, Scheme.ZERO_REFERENCE]
+
+    def __init__(self, in_channels: int = 3, num_channels: int = 64, embed_channels: int = 48, weights: Any = None, seed: int = None,
+                 *args, **kwargs):
+        kwargs.pop("name", None)
+        super().__init__(name="zero_ig_re", in_channels=in_channels, weights=weights, *args, **kwargs)
+        if isinstance(self.weights, dict):
+            in_channels = self.weights.get("in_channels", in_channels)
+            num_channels = self.weights.get("num_channels", num_channels)
+            embed_channels = self.weights.get("embed_channels", embed_channels)
+        self.in_channels, self.num_channels, self.embed_channels = in_channels, num_channels, embed_channels
+        self.layers = in_channels                      # zero_ig.py:388: Enhance(layers=self.in_channels, ...)
+        self.predicting = True
+        c, e, P = num_channels, embed_channels, self._params
+        P["enhance.in_conv.0.weight"], P["enhance.in_conv.0.bias"] = torch.zeros(c, 3, 3, 3), torch.zeros(c)
+        P["enhance.conv.0.weight"], P["enhance.conv.0.bias"] = torch.zeros(c, c, 3, 3), torch.zeros(c)
+        P["enhance.conv.1.weight"], P["enhance.conv.1.bias"] = torch.ones(c), torch.zeros(c)
+        P["enhance.conv.1.running_mean"], P["enhance.conv.1.running_var"] = torch.zeros(c), torch.ones(c)
+        P["enhance.out_conv.0.weight"], P["enhance.out_conv.0.bias"] = torch.zeros(3, c, 3, 3), torch.zeros(3)
+        for n, ci in (("denoise1", 3), ("denoise2", 6)):
+            P[f"{n}.conv1.weight"], P[f"{n}.conv1.bias"] = torch.zeros(e, ci, 3, 3), torch.zeros(e)
+            P[f"{n}.conv2.weight"], P[f"{n}.conv2.bias"] = torch.zeros(e, e, 3, 3), torch.zeros(e)
+            P[f"{n}.conv3.weight"], P[f"{n}.conv3.bias"] = torch.zeros(ci, e, 1, 1), torch.zeros(ci)
+        self._finish_init(seed)
+
+    def map_key(self, k: str) -> str:
+        return k.replace("denoise_1.", "denoise1.").replace("denoise_2.", "denoise2.")
+
+    def load_state_dict(self, state_dict: dict, strict: bool = True):
+        sd = {k: v for k, v in state_dict.items() if not k.endswith("num_batches_tracked") and ".blocks." not in k
+              and not k.startswith("texture_difference.")}
+        super().load_state_dict(sd, strict)
+
+    def init_weights(self, seed: int = None):
+        g = self._gen(seed)            # zero_ig.py:404-409: conv N(0, 0.02), bias 0, BN weight N(1, 0.02)
+        for k in list(self._params):
+            if k.endswith(".weight") and self._params[k].dim() == 4:
+                self._init_conv(k[:-7], g, std=0.02, zero_bias=True)
+        c = self.num_channels
+        self._params["enhance.conv.1.weight"] = 1.0 + torch.randn(c, generator=g) * 0.02
+        self._params["enhance.conv.1.running_mean"] = torch.randn(c, generator=g) * 0.05
+        self._params["enhance.conv.1.running_var"] = torch.rand(c, generator=g) + 0.5
+        self._on_params_change()
+
+    def forward(self, datapoint: dict, *args, **kwargs) -> dict:
+        eps, c = 1e-4, self._conv
+        f32 = self.compute_dtype == "f32"
+        image = ops.affine(self._input(datapoint), 1.0, eps)                              # image + eps (fp32)
+        img = image if f32 else ops.cast(image, self._tdt, 8)
+        cp = None if f32 else 8
+
+        def denoise_residual(n, srcs, res, cout, valid=None):
+            # res - Denoise(srcs)[:, :cout], clamped to [eps, 1]
+            y = c(srcs, f"{n}.conv1", act="lrelu", slope=0.2, valid=valid)
+            y = c(y, f"{n}.conv2", act="lrelu", slope=0.2)
+            return c(y, f"{n}.conv3", pad=0, negate=True, cout=cout, residual=res, clamp=(eps, 1.0), cout_pad=cp)
+
+        l2 = denoise_residual("denoise1", img, img, 3)
+        fea = c(l2, "enhance.in_conv.0", act="relu")
+        for _ in range(self.layers):
+            fea = c(fea, "enhance.conv.0", "enhance.conv.1", act="relu", residual=fea)
+        s2 = c(fea, "enhance.out_conv.0", act="sigmoid", clamp=(0.0001, 1.0), out_f32=True)   # 3 channels, fp32 on every path
+        h2 = ops.div_clamp(image, s2, eps, 1.0)
+        if f32:
+            h3 = denoise_residual("denoise2", [h2, s2], h2, 3)
+        else:
+            h2p, s2p = ops.cast(h2, self._tdt, 8), ops.cast(s2, self._tdt, 8)
+            h3 = ops.cast(denoise_residual("denoise2", [h2p, s2p], h2p, 3, valid=[3, 3]), torch.float32, 3)
+        return OrderedDict(denoise=ops.to_nchw(h3), enhanced=ops.to_nchw(h2))
+
+
+# ----------------------------------------------------------------------------------------------------------------
+@MODELS.register(name="rrdnet_re", arch="rrdnet")
+class RRDNet_RE(_GraphModel):
+    """RRDNet (rrdnet.py:183-289): three 5-layer Conv3x3 stacks (3-16-32-64-32-out, ReLU between) for illumination (1 ch,
+    sigmoid), reflectance (3 ch, sigmoid) and noise (3 ch, tanh); ``enhanced = clamp(illumination^gamma * ((image - noise) /
+    illumination), 0, 1)`` (:271-279).  Keys ``{illumination,reflectance,noise}_net.{0,2,4,6,8}.*``.  The reference's ``infer``
+    fits the three stacks to ONE image for 1000 iterations (:291-335); this class provides ``forward``."""
+
+    arch = "rrdnet"
+    tasks = [Task.LLIE]
+    schemes = [Scheme.UNSUPERVISED, Scheme.ZERO_REFERENCE, Scheme.INSTANCE]
+    _NETS = (("illumination_net", 1, "sigmoid"), ("reflectance_net", 3, "sigmoid"), ("noise_net", 3, "tanh"))
+
+    def __init__(self, gamma: float = 0.4, illu_factor: float = 1, reflect_factor: float = 1, noise_factor: float = 5000,
+                 weights: Any = None, seed: int = None, *args, **kwargs):
+        kwargs.pop("name", None)
+        super().__init__(name="rrdnet_re", in_channels=3, weights=weights, *args, **kwargs)
+        self.gamma, self.illu_factor, self.reflect_factor, self.noise_factor = gamma, illu_factor, reflect_factor, noise_factor
+        self.predicting = True
+        for net, co, _ in self._NETS:
+            for i, (a, b) in zip((0, 2, 4, 6, 8), ((3, 16), (16, 32), (32, 64), (64, 32), (32, co))):
+                self._params[f"{net}.{i}.weight"], self._params[f"{net}.{i}.bias"] = torch.zeros(b, a, 3, 3), torch.zeros(b)
+        self._finish_init(seed)
+
+    def init_weights(self, seed: int = None):
+        g = self._gen(seed)            # rrdnet.py:255-256: init_weights is a no-op -> torch's Conv2d default
+        for k in list(self._params):
+            if k.endswith(".weight"):
+                self._init_conv(k[:-7], g)
+        self._on_params_change()
+
+    def forward(self, datapoint: dict, *args, **kwargs) -> dict:
+        image = self._input(datapoint)
+        x = image if self.compute_dtype == "f32" else ops.cast(image, self._tdt, 8)
+        outs = {}
+        for net, co, act in self._NETS:
+            y = x
+            for i in (0, 2, 4, 6):
+                y = self._conv(y, f"{net}.{i}", act="relu")
+            outs[net] = self._conv(y, f"{net}.8", act=act, out_f32=True)
+        illumination, reflectance, noise = outs["illumination_net"], outs["reflectance_net"], outs["noise_net"]
+        adjust = ops.pow_scalar(illumination, self.gamma)
+        enhanced = ops.clamp(ops.mul(ops.div_clamp(ops.sub(image, noise), illumination), adjust), 0.0, 1.0)
+        out = OrderedDict(image=ops.to_nchw(image), illumination=ops.to_nchw(illumination), reflectance=ops.to_nchw(reflectance),
+                          noise=ops.to_nchw(noise))
+        out["enhanced"] = ops.to_nchw(enhanced)
+        return out
+
+
+# ----------------------------------------------------------------------------------------------------------------
+@MODELS.register(name="zsn2n", arch="zsn2n")
+class ZSN2N(_GraphModel):
+    """ZS-N2N (zsn2n.py:40-124): Conv3x3 + LeakyReLU(0.2), Conv3x3 + LeakyReLU(0.2), Conv1x1; ``enhanced`` is clamped to [0, 1]
+    when ``predicting`` (:116-124).  Keys ``conv1/conv2/conv3``.  (Its ``infer`` trains on the single input image for 3000
+    iterations, :126-190; this class provides ``forward``.)"""
+
+    arch = "zsn2n"
+    tasks = [Task.DENOISE]
+    schemes = [Scheme.UNSUPERVISED, Scheme.ZERO_SHOT, Scheme.INSTANCE]
+
+    def __init__(self, in_channels: int = 3, num_channels: int = 48, weights: Any = None, seed: int = None, predicting: bool = True,
+                 *args, **kwargs):
+        kwargs.pop("name", None)
+        super().__init__(name="zsn2n", in_channels=in_channels, weights=weights, *args, **kwargs)
+        if isinstance(self.weights, dict):
+            in_channels = self.weights.get("in_channels", in_channels)
+            num_channels = self.weights.get("num_channels", num_channels)
+        self.in_channels, self.num_channels, self.predicting = in_channels, num_channels, predicting
+        c, P = num_channels, self._params
+        P["conv1.weight"], P["conv1.bias"] = torch.zeros(c, in_channels, 3, 3), torch.zeros(c)
+        P["conv2.weight"], P["conv2.bias"] = torch.zeros(c, c, 3, 3), torch.zeros(c)
+        P["conv3.weight"], P["conv3.bias"] = torch.zeros(self.out_channels, c, 1, 1), torch.zeros(self.out_channels)
+        self._finish_init(seed)
+
+    def init_weights(self, seed: int = None):
+        g = self._gen(seed)            # zsn2n.py:88-89: no-op -> torch's Conv2d default
+        for n in ("conv1", "conv2", "conv3"):
+            self._init_conv(n, g)
+        self._on_params_change()
+
+    def forward(self, datapoint: dict, *args, **kwargs) -> dict:
+        x = self._input_any(datapoint)
+        y = self._conv(x, "conv1", act="lrelu", slope=0.2)
+        y = self._conv(y, "conv2", act="lrelu", slope=0.2)
+        y = self._conv(y, "conv3", pad=0, clamp=(0.0, 1.0) if self.predicting else None, out_f32=True)
         return OrderedDict(enhanced=ops.to_nchw(y))
 
 

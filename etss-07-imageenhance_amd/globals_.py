@@ -10,10 +10,15 @@ class Task(Enum):
     DESNOW = "desnow"
     LES = "les"
     SEGMENT = "segment"
+    DEHAZE = "dehaze"
+    UIE = "uie"
 
 
 class Scheme(Enum):
+    INFERENCE = "inference"
+    INSTANCE = "instance"
     SUPERVISED = "supervised"
+    TRADITIONAL = "traditional"
     UNSUPERVISED = "unsupervised"
     ZERO_REFERENCE = "zero_reference"
     ZERO_SHOT = "zero_shot"

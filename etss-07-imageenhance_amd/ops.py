@@ -268,6 +268,24 @@ def clamp(a, lo, hi):
     return _elt(2, a, None, lo, hi)
 
 
+def sub(a, b):
+    return _elt(4, a, b)
+
+
+def div_clamp(a, b, lo=float("-inf"), hi=float("inf")):
+    """clamp(a / b, lo, hi); b has the channels of a or one channel."""
+    return _elt(5, a, b, lo, hi)
+
+
+def affine(a, scale=1.0, shift=0.0):
+    """a * scale + shift (fp32)."""
+    return _elt(6, a, None, scale, shift)
+
+
+def pow_scalar(a, exponent):
+    return _elt(7, a, None, exponent, 0.0)
+
+
 def mul_prefix(a, b) -> torch.Tensor:
     """y = a[:, :C] * b for a with C+1 channels and a single-channel b (RetinexNet: S = R * I_delta)."""
     _chk(a); _chk(b)

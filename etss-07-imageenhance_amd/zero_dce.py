@@ -26,7 +26,11 @@ _LAYERS = tuple(f"e_conv{k}" for k in range(1, 8))
 @MODELS.register(name="zero_dce_re", arch="zero_dce")
 class ZeroDCE_RE(ImageEnhancementModel):
     """Args mirror zero_dce.py:107-131.  Extra (engine) arguments:
-        compute_dtype: "f16" | "bf16" (MFMA path, fp32 accumulate) or "f32" (VALU parity mode).
+        compute_dtype: "f16" | "bf16" | "bf16_pure" (MFMA path, fp32 accumulate) or "f32" (VALU parity mode).
+            "bf16" holds the tensors that carry the rounding error (x1, x2, x6, the partial sum P and the weights
+            contracted with them) in fp16 and x3/x4/x5 in bf16: 6e-4 of the fp32 result at the same bytes and MFMA
+            rate; "bf16_pure" (= variant | capi.VAR_PURE_BF16) keeps every tensor and weight in bf16: 2e-3
+            (tools/bf16_attrib.py).
         variant: kernel variant bitmask (capi.VAR_*), 0 = default.
     """
 
@@ -47,8 +51,10 @@ class ZeroDCE_RE(ImageEnhancementModel):
         self.num_channels = num_channels
         self.num_iters = num_iters
         self.out_channels = self.in_channels * self.num_iters
+        if compute_dtype == "bf16_pure":
+            compute_dtype, variant = "bf16", int(variant) | capi.VAR_PURE_BF16
         if compute_dtype not in capi.DTYPES:
-            raise ValueError(f"`compute_dtype` must be one of {sorted(capi.DTYPES)}, but got {compute_dtype}.")
+            raise ValueError(f"`compute_dtype` must be one of {sorted(capi.DTYPES) + ['bf16_pure']}, but got {compute_dtype}.")
         self.compute_dtype = compute_dtype
         self.variant = int(variant)
         self._plan = None

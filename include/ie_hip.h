@@ -131,7 +131,9 @@ int ie_conv_transpose2x2_nhwc_f32(const float* x_dev, const float* w_ijco_dev, c
 /* F.pad zero padding (unet.py:90-93). */
 int ie_pad_nhwc_f32(const float* x_dev, float* y_dev, int N, int H, int W, int C, int top, int bottom, int left, int right, void* stream);
 /* op 0: a + b, 1: a * b (b with C or 1 channels), 2: clamp(a, lo, hi), 3: y(C ch) = a[:, :C] * b where a has
- * C+1 channels and b one (S = R * I_delta with R = first 3 of DecomNet's 4 outputs, retinexnet/model.py:49-50,238). */
+ * C+1 channels and b one (S = R * I_delta with R = first 3 of DecomNet's 4 outputs, retinexnet/model.py:49-50,238),
+ * 4: a - b, 5: clamp(a / b, lo, hi) (zero_ig.py:441-442, rrdnet.py:277), 6: a * lo + hi (zero_ig.py:438 `image + eps`),
+ * 7: pow(a, lo) (rrdnet.py:276), 8: a / b[0] with b ONE device float (zero_dce_v.py:205 `x / torch.max(x)`). */
 int ie_eltwise_nhwc_f32(int op, const float* a_dev, const float* b_dev, float* y_dev, size_t npix, int C, int Cb, float lo, float hi, void* stream);
 /* [max_c(x), x] channel concat (retinexnet/model.py:45-46). */
 int ie_max_concat_nhwc_f32(const float* x_dev, float* y_dev, size_t npix, int C, void* stream);
@@ -328,6 +330,10 @@ typedef struct ie_zdce_config {
 #define IE_ZDCE_VAR_NARROW_STORE 2 /* 8-byte epilogue stores instead of permlane-widened 16-byte */
 #define IE_ZDCE_VAR_NO_DMA 4 /* register-staged global->LDS copies instead of LDS-DMA (debug / A-B) */
 #define IE_ZDCE_VAR_UNFUSED 8 /* one kernel per layer instead of the fused conv1+2 / conv4+5 / conv6+7 kernels */
+#define IE_ZDCE_VAR_PURE_BF16 16 /* compute_dtype IE_BF16 only: every 16-bit tensor and weight in bf16.  Without it the
+                                    "bf16" schedule holds the tensors that carry the rounding error (x1, x2, x6, the partial
+                                    sum P and the weights contracted with them) in fp16 and x3/x4/x5 (+ theirs) in bf16 --
+                                    same bytes, same MFMA rate, 6e-4 instead of 2e-3 of the fp32 result */
 
 int ie_zdce_create(const ie_zdce_config* cfg, ie_zdce_plan** out);
 /* layer in 1..7 (e_conv{layer}); w OIHW fp32 host, b fp32 host; shapes per zero_dce.py:133-139. */

@@ -7,7 +7,15 @@
   unet_forward         src/mon/vision/segment/unet/unet.py:35-197 with line 51's typo read as conv1; eval-mode BN.
                        parity unpinned (the reference class does not run as shipped); leaf ops are torch's.
   unet_ps variant      + Upsampler conv3x3 + nn.PixelShuffle(2) (nn/modules/encoder/edsr.py:88-123): parity unpinned.
-  zero_ig_enhance      src/mon/vision/enhance/llie/zero_ig/zero_ig.py:307-348: parity unpinned (mon not importable).
+  zero_ig_enhance      src/mon/vision/enhance/llie/zero_ig/zero_ig.py:307-348 (Enhance)
+  zero_ig_denoise      zero_ig.py:257-304 (Denoise1 / Denoise2)
+  zero_ig_forward      zero_ig.py:434-452 (ZeroIG.forward, predicting branch)
+                       all three PINNED by tests/golden/zero_ig_*.npz (reference file mon_extra/.../zero_ig/model.py:
+                       Enhancer, Denoise_1, Denoise_2 and Finetunemodel.forward run in the build container)
+  hinet_forward        src/mon/vision/enhance/multitask/hinet/hinet.py:34-198, 322-362
+                       PINNED by tests/golden/hinet_*.npz (reference file mon_extra/.../hinet/basicsr/models/archs/hinet_arch.py)
+  rrdnet_forward       src/mon/vision/enhance/llie/rrdnet/rrdnet.py:208-289: parity unpinned (mon not importable, no mon_extra twin).
+  zsn2n_forward        src/mon/vision/enhance/denoise/zsn2n/zsn2n.py:73-124: parity unpinned (same).
   retinexnet_forward   src/mon_extra/vision/enhance/llie/retinexnet/model.py:21-90,199-238: parity unpinned (file
                        imports cv2/thop/mon and hard-codes .cuda()); single Decom pass, S = R * I_delta.
 """
@@ -132,6 +140,50 @@ def zero_ig_enhance_forward(sd: dict, x: torch.Tensor, layers: int = 3) -> dict:
     return {"enhanced": torch.clamp(fea, 0.0001, 1)}
 
 
+def zero_ig_denoise_forward(sd: dict, x: torch.Tensor, prefix: str) -> torch.Tensor:
+    """Denoise1 / Denoise2 (zero_ig.py:257-304): Conv3x3 + LeakyReLU(0.2), Conv3x3 + LeakyReLU(0.2), Conv1x1."""
+    y = F.leaky_relu(_c(sd, f"{prefix}.conv1", x), 0.2)
+    y = F.leaky_relu(_c(sd, f"{prefix}.conv2", y), 0.2)
+    return _c(sd, f"{prefix}.conv3", y, padding=0)
+
+
+def zero_ig_forward(sd: dict, x: torch.Tensor, layers: int = 3) -> dict:
+    """ZeroIG.forward, predicting branch (zero_ig.py:434-452; == Finetunemodel.forward, mon_extra/.../zero_ig/model.py:188-199).
+    Keys: ``enhance.*``, ``denoise1.*``, ``denoise2.*``."""
+    eps = 1e-4
+    image = x + eps
+    l2 = torch.clamp(image - zero_ig_denoise_forward(sd, image, "denoise1"), eps, 1.0)
+    s2 = zero_ig_enhance_forward({k[8:]: v for k, v in sd.items() if k.startswith("enhance.")}, l2, layers)["enhanced"]
+    h2 = torch.clamp(image / s2, eps, 1.0)
+    hs = torch.cat([h2, s2], 1)
+    h5 = torch.clamp(hs - zero_ig_denoise_forward(sd, hs, "denoise2"), eps, 1.0)
+    return {"denoise": h5[:, :3], "enhanced": h2}
+
+
+# ---- RRDNet / ZS-N2N (parity unpinned: the mon package does not import here, SURVEY 8c; leaf ops are torch's) ---
+def rrdnet_forward(sd: dict, x: torch.Tensor, gamma: float = 0.4) -> dict:
+    """src/mon/vision/enhance/llie/rrdnet/rrdnet.py:208-240 (three Conv3x3 stacks), :271-289 (forward)."""
+    def net(n):
+        y = x
+        for i in (0, 2, 4, 6):
+            y = F.relu(_c(sd, f"{n}.{i}", y))
+        return _c(sd, f"{n}.8", y)
+    illumination = torch.sigmoid(net("illumination_net"))
+    reflectance = torch.sigmoid(net("reflectance_net"))
+    noise = torch.tanh(net("noise_net"))
+    adjust = torch.pow(illumination, gamma)
+    enhanced = torch.clamp(adjust * ((x - noise) / illumination), min=0, max=1)
+    return {"image": x, "illumination": illumination, "reflectance": reflectance, "noise": noise, "enhanced": enhanced}
+
+
+def zsn2n_forward(sd: dict, x: torch.Tensor, predicting: bool = True) -> dict:
+    """src/mon/vision/enhance/denoise/zsn2n/zsn2n.py:73-76, 116-124."""
+    y = F.leaky_relu(_c(sd, "conv1", x), 0.2)
+    y = F.leaky_relu(_c(sd, "conv2", y), 0.2)
+    y = _c(sd, "conv3", y, padding=0)
+    return {"enhanced": torch.clamp(y, 0, 1) if predicting else y}
+
+
 # ---- RetinexNet ------------------------------------------------------------------------------------------------
 def retinexnet_forward(sd: dict, x: torch.Tensor) -> dict:
     R = "replicate"
@@ -159,7 +211,8 @@ def retinexnet_forward(sd: dict, x: torch.Tensor) -> dict:
 # ---- HINet -------------------------------------------------------------------------------------------------------
 def hinet_forward(sd: dict, x: torch.Tensor, depth: int = 5, relu_slope: float = 0.2, in_pos_left: int = 0, in_pos_right: int = 4) -> dict:
     """src/mon/vision/enhance/multitask/hinet/hinet.py:34-198, 322-362 with hinet.py:80's ``if enc and dec`` read as
-    ``enc is not None and dec is not None`` (as shipped it raises on tensors).  parity unpinned (mon not importable)."""
+    ``enc is not None and dec is not None`` (as shipped it raises on tensors; the original repository's hinet_arch.py:147 has
+    exactly that test).  Pinned by tests/golden/hinet_*.npz."""
     lr = lambda t: F.leaky_relu(t, relu_slope)
 
     def block(n, t, hin, down, enc=None, dec=None):

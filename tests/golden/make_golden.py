@@ -6,6 +6,8 @@ the pure-torch reference files
     src/mon_extra/vision/enhance/llie/zero_dce/model.py      (enhance_net_nopool)
     src/mon_extra/vision/enhance/llie/zero_dce++/model.py    (enhance_net_nopool, CSDN_Tem)
     src/mon_extra/vision/enhance/llie/llunet++/model.py      (NestedUNet)
+    src/mon_extra/vision/enhance/multitask/hinet/basicsr/models/archs/hinet_arch.py   (HINet)
+    src/mon_extra/vision/enhance/llie/zero_ig/model.py       (Enhancer, Denoise_1, Denoise_2, Finetunemodel.forward)
 loads seeded weights into them, runs their forward on CPU fp32 and stores
 inputs / weights / outputs as small fixtures.  The fixtures are data only; no
 reference source is copied.  Usage:  python tests/golden/make_golden.py
@@ -111,12 +113,80 @@ def gen_llunetpp():
     print("wrote", path, os.path.getsize(path) // 1024, "KiB | out range", float(y.min()), float(y.max()), "mean", float(y.mean()))
 
 
+def gen_hinet():
+    """HINet at reduced widths (wf = 8 and 16; the published wf = 64 has 88.7 M parameters): weights regenerated from the
+    seed by tests/helpers.seeded_state_dict, only input / both stage outputs travel."""
+    mod = _load("src/mon_extra/vision/enhance/multitask/hinet/basicsr/models/archs/hinet_arch.py", "ref_hinet_arch")
+    for wf, seed, (h, w) in ((8, 41, (32, 48)), (16, 42, (32, 32))):
+        net = mod.HINet(wf=wf)
+        shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+        sd = _seeded(shapes, seed=seed)
+        net.load_state_dict(sd, strict=True)
+        net.eval()
+        x = torch.rand(1, 3, h, w, generator=torch.Generator().manual_seed(seed + 100))
+        with torch.no_grad():
+            out_1, out_2 = net(x)
+        path = os.path.join(HERE, f"hinet_wf{wf}_seed{seed}_1x{h}x{w}.npz")
+        np.savez_compressed(path, image=x.numpy(), stage1=out_1.numpy(), enhanced=out_2.numpy(), seed=np.array(seed), wf=np.array(wf),
+                            key_order=np.array(list(shapes.keys())), key_shapes=np.array([str(s) for s in shapes.values()]))
+        print("wrote", path, os.path.getsize(path) // 1024, "KiB | params", sum(v.numel() for v in sd.values()),
+              "| out range", float(out_2.min()), float(out_2.max()))
+
+
+def gen_zero_ig():
+    """Zero-IG: the reference's Enhancer / Denoise_1 / Denoise_2 and the predicting forward (Finetunemodel.forward ==
+    mon's ZeroIG.forward predicting branch, zero_ig.py:434-452).  Finetunemodel.__init__ wants a checkpoint file mapped to
+    cuda:0, so the object is assembled from the reference's own sub-modules and its own forward() is called on it."""
+    zdir = os.path.join(REF, "src/mon_extra/vision/enhance/llie/zero_ig")
+    sys.path.insert(0, zdir)
+    try:
+        mod = _load("src/mon_extra/vision/enhance/llie/zero_ig/model.py", "ref_zero_ig")
+    finally:
+        sys.path.remove(zdir)
+    net = mod.Finetunemodel.__new__(mod.Finetunemodel)
+    torch.nn.Module.__init__(net)
+    net.enhance, net.denoise_1, net.denoise_2 = mod.Enhancer(layers=3, channels=64), mod.Denoise_1(chan_embed=48), mod.Denoise_2(chan_embed=48)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    g = torch.Generator().manual_seed(51)
+    sd = _seeded({k: s for k, s in shapes.items() if len(s) > 0}, seed=51)
+    for k in shapes:                                     # BatchNorm entries: a valid, non-trivial eval-mode state
+        if k.endswith("running_var"):
+            sd[k] = torch.rand(shapes[k], generator=g) + 0.5
+        elif k.endswith("running_mean"):
+            sd[k] = torch.randn(shapes[k], generator=g) * 0.1
+        elif k.endswith("num_batches_tracked"):
+            sd[k] = torch.tensor(0)
+        elif k.endswith(".1.weight") and len(shapes[k]) == 1:
+            sd[k] = 1.0 + torch.randn(shapes[k], generator=g) * 0.1
+    net.load_state_dict(sd, strict=True)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}   # enhance.conv.* and enhance.blocks.i.* alias ONE module: keep what it holds
+    net.eval()
+    x = torch.rand(2, 3, 40, 56, generator=torch.Generator().manual_seed(52)) ** 2.2 * 0.4
+    xe = torch.rand(1, 3, 24, 40, generator=torch.Generator().manual_seed(53))
+    with torch.no_grad():
+        h2, h3 = net(x)
+        s = net.enhance(xe)
+        d1 = net.denoise_1(xe)
+        d2 = net.denoise_2(torch.cat([xe, xe.flip(1)], 1))
+    out = {f"w.{k}": v.numpy() for k, v in sd.items() if not k.endswith("num_batches_tracked")}
+    out.update(image=x.numpy(), enhanced=h2.numpy(), denoise=h3.numpy(), enhancer_in=xe.numpy(), enhancer_out=s.numpy(),
+               denoise1_out=d1.numpy(), denoise2_out=d2.numpy())
+    path = os.path.join(HERE, "zero_ig_seed51_2x40x56.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB | enhanced range", float(h2.min()), float(h2.max()), "mean", float(h2.mean()),
+          "| denoise mean", float(h3.mean()))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["zero_dce", "zero_dcepp", "llunetpp"]
+    which = sys.argv[1:] or ["zero_dce", "zero_dcepp", "llunetpp", "hinet", "zero_ig"]
     if "zero_dce" in which:
         gen_zero_dce()
     if "zero_dcepp" in which:
         gen_zero_dcepp()
     if "llunetpp" in which:
         gen_llunetpp()
+    if "hinet" in which:
+        gen_hinet()
+    if "zero_ig" in which:
+        gen_zero_ig()

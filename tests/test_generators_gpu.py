@@ -84,6 +84,71 @@ def test_zero_ig_enhance_vs_oracle():
     assert rel_err(out, ref) <= TOL and float(out.min()) >= 0.99e-4 and float(out.max()) <= 1.0
 
 
+def _zero_ig_golden():
+    g = np.load(os.path.join(GOLDEN, "zero_ig_seed51_2x40x56.npz"))
+    return g, {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w.")}
+
+
+@pytest.mark.parametrize("dt,tol", [("f32", TOL), ("f16", 2e-3), ("bf16", 1.5e-2)])
+def test_zero_ig_golden(dt, tol):
+    """zero_ig_re (Denoise1 -> Enhance -> H2 = image / s2 -> Denoise2) and the Enhance block alone against outputs of the
+    reference's own Finetunemodel.forward / Enhancer (tests/golden/make_golden.py); checkpoint in the original key spelling."""
+    g, sd = _zero_ig_golden()
+    m = mon_amd.MODELS.build(name="zero_ig_re", weights=dict(sd), compute_dtype=dt).to("cuda")
+    out = m.forward({"image": torch.from_numpy(g["image"]).cuda()})
+    assert list(out.keys()) == ["denoise", "enhanced"]
+    assert rel_err(out["enhanced"].cpu(), g["enhanced"]) <= tol
+    assert rel_err(out["denoise"].cpu(), g["denoise"]) <= tol
+    e = mon_amd.MODELS.build(name="zero_ig_enhance", weights={k[8:]: v for k, v in m.state_dict().items() if k.startswith("enhance.")},
+                             compute_dtype=dt).to("cuda")
+    assert rel_err(e.forward({"image": torch.from_numpy(g["enhancer_in"]).cuda()})["enhanced"].cpu(), g["enhancer_out"]) <= tol
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "hinet_*.npz"))), ids=lambda p: os.path.basename(p)[6:-4])
+def test_hinet_golden(path):
+    """hinet_re against both stage outputs of the reference's hinet_arch.HINet (weights regenerated from the seed)."""
+    g = np.load(path)
+    shapes = {str(k): ast.literal_eval(str(s)) for k, s in zip(g["key_order"], g["key_shapes"])}
+    m = mon_amd.MODELS.build(name="hinet_re", num_channels=int(g["wf"]), weights=seeded_state_dict(shapes, int(g["seed"]))).to("cuda")
+    out = m.forward({"image": torch.from_numpy(g["image"]).cuda()})
+    assert rel_err(out["stage1"].cpu(), g["stage1"]) <= TOL and rel_err(out["enhanced"].cpu(), g["enhanced"]) <= TOL
+    if int(g["wf"]) % 16 == 0:                 # the matrix-core path of the same graph
+        for dt, tol in (("f16", 2e-3), ("bf16", 1.5e-2)):
+            m16 = mon_amd.MODELS.build(name="hinet_re", num_channels=int(g["wf"]), weights=m.state_dict(), compute_dtype=dt).to("cuda")
+            o16 = m16.forward({"image": torch.from_numpy(g["image"]).cuda()})
+            assert rel_err(o16["enhanced"].cpu(), g["enhanced"]) <= tol, dt
+
+
+@pytest.mark.parametrize("dt,tol", [("f32", TOL), ("f16", 2e-3), ("bf16", 1.5e-2)])
+def test_rrdnet_and_zsn2n_vs_oracle(dt, tol):
+    x = torch.rand(2, 3, 37, 53, generator=torch.Generator().manual_seed(9)) * 0.6 + 0.05
+    m = mon_amd.MODELS.build(name="rrdnet_re", seed=11, compute_dtype=dt).to("cuda")
+    out, ref = m.forward({"image": x.cuda()}), og.rrdnet_forward(m.state_dict(), x, 0.4)
+    assert list(out.keys()) == ["image", "illumination", "reflectance", "noise", "enhanced"]
+    for k in ("illumination", "reflectance", "noise", "enhanced"):
+        assert tuple(out[k].shape) == tuple(ref[k].shape) and rel_err(out[k].cpu(), ref[k]) <= tol, k
+    assert torch.equal(out["image"].cpu(), x)
+    for predicting in (True, False):
+        z = mon_amd.MODELS.build(name="zsn2n", seed=12, compute_dtype=dt, predicting=predicting).to("cuda")
+        sd = {k: v * (3.0 if k.endswith("weight") else 1.0) for k, v in z.state_dict().items()}     # make the clamp bite
+        z.load_state_dict(sd)
+        got, want = z.forward({"image": x.cuda()})["enhanced"].cpu(), og.zsn2n_forward(sd, x, predicting)["enhanced"]
+        assert rel_err(got, want) <= tol, predicting
+    assert mon_amd.MODELS.build(name="zsn2n", seed=1).params == 48 * 27 + 48 + 48 * 48 * 9 + 48 + 3 * 48 + 3
+
+
+def test_new_eltwise_ops_against_torch():
+    g = torch.Generator().manual_seed(3)
+    a, b = torch.rand(2, 3, 9, 11, generator=g) + 0.1, torch.rand(2, 3, 9, 11, generator=g) + 0.2
+    one = torch.rand(2, 1, 9, 11, generator=g) + 0.3
+    an, bn, on = ops.to_nhwc(a.cuda()), ops.to_nhwc(b.cuda()), ops.to_nhwc(one.cuda())
+    assert torch.equal(ops.to_nchw(ops.sub(an, bn)).cpu(), a - b)
+    assert torch.equal(ops.to_nchw(ops.div_clamp(an, bn, 0.5, 2.0)).cpu(), (a / b).clamp(0.5, 2.0))
+    assert torch.equal(ops.to_nchw(ops.div_clamp(an, on)).cpu(), a / one)
+    assert torch.equal(ops.to_nchw(ops.affine(an, 1.0, 1e-4)).cpu(), a + 1e-4)
+    assert rel_err(ops.to_nchw(ops.pow_scalar(an, 0.4)).cpu(), a.pow(0.4)) <= 1e-6
+
+
 @pytest.mark.parametrize("hw", [(40, 56), (45, 67)])
 def test_retinexnet_vs_oracle(hw):
     m = mon_amd.MODELS.build(name="retinexnet", seed=6).to("cuda")

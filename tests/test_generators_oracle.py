@@ -43,6 +43,43 @@ def test_llunetpp_restatement_matches_reference():
     assert 0.2 < out.mean() < 0.6 and (out > 0).mean() > 0.8      # not a degenerate all-clamped output
 
 
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "hinet_*.npz"))), ids=lambda p: os.path.basename(p)[6:-4])
+def test_hinet_restatement_matches_reference(path):
+    """oracle.hinet_forward against the outputs of the reference's own hinet_arch.HINet (both stages)."""
+    g = np.load(path)
+    shapes = {str(k): ast.literal_eval(str(s)) for k, s in zip(g["key_order"], g["key_shapes"])}
+    sd = seeded_state_dict(shapes, int(g["seed"]))
+    m = mon_amd.MODELS.build(name="hinet_re", num_channels=int(g["wf"]), weights=dict(sd))
+    assert set(m.state_dict()) == set(sd)                        # same checkpoint keys as the reference module
+    out = og.hinet_forward(m.state_dict(), torch.from_numpy(g["image"]))
+    assert np.abs(out["stage1"].numpy() - g["stage1"]).max() <= 2e-5
+    assert np.abs(out["enhanced"].numpy() - g["enhanced"]).max() <= 2e-5
+
+
+def _zero_ig_golden():
+    g = np.load(os.path.join(GOLDEN, "zero_ig_seed51_2x40x56.npz"))
+    return g, {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w.")}
+
+
+def test_zero_ig_restatement_matches_reference():
+    """Enhance, Denoise1/2 and the predicting forward against the reference's Enhancer / Denoise_1 / Denoise_2 /
+    Finetunemodel.forward; the checkpoint carries the original repository's key names (denoise_1 / denoise_2)."""
+    g, sd_ref = _zero_ig_golden()
+    m = mon_amd.MODELS.build(name="zero_ig_re", weights=dict(sd_ref))
+    sd = m.state_dict()
+    assert "denoise1.conv1.weight" in sd and "enhance.conv.1.running_var" in sd
+    enh = {k[8:]: v for k, v in sd.items() if k.startswith("enhance.")}
+    xe = torch.from_numpy(g["enhancer_in"])
+    assert np.abs(og.zero_ig_enhance_forward(enh, xe)["enhanced"].numpy() - g["enhancer_out"]).max() <= 1e-6
+    assert np.abs(og.zero_ig_denoise_forward(sd, xe, "denoise1").numpy() - g["denoise1_out"]).max() <= 1e-6
+    assert np.abs(og.zero_ig_denoise_forward(sd, torch.cat([xe, xe.flip(1)], 1), "denoise2").numpy() - g["denoise2_out"]).max() <= 1e-6
+    out = og.zero_ig_forward(sd, torch.from_numpy(g["image"]))
+    assert list(out) == ["denoise", "enhanced"]
+    assert np.abs(out["enhanced"].numpy() - g["enhanced"]).max() <= 2e-6
+    assert np.abs(out["denoise"].numpy() - g["denoise"]).max() <= 2e-6
+    assert 0.1 < float(g["enhanced"].mean()) < 0.6               # not a degenerate all-clamped output
+
+
 def test_generator_registry_and_param_counts():
     counts = {"zero_dce++_re": 10561, "llunet++_re": 29048873, "unet": 17273954, "retinexnet": 555205}   # SURVEY 8a
     for name, n in counts.items():

@@ -4,9 +4,11 @@ the CPU oracle on seeded inputs, and size-independent properties at 1080p.
 Tolerances (max |a-b| / max |b|, the 'relative fp32' measure of the north star):
     f32  (VALU parity mode)        <= 1e-4 on every tensor      (bound asked: 1e-3)
     f16  (MFMA, fp32 accumulate)   <= 1e-3 on `enhanced`; features <= 2e-3
-    bf16 (MFMA, fp32 accumulate)   <= 2e-2 on `enhanced`, PSNR >= 45 dB (storage rounding 2^-9)
+    bf16 (MFMA, fp32 accumulate)   <= 1e-3 on `enhanced`: the "bf16" schedule keeps the tensors that carry the rounding
+                                   error (x1, x2, x6, P and their weights) in fp16 (tools/bf16_attrib.py)
+    bf16_pure (every tensor bf16)  <= 2e-2 on `enhanced`, PSNR >= 45 dB (storage rounding 2^-9; weights alone cost 1.3e-3)
 uint8 (save_image rule): f32 mode must differ from the reference in <= 0.1 % of bytes and by at
-most 1 LSB (an fp32 reordering can flip x*255+0.5 across an integer); f16/bf16 <= 1 / 2 LSB.
+most 1 LSB (an fp32 reordering can flip x*255+0.5 across an integer); f16/bf16 <= 1, bf16_pure <= 2 LSB.
 """
 import os
 
@@ -21,16 +23,27 @@ from tests.helpers import load_golden, psnr, rel_err, zero_dce_goldens
 
 pytestmark = pytest.mark.gpu
 
-TOL_ENH = {"f32": 1e-4, "f16": 1e-3, "bf16": 2e-2}
-TOL_FEAT = {"f32": 1e-4, "f16": 2e-3, "bf16": 2e-2}
-U8_MAXDIFF = {"f32": 1, "f16": 1, "bf16": 2}
+TOL_ENH = {"f32": 1e-4, "f16": 1e-3, "bf16": 1e-3, "bf16_pure": 2e-2}
+# The two gain-4 low-light goldens (|enhanced| <= 0.5, activations that do not shrink from layer to layer) are the one place
+# where the "bf16" schedule is held to a looser bound: on them EVERY single tensor rounded to bf16 -- any one of x1..x6, P or
+# one layer's weights, everything else exact -- already costs 0.4e-3 .. 2.1e-3 (fp16: 0.05e-3 .. 0.37e-3; all-fp16 5.6e-4;
+# tools/bf16_attrib.py --golden), so no schedule with a bf16 MFMA operand can meet 1e-3 there.  compute_dtype "f16" is the
+# 16-bit mode that holds 1e-3 on every golden; "bf16" holds it on the benchmarked workload and everything else below.
+TOL_BF16_GAIN4_LOWLIGHT = 5e-3
+TOL_FEAT = {"f32": 1e-4, "f16": 2e-3, "bf16": 2e-2, "bf16_pure": 2e-2}
+U8_MAXDIFF = {"f32": 1, "f16": 1, "bf16": 1, "bf16_pure": 2}
+
+
+def _tol(path, dtype):
+    hard = dtype == "bf16" and ("trained_lowlight" in path or "trained_sample" in path)
+    return TOL_BF16_GAIN4_LOWLIGHT if hard else TOL_ENH[dtype]
 
 
 def _model(sd, dtype, variant=0):
     return mon_amd.MODELS.build(name="zero_dce_re", weights=dict(sd), compute_dtype=dtype, variant=variant).to("cuda").eval()
 
 
-@pytest.mark.parametrize("dtype", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "f16", "bf16", "bf16_pure"])
 @pytest.mark.parametrize("path", zero_dce_goldens(), ids=lambda p: p.split("zero_dce_")[-1][:-4])
 def test_golden_parity(path, dtype):
     sd, g = load_golden(path)
@@ -40,8 +53,9 @@ def test_golden_parity(path, dtype):
     assert list(out.keys())[-1] == "enhanced" and "adjust_7" in out
     assert out["adjust_3"].data_ptr() == out["adjust"][:, 9:12].data_ptr()
     enh, adj = out["enhanced"].cpu(), out["adjust"].cpu()
-    assert rel_err(enh, g["enhanced"]) <= TOL_ENH[dtype]
-    assert rel_err(adj, g["adjust"]) <= max(TOL_ENH[dtype], 5 * TOL_ENH[dtype] * (dtype != "f32"))
+    tol = _tol(path, dtype)
+    assert rel_err(enh, g["enhanced"]) <= tol
+    assert rel_err(adj, g["adjust"]) <= max(tol, 5 * tol * (dtype != "f32"))
     u8 = m.enhance(x, want_enhanced=False, want_u8=True)["u8"].cpu().numpy()
     d = np.abs(u8.astype(int) - g["enhanced_u8"].astype(int))
     assert d.max() <= U8_MAXDIFF[dtype]
@@ -53,7 +67,7 @@ def test_golden_parity(path, dtype):
 
 
 @pytest.mark.parametrize("variant", [0, capi.VAR_UNFUSED])
-@pytest.mark.parametrize("dtype", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "f16", "bf16", "bf16_pure"])
 def test_feature_parity_per_layer(dtype, variant):
     """x1..x6 against the oracle.  The fused schedule keeps x1, x4 and x6 in LDS only (x1's HBM slot holds
     P = W7a*x1 + bias7 instead), so those are checked on the one-kernel-per-layer schedule."""
@@ -68,20 +82,20 @@ def test_feature_parity_per_layer(dtype, variant):
         assert rel_err(f, ref[k - 1]) <= TOL_FEAT[dtype], f"x{k}"
 
 
-@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("dtype", ["f16", "bf16", "bf16_pure"])
 @pytest.mark.parametrize("path", zero_dce_goldens(), ids=lambda p: p.split("zero_dce_")[-1][:-4])
 def test_unfused_schedule_golden_parity(path, dtype):
     """The one-kernel-per-layer schedule (IE_ZDCE_VAR_UNFUSED) meets the same bounds as the fused one."""
     sd, g = load_golden(path)
     out = _model(sd, dtype, capi.VAR_UNFUSED).forward({"image": torch.from_numpy(g["image"]).cuda()})
-    assert rel_err(out["enhanced"].cpu(), g["enhanced"]) <= TOL_ENH[dtype]
-    assert rel_err(out["adjust"].cpu(), g["adjust"]) <= 5 * TOL_ENH[dtype]
+    assert rel_err(out["enhanced"].cpu(), g["enhanced"]) <= _tol(path, dtype)
+    assert rel_err(out["adjust"].cpu(), g["adjust"]) <= 5 * _tol(path, dtype)
 
 
 @pytest.mark.parametrize("base", [0, capi.VAR_UNFUSED])
 @pytest.mark.parametrize("variant", [capi.VAR_SYNC_STAGE, capi.VAR_NARROW_STORE, capi.VAR_NO_DMA,
                                      capi.VAR_NO_DMA | capi.VAR_NARROW_STORE])
-@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("dtype", ["f16", "bf16", "bf16_pure"])
 def test_kernel_variants_bit_identical(variant, dtype, base):
     """LDS-DMA vs register staging, counted vs drained waits, wide vs narrow stores: same bits
     (on both the fused and the one-kernel-per-layer schedule)."""
@@ -105,7 +119,7 @@ def test_ragged_and_tiny_shapes(shape, dtype):
     assert rel_err(out["adjust"].cpu(), ref["adjust"]) <= 5 * TOL_ENH[dtype]
 
 
-@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+@pytest.mark.parametrize("dtype", ["f16", "bf16", "bf16_pure"])
 def test_schedule_invariance(dtype):
     """rows-per-workgroup / band / frame-group choices change the launch geometry only: bit-identical."""
     sd = o_zdce.init_state_dict(seed=12, gain=3.0)
@@ -124,10 +138,10 @@ def test_oracle_parity_512_config1():
     sd = o_zdce.init_state_dict(seed=1, gain=3.0)
     x = torch.rand(1, 3, 512, 512, generator=torch.Generator().manual_seed(0)) ** 2.2 * 0.25
     ref = o_zdce.forward(sd, x)["enhanced"]
-    for dtype in ("f32", "f16", "bf16"):
+    for dtype in ("f32", "f16", "bf16", "bf16_pure"):
         out = _model(sd, dtype).enhance(x.cuda())["enhanced"].cpu()
         assert rel_err(out, ref) <= TOL_ENH[dtype], dtype
-        if dtype == "bf16":
+        if dtype == "bf16_pure":
             assert psnr(out, ref) >= 45.0
 
 
@@ -151,6 +165,19 @@ def test_1080p_properties():
     z = {k: torch.zeros_like(v) for k, v in sd.items()}
     ident = _model(z, "bf16").enhance(x[:1])["enhanced"]
     assert torch.equal(ident, x[:1])
+
+
+def test_1080p_bf16_meets_the_parity_bound():
+    """BASELINE configs[1]'s frame size and weights rule, the benchmarked "bf16" schedule against the CPU fp32 oracle:
+    <= 1e-3 of max|ref| and at most 1 LSB in the save_image uint8 (the bound bench.py's `parity` reports)."""
+    sd = o_zdce.init_state_dict(seed=1, gain=3.0)
+    x = torch.rand(1, 3, 1080, 1920, generator=torch.Generator().manual_seed(1234))
+    torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 32)))
+    ref = o_zdce.forward(sd, x)["enhanced"]
+    got = _model(sd, "bf16").enhance(x.cuda(), want_enhanced=True, want_u8=True)
+    assert rel_err(got["enhanced"].cpu(), ref) <= 1e-3
+    d = (got["u8"].cpu().int() - o_zdce.to_uint8_save_image(ref).int()).abs()
+    assert int(d.max()) <= 1 and float((d == 0).float().mean()) >= 0.97
 
 
 def test_infer_resizes_to_multiple_of_32_and_back():
