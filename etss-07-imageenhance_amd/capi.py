@@ -19,7 +19,7 @@ DTYPES = {"f32": IE_F32, "fp32": IE_F32, "float32": IE_F32, "f16": IE_F16, "fp16
 ACT = {"none": 0, "relu": 1, "lrelu": 2, "tanh": 3, "sigmoid": 4}
 PAD = {"zeros": 0, "replicate": 1}
 SUMSQ_WS_DOUBLES = 2048
-VAR_SYNC_STAGE, VAR_NARROW_STORE, VAR_NO_DMA, VAR_UNFUSED, VAR_PURE_BF16 = 1, 2, 4, 8, 16
+VAR_SYNC_STAGE, VAR_NARROW_STORE, VAR_NO_DMA, VAR_UNFUSED, VAR_PURE_BF16, VAR_NO_K345 = 1, 2, 4, 8, 16, 32
 
 # every exported symbol of include/ie_hip.h (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
@@ -33,7 +33,7 @@ SYMBOLS = [
     "ie_mconv_packed_bytes", "ie_mconv_pack_weights", "ie_mconv_pack_weights_dev", "ie_mconv_nhwc", "ie_dsconv_nhwc",
     "ie_norm_forward_nhwc_f32", "ie_norm_backward_nhwc_f32", "ie_convn_wgrad_nhwc_f32", "ie_convn_dgrad_nhwc_f32",
     "ie_maxpool2x2_backward_nhwc_f32", "ie_resize_backward_nhwc_f32", "ie_crop_nhwc_f32", "ie_pixel_unshuffle_nhwc_f32",
-    "ie_act_backward_f32", "ie_act_backward", "ie_pixel_unshuffle_nhwc", "ie_l1_loss_f32", "ie_ssim_forward_f32", "ie_ssim_backward_f32", "ie_sumsq_f32", "ie_adam_step_f32",
+    "ie_act_backward_f32", "ie_act_backward", "ie_pixel_unshuffle_nhwc", "ie_l1_loss_f32", "ie_ssim_forward_f32", "ie_ssim_backward_f32", "ie_sumsq_f32", "ie_adam_step_f32", "ie_adam_step_counted_f32",
     "ie_norm_forward_nhwc", "ie_norm_backward_nhwc", "ie_convn_wgrad_nhwc", "ie_maxpool2x2_backward_nhwc", "ie_resize_backward_nhwc", "ie_crop_nhwc",
     "ie_zref_workspace_floats", "ie_zref_image_losses_f32", "ie_tv_loss_nhwc_f32", "ie_le_curve_backward",
     "ie_zdce_create", "ie_zdce_set_layer", "ie_zdce_finalize", "ie_zdce_reserve", "ie_zdce_forward",
@@ -136,6 +136,7 @@ def lib():
     L.ie_ssim_backward_f32.argtypes = [vp, vp, vp, vp, vp, ip, ip, ip, ip, i64, i64, i64, i64, fp, fp, ip, ip, vp]
     L.ie_sumsq_f32.argtypes = [vp, sz, fp, vp, vp, ip, vp]
     L.ie_adam_step_f32.argtypes = [vp, vp, vp, vp, sz, ip, fp, fp, fp, fp, fp, fp, vp, fp, vp]
+    L.ie_adam_step_counted_f32.argtypes = [vp, vp, vp, vp, sz, vp, fp, fp, fp, fp, fp, fp, vp, fp, vp]
     L.ie_norm_forward_nhwc.argtypes = [vp, vp, vp, vp, ip, vp, vp, vp, vp, vp, fp, ip, ip, ip, ip, ip, ip, ip, fp, ip, fp, vp]
     L.ie_norm_backward_nhwc.argtypes = [vp, vp, vp, ip, vp, vp, vp, vp, vp, vp, vp, ip, ip, ip, ip, ip, ip, ip, ip, ip, fp, vp]
     L.ie_convn_wgrad_nhwc.argtypes = [C.POINTER(ConvNDesc), C.POINTER(vp), C.POINTER(ip), vp, ip, vp, vp, ip, vp, vp]

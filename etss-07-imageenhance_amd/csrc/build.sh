@@ -10,10 +10,22 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno
 KEY=$(printf '%s' "$FLAGS" | md5sum | cut -c1-10)
 OBJ=_obj/$KEY
 mkdir -p "$OBJ"
-HDR_STAMP=$(cat ie_*.h | md5sum | cut -c1-16)
+# signature of the headers a source includes (transitively, csrc/ie_*.h and the public ABI header)
+hdr_sig() {
+    local seen="" todo="$1" f inc
+    while [ -n "$todo" ]; do
+        set -- $todo; f=$1; shift; todo="$*"
+        case " $seen " in *" $f "*) continue;; esac
+        seen="$seen $f"
+        for inc in $(grep -o '#include "[^"]*"' "$f" | sed 's/#include "//; s/"//'); do
+            [ -f "$inc" ] && todo="$todo $inc"
+        done
+    done
+    cat $seen | md5sum | cut -c1-16
+}
 todo=""
 for s in $SRCS; do
-    sig="$(md5sum < "$s" | cut -c1-16)-$HDR_STAMP"
+    sig="$(hdr_sig "$s")"
     if [ ! -f "$OBJ/$s.o" ] || [ "$(cat "$OBJ/$s.sig" 2>/dev/null)" != "$sig" ]; then
         todo="$todo $s"; rm -f "$OBJ/$s.sig"; echo "$sig" > "$OBJ/$s.sig.new"   # the signature of what is compiled NOW (edits during the build re-trigger)
     fi

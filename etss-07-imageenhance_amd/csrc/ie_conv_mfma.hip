@@ -466,13 +466,23 @@ __device__ __forceinline__ void mconv3_epilogue(const MConvParams& p, ie_f32x4 (
             const unsigned lane_off = (unsigned)((l16 * p.Cout + co) * (int)sizeof(T));
             const unsigned row_b = (unsigned)p.Ws * (unsigned)p.Cout * (unsigned)sizeof(T), half_b = 16u * (unsigned)p.Cout * (unsigned)sizeof(T);
             const ie_f32x2 b01 = {bv[0], bv[1]}, b23 = {bv[2], bv[3]};
+            // the two column halves of a row are stored by ONE instruction: lanes kc / kc+1 exchange halves (v_permlane16_swap), so
+            // even-kc lanes hold couts 4kc..4kc+7 of the left-half pixel and odd-kc lanes couts 4(kc-1)..+7 of the right-half pixel:
+            // 16 bytes per lane, half the store instructions (the epilogue is store-ISSUE-bound: 32 -> 16 per wave and tile)
+            const unsigned lane_off16 = (unsigned)(((l16 + 16 * (kc & 1)) * p.Cout + co0 + 4 * (kc & 2)) * (int)sizeof(T));
+            (void)half_b; (void)lane_off;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const ie_f32x2 v01 = ie_f32x2{acc[t][0], acc[t][1]} + b01, v23 = ie_f32x2{acc[t][2], acc[t][3]} + b23;
-                ie_u32x2 o;
-                if constexpr (ACT == IE_ACT_RELU) o = ie_u32x2{ie_pack2_relu<T>(v01[0], v01[1]), ie_pack2_relu<T>(v23[0], v23[1])};
-                else o = ie_u32x2{ie_pack2<T>(v01[0], v01[1]), ie_pack2<T>(v23[0], v23[1])};
-                *(ie_u32x2*)(const_cast<char*>(tile) + ((unsigned)(t >> 1) * row_b + (unsigned)(t & 1) * half_b) + lane_off) = o;
+            for (int t = 0; t < NT; t += 2) {
+                ie_u32x2 o[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const ie_f32x2 v01 = ie_f32x2{acc[t + h][0], acc[t + h][1]} + b01, v23 = ie_f32x2{acc[t + h][2], acc[t + h][3]} + b23;
+                    if constexpr (ACT == IE_ACT_RELU) o[h] = ie_u32x2{ie_pack2_relu<T>(v01[0], v01[1]), ie_pack2_relu<T>(v23[0], v23[1])};
+                    else o[h] = ie_u32x2{ie_pack2<T>(v01[0], v01[1]), ie_pack2<T>(v23[0], v23[1])};
+                }
+                const auto sx = __builtin_amdgcn_permlane16_swap(o[0][0], o[1][0], false, false);
+                const auto sy = __builtin_amdgcn_permlane16_swap(o[0][1], o[1][1], false, false);
+                *(ie_u32x4*)(const_cast<char*>(tile) + (unsigned)(t >> 1) * row_b + lane_off16) = ie_u32x4{sx[0], sy[0], sx[1], sy[1]};
             }
             return;
         }

@@ -592,6 +592,36 @@ __global__ void adam_kernel(float* __restrict__ param, const float* __restrict__
     param[i] = w - (lr / bc1) * (mi / denom);
 }
 
+// Step counter kept on the device (GradScaler semantics without a host sync): state = {int step, int applied, float bc1,
+// float bc2_sqrt}.  A step whose gradient norm is not finite is not applied and does not advance the counter, so Adam's bias
+// correction and the checkpointed global_step count the updates that really happened.
+__global__ void adam_prepare_kernel(int* __restrict__ state, const double* __restrict__ sumsq, float b1, float b2) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const bool ok = !sumsq || (*sumsq < (double)INFINITY);
+    int t = state[0];
+    if (ok) { t += 1; state[0] = t; }
+    state[1] = ok ? 1 : 0;
+    ((float*)state)[2] = (float)(1.0 - pow((double)b1, (double)t));
+    ((float*)state)[3] = (float)sqrt(1.0 - pow((double)b2, (double)t));
+}
+__global__ void adam_counted_kernel(float* __restrict__ param, const float* __restrict__ grad, float* __restrict__ m, float* __restrict__ v,
+                                    const double* __restrict__ sumsq, const int* __restrict__ state, float grad_scale, float max_norm,
+                                    float lr, float b1, float b2, float eps, float wd, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total || state[1] == 0) return;
+    const float bc1 = ((const float*)state)[2], bc2_sqrt = ((const float*)state)[3];
+    float coef = 1.f;
+    if (sumsq && max_norm > 0.f) coef = fminf(1.f, max_norm / ((float)sqrt(*sumsq) + 1e-6f));
+    float g = grad[i] * grad_scale * coef;
+    const float w = param[i];
+    if (wd != 0.f) g = fmaf(wd, w, g);
+    const float mi = b1 * m[i] + (1.f - b1) * g;
+    const float vi = b2 * v[i] + (1.f - b2) * g * g;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    param[i] = w - (lr / bc1) * (mi / denom);
+}
+
 }  // namespace
 
 // ---- entry points ----------------------------------------------------------------------------------------------------
@@ -937,6 +967,19 @@ IE_EXPORT int ie_adam_step_f32(float* param, const float* grad, float* exp_avg, 
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     hipLaunchKernelGGL(adam_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, sumsq_dev,
                        grad_scale, max_norm, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), n);
+    IE_LAUNCH_CHECK();
+    return IE_OK;
+}
+
+IE_EXPORT int ie_adam_step_counted_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, int* state_dev, float lr,
+                                       float beta1, float beta2, float eps, float weight_decay, float grad_scale, const double* sumsq_dev,
+                                       float max_norm, void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !state_dev || n == 0) IE_FAIL(IE_ERR_INVALID, "ie_adam_step_counted_f32: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(64), 0, st, state_dev, sumsq_dev, beta1, beta2);
+    IE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(adam_counted_kernel, dim3(nblk(n)), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, sumsq_dev, state_dev,
+                       grad_scale, max_norm, lr, beta1, beta2, eps, weight_decay, n);
     IE_LAUNCH_CHECK();
     return IE_OK;
 }

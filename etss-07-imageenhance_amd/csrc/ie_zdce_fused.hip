@@ -5,6 +5,9 @@
 //        (e_conv7([x1,x6]) = W7a*x1 + W7b*x6: P = W7a*x1 + bias7 is computed where x1 lives and replaces x1 in HBM,
 //         which halves stage B of K67 -- the busiest kernel -- and uses MFMA slots K12, a write-bound kernel, has free)
 //   K45: e_conv4 (x3 -> x4, LDS only) + e_conv5 ([x3,x4] -> x5)       64+64    = 128 B/px (was 320)
+//   K345: e_conv3 + e_conv4 on stage A (x2 -> x3 -> x4, both LDS only; 72 MFMAs per wave and row) + e_conv5 on stage B
+//        (72 MFMAs): x3 never reaches HBM and the two stages are balanced.  64+64 = 128 B/px for three layers (conv3 + K45: 256).
+//        Two hand-offs cost two halo columns a side: 124 of the 128 computed columns are stored.
 //   K67: e_conv6 ([x2,x5] -> x6, LDS only) + e_conv7 (P + W7b*x6) + curve  192+12+12 = 216 B/px (was 344)
 //
 // Reference semantics: src/mon/vision/enhance/llie/zero_dce/zero_dce.py:173-191.
@@ -34,7 +37,7 @@ constexpr unsigned OOB = 0x80000000u;
 #endif
 constexpr int PF_DEFAULT = IE_PF; // rows of DMA issued ahead (K67 is LDS-limited to 3)
 
-enum { K12 = 12, K45 = 45, K67 = 67 };
+enum { K12 = 12, K45 = 45, K67 = 67, K345 = 345 };
 
 struct FusedParams {
     const void* a_src0;  // stage A HBM source 0 (NHWC T)            K45: x3, K67: x2
@@ -42,6 +45,7 @@ struct FusedParams {
     const void* b_src;   // stage B HBM source with its own ring     K67: P (accumulator seed of e_conv7)
     const float* img;    // NCHW fp32 image                          K12 (A input), K67 (curve)
     const void* a_w; const float* a_bias;
+    const void* a2_w; const float* a2_bias;   // K345: e_conv4 (stage A's second layer)
     const void* b_w; const float* b_bias;
     const float* b2_bias; // K12: e_conv7's bias (folded into P)
     void* a_dst;         // K12: P = W7a*x1 + bias7 (NHWC T, 32 ch, 24 used)
@@ -77,32 +81,36 @@ template <typename T> struct ie_tag { using type = T; };
 // TH = the LDS hand-off (x1 / x4 / x6), stage B's weights on it and K67's P seed (K12: also e_conv1's operands);
 // TO = stage B's HBM outputs (K12: x2 and P, K45: x5).  They differ only in the "bf16" schedule of the plan,
 // which keeps the precision-critical tensors x1, x2, x6 and P in fp16.
-template <typename TA0, typename TA1, typename TH, typename TO, int KIND>
+template <typename TA0, typename TA1, typename TH, typename TO, int KIND, typename T3 = TH>
 __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     using frag = ie_u32x4;
     constexpr int PF = (KIND == K67) ? 3 : PF_DEFAULT;
     constexpr int PXB = 32 * 2;                             // 64 B per pixel per tensor
     constexpr int ROW_B = ROW_PX * PXB;                     // one ring row of one tensor
-    constexpr int NSA = (KIND == K67) ? 2 : (KIND == K45 ? 1 : 0);   // stage A HBM sources (K12: image)
-    constexpr int NFB = (KIND == K45 || KIND == K12) ? 18 : 9;       // stage B weight fragments (K12: e_conv2 + e_conv7a)
-    constexpr int NW = (KIND == K67) ? 18 : NFB;                     // weight fragments held per wave (K12 stage A: 2, K67 stage A: 18)
+    constexpr int NSA = (KIND == K67) ? 2 : ((KIND == K45 || KIND == K345) ? 1 : 0);   // stage A HBM sources (K12: image)
+    constexpr int NFB = (KIND == K45 || KIND == K12 || KIND == K345) ? 18 : 9;         // stage B weight fragments (K12: e_conv2 + e_conv7a)
+    constexpr int NW = (KIND == K67) ? 18 : NFB;                     // weight fragments held per wave (K12 stage A: 2, K67 / K345 stage A: 18)
+    constexpr int MARG = (KIND == K345) ? 2 : 1;                     // computed columns lost per side (one per LDS hand-off)
+    constexpr int TSK = TW - 2 * MARG;                               // stored columns = strip pitch
     // ---- LDS carve ------------------------------------------------------------------------------
     constexpr int NRA = (KIND == K45) ? PF + 3 : PF + 1;    // slots of the A rings (K45: B re-reads x3 two rows later)
     constexpr int A_RING_B = NSA * NRA * ROW_B;
     constexpr int NRB = PF + 1;                             // K67: x1 ring of stage B
     constexpr int B_RING_B = (KIND == K67) ? NRB * ROW_B : 0;
+    constexpr int NR3 = 4;                                  // K345: x3 ring (written at step t, read by e_conv4 at t+1 and e_conv5 at t+3)
+    constexpr int R3_B = (KIND == K345) ? NR3 * ROW_B : 0;
     constexpr int RA_B = 2 * ROW_B;                         // A -> B hand-off ring (2 slots)
     constexpr int LAG_A = (KIND == K12) ? 1 : 0;            // K12: stage A runs one row later (image row conversion)
     constexpr int NRI = (KIND == K12) ? PF + 1 : PF + 3;    // fp32 image ring slots (K67: kept until the deferred curve)
     constexpr int IMG_SLOT_B = 2048;                        // 3 planes x 132 px fp32 (K12) / 3 x 128 (K67)
-    constexpr int IMG_B = (KIND == K45) ? 0 : NRI * IMG_SLOT_B;
+    constexpr int IMG_B = (KIND == K45 || KIND == K345) ? 0 : NRI * IMG_SLOT_B;
     constexpr int CV_PLANE_B = 1088;                        // K12: converted image row, [136 px][RGB0] 16-bit
     constexpr int CV_SLOT_B = 2 * CV_PLANE_B;               //      hi plane + lo plane
     constexpr int NRC = 4;
     constexpr int CV_B = (KIND == K12) ? NRC * CV_SLOT_B : 0;
     constexpr int STAGE_SLOT_B = 24 * TW * 4;               // K67: tanh(r) staging [24][128] fp32, double buffered
-    constexpr int OFF_BRING = A_RING_B, OFF_RA = OFF_BRING + B_RING_B, OFF_IMG = OFF_RA + RA_B, OFF_CV = OFF_IMG + IMG_B,
-                  OFF_STAGE = OFF_CV + CV_B;
+    constexpr int OFF_BRING = A_RING_B, OFF_R3 = OFF_BRING + B_RING_B, OFF_RA = OFF_R3 + R3_B, OFF_IMG = OFF_RA + RA_B,
+                  OFF_CV = OFF_IMG + IMG_B, OFF_STAGE = OFF_CV + CV_B;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -117,10 +125,11 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     const int strip = b % p.strips; b /= p.strips;
     const int chunk = b % p.chunks; b /= p.chunks;
     const int n = p.n_begin + b;
-    const int xc0 = strip * TS - 1;                         // image column of computed column 0
+    const int xc0 = strip * TSK - MARG;                     // image column of computed column 0
     const int ys = p.y_begin + chunk * p.rows_per_block;
     const int ye = min(ys + p.rows_per_block, p.y_end);
-    const int n_steps = (ye - ys) + 6 + LAG_A + (KIND == K67 ? 1 : 0);
+    const int n_steps = (ye - ys) + 6 + LAG_A + (KIND == K67 ? 1 : 0) + (KIND == K345 ? 4 : 0);
+    constexpr int A_ROW0 = (KIND == K345) ? 4 : 2;          // stage A's HBM input row at step t is ys - A_ROW0 + t
     const int H = p.H, W = p.W;
     const size_t plane = (size_t)H * W;
     const size_t frame_b = plane * PXB;
@@ -132,7 +141,7 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     const auto rsA0 = mk((const char*)(NSA >= 1 ? p.a_src0 : p.b_w) + (NSA >= 1 ? (size_t)n * frame_b : 0), frame_b);
     const auto rsA1 = mk((const char*)(NSA >= 2 ? p.a_src1 : p.b_w) + (NSA >= 2 ? (size_t)n * frame_b : 0), frame_b);
     const auto rsB = mk((const char*)(KIND == K67 ? p.b_src : p.b_w) + (KIND == K67 ? (size_t)n * frame_b : 0), frame_b);
-    const auto rsI = mk((const char*)(KIND != K45 ? (const void*)(p.img + (size_t)n * 3 * plane) : p.b_w), 3 * plane * 4);
+    const auto rsI = mk((const char*)((KIND != K45 && KIND != K345) ? (const void*)(p.img + (size_t)n * 3 * plane) : p.b_w), 3 * plane * 4);
     const auto rsDa = mk((char*)(KIND == K12 ? p.a_dst : (void*)p.b_w) + (KIND == K12 ? (size_t)n * frame_b : 0), frame_b);
     const auto rsDb = mk((char*)(KIND != K67 ? p.b_dst : (void*)p.b_w) + (KIND != K67 ? (size_t)n * frame_b : 0), frame_b);
 
@@ -143,6 +152,13 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
         const frag* wp = (const frag*)(stg ? p.b_w : p.a_w) + (size_t)ch * nfr * 64;
 #pragma unroll
         for (int f = 0; f < NW; ++f) wv[f] = wp[(f < nfr ? f : 0) * 64 + lane];
+        if constexpr (KIND == K345) {       // stage A: e_conv3 in wv[0..8], e_conv4 in wv[9..17]
+            if (stg == 0) {
+                const frag* wp2 = (const frag*)p.a2_w + (size_t)ch * 9 * 64;
+#pragma unroll
+                for (int f = 0; f < 9; ++f) wv[9 + f] = wp2[f * 64 + lane];
+            }
+        }
     }
     ie_f32x4 bias4, bias4p;
     {
@@ -150,7 +166,8 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) bias4[i] = (KIND == K67 && stg) ? 0.f : bp[16 * ch + 4 * kq + i];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) bias4p[i] = (KIND == K12) ? p.b2_bias[16 * ch + 4 * kq + i] : 0.f;
+        for (int i = 0; i < 4; ++i)
+            bias4p[i] = (KIND == K12) ? p.b2_bias[16 * ch + 4 * kq + i] : ((KIND == K345 && stg == 0) ? p.a2_bias[16 * ch + 4 * kq + i] : 0.f);
     }
 
     // ---- DMA geometry ------------------------------------------------------------------------------
@@ -187,6 +204,18 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
                                                          (int)off_, 0, 0, 0);                                          \
         }                                                                                                              \
     } while (0)
+    // Any body piece m (16 pixels, 1 KiB) from any wave: the swizzle term does not depend on m ((16m + l) >> 1 & 3 == (l >> 1) & 3),
+    // so piece m's per-lane source offset is piece 0's + 1024 m, valid while its column is inside the image.
+    const int pc_x = xc0 + (lane >> 2);
+    const int pc_off = pc_x * PXB + (((lane & 3) ^ ((lane >> 3) & 3)) << 4);
+#define IE_DMA_PIECE(RS, SLOT, M, ROWB, RMASK)                                                                          \
+    do {                                                                                                               \
+        const int m_ = (M);                                                                                            \
+        const bool ok_ = (unsigned)(pc_x + 16 * m_) < (unsigned)W;                                                     \
+        const unsigned off_ = (ok_ ? (ROWB) + (unsigned)(pc_off + 1024 * m_) : OOB) | (RMASK);                         \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (__attribute__((address_space(3))) void*)((SLOT) + m_ * 1024), 16, \
+                                                 (int)off_, 0, 0, 0);                                                  \
+    } while (0)
     // K12 image ring: element e = 64*(2*sw+j) + lane over [3 planes][132 px]; px <-> x = xc0 - 1 + px
     unsigned img12_off[2];
 #pragma unroll
@@ -207,8 +236,8 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     // issue the DMA for step `t` (this wave's stage only)
     auto issue = [&](int t) __attribute__((always_inline)) {
         if (stg == 0) {
-            if constexpr (NSA >= 1) IE_DMA_ROW(rsA0, smem + (t % NRA) * ROW_B, ys - 2 + t);
-            if constexpr (NSA >= 2) IE_DMA_ROW(rsA1, smem + NRA * ROW_B + (t % NRA) * ROW_B, ys - 2 + t);
+            if constexpr (NSA >= 1) IE_DMA_ROW(rsA0, smem + (t % NRA) * ROW_B, ys - A_ROW0 + t);
+            if constexpr (NSA >= 2) IE_DMA_ROW(rsA1, smem + NRA * ROW_B + (t % NRA) * ROW_B, ys - A_ROW0 + t);
             if constexpr (KIND == K12) {
                 const int y = ys - 2 + t;
                 const unsigned rmask = ((y >= 0) && (y < H)) ? 0u : OOB;
@@ -223,17 +252,37 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
             }
         } else {
             if constexpr (KIND == K67) {
-                IE_DMA_ROW(rsB, smem + OFF_BRING + (t % NRB) * ROW_B, ys - 3 + t);   // P row that seeds the row started at step t
-                if (sw < 3) {
+                // Waves 4 and 5 carry the curve of colour channel 2 and are the slowest of the step (in-kernel stamps); waves 6 and 7
+                // idle a third of it, so THEY issue all of stage B's DMA: the P row that seeds the output row started at step t
+                // (8 body pieces + halo) and the three fp32 image planes of the row whose curve runs at step t+2.
+                if (sw >= 2) {
+                    {
+                        const int y = ys - 3 + t;
+                        const unsigned rmask = ((y >= 0) && (y < H)) ? 0u : OOB;
+                        const unsigned row_b = rmask ? 0u : (unsigned)y * (unsigned)W * PXB;
+                        char* slot = smem + OFF_BRING + (t % NRB) * ROW_B;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) IE_DMA_PIECE(rsB, slot, (sw - 2) * 4 + j, row_b, rmask);
+                        if (sw == 2) {
+                            const unsigned off = (row_b + halo_xoff) | rmask;
+                            if (lane < 8)
+                                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(slot + TW * PXB), 16,
+                                                                         (int)off, 0, 0, 0);
+                        }
+                    }
                     const int yo = ys - 5 + t;      // row finished at step t, consumed at step t+2
                     const unsigned rmask = ((yo >= ys) && (yo < ye)) ? 0u : OOB;
-                    const unsigned base = rmask ? 0u : ((unsigned)sw * (unsigned)plane + (unsigned)yo * (unsigned)W) * 4u;
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const unsigned off = (base + img67_off[j]) | rmask;
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                            rsI, (__attribute__((address_space(3))) void*)(smem + OFF_IMG + (t % NRI) * IMG_SLOT_B + sw * (TW * 4) + j * 256),
-                            4, (int)off, 0, 0, 0);
+                    for (int pl = 0; pl < 3; ++pl) {
+                        if ((pl == 0) != (sw == 2)) continue;          // wave 6: plane 0; wave 7: planes 1, 2
+                        const unsigned base = rmask ? 0u : ((unsigned)pl * (unsigned)plane + (unsigned)yo * (unsigned)W) * 4u;
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const unsigned off = (base + img67_off[j]) | rmask;
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                                rsI, (__attribute__((address_space(3))) void*)(smem + OFF_IMG + (t % NRI) * IMG_SLOT_B + pl * (TW * 4) + j * 256),
+                                4, (int)off, 0, 0, 0);
+                        }
                     }
                 }
             }
@@ -242,8 +291,8 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     // DMA instructions per step of this wave -> counted wait that leaves PF-1 younger rows in flight
     // Waves that issue no DMA do not wait at all; stage-A waves issue no stores, so their count is exact.
     int L = 0, S = 0;
-    if (stg == 0) { L = (KIND == K12) ? 2 : (2 * NSA + (sw == 0 ? NSA : 0)); }
-    else if (KIND == K67) L = 2 + (sw == 0 ? 1 : 0) + (sw < 3 ? 2 : 0);
+    if (stg == 0) { L = (KIND == K12) ? 2 : (2 * NSA + (sw == 0 ? NSA : 0)); }   // K345: NSA = 1
+    else if (KIND == K67) L = sw == 2 ? 7 : (sw == 3 ? 8 : 0);
     const int wait_base = L ? (PF - 1) * L : -1;
     (void)S;
 
@@ -311,21 +360,23 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     };
 
     // write a finished stage-A row (ReLU, 16-bit, zero outside the image) into the hand-off ring slot
-    auto a_emit = [&](const ie_f32x4 (&acc)[4], int t) __attribute__((always_inline)) {
-        const int ra = ys - 3 - LAG_A + t;
+    auto a_emit_to = [&](auto tg, const ie_f32x4 (&acc)[4], char* slot, int ra, bool relu = true) __attribute__((always_inline)) {
+        using TE = typename decltype(tg)::type;
         const bool row_in = (ra >= 0) && (ra < H);
-        char* slot = smem + OFF_RA + (t & 1) * ROW_B;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             const int q = 64 * ph + 16 * nt + p16;
             const int x = xc0 + q;
             const bool in_img = row_in && x >= 0 && x < W;
             ie_u32x2 pk;
-            pk[0] = in_img ? ie_pack2_relu<TH>(acc[nt][0], acc[nt][1]) : 0u;
-            pk[1] = in_img ? ie_pack2_relu<TH>(acc[nt][2], acc[nt][3]) : 0u;
+            pk[0] = in_img ? (relu ? ie_pack2_relu<TE>(acc[nt][0], acc[nt][1]) : ie_pack2<TE>(acc[nt][0], acc[nt][1])) : 0u;
+            pk[1] = in_img ? (relu ? ie_pack2_relu<TE>(acc[nt][2], acc[nt][3]) : ie_pack2<TE>(acc[nt][2], acc[nt][3])) : 0u;
             const int c = 2 * ch + (kq >> 1);      // 16-byte chunk holding couts 16ch+4kq .. +3
             *(ie_u32x2*)(slot + q * PXB + ((c ^ ((q >> 1) & 3)) << 4) + (kq & 1) * 8) = pk;
         }
+    };
+    auto a_emit = [&](const ie_f32x4 (&acc)[4], int t) __attribute__((always_inline)) {
+        a_emit_to(ie_tag<TH>{}, acc, smem + OFF_RA + (t & 1) * ROW_B, ys - 3 - LAG_A + t);
     };
 
     // stage-B epilogue to HBM (centre 126 columns): ReLU'd activations (x2, x5) or the raw P map (K12)
@@ -345,7 +396,7 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
             ie_u32x4 v_ = {sx_[0], sy_[0], sx_[1], sy_[1]};                                                               \
             const int q_ = 64 * ph + 16 * (nt + (kq & 1)) + p16;                                                          \
             const int xo_ = xc0 + q_;                                                                                     \
-            const bool ok_ = row_ok_ && q_ >= 1 && q_ < TW - 1 && xo_ < W;                                                \
+            const bool ok_ = row_ok_ && q_ >= MARG && q_ < TW - MARG && xo_ < W;                                          \
             const unsigned off_ = ok_ ? row_b_ + (unsigned)xo_ * PXB + (unsigned)((16 * ch + 4 * (kq & 2)) * 2) : OOB;         \
             __builtin_amdgcn_raw_buffer_store_b128(v_, RS, (int)off_, 0, 0);                                              \
         }                                                                                                                 \
@@ -467,77 +518,116 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     // issue, then the hand-off write.  Stage B: the epilogue of the row it finished in the PREVIOUS step
     // first (that accumulator set is this step's accN, reset afterwards), then its MFMAs.  The two stages
     // share each SIMD, so B's epilogue VALU runs under A's MFMAs and A's tail under B's MFMAs.
-    auto step = [&](int t, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4], ie_f32x4 (&pN)[4], ie_f32x4 (&pM)[4],
-                    ie_f32x4 (&pO)[4]) __attribute__((always_inline)) {
-        unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
-        (void)ts0; (void)ts1; (void)ts2; (void)ts3;
-        IE_T(ts0);
-        wait_vm(wait_base);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS writes of step t-1 (hand-off, staging)
-        __builtin_amdgcn_s_barrier();
-        IE_T(ts1);
-        if (stg == 0) {
-            if constexpr (KIND == K12) {
-                conv1_row(t, accO);
-                IE_T(ts2);
-                issue(t + PF);
-                if (t >= 3) a_emit(accO, t);
-            } else {
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) accN[nt] = bias4;
-                src_mfma(ie_tag<TA0>{}, smem + (t % NRA) * ROW_B, 0, accN, accM, accO, 0);
-                if constexpr (NSA == 2) src_mfma(ie_tag<TA1>{}, smem + NRA * ROW_B + (t % NRA) * ROW_B, 9, accN, accM, accO, 0);
-                IE_T(ts2);
-                issue(t + PF);
-                if (t >= 2) a_emit(accO, t);
-                if constexpr (KIND == K67) { if (t >= 7) curve_consume(t - 2); }
-            }
-        } else {
-            issue(t + PF);
-            IE_T(ts2);
-            // accN (and pN) still hold the output row finished at step t-1: ys-5-LAG_A+(t-1)
-            if constexpr (KIND == K12) convert_row(t);
-            if constexpr (KIND == K12) {
-                if (t >= 6 + LAG_A) { IE_B_STORE(accN, ys - 6 - LAG_A + t, rsDb, true); IE_B_STORE(pN, ys - 6 - LAG_A + t, rsDa, false); }
-            } else if constexpr (KIND == K45) {
-                if (t >= 6) IE_B_STORE(accN, ys - 6 + t, rsDb, true);
-            } else {
-                if (t >= 7) curve_consume(t - 2);
-                if (t >= 6) stage_write(accN, (t - 1) & 1);
-            }
-            const char* ra_row = smem + OFF_RA + ((t + 1) & 1) * ROW_B;     // written by stage A at step t-1
-            if constexpr (KIND == K12) {
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) { accN[nt] = bias4; pN[nt] = bias4p; }
-                src_mfma2(ra_row, accN, accM, accO, pN, pM, pO);                           // x1 row ys-5+t
-            } else if constexpr (KIND == K45) {
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) accN[nt] = bias4;
-                src_mfma(ie_tag<TA0>{}, smem + ((t + NRA - 2) % NRA) * ROW_B, 0, accN, accM, accO, 0);   // x3 row ys-4+t
-                src_mfma(ie_tag<TH>{}, ra_row, 9, accN, accM, accO, 0);                                   // x4 row ys-4+t
-            } else {
-                seed_from_p(t, accN);                                                      // P row ys-3+t = W7a*x1 + bias7
-                src_mfma(ie_tag<TH>{}, ra_row, 0, accN, accM, accO, 0);                    // x6 row ys-4+t
-            }
-        }
+    // Each stage runs its OWN loop (the wave-uniform `stg` branch is taken once, outside): the register allocator then sees two
+    // independent live ranges -- stage A's second accumulator family (K345) or stage B's (K12) is not carried through the other
+    // stage's loop -- and both loops execute exactly one s_barrier per step.
+#define IE_STEP_HEAD()                                                                                              \
+        unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;                                                     \
+        (void)ts0; (void)ts1; (void)ts2; (void)ts3;                                                                \
+        IE_T(ts0);                                                                                                 \
+        wait_vm(wait_base);                                                                                        \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* this wave's LDS writes of step t-1 (hand-off, staging) */ \
+        __builtin_amdgcn_s_barrier();                                                                              \
+        IE_T(ts1)
 #ifdef IE_STAMP
-        IE_T(ts3);
-        st_wait += ts1 - ts0; st_issue += ts2 - ts1; st_work += ts3 - ts2;
+#define IE_STEP_TAIL() do { IE_T(ts3); st_wait += ts1 - ts0; st_issue += ts2 - ts1; st_work += ts3 - ts2; } while (0)
+#else
+#define IE_STEP_TAIL() do { } while (0)
 #endif
+    // Stage A: MFMAs first (the pipe is busy from the first cycle after the barrier), then its DMA issue, then the hand-off write.
+    auto step_a = [&](int t, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4], ie_f32x4 (&pN)[4], ie_f32x4 (&pM)[4],
+                      ie_f32x4 (&pO)[4]) __attribute__((always_inline)) {
+        IE_STEP_HEAD();
+        if constexpr (KIND == K12) {
+            conv1_row(t, accO);
+            IE_T(ts2);
+            issue(t + PF);
+            if (t >= 3) a_emit(accO, t);
+        } else if constexpr (KIND == K345) {
+            // e_conv3 on x2 row ys-4+t -> x3 row ys-5+t (accO); e_conv4 on the x3 row emitted at step t-1 -> x4 row ys-7+t (pO)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) { accN[nt] = bias4; pN[nt] = bias4p; }
+            src_mfma(ie_tag<TA0>{}, smem + (t % NRA) * ROW_B, 0, accN, accM, accO, 0);
+            src_mfma(ie_tag<T3>{}, smem + OFF_R3 + ((t + NR3 - 1) % NR3) * ROW_B, 9, pN, pM, pO, 0);
+            IE_T(ts2);
+            issue(t + PF);
+            if (t >= 2) a_emit_to(ie_tag<T3>{}, accO, smem + OFF_R3 + (t % NR3) * ROW_B, ys - 5 + t);
+            if (t >= 5) a_emit_to(ie_tag<TH>{}, pO, smem + OFF_RA + (t & 1) * ROW_B, ys - 7 + t);
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) accN[nt] = bias4;
+            src_mfma(ie_tag<TA0>{}, smem + (t % NRA) * ROW_B, 0, accN, accM, accO, 0);
+            if constexpr (NSA == 2) src_mfma(ie_tag<TA1>{}, smem + NRA * ROW_B + (t % NRA) * ROW_B, 9, accN, accM, accO, 0);
+            IE_T(ts2);
+            issue(t + PF);
+            if (t >= 2) a_emit(accO, t);
+            if constexpr (KIND == K67) { if (t >= 7) curve_consume(t - 2); }
+        }
+        IE_STEP_TAIL();
+    };
+    // Stage B: the epilogue of the row it finished in the PREVIOUS step first (that accumulator set is this step's accN, reset
+    // afterwards), then its MFMAs.  The two stages share each SIMD, so B's epilogue VALU runs under A's MFMAs and A's tail under B's.
+    auto step_b = [&](int t, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4], ie_f32x4 (&pN)[4], ie_f32x4 (&pM)[4],
+                      ie_f32x4 (&pO)[4]) __attribute__((always_inline)) {
+        IE_STEP_HEAD();
+        issue(t + PF);
+        IE_T(ts2);
+        // accN (and pN) still hold the output row finished at step t-1: ys-5-LAG_A+(t-1)
+        if constexpr (KIND == K12) convert_row(t);
+        if constexpr (KIND == K12) {
+            if (t >= 6 + LAG_A) { IE_B_STORE(accN, ys - 6 - LAG_A + t, rsDb, true); IE_B_STORE(pN, ys - 6 - LAG_A + t, rsDa, false); }
+        } else if constexpr (KIND == K45) {
+            if (t >= 6) IE_B_STORE(accN, ys - 6 + t, rsDb, true);
+        } else if constexpr (KIND == K345) {
+            if (t >= 10) IE_B_STORE(accN, ys - 10 + t, rsDb, true);
+        } else {
+            if (t >= 7) curve_consume(t - 2);
+            if (t >= 6) stage_write(accN, (t - 1) & 1);
+        }
+        const char* ra_row = smem + OFF_RA + ((t + 1) & 1) * ROW_B;     // written by stage A at step t-1
+        if constexpr (KIND == K12) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) { accN[nt] = bias4; pN[nt] = bias4p; }
+            src_mfma2(ra_row, accN, accM, accO, pN, pM, pO);                           // x1 row ys-5+t
+        } else if constexpr (KIND == K45) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) accN[nt] = bias4;
+            src_mfma(ie_tag<TA0>{}, smem + ((t + NRA - 2) % NRA) * ROW_B, 0, accN, accM, accO, 0);   // x3 row ys-4+t
+            src_mfma(ie_tag<TH>{}, ra_row, 9, accN, accM, accO, 0);                                   // x4 row ys-4+t
+        } else if constexpr (KIND == K345) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) accN[nt] = bias4;
+            src_mfma(ie_tag<T3>{}, smem + OFF_R3 + ((t + NR3 - 3) % NR3) * ROW_B, 0, accN, accM, accO, 0);   // x3 row ys-8+t (emitted at step t-3)
+            src_mfma(ie_tag<TH>{}, ra_row, 9, accN, accM, accO, 0);                                           // x4 row ys-8+t (emitted at step t-1)
+        } else {
+            seed_from_p(t, accN);                                                      // P row ys-3+t = W7a*x1 + bias7
+            src_mfma(ie_tag<TH>{}, ra_row, 0, accN, accM, accO, 0);                    // x6 row ys-4+t
+        }
+        IE_STEP_TAIL();
     };
 
 #pragma unroll
     for (int t = 0; t < PF; ++t) issue(t);
 
     ie_f32x4 a0[4], a1[4], a2[4];
-    ie_f32x4 q0[4], q1[4], q2[4];     // K12 stage B: the e_conv7a (P) accumulator family
+    ie_f32x4 q0[4], q1[4], q2[4];     // second accumulator family: K12 stage B (the e_conv7a / P map), K345 stage A (e_conv4)
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) { a0[nt] = bias4; a1[nt] = bias4; a2[nt] = bias4; q0[nt] = bias4p; q1[nt] = bias4p; q2[nt] = bias4p; }
-    for (int t = 0; t < n_steps; t += 3) {
-        step(t, a0, a1, a2, q0, q1, q2);
-        if (t + 1 < n_steps) step(t + 1, a2, a0, a1, q2, q0, q1);
-        if (t + 2 < n_steps) step(t + 2, a1, a2, a0, q1, q2, q0);
+    if (stg == 0) {
+        for (int t = 0; t < n_steps; t += 3) {
+            step_a(t, a0, a1, a2, q0, q1, q2);
+            if (t + 1 < n_steps) step_a(t + 1, a2, a0, a1, q2, q0, q1);
+            if (t + 2 < n_steps) step_a(t + 2, a1, a2, a0, q1, q2, q0);
+        }
+    } else {
+        for (int t = 0; t < n_steps; t += 3) {
+            step_b(t, a0, a1, a2, q0, q1, q2);
+            if (t + 1 < n_steps) step_b(t + 1, a2, a0, a1, q2, q0, q1);
+            if (t + 2 < n_steps) step_b(t + 2, a1, a2, a0, q1, q2, q0);
+        }
     }
+#undef IE_STEP_HEAD
+#undef IE_STEP_TAIL
 #undef IE_B_STORE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef IE_STAMP
@@ -561,6 +651,12 @@ IE_DEF_FUSED(zdce_k67_conv6_conv7_curve_bf16, __bf16, __bf16, __bf16, __bf16, K6
 // the "bf16" schedule's last kernel: x2 (fp16) and x5 (bf16) in, x6 / P / e_conv7b in fp16
 IE_DEF_FUSED(zdce_k67_conv6_conv7_curve_mix, _Float16, __bf16, _Float16, _Float16, K67)
 #undef IE_DEF_FUSED
+#define IE_DEF_FUSED3(NAME, TA0, T3, TH, TO) \
+    __global__ __launch_bounds__(512, 2) void NAME(FusedParams p) { zdce_fused2_body<TA0, TA0, TH, TO, K345, T3>(p); }
+IE_DEF_FUSED3(zdce_k345_conv3_conv4_conv5_f16, _Float16, _Float16, _Float16, _Float16)
+IE_DEF_FUSED3(zdce_k345_conv3_conv4_conv5_bf16, __bf16, __bf16, __bf16, __bf16)
+IE_DEF_FUSED3(zdce_k345_conv3_conv4_conv5_mix, _Float16, __bf16, __bf16, __bf16)      // x2 fp16 in; x3, x4, x5 bf16
+#undef IE_DEF_FUSED3
 
 typedef void (*FusedFn)(FusedParams);
 
@@ -568,23 +664,23 @@ template <int KIND>
 static int launch_fused_t(FusedFn fn, const ZdceFusedLaunch& a, hipStream_t st) {
     FusedParams p;
     p.a_src0 = a.a_src0; p.a_src1 = a.a_src1; p.b_src = a.b_src; p.img = a.img;
-    p.a_w = a.a_w; p.a_bias = a.a_bias; p.b_w = a.b_w; p.b_bias = a.b_bias; p.b2_bias = a.b2_bias; p.a_dst = a.a_dst; p.b_dst = a.b_dst;
+    p.a_w = a.a_w; p.a_bias = a.a_bias; p.a2_w = a.a2_w; p.a2_bias = a.a2_bias; p.b_w = a.b_w; p.b_bias = a.b_bias; p.b2_bias = a.b2_bias; p.a_dst = a.a_dst; p.b_dst = a.b_dst;
     p.enhanced = a.enhanced; p.adjust = a.adjust; p.u8 = a.u8;
     p.N = a.N; p.H = a.H; p.W = a.W; p.y_begin = a.y_begin; p.y_end = a.y_end; p.rows_per_block = a.rows_per_block;
     p.n_begin = a.n_begin;
     p.stamps = (unsigned long long*)a.stamps;
-    p.strips = ie_cdiv(a.W, TS);
+    p.strips = ie_cdiv(a.W, KIND == K345 ? TW - 4 : TS);
     p.chunks = ie_cdiv(a.y_end - a.y_begin, a.rows_per_block);
     const long long blocks = (long long)p.strips * p.chunks * a.n_count;
     if (blocks <= 0 || blocks > 0x7fffffffLL) IE_FAIL(IE_ERR_INVALID, "zdce fused: bad grid %lld", blocks);
     if ((size_t)a.H * a.W * 32 * 2 >= 0x7fffffffull) IE_FAIL(IE_ERR_UNSUPPORTED, "zdce fused: frame too large for 31-bit offsets");
     constexpr int PF = (KIND == K67) ? 3 : PF_DEFAULT;
     constexpr int ROW_B = ROW_PX * 32 * 2;
-    constexpr int NSA = (KIND == K67) ? 2 : (KIND == K45 ? 1 : 0);
+    constexpr int NSA = (KIND == K67) ? 2 : ((KIND == K45 || KIND == K345) ? 1 : 0);
     constexpr int NRA = (KIND == K45) ? PF + 3 : PF + 1;
     constexpr int NRI = (KIND == K12) ? PF + 1 : PF + 3;
-    const size_t lds = (size_t)NSA * NRA * ROW_B + (KIND == K67 ? (PF + 1) * ROW_B : 0) + 2 * ROW_B +
-                       (KIND == K45 ? 0 : NRI * 2048) + (KIND == K12 ? 4 * 2 * 1088 : 0) + (KIND == K67 ? 2 * 24 * TW * 4 : 0);
+    const size_t lds = (size_t)NSA * NRA * ROW_B + (KIND == K67 ? (PF + 1) * ROW_B : 0) + (KIND == K345 ? 4 * ROW_B : 0) + 2 * ROW_B +
+                       ((KIND == K45 || KIND == K345) ? 0 : NRI * 2048) + (KIND == K12 ? 4 * 2 * 1088 : 0) + (KIND == K67 ? 2 * 24 * TW * 4 : 0);
     // the dynamic-LDS limit is a per-function attribute: set it once per kernel
     static FusedFn attr_done[8] = {nullptr};
     bool done = false;
@@ -612,6 +708,11 @@ int ie_zdce_launch_fused(const ZdceFusedLaunch& a, hipStream_t st) {
         if (h_all) return launch_fused_t<K67>(zdce_k67_conv6_conv7_curve_f16, a, st);
         if (b_all) return launch_fused_t<K67>(zdce_k67_conv6_conv7_curve_bf16, a, st);
         if (a.dt_a0 == IE_F16 && a.dt_a1 == IE_BF16 && a.dt_h == IE_F16) return launch_fused_t<K67>(zdce_k67_conv6_conv7_curve_mix, a, st);
+    } else if (a.kind == 345) {      // dt_a0 = x2, dt_a1 = x3 (LDS), dt_h = x4 (LDS), dt_o = x5
+        if (h_all) return launch_fused_t<K345>(zdce_k345_conv3_conv4_conv5_f16, a, st);
+        if (b_all) return launch_fused_t<K345>(zdce_k345_conv3_conv4_conv5_bf16, a, st);
+        if (a.dt_a0 == IE_F16 && a.dt_a1 == IE_BF16 && a.dt_h == IE_BF16 && a.dt_o == IE_BF16)
+            return launch_fused_t<K345>(zdce_k345_conv3_conv4_conv5_mix, a, st);
     }
     IE_FAIL(IE_ERR_UNSUPPORTED, "zdce fused: kind=%d dtypes a0=%d a1=%d h=%d o=%d", a.kind, a.dt_a0, a.dt_a1, a.dt_h, a.dt_o);
 }

@@ -13,7 +13,7 @@ int ie_zdce_launch_mfma(const ZdceConvLaunch& a, hipStream_t st);
 int ie_zdce_launch_conv1(const float* img, const float* wk, const float* bias, void* dst, int dtype, int N, int H,
                          int W, int y_begin, int y_end, int n_begin, int n_count, hipStream_t st);
 
-// two-stage fused strip kernels (ie_zdce_fused.hip); kind = 12, 45 or 67
+// two-stage fused strip kernels (ie_zdce_fused.hip); kind = 12, 45, 67 or 345 (e_conv3 + e_conv4 on stage A, e_conv5 on stage B)
 struct ZdceFusedLaunch {
     int kind;
     int dt_a0, dt_a1;    // element types of stage A's HBM sources (K45: x3; K67: x2, x5)
@@ -21,6 +21,7 @@ struct ZdceFusedLaunch {
     int dt_o;            // element type of the HBM outputs (K12: x2 and P; K45: x5)
     const void* a_src0; const void* a_src1; const void* b_src; const float* img;
     const void* a_w; const float* a_bias; const void* b_w; const float* b_bias; const float* b2_bias;
+    const void* a2_w; const float* a2_bias;   // kind 345: e_conv4
     void* a_dst; void* b_dst; float* enhanced; float* adjust; unsigned char* u8;
     int N, H, W, y_begin, y_end, n_begin, n_count, rows_per_block;
     void* stamps;   // diagnostic builds only

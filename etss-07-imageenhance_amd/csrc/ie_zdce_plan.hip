@@ -23,6 +23,9 @@ const char* const kLayerNames[NL] = {"zdce_conv1", "zdce_conv2", "zdce_conv3", "
 // profiling slots used by the fused schedule (slot index = last layer of the kernel)
 const char* const kFusedNames[NL] = {"", "zdce_k12_conv1_conv2", "zdce_conv3", "", "zdce_k45_conv4_conv5", "",
                                      "zdce_k67_conv6_conv7_curve"};
+// default schedule: e_conv3 rides in the three-layer kernel (slot 4), slot 2 stays empty
+const char* const kFused3Names[NL] = {"", "zdce_k12_conv1_conv2", "", "", "zdce_k345_conv3_conv4_conv5", "",
+                                      "zdce_k67_conv6_conv7_curve"};
 
 unsigned short f32_to_f16_bits(float f) { _Float16 h = (_Float16)f; unsigned short u; memcpy(&u, &h, 2); return u; }
 unsigned short f32_to_bf16_bits(float f) {
@@ -356,7 +359,7 @@ static int forward_mfma(ie_zdce_plan* p, const float* image, float* enhanced, fl
                 memset(&a, 0, sizeof(a));
                 a.kind = kind; a.N = N; a.H = H; a.W = W; a.n_begin = n0; a.n_count = g; a.rows_per_block = rb;
                 a.img = image;
-                a.stamps = g_ie_stamps ? (void*)((unsigned long long*)g_ie_stamps + (size_t)(kind == 12 ? 0 : kind == 45 ? 1 : 2) * (1u << 20)) : nullptr;
+                a.stamps = g_ie_stamps ? (void*)((unsigned long long*)g_ie_stamps + (size_t)(kind == 12 ? 0 : (kind == 45 || kind == 345) ? 1 : 2) * (1u << 20)) : nullptr;
                 if (kind == 12) {
                     a.a_w = p->d_w + p->off_w1m; a.a_bias = B_(0); a.b_w = p->d_w + p->off_w27; a.b_bias = B_(1); a.b2_bias = B_(6);
                     a.a_dst = x[1]; a.b_dst = x[2]; a.y_begin = lo(2); a.y_end = hi(2);   // x[1] holds P = W7a*x1 + bias7, not x1
@@ -365,6 +368,10 @@ static int forward_mfma(ie_zdce_plan* p, const float* image, float* enhanced, fl
                     a.a_src0 = x[3]; a.a_w = W_(3); a.a_bias = B_(3); a.b_w = W_(4); a.b_bias = B_(4);
                     a.b_dst = x[5]; a.y_begin = lo(5); a.y_end = hi(5);
                     a.dt_a0 = a.dt_a1 = p->xdt[3]; a.dt_h = p->xdt[4]; a.dt_o = p->xdt[5];
+                } else if (kind == 345) {
+                    a.a_src0 = x[2]; a.a_w = W_(2); a.a_bias = B_(2); a.a2_w = W_(3); a.a2_bias = B_(3); a.b_w = W_(4); a.b_bias = B_(4);
+                    a.b_dst = x[5]; a.y_begin = lo(5); a.y_end = hi(5);
+                    a.dt_a0 = p->xdt[2]; a.dt_a1 = p->xdt[3]; a.dt_h = p->xdt[4]; a.dt_o = p->xdt[5];
                 } else {
                     a.a_src0 = x[2]; a.a_src1 = x[5]; a.b_src = x[1]; a.a_w = W_(5); a.a_bias = B_(5); a.b_w = p->d_w + p->off_w7b; a.b_bias = B_(6);
                     a.enhanced = enhanced; a.adjust = adjust; a.u8 = u8; a.y_begin = b0; a.y_end = b1;
@@ -382,8 +389,12 @@ static int forward_mfma(ie_zdce_plan* p, const float* image, float* enhanced, fl
             } else {
                 // K12 writes x1 over the rows conv7 and conv2's consumers need (= x2's range), then conv3, K45, K67
                 rc = fused(12, 1);
-                if (rc == IE_OK) rc = single(2);
-                if (rc == IE_OK) rc = fused(45, 4);
+                if (p->cfg.variant & IE_ZDCE_VAR_NO_K345) {
+                    if (rc == IE_OK) rc = single(2);
+                    if (rc == IE_OK) rc = fused(45, 4);
+                } else if (rc == IE_OK) {
+                    rc = fused(345, 4);        // e_conv3 + e_conv4 + e_conv5: x3 and x4 never reach HBM
+                }
                 if (rc == IE_OK) rc = fused(67, 6);
             }
             if (rc) return rc;
@@ -467,7 +478,8 @@ IE_EXPORT int ie_zdce_profile_forward(ie_zdce_plan* p, const float* image, float
     if (rc) return rc;
     IE_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
     const bool fused = p->cfg.compute_dtype != IE_F32 && !(p->cfg.variant & IE_ZDCE_VAR_UNFUSED);
-    for (int l = 0; l < NL; ++l) { ms[l] = 0.f; names[l] = fused ? kFusedNames[l] : kLayerNames[l]; if (launches) launches[l] = 0; }
+    const bool k345 = fused && !(p->cfg.variant & IE_ZDCE_VAR_NO_K345);
+    for (int l = 0; l < NL; ++l) { ms[l] = 0.f; names[l] = k345 ? kFused3Names[l] : (fused ? kFusedNames[l] : kLayerNames[l]); if (launches) launches[l] = 0; }
     for (size_t i = 0; i < p->ev_layer.size(); ++i) {
         float t = 0.f;
         IE_HIP_CHECK(hipEventElapsedTime(&t, p->ev[2 * i], p->ev[2 * i + 1]));

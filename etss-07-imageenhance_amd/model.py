@@ -259,8 +259,9 @@ class VisionModel(Model, ABC):
         if (h, w) == tuple(size):
             return v
         out = torch.empty((n, c, size[0], size[1]), device=x.device, dtype=torch.float32)
-        capi.check(capi.lib().ie_resize_bilinear_nchw_f32(capi.ptr(x), capi.ptr(out), n, c, h, w, size[0], size[1], 0,
-                                                          capi.current_stream()), "ie_resize_bilinear_nchw_f32")
+        with torch.cuda.device(x.device):          # the current-stream lookup must be this device's
+            capi.check(capi.lib().ie_resize_bilinear_nchw_f32(capi.ptr(x), capi.ptr(out), n, c, h, w, size[0], size[1], 0,
+                                                              capi.current_stream()), "ie_resize_bilinear_nchw_f32")
         return out[0] if squeeze else out
 
     def infer(self, datapoint: dict, image_size: int | Sequence[int] = 512, resize: bool = False, *args, **kwargs) -> dict:

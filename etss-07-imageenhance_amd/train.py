@@ -521,7 +521,6 @@ class Trainer:
         if not isinstance(self.loss, Loss):
             raise TypeError("`loss` must be a mon_amd.losses.Loss or its config dict")
         self.group = process_group
-        self.step = 0
         cd = {capi.IE_F32: "f32", capi.IE_F16: "f16", capi.IE_BF16: "bf16"}[capi.DTYPES[str(compute_dtype).lower()]]
         if cd != "f32" and not getattr(model, "supports_mixed_training", False):
             raise capi.IEError(f"{model.__class__.__name__} has no 16-bit training graph")
@@ -533,10 +532,25 @@ class Trainer:
         if getattr(self.loss, "zero_reference", False):
             self.loss.grad_scale = self.loss_scale          # this loss computes its gradients in the forward pass
         self.store = ParamStore(model, self.device, cd)
+        # {step, applied, bc1, bc2_sqrt} on the device: a skipped (overflowed) step does not advance Adam's step count
+        self._opt_state = torch.zeros(4, device=self.device, dtype=torch.int32)
         self._sumsq = torch.zeros(1, device=self.device, dtype=torch.float64)
         self._sumsq_ws = torch.zeros(capi.SUMSQ_WS_DOUBLES, device=self.device, dtype=torch.float64)
         model.predicting = False
         model.train()
+
+    @property
+    def step(self) -> int:
+        """Optimiser steps actually applied (a host read of the device-side counter; checkpointed as ``global_step``)."""
+        return int(self._opt_state[0].item())
+
+    @step.setter
+    def step(self, v: int):
+        self._opt_state[0] = int(v)
+
+    @property
+    def last_step_applied(self) -> bool:
+        return bool(self._opt_state[1].item())
 
     # nn/model.py:498 -- kept for API parity; the optimiser state lives in the ParamStore
     def configure_optimizers(self):
@@ -599,17 +613,19 @@ class Trainer:
         from .sharding import allreduce_gradients
         st = self.store
         scale = allreduce_gradients(st.grads, self.group) / self.loss_scale
-        self.step += 1
         L = capi.lib()
         with torch.cuda.device(self.device):
             sumsq = None
-            if self.clip > 0:
+            # the norm is needed for clipping AND as the overflow check of 16-bit / loss-scaled gradients: without it inf / NaN
+            # gradients would be written into the fp32 master weights and both Adam moments for good
+            if self.clip > 0 or self.compute_dtype == "f16" or self.loss_scale != 1.0:
                 capi.check(L.ie_sumsq_f32(capi.ptr(st.grads), st.numel, scale, capi.ptr(self._sumsq), capi.ptr(self._sumsq_ws), 1,
                                           capi.current_stream()), "ie_sumsq_f32")
                 sumsq = self._sumsq
-            capi.check(L.ie_adam_step_f32(capi.ptr(st.params), capi.ptr(st.grads), capi.ptr(st.exp_avg), capi.ptr(st.exp_avg_sq), st.numel,
-                                          self.step, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, scale,
-                                          capi.ptr(sumsq), self.clip, capi.current_stream()), "ie_adam_step_f32")
+            capi.check(L.ie_adam_step_counted_f32(capi.ptr(st.params), capi.ptr(st.grads), capi.ptr(st.exp_avg), capi.ptr(st.exp_avg_sq),
+                                                  st.numel, capi.ptr(self._opt_state), self.lr, self.betas[0], self.betas[1], self.eps,
+                                                  self.weight_decay, scale, capi.ptr(sumsq), self.clip, capi.current_stream()),
+                       "ie_adam_step_counted_f32")
         st.repack16()                             # 16-bit copies of the weights for the next step's matrix-core convolutions
 
     def training_step(self, batch: dict, batch_idx: int = 0) -> dict:
@@ -640,7 +656,7 @@ class Trainer:
     def save_checkpoint(self, path) -> str:
         st = self.store
         ckpt = {"state_dict": self.state_dict(), "global_step": self.step,
-                "optimizer_states": [{"name": "adam", "lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay,
+                "optimizer_states": [{"name": "adam", "lr": self.lr, "betas": list(self.betas), "eps": self.eps, "weight_decay": self.weight_decay,
                                       "exp_avg": self.store.export(st.exp_avg), "exp_avg_sq": self.store.export(st.exp_avg_sq)}],
                 "gradient_clip_val": self.clip, "model": self.model.name}
         import os
@@ -650,7 +666,7 @@ class Trainer:
 
     def load_checkpoint(self, path):
         """Resume: parameters, BatchNorm buffers, Adam moments and the step counter; the next step continues bit-identically."""
-        ckpt = torch.load(str(path), map_location="cpu", weights_only=False)
+        ckpt = torch.load(str(path), map_location="cpu", weights_only=True)     # dicts / lists / numbers / strings / tensors only
         st = self.store
         opt = ckpt["optimizer_states"][0]
 

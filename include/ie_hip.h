@@ -265,6 +265,13 @@ int ie_sumsq_f32(const float* a_dev, size_t n, float scale, double* acc_dev, dou
 int ie_adam_step_f32(float* param_dev, const float* grad_dev, float* exp_avg_dev, float* exp_avg_sq_dev, size_t n, int step, float lr,
                      float beta1, float beta2, float eps, float weight_decay, float grad_scale, const double* sumsq_dev,
                      float max_norm, void* stream);
+/* The same step with the step counter ON THE DEVICE: state_dev = {int step, int applied, float bc1, float bc2_sqrt} (16 bytes,
+ * zero-initialised by the caller).  A step with a non-finite *sumsq_dev is skipped AND does not advance `step`, so the bias
+ * correction and a checkpoint's global_step count the updates actually applied (GradScaler skips optimizer.step() entirely);
+ * `applied` reports the outcome of the last call.  Pass sumsq_dev with max_norm <= 0 for the overflow check without clipping. */
+int ie_adam_step_counted_f32(float* param_dev, const float* grad_dev, float* exp_avg_dev, float* exp_avg_sq_dev, size_t n, int* state_dev,
+                             float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale, const double* sumsq_dev,
+                             float max_norm, void* stream);
 
 /* ---- dtype-generic twins of the training entry points (dtype = IE_F32 / IE_F16 / IE_BF16 of the activation tensors; parameter
  * gradients, statistics and saved mean / invstd stay fp32 / fp64): the 16-bit training path keeps activations and their gradients in
@@ -330,6 +337,7 @@ typedef struct ie_zdce_config {
 #define IE_ZDCE_VAR_NARROW_STORE 2 /* 8-byte epilogue stores instead of permlane-widened 16-byte */
 #define IE_ZDCE_VAR_NO_DMA 4 /* register-staged global->LDS copies instead of LDS-DMA (debug / A-B) */
 #define IE_ZDCE_VAR_UNFUSED 8 /* one kernel per layer instead of the fused conv1+2 / conv4+5 / conv6+7 kernels */
+#define IE_ZDCE_VAR_NO_K345 32 /* e_conv3 as its own kernel + the two-layer conv4+5 kernel instead of the three-layer conv3+4+5 kernel (A-B) */
 #define IE_ZDCE_VAR_PURE_BF16 16 /* compute_dtype IE_BF16 only: every 16-bit tensor and weight in bf16.  Without it the
                                     "bf16" schedule holds the tensors that carry the rounding error (x1, x2, x6, the partial
                                     sum P and the weights contracted with them) in fp16 and x3/x4/x5 (+ theirs) in bf16 --

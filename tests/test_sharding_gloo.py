@@ -74,3 +74,19 @@ def test_gradient_allreduce_without_group_is_identity():
     from mon_amd.sharding import allreduce_gradients
     g = torch.ones(4)
     assert allreduce_gradients(g) == 1.0 and torch.equal(g, torch.ones(4))
+
+
+def test_bench_gpus_n_starts_n_ranks_command():
+    """`python bench.py --gpus N` without a launcher re-launches itself as N ranks (torch.distributed.run on 127.0.0.1) before
+    any GPU call; the JSON line's n_gpus is the children's WORLD_SIZE (checked on the GPU box by test_bench_two_ranks_one_device)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    cmd = b._spawn_cmd(4, ["--gpus", "4", "--steps", "2"])
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "2"]
+    assert cmd[cmd.index("--master-port") + 2].endswith("bench.py")
+    src = open(os.path.join(root, "bench.py")).read()
+    assert src.index("_spawn_ranks(args.gpus)") < src.index("import torch\n")      # spawn happens before torch / HIP is touched
