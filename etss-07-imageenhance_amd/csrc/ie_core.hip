@@ -15,6 +15,33 @@ void ie_set_error(const char* fmt, ...) {
 IE_EXPORT const char* ie_last_error(void) { return g_err; }
 IE_EXPORT int ie_abi_version(void) { return IE_ABI_VERSION; }
 
+// ---- deterministic mode -------------------------------------------------------------------
+// Off (default): the conv weight gradients combine their split-K partial sums with fp32 atomics, whose order -- and with
+// it the last bits of dW -- changes from run to run.  On: every split writes its partial tile to a slab of a library-owned
+// scratch buffer and a second kernel adds the slabs in a fixed order (fp64 accumulate), so identical inputs give identical
+// bits.  The scratch grows on demand with hipMalloc (a device synchronisation; do not toggle inside a graph capture).
+static int g_det = 0;
+static void* g_det_ws[16] = {nullptr};
+static size_t g_det_bytes[16] = {0};
+IE_EXPORT int ie_set_deterministic(int on) { g_det = on ? 1 : 0; return IE_OK; }
+IE_EXPORT int ie_get_deterministic(void) { return g_det; }
+int ie_det_workspace(size_t bytes, void** out) {
+    int dev = 0;
+    IE_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 16) IE_FAIL(IE_ERR_UNSUPPORTED, "deterministic workspace: device ordinal %d", dev);
+    if (bytes > g_det_bytes[dev]) {
+        IE_HIP_CHECK(hipDeviceSynchronize());
+        if (g_det_ws[dev]) (void)hipFree(g_det_ws[dev]);
+        g_det_ws[dev] = nullptr; g_det_bytes[dev] = 0;
+        const size_t want = bytes + bytes / 4;
+        hipError_t e = hipMalloc(&g_det_ws[dev], want);
+        if (e != hipSuccess) { ie_set_error("deterministic workspace: hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); return IE_ERR_NOMEM; }
+        g_det_bytes[dev] = want;
+    }
+    *out = g_det_ws[dev];
+    return IE_OK;
+}
+
 IE_EXPORT int ie_device_info(int device, char* name, int cap, int* cu, size_t* hbm_bytes) {
     hipDeviceProp_t prop;
     IE_HIP_CHECK(hipGetDeviceProperties(&prop, device));

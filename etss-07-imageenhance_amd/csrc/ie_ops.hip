@@ -328,7 +328,8 @@ __global__ void pad_nhwc_kernel(const float* __restrict__ x, float* __restrict__
 }
 
 // op 0: a + b, 1: a * b, 2: clamp(a, lo, hi), 3: a[:, :C] * b (a has C+1 channels), 4: a - b, 5: clamp(a / b, lo, hi),
-// 6: a * lo + hi, 7: pow(a, lo), 8: a / max_all where b points at ONE float (a device-side reduction result);
+// 6: a * lo + hi, 7: pow(a, lo), 8: a / max_all where b points at ONE float (a device-side reduction result),
+// 9: a / b[0] > lo ? 1 : 0 (b ONE device float; BoundaryAwarePrior's normalised threshold);
 // b may have 1 channel (broadcast) or C channels
 __global__ void eltwise_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, int C, int Cb,
                                int op, float lo, float hi, size_t total) {
@@ -337,7 +338,7 @@ __global__ void eltwise_kernel(const float* __restrict__ a, const float* __restr
     if (op == 3) { y[i] = a[(i / C) * (C + 1) + (i % C)] * b[i / C]; return; }
     const float va = a[i];
     float vb = 0.f;
-    if (b && op != 8) vb = (Cb == C) ? b[i] : b[i / C];
+    if (b && op < 8) vb = (Cb == C) ? b[i] : b[i / C];
     float r;
     switch (op) {
     case 0: r = va + vb; break;
@@ -347,7 +348,8 @@ __global__ void eltwise_kernel(const float* __restrict__ a, const float* __restr
     case 5: r = fminf(fmaxf(va / vb, lo), hi); break;
     case 6: r = va * lo + hi; break;
     case 7: r = powf(va, lo); break;
-    default: r = va / b[0]; break;       // 8
+    case 8: r = va / b[0]; break;
+    default: r = (va / b[0]) > lo ? 1.f : 0.f; break;       // 9
     }
     y[i] = r;
 }
@@ -461,7 +463,7 @@ IE_EXPORT int ie_pad_nhwc_f32(const float* x, float* y, int N, int H, int W, int
 
 IE_EXPORT int ie_eltwise_nhwc_f32(int op, const float* a, const float* b, float* y, size_t npix, int C, int Cb, float lo, float hi, void* stream) {
     const bool unary = op == 2 || op == 6 || op == 7;
-    if (!a || !y || npix == 0 || C <= 0 || op < 0 || op > 8 || (!unary && (!b || (Cb != C && Cb != 1))) || ((op == 3 || op == 8) && Cb != 1))
+    if (!a || !y || npix == 0 || C <= 0 || op < 0 || op > 9 || (!unary && (!b || (Cb != C && Cb != 1))) || ((op == 3 || op == 8 || op == 9) && Cb != 1))
         IE_FAIL(IE_ERR_INVALID, "ie_eltwise_nhwc_f32: bad args");
     if (unary) b = nullptr;
     const size_t total = npix * C;

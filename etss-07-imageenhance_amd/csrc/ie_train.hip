@@ -24,6 +24,7 @@ constexpr int WG_T = 64, WG_K = 16;
 struct WgradParams {
     const void* x; const void* dy; float* dw;
     int N, H, W, Cs, Cout, Cin_total, cbase, kh, kw, stride, pad, pad_mode, Ho, Wo, rows_per_wg, ci_tiles;
+    float* slab;       // deterministic mode: [chunk][tile = blockIdx.y * gridDim.x + blockIdx.x][64 ci][64 co] partial sums, else NULL
 };
 
 // 4 consecutive channels of an fp32 / 16-bit NHWC tensor as fp32
@@ -98,6 +99,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
             }
         }
     }
+    if (p.slab) {       // deterministic mode: park the whole 64 x 64 partial tile, wgrad_reduce_kernel adds the chunks in order
+        float* sl = p.slab + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (WG_T * WG_T);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *(ie_f32x4*)(sl + (tci + i) * WG_T + tco) = ie_f32x4{acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int ci = ci_t + tci + i;
@@ -109,6 +116,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
             if (co < p.Cout && acc[i][j] != 0.f) atomicAdd(row + co, acc[i][j]);
         }
     }
+}
+
+// deterministic mode, second stage: dW element += sum over the chunks' slabs in chunk order (fp64 accumulate, one rounding)
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int chunks, int co_tiles, int ci_tiles, int taps,
+                                    int Cs, int Cout, int Cin_total, int cbase) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t tiles = (size_t)co_tiles * ci_tiles * taps;
+    if (e >= tiles * WG_T * WG_T) return;
+    const int tile = (int)(e / (WG_T * WG_T)), r = (int)(e % (WG_T * WG_T));
+    const int cot = tile % co_tiles, y = tile / co_tiles, cit = y % ci_tiles, tap = y / ci_tiles;
+    const int ci = cit * WG_T + r / WG_T, co = cot * WG_T + r % WG_T;
+    if (ci >= Cs || co >= Cout) return;
+    double s = 0.0;
+    for (int z = 0; z < chunks; ++z) s += (double)slab[((size_t)z * tiles + tile) * (WG_T * WG_T) + r];
+    float* d = dw + ((size_t)tap * Cin_total + cbase + ci) * Cout + co;
+    *d = (float)((double)*d + s);
 }
 
 // ---- conv data gradient ----------------------------------------------------------------------------------------
@@ -671,8 +694,21 @@ static int wgrad_impl(ie_convn_desc* d, const void* const* srcs, const int* cs, 
         if (chunks > total_rows) chunks = total_rows;
         p.rows_per_wg = ie_cdiv(total_rows, chunks);
         chunks = ie_cdiv(total_rows, p.rows_per_wg);
+        p.slab = nullptr;
+        if (ie_get_deterministic()) {
+            void* ws_det = nullptr;
+            rc = ie_det_workspace((size_t)chunks * tiles * WG_T * WG_T * sizeof(float), &ws_det);
+            if (rc != IE_OK) return rc;
+            p.slab = (float*)ws_det;
+        }
         hipLaunchKernelGGL(conv_wgrad_kernel<T>, dim3(co_tiles, p.ci_tiles * taps, chunks), dim3(256), 0, st, p);
         IE_LAUNCH_CHECK();
+        if (p.slab) {
+            const size_t total = (size_t)tiles * WG_T * WG_T;
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nblk(total)), dim3(256), 0, st, p.slab, dw_hwio, chunks, co_tiles, p.ci_tiles, taps, cs[s],
+                               d->Cout, Cin, cbase);
+            IE_LAUNCH_CHECK();
+        }
         cbase += cs[s];
     }
     if (dbias) {

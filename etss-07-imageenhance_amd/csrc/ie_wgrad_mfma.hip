@@ -35,6 +35,7 @@ constexpr int WM_LDS = 4 * WM_ROWB + 2 * WM_DYB;
 struct WgradMParams {
     const void* x; const void* dy; float* dw;
     int N, H, W, Cs, Cout, Cin_total, cbase, rows_per_wg, co_tiles, xchunks, nci;
+    float* slab;       // deterministic mode: [split = blockIdx.z * gridDim.y + blockIdx.y][tile = blockIdx.x][tap][64 ci][64 co], else NULL
 };
 
 __device__ __forceinline__ int wm_swz(int pix) { return ((pix >> 1) & 1) | (((pix >> 3) & 1) << 1); }
@@ -169,6 +170,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_kernel(WgradMParams p)
 
     if (!wave_live) return;
     const int co_l = lane & 15;
+    if (p.slab) {       // deterministic mode: park this wave's partial sums, wgrad_mfma_reduce_kernel adds the splits in order
+        float* sl = p.slab + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (size_t)(NT * 4096);
+#pragma unroll
+        for (int tap = 0; tap < NT; ++tap)
+#pragma unroll
+            for (int cob = 0; cob < NCO; ++cob) {
+                if (cob0 + cob >= 4) continue;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sl[tap * 4096 + (cb * 16 + g * 4 + j) * 64 + (cob0 + cob) * 16 + co_l] = acc[tap][cob][j];
+            }
+        return;
+    }
 #pragma unroll
     for (int tap = 0; tap < NT; ++tap)
 #pragma unroll
@@ -181,6 +194,21 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_kernel(WgradMParams p)
                 if (ci < p.Cs) atomicAdd(p.dw + ((size_t)tap * p.Cin_total + p.cbase + ci) * p.Cout + co, acc[tap][cob][j]);
             }
         }
+}
+
+// deterministic mode, second stage: one thread per (tile, tap, ci, co); adds the splits' slabs in split order (fp64 accumulate)
+__global__ void wgrad_mfma_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nsplit, int tiles, int co_tiles, int nt,
+                                         int Cs, int Cout, int Cin_total, int cbase) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t per_tile = (size_t)nt * 4096;
+    if (e >= (size_t)tiles * per_tile) return;
+    const int tile = (int)(e / per_tile), r = (int)(e % per_tile);
+    const int tap = r / 4096, ci = (tile / co_tiles) * 64 + (r % 4096) / 64, co = (tile % co_tiles) * 64 + r % 64;
+    if (ci >= Cs || co >= Cout) return;
+    double s = 0.0;
+    for (int z = 0; z < nsplit; ++z) s += (double)slab[((size_t)z * tiles + tile) * per_tile + r];
+    float* d = dw + ((size_t)tap * Cin_total + cbase + ci) * Cout + co;
+    *d = (float)((double)*d + s);
 }
 
 }  // namespace
@@ -225,6 +253,14 @@ int ie_wgrad_mfma_launch(const void* x, const void* dy, int dtype, float* dw_hwi
     const long ychunks = ie_cdiv(H, p.rows_per_wg);
     const dim3 grid((unsigned)tiles, (unsigned)strips, (unsigned)ychunks);
     const bool h = dtype == IE_F16;
+    const int ntap = ksize == 3 ? 9 : 1;
+    p.slab = nullptr;
+    if (ie_get_deterministic()) {
+        void* ws_det = nullptr;
+        const int rc = ie_det_workspace((size_t)strips * ychunks * tiles * ntap * 4096 * sizeof(float), &ws_det);
+        if (rc != IE_OK) return rc;
+        p.slab = (float*)ws_det;
+    }
 #define WM_LAUNCH(KS_, NCO_)                                                                                              \
     do {                                                                                                                  \
         if (h) hipLaunchKernelGGL((conv_wgrad_mfma_kernel<_Float16, KS_, NCO_>), grid, dim3(256), 0, stream, p);          \
@@ -237,5 +273,11 @@ int ie_wgrad_mfma_launch(const void* x, const void* dy, int dtype, float* dw_hwi
     }
 #undef WM_LAUNCH
     IE_LAUNCH_CHECK();
+    if (p.slab) {
+        const size_t total = (size_t)tiles * ntap * 4096;
+        hipLaunchKernelGGL(wgrad_mfma_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p.slab, dw_hwio,
+                           (int)(strips * ychunks), (int)tiles, p.co_tiles, ntap, cs, cout, cin_total, cbase);
+        IE_LAUNCH_CHECK();
+    }
     return IE_OK;
 }

@@ -25,6 +25,8 @@
 // operand in registers, HBM rows DMA'd once into LDS rings (buffer_load ... lds) behind counted
 // vmcnt waits, every pixel fragment feeding three MFMAs (ky = 0,1,2) into rotating accumulators.
 #include "ie_zdce_internal.h"
+#include <string.h>
+#include <stdlib.h>
 
 namespace {
 

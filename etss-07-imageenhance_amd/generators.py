@@ -7,6 +7,8 @@
   zero_ig_re      ZeroIG         src/mon/vision/enhance/llie/zero_ig/zero_ig.py:257-304, 355-452 (predicting branch)
   rrdnet_re       RRDNet_RE      src/mon/vision/enhance/llie/rrdnet/rrdnet.py:183-289
   zsn2n           ZSN2N          src/mon/vision/enhance/denoise/zsn2n/zsn2n.py:40-124
+  zero_dce_v      ZeroDCEV       src/mon/vision/enhance/llie/zero_dce/zero_dce_v.py:87-230 (+ filtering/guided_filter.py:150-204)
+  gcenet          GCENet         src/mon/vision/enhance/llie/gcenet/gcenet.py:203-309, 338-502 (+ guided_filter.py:99-147, prior/image.py:221-331)
   retinexnet      RetinexNet     src/mon_extra/vision/enhance/llie/retinexnet/model.py:21-90, 199-238
 
 Same registry names, constructor hyper-parameters, checkpoint key names and output dicts as the reference
@@ -94,6 +96,45 @@ class _GraphModel(ImageEnhancementModel):
             self._dev_cache[key] = ops.MConvWeights(w, b, split, self._tdt, self.device, cin_map)
         return ops.mconv2d(srcs, self._dev_cache[key], stride=stride, pad=pad, pad_mode=pad_mode, act=act, slope=slope,
                            residual=residual, clamp=clamp, out_f32=out_f32)
+
+    def _ds_block(self, prefix, srcs, act, out_f32=False, slope=0.0):
+        """DepthwiseSeparableConv2d ``prefix`` (dsconv.py:106-149: ``prefix.dw_conv`` 3x3 depthwise + ``prefix.pw_conv`` 1x1) over the channel
+        concat of ``srcs``, + activation.  Depthwise over the concat == depthwise per source with the matching weight slice."""
+        outs, off, valid = [], 0, []
+        f32 = self.compute_dtype == "f32"
+        if self._dev_cache is None:
+            self._dev_cache = {}
+        wdw, bdw = self._params[f"{prefix}.dw_conv.weight"], self._params[f"{prefix}.dw_conv.bias"]
+        split = tuple(int(t.shape[1]) for t in srcs)
+        if not f32 and sum(split) == wdw.shape[0] and split != (8,):
+            # fused depthwise + pointwise kernel (the depthwise result stays in LDS); the 8-channel RGB input takes the unfused path
+            key = ("dsfused", prefix, split)
+            if key not in self._dev_cache:
+                pw = ops.MConvWeights(self._params[f"{prefix}.pw_conv.weight"], self._params[f"{prefix}.pw_conv.bias"], list(split), self._tdt, self.device)
+                self._dev_cache[key] = (wdw[:, 0].reshape(wdw.shape[0], 9).contiguous().to(self.device), bdw.to(self.device).contiguous(), pw)
+            dw_w, dw_b, pw = self._dev_cache[key]
+            return ops.dsconv2d(list(srcs), dw_w, dw_b, pw, act=act, slope=slope, out_f32=out_f32)
+        for t in srcs:
+            c = t.shape[1]
+            real = min(c, wdw.shape[0] - off)         # 16-bit path: the RGB input is carried as 8 channels
+            key = ("dw", prefix, off, c)
+            if key not in self._dev_cache:
+                if f32:
+                    self._dev_cache[key] = ops.ConvWeights(wdw[off:off + c], bdw[off:off + c], self.device)
+                else:
+                    wt = torch.zeros(9, c)
+                    wt[:, :real] = wdw[off:off + real, 0].reshape(real, 9).t()
+                    bt = torch.zeros(c)
+                    bt[:real] = bdw[off:off + real]
+                    self._dev_cache[key] = (wt.contiguous().to(self.device), bt.to(self.device))
+            if f32:
+                outs.append(ops.depthwise_conv2d(t, self._dev_cache[key]))
+            else:
+                outs.append(ops.depthwise3x3_16(t, *self._dev_cache[key]))
+            valid.append(real)
+            off += real
+        return self._conv(outs, f"{prefix}.pw_conv", pad=0, act=act, slope=slope, out_f32=out_f32,
+                          valid=None if f32 or valid == [t.shape[1] for t in outs] else valid)
 
     def _on_params_change(self):
         self._dev_cache = None
@@ -228,41 +269,7 @@ class ZeroDCEpp_RE(_GraphModel):
         self._on_params_change()
 
     def _ds(self, k, srcs, act, out_f32=False):
-        # depthwise over the concat == depthwise per source with the matching weight slice
-        outs, off, valid = [], 0, []
-        f32 = self.compute_dtype == "f32"
-        if self._dev_cache is None:
-            self._dev_cache = {}
-        wdw, bdw = self._params[f"e_conv{k}.dw_conv.weight"], self._params[f"e_conv{k}.dw_conv.bias"]
-        split = tuple(int(t.shape[1]) for t in srcs)
-        if not f32 and sum(split) == wdw.shape[0] and split != (8,):
-            # fused depthwise + pointwise kernel (the depthwise result stays in LDS); the 8-channel RGB input takes the unfused path
-            key = ("dsfused", k, split)
-            if key not in self._dev_cache:
-                pw = ops.MConvWeights(self._params[f"e_conv{k}.pw_conv.weight"], self._params[f"e_conv{k}.pw_conv.bias"], list(split), self._tdt, self.device)
-                self._dev_cache[key] = (wdw[:, 0].reshape(wdw.shape[0], 9).contiguous().to(self.device), bdw.to(self.device).contiguous(), pw)
-            dw_w, dw_b, pw = self._dev_cache[key]
-            return ops.dsconv2d(list(srcs), dw_w, dw_b, pw, act=act, out_f32=out_f32)
-        for s in srcs:
-            c = s.shape[1]
-            real = min(c, wdw.shape[0] - off)         # 16-bit path: the RGB input is carried as 8 channels
-            key = ("dw", k, off, c)
-            if key not in self._dev_cache:
-                if f32:
-                    self._dev_cache[key] = ops.ConvWeights(wdw[off:off + c], bdw[off:off + c], self.device)
-                else:
-                    wt = torch.zeros(9, c)
-                    wt[:, :real] = wdw[off:off + real, 0].reshape(real, 9).t()
-                    bt = torch.zeros(c)
-                    bt[:real] = bdw[off:off + real]
-                    self._dev_cache[key] = (wt.contiguous().to(self.device), bt.to(self.device))
-            if f32:
-                outs.append(ops.depthwise_conv2d(s, self._dev_cache[key]))
-            else:
-                outs.append(ops.depthwise3x3_16(s, *self._dev_cache[key]))
-            valid.append(real)
-            off += real
-        return self._conv(outs, f"e_conv{k}.pw_conv", pad=0, act=act, out_f32=out_f32, valid=None if f32 or valid == [t.shape[1] for t in outs] else valid)
+        return self._ds_block(f"e_conv{k}", srcs, act, out_f32)
 
     def forward(self, datapoint: dict, *args, **kwargs) -> dict:
         x = self._input(datapoint)
@@ -803,6 +810,143 @@ class ZSN2N(_GraphModel):
         y = self._conv(y, "conv2", act="lrelu", slope=0.2)
         y = self._conv(y, "conv3", pad=0, clamp=(0.0, 1.0) if self.predicting else None, out_f32=True)
         return OrderedDict(enhanced=ops.to_nchw(y))
+
+
+# ----------------------------------------------------------------------------------------------------------------
+@MODELS.register(name="zero_dce_v", arch="zero_dce")
+class ZeroDCEV(_GraphModel):
+    """Zero-DCE-V (zero_dce_v.py:87-230): the curve net runs on the HSV V channel at ``down_size`` x ``down_size`` (nearest), the
+    curve is applied there (``num_iters`` = 15 maps), a FastGuidedFilter(radius 1) carries the result to full resolution
+    (bicubic interpolation of the linear coefficients), V is replaced, HSV -> RGB and the frame is divided by its maximum.
+    Outputs ``image_v, image_v_lr, adjust, image_v_fixed_lr, image_v_fixed, enhanced`` (:206-213).  Keys ``e_conv{1..7}``."""
+
+    arch = "zero_dce"
+    tasks = [Task.LLIE]
+    schemes = [Scheme.UNSUPERVISED, Scheme.ZERO_REFERENCE, Scheme.INSTANCE]
+
+    def __init__(self, in_channels: int = 1, num_channels: int = 32, num_iters: int = 15, down_size: int = 256, weights: Any = None,
+                 seed: int = None, *args, **kwargs):
+        kwargs.pop("name", None)
+        super().__init__(name="zero_dce_v", in_channels=3, weights=weights, *args, **kwargs)
+        if isinstance(self.weights, dict):
+            in_channels = self.weights.get("in_channels", in_channels)
+            num_channels = self.weights.get("num_channels", num_channels)
+            num_iters = self.weights.get("num_iters", num_iters)
+            down_size = self.weights.get("down_size", down_size)
+        if in_channels != 1:
+            raise ValueError("zero_dce_v: the curve net works on the one-channel V image (in_channels = 1)")
+        self.net_channels, self.num_channels, self.num_iters, self.down_size = in_channels, num_channels, num_iters, down_size
+        c, o = num_channels, in_channels * num_iters
+        for k, (ci, co) in enumerate([(in_channels, c), (c, c), (c, c), (c, c), (2 * c, c), (2 * c, c), (2 * c, o)], 1):
+            self._params[f"e_conv{k}.weight"], self._params[f"e_conv{k}.bias"] = torch.zeros(co, ci, 3, 3), torch.zeros(co)
+        self._finish_init(seed)
+
+    def init_weights(self, seed: int = None):
+        g = self._gen(seed)            # zero_dce_v.py:151-157: conv weight ~ N(0, 0.02), bias torch default
+        for k in range(1, 8):
+            self._init_conv(f"e_conv{k}", g, std=0.02)
+        self._on_params_change()
+
+    def forward(self, datapoint: dict, *args, **kwargs) -> dict:
+        rgb = self._input(datapoint)
+        hsv, v = ops.rgb_to_hsv(rgb)
+        v_lr = ops.resize(v, (self.down_size, self.down_size), "nearest")
+        x = v_lr if self.compute_dtype == "f32" else ops.cast(v_lr, self._tdt, 8)
+        c = self._conv
+        x1 = c(x, "e_conv1", act="relu")
+        x2 = c(x1, "e_conv2", act="relu")
+        x3 = c(x2, "e_conv3", act="relu")
+        x4 = c(x3, "e_conv4", act="relu")
+        x5 = c([x3, x4], "e_conv5", act="relu")
+        x6 = c([x2, x5], "e_conv6", act="relu")
+        xr = c([x1, x6], "e_conv7", act="tanh", out_f32=True)
+        v_fixed_lr = ops.le_curve(v_lr, xr, self.num_iters)
+        v_fixed = ops.fast_guided_filter(v_lr, v_fixed_lr, v, radius=1, eps=1e-8, clip=(0.0, 1.0))
+        enhanced = ops.div_by_max(ops.hsv_to_rgb(hsv, v_fixed))
+        out = OrderedDict(image_v=ops.to_nchw(v), image_v_lr=ops.to_nchw(v_lr), adjust=ops.to_nchw(xr), image_v_fixed_lr=ops.to_nchw(v_fixed_lr),
+                          image_v_fixed=ops.to_nchw(v_fixed))
+        out["enhanced"] = ops.to_nchw(enhanced)
+        return out
+
+
+# ----------------------------------------------------------------------------------------------------------------
+@MODELS.register(name="gcenet", arch="gcenet")
+class GCENet(_GraphModel):
+    """GCENet (gcenet.py:338-502): ``EnhanceNet`` (:238-309) = seven DSConv2d + LeakyReLU(0.2) blocks (the last with tanh; ``norm=None`` as
+    the model builds it, :387) on [image, depth, edge] with Zero-DCE's concat pattern -> ONE 3-channel curve map; edge =
+    BoundaryAwarePrior(depth) (Sobel magnitude / max > ``dba_eps``); the curve runs ``num_iters`` times in its brightness-attention
+    form (bam = (1 - V(median_blur(image, bam_ksize)))^bam_gamma, :478-484) and the result goes through GuidedFilter(gf_radius,
+    gf_eps)(image, enhanced).  ``datapoint`` needs ``depth`` (N,1,H,W) when ``use_depth``.  Keys ``en.e_conv{k}.conv.{dw,pw}_conv``."""
+
+    arch = "gcenet"
+    tasks = [Task.LLIE]
+    schemes = [Scheme.UNSUPERVISED, Scheme.ZERO_REFERENCE]
+
+    def __init__(self, in_channels: int = 3, num_channels: int = 32, num_iters: int = 15, dba_eps: float = 0.05, gf_radius: int = 3,
+                 gf_eps: float = 1e-4, bam_gamma: float = 2.6, bam_ksize: int = 9, use_depth: bool = True, use_edge: bool = True,
+                 weights: Any = None, seed: int = None, debug: bool = False, *args, **kwargs):
+        kwargs.pop("name", None)
+        super().__init__(name="gcenet", in_channels=in_channels, weights=weights, *args, **kwargs)
+        if self.compute_dtype != "f32":
+            raise capi.IEError("gcenet: only the fp32 path is built (compute_dtype='f32')")
+        self.num_channels, self.num_iters, self.dba_eps, self.gf_radius, self.gf_eps = num_channels, num_iters, dba_eps, gf_radius, gf_eps
+        self.bam_gamma, self.bam_ksize, self.use_depth, self.use_edge, self.debug = bam_gamma, bam_ksize, use_depth, use_edge, debug
+        ci0 = in_channels + (1 if use_depth else 0) + (1 if use_edge else 0)
+        c = num_channels
+        for k, (ci, co) in enumerate([(ci0, c), (c, c), (c, c), (c, c), (2 * c, c), (2 * c, c), (2 * c, 3)], 1):
+            P, n = self._params, f"en.e_conv{k}.conv"
+            P[f"{n}.dw_conv.weight"], P[f"{n}.dw_conv.bias"] = torch.zeros(ci, 1, 3, 3), torch.zeros(ci)
+            P[f"{n}.pw_conv.weight"], P[f"{n}.pw_conv.bias"] = torch.zeros(co, ci, 1, 1), torch.zeros(co)
+        self._finish_init(seed)
+
+    def init_weights(self, seed: int = None):
+        g = self._gen(seed)            # gcenet.py:268-281: dw / pw conv weights ~ N(0, 0.02)
+        for k in range(1, 8):
+            self._init_conv(f"en.e_conv{k}.conv.dw_conv", g, std=0.02)
+            self._init_conv(f"en.e_conv{k}.conv.pw_conv", g, std=0.02)
+        self._on_params_change()
+
+    def _gray(self, x):
+        if self._dev_cache is None:
+            self._dev_cache = {}
+        if "gray" not in self._dev_cache:      # kornia.color.rgb_to_grayscale: 0.299 R + 0.587 G + 0.114 B, as a 1x1 convolution
+            self._dev_cache["gray"] = ops.ConvWeights(torch.tensor([0.299, 0.587, 0.114]).reshape(1, 3, 1, 1), None, self.device)
+        return ops.conv2d([x], self._dev_cache["gray"], pad=0)
+
+    def forward(self, datapoint: dict, *args, **kwargs) -> dict:
+        image = self._input(datapoint)
+        depth = datapoint.get("depth")
+        if depth is not None:
+            depth = ops.to_nhwc(depth.to(self.device, torch.float32))
+            if depth.shape[1] == 3:
+                depth = self._gray(depth)
+        if self.use_depth and depth is None:
+            raise ValueError("gcenet: `depth` must be given in the datapoint when use_depth=True")
+        srcs, edge = [image], None
+        if self.use_depth:
+            srcs.append(depth)
+        if self.use_edge:
+            edge = ops.threshold_of_max(ops.sobel(depth if depth is not None else self._gray(image), 1e-6), self.dba_eps)
+            srcs.append(edge)
+        B = lambda k, ss, act="lrelu", f32=False: self._ds_block(f"en.e_conv{k}.conv", ss, act, f32, 0.2)
+        x1 = B(1, srcs); x2 = B(2, [x1]); x3 = B(3, [x2]); x4 = B(4, [x3])
+        x5 = B(5, [x3, x4]); x6 = B(6, [x2, x5])
+        adjust = B(7, [x1, x6], "tanh", True)
+        bam = None
+        if self.bam_gamma not in (None, 0.0):
+            blurred = ops.median_blur(image, self.bam_ksize) if self.bam_ksize else image
+            _, v = ops.rgb_to_hsv(blurred, want_hsv=False)
+            bam = ops.pow_scalar(ops.affine(v, -1.0, 1.0), self.bam_gamma)                    # (1 - v)^gamma
+        enhanced = ops.le_curve(image, adjust, self.num_iters, bam)
+        enhanced = ops.guided_filter(image, enhanced, self.gf_radius, self.gf_eps)
+        out = OrderedDict()
+        if self.debug:
+            out["adjust"] = ops.to_nchw(adjust)
+            out["depth"] = None if depth is None else ops.to_nchw(depth)
+            out["edge"] = None if edge is None else ops.to_nchw(edge)
+            out["bam"] = None if bam is None else ops.to_nchw(bam)
+        out["enhanced"] = ops.to_nchw(enhanced)
+        return out
 
 
 # ----------------------------------------------------------------------------------------------------------------

@@ -286,6 +286,130 @@ def pow_scalar(a, exponent):
     return _elt(7, a, None, exponent, 0.0)
 
 
+def div_by_max(a) -> torch.Tensor:
+    """a / max(a) over the whole tensor (zero_dce_v.py:205); the maximum stays on the device."""
+    _chk(a)
+    m = torch.empty(1, device=a.device, dtype=torch.float32)
+    ws = torch.empty(1024, device=a.device, dtype=torch.float32)
+    y = torch.empty_like(a, memory_format=CL)
+    n, c, h, w = a.shape
+    with torch.cuda.device(a.device):
+        capi.check(capi.lib().ie_reduce_max_f32(capi.ptr(a), a.numel(), capi.ptr(m), capi.ptr(ws), capi.current_stream()), "ie_reduce_max_f32")
+        capi.check(capi.lib().ie_eltwise_nhwc_f32(8, capi.ptr(a), capi.ptr(m), capi.ptr(y), n * h * w, c, 1, 0.0, 0.0, capi.current_stream()),
+                   "ie_eltwise_nhwc_f32")
+    return y
+
+
+def threshold_of_max(a, thr) -> torch.Tensor:
+    """(a / max(a) > thr).float() (BoundaryAwarePrior, nn/modules/prior/image.py:205-208)."""
+    _chk(a)
+    m = torch.empty(1, device=a.device, dtype=torch.float32)
+    ws = torch.empty(1024, device=a.device, dtype=torch.float32)
+    y = torch.empty_like(a, memory_format=CL)
+    n, c, h, w = a.shape
+    with torch.cuda.device(a.device):
+        capi.check(capi.lib().ie_reduce_max_f32(capi.ptr(a), a.numel(), capi.ptr(m), capi.ptr(ws), capi.current_stream()), "ie_reduce_max_f32")
+        capi.check(capi.lib().ie_eltwise_nhwc_f32(9, capi.ptr(a), capi.ptr(m), capi.ptr(y), n * h * w, c, 1, thr, 0.0, capi.current_stream()),
+                   "ie_eltwise_nhwc_f32")
+    return y
+
+
+def rgb_to_hsv(x, eps=1e-8, want_hsv=True, want_v=True):
+    """core.rgb_to_hsv / core.rgb_to_v on an fp32 NHWC RGB tensor -> (hsv (N,3,H,W) or None, v (N,1,H,W) or None)."""
+    _chk(x)
+    n, c, h, w = x.shape
+    if c != 3:
+        raise ValueError(f"rgb_to_hsv needs 3 channels, got {c}")
+    hsv = empty_nhwc(n, 3, h, w, x.device) if want_hsv else None
+    v = empty_nhwc(n, 1, h, w, x.device) if want_v else None
+    with torch.cuda.device(x.device):
+        capi.check(capi.lib().ie_rgb_to_hsv_nhwc_f32(capi.ptr(x), capi.ptr(hsv), capi.ptr(v), n * h * w, eps, capi.current_stream()), "ie_rgb_to_hsv_nhwc_f32")
+    return hsv, v
+
+
+def hsv_to_rgb(hsv, v_new=None):
+    _chk(hsv)
+    n, c, h, w = hsv.shape
+    y = torch.empty_like(hsv, memory_format=CL)
+    with torch.cuda.device(hsv.device):
+        capi.check(capi.lib().ie_hsv_to_rgb_nhwc_f32(capi.ptr(hsv), capi.ptr(v_new), capi.ptr(y), n * h * w, capi.current_stream()), "ie_hsv_to_rgb_nhwc_f32")
+    return y
+
+
+def le_curve(x, adjust, iters, bam=None):
+    """LE curve on an fp32 NHWC image of C channels with C*iters (or C: shared) curve maps; ``bam``: GCENet's attention form."""
+    _chk(x); _chk(adjust)
+    n, c, h, w = x.shape
+    y = torch.empty_like(x, memory_format=CL)
+    with torch.cuda.device(x.device):
+        capi.check(capi.lib().ie_le_curve_nhwc_f32(capi.ptr(x), capi.ptr(adjust), capi.ptr(bam), capi.ptr(y), n * h * w, c, int(adjust.shape[1]),
+                                                   iters, capi.current_stream()), "ie_le_curve_nhwc_f32")
+    return y
+
+
+def box_filter(x, radius):
+    _chk(x)
+    n, c, h, w = x.shape
+    y = torch.empty_like(x, memory_format=CL)
+    with torch.cuda.device(x.device):
+        capi.check(capi.lib().ie_box_filter_nhwc_f32(capi.ptr(x), capi.ptr(y), n, h, w, c, radius, capi.current_stream()), "ie_box_filter_nhwc_f32")
+    return y
+
+
+def guided_filter(x, y, radius, eps=1e-8):
+    """GuidedFilter(radius, eps)(image=x, guide=y) (guided_filter.py:99-147)."""
+    _chk(x); _chk(y)
+    n, cy, h, w = y.shape
+    out = torch.empty_like(y, memory_format=CL)
+    ws = torch.empty(2 * y.numel(), device=y.device, dtype=torch.float32)
+    with torch.cuda.device(y.device):
+        capi.check(capi.lib().ie_guided_filter_nhwc_f32(capi.ptr(x), capi.ptr(y), capi.ptr(out), capi.ptr(ws), n, h, w, int(x.shape[1]), cy, radius, eps,
+                                                        capi.current_stream()), "ie_guided_filter_nhwc_f32")
+    return out
+
+
+def fast_guided_filter(x_lr, y_lr, x_hr, radius, eps=1e-8, clip=None):
+    """FastGuidedFilter(radius, eps)(x_lr, y_lr, x_hr) (guided_filter.py:150-204), optionally clipped."""
+    _chk(x_lr); _chk(y_lr); _chk(x_hr)
+    n, cy, h, w = y_lr.shape
+    H, W = int(x_hr.shape[2]), int(x_hr.shape[3])
+    out = empty_nhwc(n, cy, H, W, x_hr.device)
+    ws = torch.empty(2 * y_lr.numel(), device=y_lr.device, dtype=torch.float32)
+    lo, hi = clip if clip is not None else (0.0, 0.0)
+    with torch.cuda.device(x_hr.device):
+        capi.check(capi.lib().ie_fast_guided_filter_nhwc_f32(capi.ptr(x_lr), capi.ptr(y_lr), capi.ptr(x_hr), capi.ptr(out), capi.ptr(ws), n, h, w, H, W,
+                                                             int(x_lr.shape[1]), cy, radius, eps, 1 if clip is not None else 0, lo, hi,
+                                                             capi.current_stream()), "ie_fast_guided_filter_nhwc_f32")
+    return out
+
+
+def resize_bicubic_align(x, size):
+    _chk(x)
+    n, c, h, w = x.shape
+    y = empty_nhwc(n, c, size[0], size[1], x.device)
+    with torch.cuda.device(x.device):
+        capi.check(capi.lib().ie_resize_bicubic_nhwc_f32(capi.ptr(x), capi.ptr(y), n, h, w, size[0], size[1], c, capi.current_stream()), "ie_resize_bicubic_nhwc_f32")
+    return y
+
+
+def median_blur(x, ksize):
+    _chk(x)
+    n, c, h, w = x.shape
+    y = torch.empty_like(x, memory_format=CL)
+    with torch.cuda.device(x.device):
+        capi.check(capi.lib().ie_median_blur_nhwc_f32(capi.ptr(x), capi.ptr(y), n, h, w, c, ksize, capi.current_stream()), "ie_median_blur_nhwc_f32")
+    return y
+
+
+def sobel(x, eps=1e-6):
+    _chk(x)
+    n, c, h, w = x.shape
+    y = torch.empty_like(x, memory_format=CL)
+    with torch.cuda.device(x.device):
+        capi.check(capi.lib().ie_sobel_nhwc_f32(capi.ptr(x), capi.ptr(y), n, h, w, c, eps, capi.current_stream()), "ie_sobel_nhwc_f32")
+    return y
+
+
 def mul_prefix(a, b) -> torch.Tensor:
     """y = a[:, :C] * b for a with C+1 channels and a single-channel b (RetinexNet: S = R * I_delta)."""
     _chk(a); _chk(b)

@@ -496,10 +496,11 @@ class Trainer:
     ``model`` must implement ``forward_train(image_nhwc, store: ParamStore, tape: Tape) -> enhanced (NHWC tensor)``.
     ``optimizer``: ``{"name": "adam", "lr": ..., "betas": (..), "eps": .., "weight_decay": ..}`` like the reference configs'
     ``optimizers[0]["optimizer"]``; ``gradient_clip_val`` like the Lightning trainer config (norm clipping).
-    ``process_group``: torch.distributed group for data parallelism (default group when initialised)."""
+    ``process_group``: torch.distributed group for data parallelism (default group when initialised).
+    ``deterministic``: weight gradients through the two-stage fixed-order reduction (run-to-run bit-identical steps)."""
 
     def __init__(self, model, optimizer: dict | None = None, loss=None, gradient_clip_val: float | None = 0.1, process_group=None,
-                 compute_dtype: str = "f32", loss_scale: float | None = None):
+                 compute_dtype: str = "f32", loss_scale: float | None = None, deterministic: bool = False):
         if not hasattr(model, "forward_train"):
             raise capi.IEError(f"{model.__class__.__name__} has no training graph (forward_train)")
         model._require_cuda()
@@ -521,6 +522,8 @@ class Trainer:
         if not isinstance(self.loss, Loss):
             raise TypeError("`loss` must be a mon_amd.losses.Loss or its config dict")
         self.group = process_group
+        if deterministic:                     # process-wide switch of the library (capi.set_deterministic)
+            capi.set_deterministic(True)
         cd = {capi.IE_F32: "f32", capi.IE_F16: "f16", capi.IE_BF16: "bf16"}[capi.DTYPES[str(compute_dtype).lower()]]
         if cd != "f32" and not getattr(model, "supports_mixed_training", False):
             raise capi.IEError(f"{model.__class__.__name__} has no 16-bit training graph")

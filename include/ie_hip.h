@@ -133,7 +133,8 @@ int ie_pad_nhwc_f32(const float* x_dev, float* y_dev, int N, int H, int W, int C
 /* op 0: a + b, 1: a * b (b with C or 1 channels), 2: clamp(a, lo, hi), 3: y(C ch) = a[:, :C] * b where a has
  * C+1 channels and b one (S = R * I_delta with R = first 3 of DecomNet's 4 outputs, retinexnet/model.py:49-50,238),
  * 4: a - b, 5: clamp(a / b, lo, hi) (zero_ig.py:441-442, rrdnet.py:277), 6: a * lo + hi (zero_ig.py:438 `image + eps`),
- * 7: pow(a, lo) (rrdnet.py:276), 8: a / b[0] with b ONE device float (zero_dce_v.py:205 `x / torch.max(x)`). */
+ * 7: pow(a, lo) (rrdnet.py:276), 8: a / b[0] with b ONE device float (zero_dce_v.py:205 `x / torch.max(x)`),
+ * 9: (a / b[0] > lo) ? 1 : 0 (nn/modules/prior/image.py:206-208). */
 int ie_eltwise_nhwc_f32(int op, const float* a_dev, const float* b_dev, float* y_dev, size_t npix, int C, int Cb, float lo, float hi, void* stream);
 /* [max_c(x), x] channel concat (retinexnet/model.py:45-46). */
 int ie_max_concat_nhwc_f32(const float* x_dev, float* y_dev, size_t npix, int C, void* stream);
@@ -254,6 +255,14 @@ int ie_ssim_forward_f32(const float* x_dev, const float* y_dev, int N, int C, in
 int ie_ssim_backward_f32(const float* x_dev, const float* y_dev, const float* d_ws_dev, const double* sum_dev, float* grad_dev, int N,
                          int C, int H, int W, int64_t sn, int64_t sc, int64_t sh, int64_t sw, float sigma, float scale,
                          int non_negative, int accumulate, void* stream);
+/* Deterministic mode (process-wide switch, default off).  On: the conv weight gradients (ie_convn_wgrad_nhwc[_f32]) replace their
+ * split-K fp32 atomics by a two-stage reduce -- every split parks its partial tile in a library-owned scratch slab and a second
+ * kernel adds the slabs in a fixed order with fp64 accumulation -- so the same inputs give the same bits of dW on every run.  The
+ * scratch grows on demand (hipMalloc + device synchronisation on growth: not inside a graph capture).  The remaining reductions of
+ * the training path (norm statistics, bias gradients, loss sums) accumulate in fp64 with atomics and round to fp32 ONCE: their
+ * result changes only when an fp64 sum falls within ~1e-16 relative of an fp32 rounding boundary. */
+int ie_set_deterministic(int on);
+int ie_get_deterministic(void);
 /* *acc_dev (+)= sum (scale*a_i)^2 -- global gradient norm for torch.nn.utils.clip_grad_norm_ (Lightning gradient_clip_val).
  * Deterministic (no atomics): identical inputs give the identical bits on every data-parallel replica.
  * ws_dev: IE_SUMSQ_WS_DOUBLES doubles of scratch. */
@@ -311,6 +320,41 @@ int ie_tv_loss_nhwc_f32(const float* a_dev, int N, int H, int W, int C, float we
  * grad_enhanced (NCHW).  The image receives no gradient (it is the network input). */
 int ie_le_curve_backward(const float* img_dev, const float* adjust_nhwc_dev, int Cp, const float* grad_enhanced_dev,
                          float* grad_adjust_nhwc_dev, int N, int H, int W, int iters, int accumulate, void* stream);
+
+/* ---- colour space, guided filter and the generalised LE curve (ie_filter.hip): the V-channel / guided curve models --------
+ * ZeroDCEV (src/mon/vision/enhance/llie/zero_dce/zero_dce_v.py:172-230), GCENet (.../gcenet/gcenet.py:460-502),
+ * filters src/mon/vision/filtering/guided_filter.py:99-204 and box_filter.py:24-110.  fp32 NHWC.  The kornia functions the
+ * reference calls there (rgb_to_hsv, hsv_to_rgb, median_blur, sobel) are restated from kornia's published algorithms. */
+/* core.rgb_to_hsv (core/image/color.py:171-195 -> kornia.color.rgb_to_hsv): h in [0, 2 pi), s, v.  hsv_dev (3 ch) and / or
+ * v_dev (1 ch, core.rgb_to_v, :198-218) may be NULL. */
+int ie_rgb_to_hsv_nhwc_f32(const float* rgb_dev, float* hsv_dev, float* v_dev, size_t npix, float eps, void* stream);
+/* core.hsv_to_rgb (:274-291 -> kornia.color.hsv_to_rgb); v_new_dev (1 ch, may be NULL) replaces the V channel first
+ * (ZeroDCEV.replace_v_component, zero_dce_v.py:225-230). */
+int ie_hsv_to_rgb_nhwc_f32(const float* hsv_dev, const float* v_new_dev, float* rgb_dev, size_t npix, void* stream);
+/* y <- y + r_k (y^2 - y), k < iters, on a C-channel NHWC image with Ca = C*iters curve maps (Ca == C: one shared map);
+ * bam_dev (1 ch, may be NULL): GCENet's brightness-attention form, gcenet.py:478-484 (bright = y (1 - bam), dark = y bam,
+ * y = bright + dark + r (dark^2 - dark)). */
+int ie_le_curve_nhwc_f32(const float* x_dev, const float* adjust_dev, const float* bam_dev, float* y_dev, size_t npix, int C, int Ca,
+                         int iters, void* stream);
+/* Un-normalised box filter: window sums over (2r+1)^2 clipped to the image == box_filter.py:24-110 (cumsum differences). */
+int ie_box_filter_nhwc_f32(const float* x_dev, float* y_dev, int N, int H, int W, int C, int radius, void* stream);
+/* GuidedFilter(radius, eps)(image = x, guide = y) (guided_filter.py:99-147): out = mean_A * x + mean_b.  Cx = 1 or Cy.
+ * ws_dev: 2 * N*H*W*Cy floats. */
+int ie_guided_filter_nhwc_f32(const float* x_dev, const float* y_dev, float* out_dev, float* ws_dev, int N, int H, int W, int Cx, int Cy,
+                              int radius, float eps, void* stream);
+/* FastGuidedFilter(radius, eps)(x_lr, y_lr, x_hr) (guided_filter.py:150-204): coefficients at (h, w), bicubic (align_corners)
+ * interpolation to (H, W), out = A * x_hr + b, clipped to [lo, hi] when clip (ZeroDCEV.filter_up).  ws_dev: 2 * N*h*w*Cy floats. */
+int ie_fast_guided_filter_nhwc_f32(const float* x_lr_dev, const float* y_lr_dev, const float* x_hr_dev, float* out_dev, float* ws_dev, int N,
+                                   int h, int w, int H, int W, int Cx, int Cy, int radius, float eps, int clip, float lo, float hi,
+                                   void* stream);
+/* F.interpolate(mode="bicubic", align_corners=True) (guided_filter.py:201-202). */
+int ie_resize_bicubic_nhwc_f32(const float* x_dev, float* y_dev, int N, int h, int w, int H, int W, int C, void* stream);
+/* *out_dev = max over n floats (two deterministic stages; ws_dev: 1024 floats) -- `x / torch.max(x)` (zero_dce_v.py:205). */
+int ie_reduce_max_f32(const float* a_dev, size_t n, float* out_dev, float* ws_dev, void* stream);
+/* kornia.filters.median_blur (k x k, zero padding; nn/modules/prior/image.py:271) and kornia.filters.sobel magnitude
+ * (replicate padding, un-normalised kernel; prior/image.py:205). */
+int ie_median_blur_nhwc_f32(const float* x_dev, float* y_dev, int N, int H, int W, int C, int ksize, void* stream);
+int ie_sobel_nhwc_f32(const float* x_dev, float* y_dev, int N, int H, int W, int C, float eps, void* stream);
 
 /* ---- LE curve (zero_dce.py:186-188) ------------------------------------ */
 /* y <- y + r_i (y^2 - y), i < iters; img NCHW fp32 (N,3,H,W); adjust NHWC fp32

@@ -404,8 +404,9 @@ def test_unet_training_steps_match_torch(upsampler, h, w):
     for step, (img, tgt) in enumerate(batches):
         out = tr.training_step({"image": img, "ref_image": tgt})
         assert list(out)[:2] == ["enhanced", "loss"]
-        # step 0 starts from identical weights and is held tight.  Later steps start from weights that differ by rounding (fp32
-        # atomics in the weight gradient sum in a different order every run), and a ReLU / max-pool decision that flips on
+        # step 0 starts from identical weights and is held tight.  Later steps start from weights that differ from the float64
+        # oracle's by fp32 rounding (of the step-0 update itself, whatever the summation order: the deterministic mode removes
+        # the run-to-run part, test_training_steps_deterministic_run_to_run), and a ReLU / max-pool decision that flips on
         # such a difference moves a gradient by a fraction of a percent: they are held to a few percent.
         loose = 1.0 if step == 0 else 150.0
         assert abs(float(out["loss"]) - log[step]["loss"][0]) < 2e-5 * loose, (step, float(out["loss"]), log[step]["loss"])
@@ -425,6 +426,82 @@ def test_unet_training_steps_match_torch(upsampler, h, w):
     model2.predicting = True
     out = model2.forward({"image": batches[0][0].cuda()})
     assert out["enhanced"].shape == (2, 3, h, w)
+
+
+def test_deterministic_weight_gradient_bitwise_reproducible():
+    """ie_set_deterministic(1): split-K partial tiles are parked in slabs and added in a fixed order (fp64 accumulate) instead of
+    fp32 atomics.  Same inputs -> same bits, on the fp32 kernel and on the matrix-core kernel; and the result agrees with the
+    atomic path to rounding."""
+    g = torch.Generator().manual_seed(4)
+    n, ci, co, h, w = 2, 40, 72, 45, 70
+    x = torch.randn(n, ci, h, w, generator=g)
+    dy = torch.randn(n, co, h, w, generator=g)
+    wt = torch.randn(co, ci, 3, 3, generator=g) * 0.1
+    ref = torch.nn.grad.conv2d_weight(x.double(), wt.shape, dy.double(), padding=1)
+    prev = capi.set_deterministic(True)
+    try:
+        for tdt, tol in ((torch.float32, 2e-5), (torch.bfloat16, 2e-2)):
+            xd = x.to(tdt).cuda().contiguous(memory_format=CL)
+            dd = dy.to(tdt).cuda().contiguous(memory_format=CL)
+            cw = ops.ConvWeights(wt, None, "cuda")
+            outs = []
+            for _ in range(3):
+                dw = torch.full((9 * ci * co,), 7.0, device="cuda")
+                ops.conv2d_wgrad([xd], dd, cw, dw, None, 1, 1, "zeros")
+                outs.append(dw.clone())
+            assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2]), tdt
+            got = outs[0].reshape(3, 3, ci, co).permute(3, 2, 0, 1).cpu()
+            r = torch.nn.grad.conv2d_weight(x.to(tdt).double(), wt.shape, dy.to(tdt).double(), padding=1) if tdt != torch.float32 else ref
+            assert rel_err(got, r) < (tol if tdt == torch.float32 else 1e-4), tdt       # 16-bit inputs, exact products, fp32/fp64 sums
+            capi.set_deterministic(False)
+            dw = torch.zeros(9 * ci * co, device="cuda")
+            ops.conv2d_wgrad([xd], dd, cw, dw, None, 1, 1, "zeros")
+            assert rel_err(dw, outs[0]) < 1e-5
+            capi.set_deterministic(True)
+    finally:
+        capi.set_deterministic(prev)
+
+
+@pytest.mark.parametrize("cdt", ["f32", "bf16"])
+def test_training_steps_deterministic_run_to_run(cdt):
+    """Three optimiser steps of U-Net, twice from the same initial state with Trainer(deterministic=True): every parameter
+    bit-identical.  (Norm statistics, bias gradients and loss sums accumulate in fp64 with atomics and round ONCE to fp32: they
+    can differ only when an fp64 sum lands within ~1e-16 relative of an fp32 rounding boundary.)"""
+    prev = capi.set_deterministic(False)
+    try:
+        finals = []
+        for _ in range(2):
+            model = _unet("bilinear", base=16)
+            tr = mon_amd.Trainer(model, optimizer={"name": "adam", "lr": 1e-3}, loss={"name": "l1_ssim_loss"}, gradient_clip_val=0.1,
+                                 compute_dtype=cdt, deterministic=True)
+            for img, tgt in _batches(2, 64, 96, 3, seed=5):
+                tr.training_step({"image": img, "ref_image": tgt})
+            assert tr.step == 3 and tr.last_step_applied
+            finals.append(tr.state_dict())
+        for k in finals[0]:
+            assert torch.equal(finals[0][k], finals[1][k]), k
+    finally:
+        capi.set_deterministic(prev)
+
+
+def test_overflowed_step_is_skipped_without_clipping():
+    """fp16 graph, gradient_clip_val = 0: an inf in the gradients must leave parameters, both Adam moments and the step counter
+    untouched (GradScaler semantics), and the next finite step must apply with bias correction t = 1."""
+    model = _unet("bilinear", base=16)
+    tr = mon_amd.Trainer(model, optimizer={"name": "adam", "lr": 1e-3}, loss={"name": "l1_ssim_loss"}, gradient_clip_val=0.0, compute_dtype="f16")
+    img, tgt = _batches(1, 32, 48, 1, seed=6)[0]
+    out = tr.forward_loss({"image": img, "ref_image": tgt})
+    tr.backward(out)
+    st = tr.store
+    p0, m0, v0 = st.params.clone(), st.exp_avg.clone(), st.exp_avg_sq.clone()
+    st.grads[123] = float("inf")
+    tr.optimizer_step()
+    assert tr.step == 0 and not tr.last_step_applied
+    assert torch.equal(st.params, p0) and torch.equal(st.exp_avg, m0) and torch.equal(st.exp_avg_sq, v0)
+    st.grads[123] = 0.0
+    tr.optimizer_step()
+    assert tr.step == 1 and tr.last_step_applied
+    assert not torch.equal(st.params, p0) and bool(torch.isfinite(st.params).all())
 
 
 def test_trainer_requires_target_and_graph():
