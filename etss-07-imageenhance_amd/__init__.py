@@ -19,9 +19,9 @@ from . import image
 from . import sharding
 from . import losses, train
 from .losses import LOSSES
-from .train import Trainer
+from .train import Trainer, ModelCheckpoint, get_latest_checkpoint
 
 __version__ = "0.1.0"
 __all__ = ["Factory", "ModelFactory", "MODELS", "Task", "Scheme", "capi", "Model", "VisionModel",
            "ImageEnhancementModel", "ZeroDCE_RE", "ZeroDCEpp_RE", "LLUnetpp_RE", "UNet", "ZeroIGEnhance", "ZeroIG", "RRDNet_RE", "ZSN2N", "ZeroDCEV", "GCENet", "RetinexNet", "HINet_RE",
-           "ops", "image", "sharding", "losses", "train", "LOSSES", "Trainer"]
+           "ops", "image", "sharding", "losses", "train", "LOSSES", "Trainer", "ModelCheckpoint", "get_latest_checkpoint"]

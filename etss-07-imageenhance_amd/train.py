@@ -656,12 +656,15 @@ class Trainer:
 
     # ---- checkpoint / resume (Lightning's ModelCheckpoint writes {"state_dict", "optimizer_states", "global_step", ...};
     #      nn/callback/model_checkpoint.py:35-185 -- the same top-level keys are used so mon's loaders find "state_dict") ----
-    def save_checkpoint(self, path) -> str:
+    def save_checkpoint(self, path, weights_only: bool = False, epoch: int = 0) -> str:
+        """Lightning-shaped checkpoint: ``state_dict`` / ``epoch`` / ``global_step`` always (what mon's loaders read,
+        nn/model.py:45-76, 129-130), the optimiser state unless ``weights_only`` (the ``.pt`` twin of ModelCheckpoint)."""
         st = self.store
-        ckpt = {"state_dict": self.state_dict(), "global_step": self.step,
-                "optimizer_states": [{"name": "adam", "lr": self.lr, "betas": list(self.betas), "eps": self.eps, "weight_decay": self.weight_decay,
-                                      "exp_avg": self.store.export(st.exp_avg), "exp_avg_sq": self.store.export(st.exp_avg_sq)}],
-                "gradient_clip_val": self.clip, "model": self.model.name}
+        ckpt = {"state_dict": self.state_dict(), "epoch": int(epoch), "global_step": self.step, "model": self.model.name}
+        if not weights_only:
+            ckpt["optimizer_states"] = [{"name": "adam", "lr": self.lr, "betas": list(self.betas), "eps": self.eps, "weight_decay": self.weight_decay,
+                                         "exp_avg": self.store.export(st.exp_avg), "exp_avg_sq": self.store.export(st.exp_avg_sq)}]
+            ckpt["gradient_clip_val"] = self.clip
         import os
         os.makedirs(os.path.dirname(os.path.abspath(str(path))) or ".", exist_ok=True)
         torch.save(ckpt, str(path))
@@ -699,3 +702,83 @@ class Trainer:
             self.model._params[k] = v
         self.model._on_params_change()
         return self.model
+
+
+# ---- checkpoint callback with the reference's file naming (nn/callback/model_checkpoint.py:35-185) ---------------------------------
+TORCH_FILE_FORMATS = (".pt", ".pth", ".weights", ".ckpt", ".tar")        # globals.py:708 (is_torch_file)
+
+
+class ModelCheckpoint:
+    """``<dirpath>/weights/<filename>_best[_<metric>].ckpt`` and, with ``save_last``, ``<filename>_last.ckpt``; every ``.ckpt`` gets a
+    weights-only ``.pt`` twin (model_checkpoint.py:167-170), because mon's weight loaders accept ``.pt`` / ``.pth`` only
+    (globals.py:709).  Always top-1, like the reference (``save_top_k`` forced to 1).  ``filename`` defaults to the model's
+    ``fullname`` (:89-110).  Call ``on_validation_end(trainer, epoch, metrics)`` (or ``save``) from the fit loop."""
+
+    CHECKPOINT_JOIN_CHAR, CHECKPOINT_NAME_LAST, CHECKPOINT_NAME_BEST, FILE_EXTENSION = "_", "last", "best", ".ckpt"
+
+    def __init__(self, dirpath, filename: str | None = None, monitor: str | None = None, mode: str = "min", save_last: bool = False,
+                 save_weights_only: bool = False, auto_insert_metric_name: bool = True):
+        import os
+        if mode not in ("min", "max"):
+            raise ValueError(f"`mode` must be 'min' or 'max', but got {mode}.")
+        dirpath = str(dirpath)
+        self.dirpath = dirpath if os.path.basename(os.path.normpath(dirpath)) == "weights" else os.path.join(dirpath, "weights")
+        self.filename, self.monitor, self.mode, self.save_last = filename, monitor, mode, save_last
+        self.save_weights_only, self.auto_insert_metric_name = save_weights_only, auto_insert_metric_name
+        self.best_model_score, self.best_model_path, self.last_model_path = None, "", ""
+        self._last_epoch_saved = self._last_global_step_saved = 0
+
+    def format_checkpoint_name(self, kind: str) -> str:
+        name = self.CHECKPOINT_NAME_LAST if "last" in kind else self.CHECKPOINT_NAME_BEST
+        if name == self.CHECKPOINT_NAME_BEST and self.auto_insert_metric_name and self.monitor:
+            name += "_" + self.monitor.replace("/", "_")
+        if self.filename not in (None, "None", ""):
+            name = f"{self.filename}_{name}"
+        import os
+        return os.path.join(self.dirpath, name + self.FILE_EXTENSION)
+
+    def _write(self, trainer, path, epoch):
+        trainer.save_checkpoint(path.replace(self.FILE_EXTENSION, ".pt"), True, epoch)
+        trainer.save_checkpoint(path, self.save_weights_only, epoch)
+        self._last_epoch_saved, self._last_global_step_saved = int(epoch), int(trainer.step)
+
+    def on_validation_end(self, trainer, epoch: int = 0, metrics: dict | None = None) -> list[str]:
+        """Saves ``best`` when the monitored value improved (or always without a monitor) and ``last`` when asked to."""
+        if self.filename is None and getattr(trainer.model, "fullname", None):
+            self.filename = trainer.model.fullname
+        written = []
+        score = None if self.monitor is None else float((metrics or {})[self.monitor])
+        better = score is None or self.best_model_score is None or (score < self.best_model_score if self.mode == "min" else score > self.best_model_score)
+        if better:
+            self.best_model_score, self.best_model_path = score, self.format_checkpoint_name("best")
+            self._write(trainer, self.best_model_path, epoch)
+            written.append(self.best_model_path)
+        if self.save_last:
+            self.last_model_path = self.format_checkpoint_name("last")
+            self._write(trainer, self.last_model_path, epoch)
+            written.append(self.last_model_path)
+        return written
+
+    save = on_validation_end
+
+    def state_dict(self) -> dict:
+        return {"dirpath": self.dirpath, "monitor": self.monitor, "last_epoch_saved": self._last_epoch_saved,
+                "last_global_step_saved": self._last_global_step_saved, "best_model_score": self.best_model_score,
+                "best_model_path": self.best_model_path, "last_model_path": self.last_model_path}
+
+
+def get_latest_checkpoint(dirpath):
+    """Newest torch file under ``dirpath`` by modification time (nn/model.py:79-92); None when there is none."""
+    import os
+    found = []
+    for root, _, files in os.walk(str(dirpath)):
+        found += [os.path.join(root, f) for f in files if f.endswith(TORCH_FILE_FORMATS)]
+    return max(found, key=lambda f: os.stat(f).st_mtime) if found else None
+
+
+def get_epoch_from_checkpoint(ckpt) -> int:
+    return 0 if ckpt is None else int(torch.load(str(ckpt), map_location="cpu", weights_only=True).get("epoch", 0))
+
+
+def get_global_step_from_checkpoint(ckpt) -> int:
+    return 0 if ckpt is None else int(torch.load(str(ckpt), map_location="cpu", weights_only=True).get("global_step", 0))

@@ -55,14 +55,43 @@ def l1_ssim_loss(x, y, l1_weight=1.0, ssim_weight=1.0, data_range=1.0, non_negat
     return l1_weight * l1_loss(x, y) + ssim_weight * ssim_loss(x, y, data_range, non_negative)
 
 
-def unet_forward_train(p: dict, buffers: dict, x, upsampler="bilinear", enhance=True):
-    """p: parameters (requires_grad), buffers: running statistics (updated in place, momentum 0.1)."""
+class _StorageRound(torch.autograd.Function):
+    """y = x rounded to a 16-bit storage format, and the gradient arriving at y rounded the same way: what a tensor (and its
+    gradient buffer) kept in bf16 / fp16 between two kernels of the engine's 16-bit training graph goes through."""
+
+    @staticmethod
+    def forward(ctx, x, dt):
+        ctx.dt = dt
+        return x.to(dt).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.dt).to(g.dtype), None
+
+
+def storage_rounding(dt):
+    """(activation rounding, weight rounding) callables for ``unet_forward_train(..., q=...)``: activations and their gradients are
+    stored in ``dt``; weights are READ in ``dt`` (the packed copies of the fp32 master weights) while their gradient stays exact."""
+    act = lambda t: _StorageRound.apply(t, dt)
+    wgt = lambda w: w + (w.detach().to(dt).to(w.dtype) - w.detach())
+    return act, wgt
+
+
+def unet_forward_train(p: dict, buffers: dict, x, upsampler="bilinear", enhance=True, q=None):
+    """p: parameters (requires_grad), buffers: running statistics (updated in place, momentum 0.1).
+    ``q = storage_rounding(dtype)``: restates the engine's 16-bit training graph -- every tensor between two kernels (conv output,
+    norm + ReLU output, resized map) and its gradient rounded to ``dtype``, weights read in ``dtype``, arithmetic in x's dtype --
+    so that a comparison isolates kernel error from storage rounding."""
+    qa, qw = q if q is not None else ((lambda t: t), (lambda w: w))
+
     def bn(n, t):
         return F.batch_norm(t, buffers[f"{n}.running_mean"], buffers[f"{n}.running_var"], p[f"{n}.weight"], p[f"{n}.bias"], True, 0.1, 1e-5)
 
     def dc(n, t):
-        t = F.relu(bn(f"{n}.norm1", F.conv2d(t, p[f"{n}.conv1.weight"], None, padding=1)))
-        return F.relu(bn(f"{n}.norm2", F.conv2d(t, p[f"{n}.conv2.weight"], None, padding=1)))
+        t = qa(F.relu(bn(f"{n}.norm1", qa(F.conv2d(t, qw(p[f"{n}.conv1.weight"]), None, padding=1)))))
+        return qa(F.relu(bn(f"{n}.norm2", qa(F.conv2d(t, qw(p[f"{n}.conv2.weight"]), None, padding=1)))))
+    if q is not None:
+        x = qa(x.detach().clone())
     x1 = dc("inc", x)
     x2 = dc("down1.conv", F.max_pool2d(x1, 2))
     x3 = dc("down2.conv", F.max_pool2d(x2, 2))
@@ -71,14 +100,14 @@ def unet_forward_train(p: dict, buffers: dict, x, upsampler="bilinear", enhance=
 
     def up(k, a, skip):
         if upsampler == "bilinear":
-            a = F.interpolate(a, scale_factor=2, mode="bilinear", align_corners=True)
+            a = qa(F.interpolate(a, scale_factor=2, mode="bilinear", align_corners=True))
         else:
-            a = F.pixel_shuffle(F.conv2d(a, p[f"up{k}.up.0.weight"], p[f"up{k}.up.0.bias"], padding=1), 2)
+            a = F.pixel_shuffle(qa(F.conv2d(a, qw(p[f"up{k}.up.0.weight"]), p[f"up{k}.up.0.bias"], padding=1)), 2)
         dy, dx = skip.shape[2] - a.shape[2], skip.shape[3] - a.shape[3]
         a = F.pad(a, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])
         return dc(f"up{k}.conv", torch.cat([skip, a], 1))
     y = up(1, x5, x4); y = up(2, y, x3); y = up(3, y, x2); y = up(4, y, x1)
-    y = F.conv2d(y, p["outc.conv.weight"], p["outc.conv.bias"])
+    y = qa(F.conv2d(y, qw(p["outc.conv.weight"]), p["outc.conv.bias"]))
     return torch.clamp(y, 0, 1) if enhance else y
 
 

@@ -466,3 +466,36 @@ def test_gcenet_vs_oracle():
     got = nodepth.forward({"image": x.cuda()})["enhanced"].cpu()
     want = of.gcenet_forward(nodepth.state_dict(), x, None, use_depth=False, bam_gamma=0.0)["enhanced"]
     assert rel_err(got, want) <= 1e-3
+
+
+# ---- BASELINE.json configs[2] / configs[3] at their frame size: properties that need no CPU reference ---------------------------------
+@pytest.mark.parametrize("cfg", [dict(name="unet", base_channels=32, num_classes=3, enhance=True, upsampler="pixelshuffle"),
+                                 dict(name="unet", base_channels=32, num_classes=3, enhance=True),
+                                 dict(name="retinexnet")], ids=["unet32-pixelshuffle", "unet32-bilinear", "retinexnet"])
+def test_1080p_properties_unet32_retinexnet(cfg):
+    """1920x1080 frames through the bf16 matrix-core path (the configuration bench.py's extras time): determinism, batch
+    independence, agreement of a crop on its interior (U-Net's receptive field is larger than any practical crop, so that check
+    runs on RetinexNet's DecomNet half only), output range, and agreement with the fp32 parity path of the SAME graph on one frame
+    within the 16-bit bound of the small-size oracle tests."""
+    g = torch.Generator().manual_seed(11)
+    x = (torch.rand(2, 3, 1080, 1920, generator=g) ** 2.2 * 0.5).cuda()
+    m = mon_amd.MODELS.build(seed=3, compute_dtype="bf16", **cfg).to("cuda")
+    a = m.forward({"image": x})
+    b = m.forward({"image": x})
+    for k in a:
+        assert torch.equal(a[k], b[k]), k                                        # deterministic
+    one = m.forward({"image": x[1:2]})
+    for k in a:
+        assert torch.equal(a[k][1:2], one[k]), k                                 # frames are independent
+    e = a["enhanced"]
+    assert tuple(e.shape) == (2, 3, 1080, 1920) and bool(torch.isfinite(e).all())
+    m32 = mon_amd.MODELS.build(seed=3, compute_dtype="f32", **cfg).to("cuda")
+    ref = m32.forward({"image": x[:1]})["enhanced"]
+    assert rel_err(e[:1].cpu(), ref.cpu()) <= 1.5e-2                             # TOL16["bf16"] of the oracle tests above
+    if cfg["name"] == "unet":
+        assert float(e.min()) >= 0.0 and float(e.max()) <= 1.0                   # enhance=True clamps (llunetpp.py:241-242)
+    else:
+        # DecomNet: 7 convolutions, receptive radius 4 + 6 = 10 (replicate padding only touches the border): a crop's reflectance
+        # agrees with the full frame's away from its edges
+        crop = m.forward({"image": x[:1, :, 400:560, 700:1000].contiguous()})["reflectance"]
+        assert torch.equal(crop[:, :, 10:-10, 10:-10], a["reflectance"][:1, :, 410:550, 710:990])

@@ -152,3 +152,41 @@ def test_padded_edge_row_maps_and_tape_bookkeeping():
     assert T._real_c(y) == 16
     y._ie_real = 3
     assert T._real_c(y) == 3
+
+
+def test_model_checkpoint_reference_naming(tmp_path):
+    """nn/callback/model_checkpoint.py:35-185: <dir>/weights/<fullname>_best[_metric].ckpt (+ _last), each with a weights-only
+    .pt twin; top-1 on the monitored value; get_latest_checkpoint picks the newest torch file (nn/model.py:79-92)."""
+    import time
+    import torch
+    from mon_amd import train as T
+
+    class FakeTrainer:
+        step = 0
+
+        class model:
+            fullname = "zero_dce_re_sice_mix"
+
+        def save_checkpoint(self, path, weights_only=False, epoch=0):
+            d = {"state_dict": {"w": torch.zeros(1)}, "epoch": epoch, "global_step": self.step}
+            if not weights_only:
+                d["optimizer_states"] = [{}]
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            torch.save(d, path)
+
+    tr = FakeTrainer()
+    cb = T.ModelCheckpoint(tmp_path / "run", monitor="val/psnr", mode="max", save_last=True)
+    assert cb.dirpath.endswith(os.path.join("run", "weights"))
+    tr.step = 10
+    w = cb.on_validation_end(tr, epoch=1, metrics={"val/psnr": 20.0})
+    assert [os.path.basename(f) for f in w] == ["zero_dce_re_sice_mix_best_val_psnr.ckpt", "zero_dce_re_sice_mix_last.ckpt"]
+    assert os.path.exists(w[0].replace(".ckpt", ".pt")) and "optimizer_states" not in torch.load(w[0].replace(".ckpt", ".pt"))
+    tr.step = 20
+    time.sleep(0.02)
+    w = cb.on_validation_end(tr, epoch=2, metrics={"val/psnr": 19.0})            # worse: only `last` is rewritten
+    assert [os.path.basename(f) for f in w] == ["zero_dce_re_sice_mix_last.ckpt"] and cb.best_model_score == 20.0
+    latest = T.get_latest_checkpoint(tmp_path / "run")
+    assert os.path.basename(latest).startswith("zero_dce_re_sice_mix_last") and T.get_global_step_from_checkpoint(latest) == 20
+    assert T.get_epoch_from_checkpoint(cb.best_model_path) == 1 and cb.state_dict()["last_global_step_saved"] == 20
+    assert T.get_latest_checkpoint(tmp_path / "nothing") is None
+    assert T.ModelCheckpoint(tmp_path / "weights").dirpath == str(tmp_path / "weights")
