@@ -10,7 +10,8 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno
 KEY=$(printf '%s' "$FLAGS" | md5sum | cut -c1-10)
 OBJ=_obj/$KEY
 mkdir -p "$OBJ"
-# signature of the headers a source includes (transitively, csrc/ie_*.h and the public ABI header)
+# signature of the csrc/ie_*.h headers a source includes (transitively).  The public ABI header include/ie_hip.h is NOT part of it
+# (new declarations would recompile every file, ~4 minutes): after changing one of ITS structs, enums or macros run with IE_FORCE=1.
 hdr_sig() {
     local seen="" todo="$1" f inc
     while [ -n "$todo" ]; do
@@ -18,6 +19,7 @@ hdr_sig() {
         case " $seen " in *" $f "*) continue;; esac
         seen="$seen $f"
         for inc in $(grep -o '#include "[^"]*"' "$f" | sed 's/#include "//; s/"//'); do
+            case "$inc" in */include/ie_hip.h) continue;; esac
             [ -f "$inc" ] && todo="$todo $inc"
         done
     done
@@ -26,7 +28,7 @@ hdr_sig() {
 todo=""
 for s in $SRCS; do
     sig="$(hdr_sig "$s")"
-    if [ ! -f "$OBJ/$s.o" ] || [ "$(cat "$OBJ/$s.sig" 2>/dev/null)" != "$sig" ]; then
+    if [ -n "$IE_FORCE" ] || [ ! -f "$OBJ/$s.o" ] || [ "$(cat "$OBJ/$s.sig" 2>/dev/null)" != "$sig" ]; then
         todo="$todo $s"; rm -f "$OBJ/$s.sig"; echo "$sig" > "$OBJ/$s.sig.new"   # the signature of what is compiled NOW (edits during the build re-trigger)
     fi
 done

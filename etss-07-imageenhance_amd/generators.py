@@ -2,6 +2,7 @@
 
   zero_dce++_re   ZeroDCEpp_RE   src/mon/vision/enhance/llie/zero_dce/zero_dcepp.py:86-208 (DSConv2d: nn/modules/conv/dsconv.py:106-149)
   llunet++_re     LLUnetpp_RE    src/mon/vision/enhance/llie/llunetpp/llunetpp.py:97-243
+  lllinet         LLLINet        src/mon/vision/enhance/llie/lllinet/lllinet.py:97-260 (normalization.py:177-224, attention.py:1156-1182)
   unet            UNet           src/mon/vision/segment/unet/unet.py:35-197  (+ ``upsampler="pixelshuffle"``: nn/modules/encoder/edsr.py:88-123)
   zero_ig_enhance Enhance        src/mon/vision/enhance/llie/zero_ig/zero_ig.py:307-348
   zero_ig_re      ZeroIG         src/mon/vision/enhance/llie/zero_ig/zero_ig.py:257-304, 355-452 (predicting branch)
@@ -442,6 +443,96 @@ class LLUnetpp_RE(_GraphModel):
         x1_3 = B("conv1_3", [x1_0, x1_1, x1_2, up(x2_2)])
         x0_4 = B("conv0_4", [x0_0, x0_1, x0_2, x0_3, up(x1_3)])
         y = self._conv(x0_4, "final", pad=0, clamp=(0.0, 1.0), out_f32=True)
+        return OrderedDict(enhanced=ops.to_nchw(y))
+
+
+# ----------------------------------------------------------------------------------------------------------------
+@MODELS.register(name="lllinet", arch="lllinet")
+class LLLINet(_GraphModel):
+    """LLLINet (lllinet.py:97-260): the UNet++ grid of LLUnet++ with a different block (lllinet.py:97-156) --
+    x1 = SimAM(LeakyReLU(LearnableInstanceNorm(Conv3x3(x)))) (no norm in ``conv0_0``), x2 = Conv3x3(x1), x3 = cat[x2, Conv1x1(x)],
+    out = LeakyReLU(Conv3x3(LeakyReLU(Conv3x3(x3)))) + Conv1x1(x3) -- and denser decoder wiring (:235-253), final Conv1x1 + clamp[0, 1].
+    Keys per block ``conv1, norm1.{weight,bias,r}, conv2, conv3, conv4, conv1_3, conv3_4``; ``loss.*`` ignored.  fp32 path."""
+
+    arch = "lllinet"
+    tasks = [Task.LLIE]
+    schemes = [Scheme.SUPERVISED]
+
+    def __init__(self, in_channels: int = 3, out_channels: int = 3, weights: Any = None, loss_weights=None, seed: int = None, *args, **kwargs):
+        kwargs.pop("name", None)
+        super().__init__(name="lllinet", in_channels=in_channels, weights=weights, *args, **kwargs)
+        if self.compute_dtype != "f32":
+            raise capi.IEError("lllinet: only the fp32 path is built (compute_dtype='f32')")
+        if isinstance(self.weights, dict):
+            in_channels = self.weights.get("in_channels", in_channels)
+            out_channels = self.weights.get("out_channels", out_channels)
+        self.in_channels, self._out = in_channels, out_channels
+        self.predicting = True
+        f = [32, 64, 128, 256, 512]
+        io = {"conv0_0": (in_channels, f[0]), "conv1_0": (f[0], f[1]), "conv2_0": (f[1], f[2]), "conv3_0": (f[2], f[3]), "conv4_0": (f[3], f[4]),
+              "conv0_1": (f[0] + 2 * f[1], f[0]), "conv1_1": (f[1] + 2 * f[2], f[1]), "conv2_1": (f[2] + 2 * f[3], f[2]), "conv3_1": (f[3] + f[4], f[3]),
+              "conv0_2": (2 * f[0] + 2 * f[1], f[0]), "conv1_2": (2 * f[1] + 2 * f[2], f[1]), "conv2_2": (2 * f[2] + f[3], f[2]),
+              "conv0_3": (3 * f[0] + 2 * f[1], f[0]), "conv1_3": (3 * f[1] + f[2], f[1]), "conv0_4": (4 * f[0] + f[1], f[0])}
+        self._io = io
+        P = self._params
+        for b, (ci, co) in io.items():
+            P[f"{b}.conv1.weight"], P[f"{b}.conv1.bias"] = torch.zeros(ci, ci, 3, 3), torch.zeros(ci)
+            if b != "conv0_0":                                           # use_in=False there (lllinet.py:203)
+                P[f"{b}.norm1.weight"], P[f"{b}.norm1.bias"], P[f"{b}.norm1.r"] = torch.ones(ci), torch.zeros(ci), torch.full((ci,), 0.5)
+            P[f"{b}.conv2.weight"], P[f"{b}.conv2.bias"] = torch.zeros(ci, ci, 3, 3), torch.zeros(ci)
+            P[f"{b}.conv3.weight"], P[f"{b}.conv3.bias"] = torch.zeros(co, 2 * ci, 3, 3), torch.zeros(co)
+            P[f"{b}.conv4.weight"], P[f"{b}.conv4.bias"] = torch.zeros(co, co, 3, 3), torch.zeros(co)
+            P[f"{b}.conv1_3.weight"], P[f"{b}.conv1_3.bias"] = torch.zeros(ci, ci, 1, 1), torch.zeros(ci)
+            P[f"{b}.conv3_4.weight"], P[f"{b}.conv3_4.bias"] = torch.zeros(co, 2 * ci, 1, 1), torch.zeros(co)
+        P["final.weight"], P["final.bias"] = torch.zeros(out_channels, f[0], 1, 1), torch.zeros(out_channels)
+        self._finish_init(seed)
+
+    def init_weights(self, seed: int = None):
+        g = self._gen(seed)            # lllinet.py:226-227: init_weights is a no-op -> torch defaults; r = 0.5, norm weight 1 / bias 0
+        for k in list(self._params):
+            if k.endswith(".weight") and self._params[k].dim() == 4:
+                self._init_conv(k[:-7], g)
+        self._on_params_change()
+
+    def _block(self, b, srcs):
+        c = self._conv
+        x1 = c(srcs, f"{b}.conv1")
+        if f"{b}.norm1.r" in self._params:
+            x1 = ops.learnable_instance_norm(x1, self._vec(f"{b}.norm1.weight"), self._vec(f"{b}.norm1.bias"), self._vec(f"{b}.norm1.r"), 1e-5, "lrelu", 0.2)
+        else:
+            x1 = ops.channel_affine_act(x1, "lrelu", 0.2)
+        x1 = ops.simam(x1, 1e-4)
+        x2 = c(x1, f"{b}.conv2")
+        s13 = c(srcs, f"{b}.conv1_3", pad=0)
+        x34 = c([x2, s13], f"{b}.conv3_4", pad=0)
+        x3 = c([x2, s13], f"{b}.conv3", act="lrelu", slope=0.2)
+        return c(x3, f"{b}.conv4", act="lrelu", slope=0.2, residual=x34)
+
+    def forward(self, datapoint: dict, *args, **kwargs) -> dict:
+        x = self._input(datapoint)
+        if x.shape[2] % 16 or x.shape[3] % 16:
+            raise ValueError(f"LLLINet needs H and W divisible by 16 (got {x.shape[2]}x{x.shape[3]}); use infer(), which resizes to a "
+                             f"multiple of 32 like the reference (vision/model.py:106).")
+        B, up, pool = self._block, ops.upsample2x_bilinear, ops.maxpool2x2
+        x0_0 = B("conv0_0", [x])
+        x1_0 = B("conv1_0", [pool(x0_0)])
+        x2_0 = B("conv2_0", [pool(x1_0)])
+        x3_0 = B("conv3_0", [pool(x2_0)])
+        x4_0 = B("conv4_0", [pool(x3_0)])
+        x3_1 = B("conv3_1", [x3_0, up(x4_0)])
+        u3_0 = up(x3_0)
+        x2_1 = B("conv2_1", [x2_0, u3_0, up(x3_1)])
+        u2_0 = up(x2_0)
+        x1_1 = B("conv1_1", [x1_0, u2_0, up(x2_1)])
+        u1_0 = up(x1_0)
+        x0_1 = B("conv0_1", [x0_0, u1_0, up(x1_1)])
+        x2_2 = B("conv2_2", [x2_0, x2_1, up(x3_1)])
+        x1_2 = B("conv1_2", [x1_0, x1_1, up(x2_1), up(x2_2)])
+        x0_2 = B("conv0_2", [x0_0, x0_1, up(x1_1), up(x1_2)])
+        x1_3 = B("conv1_3", [x1_0, x1_1, x1_2, up(x2_2)])
+        x0_3 = B("conv0_3", [x0_0, x0_1, x0_2, up(x1_2), up(x1_3)])
+        x0_4 = B("conv0_4", [x0_0, x0_1, x0_2, x0_3, up(x1_3)])
+        y = self._conv(x0_4, "final", pad=0, clamp=(0.0, 1.0))
         return OrderedDict(enhanced=ops.to_nchw(y))
 
 

@@ -286,6 +286,66 @@ def pow_scalar(a, exponent):
     return _elt(7, a, None, exponent, 0.0)
 
 
+def channel_stats(x) -> torch.Tensor:
+    """(N, C, 2) fp64 {sum, sum of squares} over H*W of an fp32 NHWC tensor."""
+    _chk(x)
+    n, c, h, w = x.shape
+    st = torch.empty((n, c, 2), device=x.device, dtype=torch.float64)
+    with torch.cuda.device(x.device):
+        capi.check(capi.lib().ie_channel_stats_nhwc_f32(capi.ptr(x), capi.ptr(st), n, h, w, c, capi.current_stream()), "ie_channel_stats_nhwc_f32")
+    return st
+
+
+def channel_affine(x, scale, shift=None, act="none", slope=0.0) -> torch.Tensor:
+    """act(x * scale[n, c] + shift[n, c]) with (N, C) fp32 coefficient tensors."""
+    _chk(x)
+    n, c, h, w = x.shape
+    y = torch.empty_like(x, memory_format=CL)
+    with torch.cuda.device(x.device):
+        capi.check(capi.lib().ie_channel_affine_nhwc_f32(capi.ptr(x), capi.ptr(scale), capi.ptr(shift), capi.ptr(y), n, h, w, c, capi.ACT[act], slope,
+                                                         capi.current_stream()), "ie_channel_affine_nhwc_f32")
+    return y
+
+
+def channel_affine_act(x, act, slope=0.0) -> torch.Tensor:
+    """Plain activation as its own pass (x * 1 + 0 per channel): LeakyReLU after a conv whose norm is nn.Identity (lllinet.py:113-115)."""
+    n, c, h, w = x.shape
+    one = torch.ones((n, c), device=x.device, dtype=torch.float32)
+    return channel_affine(x, one, None, act, slope)
+
+
+def learnable_instance_norm(x, gamma, beta, r, eps=1e-5, act="none", slope=0.0) -> torch.Tensor:
+    """LearnableInstanceNorm2d (normalization.py:177-224) + activation: IN(x) * r + x * (1 - r)."""
+    n, c, h, w = x.shape
+    st = channel_stats(x)
+    scale = torch.empty((n, c), device=x.device, dtype=torch.float32)
+    shift = torch.empty_like(scale)
+    with torch.cuda.device(x.device):
+        capi.check(capi.lib().ie_lin_coeffs_f32(capi.ptr(st), capi.ptr(gamma), capi.ptr(beta), capi.ptr(r), capi.ptr(scale), capi.ptr(shift), n, c, h * w, eps,
+                                                capi.current_stream()), "ie_lin_coeffs_f32")
+    return channel_affine(x, scale, shift, act, slope)
+
+
+def simam(x, e_lambda=1e-4) -> torch.Tensor:
+    _chk(x)
+    n, c, h, w = x.shape
+    st = channel_stats(x)
+    y = torch.empty_like(x, memory_format=CL)
+    with torch.cuda.device(x.device):
+        capi.check(capi.lib().ie_simam_nhwc_f32(capi.ptr(x), capi.ptr(st), capi.ptr(y), n, h, w, c, e_lambda, capi.current_stream()), "ie_simam_nhwc_f32")
+    return y
+
+
+def global_avg_pool(x) -> torch.Tensor:
+    """nn.AdaptiveAvgPool2d(1): (N, C, 1, 1) fp32 NHWC."""
+    n, c, h, w = x.shape
+    st = channel_stats(x)
+    m = empty_nhwc(n, c, 1, 1, x.device)
+    with torch.cuda.device(x.device):
+        capi.check(capi.lib().ie_stats_mean_f32(capi.ptr(st), capi.ptr(m), n, c, h * w, capi.current_stream()), "ie_stats_mean_f32")
+    return m
+
+
 def div_by_max(a) -> torch.Tensor:
     """a / max(a) over the whole tensor (zero_dce_v.py:205); the maximum stays on the device."""
     _chk(a)

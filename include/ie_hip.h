@@ -356,6 +356,22 @@ int ie_reduce_max_f32(const float* a_dev, size_t n, float* out_dev, float* ws_de
 int ie_median_blur_nhwc_f32(const float* x_dev, float* y_dev, int N, int H, int W, int C, int ksize, void* stream);
 int ie_sobel_nhwc_f32(const float* x_dev, float* y_dev, int N, int H, int W, int C, float eps, void* stream);
 
+/* ---- per-(sample, channel) statistics and the layers built on them (ie_attn.hip) -------------------------------
+ * stats_dev: N*C*2 doubles {sum, sum of squares over H*W} (zeroed by the call). */
+int ie_channel_stats_nhwc_f32(const float* x_dev, double* stats_dev, int N, int H, int W, int C, void* stream);
+/* LearnableInstanceNorm2d (src/mon/nn/modules/normalization.py:177-224): y = IN(x; gamma, beta) * r + x * (1 - r) == x * scale + shift
+ * per (n, c); gamma / beta / r (C floats each) may be NULL (1, 0, 1).  scale_dev / shift_dev: N*C floats. */
+int ie_lin_coeffs_f32(const double* stats_dev, const float* gamma_dev, const float* beta_dev, const float* r_dev, float* scale_dev,
+                      float* shift_dev, int N, int C, int HW, float eps, void* stream);
+/* mean_dev[n][c] = sum / HW: nn.AdaptiveAvgPool2d(1) of the channel-attention layer (mprnet.py:60, 76). */
+int ie_stats_mean_f32(const double* stats_dev, float* mean_dev, int N, int C, int HW, void* stream);
+/* y = act(x * scale[n][c] + shift[n][c]) (shift_dev may be NULL): the apply pass of the learnable instance norm (+ LeakyReLU,
+ * lllinet.py:140-142) and the per-channel rescale of channel attention (mprnet.py:78). */
+int ie_channel_affine_nhwc_f32(const float* x_dev, const float* scale_dev, const float* shift_dev, float* y_dev, int N, int H, int W, int C,
+                               int act, float slope, void* stream);
+/* SimAM (src/mon/nn/modules/attention.py:1156-1182) from the statistics of its own input. */
+int ie_simam_nhwc_f32(const float* x_dev, const double* stats_dev, float* y_dev, int N, int H, int W, int C, float lambda, void* stream);
+
 /* ---- LE curve (zero_dce.py:186-188) ------------------------------------ */
 /* y <- y + r_i (y^2 - y), i < iters; img NCHW fp32 (N,3,H,W); adjust NHWC fp32
  * with Cp channels (first 3*iters used, already tanh'ed; 3 <= Cp < 3*iters: one

@@ -4,6 +4,7 @@
                        PINNED by tests/golden/zero_dcepp_*.npz (reference file mon_extra/.../zero_dce++/model.py)
   llunetpp_forward     src/mon/vision/enhance/llie/llunetpp/llunetpp.py:97-137, 218-243
                        PINNED by tests/golden/llunetpp_*.npz (reference file mon_extra/.../llunet++/model.py)
+  lllinet_forward      src/mon/vision/enhance/llie/lllinet/lllinet.py:97-260 (+ normalization.py:177-224, attention.py:1156-1182): parity unpinned.
   unet_forward         src/mon/vision/segment/unet/unet.py:35-197 with line 51's typo read as conv1; eval-mode BN.
                        parity unpinned (the reference class does not run as shipped); leaf ops are torch's.
   unet_ps variant      + Upsampler conv3x3 + nn.PixelShuffle(2) (nn/modules/encoder/edsr.py:88-123): parity unpinned.
@@ -83,6 +84,56 @@ def llunetpp_forward(sd: dict, x: torch.Tensor) -> dict:
     x3_1 = B("conv3_1", cat(x3_0, up(x4_0)))
     x2_2 = B("conv2_2", cat(x2_0, x2_1, up(x3_1)))
     x1_3 = B("conv1_3", cat(x1_0, x1_1, x1_2, up(x2_2)))
+    x0_4 = B("conv0_4", cat(x0_0, x0_1, x0_2, x0_3, up(x1_3)))
+    return {"enhanced": torch.clamp(_c(sd, "final", x0_4, padding=0), 0, 1)}
+
+
+# ---- LLLINet (parity unpinned: the mon package does not import here and the model has no mon_extra twin) ---------------------------
+def learnable_instance_norm(x, weight, bias, r, eps=1e-5):
+    """src/mon/nn/modules/normalization.py:208-224."""
+    xn = F.instance_norm(x, weight=weight, bias=bias, eps=eps)
+    rr = r.reshape(1, -1, 1, 1)
+    return xn * rr + x * (1 - rr)
+
+
+def simam(x, e_lambda=1e-4):
+    """src/mon/nn/modules/attention.py:1169-1182."""
+    n = x.shape[2] * x.shape[3] - 1
+    d = (x - x.mean(dim=[2, 3], keepdim=True)).pow(2)
+    v = d.sum(dim=[2, 3], keepdim=True) / n
+    return x * torch.sigmoid(d / (4 * (v + e_lambda)) + 0.5)
+
+
+def _lllinet_block(sd, b, x):
+    """src/mon/vision/enhance/llie/lllinet/lllinet.py:133-156."""
+    x1 = _c(sd, f"{b}.conv1", x)
+    if f"{b}.norm1.r" in sd:
+        x1 = learnable_instance_norm(x1, sd[f"{b}.norm1.weight"], sd[f"{b}.norm1.bias"], sd[f"{b}.norm1.r"])
+    x1 = simam(F.leaky_relu(x1, 0.2))
+    x2 = _c(sd, f"{b}.conv2", x1)
+    x3 = torch.cat([x2, _c(sd, f"{b}.conv1_3", x, padding=0)], 1)
+    x34 = _c(sd, f"{b}.conv3_4", x3, padding=0)
+    x3 = F.leaky_relu(_c(sd, f"{b}.conv3", x3), 0.2)
+    return F.leaky_relu(_c(sd, f"{b}.conv4", x3), 0.2) + x34
+
+
+def lllinet_forward(sd: dict, x: torch.Tensor) -> dict:
+    """lllinet.py:229-260."""
+    B = lambda n, t: _lllinet_block(sd, n, t)
+    pool = lambda t: F.max_pool2d(t, 2, 2)
+    up = lambda t: F.interpolate(t, scale_factor=2, mode="bilinear", align_corners=True)
+    cat = lambda *ts: torch.cat(ts, 1)
+    x0_0 = B("conv0_0", x)
+    x1_0 = B("conv1_0", pool(x0_0)); x2_0 = B("conv2_0", pool(x1_0)); x3_0 = B("conv3_0", pool(x2_0)); x4_0 = B("conv4_0", pool(x3_0))
+    x3_1 = B("conv3_1", cat(x3_0, up(x4_0)))
+    x2_1 = B("conv2_1", cat(x2_0, up(x3_0), up(x3_1)))
+    x1_1 = B("conv1_1", cat(x1_0, up(x2_0), up(x2_1)))
+    x0_1 = B("conv0_1", cat(x0_0, up(x1_0), up(x1_1)))
+    x2_2 = B("conv2_2", cat(x2_0, x2_1, up(x3_1)))
+    x1_2 = B("conv1_2", cat(x1_0, x1_1, up(x2_1), up(x2_2)))
+    x0_2 = B("conv0_2", cat(x0_0, x0_1, up(x1_1), up(x1_2)))
+    x1_3 = B("conv1_3", cat(x1_0, x1_1, x1_2, up(x2_2)))
+    x0_3 = B("conv0_3", cat(x0_0, x0_1, x0_2, up(x1_2), up(x1_3)))
     x0_4 = B("conv0_4", cat(x0_0, x0_1, x0_2, x0_3, up(x1_3)))
     return {"enhanced": torch.clamp(_c(sd, "final", x0_4, padding=0), 0, 1)}
 

