@@ -100,6 +100,13 @@ __device__ __forceinline__ float ie_curve_step(float y, float r) {
     const float v = r * u;
     return y + v;
 }
+// The same step as two FMAs (y*y - y, then r*u + y): what the 16-bit Zero-DCE kernels use -- their r already carries 16-bit
+// rounding (1e-4 .. 1e-3), so the reference's rounding ORDER (<= 1 ulp of fp32 per step) is not what limits them, and the curve's
+// VALU work competes with the matrix pipe for issue slots (8 steps x 3 channels per pixel: 96 -> 48 instructions).
+__device__ __forceinline__ float ie_curve_step_fma(float y, float r) {
+    const float u = __builtin_fmaf(y, y, -y);
+    return __builtin_fmaf(r, u, y);
+}
 // torchvision save_image rule: clamp(x*255+0.5, 0, 255) -> u8 (truncate).
 __device__ __forceinline__ unsigned char ie_quant_u8(float v) {
 #pragma clang fp contract(off)

@@ -92,7 +92,11 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     constexpr int NSA = (KIND == K67) ? 2 : ((KIND == K45 || KIND == K345) ? 1 : 0);   // stage A HBM sources (K12: image)
     constexpr int NFB = (KIND == K45 || KIND == K12 || KIND == K345) ? 18 : 9;         // stage B weight fragments (K12: e_conv2 + e_conv7a)
     constexpr int NW = (KIND == K67) ? 18 : NFB;                     // weight fragments held per wave (K12 stage A: 2, K67 / K345 stage A: 18)
-    constexpr int MARG = (KIND == K345) ? 2 : 1;                     // computed columns lost per side (one per LDS hand-off)
+    // K67 and K345 load NO halo columns for stage A's HBM rows (one 8-lane LDS-DMA instruction per tensor and row on the
+    // stage's busiest wave): the outermost computed column of stage A is then wrong too and one more column a side is dropped.
+    // At 1920 columns the strip count stays 16 (124- and 122-column pitches).
+    constexpr bool HALO = (KIND == K12 || KIND == K45);
+    constexpr int MARG = ((KIND == K345) ? 2 : 1) + (HALO ? 0 : 1);  // computed columns lost per side (one per LDS hand-off, one without halo)
     constexpr int TSK = TW - 2 * MARG;                               // stored columns = strip pitch
     // ---- LDS carve ------------------------------------------------------------------------------
     constexpr int NRA = (KIND == K45) ? PF + 3 : PF + 1;    // slots of the A rings (K45: B re-reads x3 two rows later)
@@ -199,7 +203,7 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (__attribute__((address_space(3))) void*)(slot_ + (2 * sw + j) * 1024), \
                                                      16, (int)off_, 0, 0, 0);                                          \
         }                                                                                                              \
-        if (sw == 0) {                                                                                                 \
+        if (HALO && sw == 0) {                                                                                         \
             const unsigned off_ = (row_b_ + halo_xoff) | rmask_;                                                       \
             if (lane < 8)                                                                                              \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (__attribute__((address_space(3))) void*)(slot_ + TW * PXB), 16, \
@@ -256,7 +260,7 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
             if constexpr (KIND == K67) {
                 // Waves 4 and 5 carry the curve of colour channel 2 and are the slowest of the step (in-kernel stamps); waves 6 and 7
                 // idle a third of it, so THEY issue all of stage B's DMA: the P row that seeds the output row started at step t
-                // (8 body pieces + halo) and the three fp32 image planes of the row whose curve runs at step t+2.
+                // (8 body pieces; P is read element-wise, it has no halo) and the three fp32 image planes of the row whose curve runs at step t+2.
                 if (sw >= 2) {
                     {
                         const int y = ys - 3 + t;
@@ -265,12 +269,6 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
                         char* slot = smem + OFF_BRING + (t % NRB) * ROW_B;
 #pragma unroll
                         for (int j = 0; j < 4; ++j) IE_DMA_PIECE(rsB, slot, (sw - 2) * 4 + j, row_b, rmask);
-                        if (sw == 2) {
-                            const unsigned off = (row_b + halo_xoff) | rmask;
-                            if (lane < 8)
-                                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(slot + TW * PXB), 16,
-                                                                         (int)off, 0, 0, 0);
-                        }
                     }
                     const int yo = ys - 5 + t;      // row finished at step t, consumed at step t+2
                     const unsigned rmask = ((yo >= ys) && (yo < ye)) ? 0u : OOB;
@@ -293,8 +291,8 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     // DMA instructions per step of this wave -> counted wait that leaves PF-1 younger rows in flight
     // Waves that issue no DMA do not wait at all; stage-A waves issue no stores, so their count is exact.
     int L = 0, S = 0;
-    if (stg == 0) { L = (KIND == K12) ? 2 : (2 * NSA + (sw == 0 ? NSA : 0)); }   // K345: NSA = 1
-    else if (KIND == K67) L = sw == 2 ? 7 : (sw == 3 ? 8 : 0);
+    if (stg == 0) { L = (KIND == K12) ? 2 : (2 * NSA + ((HALO && sw == 0) ? NSA : 0)); }   // K345: NSA = 1
+    else if (KIND == K67) L = sw == 2 ? 6 : (sw == 3 ? 8 : 0);
     const int wait_base = L ? (PF - 1) * L : -1;
     (void)S;
 
@@ -306,9 +304,9 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     int rd_first, rd_last;
     {
         const int xf = 64 * ph + p16 - 1;
-        rd_first = lds_px(xf < 0 ? TW : xf);
+        rd_first = lds_px(xf < 0 ? (HALO ? TW : 0) : xf);             // without halo DMA: any loaded pixel (the column is dropped)
         const int xl = 64 * ph + 48 + p16 + 1;
-        rd_last = lds_px(xl >= TW ? TW + 1 : xl);
+        rd_last = lds_px(xl >= TW ? (HALO ? TW + 1 : TW - 1) : xl);
     }
 
     // one source row into the three live accumulator sets
@@ -440,7 +438,7 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
         const int yo = ys - 5 + s_fin;
         const int q = tid & 127, c = tid >> 7;       // c = 0,1 on stage-A waves, 2 on stage-B waves 4,5; 3: idle
         const int xo = xc0 + q;
-        if (c < 3 && q >= 1 && q < TW - 1 && xo < W && yo >= ys && yo < ye) {
+        if (c < 3 && q >= MARG && q < TW - MARG && xo < W && yo >= ys && yo < ye) {
             const float* sp = (const float*)(smem + OFF_STAGE + (s_fin & 1) * STAGE_SLOT_B);
             const float* ip = (const float*)(smem + OFF_IMG + (s_fin % NRI) * IMG_SLOT_B);
             const size_t pix = (size_t)yo * W + xo;
@@ -452,7 +450,7 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
                 r[i] = ie_tanh_fast(sp[k * TW + ((q + 16 * ((k >> 2) & 1)) & (TW - 1))]);
             }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v = ie_curve_step(v, r[i]);
+            for (int i = 0; i < 8; ++i) v = ie_curve_step_fma(v, r[i]);
             if (p.enhanced) p.enhanced[((size_t)n * 3 + c) * plane + pix] = v;
             if (p.u8) p.u8[((size_t)n * plane + pix) * 3 + c] = ie_quant_u8(v);
             if (p.adjust) {
@@ -671,7 +669,7 @@ static int launch_fused_t(FusedFn fn, const ZdceFusedLaunch& a, hipStream_t st) 
     p.N = a.N; p.H = a.H; p.W = a.W; p.y_begin = a.y_begin; p.y_end = a.y_end; p.rows_per_block = a.rows_per_block;
     p.n_begin = a.n_begin;
     p.stamps = (unsigned long long*)a.stamps;
-    p.strips = ie_cdiv(a.W, KIND == K345 ? TW - 4 : TS);
+    p.strips = ie_cdiv(a.W, KIND == K345 ? TW - 6 : (KIND == K67 ? TW - 4 : TS));
     p.chunks = ie_cdiv(a.y_end - a.y_begin, a.rows_per_block);
     const long long blocks = (long long)p.strips * p.chunks * a.n_count;
     if (blocks <= 0 || blocks > 0x7fffffffLL) IE_FAIL(IE_ERR_INVALID, "zdce fused: bad grid %lld", blocks);

@@ -301,7 +301,7 @@ __global__ __launch_bounds__(NWAVE * 64, (NSRC == 1 ? 3 : 2)) void zdce_conv3x3_
             for (int c = 0; c < 3; ++c) {
                 float v = ip[c * TW + tid];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) v = ie_curve_step(v, sp[(3 * i + c) * TW + tid]);
+                for (int i = 0; i < 8; ++i) v = ie_curve_step_fma(v, sp[(3 * i + c) * TW + tid]);
                 y[c] = v;
             }
             if (p.enhanced) {

@@ -80,7 +80,7 @@ static void pick_schedule(const ie_zdce_plan* p, int N, int H, int W, int* group
     if (r <= 0) {
         // The fused kernels run one 8-wave workgroup per CU: aim for two full rounds of 256 workgroups per
         // launch (equal-length blocks -> no tail), with rows long enough to amortise the 6-7 apron steps.
-        const long long strips = (W + 125) / 126;
+        const long long strips = (W + 123) / 124;
         long long chunks = (512 + (long long)g * strips - 1) / ((long long)g * strips);
         if (chunks < 1) chunks = 1;
         long long rbv = (bd + chunks - 1) / chunks;

@@ -53,23 +53,33 @@ def zero_dcepp_forward(sd: dict, x: torch.Tensor, num_iters: int = 8, scale_fact
 
 
 # ---- LLUnet++ -------------------------------------------------------------------------------------------------
-def _llunet_block(sd, b, x):
-    x12 = _c(sd, f"{b}.conv1_2", x, padding=0)
-    x1 = _c(sd, f"{b}.conv1", x)
+def _llunet_block(sd, b, x, qa=None, qw=None):
+    qa = qa or (lambda t: t)
+    qw = qw or (lambda w: w)
+    cw = lambda name, t, **kw: F.conv2d(t, qw(sd[f"{name}.weight"]), sd.get(f"{name}.bias"), **kw)
+    x12 = qa(cw(f"{b}.conv1_2", x))
+    x1 = qa(cw(f"{b}.conv1", x, padding=1))
     x1 = F.instance_norm(x1, weight=sd[f"{b}.norm1.weight"], bias=sd[f"{b}.norm1.bias"], eps=1e-5)
-    x1 = F.leaky_relu(x1, 0.2)
+    x1 = qa(F.leaky_relu(x1, 0.2))
     x2 = torch.cat([x1, x12], 1)
-    x23 = _c(sd, f"{b}.conv2_3", x2, padding=0)
-    x2 = F.leaky_relu(_c(sd, f"{b}.conv2", x2), 0.2)
-    x3 = F.leaky_relu(_c(sd, f"{b}.conv3", x2), 0.2)
-    return x3 + x23
+    x23 = qa(cw(f"{b}.conv2_3", x2))
+    x2 = qa(F.leaky_relu(cw(f"{b}.conv2", x2, padding=1), 0.2))
+    x3 = qa(F.leaky_relu(cw(f"{b}.conv3", x2, padding=1), 0.2))
+    return qa(x3 + x23)
 
 
-def llunetpp_forward(sd: dict, x: torch.Tensor) -> dict:
-    B = lambda n, t: _llunet_block(sd, n, t)
+def llunetpp_forward(sd: dict, x: torch.Tensor, q=None) -> dict:
+    """``q = oracle.train.storage_rounding(dtype)``: the engine's 16-bit training graph restated -- every tensor between two kernels
+    (conv + fused activation output, norm output, residual sum, resized map) and its gradient rounded to ``dtype``, weights read in
+    ``dtype`` -- for tests that separate kernel error from storage rounding.  Default: the plain fp32 / fp64 forward."""
+    qa, qw = q if q is not None else (None, None)
+    B = lambda n, t: _llunet_block(sd, n, t, qa, qw)
     pool = lambda t: F.max_pool2d(t, 2, 2)
-    up = lambda t: F.interpolate(t, scale_factor=2, mode="bilinear", align_corners=True)
+    up = (lambda t: qa(F.interpolate(t, scale_factor=2, mode="bilinear", align_corners=True))) if qa else \
+        (lambda t: F.interpolate(t, scale_factor=2, mode="bilinear", align_corners=True))
     cat = lambda *ts: torch.cat(ts, 1)
+    if qa:
+        x = qa(x.detach().clone())
     x0_0 = B("conv0_0", x)
     x1_0 = B("conv1_0", pool(x0_0))
     x0_1 = B("conv0_1", cat(x0_0, up(x1_0)))
@@ -85,7 +95,24 @@ def llunetpp_forward(sd: dict, x: torch.Tensor) -> dict:
     x2_2 = B("conv2_2", cat(x2_0, x2_1, up(x3_1)))
     x1_3 = B("conv1_3", cat(x1_0, x1_1, x1_2, up(x2_2)))
     x0_4 = B("conv0_4", cat(x0_0, x0_1, x0_2, x0_3, up(x1_3)))
-    return {"enhanced": torch.clamp(_c(sd, "final", x0_4, padding=0), 0, 1)}
+    y = F.conv2d(x0_4, (qw or (lambda w: w))(sd["final.weight"]), sd.get("final.bias"))
+    if qa:
+        y = qa(y)
+    return {"enhanced": torch.clamp(y, 0, 1)}
+
+
+MON_EXTRA_LLUNET_KEYS = ((".conv1_2.", ".conv_1_1_1."), (".conv2_3.", ".conv_1_1."), (".conv1.", ".conv_1."),
+                         (".conv2.", ".conv_2."), (".conv3.", ".conv_3."))
+
+
+def llunetpp_to_extra_keys(sd: dict) -> dict:
+    """mon key names -> the original repository's (llunet++/model.py:9-20)."""
+    out = {}
+    for k, v in sd.items():
+        for a, b in MON_EXTRA_LLUNET_KEYS:
+            k = k.replace(a, b)
+        out[k] = v
+    return out
 
 
 # ---- LLLINet (parity unpinned: the mon package does not import here and the model has no mon_extra twin) ---------------------------
@@ -136,20 +163,6 @@ def lllinet_forward(sd: dict, x: torch.Tensor) -> dict:
     x0_3 = B("conv0_3", cat(x0_0, x0_1, x0_2, up(x1_2), up(x1_3)))
     x0_4 = B("conv0_4", cat(x0_0, x0_1, x0_2, x0_3, up(x1_3)))
     return {"enhanced": torch.clamp(_c(sd, "final", x0_4, padding=0), 0, 1)}
-
-
-MON_EXTRA_LLUNET_KEYS = ((".conv1_2.", ".conv_1_1_1."), (".conv2_3.", ".conv_1_1."), (".conv1.", ".conv_1."),
-                         (".conv2.", ".conv_2."), (".conv3.", ".conv_3."))
-
-
-def llunetpp_to_extra_keys(sd: dict) -> dict:
-    """mon key names -> the original repository's (llunet++/model.py:9-20)."""
-    out = {}
-    for k, v in sd.items():
-        for a, b in MON_EXTRA_LLUNET_KEYS:
-            k = k.replace(a, b)
-        out[k] = v
-    return out
 
 
 # ---- U-Net ----------------------------------------------------------------------------------------------------

@@ -751,33 +751,47 @@ def test_hinet_training_step_matches_torch():
         assert float((sd1[k] - ref).abs().max()) < 0.05 * lr, k
 
 
-@pytest.mark.parametrize("dt,min_cos,upsampler", [("f16", 0.98, "bilinear"), ("bf16", 0.85, "bilinear"), ("f16", 0.98, "pixelshuffle"),
-                                                  ("bf16", 0.85, "pixelshuffle")])
-def test_unet_mixed_precision_training_step(dt, min_cos, upsampler):
+@pytest.mark.parametrize("dt,min_cos,min_layer,upsampler", [("f16", 0.985, 0.97, "bilinear"), ("bf16", 0.97, 0.94, "bilinear"),
+                                                            ("f16", 0.985, 0.97, "pixelshuffle"), ("bf16", 0.97, 0.94, "pixelshuffle")])
+def test_unet_mixed_precision_training_step(dt, min_cos, min_layer, upsampler):
     """compute_dtype f16 / bf16: 16-bit activations and gradients between matrix-core convolutions (forward and data gradient), fp32
-    master weights / statistics / weight gradients / Adam.  Against torch float64 the loss agrees to 16-bit accuracy; the gradient
-    direction degrades with back-propagation depth because BatchNorm's backward subtracts the mean of a 16-bit-rounded gradient
-    (measured cosine 0.99 with fp16, 0.90 with bf16 on this 23-layer net, 0.9995 at the last layer; tools/mixed_diag.py)."""
+    master weights / statistics / weight gradients / Adam.
+
+    The reference of THIS test is oracle.train.unet_forward_train(q=storage_rounding(dtype)): torch float64 arithmetic with every
+    tensor between two kernels -- and its gradient -- rounded to the 16-bit storage format, i.e. the same graph with the same
+    rounding points, so the comparison isolates kernel error from storage rounding (measured whole-gradient cosine 0.981 bf16 /
+    0.993 fp16, worst parameter 0.968 / 0.98; what is left are roundings that flip because fp32 and float64 intermediate values
+    differ in the last bit, amplified by the 24-sample BatchNorms of this 48x64 test frame).  The plain float64 oracle is further
+    away BY CONSTRUCTION: the rounded oracle itself has cosine 0.878 (bf16) / 0.985 (fp16) to it, and computing BatchNorm's channel
+    sums from unrounded gradients does not change that (0.8784 -> 0.8785 in the same emulation; tools/mixed_diag.py).  The engine
+    must be no further from float64 than that inherent figure."""
     model = _unet(upsampler, seed=13, base=16)           # 16-bit sources need >= 16 channels on the device-packed path
     sd0 = model.state_dict()
     batches = _batches(2, 48, 64, 1, seed=14)
     lr, clip, eps = 1e-3, 0.1, 1e-3
+    tdt = {"f16": torch.float16, "bf16": torch.bfloat16}[dt]
     fwd = lambda p, b, x: otrain.unet_forward_train(p, b, x, upsampler, True)
-    log, final = otrain.training_steps({k: v.double() for k, v in sd0.items()}, [(a.double(), b.double()) for a, b in batches], fwd,
-                                       lambda a, b: otrain.l1_ssim_loss(a, b), lr=lr, clip=clip, eps=eps)
+    fwd_q = lambda p, b, x: otrain.unet_forward_train(p, b, x, upsampler, True, q=otrain.storage_rounding(tdt))
+    b64 = [(a.double(), b.double()) for a, b in batches]
+    log, final = otrain.training_steps({k: v.double() for k, v in sd0.items()}, b64, fwd, lambda a, b: otrain.l1_ssim_loss(a, b), lr=lr, clip=clip, eps=eps)
+    logq, _ = otrain.training_steps({k: v.double() for k, v in sd0.items()}, b64, fwd_q, lambda a, b: otrain.l1_ssim_loss(a, b), lr=lr, clip=clip, eps=eps)
     tr = mon_amd.Trainer(model, optimizer={"name": "adam", "lr": lr, "eps": eps}, loss={"name": "l1_ssim_loss"}, gradient_clip_val=clip,
                          compute_dtype=dt)
     out = tr.training_step({"image": batches[0][0], "ref_image": batches[0][1]})
     assert out["enhanced"].dtype == torch.float32
-    assert abs(float(out["loss"]) - log[0]["loss"][0]) < 2e-3
+    assert abs(float(out["loss"]) - logq[0]["loss"][0]) < 2e-4 and abs(float(out["loss"]) - log[0]["loss"][0]) < 2e-3
     grads = tr.gradients()
-    a = torch.cat([grads[k].double().reshape(-1) for k in log[0]["grads"]])
-    b = torch.cat([log[0]["grads"][k].reshape(-1) for k in log[0]["grads"]])
-    cos = float((a * b).sum() / (a.norm() * b.norm()))
-    assert cos > min_cos, cos
-    assert abs(float(a.norm()) / float(b.norm()) - 1.0) < 0.05
+    cs = lambda u, v: float((u * v).sum() / (u.norm() * v.norm() + 1e-30))
+    flat = lambda d: torch.cat([d[k].double().reshape(-1) for k in log[0]["grads"]])
+    a, b, c = flat(grads), flat(log[0]["grads"]), flat(logq[0]["grads"])
+    assert cs(a, c) > min_cos, cs(a, c)                                   # engine vs the same graph with the same rounding points
+    for k in log[0]["grads"]:
+        if float(logq[0]["grads"][k].norm()) > 1e-3 * float(c.norm()):    # parameters that carry gradient
+            assert cs(grads[k].double().reshape(-1), logq[0]["grads"][k].reshape(-1)) > min_layer, k
+    assert abs(float(a.norm()) / float(c.norm()) - 1.0) < 0.03
+    assert cs(a, b) > cs(c, b) - 0.03, (cs(a, b), cs(c, b))                # no further from float64 than storage rounding makes it
     ga, gb = grads["outc.conv.weight"].double().reshape(-1), log[0]["grads"]["outc.conv.weight"].reshape(-1)
-    assert float((ga * gb).sum() / (ga.norm() * gb.norm())) > 0.999          # the last layer sees one rounding only
+    assert cs(ga, gb) > 0.999                                             # the last layer sees one rounding only
     sd1 = tr.state_dict()
     moved = max(float((sd1[k] - sd0[k]).abs().max()) for k in sd0 if "running_" not in k)
     assert moved > 0.5 * lr
@@ -815,10 +829,12 @@ def test_zero_dce_mixed_precision_training_step(dt, min_cos):
     assert max(float((sd1[k] - sd0[k]).abs().max()) for k in sd0) > 0.2 * 5e-5
 
 
-@pytest.mark.parametrize("dt,min_cos", [("f16", 0.98), ("bf16", 0.80)])
+@pytest.mark.parametrize("dt,min_cos", [("f16", 0.98), ("bf16", 0.93)])
 def test_llunetpp_mixed_precision_training_step(dt, min_cos):
     """LLUnet++ on the 16-bit graph: the RGB block (3->3 convs, 3-channel instance norm, 6-channel concat) runs channel-padded to 16,
-    fused LeakyReLU epilogues, 16-bit residual adds and 5-way concats; loss and gradient direction against torch float64."""
+    fused LeakyReLU epilogues, 16-bit residual adds and 5-way concats.  Gradient direction against the storage-rounding restatement
+    of the same graph (oracle.generators.llunetpp_forward(q=...), see test_unet_mixed_precision_training_step); against plain float64
+    the engine must be no further away than that restatement is (instance norms over 6x6 pixels at the deepest level)."""
     from oracle import generators as og
     model = mon_amd.MODELS.build(name="llunet++_re", seed=31).to("cuda")
     sd0 = model.state_dict()
@@ -826,22 +842,26 @@ def test_llunetpp_mixed_precision_training_step(dt, min_cos):
     tgt = torch.rand(1, 3, 96, 96, generator=g)
     img = (tgt ** 2.2 * 0.4).contiguous()
     lr, clip, eps = 1e-4, 0.1, 1e-3
-    log, final = otrain.training_steps({k: v.double() for k, v in sd0.items()}, [(img.double(), tgt.double())],
-                                       lambda p, b, x: og.llunetpp_forward(p, x)["enhanced"], lambda a, b: otrain.l1_ssim_loss(a, b),
-                                       lr=lr, clip=clip, eps=eps)
+    tdt = {"f16": torch.float16, "bf16": torch.bfloat16}[dt]
+    run = lambda q: otrain.training_steps({k: v.double() for k, v in sd0.items()}, [(img.double(), tgt.double())],
+                                          lambda p, b, x: og.llunetpp_forward(p, x, q=q)["enhanced"], lambda a, b: otrain.l1_ssim_loss(a, b),
+                                          lr=lr, clip=clip, eps=eps)[0]
+    log, logq = run(None), run(otrain.storage_rounding(tdt))
     tr = mon_amd.Trainer(model, optimizer={"name": "adam", "lr": lr, "eps": eps}, loss={"name": "l1_ssim_loss"}, gradient_clip_val=clip,
                          compute_dtype=dt)
     out = tr.training_step({"image": img, "ref_image": tgt})
     assert out["enhanced"].dtype == torch.float32 and tuple(out["enhanced"].shape) == (1, 3, 96, 96)
     assert abs(float(out["loss"]) - log[0]["loss"][0]) < (3e-3 if dt == "f16" else 2e-2)
     grads = tr.gradients()
-    a = torch.cat([grads[k].double().reshape(-1) for k in log[0]["grads"]])
-    b = torch.cat([log[0]["grads"][k].reshape(-1) for k in log[0]["grads"]])
-    cos = float((a * b).sum() / (a.norm() * b.norm()))
-    assert cos > min_cos, cos
-    assert abs(float(a.norm()) / float(b.norm()) - 1.0) < 0.1
+    cs = lambda u, v: float((u * v).sum() / (u.norm() * v.norm() + 1e-30))
+    flat = lambda d: torch.cat([d[k].double().reshape(-1) for k in log[0]["grads"]])
+    a, b, c = flat(grads), flat(log[0]["grads"]), flat(logq[0]["grads"])
+    print(f"llunet++ {dt}: engine vs rounded oracle {cs(a, c):.4f}, engine vs float64 {cs(a, b):.4f}, rounded oracle vs float64 {cs(c, b):.4f}")
+    assert cs(a, c) > min_cos, (cs(a, c), cs(a, b), cs(c, b))
+    assert cs(a, b) > cs(c, b) - 0.05, (cs(a, b), cs(c, b))
+    assert abs(float(a.norm()) / float(c.norm()) - 1.0) < 0.1
     ga, gb = grads["final.weight"].double().reshape(-1), log[0]["grads"]["final.weight"].reshape(-1)
-    assert float((ga * gb).sum() / (ga.norm() * gb.norm())) > 0.999
+    assert cs(ga, gb) > 0.999
     sd1 = tr.state_dict()
     assert max(float((sd1[k] - sd0[k]).abs().max()) for k in sd0) > 0.5 * lr
 
