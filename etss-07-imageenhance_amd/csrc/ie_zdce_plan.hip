@@ -55,6 +55,8 @@ struct ie_zdce_plan {
     // workspace
     char* ws = nullptr;
     size_t ws_bytes = 0;
+    float* img_ws = nullptr;      // ie_zdce_forward_u8: the current frame group as NCHW fp32
+    size_t img_ws_bytes = 0;
     int cap_frames = 0, cap_H = 0, cap_W = 0;
     // schedule knobs
     int rows_per_block = 0, band_rows = 0, group_frames = 0;
@@ -422,6 +424,37 @@ IE_EXPORT int ie_zdce_forward(ie_zdce_plan* p, const float* image, float* enhanc
     return forward_mfma(p, image, enhanced, adjust, u8, N, H, W, st, g, bd, rb);
 }
 
+// uint8 frames in (what the reference's loader produces: HWC uint8, core/image/io.py:82-89), uint8 / fp32 frames out: the
+// /255 normalisation (to_image_tensor, core/image/utils.py:801-847) runs group by group into a plan-owned NCHW fp32 buffer that the
+// first kernel reads straight away (12 B/px written and read once, L2 / Infinity-Cache resident for one group), the
+// save_image quantisation is fused into the last kernel.
+IE_EXPORT int ie_zdce_forward_u8(ie_zdce_plan* p, const uint8_t* image_u8_nhwc, float* enhanced, float* adjust, uint8_t* u8, int N, int H, int W,
+                                 void* stream) {
+    if (!p || !image_u8_nhwc) IE_FAIL(IE_ERR_INVALID, "ie_zdce_forward_u8: null plan/image");
+    if (N <= 0 || H <= 0 || W <= 0) IE_FAIL(IE_ERR_INVALID, "ie_zdce_forward_u8: bad shape N=%d H=%d W=%d", N, H, W);
+    int g, bd, rb;
+    pick_schedule(p, N, H, W, &g, &bd, &rb);
+    const size_t plane3 = (size_t)3 * H * W, need = plane3 * g * sizeof(float);
+    if (need > p->img_ws_bytes) {
+        IE_HIP_CHECK(hipSetDevice(p->cfg.device));
+        if (p->img_ws) { IE_HIP_CHECK(hipDeviceSynchronize()); (void)hipFree(p->img_ws); p->img_ws = nullptr; p->img_ws_bytes = 0; }
+        hipError_t e = hipMalloc(&p->img_ws, need);
+        if (e != hipSuccess) { ie_set_error("ie_zdce_forward_u8: hipMalloc(%zu) failed: %s", need, hipGetErrorString(e)); return IE_ERR_NOMEM; }
+        p->img_ws_bytes = need;
+    }
+    for (int n0 = 0; n0 < N; n0 += g) {
+        const int gn = (N - n0) < g ? (N - n0) : g;
+        int rc = ie_u8_nhwc_to_nchw_f32(image_u8_nhwc + (size_t)n0 * plane3, p->img_ws, gn, 3, H, W, stream);
+        if (rc) return rc;
+        rc = ie_zdce_forward(p, p->img_ws, enhanced ? enhanced + (size_t)n0 * plane3 : nullptr, adjust ? adjust + (size_t)n0 * 24 * H * W : nullptr,
+                             u8 ? u8 + (size_t)n0 * plane3 : nullptr, gn, H, W, stream);
+        if (rc) return rc;
+    }
+    p->last_N = N;
+    p->last_whole = (g >= N);
+    return IE_OK;
+}
+
 IE_EXPORT int ie_zdce_get_feature(ie_zdce_plan* p, int idx, float* dst, void* stream) {
     if (!p || !dst || idx < 1 || idx > 6) IE_FAIL(IE_ERR_INVALID, "ie_zdce_get_feature: bad args");
     if (!p->last_whole) IE_FAIL(IE_ERR_STATE, "ie_zdce_get_feature: last forward did not keep the whole batch in one group");
@@ -443,6 +476,7 @@ IE_EXPORT int ie_zdce_destroy(ie_zdce_plan* p) {
     (void)hipDeviceSynchronize();
     if (p->d_w) (void)hipFree(p->d_w);
     if (p->ws) (void)hipFree(p->ws);
+    if (p->img_ws) (void)hipFree(p->img_ws);
     for (hipEvent_t e : p->ev) (void)hipEventDestroy(e);
     delete p;
     return IE_OK;

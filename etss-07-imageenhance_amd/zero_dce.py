@@ -167,6 +167,26 @@ class ZeroDCE_RE(ImageEnhancementModel):
                                                   capi.current_stream()), "ie_zdce_forward")
         return out
 
+    def enhance_u8(self, image_u8: torch.Tensor, want_enhanced: bool = False, want_u8: bool = True, out: dict = None) -> dict:
+        """uint8 HWC frames in -- (N,H,W,3) or (H,W,3), as read from disk (core/image/io.py:82-89) -- uint8 HWC frames out under the
+        save_image rule (and / or the fp32 ``enhanced``): predict.py:76-105's read -> /255 -> forward -> save_image in one call."""
+        plan = self._ensure_plan()
+        x = image_u8[None] if image_u8.dim() == 3 else image_u8
+        if x.dim() != 4 or x.shape[3] != 3 or x.dtype != torch.uint8:
+            raise ValueError(f"`image_u8` must be uint8 (N,H,W,3), but got {tuple(x.shape)} {x.dtype}.")
+        x = x.to(self.device).contiguous()
+        n, h, w, _ = x.shape
+        self._last_shape = (n, h, w)
+        out = dict(out or {})
+        if want_enhanced and "enhanced" not in out:
+            out["enhanced"] = torch.empty((n, 3, h, w), device=x.device, dtype=torch.float32)
+        if want_u8 and "u8" not in out:
+            out["u8"] = torch.empty((n, h, w, 3), device=x.device, dtype=torch.uint8)
+        with torch.cuda.device(x.device):
+            capi.check(capi.lib().ie_zdce_forward_u8(plan, capi.ptr(x), capi.ptr(out.get("enhanced")), None, capi.ptr(out.get("u8")), n, h, w,
+                                                     capi.current_stream()), "ie_zdce_forward_u8")
+        return out
+
     def forward(self, datapoint: dict, *args, **kwargs) -> dict:
         """zero_dce.py:173-191.  Returns ``adjust_0..7`` (views of ``adjust``), ``adjust`` and
         ``enhanced`` -- ``enhanced`` is inserted last (predict.py:97 pops the last item)."""

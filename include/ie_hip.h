@@ -416,6 +416,11 @@ int ie_zdce_reserve(ie_zdce_plan* p, int N, int H, int W);
  *   u8_dev        NHWC uint8 (N,H,W,3)       save_image rule applied to enhanced */
 int ie_zdce_forward(ie_zdce_plan* p, const float* image_dev, float* enhanced_dev, float* adjust_dev,
                     uint8_t* u8_dev, int N, int H, int W, void* stream);
+/* uint8 in, uint8 (and / or fp32) out -- the frames as the reference's loader hands them over (HWC uint8, core/image/io.py:82-89; /255
+ * like to_image_tensor, core/image/utils.py:801-847) and as `write_image` wants them back (save_image rule): replaces
+ * read -> to_image_tensor -> forward -> save_image of project/runml/predict.py:76-105 for this model.  image_u8_dev: (N,H,W,3). */
+int ie_zdce_forward_u8(ie_zdce_plan* plan, const uint8_t* image_u8_dev, float* enhanced_dev, float* adjust_dev, uint8_t* u8_dev, int N, int H,
+                       int W, void* stream);
 /* Debug/unit parity: copy intermediate feature x{idx} (idx 1..6) of the last forward to
  * NCHW fp32 (N,num_channels,H,W). */
 int ie_zdce_get_feature(ie_zdce_plan* p, int idx, float* dst_dev, void* stream);

@@ -829,7 +829,7 @@ def test_zero_dce_mixed_precision_training_step(dt, min_cos):
     assert max(float((sd1[k] - sd0[k]).abs().max()) for k in sd0) > 0.2 * 5e-5
 
 
-@pytest.mark.parametrize("dt,min_cos", [("f16", 0.98), ("bf16", 0.93)])
+@pytest.mark.parametrize("dt,min_cos", [("f16", 0.995), ("bf16", 0.99)])
 def test_llunetpp_mixed_precision_training_step(dt, min_cos):
     """LLUnet++ on the 16-bit graph: the RGB block (3->3 convs, 3-channel instance norm, 6-channel concat) runs channel-padded to 16,
     fused LeakyReLU epilogues, 16-bit residual adds and 5-way concats.  Gradient direction against the storage-rounding restatement

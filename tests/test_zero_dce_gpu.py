@@ -255,3 +255,21 @@ def test_bench_two_ranks_one_device():
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 4 and line["dtype"] == "bf16" and line["value"] > 0
     assert line["roofline"]["bound"] == "mfma" and 0 < line["roofline"]["frac"] < 1
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_u8_in_u8_out_entry_point(dtype):
+    """ie_zdce_forward_u8 == to_image_tensor (/255) -> forward -> save_image rule, bit for bit, over several frame groups."""
+    sd = o_zdce.init_state_dict(seed=5, gain=3.0)
+    m = _model(sd, dtype)
+    m.set_tuning(0, 0, 2)                                             # 5 frames in groups of 2
+    u8 = torch.randint(0, 256, (5, 45, 77, 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(3))
+    got = m.enhance_u8(u8.cuda(), want_enhanced=True)
+    x = (u8.permute(0, 3, 1, 2).float() / 255.0).contiguous()
+    want = m.enhance(x.cuda(), want_enhanced=True, want_u8=True)
+    assert torch.equal(got["enhanced"], want["enhanced"]) and torch.equal(got["u8"], want["u8"])
+    assert got["u8"].dtype == torch.uint8 and tuple(got["u8"].shape) == (5, 45, 77, 3)
+    one = m.enhance_u8(u8[2].cuda())["u8"]
+    assert torch.equal(one[0], got["u8"][2])
+    with pytest.raises(ValueError):
+        m.enhance_u8(torch.zeros(1, 3, 8, 8, dtype=torch.uint8).cuda())
