@@ -3,7 +3,8 @@
 //
 //   K12: e_conv1 (image -> x1, LDS only) + e_conv2 (x1 -> x2) + the x1 half of e_conv7 (x1 -> P)   12+64+64 = 140 B/px
 //        (e_conv7([x1,x6]) = W7a*x1 + W7b*x6: P = W7a*x1 + bias7 is computed where x1 lives and replaces x1 in HBM,
-//         which halves stage B of K67 -- the busiest kernel -- and uses MFMA slots K12, a write-bound kernel, has free)
+//         which halves stage B of K67 -- the busiest kernel).  Stage A = e_conv1 + e_conv7a (44 MFMAs per wave and row),
+//         stage B = e_conv2 (36): balanced like K345, each wave's non-MFMA work hides under its SIMD partner's MFMAs.
 //   K45: e_conv4 (x3 -> x4, LDS only) + e_conv5 ([x3,x4] -> x5)       64+64    = 128 B/px (was 320)
 //   K345: e_conv3 + e_conv4 on stage A (x2 -> x3 -> x4, both LDS only; 72 MFMAs per wave and row) + e_conv5 on stage B
 //        (72 MFMAs): x3 never reaches HBM and the two stages are balanced.  64+64 = 128 B/px for three layers (conv3 + K45: 256).
@@ -41,6 +42,40 @@ constexpr int PF_DEFAULT = IE_PF; // rows of DMA issued ahead (K67 is LDS-limite
 
 enum { K12 = 12, K45 = 45, K67 = 67, K345 = 345 };
 
+#ifndef IE_K12_RPB
+#define IE_K12_RPB 2
+#endif
+// Ring geometry shared by the kernel body and the launcher (LDS size).
+template <int KIND> struct FusedGeom {
+    // rows per barrier.  K12's per-row fixed chain (barrier, e_conv1's LDS-read -> MFMA -> MFMA chain, row conversion, hand-off write)
+    // is as long as its MFMA time, and its rings are small: it runs TWO rows between barriers (the stages then talk through rows
+    // that are one barrier period old, so every hand-off lags RPB rows and the rings hold 2 RPB slots).
+    static constexpr int RPB = (KIND == K12) ? IE_K12_RPB : 1;
+    static constexpr int PF = (KIND == K67) ? 3 : (KIND == K12 && RPB > 1 ? 5 : PF_DEFAULT);   // rows of DMA issued ahead
+    static constexpr int ROW_B = ROW_PX * 64;
+    static constexpr int NSA = (KIND == K67) ? 2 : ((KIND == K45 || KIND == K345) ? 1 : 0);     // stage A HBM sources (K12: image)
+    static constexpr int NRA = (KIND == K45) ? PF + 3 : PF + 1;   // slots of the A rings (K45: B re-reads x3 two rows later)
+    static constexpr int NRB = PF + 1;                            // K67: P ring of stage B
+    static constexpr int NR3 = 4;                                 // K345: x3 ring (written at step t, read by e_conv4 at t+1 and e_conv5 at t+3)
+    static constexpr int NRH = 2 * RPB;                           // A -> B hand-off ring
+    static constexpr int LAG_A = (KIND == K12) ? RPB : 0;         // K12: stage A runs behind the image row conversion
+    static constexpr int LAG_B = RPB - 1;                         // extra rows stage B runs behind stage A
+    static constexpr int NRI = (KIND == K12) ? PF + RPB : PF + 3; // fp32 image ring slots (K67: kept until the deferred curve)
+    static constexpr int NRC = 2 + LAG_A + RPB;                   // K12: converted image rows (3 being read + RPB being written)
+    static constexpr int IMG_SLOT_B = 2048;                       // 3 planes x 132 px fp32 (K12) / 3 x 128 (K67)
+    static constexpr int CV_PLANE_B = 1088;                       // K12: converted image row, [136 px][RGB0] 16-bit
+    static constexpr int CV_SLOT_B = 2 * CV_PLANE_B;              //      hi plane + lo plane
+    static constexpr int STAGE_SLOT_B = 24 * TW * 4;              // K67: tanh(r) staging [24][128] fp32, double buffered
+    static constexpr int A_RING_B = NSA * NRA * ROW_B;
+    static constexpr int B_RING_B = (KIND == K67) ? NRB * ROW_B : 0;
+    static constexpr int R3_B = (KIND == K345) ? NR3 * ROW_B : 0;
+    static constexpr int RA_B = NRH * ROW_B;
+    static constexpr int IMG_B = (KIND == K45 || KIND == K345) ? 0 : NRI * IMG_SLOT_B;
+    static constexpr int CV_B = (KIND == K12) ? NRC * CV_SLOT_B : 0;
+    static constexpr int STAGE_B = (KIND == K67) ? 2 * STAGE_SLOT_B : 0;
+    static constexpr int LDS_B = A_RING_B + B_RING_B + R3_B + RA_B + IMG_B + CV_B + STAGE_B;
+};
+
 struct FusedParams {
     const void* a_src0;  // stage A HBM source 0 (NHWC T)            K45: x3, K67: x2
     const void* a_src1;  // stage A HBM source 1                     K67: x5
@@ -55,7 +90,7 @@ struct FusedParams {
     float* enhanced; float* adjust; unsigned char* u8;   // K67
     int N, H, W;
     int y_begin, y_end, rows_per_block, strips, chunks, n_begin;
-    unsigned long long* stamps;   // diagnostic builds (-DIE_STAMP) only: [block][wave][4] cycle sums
+    unsigned long long* stamps;   // diagnostic builds (-DIE_STAMP) only: [block][wave][8] cycle sums
 };
 
 __device__ __forceinline__ void wait_vm(int n) {
@@ -86,10 +121,11 @@ template <typename T> struct ie_tag { using type = T; };
 template <typename TA0, typename TA1, typename TH, typename TO, int KIND, typename T3 = TH>
 __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     using frag = ie_u32x4;
-    constexpr int PF = (KIND == K67) ? 3 : PF_DEFAULT;
+    using G = FusedGeom<KIND>;
+    constexpr int PF = G::PF, RPB = G::RPB;
     constexpr int PXB = 32 * 2;                             // 64 B per pixel per tensor
-    constexpr int ROW_B = ROW_PX * PXB;                     // one ring row of one tensor
-    constexpr int NSA = (KIND == K67) ? 2 : ((KIND == K45 || KIND == K345) ? 1 : 0);   // stage A HBM sources (K12: image)
+    constexpr int ROW_B = G::ROW_B;                         // one ring row of one tensor
+    constexpr int NSA = G::NSA;
     constexpr int NFB = (KIND == K45 || KIND == K12 || KIND == K345) ? 18 : 9;         // stage B weight fragments (K12: e_conv2 + e_conv7a)
     constexpr int NW = (KIND == K67) ? 18 : NFB;                     // weight fragments held per wave (K12 stage A: 2, K67 / K345 stage A: 18)
     // K67 and K345 load NO halo columns for stage A's HBM rows (one 8-lane LDS-DMA instruction per tensor and row on the
@@ -98,25 +134,11 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     constexpr bool HALO = (KIND == K12 || KIND == K45);
     constexpr int MARG = ((KIND == K345) ? 2 : 1) + (HALO ? 0 : 1);  // computed columns lost per side (one per LDS hand-off, one without halo)
     constexpr int TSK = TW - 2 * MARG;                               // stored columns = strip pitch
-    // ---- LDS carve ------------------------------------------------------------------------------
-    constexpr int NRA = (KIND == K45) ? PF + 3 : PF + 1;    // slots of the A rings (K45: B re-reads x3 two rows later)
-    constexpr int A_RING_B = NSA * NRA * ROW_B;
-    constexpr int NRB = PF + 1;                             // K67: x1 ring of stage B
-    constexpr int B_RING_B = (KIND == K67) ? NRB * ROW_B : 0;
-    constexpr int NR3 = 4;                                  // K345: x3 ring (written at step t, read by e_conv4 at t+1 and e_conv5 at t+3)
-    constexpr int R3_B = (KIND == K345) ? NR3 * ROW_B : 0;
-    constexpr int RA_B = 2 * ROW_B;                         // A -> B hand-off ring (2 slots)
-    constexpr int LAG_A = (KIND == K12) ? 1 : 0;            // K12: stage A runs one row later (image row conversion)
-    constexpr int NRI = (KIND == K12) ? PF + 1 : PF + 3;    // fp32 image ring slots (K67: kept until the deferred curve)
-    constexpr int IMG_SLOT_B = 2048;                        // 3 planes x 132 px fp32 (K12) / 3 x 128 (K67)
-    constexpr int IMG_B = (KIND == K45 || KIND == K345) ? 0 : NRI * IMG_SLOT_B;
-    constexpr int CV_PLANE_B = 1088;                        // K12: converted image row, [136 px][RGB0] 16-bit
-    constexpr int CV_SLOT_B = 2 * CV_PLANE_B;               //      hi plane + lo plane
-    constexpr int NRC = 4;
-    constexpr int CV_B = (KIND == K12) ? NRC * CV_SLOT_B : 0;
-    constexpr int STAGE_SLOT_B = 24 * TW * 4;               // K67: tanh(r) staging [24][128] fp32, double buffered
-    constexpr int OFF_BRING = A_RING_B, OFF_R3 = OFF_BRING + B_RING_B, OFF_RA = OFF_R3 + R3_B, OFF_IMG = OFF_RA + RA_B,
-                  OFF_CV = OFF_IMG + IMG_B, OFF_STAGE = OFF_CV + CV_B;
+    // ---- LDS carve (FusedGeom) ------------------------------------------------------------------
+    constexpr int NRA = G::NRA, NRB = G::NRB, NR3 = G::NR3, NRH = G::NRH, LAG_A = G::LAG_A, LAG_B = G::LAG_B, NRI = G::NRI, NRC = G::NRC;
+    constexpr int IMG_SLOT_B = G::IMG_SLOT_B, CV_PLANE_B = G::CV_PLANE_B, CV_SLOT_B = G::CV_SLOT_B, STAGE_SLOT_B = G::STAGE_SLOT_B;
+    constexpr int OFF_BRING = G::A_RING_B, OFF_R3 = OFF_BRING + G::B_RING_B, OFF_RA = OFF_R3 + G::R3_B, OFF_IMG = OFF_RA + G::RA_B,
+                  OFF_CV = OFF_IMG + G::IMG_B, OFF_STAGE = OFF_CV + G::CV_B;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -134,7 +156,7 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     const int xc0 = strip * TSK - MARG;                     // image column of computed column 0
     const int ys = p.y_begin + chunk * p.rows_per_block;
     const int ye = min(ys + p.rows_per_block, p.y_end);
-    const int n_steps = (ye - ys) + 6 + LAG_A + (KIND == K67 ? 1 : 0) + (KIND == K345 ? 4 : 0);
+    const int n_steps = (ye - ys) + 6 + LAG_A + LAG_B + (KIND == K67 ? 1 : 0) + (KIND == K345 ? 4 : 0);
     constexpr int A_ROW0 = (KIND == K345) ? 4 : 2;          // stage A's HBM input row at step t is ys - A_ROW0 + t
     const int H = p.H, W = p.W;
     const size_t plane = (size_t)H * W;
@@ -163,6 +185,13 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
                 const frag* wp2 = (const frag*)p.a2_w + (size_t)ch * 9 * 64;
 #pragma unroll
                 for (int f = 0; f < 9; ++f) wv[9 + f] = wp2[f * 64 + lane];
+            }
+        }
+        if constexpr (KIND == K12) {        // stage A: e_conv1 in wv[0..1], the x1 half of e_conv7 in wv[9..17] (packed behind e_conv2)
+            if (stg == 0) {
+                const frag* wp2 = (const frag*)p.b_w + (size_t)ch * NFB * 64;
+#pragma unroll
+                for (int f = 9; f < 18; ++f) wv[f] = wp2[f * 64 + lane];
             }
         }
     }
@@ -289,7 +318,9 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
         }
     };
     // DMA instructions per step of this wave -> counted wait that leaves PF-1 younger rows in flight
-    // Waves that issue no DMA do not wait at all; stage-A waves issue no stores, so their count is exact.
+    // Waves that issue no DMA do not wait at all.  gfx950 counts loads and stores in the one in-order vmcnt: K12's stage A issues
+    // exactly two (possibly out-of-range = dropped) P stores per step after its two loads, which its wait adds in (IE_STEP_HEAD's
+    // argument); K67's curve stores only make the wait stricter than needed.
     int L = 0, S = 0;
     if (stg == 0) { L = (KIND == K12) ? 2 : (2 * NSA + ((HALO && sw == 0) ? NSA : 0)); }   // K345: NSA = 1
     else if (KIND == K67) L = sw == 2 ? 6 : (sw == 3 ? 8 : 0);
@@ -334,31 +365,6 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
         __builtin_amdgcn_sched_group_barrier(0x008, 3 * IE_LDS_DEPTH, 0);
     };
 
-    // K12 stage B: every x1 fragment feeds e_conv2 (weights 0..8 -> acc) and the x1 half of e_conv7 (weights 9..17 -> accp)
-    auto src_mfma2 = [&](const char* row, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4], ie_f32x4 (&pN)[4],
-                         ie_f32x4 (&pM)[4], ie_f32x4 (&pO)[4]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const int off = (kx == 0 && nt == 0) ? rd_first : (kx == 2 && nt == 3) ? rd_last : rd_base[kx] + 1024 * nt;
-                const frag bx = *(const frag*)(row + off);
-                accN[nt] = ie_mfma16_raw<TH>(wv[0 * 3 + kx], bx, accN[nt]);
-                accM[nt] = ie_mfma16_raw<TH>(wv[1 * 3 + kx], bx, accM[nt]);
-                accO[nt] = ie_mfma16_raw<TH>(wv[2 * 3 + kx], bx, accO[nt]);
-                pN[nt] = ie_mfma16_raw<TH>(wv[(NW > 9 ? 9 : 0) + 0 * 3 + kx], bx, pN[nt]);
-                pM[nt] = ie_mfma16_raw<TH>(wv[(NW > 9 ? 9 : 0) + 1 * 3 + kx], bx, pM[nt]);
-                pO[nt] = ie_mfma16_raw<TH>(wv[(NW > 9 ? 9 : 0) + 2 * 3 + kx], bx, pO[nt]);
-            }
-        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-#pragma unroll
-        for (int f = 0; f < 12 - 3; ++f) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 18, 0);
-    };
-
     // write a finished stage-A row (ReLU, 16-bit, zero outside the image) into the hand-off ring slot
     auto a_emit_to = [&](auto tg, const ie_f32x4 (&acc)[4], char* slot, int ra, bool relu = true) __attribute__((always_inline)) {
         using TE = typename decltype(tg)::type;
@@ -376,7 +382,7 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
         }
     };
     auto a_emit = [&](const ie_f32x4 (&acc)[4], int t) __attribute__((always_inline)) {
-        a_emit_to(ie_tag<TH>{}, acc, smem + OFF_RA + (t & 1) * ROW_B, ys - 3 - LAG_A + t);
+        a_emit_to(ie_tag<TH>{}, acc, smem + OFF_RA + (t % NRH) * ROW_B, ys - 3 - LAG_A + t);
     };
 
     // stage-B epilogue to HBM (centre 126 columns): ReLU'd activations (x2, x5) or the raw P map (K12)
@@ -484,11 +490,11 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
         }
     };
     auto conv1_row = [&](int t, ie_f32x4 (&acc)[4]) __attribute__((always_inline)) {
-        // output row ra = ys-4+t from converted rows R(t-3), R(t-2), R(t-1); this lane reads row
-        // ky = 2m + (kq>>1): slot (t - 3 + ky) % NRC
+        // output row ra = ys-3-LAG_A+t from converted rows R(t-2-LAG_A+ky), ky = 0..2 (all converted before this barrier period);
+        // this lane reads row ky = 2m + (kq>>1): slot (t - 2 - LAG_A + ky) % NRC
         const int pxo = (64 * ph + p16 + 2 * (kq & 1)) * 8;
-        const int s0 = OFF_CV + ((t + NRC - 3 + (kq >> 1)) % NRC) * CV_SLOT_B + pxo;     // m = 0: ky = kq>>1
-        const int s1 = OFF_CV + ((t + NRC - 1) % NRC) * CV_SLOT_B + pxo;                 // m = 1: ky = 2 (kq < 2)
+        const int s0 = OFF_CV + ((t + NRC - 2 - LAG_A + (kq >> 1)) % NRC) * CV_SLOT_B + pxo;     // m = 0: ky = kq>>1
+        const int s1 = OFF_CV + ((t + NRC - LAG_A) % NRC) * CV_SLOT_B + pxo;                     // m = 1: ky = 2 (kq < 2)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) acc[nt] = bias4;
 #pragma unroll
@@ -511,7 +517,13 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     };
 
 #ifdef IE_STAMP
-    unsigned long long st_wait = 0, st_issue = 0, st_work = 0;
+    unsigned long long st_wait = 0, st_issue = 0, st_work = 0, st_e[4] = {0, 0, 0, 0}, st_last = 0;
+    // finer split of a step: IE_TX(i) adds the cycles since the previous IE_TX / IE_TX0 to bucket i
+#define IE_TX0() do { IE_T(st_last); } while (0)
+#define IE_TX(i) do { unsigned long long now_; IE_T(now_); st_e[i] += now_ - st_last; st_last = now_; } while (0)
+#else
+#define IE_TX0() do { } while (0)
+#define IE_TX(i) do { } while (0)
 #endif
     // ---- one step -----------------------------------------------------------------------------------
     // Stage A: MFMAs first (the pipe is busy from the first cycle after the barrier), then its DMA
@@ -521,13 +533,15 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     // Each stage runs its OWN loop (the wave-uniform `stg` branch is taken once, outside): the register allocator then sees two
     // independent live ranges -- stage A's second accumulator family (K345) or stage B's (K12) is not carried through the other
     // stage's loop -- and both loops execute exactly one s_barrier per step.
-#define IE_STEP_HEAD()                                                                                              \
+#define IE_STEP_HEAD(WAITN)                                                                                         \
         unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;                                                     \
         (void)ts0; (void)ts1; (void)ts2; (void)ts3;                                                                \
         IE_T(ts0);                                                                                                 \
-        wait_vm(wait_base);                                                                                        \
+        if (RPB == 1 || (t % RPB) == 0) {                                                                          \
+        wait_vm(WAITN);                                                                                      \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* this wave's LDS writes of step t-1 (hand-off, staging) */ \
         __builtin_amdgcn_s_barrier();                                                                              \
+        }                                                                                                          \
         IE_T(ts1)
 #ifdef IE_STAMP
 #define IE_STEP_TAIL() do { IE_T(ts3); st_wait += ts1 - ts0; st_issue += ts2 - ts1; st_work += ts3 - ts2; } while (0)
@@ -537,12 +551,26 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     // Stage A: MFMAs first (the pipe is busy from the first cycle after the barrier), then its DMA issue, then the hand-off write.
     auto step_a = [&](int t, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4], ie_f32x4 (&pN)[4], ie_f32x4 (&pM)[4],
                       ie_f32x4 (&pO)[4]) __attribute__((always_inline)) {
-        IE_STEP_HEAD();
+        // K12: at the barrier before rows t .. t+RPB-1 the image DMA of row t+RPB-1 must have landed.  Ops younger than it: the
+        // 2 (PF-RPB) loads of the rows behind it plus, for each of the min(t, PF-RPB+1) row steps since it was issued, two P stores.
+        IE_STEP_HEAD(KIND == K12 ? 2 * (PF - RPB) + 2 * (t < PF - RPB + 1 ? t : PF - RPB + 1) : wait_base);
         if constexpr (KIND == K12) {
+            // e_conv1 on the converted image rows -> x1 row ys-4+t (accO); the x1 half of e_conv7 on the x1 row emitted at step t-1
+            // (ys-5+t) -> P row ys-6+t complete in pO.  With e_conv7a here and e_conv2 on stage B the two waves of a SIMD carry 44 and
+            // 36 MFMAs per row instead of 8 and 72, so each one's LDS / VALU / store work hides under the other's MFMAs.
+            IE_TX0();
             conv1_row(t, accO);
+            IE_TX(0);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) pN[nt] = bias4p;
+            src_mfma(ie_tag<TH>{}, smem + OFF_RA + ((t + RPB) % NRH) * ROW_B, 9, pN, pM, pO, 0);    // x1 row emitted at step t-RPB
+            IE_TX(1);
             IE_T(ts2);
             issue(t + PF);
-            if (t >= 3) a_emit(accO, t);
+            IE_TX(2);
+            if (t >= 2 + LAG_A) a_emit(accO, t);
+            IE_TX(3);
+            IE_B_STORE(pO, ys - 5 - LAG_A - LAG_B + t, rsDa, false);         // always issued (rows outside the chunk go out of range): the vmcnt bookkeeping counts on it
         } else if constexpr (KIND == K345) {
             // e_conv3 on x2 row ys-4+t -> x3 row ys-5+t (accO); e_conv4 on the x3 row emitted at step t-1 -> x4 row ys-7+t (pO)
 #pragma unroll
@@ -569,13 +597,16 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     // afterwards), then its MFMAs.  The two stages share each SIMD, so B's epilogue VALU runs under A's MFMAs and A's tail under B's.
     auto step_b = [&](int t, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4], ie_f32x4 (&pN)[4], ie_f32x4 (&pM)[4],
                       ie_f32x4 (&pO)[4]) __attribute__((always_inline)) {
-        IE_STEP_HEAD();
+        IE_STEP_HEAD(wait_base);
         issue(t + PF);
         IE_T(ts2);
         // accN (and pN) still hold the output row finished at step t-1: ys-5-LAG_A+(t-1)
+        IE_TX0();
         if constexpr (KIND == K12) convert_row(t);
+        IE_TX(0);
         if constexpr (KIND == K12) {
-            if (t >= 6 + LAG_A) { IE_B_STORE(accN, ys - 6 - LAG_A + t, rsDb, true); IE_B_STORE(pN, ys - 6 - LAG_A + t, rsDa, false); }
+            if (t >= 6 + LAG_A + LAG_B) IE_B_STORE(accN, ys - 6 - LAG_A - LAG_B + t, rsDb, true);
+            IE_TX(1);
         } else if constexpr (KIND == K45) {
             if (t >= 6) IE_B_STORE(accN, ys - 6 + t, rsDb, true);
         } else if constexpr (KIND == K345) {
@@ -584,11 +615,11 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
             if (t >= 7) curve_consume(t - 2);
             if (t >= 6) stage_write(accN, (t - 1) & 1);
         }
-        const char* ra_row = smem + OFF_RA + ((t + 1) & 1) * ROW_B;     // written by stage A at step t-1
+        const char* ra_row = smem + OFF_RA + ((t + RPB) % NRH) * ROW_B;     // written by stage A at step t-RPB
         if constexpr (KIND == K12) {
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) { accN[nt] = bias4; pN[nt] = bias4p; }
-            src_mfma2(ra_row, accN, accM, accO, pN, pM, pO);                           // x1 row ys-5+t
+            for (int nt = 0; nt < 4; ++nt) accN[nt] = bias4;
+            src_mfma(ie_tag<TH>{}, ra_row, 0, accN, accM, accO, 0);                    // x1 row ys-5+t
         } else if constexpr (KIND == K45) {
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) accN[nt] = bias4;
@@ -632,8 +663,9 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef IE_STAMP
     if (p.stamps && lane == 0) {
-        unsigned long long* d = p.stamps + ((size_t)blockIdx.x * 8 + wave) * 4;
+        unsigned long long* d = p.stamps + ((size_t)blockIdx.x * 8 + wave) * 8;
         d[0] = st_wait; d[1] = st_issue; d[2] = st_work; d[3] = n_steps;
+        d[4] = st_e[0]; d[5] = st_e[1]; d[6] = st_e[2]; d[7] = st_e[3];
     }
 #endif
 }
@@ -674,13 +706,7 @@ static int launch_fused_t(FusedFn fn, const ZdceFusedLaunch& a, hipStream_t st) 
     const long long blocks = (long long)p.strips * p.chunks * a.n_count;
     if (blocks <= 0 || blocks > 0x7fffffffLL) IE_FAIL(IE_ERR_INVALID, "zdce fused: bad grid %lld", blocks);
     if ((size_t)a.H * a.W * 32 * 2 >= 0x7fffffffull) IE_FAIL(IE_ERR_UNSUPPORTED, "zdce fused: frame too large for 31-bit offsets");
-    constexpr int PF = (KIND == K67) ? 3 : PF_DEFAULT;
-    constexpr int ROW_B = ROW_PX * 32 * 2;
-    constexpr int NSA = (KIND == K67) ? 2 : ((KIND == K45 || KIND == K345) ? 1 : 0);
-    constexpr int NRA = (KIND == K45) ? PF + 3 : PF + 1;
-    constexpr int NRI = (KIND == K12) ? PF + 1 : PF + 3;
-    const size_t lds = (size_t)NSA * NRA * ROW_B + (KIND == K67 ? (PF + 1) * ROW_B : 0) + (KIND == K345 ? 4 * ROW_B : 0) + 2 * ROW_B +
-                       ((KIND == K45 || KIND == K345) ? 0 : NRI * 2048) + (KIND == K12 ? 4 * 2 * 1088 : 0) + (KIND == K67 ? 2 * 24 * TW * 4 : 0);
+    const size_t lds = FusedGeom<KIND>::LDS_B;
     // the dynamic-LDS limit is a per-function attribute: set it once per kernel
     static FusedFn attr_done[8] = {nullptr};
     bool done = false;

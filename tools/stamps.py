@@ -11,12 +11,12 @@ L = capi.lib()
 m.enhance(x, out=out); torch.cuda.synchronize()
 L.ie_debug_set_stamps(C.c_void_p(buf.data_ptr()))
 m.enhance(x, out=out); torch.cuda.synchronize()
-b = buf.cpu().reshape(3, -1, 8, 4)
-for ki, name in enumerate(["K12", "K45", "K67"]):
+b = buf.cpu().reshape(3, -1, 8, 8)
+for ki, name in enumerate(["K12", "K345", "K67"]):
     d = b[ki]
     nb = int((d[:, 0, 3] > 0).sum())
     d = d[:nb].double()
     steps = d[:, :, 3].mean()
     for wv in range(8):
         w, i, k = d[:, wv, 0].mean() / steps, d[:, wv, 1].mean() / steps, d[:, wv, 2].mean() / steps
-        print(f"{name} wave{wv} ({'A' if wv < 4 else 'B'}): per step wait+barrier {w:7.0f}  dma-issue {i:6.0f}  work {k:7.0f}  total {w+i+k:7.0f}  (blocks {nb}, steps {steps:.0f})")
+        print(f"{name} wave{wv} ({'A' if wv < 4 else 'B'}): per step wait+barrier {w:7.0f}  dma-issue {i:6.0f}  work {k:7.0f}  total {w+i+k:7.0f}  (blocks {nb}, steps {steps:.0f})  fine " + " ".join(f"{float(d[:, wv, 4 + e].mean() / steps):6.0f}" for e in range(4)))
