@@ -27,6 +27,7 @@
 // vmcnt waits, every pixel fragment feeding three MFMAs (ky = 0,1,2) into rotating accumulators.
 #include "ie_zdce_internal.h"
 #include <string.h>
+#include <type_traits>
 #include <stdlib.h>
 
 namespace {
@@ -42,8 +43,14 @@ constexpr int PF_DEFAULT = IE_PF; // rows of DMA issued ahead (K67 is LDS-limite
 
 enum { K12 = 12, K45 = 45, K67 = 67, K345 = 345 };
 
+#ifndef IE_EXP
+#define IE_EXP 0      // timing experiments (wrong results): 1 no image DMA / row conversion, 2 e_conv1 without LDS reads, 4 no hand-off write,
+#endif                // 8 MFMA streams without LDS reads, 16 no K12 stores, 32 no e_conv1 at all, 64 raw-accumulator stores (no epilogue VALU), 128 K12 stores forced out of range
 #ifndef IE_K12_RPB
-#define IE_K12_RPB 2
+#define IE_K12_RPB 1
+#endif
+#ifndef IE_K12_STREAM
+#define IE_K12_STREAM 1
 #endif
 // Ring geometry shared by the kernel body and the launcher (LDS size).
 template <int KIND> struct FusedGeom {
@@ -60,6 +67,9 @@ template <int KIND> struct FusedGeom {
     static constexpr int NRH = 2 * RPB;                           // A -> B hand-off ring
     static constexpr int LAG_A = (KIND == K12) ? RPB : 0;         // K12: stage A runs behind the image row conversion
     static constexpr int LAG_B = RPB - 1;                         // extra rows stage B runs behind stage A
+    // K12 streamed form: every epilogue (hand-off write, stores) is deferred by one step and rides between the MFMAs of the next
+    static constexpr int DEF = (KIND == K12 && IE_K12_STREAM) ? 1 : 0;
+    static constexpr int LAG_H = LAG_B + DEF;                     // rows between stage A computing a hand-off row and its consumers reading it, minus one
     static constexpr int NRI = (KIND == K12) ? PF + RPB : PF + 3; // fp32 image ring slots (K67: kept until the deferred curve)
     static constexpr int NRC = 2 + LAG_A + RPB;                   // K12: converted image rows (3 being read + RPB being written)
     static constexpr int IMG_SLOT_B = 2048;                       // 3 planes x 132 px fp32 (K12) / 3 x 128 (K67)
@@ -73,7 +83,8 @@ template <int KIND> struct FusedGeom {
     static constexpr int IMG_B = (KIND == K45 || KIND == K345) ? 0 : NRI * IMG_SLOT_B;
     static constexpr int CV_B = (KIND == K12) ? NRC * CV_SLOT_B : 0;
     static constexpr int STAGE_B = (KIND == K67) ? 2 * STAGE_SLOT_B : 0;
-    static constexpr int LDS_B = A_RING_B + B_RING_B + R3_B + RA_B + IMG_B + CV_B + STAGE_B;
+    static constexpr int DUMP_B = (KIND == K12) ? 1024 : 0;       // K12: where the idle lanes of the branch-free row conversion write
+    static constexpr int LDS_B = A_RING_B + B_RING_B + R3_B + RA_B + IMG_B + CV_B + STAGE_B + DUMP_B;
 };
 
 struct FusedParams {
@@ -135,10 +146,12 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     constexpr int MARG = ((KIND == K345) ? 2 : 1) + (HALO ? 0 : 1);  // computed columns lost per side (one per LDS hand-off, one without halo)
     constexpr int TSK = TW - 2 * MARG;                               // stored columns = strip pitch
     // ---- LDS carve (FusedGeom) ------------------------------------------------------------------
-    constexpr int NRA = G::NRA, NRB = G::NRB, NR3 = G::NR3, NRH = G::NRH, LAG_A = G::LAG_A, LAG_B = G::LAG_B, NRI = G::NRI, NRC = G::NRC;
+    constexpr int NRA = G::NRA, NRB = G::NRB, NR3 = G::NR3, NRH = G::NRH, LAG_A = G::LAG_A, LAG_B = G::LAG_B, LAG_H = G::LAG_H, NRI = G::NRI, NRC = G::NRC;
+    (void)LAG_B;
     constexpr int IMG_SLOT_B = G::IMG_SLOT_B, CV_PLANE_B = G::CV_PLANE_B, CV_SLOT_B = G::CV_SLOT_B, STAGE_SLOT_B = G::STAGE_SLOT_B;
     constexpr int OFF_BRING = G::A_RING_B, OFF_R3 = OFF_BRING + G::B_RING_B, OFF_RA = OFF_R3 + G::R3_B, OFF_IMG = OFF_RA + G::RA_B,
-                  OFF_CV = OFF_IMG + G::IMG_B, OFF_STAGE = OFF_CV + G::CV_B;
+                  OFF_CV = OFF_IMG + G::IMG_B, OFF_STAGE = OFF_CV + G::CV_B, OFF_DUMP = OFF_STAGE + G::STAGE_B;
+    (void)OFF_DUMP;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -156,7 +169,7 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     const int xc0 = strip * TSK - MARG;                     // image column of computed column 0
     const int ys = p.y_begin + chunk * p.rows_per_block;
     const int ye = min(ys + p.rows_per_block, p.y_end);
-    const int n_steps = (ye - ys) + 6 + LAG_A + LAG_B + (KIND == K67 ? 1 : 0) + (KIND == K345 ? 4 : 0);
+    const int n_steps = (ye - ys) + 6 + LAG_A + LAG_H + (KIND == K67 ? 1 : 0) + (KIND == K345 ? 4 : 0);
     constexpr int A_ROW0 = (KIND == K345) ? 4 : 2;          // stage A's HBM input row at step t is ys - A_ROW0 + t
     const int H = p.H, W = p.W;
     const size_t plane = (size_t)H * W;
@@ -273,7 +286,7 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
         if (stg == 0) {
             if constexpr (NSA >= 1) IE_DMA_ROW(rsA0, smem + (t % NRA) * ROW_B, ys - A_ROW0 + t);
             if constexpr (NSA >= 2) IE_DMA_ROW(rsA1, smem + NRA * ROW_B + (t % NRA) * ROW_B, ys - A_ROW0 + t);
-            if constexpr (KIND == K12) {
+            if constexpr (KIND == K12 && !(IE_EXP & 1)) {
                 const int y = ys - 2 + t;
                 const unsigned rmask = ((y >= 0) && (y < H)) ? 0u : OOB;
                 const unsigned row_b = rmask ? 0u : (unsigned)y * (unsigned)W * 4u;
@@ -340,16 +353,24 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
         rd_last = lds_px(xl >= TW ? (HALO ? TW + 1 : TW - 1) : xl);
     }
 
-    // one source row into the three live accumulator sets
-    auto src_mfma = [&](auto tg, const char* row, int wbase, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4], int x1_row) __attribute__((always_inline)) {
+    // one source row into the three live accumulator sets.  The set started by this row (accN, ky = 0) takes its initial value
+    // (`init`: the bias) as the C operand of its first MFMA when `first` is set -- no reset moves, and whatever still reads the
+    // previous contents of accN (the epilogue of the row finished one step earlier) only has to come before THAT MFMA.
+    // nv (a std::integral_constant): vector instructions the scheduler is asked to place after every MFMA.  Independent VALU work
+    // of the same basic block (the deferred epilogue, address arithmetic) then rides in the MFMAs' issue shadow -- two per MFMA are
+    // nearly free in a wave's own stream, whereas a VALU-only phase beside the SIMD partner's MFMA-only phase costs almost its full
+    // length (tools/micro/coissue.hip, profiles/r02/coissue_microbench.log).
+    auto src_mfma = [&](auto tg, const char* row, int wbase, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4], bool first,
+                        const ie_f32x4& init, auto nv) __attribute__((always_inline)) {
         using TT = typename decltype(tg)::type;
+        constexpr int NV = decltype(nv)::value;
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 const int off = (kx == 0 && nt == 0) ? rd_first : (kx == 2 && nt == 3) ? rd_last : rd_base[kx] + 1024 * nt;
-                const frag bx = *(const frag*)(row + off);
-                accN[nt] = ie_mfma16_raw<TT>(wv[wbase + 0 * 3 + kx], bx, accN[nt]);
+                const frag bx = (IE_EXP & 8) ? wv[wbase + (kx + nt) % 9] : *(const frag*)(row + off);
+                accN[nt] = ie_mfma16_raw<TT>(wv[wbase + 0 * 3 + kx], bx, (first && kx == 0) ? init : accN[nt]);
                 accM[nt] = ie_mfma16_raw<TT>(wv[wbase + 1 * 3 + kx], bx, accM[nt]);
                 accO[nt] = ie_mfma16_raw<TT>(wv[wbase + 2 * 3 + kx], bx, accO[nt]);
             }
@@ -357,13 +378,28 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
 #define IE_LDS_DEPTH 3
 #endif
         __builtin_amdgcn_sched_group_barrier(0x100, IE_LDS_DEPTH, 0);
+        if constexpr (NV == 0) {
 #pragma unroll
-        for (int f = 0; f < 12 - IE_LDS_DEPTH; ++f) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            for (int f = 0; f < 12 - IE_LDS_DEPTH; ++f) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 3 * IE_LDS_DEPTH, 0);
+        } else {
+#pragma unroll
+            for (int f = 0; f < 12; ++f) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
+                }
+                if (f < 12 - IE_LDS_DEPTH) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, 3 * IE_LDS_DEPTH, 0);
     };
+    constexpr std::integral_constant<int, 0> NV0{};
+    constexpr std::integral_constant<int, 2> NV2{};
+    (void)NV0; (void)NV2;
 
     // write a finished stage-A row (ReLU, 16-bit, zero outside the image) into the hand-off ring slot
     auto a_emit_to = [&](auto tg, const ie_f32x4 (&acc)[4], char* slot, int ra, bool relu = true) __attribute__((always_inline)) {
@@ -388,6 +424,13 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     // stage-B epilogue to HBM (centre 126 columns): ReLU'd activations (x2, x5) or the raw P map (K12)
 #define IE_B_STORE(ACC, YO, RS, RELU)                                                                                     \
     do {                                                                                                                  \
+        if constexpr (IE_EXP & 64) { /* keep the MFMAs alive with no VALU: raw accumulators to an out-of-range offset */   \
+            _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                                            \
+                ie_u32x4 v_ = {__float_as_uint(ACC[nt][0]), __float_as_uint(ACC[nt][1]), __float_as_uint(ACC[nt][2]), __float_as_uint(ACC[nt][3])}; \
+                __builtin_amdgcn_raw_buffer_store_b128(v_, RS, (int)OOB, 0, 0);                                           \
+            }                                                                                                             \
+            break;                                                                                                        \
+        }                                                                                                                 \
         const int yo_ = (YO);                                                                                             \
         const bool row_ok_ = (yo_ >= ys) && (yo_ < ye);                                                                   \
         ie_u32x2 pk_[4];                                                                                                  \
@@ -473,20 +516,23 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     //   MFMA m, lane group kq:  ky = 2m + (kq>>1),  kx = 2(kq&1) + (j>>2),  c = j&3     (ky,kx = 3: zero weights)
     // so a lane's 8 k-values are two adjacent interleaved pixels = 16 contiguous bytes of the row.
     auto convert_row = [&](int t) __attribute__((always_inline)) {
+        // branch-free (one basic block with stage B's MFMAs): lanes past the row read a clamped pixel and write into a per-lane dump
         const int px = sw * 64 + lane;      // row R(t) = ys-2+t landed in fp32 slot t % NRI
-        if (px < 132) {                     // px 130/131 are read by the zero-weight pad tap: keep them finite (0)
-            const float* ip = (const float*)(smem + OFF_IMG + (t % NRI) * IMG_SLOT_B) + px;
+        {                                   // px 130/131 are read by the zero-weight pad tap: keep them finite (0)
+            const float* ip = (const float*)(smem + OFF_IMG + (t % NRI) * IMG_SLOT_B) + (px < 131 ? px : 131);
             const bool real = px < 130;
-            const float r = real ? ip[0] : 0.f, g = real ? ip[132] : 0.f, bl = real ? ip[264] : 0.f;
+            const float r0 = ip[0], g0 = ip[132], b0 = ip[264];
+            const float r = real ? r0 : 0.f, g = real ? g0 : 0.f, bl = real ? b0 : 0.f;
             const TH hr = (TH)r, hg = (TH)g, hb = (TH)bl;
             ie_u32x2 hi, lo;
             hi[0] = ie_pack2<TH>(r, g);
             hi[1] = ie_pack2<TH>(bl, 0.f);
             lo[0] = ie_pack2<TH>(r - (float)hr, g - (float)hg);
             lo[1] = ie_pack2<TH>(bl - (float)hb, 0.f);
-            char* cv = smem + OFF_CV + (t % NRC) * CV_SLOT_B + px * 8;
+            const bool keep = px < 132;
+            char* cv = smem + (keep ? OFF_CV + (t % NRC) * CV_SLOT_B + px * 8 : OFF_DUMP + lane * 8);
             *(ie_u32x2*)cv = hi;
-            *(ie_u32x2*)(cv + CV_PLANE_B) = lo;
+            *(ie_u32x2*)(cv + (keep ? CV_PLANE_B : 512)) = lo;
         }
     };
     auto conv1_row = [&](int t, ie_f32x4 (&acc)[4]) __attribute__((always_inline)) {
@@ -504,6 +550,7 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
             for (int nt = 0; nt < 4; ++nt) {       // all loads first: the four tiles are independent MFMA chains
                 const char* r0 = smem + s0 + part * CV_PLANE_B + 128 * nt;
                 const char* r1 = smem + s1 + part * CV_PLANE_B + 128 * nt;
+                if constexpr (IE_EXP & 2) { b0[nt] = wv[0]; b1[nt] = wv[1]; continue; }
                 const ie_u32x2 b0a = *(const ie_u32x2*)r0, b0b = *(const ie_u32x2*)(r0 + 8);
                 const ie_u32x2 b1a = *(const ie_u32x2*)r1, b1b = *(const ie_u32x2*)(r1 + 8);
                 b0[nt] = ie_u32x4{b0a[0], b0a[1], b0b[0], b0b[1]};
@@ -559,24 +606,22 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
             // (ys-5+t) -> P row ys-6+t complete in pO.  With e_conv7a here and e_conv2 on stage B the two waves of a SIMD carry 44 and
             // 36 MFMAs per row instead of 8 and 72, so each one's LDS / VALU / store work hides under the other's MFMAs.
             IE_TX0();
-            conv1_row(t, accO);
+            if constexpr (!(IE_EXP & 32)) conv1_row(t, accO);
             IE_TX(0);
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) pN[nt] = bias4p;
-            src_mfma(ie_tag<TH>{}, smem + OFF_RA + ((t + RPB) % NRH) * ROW_B, 9, pN, pM, pO, 0);    // x1 row emitted at step t-RPB
+            src_mfma(ie_tag<TH>{}, smem + OFF_RA + ((t + RPB) % NRH) * ROW_B, 9, pN, pM, pO, true, bias4p, NV2);    // x1 row emitted at step t-RPB
             IE_TX(1);
             IE_T(ts2);
             issue(t + PF);
             IE_TX(2);
-            if (t >= 2 + LAG_A) a_emit(accO, t);
+            if constexpr (!(IE_EXP & 4)) a_emit(accO, t);          // unconditional: rows emitted before the first valid one are never part of a stored row
             IE_TX(3);
-            IE_B_STORE(pO, ys - 5 - LAG_A - LAG_B + t, rsDa, false);         // always issued (rows outside the chunk go out of range): the vmcnt bookkeeping counts on it
+            if constexpr (!(IE_EXP & 16)) IE_B_STORE(pO, ys - 5 - LAG_A - LAG_B + t, rsDa, false);         // always issued (rows outside the chunk go out of range): the vmcnt bookkeeping counts on it
         } else if constexpr (KIND == K345) {
             // e_conv3 on x2 row ys-4+t -> x3 row ys-5+t (accO); e_conv4 on the x3 row emitted at step t-1 -> x4 row ys-7+t (pO)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) { accN[nt] = bias4; pN[nt] = bias4p; }
-            src_mfma(ie_tag<TA0>{}, smem + (t % NRA) * ROW_B, 0, accN, accM, accO, 0);
-            src_mfma(ie_tag<T3>{}, smem + OFF_R3 + ((t + NR3 - 1) % NR3) * ROW_B, 9, pN, pM, pO, 0);
+            src_mfma(ie_tag<TA0>{}, smem + (t % NRA) * ROW_B, 0, accN, accM, accO, false, bias4, NV0);
+            src_mfma(ie_tag<T3>{}, smem + OFF_R3 + ((t + NR3 - 1) % NR3) * ROW_B, 9, pN, pM, pO, false, bias4, NV0);
             IE_T(ts2);
             issue(t + PF);
             if (t >= 2) a_emit_to(ie_tag<T3>{}, accO, smem + OFF_R3 + (t % NR3) * ROW_B, ys - 5 + t);
@@ -584,8 +629,8 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
         } else {
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) accN[nt] = bias4;
-            src_mfma(ie_tag<TA0>{}, smem + (t % NRA) * ROW_B, 0, accN, accM, accO, 0);
-            if constexpr (NSA == 2) src_mfma(ie_tag<TA1>{}, smem + NRA * ROW_B + (t % NRA) * ROW_B, 9, accN, accM, accO, 0);
+            src_mfma(ie_tag<TA0>{}, smem + (t % NRA) * ROW_B, 0, accN, accM, accO, false, bias4, NV0);
+            if constexpr (NSA == 2) src_mfma(ie_tag<TA1>{}, smem + NRA * ROW_B + (t % NRA) * ROW_B, 9, accN, accM, accO, false, bias4, NV0);
             IE_T(ts2);
             issue(t + PF);
             if (t >= 2) a_emit(accO, t);
@@ -602,10 +647,10 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
         IE_T(ts2);
         // accN (and pN) still hold the output row finished at step t-1: ys-5-LAG_A+(t-1)
         IE_TX0();
-        if constexpr (KIND == K12) convert_row(t);
+        if constexpr (KIND == K12 && !(IE_EXP & 1)) convert_row(t);
         IE_TX(0);
         if constexpr (KIND == K12) {
-            if (t >= 6 + LAG_A + LAG_B) IE_B_STORE(accN, ys - 6 - LAG_A - LAG_B + t, rsDb, true);
+            if constexpr (!(IE_EXP & 16)) IE_B_STORE(accN, ys - 6 - LAG_A - LAG_B + t, rsDb, true);      // branch-free (rows outside the chunk go out of range): one basic block with the MFMAs
             IE_TX(1);
         } else if constexpr (KIND == K45) {
             if (t >= 6) IE_B_STORE(accN, ys - 6 + t, rsDb, true);
@@ -617,22 +662,186 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
         }
         const char* ra_row = smem + OFF_RA + ((t + RPB) % NRH) * ROW_B;     // written by stage A at step t-RPB
         if constexpr (KIND == K12) {
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) accN[nt] = bias4;
-            src_mfma(ie_tag<TH>{}, ra_row, 0, accN, accM, accO, 0);                    // x1 row ys-5+t
+            src_mfma(ie_tag<TH>{}, ra_row, 0, accN, accM, accO, true, bias4, NV2);     // x1 row ys-5-LAG_B+t
         } else if constexpr (KIND == K45) {
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) accN[nt] = bias4;
-            src_mfma(ie_tag<TA0>{}, smem + ((t + NRA - 2) % NRA) * ROW_B, 0, accN, accM, accO, 0);   // x3 row ys-4+t
-            src_mfma(ie_tag<TH>{}, ra_row, 9, accN, accM, accO, 0);                                   // x4 row ys-4+t
+            src_mfma(ie_tag<TA0>{}, smem + ((t + NRA - 2) % NRA) * ROW_B, 0, accN, accM, accO, false, bias4, NV0);   // x3 row ys-4+t
+            src_mfma(ie_tag<TH>{}, ra_row, 9, accN, accM, accO, false, bias4, NV0);                                   // x4 row ys-4+t
         } else if constexpr (KIND == K345) {
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) accN[nt] = bias4;
-            src_mfma(ie_tag<T3>{}, smem + OFF_R3 + ((t + NR3 - 3) % NR3) * ROW_B, 0, accN, accM, accO, 0);   // x3 row ys-8+t (emitted at step t-3)
-            src_mfma(ie_tag<TH>{}, ra_row, 9, accN, accM, accO, 0);                                           // x4 row ys-8+t (emitted at step t-1)
+            src_mfma(ie_tag<T3>{}, smem + OFF_R3 + ((t + NR3 - 3) % NR3) * ROW_B, 0, accN, accM, accO, false, bias4, NV0);   // x3 row ys-8+t (emitted at step t-3)
+            src_mfma(ie_tag<TH>{}, ra_row, 9, accN, accM, accO, false, bias4, NV0);                                           // x4 row ys-8+t (emitted at step t-1)
         } else {
             seed_from_p(t, accN);                                                      // P row ys-3+t = W7a*x1 + bias7
-            src_mfma(ie_tag<TH>{}, ra_row, 0, accN, accM, accO, 0);                    // x6 row ys-4+t
+            src_mfma(ie_tag<TH>{}, ra_row, 0, accN, accM, accO, false, bias4, NV0);                    // x6 row ys-4+t
+        }
+        IE_STEP_TAIL();
+    };
+
+
+    // ---- K12, streamed form ------------------------------------------------------------------------
+    // tools/micro/coissue.hip: a wave's vector instructions are nearly free when they sit between its OWN MFMAs (two per MFMA),
+    // and cost almost their full issue time as a VALU-only phase beside the SIMD partner's MFMA-only phase.  So both stages run ONE
+    // MFMA stream per step and everything else of the step is cut into small fillers placed after fixed MFMAs of that stream
+    // (sched_barrier pins the order).  Fillers must not depend on the stream's results: every epilogue is deferred by one step
+    // (the row finished at step t-1 still sits in the accumulator set that step t starts afresh; its tile nt is packed before
+    // the first MFMA that overwrites tile nt), which costs the hand-off one more row of lag (G::DEF).
+#define IE_SB() __builtin_amdgcn_sched_barrier(0)
+    auto mfma_stream = [&](auto tg, const char* row, int wbase, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4], const ie_f32x4& init,
+                           auto&& fill) __attribute__((always_inline)) {
+        using TT = typename decltype(tg)::type;
+        frag bx[12];
+        auto rd = [&](int g) __attribute__((always_inline)) {
+            const int kx = g >> 2, nt = g & 3;
+            const int off = (kx == 0 && nt == 0) ? rd_first : (kx == 2 && nt == 3) ? rd_last : rd_base[kx] + 1024 * nt;
+            bx[g] = (IE_EXP & 8) ? wv[wbase + (kx + nt) % 9] : *(const frag*)(row + off);
+        };
+        rd(0); rd(1); rd(2);
+        IE_SB();
+#pragma unroll
+        for (int g = 0; g < 12; ++g) {
+            const int kx = g >> 2, nt = g & 3;
+            if (g + 3 < 12) rd(g + 3);
+            accN[nt] = ie_mfma16_raw<TT>(wv[wbase + 0 * 3 + kx], bx[g], kx == 0 ? init : accN[nt]);
+            fill(3 * g);
+            IE_SB();
+            accM[nt] = ie_mfma16_raw<TT>(wv[wbase + 1 * 3 + kx], bx[g], accM[nt]);
+            fill(3 * g + 1);
+            IE_SB();
+            accO[nt] = ie_mfma16_raw<TT>(wv[wbase + 2 * 3 + kx], bx[g], accO[nt]);
+            fill(3 * g + 2);
+            IE_SB();
+        }
+    };
+    // loop-invariant lane geometry of the deferred epilogues
+    unsigned st_col[2];     // byte offset of this lane's 16-byte store of tile pair j inside an output row, or OOB
+    int em_off[4];          // hand-off write of tile nt: byte offset inside the ring slot
+    unsigned em_in = 0;     // bit nt: tile nt's column lies inside the image
+    if constexpr (KIND == K12) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int q = 64 * ph + 16 * (2 * j + (kq & 1)) + p16, xo = xc0 + q;
+            st_col[j] = (q >= MARG && q < TW - MARG && xo < W) ? (unsigned)(xo * PXB + (16 * ch + 4 * (kq & 2)) * 2) : OOB;
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int q = 64 * ph + 16 * nt + p16, x = xc0 + q, c = 2 * ch + (kq >> 1);
+            em_off[nt] = q * PXB + ((c ^ ((q >> 1) & 3)) << 4) + (kq & 1) * 8;
+            em_in |= (x >= 0 && x < W) ? (1u << nt) : 0u;
+        }
+    }
+#define IE_PACK_TILE(TT, A, RELU)                                                                                          \
+    ie_u32x2{(RELU) ? ie_pack2_relu<TT>((A)[0], (A)[1]) : ie_pack2<TT>((A)[0], (A)[1]),                                    \
+             (RELU) ? ie_pack2_relu<TT>((A)[2], (A)[3]) : ie_pack2<TT>((A)[2], (A)[3])}
+#define IE_STORE_PAIR(RS, P0, P1, J, ROWB, RMASK)                                                                          \
+    do {                                                                                                                  \
+        auto sx_ = __builtin_amdgcn_permlane16_swap((P0)[0], (P1)[0], false, false);                                      \
+        auto sy_ = __builtin_amdgcn_permlane16_swap((P0)[1], (P1)[1], false, false);                                      \
+        ie_u32x4 v_ = {sx_[0], sy_[0], sx_[1], sy_[1]};                                                                   \
+        __builtin_amdgcn_raw_buffer_store_b128(v_, RS, (int)(((ROWB) + st_col[J]) | (RMASK)), 0, 0);                       \
+    } while (0)
+
+    // Stage B: e_conv2.  accN = the x2 row finished at step t-1.  Fillers: its pack + store, and the conversion of image row R(t).
+    auto step_b12 = [&](int t, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4]) __attribute__((always_inline)) {
+        IE_STEP_HEAD(wait_base);
+        IE_T(ts2);
+        const int yo = ys - 6 - LAG_A - LAG_H + t;
+        const unsigned rmask = ((yo >= ys) && (yo < ye) && !((IE_EXP & 128) && p.N > 0)) ? 0u : OOB;   // IE_EXP 128: every store out of range (same instructions, no HBM writes)
+        const unsigned row_b = rmask ? 0u : (unsigned)yo * (unsigned)W * PXB;
+        ie_u32x2 pk[4];
+        const int px = sw * 64 + lane;
+        const float* ip = (const float*)(smem + OFF_IMG + (t % NRI) * IMG_SLOT_B) + (px < 131 ? px : 131);
+        const bool keep = px < 132;
+        char* cv = smem + (keep ? OFF_CV + (t % NRC) * CV_SLOT_B + px * 8 : OFF_DUMP + lane * 8);
+        float r0 = 0.f, g0 = 0.f, b0 = 0.f;
+        ie_u32x2 hi = {0u, 0u}, lo = {0u, 0u};
+        pk[0] = IE_PACK_TILE(TO, accN[0], true);
+        auto fill = [&](int s) __attribute__((always_inline)) {
+            if (s == 0) pk[1] = IE_PACK_TILE(TO, accN[1], true);
+            if (s == 1) { if constexpr (!(IE_EXP & 16)) IE_STORE_PAIR(rsDb, pk[0], pk[1], 0, row_b, rmask); }
+            if (s == 3) pk[2] = IE_PACK_TILE(TO, accN[2], true);
+            if (s == 6) pk[3] = IE_PACK_TILE(TO, accN[3], true);
+            if (s == 7) { if constexpr (!(IE_EXP & 16)) IE_STORE_PAIR(rsDb, pk[2], pk[3], 1, row_b, rmask); }
+            if constexpr (!(IE_EXP & 1)) {
+                if (s == 9) { r0 = ip[0]; g0 = ip[132]; b0 = ip[264]; }
+                if (s == 20) { const bool real = px < 130; r0 = real ? r0 : 0.f; g0 = real ? g0 : 0.f; b0 = real ? b0 : 0.f; }
+                if (s == 21) { hi[0] = ie_pack2<TH>(r0, g0); hi[1] = ie_pack2<TH>(b0, 0.f); }
+                if (s == 22) { r0 -= (float)(TH)r0; g0 -= (float)(TH)g0; }
+                if (s == 23) { b0 -= (float)(TH)b0; lo[0] = ie_pack2<TH>(r0, g0); }
+                if (s == 24) { lo[1] = ie_pack2<TH>(b0, 0.f); *(ie_u32x2*)cv = hi; }
+                if (s == 25) *(ie_u32x2*)(cv + (keep ? CV_PLANE_B : 512)) = lo;
+            }
+        };
+        mfma_stream(ie_tag<TH>{}, smem + OFF_RA + ((t + RPB) % NRH) * ROW_B, 0, accN, accM, accO, bias4, fill);
+        IE_STEP_TAIL();
+    };
+    // Stage A: the x1 half of e_conv7 (36 MFMAs) then e_conv1 (8, or 16 with bf16 operands).  eN = the x1 row e_conv1 finished at
+    // step t-1, pN = the P row finished at step t-1.  Fillers: P pack + store, the hand-off write of eN, the image DMA of row t+PF,
+    // the LDS reads of e_conv1's operands.
+    auto step_a12 = [&](int t, ie_f32x4 (&eN)[4], ie_f32x4 (&eO)[4], ie_f32x4 (&pN)[4], ie_f32x4 (&pM)[4], ie_f32x4 (&pO)[4]) __attribute__((always_inline)) {
+        // at the barrier the image DMA of row t+RPB-1 must have landed.  Per step this wave issues two P stores, then two loads:
+        // ops younger than that DMA = 2 (PF-RPB) prologue loads + 2 per elapsed step, 4 (PF-RPB) in the steady state
+        IE_STEP_HEAD(2 * (PF - RPB) + 2 * (t < PF - RPB ? t : PF - RPB));
+        IE_T(ts2);
+        const int yo = ys - 6 - LAG_A - LAG_H + t;
+        const unsigned rmask = ((yo >= ys) && (yo < ye) && !((IE_EXP & 128) && p.N > 0)) ? 0u : OOB;   // IE_EXP 128: every store out of range (same instructions, no HBM writes)
+        const unsigned row_b = rmask ? 0u : (unsigned)yo * (unsigned)W * PXB;
+        const int ra = ys - 3 - LAG_A - 1 + t;                      // x1 row computed at step t-1
+        const bool row_in = (ra >= 0) && (ra < H);
+        char* eslot = smem + OFF_RA + (t % NRH) * ROW_B;
+        ie_u32x2 pk[4], ek = {0u, 0u};
+        constexpr int PARTS = (ie_elem<TH>::dtype == IE_BF16) ? 2 : 1;
+        ie_u32x4 c0[PARTS][4], c1[PARTS][4];
+        const int pxo = (64 * ph + p16 + 2 * (kq & 1)) * 8;
+        const int s0 = OFF_CV + ((t + NRC - 2 - LAG_A + (kq >> 1)) % NRC) * CV_SLOT_B + pxo;     // m = 0: ky = kq>>1
+        const int s1 = OFF_CV + ((t + NRC - LAG_A) % NRC) * CV_SLOT_B + pxo;                     // m = 1: ky = 2 (kq < 2)
+        auto c1_read = [&](int part, int nt) __attribute__((always_inline)) {
+            if constexpr (IE_EXP & 2) { c0[part][nt] = wv[0]; c1[part][nt] = wv[1]; return; }
+            const char* r0 = smem + s0 + part * CV_PLANE_B + 128 * nt;
+            const char* r1 = smem + s1 + part * CV_PLANE_B + 128 * nt;
+            const ie_u32x2 a0_ = *(const ie_u32x2*)r0, a1_ = *(const ie_u32x2*)(r0 + 8);
+            const ie_u32x2 b0_ = *(const ie_u32x2*)r1, b1_ = *(const ie_u32x2*)(r1 + 8);
+            c0[part][nt] = ie_u32x4{a0_[0], a0_[1], a1_[0], a1_[1]};
+            c1[part][nt] = ie_u32x4{b0_[0], b0_[1], b1_[0], b1_[1]};
+        };
+        pk[0] = IE_PACK_TILE(TO, pN[0], false);
+        auto fill = [&](int s) __attribute__((always_inline)) {
+            if (s == 0) pk[1] = IE_PACK_TILE(TO, pN[1], false);
+            if (s == 1) { if constexpr (!(IE_EXP & 16)) IE_STORE_PAIR(rsDa, pk[0], pk[1], 0, row_b, rmask); }
+            if (s == 3) pk[2] = IE_PACK_TILE(TO, pN[2], false);
+            if (s == 6) pk[3] = IE_PACK_TILE(TO, pN[3], false);
+            if (s == 7) { if constexpr (!(IE_EXP & 16)) IE_STORE_PAIR(rsDa, pk[2], pk[3], 1, row_b, rmask); }
+            if constexpr (!(IE_EXP & 4)) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    if (s == 9 + 3 * nt) ek = IE_PACK_TILE(TH, eN[nt], true);
+                    if (s == 10 + 3 * nt) {
+                        const bool in_img = row_in && ((em_in >> nt) & 1u);
+                        ek[0] = in_img ? ek[0] : 0u; ek[1] = in_img ? ek[1] : 0u;
+                        *(ie_u32x2*)(eslot + em_off[nt]) = ek;
+                    }
+                }
+            }
+            if (s == 21) issue(t + PF);
+            if constexpr (!(IE_EXP & 32)) {
+#pragma unroll
+                for (int part = 0; part < PARTS; ++part)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+                        if (s == 24 + 4 * part + nt) c1_read(part, nt);
+            }
+        };
+        mfma_stream(ie_tag<TH>{}, smem + OFF_RA + ((t + RPB) % NRH) * ROW_B, 9, pN, pM, pO, bias4p, fill);
+        if constexpr (!(IE_EXP & 32)) {
+#pragma unroll
+            for (int part = 0; part < PARTS; ++part) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) eO[nt] = ie_mfma16_raw<TH>(wv[0], c0[part][nt], part == 0 ? bias4 : eO[nt]);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) eO[nt] = ie_mfma16_raw<TH>(wv[1], c1[part][nt], eO[nt]);
+            }
         }
         IE_STEP_TAIL();
     };
@@ -644,7 +853,21 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     ie_f32x4 q0[4], q1[4], q2[4];     // second accumulator family: K12 stage B (the e_conv7a / P map), K345 stage A (e_conv4)
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) { a0[nt] = bias4; a1[nt] = bias4; a2[nt] = bias4; q0[nt] = bias4p; q1[nt] = bias4p; q2[nt] = bias4p; }
-    if (stg == 0) {
+    if constexpr (KIND == K12 && G::DEF) {
+        if (stg == 0) {
+            for (int t = 0; t < n_steps; t += 3) {
+                step_a12(t, a0, a2, q0, q1, q2);
+                if (t + 1 < n_steps) step_a12(t + 1, a2, a1, q2, q0, q1);
+                if (t + 2 < n_steps) step_a12(t + 2, a1, a0, q1, q2, q0);
+            }
+        } else {
+            for (int t = 0; t < n_steps; t += 3) {
+                step_b12(t, a0, a1, a2);
+                if (t + 1 < n_steps) step_b12(t + 1, a2, a0, a1);
+                if (t + 2 < n_steps) step_b12(t + 2, a1, a2, a0);
+            }
+        }
+    } else if (stg == 0) {
         for (int t = 0; t < n_steps; t += 3) {
             step_a(t, a0, a1, a2, q0, q1, q2);
             if (t + 1 < n_steps) step_a(t + 1, a2, a0, a1, q2, q0, q1);
@@ -660,6 +883,9 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
 #undef IE_STEP_HEAD
 #undef IE_STEP_TAIL
 #undef IE_B_STORE
+#undef IE_PACK_TILE
+#undef IE_STORE_PAIR
+#undef IE_SB
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef IE_STAMP
     if (p.stamps && lane == 0) {

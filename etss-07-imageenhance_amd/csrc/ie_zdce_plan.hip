@@ -356,6 +356,9 @@ static int forward_mfma(ie_zdce_plan* p, const float* image, float* enhanced, fl
                 return ie_zdce_launch_mfma(a, st);
             };
             auto fused = [&](int kind, int prof_layer) -> int {
+                // diagnostic (wrong results): IE_ZDCE_ONLY=12|345|67 launches just that kernel, e.g. to time it without its neighbours' power draw
+                static const int only = getenv("IE_ZDCE_ONLY") ? atoi(getenv("IE_ZDCE_ONLY")) : 0;
+                if (only && only != kind) return IE_OK;
                 ProfScope ps(p, prof_layer, st);
                 ZdceFusedLaunch a;
                 memset(&a, 0, sizeof(a));
