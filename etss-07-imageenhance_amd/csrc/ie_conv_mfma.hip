@@ -469,7 +469,11 @@ __device__ __forceinline__ void mconv3_epilogue(const MConvParams& p, ie_f32x4 (
             // the two column halves of a row are stored by ONE instruction: lanes kc / kc+1 exchange halves (v_permlane16_swap), so
             // even-kc lanes hold couts 4kc..4kc+7 of the left-half pixel and odd-kc lanes couts 4(kc-1)..+7 of the right-half pixel:
             // 16 bytes per lane, half the store instructions (the epilogue is store-ISSUE-bound: 32 -> 16 per wave and tile)
+#ifdef IE_MEXP_FULL_LINES   // timing experiment (wrong results, Cout = 64): the same bytes, but every store instruction writes 1 KiB of whole lines
+            const unsigned lane_off16 = (unsigned)(((co0 >> 4) & 3) * 1024 + (kc * 16 + l16) * 16);
+#else
             const unsigned lane_off16 = (unsigned)(((l16 + 16 * (kc & 1)) * p.Cout + co0 + 4 * (kc & 2)) * (int)sizeof(T));
+#endif
             (void)half_b; (void)lane_off;
 #pragma unroll
             for (int t = 0; t < NT; t += 2) {

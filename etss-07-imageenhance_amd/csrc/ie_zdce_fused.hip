@@ -52,6 +52,9 @@ enum { K12 = 12, K45 = 45, K67 = 67, K345 = 345 };
 #ifndef IE_K12_STREAM
 #define IE_K12_STREAM 1
 #endif
+#ifndef IE_K345_OUT
+#define IE_K345_OUT 0     // 1: K345 parks its x5 rows in LDS and stores whole lines like K12 (measured slower: 7.42 vs 7.0 ms -- the kernel is
+#endif                    // MFMA-dense and its writes are half of K12's, so the extra LDS traffic costs more than the write path gives back)
 // Ring geometry shared by the kernel body and the launcher (LDS size).
 template <int KIND> struct FusedGeom {
     // rows per barrier.  K12's per-row fixed chain (barrier, e_conv1's LDS-read -> MFMA -> MFMA chain, row conversion, hand-off write)
@@ -84,7 +87,12 @@ template <int KIND> struct FusedGeom {
     static constexpr int CV_B = (KIND == K12) ? NRC * CV_SLOT_B : 0;
     static constexpr int STAGE_B = (KIND == K67) ? 2 * STAGE_SLOT_B : 0;
     static constexpr int DUMP_B = (KIND == K12) ? 1024 : 0;       // K12: where the idle lanes of the branch-free row conversion write
-    static constexpr int LDS_B = A_RING_B + B_RING_B + R3_B + RA_B + IMG_B + CV_B + STAGE_B + DUMP_B;
+    // K12 streamed form: finished x2 / P rows are parked in LDS as whole pixel lines ([px][32 ch], the hand-off image) and stored one
+    // step later, 1 KiB of whole 64-byte lines per store instruction.  Stored straight from the accumulators a wave covers only 32
+    // bytes of each pixel (its 16 output channels), and half-line writes cost the write path twice (profiles/r02/k12_experiments_2.log).
+    static constexpr int OUT = (DEF || (KIND == K345 && IE_K345_OUT)) ? 1 : 0;
+    static constexpr int OUT_B = OUT ? (KIND == K12 ? 2 : 1) * 2 * ROW_B : 0;     // (two tensors x) two slots
+    static constexpr int LDS_B = A_RING_B + B_RING_B + R3_B + RA_B + IMG_B + CV_B + STAGE_B + DUMP_B + OUT_B;
 };
 
 struct FusedParams {
@@ -150,8 +158,8 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     (void)LAG_B;
     constexpr int IMG_SLOT_B = G::IMG_SLOT_B, CV_PLANE_B = G::CV_PLANE_B, CV_SLOT_B = G::CV_SLOT_B, STAGE_SLOT_B = G::STAGE_SLOT_B;
     constexpr int OFF_BRING = G::A_RING_B, OFF_R3 = OFF_BRING + G::B_RING_B, OFF_RA = OFF_R3 + G::R3_B, OFF_IMG = OFF_RA + G::RA_B,
-                  OFF_CV = OFF_IMG + G::IMG_B, OFF_STAGE = OFF_CV + G::CV_B, OFF_DUMP = OFF_STAGE + G::STAGE_B;
-    (void)OFF_DUMP;
+                  OFF_CV = OFF_IMG + G::IMG_B, OFF_STAGE = OFF_CV + G::CV_B, OFF_DUMP = OFF_STAGE + G::STAGE_B, OFF_OUT = OFF_DUMP + G::DUMP_B;
+    (void)OFF_DUMP; (void)OFF_OUT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -169,7 +177,7 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     const int xc0 = strip * TSK - MARG;                     // image column of computed column 0
     const int ys = p.y_begin + chunk * p.rows_per_block;
     const int ye = min(ys + p.rows_per_block, p.y_end);
-    const int n_steps = (ye - ys) + 6 + LAG_A + LAG_H + (KIND == K67 ? 1 : 0) + (KIND == K345 ? 4 : 0);
+    const int n_steps = (ye - ys) + 6 + LAG_A + LAG_H + G::OUT + (KIND == K67 ? 1 : 0) + (KIND == K345 ? 4 : 0);
     constexpr int A_ROW0 = (KIND == K345) ? 4 : 2;          // stage A's HBM input row at step t is ys - A_ROW0 + t
     const int H = p.H, W = p.W;
     const size_t plane = (size_t)H * W;
@@ -421,6 +429,42 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
         a_emit_to(ie_tag<TH>{}, acc, smem + OFF_RA + (t % NRH) * ROW_B, ys - 3 - LAG_A + t);
     };
 
+    // loop-invariant lane geometry of the deferred epilogues
+    unsigned st_col[2];     // byte offset of this lane's 16-byte store of piece 2 sw + j inside an output row, or OOB
+    int st_lds[2];          // ... and where that chunk sits in the parked row
+    int em_off[4];          // hand-off write of tile nt: byte offset inside the ring slot
+    unsigned em_in = 0;     // bit nt: tile nt's column lies inside the image
+    if constexpr (KIND == K12 || KIND == K345) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            {   // piece m = 2 sw + j of the parked row: 16 pixels x 64 bytes, lane = (pixel, 16-byte chunk)
+                const int q = 16 * (2 * sw + j) + (lane >> 2), xo = xc0 + q, c = lane & 3;
+                st_col[j] = (q >= MARG && q < TW - MARG && xo < W) ? (unsigned)(xo * PXB + c * 16) : OOB;
+                st_lds[j] = q * PXB + ((c ^ ((q >> 1) & 3)) << 4);
+            }
+            if constexpr (!G::OUT) {
+            const int q = 64 * ph + 16 * (2 * j + (kq & 1)) + p16, xo = xc0 + q;
+            st_col[j] = (q >= MARG && q < TW - MARG && xo < W) ? (unsigned)(xo * PXB + (16 * ch + 4 * (kq & 2)) * 2) : OOB;
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int q = 64 * ph + 16 * nt + p16, x = xc0 + q, c = 2 * ch + (kq >> 1);
+            em_off[nt] = q * PXB + ((c ^ ((q >> 1) & 3)) << 4) + (kq & 1) * 8;
+            em_in |= (x >= 0 && x < W) ? (1u << nt) : 0u;
+        }
+    }
+#define IE_PACK_TILE(TT, A, RELU)                                                                                          \
+    ie_u32x2{(RELU) ? ie_pack2_relu<TT>((A)[0], (A)[1]) : ie_pack2<TT>((A)[0], (A)[1]),                                    \
+             (RELU) ? ie_pack2_relu<TT>((A)[2], (A)[3]) : ie_pack2<TT>((A)[2], (A)[3])}
+#define IE_STORE_PAIR(RS, P0, P1, J, ROWB, RMASK)                                                                          \
+    do {                                                                                                                  \
+        auto sx_ = __builtin_amdgcn_permlane16_swap((P0)[0], (P1)[0], false, false);                                      \
+        auto sy_ = __builtin_amdgcn_permlane16_swap((P0)[1], (P1)[1], false, false);                                      \
+        ie_u32x4 v_ = {sx_[0], sy_[0], sx_[1], sy_[1]};                                                                   \
+        __builtin_amdgcn_raw_buffer_store_b128(v_, RS, (int)(((ROWB) + st_col[J]) | (RMASK)), 0, 0);                       \
+    } while (0)
+
     // stage-B epilogue to HBM (centre 126 columns): ReLU'd activations (x2, x5) or the raw P map (K12)
 #define IE_B_STORE(ACC, YO, RS, RELU)                                                                                     \
     do {                                                                                                                  \
@@ -563,6 +607,40 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
         }
     };
 
+    // ---- K12, streamed form ------------------------------------------------------------------------
+    // tools/micro/coissue.hip: a wave's vector instructions are nearly free when they sit between its OWN MFMAs (two per MFMA),
+    // and cost almost their full issue time as a VALU-only phase beside the SIMD partner's MFMA-only phase.  So both stages run ONE
+    // MFMA stream per step and everything else of the step is cut into small fillers placed after fixed MFMAs of that stream
+    // (sched_barrier pins the order).  Fillers must not depend on the stream's results: every epilogue is deferred by one step
+    // (the row finished at step t-1 still sits in the accumulator set that step t starts afresh; its tile nt is packed before
+    // the first MFMA that overwrites tile nt), which costs the hand-off one more row of lag (G::DEF).
+#define IE_SB() __builtin_amdgcn_sched_barrier(0)
+    auto mfma_stream = [&](auto tg, const char* row, int wbase, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4], bool first,
+                           const ie_f32x4& init, auto&& fill) __attribute__((always_inline)) {
+        using TT = typename decltype(tg)::type;
+        frag bx[12];
+        auto rd = [&](int g) __attribute__((always_inline)) {
+            const int kx = g >> 2, nt = g & 3;
+            const int off = (kx == 0 && nt == 0) ? rd_first : (kx == 2 && nt == 3) ? rd_last : rd_base[kx] + 1024 * nt;
+            bx[g] = (IE_EXP & 8) ? wv[wbase + (kx + nt) % 9] : *(const frag*)(row + off);
+        };
+        rd(0); rd(1); rd(2);
+        IE_SB();
+#pragma unroll
+        for (int g = 0; g < 12; ++g) {
+            const int kx = g >> 2, nt = g & 3;
+            if (g + 3 < 12) rd(g + 3);
+            accN[nt] = ie_mfma16_raw<TT>(wv[wbase + 0 * 3 + kx], bx[g], (first && kx == 0) ? init : accN[nt]);
+            fill(3 * g);
+            IE_SB();
+            accM[nt] = ie_mfma16_raw<TT>(wv[wbase + 1 * 3 + kx], bx[g], accM[nt]);
+            fill(3 * g + 1);
+            IE_SB();
+            accO[nt] = ie_mfma16_raw<TT>(wv[wbase + 2 * 3 + kx], bx[g], accO[nt]);
+            fill(3 * g + 2);
+            IE_SB();
+        }
+    };
 #ifdef IE_STAMP
     unsigned long long st_wait = 0, st_issue = 0, st_work = 0, st_e[4] = {0, 0, 0, 0}, st_last = 0;
     // finer split of a step: IE_TX(i) adds the cycles since the previous IE_TX / IE_TX0 to bucket i
@@ -655,7 +733,7 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
         } else if constexpr (KIND == K45) {
             if (t >= 6) IE_B_STORE(accN, ys - 6 + t, rsDb, true);
         } else if constexpr (KIND == K345) {
-            if (t >= 10) IE_B_STORE(accN, ys - 10 + t, rsDb, true);
+            if constexpr (!G::OUT) { if (t >= 10) IE_B_STORE(accN, ys - 10 + t, rsDb, true); }
         } else {
             if (t >= 7) curve_consume(t - 2);
             if (t >= 6) stage_write(accN, (t - 1) & 1);
@@ -668,11 +746,33 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
             for (int nt = 0; nt < 4; ++nt) accN[nt] = bias4;
             src_mfma(ie_tag<TA0>{}, smem + ((t + NRA - 2) % NRA) * ROW_B, 0, accN, accM, accO, false, bias4, NV0);   // x3 row ys-4+t
             src_mfma(ie_tag<TH>{}, ra_row, 9, accN, accM, accO, false, bias4, NV0);                                   // x4 row ys-4+t
-        } else if constexpr (KIND == K345) {
+        } else if constexpr (KIND == K345 && !G::OUT) {
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) accN[nt] = bias4;
             src_mfma(ie_tag<T3>{}, smem + OFF_R3 + ((t + NR3 - 3) % NR3) * ROW_B, 0, accN, accM, accO, false, bias4, NV0);   // x3 row ys-8+t (emitted at step t-3)
             src_mfma(ie_tag<TH>{}, ra_row, 9, accN, accM, accO, false, bias4, NV0);                                           // x4 row ys-8+t (emitted at step t-1)
+        } else if constexpr (KIND == K345) {
+            // accN = the x5 row finished at step t-1: packed tile by tile ahead of the MFMAs that restart the set and parked in LDS as
+            // whole pixel lines; the row parked at step t-1 leaves as 1 KiB of whole lines per store instruction.
+            const int yo = ys - 11 + t;
+            const unsigned rmask = ((yo >= ys) && (yo < ye)) ? 0u : OOB;
+            const unsigned row_b = rmask ? 0u : (unsigned)yo * (unsigned)W * PXB;
+            char* oslot = smem + OFF_OUT + (t & 1) * ROW_B;
+            const char* islot = smem + OFF_OUT + ((t + 1) & 1) * ROW_B;
+            ie_u32x2 pk[4];
+            const ie_u32x4 l0 = *(const ie_u32x4*)(islot + st_lds[0]), l1 = *(const ie_u32x4*)(islot + st_lds[1]);
+            pk[0] = IE_PACK_TILE(TO, accN[0], true);
+            auto fill = [&](int s) __attribute__((always_inline)) {
+                if (s == 0) { pk[1] = IE_PACK_TILE(TO, accN[1], true); *(ie_u32x2*)(oslot + em_off[0]) = pk[0]; }
+                if (s == 1) *(ie_u32x2*)(oslot + em_off[1]) = pk[1];
+                if (s == 3) { pk[2] = IE_PACK_TILE(TO, accN[2], true); *(ie_u32x2*)(oslot + em_off[2]) = pk[2]; }
+                if (s == 6) { pk[3] = IE_PACK_TILE(TO, accN[3], true); *(ie_u32x2*)(oslot + em_off[3]) = pk[3]; }
+                if (s == 10) __builtin_amdgcn_raw_buffer_store_b128(l0, rsDb, (int)((row_b + st_col[0]) | rmask), 0, 0);
+                if (s == 12) __builtin_amdgcn_raw_buffer_store_b128(l1, rsDb, (int)((row_b + st_col[1]) | rmask), 0, 0);
+            };
+            auto nofill = [&](int) __attribute__((always_inline)) {};
+            mfma_stream(ie_tag<T3>{}, smem + OFF_R3 + ((t + NR3 - 3) % NR3) * ROW_B, 0, accN, accM, accO, true, bias4, fill);   // x3 row ys-8+t (emitted at step t-3)
+            mfma_stream(ie_tag<TH>{}, ra_row, 9, accN, accM, accO, false, bias4, nofill);                                       // x4 row ys-8+t (emitted at step t-1)
         } else {
             seed_from_p(t, accN);                                                      // P row ys-3+t = W7a*x1 + bias7
             src_mfma(ie_tag<TH>{}, ra_row, 0, accN, accM, accO, false, bias4, NV0);                    // x6 row ys-4+t
@@ -681,76 +781,17 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     };
 
 
-    // ---- K12, streamed form ------------------------------------------------------------------------
-    // tools/micro/coissue.hip: a wave's vector instructions are nearly free when they sit between its OWN MFMAs (two per MFMA),
-    // and cost almost their full issue time as a VALU-only phase beside the SIMD partner's MFMA-only phase.  So both stages run ONE
-    // MFMA stream per step and everything else of the step is cut into small fillers placed after fixed MFMAs of that stream
-    // (sched_barrier pins the order).  Fillers must not depend on the stream's results: every epilogue is deferred by one step
-    // (the row finished at step t-1 still sits in the accumulator set that step t starts afresh; its tile nt is packed before
-    // the first MFMA that overwrites tile nt), which costs the hand-off one more row of lag (G::DEF).
-#define IE_SB() __builtin_amdgcn_sched_barrier(0)
-    auto mfma_stream = [&](auto tg, const char* row, int wbase, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4], const ie_f32x4& init,
-                           auto&& fill) __attribute__((always_inline)) {
-        using TT = typename decltype(tg)::type;
-        frag bx[12];
-        auto rd = [&](int g) __attribute__((always_inline)) {
-            const int kx = g >> 2, nt = g & 3;
-            const int off = (kx == 0 && nt == 0) ? rd_first : (kx == 2 && nt == 3) ? rd_last : rd_base[kx] + 1024 * nt;
-            bx[g] = (IE_EXP & 8) ? wv[wbase + (kx + nt) % 9] : *(const frag*)(row + off);
-        };
-        rd(0); rd(1); rd(2);
-        IE_SB();
-#pragma unroll
-        for (int g = 0; g < 12; ++g) {
-            const int kx = g >> 2, nt = g & 3;
-            if (g + 3 < 12) rd(g + 3);
-            accN[nt] = ie_mfma16_raw<TT>(wv[wbase + 0 * 3 + kx], bx[g], kx == 0 ? init : accN[nt]);
-            fill(3 * g);
-            IE_SB();
-            accM[nt] = ie_mfma16_raw<TT>(wv[wbase + 1 * 3 + kx], bx[g], accM[nt]);
-            fill(3 * g + 1);
-            IE_SB();
-            accO[nt] = ie_mfma16_raw<TT>(wv[wbase + 2 * 3 + kx], bx[g], accO[nt]);
-            fill(3 * g + 2);
-            IE_SB();
-        }
-    };
-    // loop-invariant lane geometry of the deferred epilogues
-    unsigned st_col[2];     // byte offset of this lane's 16-byte store of tile pair j inside an output row, or OOB
-    int em_off[4];          // hand-off write of tile nt: byte offset inside the ring slot
-    unsigned em_in = 0;     // bit nt: tile nt's column lies inside the image
-    if constexpr (KIND == K12) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int q = 64 * ph + 16 * (2 * j + (kq & 1)) + p16, xo = xc0 + q;
-            st_col[j] = (q >= MARG && q < TW - MARG && xo < W) ? (unsigned)(xo * PXB + (16 * ch + 4 * (kq & 2)) * 2) : OOB;
-        }
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const int q = 64 * ph + 16 * nt + p16, x = xc0 + q, c = 2 * ch + (kq >> 1);
-            em_off[nt] = q * PXB + ((c ^ ((q >> 1) & 3)) << 4) + (kq & 1) * 8;
-            em_in |= (x >= 0 && x < W) ? (1u << nt) : 0u;
-        }
-    }
-#define IE_PACK_TILE(TT, A, RELU)                                                                                          \
-    ie_u32x2{(RELU) ? ie_pack2_relu<TT>((A)[0], (A)[1]) : ie_pack2<TT>((A)[0], (A)[1]),                                    \
-             (RELU) ? ie_pack2_relu<TT>((A)[2], (A)[3]) : ie_pack2<TT>((A)[2], (A)[3])}
-#define IE_STORE_PAIR(RS, P0, P1, J, ROWB, RMASK)                                                                          \
-    do {                                                                                                                  \
-        auto sx_ = __builtin_amdgcn_permlane16_swap((P0)[0], (P1)[0], false, false);                                      \
-        auto sy_ = __builtin_amdgcn_permlane16_swap((P0)[1], (P1)[1], false, false);                                      \
-        ie_u32x4 v_ = {sx_[0], sy_[0], sx_[1], sy_[1]};                                                                   \
-        __builtin_amdgcn_raw_buffer_store_b128(v_, RS, (int)(((ROWB) + st_col[J]) | (RMASK)), 0, 0);                       \
-    } while (0)
-
     // Stage B: e_conv2.  accN = the x2 row finished at step t-1.  Fillers: its pack + store, and the conversion of image row R(t).
     auto step_b12 = [&](int t, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4]) __attribute__((always_inline)) {
         IE_STEP_HEAD(wait_base);
         IE_T(ts2);
-        const int yo = ys - 6 - LAG_A - LAG_H + t;
+        const int yo = ys - 6 - LAG_A - LAG_H - G::OUT + t;    // the row parked at step t-1 (finished at step t-2)
         const unsigned rmask = ((yo >= ys) && (yo < ye) && !((IE_EXP & 128) && p.N > 0)) ? 0u : OOB;   // IE_EXP 128: every store out of range (same instructions, no HBM writes)
         const unsigned row_b = rmask ? 0u : (unsigned)yo * (unsigned)W * PXB;
         ie_u32x2 pk[4];
+        ie_u32x4 ln[2] = {};
+        char* oslot = smem + OFF_OUT + (t & 1) * ROW_B;                   // x2 rows: slots 0, 1
+        const char* islot = smem + OFF_OUT + ((t + 1) & 1) * ROW_B;
         const int px = sw * 64 + lane;
         const float* ip = (const float*)(smem + OFF_IMG + (t % NRI) * IMG_SLOT_B) + (px < 131 ? px : 131);
         const bool keep = px < 132;
@@ -758,12 +799,17 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
         float r0 = 0.f, g0 = 0.f, b0 = 0.f;
         ie_u32x2 hi = {0u, 0u}, lo = {0u, 0u};
         pk[0] = IE_PACK_TILE(TO, accN[0], true);
+        ln[0] = *(const ie_u32x4*)(islot + st_lds[0]);
+        ln[1] = *(const ie_u32x4*)(islot + st_lds[1]);
         auto fill = [&](int s) __attribute__((always_inline)) {
-            if (s == 0) pk[1] = IE_PACK_TILE(TO, accN[1], true);
-            if (s == 1) { if constexpr (!(IE_EXP & 16)) IE_STORE_PAIR(rsDb, pk[0], pk[1], 0, row_b, rmask); }
-            if (s == 3) pk[2] = IE_PACK_TILE(TO, accN[2], true);
-            if (s == 6) pk[3] = IE_PACK_TILE(TO, accN[3], true);
-            if (s == 7) { if constexpr (!(IE_EXP & 16)) IE_STORE_PAIR(rsDb, pk[2], pk[3], 1, row_b, rmask); }
+            if (s == 0) { pk[1] = IE_PACK_TILE(TO, accN[1], true); *(ie_u32x2*)(oslot + em_off[0]) = pk[0]; }
+            if (s == 1) *(ie_u32x2*)(oslot + em_off[1]) = pk[1];
+            if (s == 3) { pk[2] = IE_PACK_TILE(TO, accN[2], true); *(ie_u32x2*)(oslot + em_off[2]) = pk[2]; }
+            if (s == 6) { pk[3] = IE_PACK_TILE(TO, accN[3], true); *(ie_u32x2*)(oslot + em_off[3]) = pk[3]; }
+            if constexpr (!(IE_EXP & 16)) {
+                if (s == 10) __builtin_amdgcn_raw_buffer_store_b128(ln[0], rsDb, (int)((row_b + st_col[0]) | rmask), 0, 0);
+                if (s == 12) __builtin_amdgcn_raw_buffer_store_b128(ln[1], rsDb, (int)((row_b + st_col[1]) | rmask), 0, 0);
+            }
             if constexpr (!(IE_EXP & 1)) {
                 if (s == 9) { r0 = ip[0]; g0 = ip[132]; b0 = ip[264]; }
                 if (s == 20) { const bool real = px < 130; r0 = real ? r0 : 0.f; g0 = real ? g0 : 0.f; b0 = real ? b0 : 0.f; }
@@ -774,7 +820,7 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
                 if (s == 25) *(ie_u32x2*)(cv + (keep ? CV_PLANE_B : 512)) = lo;
             }
         };
-        mfma_stream(ie_tag<TH>{}, smem + OFF_RA + ((t + RPB) % NRH) * ROW_B, 0, accN, accM, accO, bias4, fill);
+        mfma_stream(ie_tag<TH>{}, smem + OFF_RA + ((t + RPB) % NRH) * ROW_B, 0, accN, accM, accO, true, bias4, fill);
         IE_STEP_TAIL();
     };
     // Stage A: the x1 half of e_conv7 (36 MFMAs) then e_conv1 (8, or 16 with bf16 operands).  eN = the x1 row e_conv1 finished at
@@ -785,9 +831,12 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
         // ops younger than that DMA = 2 (PF-RPB) prologue loads + 2 per elapsed step, 4 (PF-RPB) in the steady state
         IE_STEP_HEAD(2 * (PF - RPB) + 2 * (t < PF - RPB ? t : PF - RPB));
         IE_T(ts2);
-        const int yo = ys - 6 - LAG_A - LAG_H + t;
+        const int yo = ys - 6 - LAG_A - LAG_H - G::OUT + t;    // the P row parked at step t-1 (finished at step t-2)
         const unsigned rmask = ((yo >= ys) && (yo < ye) && !((IE_EXP & 128) && p.N > 0)) ? 0u : OOB;   // IE_EXP 128: every store out of range (same instructions, no HBM writes)
         const unsigned row_b = rmask ? 0u : (unsigned)yo * (unsigned)W * PXB;
+        ie_u32x4 ln[2] = {};
+        char* oslot = smem + OFF_OUT + (2 + (t & 1)) * ROW_B;             // P rows: slots 2, 3
+        const char* islot = smem + OFF_OUT + (2 + ((t + 1) & 1)) * ROW_B;
         const int ra = ys - 3 - LAG_A - 1 + t;                      // x1 row computed at step t-1
         const bool row_in = (ra >= 0) && (ra < H);
         char* eslot = smem + OFF_RA + (t % NRH) * ROW_B;
@@ -807,12 +856,17 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
             c1[part][nt] = ie_u32x4{b0_[0], b0_[1], b1_[0], b1_[1]};
         };
         pk[0] = IE_PACK_TILE(TO, pN[0], false);
+        ln[0] = *(const ie_u32x4*)(islot + st_lds[0]);
+        ln[1] = *(const ie_u32x4*)(islot + st_lds[1]);
         auto fill = [&](int s) __attribute__((always_inline)) {
-            if (s == 0) pk[1] = IE_PACK_TILE(TO, pN[1], false);
-            if (s == 1) { if constexpr (!(IE_EXP & 16)) IE_STORE_PAIR(rsDa, pk[0], pk[1], 0, row_b, rmask); }
-            if (s == 3) pk[2] = IE_PACK_TILE(TO, pN[2], false);
-            if (s == 6) pk[3] = IE_PACK_TILE(TO, pN[3], false);
-            if (s == 7) { if constexpr (!(IE_EXP & 16)) IE_STORE_PAIR(rsDa, pk[2], pk[3], 1, row_b, rmask); }
+            if (s == 0) { pk[1] = IE_PACK_TILE(TO, pN[1], false); *(ie_u32x2*)(oslot + em_off[0]) = pk[0]; }
+            if (s == 1) *(ie_u32x2*)(oslot + em_off[1]) = pk[1];
+            if (s == 3) { pk[2] = IE_PACK_TILE(TO, pN[2], false); *(ie_u32x2*)(oslot + em_off[2]) = pk[2]; }
+            if (s == 6) { pk[3] = IE_PACK_TILE(TO, pN[3], false); *(ie_u32x2*)(oslot + em_off[3]) = pk[3]; }
+            if constexpr (!(IE_EXP & 16)) {
+                if (s == 7) __builtin_amdgcn_raw_buffer_store_b128(ln[0], rsDa, (int)((row_b + st_col[0]) | rmask), 0, 0);
+                if (s == 8) __builtin_amdgcn_raw_buffer_store_b128(ln[1], rsDa, (int)((row_b + st_col[1]) | rmask), 0, 0);
+            }
             if constexpr (!(IE_EXP & 4)) {
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
@@ -833,7 +887,7 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
                         if (s == 24 + 4 * part + nt) c1_read(part, nt);
             }
         };
-        mfma_stream(ie_tag<TH>{}, smem + OFF_RA + ((t + RPB) % NRH) * ROW_B, 9, pN, pM, pO, bias4p, fill);
+        mfma_stream(ie_tag<TH>{}, smem + OFF_RA + ((t + RPB) % NRH) * ROW_B, 9, pN, pM, pO, true, bias4p, fill);
         if constexpr (!(IE_EXP & 32)) {
 #pragma unroll
             for (int part = 0; part < PARTS; ++part) {
