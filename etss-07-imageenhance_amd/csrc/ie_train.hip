@@ -384,6 +384,19 @@ __global__ void crop_nhwc_kernel(const T* __restrict__ src, T* __restrict__ dst,
     dst[i] = (T)((accumulate ? (float)dst[i] : 0.f) + (float)src[((n * Hs + h + top) * Ws + w + left) * C + c]);
 }
 
+// a tile of a spatial torch.cat (mprnet.py:484-505: patches joined along H or W): dst[h+top, w+left] = src[h, w]
+template <typename T>
+__global__ void paste_nhwc_kernel(const T* __restrict__ src, T* __restrict__ dst, int Hd, int Wd, int C, int top, int left, int H, int W, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    size_t q = i / C;
+    const int w = (int)(q % W); q /= W;
+    const int h = (int)(q % H);
+    const size_t n = q / H;
+    dst[((n * Hd + h + top) * Wd + w + left) * C + c] = src[i];
+}
+
 // adjoint of pixel shuffle: dx[n,h,w,c*r*r+i*r+j] = dy[n,h*r+i,w*r+j,c]
 template <typename T>
 __global__ void pixel_unshuffle_kernel(const T* __restrict__ dy, T* __restrict__ dx, int H, int W, int Co, int r,
@@ -886,6 +899,24 @@ IE_EXPORT int ie_crop_nhwc(const void* src, void* dst, int dtype, int N, int Hs,
 IE_EXPORT int ie_crop_nhwc_f32(const float* src, float* dst, int N, int Hs, int Ws, int C, int top, int left, int H, int W,
                                int accumulate, void* stream) {
     return crop_impl<float>(src, dst, N, Hs, Ws, C, top, left, H, W, accumulate, stream);
+}
+
+template <typename T>
+static int paste_impl(const void* src, void* dst, int N, int H, int W, int C, int Hd, int Wd, int top, int left, void* stream) {
+    if (!src || !dst || N <= 0 || C <= 0 || top < 0 || left < 0 || H <= 0 || W <= 0 || top + H > Hd || left + W > Wd)
+        IE_FAIL(IE_ERR_INVALID, "ie_paste_nhwc: bad args");
+    const size_t total = (size_t)N * H * W * C;
+    hipLaunchKernelGGL(paste_nhwc_kernel<T>, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, (const T*)src, (T*)dst, Hd, Wd, C, top, left, H, W, total);
+    IE_LAUNCH_CHECK();
+    return IE_OK;
+}
+IE_EXPORT int ie_paste_nhwc(const void* src, void* dst, int dtype, int N, int H, int W, int C, int Hd, int Wd, int top, int left, void* stream) {
+    switch (dtype) {
+    case IE_F32: return paste_impl<float>(src, dst, N, H, W, C, Hd, Wd, top, left, stream);
+    case IE_F16: return paste_impl<_Float16>(src, dst, N, H, W, C, Hd, Wd, top, left, stream);
+    case IE_BF16: return paste_impl<__bf16>(src, dst, N, H, W, C, Hd, Wd, top, left, stream);
+    default: IE_FAIL(IE_ERR_INVALID, "ie_paste_nhwc: bad dtype");
+    }
 }
 
 template <typename T>

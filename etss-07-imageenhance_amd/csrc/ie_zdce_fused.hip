@@ -45,7 +45,7 @@ enum { K12 = 12, K45 = 45, K67 = 67, K345 = 345 };
 
 #ifndef IE_EXP
 #define IE_EXP 0      // timing experiments (wrong results): 1 no image DMA / row conversion, 2 e_conv1 without LDS reads, 4 no hand-off write,
-#endif                // 8 MFMA streams without LDS reads, 16 no K12 stores, 32 no e_conv1 at all, 64 raw-accumulator stores (no epilogue VALU), 128 K12 stores forced out of range
+#endif                // 8 MFMA streams without LDS reads, 16 no K12 stores, 32 no e_conv1 at all, 64 raw-accumulator stores (no epilogue VALU), 128 K12 stores forced out of range; K67: 1024 no curve, 2048 curve without tanh, 4096 no image DMA, 8192 no P DMA
 #ifndef IE_K12_RPB
 #define IE_K12_RPB 1
 #endif
@@ -317,6 +317,7 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
                         const unsigned rmask = ((y >= 0) && (y < H)) ? 0u : OOB;
                         const unsigned row_b = rmask ? 0u : (unsigned)y * (unsigned)W * PXB;
                         char* slot = smem + OFF_BRING + (t % NRB) * ROW_B;
+                        if constexpr (!(IE_EXP & 8192))
 #pragma unroll
                         for (int j = 0; j < 4; ++j) IE_DMA_PIECE(rsB, slot, (sw - 2) * 4 + j, row_b, rmask);
                     }
@@ -324,6 +325,7 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
                     const unsigned rmask = ((yo >= ys) && (yo < ye)) ? 0u : OOB;
 #pragma unroll
                     for (int pl = 0; pl < 3; ++pl) {
+                        if constexpr (IE_EXP & 4096) continue;
                         if ((pl == 0) != (sw == 2)) continue;          // wave 6: plane 0; wave 7: planes 1, 2
                         const unsigned base = rmask ? 0u : ((unsigned)pl * (unsigned)plane + (unsigned)yo * (unsigned)W) * 4u;
 #pragma unroll
@@ -540,7 +542,7 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int k = 3 * i + c;
-                r[i] = ie_tanh_fast(sp[k * TW + ((q + 16 * ((k >> 2) & 1)) & (TW - 1))]);
+                r[i] = (IE_EXP & 2048) ? sp[k * TW + ((q + 16 * ((k >> 2) & 1)) & (TW - 1))] : ie_tanh_fast(sp[k * TW + ((q + 16 * ((k >> 2) & 1)) & (TW - 1))]);
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i) v = ie_curve_step_fma(v, r[i]);
@@ -712,7 +714,7 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
             IE_T(ts2);
             issue(t + PF);
             if (t >= 2) a_emit(accO, t);
-            if constexpr (KIND == K67) { if (t >= 7) curve_consume(t - 2); }
+            if constexpr (KIND == K67 && !(IE_EXP & 1024)) { if (t >= 7) curve_consume(t - 2); }
         }
         IE_STEP_TAIL();
     };
@@ -735,7 +737,7 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
         } else if constexpr (KIND == K345) {
             if constexpr (!G::OUT) { if (t >= 10) IE_B_STORE(accN, ys - 10 + t, rsDb, true); }
         } else {
-            if (t >= 7) curve_consume(t - 2);
+            if constexpr (!(IE_EXP & 1024)) { if (t >= 7) curve_consume(t - 2); }
             if (t >= 6) stage_write(accN, (t - 1) & 1);
         }
         const char* ra_row = smem + OFF_RA + ((t + RPB) % NRH) * ROW_B;     // written by stage A at step t-RPB

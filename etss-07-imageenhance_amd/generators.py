@@ -3,6 +3,7 @@
   zero_dce++_re   ZeroDCEpp_RE   src/mon/vision/enhance/llie/zero_dce/zero_dcepp.py:86-208 (DSConv2d: nn/modules/conv/dsconv.py:106-149)
   llunet++_re     LLUnetpp_RE    src/mon/vision/enhance/llie/llunetpp/llunetpp.py:97-243
   lllinet         LLLINet        src/mon/vision/enhance/llie/lllinet/lllinet.py:97-260 (normalization.py:177-224, attention.py:1156-1182)
+  mprnet          MPRNet         src/mon/vision/enhance/multitask/mprnet/mprnet.py:33-548
   unet            UNet           src/mon/vision/segment/unet/unet.py:35-197  (+ ``upsampler="pixelshuffle"``: nn/modules/encoder/edsr.py:88-123)
   zero_ig_enhance Enhance        src/mon/vision/enhance/llie/zero_ig/zero_ig.py:307-348
   zero_ig_re      ZeroIG         src/mon/vision/enhance/llie/zero_ig/zero_ig.py:257-304, 355-452 (predicting branch)
@@ -534,6 +535,182 @@ class LLLINet(_GraphModel):
         x0_4 = B("conv0_4", [x0_0, x0_1, x0_2, x0_3, up(x1_3)])
         y = self._conv(x0_4, "final", pad=0, clamp=(0.0, 1.0))
         return OrderedDict(enhanced=ops.to_nchw(y))
+
+
+# ----------------------------------------------------------------------------------------------------------------
+@MODELS.register(name="mprnet", arch="mprnet")
+class MPRNet(_GraphModel):
+    """MPRNet (mprnet.py:349-548): three stages over a 4 / 2 / 1 patch hierarchy.  Stage 1 and 2 are encoder-decoders of channel
+    attention blocks (CAB, :138-160: conv3x3 - PReLU - conv3x3, global-average-pool -> 1x1 -> ReLU -> 1x1 -> sigmoid channel gate,
+    residual) with bilinear x0.5 / x2 + 1x1 resampling (:50-113) and cross-stage feature fusion (:205-238); stage 3 is the
+    original-resolution ORSNet (:296-343); supervised attention modules (SAM, :163-182) hand the features on and emit the stage
+    images.  The ONE ``nn.PReLU()`` of :421 is shared by all CABs: its slope is read from ``shallow_feat1.1.body.1.weight`` (a
+    checkpoint repeats it under every ``...body.1.weight``).  Outputs ``stage1, stage2, enhanced`` (:543-547).  fp32 path; H and W
+    must be multiples of 8 (two patch splits and two x0.5 levels)."""
+
+    arch = "mprnet"
+    tasks = [Task.DEBLUR, Task.DENOISE, Task.DERAIN, Task.DESNOW]
+    schemes = [Scheme.SUPERVISED]
+
+    def __init__(self, in_channels: int = 3, num_channels: int = 96, scale_unetfeats: int = 48, scale_orsnetfeats: int = 32, num_cab: int = 8,
+                 kernel_size: int = 3, reduction: int = 4, bias: bool = False, weights: Any = None, seed: int = None, *args, **kwargs):
+        kwargs.pop("name", None)
+        super().__init__(name="mprnet", in_channels=in_channels, weights=weights, *args, **kwargs)
+        if self.compute_dtype != "f32":
+            raise capi.IEError("mprnet: only the fp32 path is built (compute_dtype='f32')")
+        if isinstance(self.weights, dict):
+            in_channels = self.weights.get("in_channels", in_channels)
+            num_channels = self.weights.get("num_channels", num_channels)
+            scale_unetfeats = self.weights.get("scale_unetfeats", scale_unetfeats)
+            scale_orsnetfeats = self.weights.get("scale_orsnetfeats", scale_orsnetfeats)
+            num_cab = self.weights.get("num_cab", num_cab)
+            kernel_size = self.weights.get("kernel_size", kernel_size)
+            reduction = self.weights.get("reduction", reduction)
+            bias = self.weights.get("bias", bias)
+        self.in_channels, self.num_channels, self.scale_unetfeats, self.scale_orsnetfeats = in_channels, num_channels, scale_unetfeats, scale_orsnetfeats
+        self.num_cab, self.kernel_size, self.reduction, self.bias = num_cab, kernel_size, reduction, bias
+        self.predicting = True
+        P, k, c, su, so = self._params, kernel_size, num_channels, scale_unetfeats, scale_orsnetfeats
+
+        def conv(name, ci, co, kk, b=bias):
+            P[f"{name}.weight"] = torch.zeros(co, ci, kk, kk)
+            if b:
+                P[f"{name}.bias"] = torch.zeros(co)
+
+        def cab(name, ch):
+            conv(f"{name}.body.0", ch, ch, k)
+            P[f"{name}.body.1.weight"] = torch.full((1,), 0.25)
+            conv(f"{name}.body.2", ch, ch, k)
+            conv(f"{name}.CA.conv_du.0", ch, ch // reduction, 1)
+            conv(f"{name}.CA.conv_du.2", ch // reduction, ch, 1)
+
+        for i in (1, 2, 3):
+            conv(f"shallow_feat{i}.0", in_channels, c, k)
+            cab(f"shallow_feat{i}.1", c)
+        lv = [c, c + su, c + 2 * su]
+        for st in (1, 2):
+            e, d = f"stage{st}_encoder", f"stage{st}_decoder"
+            for l in range(3):
+                for i in range(2):
+                    cab(f"{e}.encoder_level{l + 1}.{i}", lv[l])
+                    cab(f"{d}.decoder_level{l + 1}.{i}", lv[l])
+                if st == 2:
+                    conv(f"{e}.csff_enc{l + 1}", lv[l], lv[l], 1)
+                    conv(f"{e}.csff_dec{l + 1}", lv[l], lv[l], 1)
+            conv(f"{e}.down12.down.1", lv[0], lv[1], 1, False)
+            conv(f"{e}.down23.down.1", lv[1], lv[2], 1, False)
+            cab(f"{d}.skip_attn1", lv[0])
+            cab(f"{d}.skip_attn2", lv[1])
+            conv(f"{d}.up21.up.1", lv[1], lv[0], 1, False)
+            conv(f"{d}.up32.up.1", lv[2], lv[1], 1, False)
+        o = "stage3_orsnet"
+        for j in (1, 2, 3):
+            for i in range(num_cab):
+                cab(f"{o}.orb{j}.body.{i}", c + so)
+            conv(f"{o}.orb{j}.body.{num_cab}", c + so, c + so, k, False)          # conv()'s default bias=False (:33-47, :284)
+            conv(f"{o}.conv_enc{j}", c, c + so, 1)
+            conv(f"{o}.conv_dec{j}", c, c + so, 1)
+        for n in ("up_enc1", "up_dec1", "up_enc2.1", "up_dec2.1"):
+            conv(f"{o}.{n}.up.1", lv[1], lv[0], 1, False)
+        for n in ("up_enc2.0", "up_dec2.0"):
+            conv(f"{o}.{n}.up.1", lv[2], lv[1], 1, False)
+        for n in ("sam12", "sam23"):
+            conv(f"{n}.conv1", c, c, 1)
+            conv(f"{n}.conv2", c, 3, 1)
+            conv(f"{n}.conv3", 3, c, 1)
+        conv("concat12", 2 * c, c, k)
+        conv("concat23", 2 * c, c + so, k)
+        conv("tail", c + so, in_channels, k)
+        self._finish_init(seed)
+
+    def init_weights(self, seed: int = None):
+        g = self._gen(seed)                # mprnet.py:444-445: init_weights is a no-op -> torch defaults (PReLU slope 0.25)
+        for name in list(self._params):
+            if name.endswith(".weight") and self._params[name].dim() == 4:
+                self._init_conv(name[:-7], g)
+        self._on_params_change()
+
+    def _cv(self, t, name, **kw):
+        return self._conv(t, name, pad=self._params[f"{name}.weight"].shape[2] // 2, **kw)
+
+    def _cab(self, name, t):
+        slope = float(self._params["shallow_feat1.1.body.1.weight"].reshape(-1)[0])
+        y = self._cv(self._cv(t, f"{name}.body.0", act="lrelu", slope=slope), f"{name}.body.2")
+        a = self._cv(self._cv(ops.global_avg_pool(y), f"{name}.CA.conv_du.0", act="relu"), f"{name}.CA.conv_du.2", act="sigmoid")
+        return ops.add(ops.channel_affine(y, a.reshape(a.shape[0], a.shape[1])), t)
+
+    def _cabs(self, name, t, k=2):
+        for i in range(k):
+            t = self._cab(f"{name}.{i}", t)
+        return t
+
+    def _down(self, name, t):
+        return self._cv(ops.resize(t, (t.shape[2] // 2, t.shape[3] // 2), "bilinear"), f"{name}.down.1")
+
+    def _up(self, name, t, residual=None):
+        return self._cv(ops.resize(t, (t.shape[2] * 2, t.shape[3] * 2), "bilinear"), f"{name}.up.1", residual=residual)
+
+    def _encoder(self, n, t, enc=None, dec=None):
+        outs = []
+        for l in (1, 2, 3):
+            if l > 1:
+                t = self._down(f"{n}.down{l - 1}{l}", t)
+            t = self._cabs(f"{n}.encoder_level{l}", t)
+            if enc is not None:
+                t = self._cv(dec[l - 1], f"{n}.csff_dec{l}", residual=self._cv(enc[l - 1], f"{n}.csff_enc{l}", residual=t))
+            outs.append(t)
+        return outs
+
+    def _decoder(self, n, e):
+        d3 = self._cabs(f"{n}.decoder_level3", e[2])
+        d2 = self._cabs(f"{n}.decoder_level2", self._up(f"{n}.up32", d3, residual=self._cab(f"{n}.skip_attn2", e[1])))
+        d1 = self._cabs(f"{n}.decoder_level1", self._up(f"{n}.up21", d2, residual=self._cab(f"{n}.skip_attn1", e[0])))
+        return [d1, d2, d3]
+
+    def _sam(self, n, t, img):
+        im = self._cv(t, f"{n}.conv2", residual=img)
+        gate = self._cv(im, f"{n}.conv3", act="sigmoid")
+        return ops.add(ops.mul(self._cv(t, f"{n}.conv1"), gate), t), im
+
+    def _orb(self, n, t):
+        return self._cv(self._cabs(f"{n}.body", t, self.num_cab), f"{n}.body.{self.num_cab}", residual=t)
+
+    def forward(self, datapoint: dict, *args, **kwargs) -> dict:
+        x = self._input(datapoint)
+        h, w = x.shape[2], x.shape[3]
+        if h % 8 or w % 8:
+            raise ValueError(f"MPRNet needs H and W divisible by 8 (got {h}x{w}); use infer(), which resizes to a multiple of 32 like the "
+                             f"reference (vision/model.py:106).")
+        shallow = lambda k, t: self._cab(f"shallow_feat{k}.1", self._cv(t, f"shallow_feat{k}.0"))
+        top, bot = ops.crop(x, 0, 0, h // 2, w), ops.crop(x, h // 2, 0, h - h // 2, w)
+        quads = [ops.crop(x, 0, 0, h // 2, w // 2), ops.crop(x, 0, w // 2, h // 2, w - w // 2),
+                 ops.crop(x, h // 2, 0, h - h // 2, w // 2), ops.crop(x, h // 2, w // 2, h - h // 2, w - w // 2)]
+        f1 = [self._encoder("stage1_encoder", shallow(1, q)) for q in quads]
+        f1_top = [ops.cat_spatial([a, b], 3) for a, b in zip(f1[0], f1[1])]
+        f1_bot = [ops.cat_spatial([a, b], 3) for a, b in zip(f1[2], f1[3])]
+        r1_top, r1_bot = self._decoder("stage1_decoder", f1_top), self._decoder("stage1_decoder", f1_bot)
+        s_top, img_top = self._sam("sam12", r1_top[0], top)
+        s_bot, img_bot = self._sam("sam12", r1_bot[0], bot)
+        stage1 = ops.cat_spatial([img_top, img_bot], 2)
+        c_top = self._cv([shallow(2, top), s_top], "concat12")
+        c_bot = self._cv([shallow(2, bot), s_bot], "concat12")
+        f2_top = self._encoder("stage2_encoder", c_top, f1_top, r1_top)
+        f2_bot = self._encoder("stage2_encoder", c_bot, f1_bot, r1_bot)
+        f2 = [ops.cat_spatial([a, b], 2) for a, b in zip(f2_top, f2_bot)]
+        r2 = self._decoder("stage2_decoder", f2)
+        s3, stage2 = self._sam("sam23", r2[0], x)
+        t = self._cv([shallow(3, x), s3], "concat23")
+        o = "stage3_orsnet"
+        t = self._orb(f"{o}.orb1", t)
+        t = self._cv(r2[0], f"{o}.conv_dec1", residual=self._cv(f2[0], f"{o}.conv_enc1", residual=t))
+        t = self._orb(f"{o}.orb2", t)
+        t = self._cv(self._up(f"{o}.up_dec1", r2[1]), f"{o}.conv_dec2", residual=self._cv(self._up(f"{o}.up_enc1", f2[1]), f"{o}.conv_enc2", residual=t))
+        t = self._orb(f"{o}.orb3", t)
+        e3 = self._up(f"{o}.up_enc2.1", self._up(f"{o}.up_enc2.0", f2[2]))
+        d3 = self._up(f"{o}.up_dec2.1", self._up(f"{o}.up_dec2.0", r2[2]))
+        t = self._cv(d3, f"{o}.conv_dec3", residual=self._cv(e3, f"{o}.conv_enc3", residual=t))
+        y = self._cv(t, "tail", residual=x)
+        return OrderedDict(stage1=ops.to_nchw(stage1), stage2=ops.to_nchw(stage2), enhanced=ops.to_nchw(y))
 
 
 # ----------------------------------------------------------------------------------------------------------------

@@ -612,6 +612,30 @@ def crop_into(src, dst, top, left, accumulate):
                                            int(accumulate), capi.current_stream()), "ie_crop_nhwc")
 
 
+def crop(x, top, left, h, w) -> torch.Tensor:
+    """x[:, :, top:top+h, left:left+w] as its own NHWC tensor."""
+    y = empty_nhwc(x.shape[0], x.shape[1], h, w, x.device, x.dtype)
+    crop_into(x, y, top, left, False)
+    return y
+
+
+def cat_spatial(tiles, dim) -> torch.Tensor:
+    """torch.cat(tiles, dim) for dim 2 (H) or 3 (W) of NHWC tensors with equal channel counts: every tile is pasted into its place."""
+    n, c = tiles[0].shape[0], tiles[0].shape[1]
+    hs, ws = [t.shape[2] for t in tiles], [t.shape[3] for t in tiles]
+    H, W = (sum(hs), ws[0]) if dim == 2 else (hs[0], sum(ws))
+    y = empty_nhwc(n, c, H, W, tiles[0].device, tiles[0].dtype)
+    off = 0
+    with torch.cuda.device(y.device):
+        for t in tiles:
+            _chk_any(t)
+            top, left = (off, 0) if dim == 2 else (0, off)
+            capi.check(capi.lib().ie_paste_nhwc(capi.ptr(t), capi.ptr(y), _dt(t), n, t.shape[2], t.shape[3], c, H, W, top, left, capi.current_stream()),
+                       "ie_paste_nhwc")
+            off += t.shape[2] if dim == 2 else t.shape[3]
+    return y
+
+
 def pixel_unshuffle_into(dy, dx, r, accumulate):
     _chk_any(dy); _chk_any(dx)
     if dy.dtype != dx.dtype:

@@ -300,6 +300,8 @@ int ie_resize_backward_nhwc(const void* dy_dev, void* dx_dev, int dtype, int N, 
                             void* stream);
 int ie_crop_nhwc(const void* src_dev, void* dst_dev, int dtype, int N, int Hs, int Ws, int C, int top, int left, int H, int W, int accumulate,
                  void* stream);
+/* one tile of a spatial torch.cat (the patch hierarchy of mprnet.py:472-505): dst[:, top:top+H, left:left+W, :] = src (N,H,W,C) */
+int ie_paste_nhwc(const void* src_dev, void* dst_dev, int dtype, int N, int H, int W, int C, int Hd, int Wd, int top, int left, void* stream);
 
 /* ---- zero-reference training of Zero-DCE: the losses of zero_dce.py:34-79 and the LE-curve backward --------- */
 /* floats of scratch ie_zref_image_losses_f32 needs for an (N,3,H,W) batch. */

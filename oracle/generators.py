@@ -315,3 +315,81 @@ def hinet_forward(sd: dict, x: torch.Tensor, depth: int = 5, relu_slope: float =
     x2 = _c(sd, "cat12", torch.cat([_c(sd, "conv_02", x), sam], 1), padding=0)
     x2, _, _ = stage(2, x2, encs, decs)
     return {"stage1": img, "enhanced": _c(sd, "last", x2) + x}
+
+
+# ---- MPRNet ------------------------------------------------------------------------------------------------------
+def mprnet_forward(sd: dict, x: torch.Tensor, num_cab: int = 8) -> dict:
+    """src/mon/vision/enhance/multitask/mprnet/mprnet.py:33-340 (modules) and :455-548 (three-stage forward with the 4 / 2 / 1 patch
+    hierarchy).  The ONE nn.PReLU() instance (mprnet.py:421) is shared by every CAB and appears in the checkpoint under each
+    ``...body.1.weight``.  parity unpinned: the mon package does not import here and MPRNet has no mon_extra twin; the leaf
+    operations are torch's own."""
+    def cv(n, t):
+        w = sd[f"{n}.weight"]
+        return F.conv2d(t, w, sd.get(f"{n}.bias"), padding=w.shape[2] // 2)
+
+    def cab(n, t):
+        y = cv(f"{n}.body.2", F.prelu(cv(f"{n}.body.0", t), sd[f"{n}.body.1.weight"]))
+        a = F.adaptive_avg_pool2d(y, 1)
+        a = torch.sigmoid(cv(f"{n}.CA.conv_du.2", F.relu(cv(f"{n}.CA.conv_du.0", a))))
+        return y * a + t
+
+    def cabs(n, t, k=2):
+        for i in range(k):
+            t = cab(f"{n}.{i}", t)
+        return t
+
+    down = lambda n, t: cv(f"{n}.down.1", F.interpolate(t, scale_factor=0.5, mode="bilinear", align_corners=False))
+    up = lambda n, t: cv(f"{n}.up.1", F.interpolate(t, scale_factor=2, mode="bilinear", align_corners=False))
+
+    def encoder(n, t, enc=None, dec=None):
+        e1 = cabs(f"{n}.encoder_level1", t)
+        if enc and dec:
+            e1 = e1 + cv(f"{n}.csff_enc1", enc[0]) + cv(f"{n}.csff_dec1", dec[0])
+        e2 = cabs(f"{n}.encoder_level2", down(f"{n}.down12", e1))
+        if enc and dec:
+            e2 = e2 + cv(f"{n}.csff_enc2", enc[1]) + cv(f"{n}.csff_dec2", dec[1])
+        e3 = cabs(f"{n}.encoder_level3", down(f"{n}.down23", e2))
+        if enc and dec:
+            e3 = e3 + cv(f"{n}.csff_enc3", enc[2]) + cv(f"{n}.csff_dec3", dec[2])
+        return [e1, e2, e3]
+
+    def decoder(n, e):
+        d3 = cabs(f"{n}.decoder_level3", e[2])
+        t = up(f"{n}.up32", d3) + cab(f"{n}.skip_attn2", e[1])
+        d2 = cabs(f"{n}.decoder_level2", t)
+        t = up(f"{n}.up21", d2) + cab(f"{n}.skip_attn1", e[0])
+        return [cabs(f"{n}.decoder_level1", t), d2, d3]
+
+    def sam(n, t, img):
+        x1 = cv(f"{n}.conv1", t)
+        im = cv(f"{n}.conv2", t) + img
+        return x1 * torch.sigmoid(cv(f"{n}.conv3", im)) + t, im
+
+    def orb(n, t):
+        return cv(f"{n}.body.{num_cab}", cabs(f"{n}.body", t, num_cab)) + t
+
+    shallow = lambda k, t: cab(f"shallow_feat{k}.1", cv(f"shallow_feat{k}.0", t))
+    h, w = x.shape[2], x.shape[3]
+    top, bot = x[:, :, :h // 2], x[:, :, h // 2:]
+    quads = [top[:, :, :, :w // 2], top[:, :, :, w // 2:], bot[:, :, :, :w // 2], bot[:, :, :, w // 2:]]
+    f1 = [encoder("stage1_encoder", shallow(1, q)) for q in quads]
+    f1_top = [torch.cat((a, b), 3) for a, b in zip(f1[0], f1[1])]
+    f1_bot = [torch.cat((a, b), 3) for a, b in zip(f1[2], f1[3])]
+    r1_top, r1_bot = decoder("stage1_decoder", f1_top), decoder("stage1_decoder", f1_bot)
+    s_top, img_top = sam("sam12", r1_top[0], top)
+    s_bot, img_bot = sam("sam12", r1_bot[0], bot)
+    stage1 = torch.cat([img_top, img_bot], 2)
+    c_top = cv("concat12", torch.cat([shallow(2, top), s_top], 1))
+    c_bot = cv("concat12", torch.cat([shallow(2, bot), s_bot], 1))
+    f2_top = encoder("stage2_encoder", c_top, f1_top, r1_top)
+    f2_bot = encoder("stage2_encoder", c_bot, f1_bot, r1_bot)
+    f2 = [torch.cat((a, b), 2) for a, b in zip(f2_top, f2_bot)]
+    r2 = decoder("stage2_decoder", f2)
+    s3, stage2 = sam("sam23", r2[0], x)
+    t = cv("concat23", torch.cat([shallow(3, x), s3], 1))
+    o = "stage3_orsnet"
+    t = orb(f"{o}.orb1", t) + cv(f"{o}.conv_enc1", f2[0]) + cv(f"{o}.conv_dec1", r2[0])
+    t = orb(f"{o}.orb2", t) + cv(f"{o}.conv_enc2", up(f"{o}.up_enc1", f2[1])) + cv(f"{o}.conv_dec2", up(f"{o}.up_dec1", r2[1]))
+    t = orb(f"{o}.orb3", t) + cv(f"{o}.conv_enc3", up(f"{o}.up_enc2.1", up(f"{o}.up_enc2.0", f2[2]))) \
+        + cv(f"{o}.conv_dec3", up(f"{o}.up_dec2.1", up(f"{o}.up_dec2.0", r2[2])))
+    return {"stage1": stage1, "stage2": stage2, "enhanced": cv("tail", t) + x}

@@ -532,3 +532,43 @@ def test_lllinet_vs_oracle_and_stat_layers():
     assert rel_err(out, ref) <= 5e-4 and 0.05 < float(ref.mean()) < 0.95
     with pytest.raises(ValueError):
         m.forward({"image": torch.rand(1, 3, 40, 48).cuda()})
+
+
+def test_mprnet_vs_oracle_and_patch_ops():
+    """MPRNet (three stages, 4 / 2 / 1 patch hierarchy, channel attention, SAM, CSFF, ORSNet) against the restated reference forward at a
+    reduced width; the patch plumbing (crop / spatial concat) against torch slicing."""
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(2, 5, 12, 20, generator=g)
+    xn = ops.to_nhwc(x.cuda())
+    a, b = ops.crop(xn, 0, 0, 12, 8), ops.crop(xn, 0, 8, 12, 12)
+    assert torch.equal(ops.to_nchw(a).cpu(), x[:, :, :, :8]) and torch.equal(ops.to_nchw(b).cpu(), x[:, :, :, 8:])
+    assert torch.equal(ops.to_nchw(ops.cat_spatial([a, b], 3)).cpu(), x)
+    t, u = ops.crop(xn, 0, 0, 5, 20), ops.crop(xn, 5, 0, 7, 20)
+    assert torch.equal(ops.to_nchw(ops.cat_spatial([t, u], 2)).cpu(), x)
+    kw = dict(num_channels=16, scale_unetfeats=8, scale_orsnetfeats=8, num_cab=2, reduction=4)
+    m = mon_amd.MODELS.build(name="mprnet", seed=17, **kw).to("cuda")
+    sd = m.state_dict()
+    assert "stage2_encoder.csff_dec3.weight" in sd and "stage1_encoder.csff_enc1.weight" not in sd
+    assert tuple(sd["stage3_orsnet.up_enc2.0.up.1.weight"].shape) == (24, 32, 1, 1) and "tail.bias" not in sd
+    for k in sd:                       # the shared PReLU slope, away from its default; livelier gates
+        if k.endswith("body.1.weight"):
+            sd[k] = torch.full((1,), 0.1)
+        elif k.endswith("conv_du.2.weight") or k.endswith("conv3.weight"):
+            sd[k] = sd[k] * 3.0
+    m.load_state_dict(sd)
+    img = torch.rand(2, 3, 32, 48, generator=g)
+    out = m.forward({"image": img.cuda()})
+    ref = og.mprnet_forward(sd, img, num_cab=2)
+    assert list(out) == ["stage1", "stage2", "enhanced"]
+    for k in ref:
+        assert tuple(out[k].shape) == tuple(ref[k].shape) and rel_err(out[k].cpu(), ref[k]) <= 2e-5, k
+    assert float((ref["enhanced"] - img).abs().max()) > 1e-2 and float((ref["stage1"] - ref["stage2"]).abs().max()) > 1e-3
+    mb = mon_amd.MODELS.build(name="mprnet", seed=3, bias=True, **kw).to("cuda")         # bias=True variant of every conv() / 1x1
+    sdb = mb.state_dict()
+    assert "tail.bias" in sdb and "stage3_orsnet.orb1.body.2.bias" not in sdb and "stage1_decoder.up21.up.1.bias" not in sdb
+    outb = mb.forward({"image": img.cuda()})["enhanced"].cpu()
+    assert rel_err(outb, og.mprnet_forward(sdb, img, num_cab=2)["enhanced"]) <= 2e-5
+    with pytest.raises(ValueError):
+        m.forward({"image": torch.rand(1, 3, 36, 48).cuda()})
+    with pytest.raises(Exception):
+        mon_amd.MODELS.build(name="mprnet", compute_dtype="bf16", **kw)
