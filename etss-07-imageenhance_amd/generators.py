@@ -1293,6 +1293,96 @@ class RetinexNet(_GraphModel):
                 pad=1, pad_mode=R)                                                 # 1x1 with replicate padding 1: (H+2, W+2)
         return c(fus, "net2_output", pad=0, out_f32=True)                          # 3x3 valid -> (H, W), fp32
 
+    # ---- training (model.py:199-238 forward with its losses; model.py:324-424 train loop) -------------------------------------------------
+    # The reference trains in two runs, each with its own fresh Adam: phase "decom" steps DecomNet on loss_Decom, phase "relight" steps
+    # RelightNet on loss_Relight.  Here: set ``train_phase`` and build one Trainer per phase (the other net's gradients and Adam moments
+    # stay zero, so it does not move); ``Trainer.sync_to_model()`` hands the trained weights to the next phase / to inference.
+    train_phase = "decom"
+
+    def forward_train_loss(self, datapoint: dict, store, tape) -> dict:
+        from . import train as T
+        from .losses import LossResult
+        if self.train_phase not in ("decom", "relight"):
+            raise ValueError(f"`train_phase` must be 'decom' or 'relight', but got {self.train_phase!r}.")
+        if store.compute_dtype != "f32":
+            raise capi.IEError("retinexnet: the training graph runs on the fp32 path")
+        if datapoint.get("ref_image") is None:
+            raise ValueError("RetinexNet's training forward needs the normal-light frame as `ref_image` (model.py:199: input_high).")
+        low = self._input(datapoint)
+        high = datapoint["ref_image"]
+        high = ops.to_nhwc((high[None] if high.dim() == 3 else high).to(self.device, torch.float32))
+        if tuple(high.shape) != tuple(low.shape):
+            raise ValueError(f"`image` {tuple(low.shape)} and `ref_image` {tuple(high.shape)} must have one shape.")
+        n, _, h, w = low.shape
+        decom_phase = self.train_phase == "decom"
+        tape_d, tape_r = (tape, T.Tape()) if decom_phase else (T.Tape(), tape)        # the other net runs on a tape that is never played back
+        store.grads.zero_()                                                             # the idle net's gradients must read zero
+
+        def conv(tp, name, srcs, pad, act="none", stride=1):
+            srcs = [T.t_pad_replicate(tp, t, pad) for t in (srcs if isinstance(srcs, (list, tuple)) else [srcs])]
+            return T.t_conv(tp, srcs, store.conv(name), *store.conv_grads(name), stride=stride, pad=0, act=act)
+
+        both = ops.empty_nhwc(2 * n, 3, h, w, low.device)                               # DecomNet on low and high in one batch (shared weights)
+        both[:n].copy_(low); both[n:].copy_(high)
+        xin = ops.max_concat(both)
+        tape_d.no_grad(xin)
+        f = conv(tape_d, "net1_conv0", xin, 4)
+        for i in (0, 2, 4, 6, 8):
+            f = conv(tape_d, f"net1_convs.{i}", f, 1, "relu")
+        rl = conv(tape_d, "net1_recon", f, 1, "sigmoid")                                # (2N, 4, H, W): channels 0-2 = R, 3 = I
+        rl_low = rl[:n]
+        tape_r.no_grad(rl_low)
+        rs = lambda t, ref: T.t_resize(tape_r, t, (ref.shape[2], ref.shape[3]), "nearest")
+        out0 = conv(tape_r, "net2_conv0_1", rl_low, 1)
+        out1 = conv(tape_r, "net2_conv1_1", out0, 1, "relu", 2)
+        out2 = conv(tape_r, "net2_conv1_2", out1, 1, "relu", 2)
+        out3 = conv(tape_r, "net2_conv1_3", out2, 1, "relu", 2)
+        d1 = conv(tape_r, "net2_deconv1_1", [rs(out3, out2), out2], 1, "relu")
+        d2 = conv(tape_r, "net2_deconv1_2", [rs(d1, out1), out1], 1, "relu")
+        d3 = conv(tape_r, "net2_deconv1_3", [rs(d2, out0), out0], 1, "relu")
+        fus = conv(tape_r, "net2_fusion", [rs(d1, rl_low), rs(d2, rl_low), d3], 1)     # 1x1 with replicate padding 1: (H+2, W+2)
+        i_delta = conv(tape_r, "net2_output", fus, 0)                                   # 3x3 valid -> (N, 1, H, W)
+
+        # ---- losses (model.py:216-238) and their gradients with respect to rl (decom phase) / i_delta (relight phase) ----------------
+        L = capi.lib()
+        import ctypes as C
+        acc = torch.zeros(2, device=low.device, dtype=torch.float64)                    # {loss_Decom, loss_Relight}
+        d_rl = torch.zeros_like(rl) if decom_phase else None
+        d_delta = None if decom_phase else torch.zeros_like(i_delta)
+        ws = torch.empty(int(L.ie_retinex_smooth_ws_floats(n, h, w)), device=low.device, dtype=torch.float32)
+        off = lambda t, k: None if t is None else C.c_void_p(t.data_ptr() + 4 * k)
+        lo_, hi_ = (lambda t: None if t is None else t[:n]), (lambda t: None if t is None else t[n:])
+        R_l, I_l, R_h, I_h = off(rl[:n], 0), off(rl[:n], 3), off(rl[n:], 0), off(rl[n:], 3)
+        dR_l, dI_l, dR_h, dI_h = off(lo_(d_rl), 0), off(lo_(d_rl), 3), off(hi_(d_rl), 0), off(hi_(d_rl), 3)
+        a_dec, a_rel = off(acc, 0), C.c_void_p(acc.data_ptr() + 8)
+        st = capi.current_stream
+        with torch.cuda.device(low.device):
+            recon = lambda R, rs_, I, is_, Tg, wgt, dR, dI, a: capi.check(
+                L.ie_retinex_recon_f32(R, rs_, I, is_, capi.ptr(Tg), wgt, dR, dI, a, n, h, w, st()), "ie_retinex_recon_f32")
+            smooth = lambda I, is_, R, wgt, dI, dR, a: capi.check(
+                L.ie_retinex_smooth_f32(I, is_, R, 4, wgt, dI, dR, a, capi.ptr(ws), n, h, w, st()), "ie_retinex_smooth_f32")
+            recon(R_l, 4, I_l, 4, low, 1.0, dR_l, dI_l, a_dec)                          # recon_loss_low
+            recon(R_h, 4, I_h, 4, high, 1.0, dR_h, dI_h, a_dec)                         # recon_loss_high
+            recon(R_h, 4, I_l, 4, low, 0.001, dR_h, dI_l, a_dec)                        # recon_loss_mutal_low  = L1(R_high * I_low,  input_low)
+            recon(R_l, 4, I_h, 4, high, 0.001, dR_l, dI_h, a_dec)                       # recon_loss_mutal_high = L1(R_low * I_high, input_high)
+            smooth(I_l, 4, R_l, 0.1, dI_l, dR_l, a_dec)                                 # Ismooth_loss_low
+            smooth(I_h, 4, R_h, 0.1, dI_h, dR_h, a_dec)                                 # Ismooth_loss_high
+            capi.check(L.ie_l1_detached_f32(R_l, R_h, 4, 3, 0.01, dR_l, a_dec, n * h * w, st()), "ie_l1_detached_f32")    # equal_R_loss
+            recon(R_l, 4, capi.ptr(i_delta), 1, high, 1.0, None, capi.ptr(d_delta), a_rel)                               # relight_loss
+            smooth(capi.ptr(i_delta), 1, R_l, 3.0, capi.ptr(d_delta), None, a_rel)                                        # 3 * Ismooth_loss_delta
+        rl_nchw = ops.to_nchw(rl_low)
+        outputs = OrderedDict()
+        outputs["reflectance"], outputs["illumination"] = rl_nchw[:, 0:3], rl_nchw[:, 3:4]
+        outputs["illumination_delta"] = ops.to_nchw(i_delta)
+        outputs["enhanced"] = ops.to_nchw(ops.mul_prefix(rl_low, i_delta))
+        outputs["loss_decom"], outputs["loss_relight"] = acc[0], acc[1]
+
+        def seed(tape_, scale=1.0):
+            g = d_rl if decom_phase else d_delta
+            tape_.seed(rl if decom_phase else i_delta, g if scale == 1.0 else ops.affine(g, scale))
+        outputs["loss"] = LossResult(lambda: float(acc[0 if decom_phase else 1].item()), None, seed)
+        return outputs
+
     def forward(self, datapoint: dict, *args, **kwargs) -> dict:
         x = self._input(datapoint)
         rl = self.decom(x)

@@ -612,6 +612,26 @@ def crop_into(src, dst, top, left, accumulate):
                                            int(accumulate), capi.current_stream()), "ie_crop_nhwc")
 
 
+def pad_replicate(x, pad) -> torch.Tensor:
+    """F.pad(x, (pad,)*4, mode="replicate") on an fp32 NHWC tensor."""
+    _chk(x)
+    if pad == 0:
+        return x
+    n, c, h, w = x.shape
+    y = empty_nhwc(n, c, h + 2 * pad, w + 2 * pad, x.device)
+    with torch.cuda.device(x.device):
+        capi.check(capi.lib().ie_pad_replicate_nhwc_f32(capi.ptr(x), capi.ptr(y), n, h, w, c, pad, capi.current_stream()), "ie_pad_replicate_nhwc_f32")
+    return y
+
+
+def pad_replicate_backward_into(dy, dx, pad, accumulate):
+    _chk(dy); _chk(dx)
+    n, c, h, w = dx.shape
+    with torch.cuda.device(dy.device):
+        capi.check(capi.lib().ie_pad_replicate_backward_nhwc_f32(capi.ptr(dy), capi.ptr(dx), n, h, w, c, pad, int(accumulate), capi.current_stream()),
+                   "ie_pad_replicate_backward_nhwc_f32")
+
+
 def crop(x, top, left, h, w) -> torch.Tensor:
     """x[:, :, top:top+h, left:left+w] as its own NHWC tensor."""
     y = empty_nhwc(x.shape[0], x.shape[1], h, w, x.device, x.dtype)

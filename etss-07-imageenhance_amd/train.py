@@ -376,6 +376,25 @@ def t_pad(tape, x, top, bottom, left, right):
     return y
 
 
+def t_pad_replicate(tape, x, pad):
+    """Replicate padding as its own taped op: a ``padding_mode="replicate"`` convolution (retinexnet/model.py:26-66) is this followed by
+    the pad-0 convolution, whose weight and data gradients are the zero-padding kernels' on the padded tensor."""
+    if pad == 0:
+        return x
+    y = ops.pad_replicate(x, pad)
+
+    def bwd():
+        dy = tape.grad(y)
+        if dy is None:
+            return
+        buf, acc = tape.slot(x)
+        if buf is not None:
+            ops.pad_replicate_backward_into(dy, buf, pad, acc)
+        tape.release(y)
+    tape.record(bwd)
+    return y
+
+
 def t_pixel_shuffle(tape, x, r=2):
     y = ops.pixel_shuffle(x, r)
 
@@ -501,7 +520,7 @@ class Trainer:
 
     def __init__(self, model, optimizer: dict | None = None, loss=None, gradient_clip_val: float | None = 0.1, process_group=None,
                  compute_dtype: str = "f32", loss_scale: float | None = None, deterministic: bool = False):
-        if not hasattr(model, "forward_train"):
+        if not hasattr(model, "forward_train") and not hasattr(model, "forward_train_loss"):
             raise capi.IEError(f"{model.__class__.__name__} has no training graph (forward_train)")
         model._require_cuda()
         self.model, self.device = model, model.device
@@ -569,8 +588,12 @@ class Trainer:
         """vision/enhance/base.py:47-57."""
         m = self.model
         m.assert_datapoint(datapoint)
-        x = ops.to_nhwc(datapoint["image"].to(self.device, torch.float32))
         tape = tape or Tape()
+        if hasattr(m, "forward_train_loss"):      # models whose training forward computes its own losses (retinexnet/model.py:199-238)
+            outputs = m.forward_train_loss(datapoint, self.store, tape)
+            outputs["_tape"] = tape
+            return outputs
+        x = ops.to_nhwc(datapoint["image"].to(self.device, torch.float32))
         tape.no_grad(x)
         res = m.forward_train(x, self.store, tape)
         if isinstance(res, dict) and "adjust" not in res:

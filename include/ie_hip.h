@@ -303,6 +303,24 @@ int ie_crop_nhwc(const void* src_dev, void* dst_dev, int dtype, int N, int Hs, i
 /* one tile of a spatial torch.cat (the patch hierarchy of mprnet.py:472-505): dst[:, top:top+H, left:left+W, :] = src (N,H,W,C) */
 int ie_paste_nhwc(const void* src_dev, void* dst_dev, int dtype, int N, int H, int W, int C, int Hd, int Wd, int top, int left, void* stream);
 
+/* ---- RetinexNet's training forward (src/mon_extra/vision/enhance/llie/retinexnet/model.py:199-260) ------------------
+ * Each call ADDS weight * term to *loss_dev (double) and weight * d term to the gradient tensors it is given (NULL = not wanted); the
+ * caller zeroes them once per step.  R / I (and dR / dI) are fp32 pixel-major with a stride in floats: 3 and 1 for separate tensors,
+ * 4 and 4 for the (R, L) output of DecomNet (I = base + 3).  T: the target image, NHWC 3 channels.
+ *   recon    mean |R * I - T|                      (model.py:216-221: recon_loss_*, recon_loss_mutal_*, relight_loss)
+ *   l1_detached  mean |A - B|, gradient to A only  (model.py:220: equal_R_loss against R_high.detach())
+ *   smooth   mean over the (H+1) x (W+1) grid of |gx I| exp(-10 avg3x3 |gx gray(R)|) + the same along y   (model.py:240-260) */
+int ie_retinex_recon_f32(const float* R_dev, int r_stride, const float* I_dev, int i_stride, const float* T_dev, float weight, float* dR_dev,
+                         float* dI_dev, double* loss_dev, int N, int H, int W, void* stream);
+int ie_l1_detached_f32(const float* A_dev, const float* B_dev, int stride, int C, float weight, float* dA_dev, double* loss_dev, size_t npx, void* stream);
+size_t ie_retinex_smooth_ws_floats(int N, int H, int W);
+int ie_retinex_smooth_f32(const float* I_dev, int i_stride, const float* R_dev, int r_stride, float weight, float* dI_dev, float* dR_dev, double* loss_dev,
+                          float* ws_dev, int N, int H, int W, void* stream);
+/* replicate padding as its own op and its adjoint (every padded position adds its gradient to the edge pixel it copied): the backward
+ * pass of a padding_mode="replicate" convolution (model.py:26-66) is the zero-padding one on the explicitly padded input */
+int ie_pad_replicate_nhwc_f32(const float* x_dev, float* y_dev, int N, int H, int W, int C, int pad, void* stream);
+int ie_pad_replicate_backward_nhwc_f32(const float* dy_dev, float* dx_dev, int N, int H, int W, int C, int pad, int accumulate, void* stream);
+
 /* ---- zero-reference training of Zero-DCE: the losses of zero_dce.py:34-79 and the LE-curve backward --------- */
 /* floats of scratch ie_zref_image_losses_f32 needs for an (N,3,H,W) batch. */
 size_t ie_zref_workspace_floats(int N, int H, int W);

@@ -249,14 +249,54 @@ def zsn2n_forward(sd: dict, x: torch.Tensor, predicting: bool = True) -> dict:
 
 
 # ---- RetinexNet ------------------------------------------------------------------------------------------------
-def retinexnet_forward(sd: dict, x: torch.Tensor) -> dict:
+def retinex_decom(sd: dict, x: torch.Tensor):
+    """DecomNet (retinexnet/model.py:21-51): returns (R, L)."""
     R = "replicate"
     xin = torch.cat((torch.max(x, dim=1, keepdim=True)[0], x), dim=1)
     f = _c(sd, "net1_conv0", xin, padding=4, mode=R)
     for i in (0, 2, 4, 6, 8):
         f = F.relu(_c(sd, f"net1_convs.{i}", f, mode=R))
     outs = _c(sd, "net1_recon", f, mode=R)
-    r_low, i_low = torch.sigmoid(outs[:, 0:3]), torch.sigmoid(outs[:, 3:4])
+    return torch.sigmoid(outs[:, 0:3]), torch.sigmoid(outs[:, 3:4])
+
+
+def retinex_relight(sd: dict, i_low: torch.Tensor, r_low: torch.Tensor) -> torch.Tensor:
+    """RelightNet (retinexnet/model.py:54-90)."""
+    return retinexnet_forward(sd, None, (r_low, i_low))["illumination_delta"]
+
+
+def retinex_smooth(input_I: torch.Tensor, input_R: torch.Tensor) -> torch.Tensor:
+    """RetinexNet.gradient / ave_gradient / smooth (retinexnet/model.py:240-260)."""
+    kx = torch.tensor([[0.0, 0.0], [-1.0, 1.0]], dtype=input_I.dtype).view(1, 1, 2, 2)
+    ky = kx.transpose(2, 3)
+    grad = lambda t, k: torch.abs(F.conv2d(t, k, stride=1, padding=1))
+    ave = lambda t, k: F.avg_pool2d(grad(t, k), kernel_size=3, stride=1, padding=1)
+    g = (0.299 * input_R[:, 0] + 0.587 * input_R[:, 1] + 0.114 * input_R[:, 2]).unsqueeze(1)
+    return torch.mean(grad(input_I, kx) * torch.exp(-10 * ave(g, kx)) + grad(input_I, ky) * torch.exp(-10 * ave(g, ky)))
+
+
+def retinexnet_losses(sd: dict, low: torch.Tensor, high: torch.Tensor) -> dict:
+    """RetinexNet.forward (retinexnet/model.py:199-238): the two losses the training phases minimise."""
+    r_low, i_low = retinex_decom(sd, low)
+    r_high, i_high = retinex_decom(sd, high)
+    i_delta = retinex_relight(sd, i_low, r_low)
+    c3 = lambda t: torch.cat((t, t, t), 1)
+    recon_low, recon_high = F.l1_loss(r_low * c3(i_low), low), F.l1_loss(r_high * c3(i_high), high)
+    mutal_low, mutal_high = F.l1_loss(r_high * c3(i_low), low), F.l1_loss(r_low * c3(i_high), high)
+    equal_r = F.l1_loss(r_low, r_high.detach())
+    relight = F.l1_loss(r_low * c3(i_delta), high)
+    loss_decom = recon_low + recon_high + 0.001 * mutal_low + 0.001 * mutal_high + 0.1 * retinex_smooth(i_low, r_low) \
+        + 0.1 * retinex_smooth(i_high, r_high) + 0.01 * equal_r
+    loss_relight = relight + 3 * retinex_smooth(i_delta, r_low)
+    return {"loss_decom": loss_decom, "loss_relight": loss_relight, "reflectance": r_low, "illumination": i_low, "illumination_delta": i_delta,
+            "enhanced": r_low * c3(i_delta)}
+
+
+def retinexnet_forward(sd: dict, x: torch.Tensor, rl=None) -> dict:
+    R = "replicate"
+    r_low, i_low = retinex_decom(sd, x) if rl is None else rl
+    if x is None:
+        x = r_low
     img = torch.cat((r_low, i_low), 1)
     out0 = _c(sd, "net2_conv0_1", img, mode=R)
     out1 = F.relu(_c(sd, "net2_conv1_1", out0, stride=2, mode=R))

@@ -944,3 +944,101 @@ def test_zero_dce_training_full_size_fp32_vs_bf16():
     for dt in traj:
         assert traj[dt][2] < traj[dt][0]
     assert abs(traj["f32"][2] - traj["bf16"][2]) < 5e-3 * traj["f32"][2]
+
+
+# ---- RetinexNet's training forward (retinexnet/model.py:199-260, 324-424) ---------------------------------------------------
+def test_replicate_pad_and_its_adjoint():
+    g = torch.Generator().manual_seed(61)
+    for shape, pad in (((2, 5, 7, 9), 1), ((1, 3, 6, 4), 4), ((1, 2, 1, 5), 2)):
+        x = torch.randn(*shape, generator=g)
+        xr = x.clone().requires_grad_(True)
+        y = F.pad(xr, (pad,) * 4, mode="replicate")
+        gy = torch.randn(y.shape, generator=g)
+        y.backward(gy)
+        yd = ops.pad_replicate(dev(x), pad)
+        assert torch.equal(host(ops.to_nchw(yd)), y.detach())
+        dx = torch.empty_like(dev(x))
+        ops.pad_replicate_backward_into(dev(gy), dx, pad, False)
+        assert rel_err(host(ops.to_nchw(dx)), xr.grad) < 1e-6
+        ops.pad_replicate_backward_into(dev(gy), dx, pad, True)
+        assert rel_err(host(ops.to_nchw(dx)), 2 * xr.grad) < 1e-6
+
+
+def test_retinex_loss_kernels_against_autograd():
+    """recon / smooth / detached-L1 terms: value and gradients against torch autograd on oracle.generators.retinex_smooth etc., with the
+    strided (R, L) layout the training graph uses and with separate tensors."""
+    import ctypes as C
+    from oracle import generators as og
+    g = torch.Generator().manual_seed(62)
+    n, h, w = 2, 13, 17
+    rl = torch.rand(n, 4, h, w, generator=g).double().requires_grad_(True)
+    tgt = torch.rand(n, 3, h, w, generator=g).double()
+    other = torch.rand(n, 3, h, w, generator=g).double()
+    delta = torch.rand(n, 1, h, w, generator=g).double().requires_grad_(True)
+    R, I = rl[:, 0:3], rl[:, 3:4]
+    ref = 0.7 * F.l1_loss(R * torch.cat((I, I, I), 1), tgt) + 0.3 * og.retinex_smooth(I, R) + 0.05 * F.l1_loss(R, other) \
+        + 1.5 * og.retinex_smooth(delta, R.detach()) + 0.4 * F.l1_loss(R.detach() * torch.cat((delta,) * 3, 1), tgt)
+    ref.backward()
+    L = capi.lib()
+    rld, td, od, dd = dev(rl.detach().float()), dev(tgt.float()), dev(other.float()), dev(delta.detach().float())
+    d_rl, d_dd = torch.zeros_like(rld), torch.zeros_like(dd)
+    acc = torch.zeros(1, device="cuda", dtype=torch.float64)
+    ws = torch.empty(int(L.ie_retinex_smooth_ws_floats(n, h, w)), device="cuda")
+    off = lambda t, k: C.c_void_p(t.data_ptr() + 4 * k)
+    st = capi.current_stream()
+    capi.check(L.ie_retinex_recon_f32(off(rld, 0), 4, off(rld, 3), 4, capi.ptr(td), 0.7, off(d_rl, 0), off(d_rl, 3), capi.ptr(acc), n, h, w, st))
+    capi.check(L.ie_retinex_smooth_f32(off(rld, 3), 4, off(rld, 0), 4, 0.3, off(d_rl, 3), off(d_rl, 0), capi.ptr(acc), capi.ptr(ws), n, h, w, st))
+    # `other` as a 3-channel tensor: stride 3 for B would differ from A's 4 -> pass it through a 4-channel carrier
+    o4 = dev(torch.cat((other.float(), torch.zeros(n, 1, h, w)), 1))
+    capi.check(L.ie_l1_detached_f32(off(rld, 0), capi.ptr(o4), 4, 3, 0.05, off(d_rl, 0), capi.ptr(acc), n * h * w, st))
+    capi.check(L.ie_retinex_smooth_f32(capi.ptr(dd), 1, off(rld, 0), 4, 1.5, capi.ptr(d_dd), None, capi.ptr(acc), capi.ptr(ws), n, h, w, st))
+    capi.check(L.ie_retinex_recon_f32(off(rld, 0), 4, capi.ptr(dd), 1, capi.ptr(td), 0.4, None, capi.ptr(d_dd), capi.ptr(acc), n, h, w, st))
+    assert abs(float(acc.item()) - float(ref.detach())) < 2e-6 * max(1.0, abs(float(ref.detach())))
+    assert rel_err(host(ops.to_nchw(d_rl)), rl.grad.float()) < 2e-5
+    assert rel_err(host(ops.to_nchw(d_dd)), delta.grad.float()) < 2e-5
+    with pytest.raises(capi.IEError):
+        capi.check(L.ie_retinex_smooth_f32(None, 1, off(rld, 0), 4, 1.0, None, None, capi.ptr(acc), capi.ptr(ws), n, h, w, st))
+
+
+@pytest.mark.parametrize("phase", ["decom", "relight"])
+def test_retinexnet_training_phase_matches_torch(phase):
+    """One Adam step of each training phase (model.py:405-414: loss_Decom steps DecomNet, loss_Relight steps RelightNet; Adam, default
+    betas, no clipping) against torch float64 autograd over oracle.generators.retinexnet_losses: both loss values, the gradients of
+    the phase's net, the post-step weights; the other net must not move."""
+    from oracle import generators as og
+    model = mon_amd.MODELS.build(name="retinexnet", channels=16, seed=71).to("cuda")
+    model.train_phase = phase
+    sd0 = model.state_dict()
+    g = torch.Generator().manual_seed(72)
+    high = torch.rand(2, 3, 24, 40, generator=g)
+    low = (high ** 2.2 * 0.3).contiguous()
+    own = "net1_" if phase == "decom" else "net2_"
+    params = {k: v.double().clone().requires_grad_(True) for k, v in sd0.items()}
+    ref = og.retinexnet_losses(params, low.double(), high.double())
+    lr, eps = 1e-3, 1e-3          # eps raised like the other chained comparisons: Adam's first step is sign(g) * lr where |g| >> eps
+    opt = torch.optim.Adam([v for k, v in params.items() if k.startswith(own)], lr=lr, betas=(0.9, 0.999), eps=eps)
+    ref["loss_" + phase].backward()
+    grads = {k: v.grad.clone() for k, v in params.items() if k.startswith(own)}
+    opt.step()
+    tr = mon_amd.Trainer(model, optimizer={"name": "adam", "lr": lr, "eps": eps}, gradient_clip_val=None)
+    out = tr.training_step({"image": low, "ref_image": high})
+    assert list(out)[:4] == ["reflectance", "illumination", "illumination_delta", "enhanced"]
+    want = {k: float(ref[k].detach()) for k in ("loss_decom", "loss_relight")}
+    assert abs(float(out["loss_decom"]) - want["loss_decom"]) < 2e-5 and abs(float(out["loss_relight"]) - want["loss_relight"]) < 2e-5
+    assert abs(float(out["loss"]) - want["loss_" + phase]) < 2e-5
+    assert rel_err(out["enhanced"].cpu(), ref["enhanced"].detach().float()) < 1e-4
+    got = tr.gradients()
+    gmax = max(float(v.abs().max()) for v in grads.values())
+    for k, r in grads.items():
+        assert float((got[k] - r).abs().max()) < 3e-4 * max(float(r.abs().max()), 0.02 * gmax), k
+    for k in sd0:
+        if not k.startswith(own):
+            assert float(got[k].abs().max()) == 0.0, k
+    sd1 = tr.state_dict()
+    for k in sd0:
+        if k.startswith(own):
+            assert float((sd1[k] - params[k].detach()).abs().max()) < 0.05 * lr, k
+        else:
+            assert torch.equal(sd1[k], sd0[k]), k
+    with pytest.raises(ValueError):
+        tr.training_step({"image": low})
