@@ -25,3 +25,10 @@ int ie_wgrad_mfma_launch(const void* x, const void* dy, int dtype, float* dw_hwi
 // deterministic mode (ie_core.hip): library-owned scratch of at least `bytes` for the split-K partial slabs
 extern "C" int ie_get_deterministic(void);
 int ie_det_workspace(size_t bytes, void** out);
+
+// Strip form of the narrow 3x3 layers (ie_conv_strip.hip): Cin 32 / 64 / 32+32, Cout 32 / 64, stride 1, zero / replicate padding 1, bias + ReLU / LeakyReLU / none,
+// reading ie_mconv_pack_weights' image.  ie_mconv_nhwc asks `applicable` first.
+bool ie_sconv3_applicable(int nsrc, const int* cs, int Cout, int kh, int kw, int stride, int pad, int pad_mode, int act, bool residual, bool clamp,
+                          bool out_f32, int W);
+int ie_sconv3_launch(const void* const* srcs, const int* cs, int nsrc, const void* wpk, const float* bias, void* dst, int dtype, int N, int H, int W,
+                     int Cout, int act, float slope, int pad_mode, hipStream_t st);

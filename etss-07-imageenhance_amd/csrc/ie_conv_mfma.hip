@@ -14,7 +14,7 @@
 // Roofline: 3x3, Cin = Cout = 64: 37.7 MFLOP per 142 KB of HBM traffic per tile = 265 FLOP/B, just under the 312 FLOP/B
 // machine balance -> the kernel is MFMA-bound only if the input tile is shared through L2 by the cout tiles of the same
 // pixels; the block index is therefore XCD-swizzled so that those workgroups run on the same XCD.
-#include "ie_common.h"
+#include "ie_conv_internal.h"
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
@@ -921,6 +921,14 @@ IE_EXPORT int ie_mconv_nhwc(ie_mconv_desc* d, const void* const* srcs, const int
     Plan pl;
     int rc = make_plan(channels, d->nsrc, d->Cout, d->kh, d->kw, &pl, "ie_mconv_nhwc");
     if (rc != IE_OK) return rc;
+    if (ie_sconv3_applicable(d->nsrc, channels, d->Cout, d->kh, d->kw, d->stride, d->pad, d->pad_mode, d->act, residual != nullptr, d->clamp != 0,
+                             d->out_dtype == IE_F32, d->W)) {
+        // narrow 3x3 layers: the strip kernel (weights in registers for the whole launch, an output row stored every step)
+        for (int s = 0; s < d->nsrc; ++s)
+            if (!srcs[s]) IE_FAIL(IE_ERR_INVALID, "ie_mconv_nhwc: source %d is null", s);
+        d->Ho = d->H; d->Wo = d->W;
+        return ie_sconv3_launch(srcs, channels, d->nsrc, packed_w, bias, dst, d->in_dtype, d->N, d->H, d->W, d->Cout, d->act, d->slope, d->pad_mode, (hipStream_t)stream);
+    }
     MConvParams p;
     memset(&p, 0, sizeof(p));
     for (int s = 0; s < d->nsrc; ++s) {

@@ -1,0 +1,348 @@
+// Strip form of the 16-bit matrix-core 3x3 convolution for the narrow layers of the generators (gfx950): Cin = 32 or 64 (one tensor,
+// or the virtual concat of two 32-channel tensors), Cout = 32 or 64, stride 1, zero or replicate padding 1 -- the full- and half-resolution layers
+// of U-Net-32 / U-Net-64 / RetinexNet (unet.py:43-48, retinexnet/model.py:28-40), where the tiled kernel (ie_conv_mfma.hip) spends as
+// long in its per-tile epilogue as in its MFMAs.  Same semantics and the same packed weight image as ie_mconv_nhwc.
+//
+// It is the Zero-DCE strip machinery (ie_zdce_kernels.hip / ie_zdce_fused.hip, where the 64 -> 32 stage of K345 holds 79 % of the
+// MFMA pipe): a workgroup marches down a 128-column strip; ALL weights of the wave's 16 output channels stay in registers for the
+// whole kernel (9 taps x Cin/32 fragments = 36 or 72 VGPRs); every input row is DMA'd once into an LDS ring (buffer_load ... lds,
+// the descriptor's range check supplies the zero padding) and each ds_read_b128 pixel fragment feeds three MFMAs (ky = 0, 1, 2) into
+// three rotating accumulator sets, so an output row is finished -- and stored -- every step instead of a whole tile at the end.
+// wave = (cout fragment, column half): Cout / 16 x 2 waves per workgroup (8 waves for 64 output channels).
+#include "ie_conv_internal.h"
+#include <stdlib.h>
+#include <string.h>
+
+namespace {
+
+constexpr int TW = 128;
+constexpr int ROW_PX = TW + 2;
+constexpr int PXB = 64;                    // bytes of one 32-channel chunk of a pixel
+constexpr int SRC_ROW_B = ROW_PX * PXB;    // one ring row of one chunk
+constexpr unsigned OOB = 0x80000000u;
+constexpr int NR = 4, PF = NR - 1;
+
+struct SConvParams {
+    const void* src[2];      // K chunk c: tensor base,
+    int ps[2], coff[2];      //            pixel stride and the chunk's byte offset inside a pixel
+    const void* wpk;         // ie_mconv_pack_weights image: [chunk][tap][16 NCF rows][32 k], 16-byte pieces swizzled by (row >> 1) & 3
+    const float* bias;       // [Cout] or null
+    void* dst;               // NHWC T, Cout channels
+    int N, H, W, rows_per_block, strips, chunks;
+    int replicate;           // padding_mode="replicate": out-of-image rows / columns are clamped to the edge instead of reading zeros
+    float slope;
+};
+
+__device__ __forceinline__ void wait_vm(int n) {
+#define IE_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    switch (n) {
+    IE_W(1) IE_W(2) IE_W(3) IE_W(4) IE_W(5) IE_W(6) IE_W(7) IE_W(8) IE_W(9) IE_W(10) IE_W(11) IE_W(12) IE_W(13) IE_W(14) IE_W(15) IE_W(16)
+    IE_W(17) IE_W(18) IE_W(19) IE_W(20)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+#undef IE_W
+}
+
+template <typename T, int NCH, int NCF, int ACT>
+__device__ __forceinline__ void sconv3_body(const SConvParams& p) {
+    using frag = ie_u32x4;
+    constexpr int NW = NCF * 2;                   // waves
+    constexpr int PPW = 8 / NW > 0 ? 8 / NW : 1;  // body DMA pieces (16 pixels x 64 B) per wave, chunk and row
+    constexpr int SLOT_B = SRC_ROW_B * NCH;
+    constexpr int OPB = 32 * NCF;                 // output bytes per pixel
+    // Finished rows are parked in LDS as whole pixel lines and leave one step later, 1 KiB of contiguous lines per store instruction: a
+    // wave owns 16 of a pixel's 32 / 64 output channels, and 32-byte pieces of a line cost the write path as much as the whole line
+    // (profiles/r02/k12_experiments_2.log).  [px][OPB bytes], the 16-byte pieces of pixel q XOR-swizzled by q (bank spread).
+    constexpr int OUT_ROW_B = TW * OPB;
+    constexpr int OFF_OUT = NR * SLOT_B;
+    constexpr int NPC = OPB / 16;                 // 16-byte pieces per pixel (4 or 8)
+    constexpr int PPI = 64 / NPC;                 // pixels per store instruction (16 or 8)
+    constexpr int SPW = (TW / PPI) / NW;          // store instructions per wave and row (2)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p16 = lane & 15, kq = lane >> 4;
+    const int ph = wave & 1, cf = wave >> 1;
+
+    int b = blockIdx.x;
+    const int strip = b % p.strips; b /= p.strips;
+    const int chunk = b % p.chunks; b /= p.chunks;
+    const int n = b;
+    const int x0 = strip * TW;
+    const int H = p.H, W = p.W;
+    const int ys = chunk * p.rows_per_block, ye = min(ys + p.rows_per_block, H);
+    const int n_it = (ye - ys) + 2;               // input rows ys-1 .. ye
+
+    // ---- buffer descriptors, one frame each -----------------------------------------------------------------------------
+    auto mk = [&](const void* base, size_t bytes) __attribute__((always_inline)) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+    };
+    const size_t fb0 = (size_t)H * W * p.ps[0], fb1 = (size_t)H * W * p.ps[NCH - 1];
+    const auto rs0 = mk((const char*)p.src[0] + (size_t)n * fb0, fb0);
+    const auto rs1 = mk((const char*)p.src[NCH - 1] + (size_t)n * fb1, fb1);
+    const size_t fbo = (size_t)H * W * OPB;
+    const auto rsd = mk((char*)p.dst + (size_t)n * fbo, fbo);
+
+    // ---- weights of this wave's 16 output channels into registers ---------------------------------------------------------
+    frag wA[NCH * 9];
+    {
+        const char* wp = (const char*)p.wpk;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+                wA[c * 9 + t] = *(const frag*)(wp + ((size_t)(c * 9 + t) * (16 * NCF) + cf * 16 + p16) * 64 + ((kq ^ ((p16 >> 1) & 3)) << 4));
+    }
+    ie_f32x4 bias4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bias4[i] = p.bias ? p.bias[16 * cf + 4 * kq + i] : 0.f;
+
+    // ---- DMA geometry: piece m = 16 pixels x 64 B of one chunk; 16-byte position (lane & 3) of ring pixel q holds channel piece
+    //      (lane & 3) ^ ((q >> 1) & 3), so the B-operand reads are bank-conflict free at every tap offset ------------------------
+    int px_q[PPW];          // ring pixel of this lane in piece j
+    int px_s[PPW];          // source 16-byte piece
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int q = (PPW * wave + j) * 16 + (lane >> 2);
+        px_q[j] = (x0 + q < W) ? x0 + q : (p.replicate ? W - 1 : -1);
+        px_s[j] = ((lane & 3) ^ ((q >> 1) & 3)) * 16;
+    }
+    int halo_x;
+    {
+        int x = (lane < 4) ? (x0 - 1) : (x0 + TW);
+        if (p.replicate) x = min(max(x, 0), W - 1);
+        halo_x = (lane < 8 && x >= 0 && x < W) ? x : -1;
+    }
+    auto issue_row = [&](int it) __attribute__((always_inline)) {
+        int yi = ys - 1 + it;
+        if (p.replicate) yi = min(max(yi, 0), H - 1);
+        const bool row_ok = (yi >= 0) && (yi < H) && (it < n_it);
+        char* slot = smem + (it % NR) * SLOT_B;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const unsigned ps = (unsigned)p.ps[c], co = (unsigned)p.coff[c];
+            const unsigned row_b = (unsigned)yi * (unsigned)W * ps;
+#pragma unroll
+            for (int j = 0; j < PPW; ++j) {
+                if (PPW * wave + j >= 8) break;
+                const unsigned off = (row_ok && px_q[j] >= 0) ? row_b + (unsigned)px_q[j] * ps + co + (unsigned)px_s[j] : OOB;
+                char* dstb = slot + c * SRC_ROW_B + (PPW * wave + j) * 1024;
+                if (c == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (__attribute__((address_space(3))) void*)dstb, 16, (int)off, 0, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (__attribute__((address_space(3))) void*)dstb, 16, (int)off, 0, 0, 0);
+            }
+            if (wave == NW - 1) {          // halo columns: (128 >> 1) & 3 == (129 >> 1) & 3 == 0, position == channel piece
+                const unsigned off = (row_ok && halo_x >= 0) ? row_b + (unsigned)halo_x * ps + co + (unsigned)((lane & 3) * 16) : OOB;
+                char* dstb = slot + c * SRC_ROW_B + TW * PXB;
+                if (lane < 8) {
+                    if (c == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (__attribute__((address_space(3))) void*)dstb, 16, (int)off, 0, 0, 0);
+                    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (__attribute__((address_space(3))) void*)dstb, 16, (int)off, 0, 0, 0);
+                }
+            }
+        }
+    };
+    const int L = (PPW * wave < 8 ? PPW : 0) * NCH + (wave == NW - 1 ? NCH : 0);
+    const int wait_n = (PF - 1) * L;
+
+    // ---- LDS read offsets of the B operand ------------------------------------------------------------------------------------
+    auto lds_px = [&](int q) __attribute__((always_inline)) { return q * PXB + ((kq ^ ((q >> 1) & 3)) << 4); };
+    int rd_base[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) rd_base[kx] = lds_px(64 * ph + 16 + p16 + kx - 1) - 1024;
+    int rd_first, rd_last;
+    {
+        const int xf = 64 * ph + p16 - 1;
+        rd_first = lds_px(xf < 0 ? TW : xf);
+        const int xl = 64 * ph + 48 + p16 + 1;
+        rd_last = lds_px(xl >= TW ? TW + 1 : xl);
+    }
+
+    // ---- epilogue -----------------------------------------------------------------------------------------------------------------
+    auto swz = [&](int q) __attribute__((always_inline)) { return NPC == 8 ? (q & 7) : ((q >> 1) & 3); };
+    int park_off[4];            // this lane's 8 bytes (couts 16cf + 4kq ..) of tile nt inside a parked row
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int q = 64 * ph + 16 * nt + p16, c = 2 * cf + (kq >> 1);
+        park_off[nt] = q * OPB + ((c ^ swz(q)) << 4) + (kq & 1) * 8;
+    }
+    unsigned st_col[SPW];       // store instruction j of this wave: PPI pixels x OPB bytes, lane = (pixel, 16-byte piece)
+    int st_lds[SPW];
+#pragma unroll
+    for (int j = 0; j < SPW; ++j) {
+        const int q = (SPW * wave + j) * PPI + lane / NPC, c = lane % NPC, xo = x0 + q;
+        st_col[j] = (xo < W) ? (unsigned)(xo * OPB + c * 16) : OOB;
+        st_lds[j] = q * OPB + ((c ^ swz(q)) << 4);
+    }
+    auto park = [&](const ie_f32x4 (&acc)[4], char* oslot) __attribute__((always_inline)) {
+        ie_u32x2 pk[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            if constexpr (ACT == IE_ACT_RELU) {
+                pk[nt][0] = ie_pack2_relu<T>(acc[nt][0], acc[nt][1]);
+                pk[nt][1] = ie_pack2_relu<T>(acc[nt][2], acc[nt][3]);
+            } else if constexpr (ACT == IE_ACT_LRELU) {
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = acc[nt][i] > 0.f ? acc[nt][i] : acc[nt][i] * p.slope;
+                pk[nt][0] = ie_pack2<T>(v[0], v[1]);
+                pk[nt][1] = ie_pack2<T>(v[2], v[3]);
+            } else {
+                pk[nt][0] = ie_pack2<T>(acc[nt][0], acc[nt][1]);
+                pk[nt][1] = ie_pack2<T>(acc[nt][2], acc[nt][3]);
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) *(ie_u32x2*)(oslot + park_off[nt]) = pk[nt];
+    };
+
+    // ---- one input row into the three live accumulator sets (output rows yi+1, yi, yi-1) -------------------------------------------
+    auto row_mfma = [&](int it, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4]) __attribute__((always_inline)) {
+        const char* slot = smem + (it % NR) * SLOT_B;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const int off = (kx == 0 && nt == 0) ? rd_first : (kx == 2 && nt == 3) ? rd_last : rd_base[kx] + 1024 * nt;
+                    const frag bx = *(const frag*)(slot + c * SRC_ROW_B + off);
+                    accN[nt] = ie_mfma16_raw<T>(wA[c * 9 + 0 * 3 + kx], bx, (c == 0 && kx == 0) ? bias4 : accN[nt]);
+                    accM[nt] = ie_mfma16_raw<T>(wA[c * 9 + 1 * 3 + kx], bx, accM[nt]);
+                    accO[nt] = ie_mfma16_raw<T>(wA[c * 9 + 2 * 3 + kx], bx, accO[nt]);
+                }
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+        for (int f = 0; f < NCH * 12 - 3; ++f) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);
+    };
+    auto step = [&](int it, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4]) __attribute__((always_inline)) {
+        // ops younger than row `it`'s DMA: the (PF-1) L loads of the rows behind it and the SPW (possibly out-of-range) stores every step issues
+        if (L) wait_vm(wait_n + SPW * (it < PF ? it : PF));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this wave's parked pieces of the previous step
+        __builtin_amdgcn_s_barrier();
+        issue_row(it + PF);
+        // the row parked in the previous step (finished two steps ago)
+        const int yo = ys - 4 + it;
+        const unsigned rmask = ((yo >= ys) && (yo < ye)) ? 0u : OOB;
+        const unsigned row_b = rmask ? 0u : (unsigned)yo * (unsigned)W * OPB;
+        const char* islot = smem + OFF_OUT + ((it + 1) & 1) * OUT_ROW_B;
+        ie_u32x4 ln[SPW];
+#pragma unroll
+        for (int j = 0; j < SPW; ++j) ln[j] = *(const ie_u32x4*)(islot + st_lds[j]);
+        // the row finished in the previous step is parked before its accumulator set is restarted by this step's MFMAs
+        park(accN, smem + OFF_OUT + (it & 1) * OUT_ROW_B);
+        row_mfma(it, accN, accM, accO);
+#pragma unroll
+        for (int j = 0; j < SPW; ++j) __builtin_amdgcn_raw_buffer_store_b128(ln[j], rsd, (int)((row_b + st_col[j]) | rmask), 0, 0);
+    };
+
+#pragma unroll
+    for (int it = 0; it < PF; ++it) issue_row(it);
+    ie_f32x4 a0[4], a1[4], a2[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) { a0[nt] = bias4; a1[nt] = bias4; a2[nt] = bias4; }
+    const int n_steps = n_it + 2;                 // two more steps: park, then store, the last finished row
+    for (int it = 0; it < n_steps; it += 3) {
+        step(it, a0, a1, a2);
+        if (it + 1 < n_steps) step(it + 1, a2, a0, a1);
+        if (it + 2 < n_steps) step(it + 2, a1, a2, a0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+typedef void (*SConvFn)(SConvParams);
+// Concrete kernels (hipcc 7.2 dropped host stubs of kernel templates in this file; readable names in rocprof traces as a bonus).
+#define IE_DEF_SCONV(TAG, T, NCH, NCF)                                                                                              \
+    __global__ __launch_bounds__(NCF * 128) void sconv3_##TAG##_none(SConvParams p) { sconv3_body<T, NCH, NCF, IE_ACT_NONE>(p); }    \
+    __global__ __launch_bounds__(NCF * 128) void sconv3_##TAG##_relu(SConvParams p) { sconv3_body<T, NCH, NCF, IE_ACT_RELU>(p); }    \
+    __global__ __launch_bounds__(NCF * 128) void sconv3_##TAG##_lrelu(SConvParams p) { sconv3_body<T, NCH, NCF, IE_ACT_LRELU>(p); }
+IE_DEF_SCONV(f16_c32_o32, _Float16, 1, 2)
+IE_DEF_SCONV(f16_c32_o64, _Float16, 1, 4)
+IE_DEF_SCONV(f16_c64_o32, _Float16, 2, 2)
+IE_DEF_SCONV(f16_c64_o64, _Float16, 2, 4)
+IE_DEF_SCONV(bf16_c32_o32, __bf16, 1, 2)
+IE_DEF_SCONV(bf16_c32_o64, __bf16, 1, 4)
+IE_DEF_SCONV(bf16_c64_o32, __bf16, 2, 2)
+IE_DEF_SCONV(bf16_c64_o64, __bf16, 2, 4)
+
+SConvFn pick_kernel(bool h, int nch, int ncf, int act) {
+#define IE_PICK_ACT(TAG) return act == IE_ACT_RELU ? sconv3_##TAG##_relu : (act == IE_ACT_LRELU ? sconv3_##TAG##_lrelu : sconv3_##TAG##_none)
+    if (h) {
+        if (nch == 1 && ncf == 2) IE_PICK_ACT(f16_c32_o32);
+        if (nch == 1 && ncf == 4) IE_PICK_ACT(f16_c32_o64);
+        if (nch == 2 && ncf == 2) IE_PICK_ACT(f16_c64_o32);
+        IE_PICK_ACT(f16_c64_o64);
+    }
+    if (nch == 1 && ncf == 2) IE_PICK_ACT(bf16_c32_o32);
+    if (nch == 1 && ncf == 4) IE_PICK_ACT(bf16_c32_o64);
+    if (nch == 2 && ncf == 2) IE_PICK_ACT(bf16_c64_o32);
+    IE_PICK_ACT(bf16_c64_o64);
+#undef IE_PICK_ACT
+}
+
+}  // namespace
+
+// Does the strip kernel cover this call?  (ie_mconv_nhwc asks before it builds its own launch.)
+bool ie_sconv3_applicable(int nsrc, const int* cs, int Cout, int kh, int kw, int stride, int pad, int pad_mode, int act, bool residual, bool clamp,
+                          bool out_f32, int W) {
+    static const int off = getenv("IE_SCONV") ? !atoi(getenv("IE_SCONV")) : 0;      // IE_SCONV=0: A/B switch back to the tiled kernel
+    if (off || kh != 3 || kw != 3 || stride != 1 || pad != 1 || residual || clamp || out_f32) return false;
+    if (pad_mode != IE_PAD_ZEROS && pad_mode != IE_PAD_REPLICATE) return false;
+    if (act != IE_ACT_NONE && act != IE_ACT_RELU && act != IE_ACT_LRELU) return false;
+    if (Cout != 32 && Cout != 64) return false;
+    if (W < 64) return false;                                                          // a 128-column strip would be mostly padding
+    if (nsrc == 1) return cs[0] == 32 || cs[0] == 64;
+    return nsrc == 2 && cs[0] == 32 && cs[1] == 32;
+}
+
+int ie_sconv3_launch(const void* const* srcs, const int* cs, int nsrc, const void* wpk, const float* bias, void* dst, int dtype, int N, int H, int W,
+                     int Cout, int act, float slope, int pad_mode, hipStream_t st) {
+    SConvParams p;
+    memset(&p, 0, sizeof(p));
+    const int nch = nsrc == 2 ? 2 : cs[0] / 32;
+    for (int c = 0; c < nch; ++c) {
+        p.src[c] = srcs[nsrc == 2 ? c : 0];
+        p.ps[c] = (nsrc == 2 ? 32 : cs[0]) * 2;
+        p.coff[c] = nsrc == 2 ? 0 : c * 64;
+    }
+    p.wpk = wpk; p.bias = bias; p.dst = dst; p.N = N; p.H = H; p.W = W; p.slope = slope; p.replicate = pad_mode == IE_PAD_REPLICATE;
+    if ((double)H * W * 128.0 >= 2147483647.0) IE_FAIL(IE_ERR_UNSUPPORTED, "ie_sconv3: frame too large for 31-bit offsets");
+    p.strips = ie_cdiv(W, TW);
+    // Row chunks per strip: the grid should fill whole rounds of the chip's resident workgroup slots (a 2.1-round grid runs 3 rounds),
+    // while every chunk pays 3 rows of pipeline fill.  Score = slot fill x useful-row fraction; 8-wave workgroups (Cout 64) sit one
+    // per CU, 4-wave ones two.
+    {
+        const int slots = 256 * (Cout == 64 ? 1 : 2);
+        const long long base = (long long)p.strips * N;
+        int best_c = 1;
+        double best = -1.0;
+        for (int c = 1; c <= H / 16 + 1 && c <= 64; ++c) {
+            const int rpb = ie_cdiv(H, c);
+            const int cc = ie_cdiv(H, rpb);
+            const long long blocks = base * cc;
+            const long long rounds = (blocks + slots - 1) / slots;
+            const double score = (double)blocks / (double)(rounds * slots) * ((double)rpb / (double)(rpb + 3));
+            if (score > best + 1e-9) { best = score; best_c = cc; }
+        }
+        p.rows_per_block = ie_cdiv(H, best_c);
+        p.chunks = ie_cdiv(H, p.rows_per_block);
+    }
+    const long long blocks = (long long)p.strips * p.chunks * N;
+    if (blocks <= 0 || blocks > 0x7fffffffLL) IE_FAIL(IE_ERR_INVALID, "ie_sconv3: bad grid");
+    const size_t lds = (size_t)NR * SRC_ROW_B * nch + 2 * (size_t)TW * (Cout * 2);
+    const int ncf = Cout / 16;
+    SConvFn fn = pick_kernel(dtype == IE_F16, nch, ncf, act);
+    static SConvFn granted[24] = {nullptr};
+    bool done = false;
+    for (auto f : granted) done = done || f == fn;
+    if (!done) {
+        IE_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        for (auto& f : granted) if (!f) { f = fn; break; }
+    }
+    hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(ncf * 128), lds, st, p);
+    IE_LAUNCH_CHECK();
+    return IE_OK;
+}

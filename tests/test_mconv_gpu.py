@@ -34,11 +34,32 @@ def _id(c):
     return f"{'+'.join(map(str, c['cs']))}-{c['co']}-k{c['k']}s{c.get('s', 1)}p{c['p']}{c.get('mode', 'zeros')[0]}-{c.get('act', 'none')}"
 
 
+# The narrow 3x3 layers leave ie_mconv_nhwc through the strip kernel (ie_conv_strip.hip) once the image is at least 64 columns wide:
+# two strips with a ragged second one, one and several row chunks, every channel / activation / padding combination it covers.
+STRIP_CASES = [
+    dict(cs=[32], co=32, k=3, p=1),
+    dict(cs=[32], co=32, k=3, p=1, act="relu", bias=False),
+    dict(cs=[64], co=64, k=3, p=1, act="relu"),                       # unet.py:43-48 at full / half resolution
+    dict(cs=[64], co=64, k=3, p=1, act="relu", mode="replicate"),     # retinexnet/model.py:28-40
+    dict(cs=[32, 32], co=32, k=3, p=1, act="lrelu"),                  # decoder concat [skip, up] of U-Net-32
+    dict(cs=[32, 32], co=64, k=3, p=1),
+    dict(cs=[64], co=32, k=3, p=1, act="lrelu", mode="replicate"),
+    dict(cs=[32], co=64, k=3, p=1, act="relu"),                       # down1 of U-Net-32
+]
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 37, 150), (1, 200, 64), (3, 5, 129)], ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("c", STRIP_CASES, ids=_id)
+def test_strip_conv_vs_torch(c, dt, shape):
+    test_mconv_vs_torch(c, dt, shape)
+
+
 @pytest.mark.parametrize("dt", ["f16", "bf16"])
 @pytest.mark.parametrize("c", CASES, ids=_id)
-def test_mconv_vs_torch(c, dt):
+def test_mconv_vs_torch(c, dt, shape=(2, 37, 45)):
     tdt = ops.TORCH_DT[dt]
-    n, h, w = 2, 37, 45                                                # ragged tiles in both directions
+    n, h, w = shape                                                    # default: ragged tiles in both directions
     g = torch.Generator().manual_seed(11)
     xs = [torch.randn(n, ci, h, w, generator=g).to(tdt) for ci in c["cs"]]
     cin, k, s, p = sum(c["cs"]), c["k"], c.get("s", 1), c["p"]

@@ -509,9 +509,11 @@ def test_trainer_requires_target_and_graph():
     tr = mon_amd.Trainer(model)
     with pytest.raises(ValueError):
         tr.training_step({"image": torch.rand(1, 3, 32, 32)})
-    rn = mon_amd.MODELS.build(name="retinexnet", seed=1).to("cuda")          # no training graph (yet)
+    rn = mon_amd.MODELS.build(name="zsn2n", seed=1).to("cuda")               # no training graph (yet)
     with pytest.raises(capi.IEError):
         mon_amd.Trainer(rn)
+    with pytest.raises(capi.IEError):                                          # RetinexNet trains on the fp32 graph only
+        mon_amd.Trainer(mon_amd.MODELS.build(name="retinexnet", seed=1).to("cuda"), compute_dtype="bf16")
 
 
 # ---- data-parallel step: 2 ranks on the one GPU of the test box, gloo carries the flat gradient buffer ---------------------
