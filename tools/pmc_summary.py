@@ -6,7 +6,7 @@ from collections import defaultdict
 
 acc = defaultdict(lambda: defaultdict(list))
 for row in csv.DictReader(open(sys.argv[1])):
-    full = row["Kernel_Name"]
+    full = row["Kernel_Name"].replace("(anonymous namespace)::", "")
     tag = "mconv3" if "mconv3" in full else ("mconv" if "mconv" in full else full.split("(")[0][-40:])
     name = tag + " grid=" + row["Grid_Size"]
     acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
