@@ -11,7 +11,8 @@ namespace {
 inline unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }
 
 // stats[n][c] = {sum, sum of squares} over H*W.  Workgroup = 256 threads over a pixel chunk of one sample; thread = (pixel lane, channel).
-__global__ void channel_stats_kernel(const float* __restrict__ x, double* __restrict__ stats, int HW, int C, int chunk) {
+template <typename T>
+__global__ void channel_stats_kernel(const T* __restrict__ x, double* __restrict__ stats, int HW, int C, int chunk) {
     const int n = blockIdx.y;
     const int p0 = blockIdx.x * chunk, p1 = min(p0 + chunk, HW);
     const int tpc = 256 / min(C, 256);                 // pixel lanes per channel when C < 256
@@ -22,7 +23,7 @@ __global__ void channel_stats_kernel(const float* __restrict__ x, double* __rest
         double s = 0.0, ss = 0.0;
         if (pl < lanes) {
             for (int p = p0 + pl; p < p1; p += lanes) {
-                const float v = x[((size_t)n * HW + p) * C + c0 + c];
+                const float v = (float)x[((size_t)n * HW + p) * C + c0 + c];
                 s += v; ss += (double)v * v;
             }
             atomicAdd(&stats[((size_t)n * C + c0 + c) * 2 + 0], s);
@@ -30,6 +31,41 @@ __global__ void channel_stats_kernel(const float* __restrict__ x, double* __rest
         }
     }
     (void)tpc;
+}
+
+// 16-bit activations, C % 8 == 0: thread = 8 channels (16 bytes) of a pixel, fp32 partial sums over the thread's pixels, one LDS fp64
+// atomic per partial, then one global fp64 atomic per channel and workgroup (the scalar kernel above ran at 0.8 TB/s on MPRNet's gates)
+template <typename T>
+__global__ void channel_stats_v8_kernel(const T* __restrict__ x, double* __restrict__ stats, int HW, int C, int chunk) {
+    extern __shared__ double acc[];                    // [C][2]
+    const int n = blockIdx.y;
+    const int p0 = blockIdx.x * chunk, p1 = min(p0 + chunk, HW);
+    const int cg = C >> 3;                             // channel groups
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) acc[i] = 0.0;
+    __syncthreads();
+    for (int g0 = 0; g0 < cg; g0 += 256) {             // C <= 2048 per pass
+        const int gn = min(cg - g0, 256);
+        const int lanes = 256 / gn;
+        const int g = threadIdx.x % gn, pl = threadIdx.x / gn;
+        if (pl < lanes) {
+            float s[8], ss[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { s[k] = 0.f; ss[k] = 0.f; }
+            typedef __attribute__((ext_vector_type(8))) T t8;
+            for (int p = p0 + pl; p < p1; p += lanes) {
+                const t8 v = *(const t8*)(x + ((size_t)n * HW + p) * C + (size_t)(g0 + g) * 8);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { const float f = (float)v[k]; s[k] += f; ss[k] = fmaf(f, f, ss[k]); }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                atomicAdd(&acc[((g0 + g) * 8 + k) * 2 + 0], (double)s[k]);
+                atomicAdd(&acc[((g0 + g) * 8 + k) * 2 + 1], (double)ss[k]);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) atomicAdd(&stats[(size_t)n * C * 2 + i], acc[i]);
 }
 
 // LearnableInstanceNorm2d coefficients: y = x * scale + shift with
@@ -55,14 +91,32 @@ __global__ void stats_mean_kernel(const double* __restrict__ stats, float* __res
 }
 
 // y = act(x * scale[n][c] + shift[n][c]); shift may be NULL
-__global__ void channel_affine_kernel(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
-                                      float* __restrict__ y, size_t hwc, int C, int act, float slope, size_t total) {
+template <typename T>
+__global__ void channel_affine_kernel(const T* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                                      T* __restrict__ y, size_t hwc, int C, int act, float slope, size_t total) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const size_t n = i / hwc;
     const int c = (int)(i % C);
-    const float v = x[i] * scale[n * C + c] + (shift ? shift[n * C + c] : 0.f);
-    y[i] = ie_act_apply(v, act, slope);
+    const float v = (float)x[i] * scale[n * C + c] + (shift ? shift[n * C + c] : 0.f);
+    y[i] = (T)ie_act_apply(v, act, slope);
+}
+
+template <typename T>
+__global__ void channel_affine_v8_kernel(const T* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift, T* __restrict__ y,
+                                         size_t hwc8, int C8, int act, float slope, size_t total8) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;       // one 8-channel group
+    if (i >= total8) return;
+    const size_t n = i / hwc8;
+    const int c0 = (int)(i % C8) * 8;
+    typedef __attribute__((ext_vector_type(8))) T t8;
+    const t8 v = *(const t8*)(x + i * 8);
+    const float* sc = scale + n * (size_t)C8 * 8 + c0;
+    const float* sh = shift ? shift + n * (size_t)C8 * 8 + c0 : nullptr;
+    t8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (T)ie_act_apply((float)v[k] * sc[k] + (sh ? sh[k] : 0.f), act, slope);
+    *(t8*)(y + i * 8) = o;
 }
 
 // SimAM: d = (x - mu)^2; v = sum d / (HW - 1); y = x * sigmoid(d / (4 (v + lambda)) + 0.5)
@@ -85,17 +139,41 @@ __global__ void simam_kernel(const float* __restrict__ x, const double* __restri
 
 }  // namespace
 
-IE_EXPORT int ie_channel_stats_nhwc_f32(const float* x, double* stats, int N, int H, int W, int C, void* stream) {
-    if (!x || !stats || N <= 0 || H <= 0 || W <= 0 || C <= 0) IE_FAIL(IE_ERR_INVALID, "ie_channel_stats_nhwc_f32: bad args");
+template <typename T>
+static int channel_stats_impl(const void* x, double* stats, int N, int H, int W, int C, void* stream) {
+    if (!x || !stats || N <= 0 || H <= 0 || W <= 0 || C <= 0) IE_FAIL(IE_ERR_INVALID, "ie_channel_stats_nhwc: bad args");
     hipStream_t st = (hipStream_t)stream;
     IE_HIP_CHECK(hipMemsetAsync(stats, 0, sizeof(double) * 2 * (size_t)N * C, st));
     const int HW = H * W;
+    if constexpr (sizeof(T) == 2) {
+        if ((C & 7) == 0 && C <= 2048) {
+            int chunks = (1024 + N - 1) / N;                 // about four workgroups per CU over the batch
+            if (chunks > (HW + 255) / 256) chunks = (HW + 255) / 256;
+            if (chunks < 1) chunks = 1;
+            const int chunk = (HW + chunks - 1) / chunks;
+            hipLaunchKernelGGL(channel_stats_v8_kernel<T>, dim3((unsigned)((HW + chunk - 1) / chunk), (unsigned)N), dim3(256), sizeof(double) * 2 * C, st,
+                               (const T*)x, stats, HW, C, chunk);
+            IE_LAUNCH_CHECK();
+            return IE_OK;
+        }
+    }
     int chunks = (HW + 4095) / 4096;
     if (chunks > 1024) chunks = 1024;
     const int chunk = (HW + chunks - 1) / chunks;
-    hipLaunchKernelGGL(channel_stats_kernel, dim3((unsigned)((HW + chunk - 1) / chunk), (unsigned)N), dim3(256), 0, st, x, stats, HW, C, chunk);
+    hipLaunchKernelGGL(channel_stats_kernel<T>, dim3((unsigned)((HW + chunk - 1) / chunk), (unsigned)N), dim3(256), 0, st, (const T*)x, stats, HW, C, chunk);
     IE_LAUNCH_CHECK();
     return IE_OK;
+}
+IE_EXPORT int ie_channel_stats_nhwc_f32(const float* x, double* stats, int N, int H, int W, int C, void* stream) {
+    return channel_stats_impl<float>(x, stats, N, H, W, C, stream);
+}
+IE_EXPORT int ie_channel_stats_nhwc(const void* x, int dtype, double* stats, int N, int H, int W, int C, void* stream) {
+    switch (dtype) {
+    case IE_F32: return channel_stats_impl<float>(x, stats, N, H, W, C, stream);
+    case IE_F16: return channel_stats_impl<_Float16>(x, stats, N, H, W, C, stream);
+    case IE_BF16: return channel_stats_impl<__bf16>(x, stats, N, H, W, C, stream);
+    default: IE_FAIL(IE_ERR_INVALID, "ie_channel_stats_nhwc: bad dtype");
+    }
 }
 IE_EXPORT int ie_lin_coeffs_f32(const double* stats, const float* gamma, const float* beta, const float* r, float* scale, float* shift, int N, int C,
                                 int HW, float eps, void* stream) {
@@ -111,13 +189,36 @@ IE_EXPORT int ie_stats_mean_f32(const double* stats, float* mean, int N, int C, 
     IE_LAUNCH_CHECK();
     return IE_OK;
 }
-IE_EXPORT int ie_channel_affine_nhwc_f32(const float* x, const float* scale, const float* shift, float* y, int N, int H, int W, int C, int act,
-                                         float slope, void* stream) {
-    if (!x || !scale || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0) IE_FAIL(IE_ERR_INVALID, "ie_channel_affine_nhwc_f32: bad args");
+template <typename T>
+static int channel_affine_impl(const void* x, const float* scale, const float* shift, void* y, int N, int H, int W, int C, int act, float slope,
+                               void* stream) {
+    if (!x || !scale || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0) IE_FAIL(IE_ERR_INVALID, "ie_channel_affine_nhwc: bad args");
     const size_t hwc = (size_t)H * W * C, total = hwc * N;
-    hipLaunchKernelGGL(channel_affine_kernel, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, x, scale, shift, y, hwc, C, act, slope, total);
+    if constexpr (sizeof(T) == 2) {
+        if ((C & 7) == 0) {
+            hipLaunchKernelGGL(channel_affine_v8_kernel<T>, dim3(nblk(total / 8)), dim3(256), 0, (hipStream_t)stream, (const T*)x, scale, shift, (T*)y,
+                               hwc / 8, C / 8, act, slope, total / 8);
+            IE_LAUNCH_CHECK();
+            return IE_OK;
+        }
+    }
+    hipLaunchKernelGGL(channel_affine_kernel<T>, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, (const T*)x, scale, shift, (T*)y, hwc, C, act,
+                       slope, total);
     IE_LAUNCH_CHECK();
     return IE_OK;
+}
+IE_EXPORT int ie_channel_affine_nhwc_f32(const float* x, const float* scale, const float* shift, float* y, int N, int H, int W, int C, int act,
+                                         float slope, void* stream) {
+    return channel_affine_impl<float>(x, scale, shift, y, N, H, W, C, act, slope, stream);
+}
+IE_EXPORT int ie_channel_affine_nhwc(const void* x, const float* scale, const float* shift, void* y, int dtype, int N, int H, int W, int C, int act,
+                                     float slope, void* stream) {
+    switch (dtype) {
+    case IE_F32: return channel_affine_impl<float>(x, scale, shift, y, N, H, W, C, act, slope, stream);
+    case IE_F16: return channel_affine_impl<_Float16>(x, scale, shift, y, N, H, W, C, act, slope, stream);
+    case IE_BF16: return channel_affine_impl<__bf16>(x, scale, shift, y, N, H, W, C, act, slope, stream);
+    default: IE_FAIL(IE_ERR_INVALID, "ie_channel_affine_nhwc: bad dtype");
+    }
 }
 IE_EXPORT int ie_simam_nhwc_f32(const float* x, const double* stats, float* y, int N, int H, int W, int C, float lambda, void* stream) {
     if (!x || !stats || !y || N <= 0 || H * W <= 1 || C <= 0) IE_FAIL(IE_ERR_INVALID, "ie_simam_nhwc_f32: bad args");

@@ -545,8 +545,9 @@ class MPRNet(_GraphModel):
     residual) with bilinear x0.5 / x2 + 1x1 resampling (:50-113) and cross-stage feature fusion (:205-238); stage 3 is the
     original-resolution ORSNet (:296-343); supervised attention modules (SAM, :163-182) hand the features on and emit the stage
     images.  The ONE ``nn.PReLU()`` of :421 is shared by all CABs: its slope is read from ``shallow_feat1.1.body.1.weight`` (a
-    checkpoint repeats it under every ``...body.1.weight``).  Outputs ``stage1, stage2, enhanced`` (:543-547).  fp32 path; H and W
-    must be multiples of 8 (two patch splits and two x0.5 levels)."""
+    checkpoint repeats it under every ``...body.1.weight``).  Outputs ``stage1, stage2, enhanced`` (:543-547).  fp32 parity path and the
+    16-bit matrix-core path (images as 8 channels, the channel gates' perceptron in fp32); H and W must be multiples of 8 (two patch
+    splits and two x0.5 levels)."""
 
     arch = "mprnet"
     tasks = [Task.DEBLUR, Task.DENOISE, Task.DERAIN, Task.DESNOW]
@@ -556,8 +557,6 @@ class MPRNet(_GraphModel):
                  kernel_size: int = 3, reduction: int = 4, bias: bool = False, weights: Any = None, seed: int = None, *args, **kwargs):
         kwargs.pop("name", None)
         super().__init__(name="mprnet", in_channels=in_channels, weights=weights, *args, **kwargs)
-        if self.compute_dtype != "f32":
-            raise capi.IEError("mprnet: only the fp32 path is built (compute_dtype='f32')")
         if isinstance(self.weights, dict):
             in_channels = self.weights.get("in_channels", in_channels)
             num_channels = self.weights.get("num_channels", num_channels)
@@ -631,12 +630,17 @@ class MPRNet(_GraphModel):
         self._on_params_change()
 
     def _cv(self, t, name, **kw):
-        return self._conv(t, name, pad=self._params[f"{name}.weight"].shape[2] // 2, **kw)
+        w = self._params[f"{name}.weight"]
+        if self.compute_dtype != "f32" and w.shape[0] % 8:               # 3-channel images travel as 8 channels on the 16-bit path
+            kw.setdefault("cout_pad", (w.shape[0] + 7) // 8 * 8)
+        return self._conv(t, name, pad=w.shape[2] // 2, **kw)
 
     def _cab(self, name, t):
         slope = float(self._params["shallow_feat1.1.body.1.weight"].reshape(-1)[0])
         y = self._cv(self._cv(t, f"{name}.body.0", act="lrelu", slope=slope), f"{name}.body.2")
-        a = self._cv(self._cv(ops.global_avg_pool(y), f"{name}.CA.conv_du.0", act="relu"), f"{name}.CA.conv_du.2", act="sigmoid")
+        # the gate is a two-layer perceptron on the pooled vector: fp32 on every path (C/4 channels need not be a multiple of 8)
+        a = ops.conv2d(ops.global_avg_pool(y), self._cw(f"{name}.CA.conv_du.0"), pad=0, act="relu")
+        a = ops.conv2d(a, self._cw(f"{name}.CA.conv_du.2"), pad=0, act="sigmoid")
         return ops.add(ops.channel_affine(y, a.reshape(a.shape[0], a.shape[1])), t)
 
     def _cabs(self, name, t, k=2):
@@ -676,7 +680,7 @@ class MPRNet(_GraphModel):
         return self._cv(self._cabs(f"{n}.body", t, self.num_cab), f"{n}.body.{self.num_cab}", residual=t)
 
     def forward(self, datapoint: dict, *args, **kwargs) -> dict:
-        x = self._input(datapoint)
+        x = self._input_any(datapoint)                # fp32 (N,3,H,W) or 16-bit (N,8,H,W) with zero channels
         h, w = x.shape[2], x.shape[3]
         if h % 8 or w % 8:
             raise ValueError(f"MPRNet needs H and W divisible by 8 (got {h}x{w}); use infer(), which resizes to a multiple of 32 like the "
@@ -710,6 +714,8 @@ class MPRNet(_GraphModel):
         d3 = self._up(f"{o}.up_dec2.1", self._up(f"{o}.up_dec2.0", r2[2]))
         t = self._cv(d3, f"{o}.conv_dec3", residual=self._cv(e3, f"{o}.conv_enc3", residual=t))
         y = self._cv(t, "tail", residual=x)
+        if self.compute_dtype != "f32":                # drop the padding channels, back to fp32
+            stage1, stage2, y = (ops.cast(v, torch.float32, self.in_channels) for v in (stage1, stage2, y))
         return OrderedDict(stage1=ops.to_nchw(stage1), stage2=ops.to_nchw(stage2), enhanced=ops.to_nchw(y))
 
 

@@ -287,23 +287,23 @@ def pow_scalar(a, exponent):
 
 
 def channel_stats(x) -> torch.Tensor:
-    """(N, C, 2) fp64 {sum, sum of squares} over H*W of an fp32 NHWC tensor."""
-    _chk(x)
+    """(N, C, 2) fp64 {sum, sum of squares} over H*W of an fp32 / 16-bit NHWC tensor."""
+    _chk_any(x)
     n, c, h, w = x.shape
     st = torch.empty((n, c, 2), device=x.device, dtype=torch.float64)
     with torch.cuda.device(x.device):
-        capi.check(capi.lib().ie_channel_stats_nhwc_f32(capi.ptr(x), capi.ptr(st), n, h, w, c, capi.current_stream()), "ie_channel_stats_nhwc_f32")
+        capi.check(capi.lib().ie_channel_stats_nhwc(capi.ptr(x), _dt(x), capi.ptr(st), n, h, w, c, capi.current_stream()), "ie_channel_stats_nhwc")
     return st
 
 
 def channel_affine(x, scale, shift=None, act="none", slope=0.0) -> torch.Tensor:
-    """act(x * scale[n, c] + shift[n, c]) with (N, C) fp32 coefficient tensors."""
-    _chk(x)
+    """act(x * scale[n, c] + shift[n, c]) with (N, C) fp32 coefficient tensors; x fp32 or 16-bit (result in x's type)."""
+    _chk_any(x)
     n, c, h, w = x.shape
     y = torch.empty_like(x, memory_format=CL)
     with torch.cuda.device(x.device):
-        capi.check(capi.lib().ie_channel_affine_nhwc_f32(capi.ptr(x), capi.ptr(scale), capi.ptr(shift), capi.ptr(y), n, h, w, c, capi.ACT[act], slope,
-                                                         capi.current_stream()), "ie_channel_affine_nhwc_f32")
+        capi.check(capi.lib().ie_channel_affine_nhwc(capi.ptr(x), capi.ptr(scale), capi.ptr(shift), capi.ptr(y), _dt(x), n, h, w, c, capi.ACT[act], slope,
+                                                     capi.current_stream()), "ie_channel_affine_nhwc")
     return y
 
 

@@ -570,5 +570,27 @@ def test_mprnet_vs_oracle_and_patch_ops():
     assert rel_err(outb, og.mprnet_forward(sdb, img, num_cab=2)["enhanced"]) <= 2e-5
     with pytest.raises(ValueError):
         m.forward({"image": torch.rand(1, 3, 36, 48).cuda()})
-    with pytest.raises(Exception):
-        mon_amd.MODELS.build(name="mprnet", compute_dtype="bf16", **kw)
+    for dt, tol in (("f16", 4e-3), ("bf16", 3e-2)):                                   # 16-bit matrix-core path (images as 8 channels)
+        m16 = mon_amd.MODELS.build(name="mprnet", weights=dict(sd), compute_dtype=dt, **kw).to("cuda")
+        o16 = m16.forward({"image": img.cuda()})
+        for k in ref:
+            assert o16[k].dtype == torch.float32 and tuple(o16[k].shape) == tuple(ref[k].shape)
+            assert rel_err(o16[k].cpu(), ref[k]) <= tol, (dt, k, rel_err(o16[k].cpu(), ref[k]))
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_channel_stats_and_affine_16bit(dt):
+    """The 16-bit forms of the channel-attention leaves (vectorised 8 channels per thread, and the scalar fallback for C % 8 != 0)."""
+    g = torch.Generator().manual_seed(33)
+    for c, h, w in ((96, 37, 53), (8, 5, 3), (12, 9, 11)):
+        x = torch.randn(3, c, h, w, generator=g).to(dt)
+        xd = x.cuda().contiguous(memory_format=torch.channels_last)
+        st = ops.channel_stats(xd).cpu()
+        xf = x.double()
+        assert (st[:, :, 0] - xf.sum((2, 3))).abs().max() <= 1e-3 * h * w ** 0.5
+        assert (st[:, :, 1] - (xf * xf).sum((2, 3))).abs().max() <= 2e-3 * h * w
+        assert (ops.to_nchw(ops.global_avg_pool(xd)).cpu()[:, :, 0, 0] - xf.mean((2, 3)).float()).abs().max() <= 1e-5
+        sc, sh = torch.rand(3, c, generator=g) + 0.5, torch.randn(3, c, generator=g)
+        y = ops.channel_affine(xd, sc.cuda(), sh.cuda(), "lrelu", 0.2)
+        ref = F.leaky_relu(x.float() * sc[:, :, None, None] + sh[:, :, None, None], 0.2)
+        assert y.dtype == dt and rel_err(y.float().cpu(), ref) <= (1.5e-3 if dt == torch.float16 else 1e-2)
