@@ -1499,18 +1499,39 @@ class HINet_RE(_GraphModel):
     def conv_transpose_keys(self):
         return [k for k in self._params if k.endswith(".up.weight")]
 
+    supports_mixed_training = True
+
     def forward_train(self, x, store, tape):
-        """Training graph of hinet.py:34-198, 322-362 on the fp32 taped ops; returns ``stage1`` and ``enhanced`` (NHWC), whose
-        losses the trainer sums (hinet.py:311-320)."""
+        """Training graph of hinet.py:34-198, 322-362 on the taped ops; returns ``stage1`` and ``enhanced`` (NHWC fp32), whose losses the
+        trainer sums (hinet.py:311-320).  16-bit graph (``Trainer(compute_dtype="bf16" | "f16")``): every stride-1 convolution, the
+        half instance norms, adds and the attention product run on 16-bit tensors (RGB carried as 16 channels); the two layer kinds the
+        matrix-core training kernels do not cover -- Conv4x4 stride 2 and ConvTranspose 2x2 -- take an fp32 detour (cast, fp32 kernels
+        for forward / data / weight gradient, cast back), their share of the FLOPs is a few per cent."""
         from . import train as T
         m = 2 ** (self.depth - 1)
         if x.shape[2] % m or x.shape[3] % m:
             raise ValueError(f"HINet needs H and W divisible by {m} (got {x.shape[2]}x{x.shape[3]}).")
         s_ = self.relu_slope
         g = store.grads
+        mixed = store.compute_dtype != "f32"
+        tdt = ops.TORCH_DT[store.compute_dtype]
+        if mixed:
+            if self.num_channels % 16:
+                raise capi.IEError("hinet: the 16-bit graph needs num_channels divisible by 16 (half instance norm on 8-channel groups)")
+            x = T.t_cast(tape, x, tdt, channels=16)
 
-        def conv(name, srcs, pad=1, act="none", stride=1):
-            return T.t_conv(tape, srcs, store.conv(name), *store.conv_grads(name), stride=stride, pad=pad, act=act, slope=s_)
+        def conv(name, srcs, pad=1, act="none", stride=1, cout_pad=None):
+            if mixed and stride != 1:
+                srcs = [T.t_cast(tape, t, torch.float32) for t in srcs]
+                y = T.t_conv(tape, srcs, store.conv(name), *store.conv_grads(name), stride=stride, pad=pad, act=act, slope=s_)
+                return T.t_cast(tape, y, tdt)
+            return T.t_conv(tape, srcs, store.conv(name), *store.conv_grads(name), stride=stride, pad=pad, act=act, slope=s_,
+                            cout_pad=cout_pad if mixed else None)
+
+        def up2x2(t, name):
+            if mixed:
+                return T.t_cast(tape, T.t_conv_transpose2x2(tape, T.t_cast(tape, t, torch.float32), store, name), tdt)
+            return T.t_conv_transpose2x2(tape, t, store, name)
 
         def block(name, srcs, hin, down, enc=None, dec=None):
             idn = conv(f"{name}.identity", srcs, pad=0)
@@ -1538,18 +1559,20 @@ class HINet_RE(_GraphModel):
                     t = block(name, [t], self._hin[i], False)
             for j in range(self.depth - 1):
                 bridge = conv(f"skip_conv_{s}.{j}", [ups[-j - 1]])
-                t = block(f"up_path_{s}.{j}.conv_block", [T.t_conv_transpose2x2(tape, t, store, f"up_path_{s}.{j}.up"), bridge], False, False)
+                t = block(f"up_path_{s}.{j}.conv_block", [up2x2(t, f"up_path_{s}.{j}.up"), bridge], False, False)
                 outs.append(t)
             return t, ups, outs
 
         x1, encs, decs = stage(1, conv("conv_01", [x]))
         f1 = conv("sam12.conv1", [x1])
-        img = T.t_add(tape, conv("sam12.conv2", [x1]), x)
+        img = T.t_add(tape, conv("sam12.conv2", [x1], cout_pad=16), x)
         att = conv("sam12.conv3", [img], act="sigmoid")
         sam = T.t_add(tape, T.t_mul(tape, f1, att), x1)
         x2 = conv("cat12", [conv("conv_02", [x]), sam], pad=0)
         x2, _, _ = stage(2, x2, encs, decs)
-        y2 = T.t_add(tape, conv("last", [x2]), x)
+        y2 = T.t_add(tape, conv("last", [x2], cout_pad=16), x)
+        if mixed:                                      # the losses run in fp32 on the 3-channel predictions
+            img, y2 = T.t_cast(tape, img, torch.float32, channels=3), T.t_cast(tape, y2, torch.float32, channels=3)
         return OrderedDict(stage1=img, enhanced=y2)
 
     def _stage(self, s, x, encs=None, decs=None):

@@ -428,6 +428,8 @@ def t_clamp(tape, x, lo, hi):
 def t_add(tape, a, b):
     """a + b (residual connection): the gradient goes to both operands unchanged."""
     y = ops.add(a, b)
+    if max(_real_c(a), _real_c(b)) < y.shape[1]:       # channel-padded operands (RGB carried as 16): the sum is padded the same way
+        y._ie_real = max(_real_c(a), _real_c(b))
 
     def bwd():
         g = tape.grad(y)

@@ -313,22 +313,31 @@ def retinexnet_forward(sd: dict, x: torch.Tensor, rl=None) -> dict:
 
 
 # ---- HINet -------------------------------------------------------------------------------------------------------
-def hinet_forward(sd: dict, x: torch.Tensor, depth: int = 5, relu_slope: float = 0.2, in_pos_left: int = 0, in_pos_right: int = 4) -> dict:
+def hinet_forward(sd: dict, x: torch.Tensor, depth: int = 5, relu_slope: float = 0.2, in_pos_left: int = 0, in_pos_right: int = 4, q=None) -> dict:
     """src/mon/vision/enhance/multitask/hinet/hinet.py:34-198, 322-362 with hinet.py:80's ``if enc and dec`` read as
     ``enc is not None and dec is not None`` (as shipped it raises on tensors; the original repository's hinet_arch.py:147 has
-    exactly that test).  Pinned by tests/golden/hinet_*.npz."""
+    exactly that test).  Pinned by tests/golden/hinet_*.npz.  ``q``: storage rounding of the 16-bit training graph
+    (oracle.train.storage_rounding) applied wherever the engine stores a tensor between two kernels; None = the plain forward."""
+    q, qw = q if q is not None else ((lambda t: t), (lambda w: w))          # (stored activations, weights as the 16-bit kernels read them)
     lr = lambda t: F.leaky_relu(t, relu_slope)
+    x = q(x)
+
+    def _c(sd_, name, t, padding=1):                                          # shadows the module helper: 16-bit layers read rounded weights
+        return F.conv2d(t, qw(sd_[f"{name}.weight"]), sd_.get(f"{name}.bias"), padding=padding)
 
     def block(n, t, hin, down, enc=None, dec=None):
+        idn = q(_c(sd, f"{n}.identity", t, padding=0))
         y = _c(sd, f"{n}.conv_1", t)
         if hin:
+            y = q(y)
             y1, y2 = torch.chunk(y, 2, dim=1)
             y = torch.cat([F.instance_norm(y1, weight=sd[f"{n}.norm.weight"], bias=sd[f"{n}.norm.bias"], eps=1e-5), y2], 1)
-        y = lr(_c(sd, f"{n}.conv_2", lr(y))) + _c(sd, f"{n}.identity", t, padding=0)
+        y = q(lr(y))
+        y = q(q(lr(_c(sd, f"{n}.conv_2", y))) + idn)
         if enc is not None and dec is not None:
-            y = y + _c(sd, f"{n}.csff_enc", enc) + _c(sd, f"{n}.csff_dec", dec)
+            y = q(q(y + q(_c(sd, f"{n}.csff_enc", enc))) + q(_c(sd, f"{n}.csff_dec", dec)))
         if down:
-            return F.conv2d(y, sd[f"{n}.downsample.weight"], None, stride=2, padding=1), y
+            return q(F.conv2d(y, sd[f"{n}.downsample.weight"], None, stride=2, padding=1)), y
         return y
 
     def stage(s, t, encs=None, decs=None):
@@ -342,19 +351,19 @@ def hinet_forward(sd: dict, x: torch.Tensor, depth: int = 5, relu_slope: float =
             else:
                 t = block(f"down_path_{s}.{i}", t, hin, False)
         for j in range(depth - 1):
-            bridge = _c(sd, f"skip_conv_{s}.{j}", ups[-j - 1])
-            u = F.conv_transpose2d(t, sd[f"up_path_{s}.{j}.up.weight"], sd[f"up_path_{s}.{j}.up.bias"], stride=2)
+            bridge = q(_c(sd, f"skip_conv_{s}.{j}", ups[-j - 1]))
+            u = q(F.conv_transpose2d(t, sd[f"up_path_{s}.{j}.up.weight"], sd[f"up_path_{s}.{j}.up.bias"], stride=2))
             t = block(f"up_path_{s}.{j}.conv_block", torch.cat([u, bridge], 1), False, False)
             outs.append(t)
         return t, ups, outs
 
-    x1, encs, decs = stage(1, _c(sd, "conv_01", x))
-    f1 = _c(sd, "sam12.conv1", x1)
-    img = _c(sd, "sam12.conv2", x1) + x
-    sam = f1 * torch.sigmoid(_c(sd, "sam12.conv3", img)) + x1
-    x2 = _c(sd, "cat12", torch.cat([_c(sd, "conv_02", x), sam], 1), padding=0)
+    x1, encs, decs = stage(1, q(_c(sd, "conv_01", x)))
+    f1 = q(_c(sd, "sam12.conv1", x1))
+    img = q(q(_c(sd, "sam12.conv2", x1)) + x)
+    sam = q(q(f1 * q(torch.sigmoid(_c(sd, "sam12.conv3", img)))) + x1)
+    x2 = q(_c(sd, "cat12", torch.cat([q(_c(sd, "conv_02", x)), sam], 1), padding=0))
     x2, _, _ = stage(2, x2, encs, decs)
-    return {"stage1": img, "enhanced": _c(sd, "last", x2) + x}
+    return {"stage1": img, "enhanced": q(q(_c(sd, "last", x2)) + x)}
 
 
 # ---- MPRNet ------------------------------------------------------------------------------------------------------

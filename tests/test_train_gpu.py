@@ -1044,3 +1044,42 @@ def test_retinexnet_training_phase_matches_torch(phase):
             assert torch.equal(sd1[k], sd0[k]), k
     with pytest.raises(ValueError):
         tr.training_step({"image": low})
+
+
+@pytest.mark.parametrize("dt,min_cos", [("f16", 0.9995), ("bf16", 0.995)])
+def test_hinet_mixed_precision_training_step(dt, min_cos):
+    """HINet on the 16-bit graph: stride-1 convolutions, half instance norms, adds and the attention product on 16-bit tensors; the
+    Conv4x4 stride-2 and ConvTranspose 2x2 layers through their fp32 detour.  Gradient direction against the storage-rounding
+    restatement of the same graph (oracle.generators.hinet_forward(q=...)); against plain float64 the engine must be about as close as
+    that restatement is."""
+    from oracle import generators as og
+    model = mon_amd.MODELS.build(name="hinet_re", num_channels=16, depth=3, in_pos_right=2, seed=7).to("cuda")
+    sd0 = model.state_dict()
+    g = torch.Generator().manual_seed(8)
+    tgt = torch.rand(2, 3, 48, 64, generator=g)
+    img = (tgt * 0.8 + 0.1 * torch.randn(2, 3, 48, 64, generator=g)).clamp(0, 1).contiguous()
+    lr, clip, eps = 1e-4, 0.1, 1e-3
+    tdt = {"f16": torch.float16, "bf16": torch.bfloat16}[dt]
+
+    def run(q):
+        def fwd(p, b, x):
+            o = og.hinet_forward(p, x, depth=3, in_pos_left=0, in_pos_right=2, q=q)
+            return o["stage1"], o["enhanced"]
+        return otrain.training_steps({k: v.double() for k, v in sd0.items()}, [(img.double(), tgt.double())], fwd,
+                                     lambda pred, t: otrain.l1_ssim_loss(pred[0], t) + otrain.l1_ssim_loss(pred[1], t), lr=lr, clip=clip, eps=eps)[0]
+    log, logq = run(None), run(otrain.storage_rounding(tdt))
+    tr = mon_amd.Trainer(model, optimizer={"name": "adam", "lr": lr, "eps": eps}, loss={"name": "l1_ssim_loss"}, gradient_clip_val=clip,
+                         compute_dtype=dt)
+    out = tr.training_step({"image": img, "ref_image": tgt})
+    assert list(out) == ["stage1", "enhanced", "loss"] and out["enhanced"].dtype == torch.float32
+    assert abs(float(out["loss"]) - log[0]["loss"][0]) < (5e-3 if dt == "f16" else 3e-2)
+    grads = tr.gradients()
+    cs = lambda u, v: float((u * v).sum() / (u.norm() * v.norm() + 1e-30))
+    flat = lambda d: torch.cat([d[k].double().reshape(-1) for k in log[0]["grads"]])
+    a, b, c = flat(grads), flat(log[0]["grads"]), flat(logq[0]["grads"])
+    print(f"hinet {dt}: engine vs rounded oracle {cs(a, c):.6f}, engine vs float64 {cs(a, b):.6f}, rounded oracle vs float64 {cs(c, b):.6f}")
+    assert cs(a, c) > min_cos, (cs(a, c), cs(a, b), cs(c, b))
+    assert cs(a, b) > cs(c, b) - 0.02
+    assert abs(float(a.norm()) / float(c.norm()) - 1.0) < 0.05
+    sd1 = tr.state_dict()
+    assert max(float((sd1[k] - sd0[k]).abs().max()) for k in sd0) > 0.2 * lr

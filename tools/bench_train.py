@@ -17,7 +17,7 @@ import torch.distributed as dist
 import mon_amd
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--model", default="unet", choices=["unet", "zero_dce", "llunetpp"])
+ap.add_argument("--model", default="unet", choices=["unet", "zero_dce", "llunetpp", "hinet"])
 ap.add_argument("--base", type=int, default=64)
 ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--hw", type=int, nargs=2, default=[1080, 1920])
@@ -33,6 +33,9 @@ if world > 1:
     dist.init_process_group("nccl")
 if a.model == "unet":
     model = mon_amd.MODELS.build(name="unet", in_channels=3, num_classes=3, base_channels=a.base, enhance=True, seed=1).to(f"cuda:{local}")
+    tr = mon_amd.Trainer(model, optimizer={"name": "adam", "lr": 1e-4}, loss={"name": "l1_ssim_loss"}, gradient_clip_val=0.1, compute_dtype=a.dtype)
+elif a.model == "hinet":
+    model = mon_amd.MODELS.build(name="hinet_re", seed=1).to(f"cuda:{local}")
     tr = mon_amd.Trainer(model, optimizer={"name": "adam", "lr": 1e-4}, loss={"name": "l1_ssim_loss"}, gradient_clip_val=0.1, compute_dtype=a.dtype)
 elif a.model == "llunetpp":
     model = mon_amd.MODELS.build(name="llunet++_re", seed=1).to(f"cuda:{local}")
@@ -59,7 +62,7 @@ if world > 1:
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
 fwd_gflop = {64: 2530.0, 32: 634.5}.get(a.base)
 if rank == 0:
-    wl = {"unet": f"unet{a.base} train L1+SSIM", "llunetpp": "llunet++ train L1+SSIM", "zero_dce": "zero_dce train zero-reference loss"}[a.model]
+    wl = {"unet": f"unet{a.base} train L1+SSIM", "llunetpp": "llunet++ train L1+SSIM", "hinet": "hinet-64 train L1+SSIM (two stages)", "zero_dce": "zero_dce train zero-reference loss"}[a.model]
     rec = {"workload": f"{wl} batch={a.batch}/GPU {a.hw[0]}x{a.hw[1]} {a.dtype}", "n_gpus": world, "s_per_step": round(dt.item(), 4),
            "images_per_s": round(a.batch * world / dt.item(), 3), "loss_first_last": [round(losses[0], 5), round(losses[-1], 5)],
            "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
