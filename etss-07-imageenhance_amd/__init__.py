@@ -16,6 +16,7 @@ from .zero_dce import ZeroDCE_RE
 from . import ops
 from .generators import ZeroDCEpp_RE, LLUnetpp_RE, LLLINet, UNet, ZeroIGEnhance, ZeroIG, RRDNet_RE, ZSN2N, ZeroDCEV, GCENet, RetinexNet, HINet_RE
 from . import image
+from . import video
 from . import sharding
 from . import losses, train
 from .losses import LOSSES
@@ -24,4 +25,4 @@ from .train import Trainer, ModelCheckpoint, get_latest_checkpoint
 __version__ = "0.1.0"
 __all__ = ["Factory", "ModelFactory", "MODELS", "Task", "Scheme", "capi", "Model", "VisionModel",
            "ImageEnhancementModel", "ZeroDCE_RE", "ZeroDCEpp_RE", "LLUnetpp_RE", "LLLINet", "UNet", "ZeroIGEnhance", "ZeroIG", "RRDNet_RE", "ZSN2N", "ZeroDCEV", "GCENet", "RetinexNet", "HINet_RE",
-           "ops", "image", "sharding", "losses", "train", "LOSSES", "Trainer", "ModelCheckpoint", "get_latest_checkpoint"]
+           "ops", "image", "video", "sharding", "losses", "train", "LOSSES", "Trainer", "ModelCheckpoint", "get_latest_checkpoint"]

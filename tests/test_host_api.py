@@ -190,3 +190,47 @@ def test_model_checkpoint_reference_naming(tmp_path):
     assert T.get_epoch_from_checkpoint(cb.best_model_path) == 1 and cb.state_dict()["last_global_step_saved"] == 20
     assert T.get_latest_checkpoint(tmp_path / "nothing") is None
     assert T.ModelCheckpoint(tmp_path / "weights").dirpath == str(tmp_path / "weights")
+
+
+def test_video_frame_sequence_round_trip(tmp_path):
+    """video.py: the loader / writer protocol of core/data/dataset/video.py and core/video/io.py over PIL frame sequences (directory of
+    frames, animated GIF); the cv2 classes are gated by the import, not faked."""
+    import numpy as np
+    from mon_amd import video, capi
+    rng = np.random.default_rng(5)
+    frames = [rng.integers(0, 256, (24, 40, 3), dtype=np.uint8) for _ in range(5)]
+    w = video.FrameSequenceWriter(tmp_path / "clip", image_size=(24, 40), frame_rate=5)
+    w.write(frames[0])
+    w.write_batch(frames[1:3])
+    w.write(torch.from_numpy(frames[3]).permute(2, 0, 1).float() / 255.0, denormalize=True)      # CHW float [0, 1]
+    w.write(torch.from_numpy(frames[4]))                                                          # HWC uint8 tensor
+    assert len(w) == 5
+    w.close()
+    ld = video.open_video(tmp_path / "clip")
+    assert isinstance(ld, video.FrameSequenceLoader) and len(ld) == 5 and ld.shape == (24, 40, 3) and ld.imgsz == (24, 40)
+    for i, d in enumerate(ld):
+        assert np.array_equal(d["frame"], frames[i]) and d["meta"]["id"] == i
+    got = list(ld.batches(2))
+    assert [tuple(b.shape) for b, _ in got] == [(2, 24, 40, 3), (2, 24, 40, 3), (1, 24, 40, 3)] and got[0][0].dtype == torch.uint8
+    t = video.FrameSequenceLoader(tmp_path / "clip", to_tensor=True)[2]["frame"]
+    assert tuple(t.shape) == (3, 24, 40) and float(t.max()) <= 1.0
+    # animated file + per-frame images
+    flat = [np.full((8, 8, 3), 40 * i, dtype=np.uint8) for i in range(4)]
+    g = video.FrameSequenceWriter(tmp_path / "anim.gif", image_size=(8, 8), frame_rate=10, save_image=True)
+    g.write_batch(flat)
+    g.close()
+    ga = video.open_video(tmp_path / "anim.gif")
+    assert len(ga) == 4 and sorted(p.name for p in (tmp_path / "anim").iterdir()) == [f"anim_{i:06d}.png" for i in range(4)]
+    assert abs(int(ga[3]["frame"][0, 0, 0]) - 120) <= 2                   # GIF palette quantisation
+    ga.close()
+    with pytest.raises(IOError):
+        video.FrameSequenceLoader(tmp_path / "missing.gif")
+    with pytest.raises(ValueError):
+        video._frame_u8("not a frame")
+    try:
+        import cv2  # noqa: F401
+    except ImportError:
+        with pytest.raises(capi.IEError):
+            video.VideoLoaderCV(tmp_path / "x.mp4")
+        with pytest.raises(capi.IEError):
+            video.VideoWriterCV(tmp_path / "y.mp4")

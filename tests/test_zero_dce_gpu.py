@@ -273,3 +273,25 @@ def test_u8_in_u8_out_entry_point(dtype):
     assert torch.equal(one[0], got["u8"][2])
     with pytest.raises(ValueError):
         m.enhance_u8(torch.zeros(1, 3, 8, 8, dtype=torch.uint8).cuda())
+
+
+def test_predict_video_frame_sequence(tmp_path):
+    """video.predict_video: an animated GIF in, enhanced frames out (PNG files), bit for bit what enhance_u8 gives on the decoded frames."""
+    import numpy as np
+    from mon_amd import video
+    rng = np.random.default_rng(9)
+    base = rng.integers(0, 90, (40, 56, 3), dtype=np.uint8)
+    w = video.FrameSequenceWriter(tmp_path / "src", image_size=(40, 56))
+    frames = [np.clip(base.astype(np.int32) + 9 * i, 0, 255).astype(np.uint8) for i in range(5)]
+    w.write_batch(frames)
+    w.close()
+    sd = o_zdce.init_state_dict(seed=5, gain=3.0)
+    m = _model(sd, "bf16")
+    res = video.predict_video(m, tmp_path / "src", tmp_path / "out", batch_size=2)
+    assert res["frames"] == 5
+    out = video.open_video(tmp_path / "out")
+    want = m.enhance_u8(torch.from_numpy(np.stack(frames)).cuda())["u8"].cpu().numpy()
+    assert len(out) == 5
+    for i in range(5):
+        assert np.array_equal(out[i]["frame"], want[i])
+    assert float(np.abs(want.astype(np.int32) - np.stack(frames)).mean()) > 1.0        # the curve did something (random weights)
