@@ -74,16 +74,19 @@ static size_t frame_elems(int H, int W, int C) { return (size_t)H * W * C; }
 
 static void pick_schedule(const ie_zdce_plan* p, int N, int H, int W, int* group, int* band, int* rb) {
     const bool f32 = p->cfg.compute_dtype == IE_F32;
-    int g = p->group_frames > 0 ? p->group_frames : (f32 ? 1 : 8);
+    // The fused kernels run one 8-wave workgroup per CU.  A launch should be ONE full round of the 256 CUs with equal-length blocks
+    // (no tail) and as few row chunks as possible -- every chunk re-runs 6-11 apron rows (4 chunks of 270 rows cost 3 %): at 1080p
+    // (16 strips) that is 16 frames per group and whole-height strips (tools/tune.py: 20.36 -> 19.94 ms per 64 frames against 8 frames
+    // x 4 chunks).  Fewer frames than that: more chunks per strip.
+    const long long strips = (W + 123) / 124;
+    int g = p->group_frames > 0 ? p->group_frames : (f32 ? 1 : (int)(256 / strips > 0 ? 256 / strips : 1));
+    if (g > 32) g = 32;
     if (g > N) g = N;
     int bd = p->band_rows > 0 ? p->band_rows : H;
     if (bd > H) bd = H;
     int r = p->rows_per_block > 0 ? p->rows_per_block : 0;
     if (r <= 0) {
-        // The fused kernels run one 8-wave workgroup per CU: aim for two full rounds of 256 workgroups per
-        // launch (equal-length blocks -> no tail), with rows long enough to amortise the 6-7 apron steps.
-        const long long strips = (W + 123) / 124;
-        long long chunks = (512 + (long long)g * strips - 1) / ((long long)g * strips);
+        long long chunks = 256 / ((long long)g * strips);
         if (chunks < 1) chunks = 1;
         long long rbv = (bd + chunks - 1) / chunks;
         if (rbv < 8) rbv = 8;
