@@ -20,5 +20,5 @@ for name, rw in parts.items():
     if "read" in rw and "write" in rw:
         out[name] = rw["read"] + rw["write"]
         out["_" + name + "_read_write"] = [rw["read"], rw["write"]]
-out["_source"] = "rocprofv3 --pmc FETCH_SIZE WRITE_SIZE on `bench.py --steps 2 --warmup 1 --no-extras` (launches of 8 frames 1080p); FETCH_SIZE x2 (gfx950) + WRITE_SIZE, KB -> bytes"
+out["_source"] = "rocprofv3 --pmc FETCH_SIZE WRITE_SIZE on `bench.py --steps 2 --warmup 1 --no-extras` (launches of 16 frames 1080p); FETCH_SIZE x2 (gfx950) + WRITE_SIZE, KB -> bytes"
 print(json.dumps(out, indent=1))
