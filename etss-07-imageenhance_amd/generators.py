@@ -50,8 +50,16 @@ class _GraphModel(ImageEnhancementModel):
 
     def _input_any(self, datapoint: dict):
         """Image as the compute dtype's NHWC tensor: fp32 with C channels, or 16-bit zero-padded to 8 channels."""
-        x = self._input(datapoint)
-        return x if self.compute_dtype == "f32" else ops.cast(x, self._tdt, 8)
+        if self.compute_dtype == "f32":
+            return self._input(datapoint)
+        self.assert_datapoint(datapoint)
+        self._require_cuda()
+        x = datapoint.get("image")
+        if x.dim() == 3:
+            x = x[None]
+        if x.dim() != 4 or x.shape[1] != self.in_channels:
+            raise ValueError(f"`image` must be (N,{self.in_channels},H,W), but got {tuple(x.shape)}.")
+        return ops.to_nhwc16(x.to(self.device), self._tdt, 8)          # NCHW fp32 -> NHWC 16-bit, channels padded, in one pass
 
     def _wb(self, name, bn=None, negate=False, cout=None):
         """Host (weight, bias) of conv ``name``: eval BatchNorm ``bn`` folded in, optionally only the first ``cout`` output
