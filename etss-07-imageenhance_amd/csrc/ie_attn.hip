@@ -120,7 +120,8 @@ __global__ void channel_affine_v8_kernel(const T* __restrict__ x, const float* _
 }
 
 // SimAM: d = (x - mu)^2; v = sum d / (HW - 1); y = x * sigmoid(d / (4 (v + lambda)) + 0.5)
-__global__ void simam_kernel(const float* __restrict__ x, const double* __restrict__ stats, float* __restrict__ y, size_t hwc, int C, int HW,
+template <typename T>
+__global__ void simam_kernel(const T* __restrict__ x, const double* __restrict__ stats, T* __restrict__ y, size_t hwc, int C, int HW,
                              float lambda, size_t total) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
@@ -131,10 +132,10 @@ __global__ void simam_kernel(const float* __restrict__ x, const double* __restri
     double sd = ss - s * mu;                        // sum (x - mu)^2
     sd = sd > 0.0 ? sd : 0.0;
     const float v = (float)(sd / (HW - 1));
-    const float xv = x[i];
+    const float xv = (float)x[i];
     const float d = (xv - (float)mu) * (xv - (float)mu);
     const float e = d / (4.f * (v + lambda)) + 0.5f;
-    y[i] = xv * (1.0f / (1.0f + expf(-e)));
+    y[i] = (T)(xv * (1.0f / (1.0f + expf(-e))));
 }
 
 }  // namespace
@@ -220,10 +221,22 @@ IE_EXPORT int ie_channel_affine_nhwc(const void* x, const float* scale, const fl
     default: IE_FAIL(IE_ERR_INVALID, "ie_channel_affine_nhwc: bad dtype");
     }
 }
-IE_EXPORT int ie_simam_nhwc_f32(const float* x, const double* stats, float* y, int N, int H, int W, int C, float lambda, void* stream) {
-    if (!x || !stats || !y || N <= 0 || H * W <= 1 || C <= 0) IE_FAIL(IE_ERR_INVALID, "ie_simam_nhwc_f32: bad args");
+template <typename T>
+static int simam_impl(const void* x, const double* stats, void* y, int N, int H, int W, int C, float lambda, void* stream) {
+    if (!x || !stats || !y || N <= 0 || H * W <= 1 || C <= 0) IE_FAIL(IE_ERR_INVALID, "ie_simam_nhwc: bad args");
     const size_t hwc = (size_t)H * W * C, total = hwc * N;
-    hipLaunchKernelGGL(simam_kernel, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, x, stats, y, hwc, C, H * W, lambda, total);
+    hipLaunchKernelGGL(simam_kernel<T>, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, (const T*)x, stats, (T*)y, hwc, C, H * W, lambda, total);
     IE_LAUNCH_CHECK();
     return IE_OK;
+}
+IE_EXPORT int ie_simam_nhwc_f32(const float* x, const double* stats, float* y, int N, int H, int W, int C, float lambda, void* stream) {
+    return simam_impl<float>(x, stats, y, N, H, W, C, lambda, stream);
+}
+IE_EXPORT int ie_simam_nhwc(const void* x, const double* stats, void* y, int dtype, int N, int H, int W, int C, float lambda, void* stream) {
+    switch (dtype) {
+    case IE_F32: return simam_impl<float>(x, stats, y, N, H, W, C, lambda, stream);
+    case IE_F16: return simam_impl<_Float16>(x, stats, y, N, H, W, C, lambda, stream);
+    case IE_BF16: return simam_impl<__bf16>(x, stats, y, N, H, W, C, lambda, stream);
+    default: IE_FAIL(IE_ERR_INVALID, "ie_simam_nhwc: bad dtype");
+    }
 }

@@ -461,7 +461,7 @@ class LLLINet(_GraphModel):
     """LLLINet (lllinet.py:97-260): the UNet++ grid of LLUnet++ with a different block (lllinet.py:97-156) --
     x1 = SimAM(LeakyReLU(LearnableInstanceNorm(Conv3x3(x)))) (no norm in ``conv0_0``), x2 = Conv3x3(x1), x3 = cat[x2, Conv1x1(x)],
     out = LeakyReLU(Conv3x3(LeakyReLU(Conv3x3(x3)))) + Conv1x1(x3) -- and denser decoder wiring (:235-253), final Conv1x1 + clamp[0, 1].
-    Keys per block ``conv1, norm1.{weight,bias,r}, conv2, conv3, conv4, conv1_3, conv3_4``; ``loss.*`` ignored.  fp32 path."""
+    Keys per block ``conv1, norm1.{weight,bias,r}, conv2, conv3, conv4, conv1_3, conv3_4``; ``loss.*`` ignored.  fp32 parity path and 16-bit matrix-core path."""
 
     arch = "lllinet"
     tasks = [Task.LLIE]
@@ -470,8 +470,6 @@ class LLLINet(_GraphModel):
     def __init__(self, in_channels: int = 3, out_channels: int = 3, weights: Any = None, loss_weights=None, seed: int = None, *args, **kwargs):
         kwargs.pop("name", None)
         super().__init__(name="lllinet", in_channels=in_channels, weights=weights, *args, **kwargs)
-        if self.compute_dtype != "f32":
-            raise capi.IEError("lllinet: only the fp32 path is built (compute_dtype='f32')")
         if isinstance(self.weights, dict):
             in_channels = self.weights.get("in_channels", in_channels)
             out_channels = self.weights.get("out_channels", out_channels)
@@ -504,21 +502,23 @@ class LLLINet(_GraphModel):
         self._on_params_change()
 
     def _block(self, b, srcs):
-        c = self._conv
-        x1 = c(srcs, f"{b}.conv1")
+        c, ci = self._conv, self._io[b][0]
+        cp = None if self.compute_dtype == "f32" or ci % 8 == 0 else (ci + 7) // 8 * 8     # conv0_0: 3 channels carried as 8 on the 16-bit path
+        x1 = c(srcs, f"{b}.conv1", cout_pad=cp)
         if f"{b}.norm1.r" in self._params:
             x1 = ops.learnable_instance_norm(x1, self._vec(f"{b}.norm1.weight"), self._vec(f"{b}.norm1.bias"), self._vec(f"{b}.norm1.r"), 1e-5, "lrelu", 0.2)
         else:
             x1 = ops.channel_affine_act(x1, "lrelu", 0.2)
-        x1 = ops.simam(x1, 1e-4)
-        x2 = c(x1, f"{b}.conv2")
-        s13 = c(srcs, f"{b}.conv1_3", pad=0)
-        x34 = c([x2, s13], f"{b}.conv3_4", pad=0)
-        x3 = c([x2, s13], f"{b}.conv3", act="lrelu", slope=0.2)
+        x1 = ops.simam(x1, 1e-4)                                      # zero padding channels stay zero: x * sigmoid(.)
+        x2 = c(x1, f"{b}.conv2", cout_pad=cp)
+        s13 = c(srcs, f"{b}.conv1_3", pad=0, cout_pad=cp)
+        v = None if cp is None else [ci, ci]
+        x34 = c([x2, s13], f"{b}.conv3_4", pad=0, valid=v)
+        x3 = c([x2, s13], f"{b}.conv3", act="lrelu", slope=0.2, valid=v)
         return c(x3, f"{b}.conv4", act="lrelu", slope=0.2, residual=x34)
 
     def forward(self, datapoint: dict, *args, **kwargs) -> dict:
-        x = self._input(datapoint)
+        x = self._input_any(datapoint)
         if x.shape[2] % 16 or x.shape[3] % 16:
             raise ValueError(f"LLLINet needs H and W divisible by 16 (got {x.shape[2]}x{x.shape[3]}); use infer(), which resizes to a "
                              f"multiple of 32 like the reference (vision/model.py:106).")
@@ -541,7 +541,7 @@ class LLLINet(_GraphModel):
         x1_3 = B("conv1_3", [x1_0, x1_1, x1_2, up(x2_2)])
         x0_3 = B("conv0_3", [x0_0, x0_1, x0_2, up(x1_2), up(x1_3)])
         x0_4 = B("conv0_4", [x0_0, x0_1, x0_2, x0_3, up(x1_3)])
-        y = self._conv(x0_4, "final", pad=0, clamp=(0.0, 1.0))
+        y = self._conv(x0_4, "final", pad=0, clamp=(0.0, 1.0), out_f32=True)
         return OrderedDict(enhanced=ops.to_nchw(y))
 
 

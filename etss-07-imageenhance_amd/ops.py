@@ -327,12 +327,12 @@ def learnable_instance_norm(x, gamma, beta, r, eps=1e-5, act="none", slope=0.0) 
 
 
 def simam(x, e_lambda=1e-4) -> torch.Tensor:
-    _chk(x)
+    _chk_any(x)
     n, c, h, w = x.shape
     st = channel_stats(x)
     y = torch.empty_like(x, memory_format=CL)
     with torch.cuda.device(x.device):
-        capi.check(capi.lib().ie_simam_nhwc_f32(capi.ptr(x), capi.ptr(st), capi.ptr(y), n, h, w, c, e_lambda, capi.current_stream()), "ie_simam_nhwc_f32")
+        capi.check(capi.lib().ie_simam_nhwc(capi.ptr(x), capi.ptr(st), capi.ptr(y), _dt(x), n, h, w, c, e_lambda, capi.current_stream()), "ie_simam_nhwc")
     return y
 
 

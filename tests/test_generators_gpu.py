@@ -530,6 +530,10 @@ def test_lllinet_vs_oracle_and_stat_layers():
     out = m.forward({"image": img.cuda()})["enhanced"].cpu()
     ref = og.lllinet_forward(sd, img)["enhanced"]
     assert rel_err(out, ref) <= 5e-4 and 0.05 < float(ref.mean()) < 0.95
+    for dt, tol in (("f16", 4e-3), ("bf16", 4e-2)):                     # 16-bit matrix-core path (RGB as 8 channels; statistics in fp64)
+        m16 = mon_amd.MODELS.build(name="lllinet", weights=dict(sd), compute_dtype=dt).to("cuda")
+        o16 = m16.forward({"image": img.cuda()})["enhanced"]
+        assert o16.dtype == torch.float32 and rel_err(o16.cpu(), ref) <= tol, (dt, rel_err(o16.cpu(), ref))
     with pytest.raises(ValueError):
         m.forward({"image": torch.rand(1, 3, 40, 48).cuda()})
 
@@ -591,6 +595,9 @@ def test_channel_stats_and_affine_16bit(dt):
         assert (st[:, :, 1] - (xf * xf).sum((2, 3))).abs().max() <= 2e-3 * h * w
         assert (ops.to_nchw(ops.global_avg_pool(xd)).cpu()[:, :, 0, 0] - xf.mean((2, 3)).float()).abs().max() <= 1e-5
         sc, sh = torch.rand(3, c, generator=g) + 0.5, torch.randn(3, c, generator=g)
+        if h * w > 1:
+            sm = ops.simam(xd, 1e-4)
+            assert sm.dtype == dt and rel_err(sm.float().cpu(), og.simam(x.float())) <= (1.5e-3 if dt == torch.float16 else 1e-2)
         y = ops.channel_affine(xd, sc.cuda(), sh.cuda(), "lrelu", 0.2)
         ref = F.leaky_relu(x.float() * sc[:, :, None, None] + sh[:, :, None, None], 0.2)
         assert y.dtype == dt and rel_err(y.float().cpu(), ref) <= (1.5e-3 if dt == torch.float16 else 1e-2)
