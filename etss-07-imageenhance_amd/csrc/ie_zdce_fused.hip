@@ -52,6 +52,11 @@ enum { K12 = 12, K45 = 45, K67 = 67, K345 = 345 };
 #ifndef IE_K12_STREAM
 #define IE_K12_STREAM 1
 #endif
+#ifndef IE_K67_CURVE2
+#define IE_K67_CURVE2 0   // 1: K67's curve on three stage-B waves, two columns per thread in packed fp32 arithmetic, the fourth wave issuing all of
+                          // stage B's DMA.  Half the vector instructions, but measured 9.6 against 7.6 ms: three waves then carry a twice as long
+                          // serial chain (transcendental latency) while five wait at the barrier -- the curve wants MORE lanes, not fewer.
+#endif
 #ifndef IE_K345_OUT
 #define IE_K345_OUT 0     // 1: K345 parks its x5 rows in LDS and stores whole lines like K12 (measured slower: 7.42 vs 7.0 ms -- the kernel is
 #endif                    // MFMA-dense and its writes are half of K12's, so the extra LDS traffic costs more than the write path gives back)
@@ -117,7 +122,7 @@ __device__ __forceinline__ void wait_vm(int n) {
 #define IE_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
     switch (n) {
     IE_W(1) IE_W(2) IE_W(3) IE_W(4) IE_W(5) IE_W(6) IE_W(7) IE_W(8) IE_W(9) IE_W(10) IE_W(11) IE_W(12) IE_W(13) IE_W(14)
-    IE_W(15) IE_W(16) IE_W(17) IE_W(18) IE_W(19) IE_W(20) IE_W(21) IE_W(22) IE_W(23) IE_W(24)
+    IE_W(15) IE_W(16) IE_W(17) IE_W(18) IE_W(19) IE_W(20) IE_W(21) IE_W(22) IE_W(23) IE_W(24) IE_W(25) IE_W(26) IE_W(27) IE_W(28) IE_W(29) IE_W(30)
     default: if (n >= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
 #undef IE_W
@@ -311,22 +316,28 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
                 // Waves 4 and 5 carry the curve of colour channel 2 and are the slowest of the step (in-kernel stamps); waves 6 and 7
                 // idle a third of it, so THEY issue all of stage B's DMA: the P row that seeds the output row started at step t
                 // (8 body pieces; P is read element-wise, it has no halo) and the three fp32 image planes of the row whose curve runs at step t+2.
-                if (sw >= 2) {
+                if (IE_K67_CURVE2 ? sw == 3 : sw >= 2) {
                     {
                         const int y = ys - 3 + t;
                         const unsigned rmask = ((y >= 0) && (y < H)) ? 0u : OOB;
                         const unsigned row_b = rmask ? 0u : (unsigned)y * (unsigned)W * PXB;
                         char* slot = smem + OFF_BRING + (t % NRB) * ROW_B;
-                        if constexpr (!(IE_EXP & 8192))
+                        if constexpr (!(IE_EXP & 8192)) {
+                            if constexpr (IE_K67_CURVE2) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) IE_DMA_PIECE(rsB, slot, (sw - 2) * 4 + j, row_b, rmask);
+                                for (int j = 0; j < 8; ++j) IE_DMA_PIECE(rsB, slot, j, row_b, rmask);
+                            } else {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) IE_DMA_PIECE(rsB, slot, (sw - 2) * 4 + j, row_b, rmask);
+                            }
+                        }
                     }
                     const int yo = ys - 5 + t;      // row finished at step t, consumed at step t+2
                     const unsigned rmask = ((yo >= ys) && (yo < ye)) ? 0u : OOB;
 #pragma unroll
                     for (int pl = 0; pl < 3; ++pl) {
                         if constexpr (IE_EXP & 4096) continue;
-                        if ((pl == 0) != (sw == 2)) continue;          // wave 6: plane 0; wave 7: planes 1, 2
+                        if (!IE_K67_CURVE2 && (pl == 0) != (sw == 2)) continue;          // (two-wave form) wave 6: plane 0; wave 7: planes 1, 2
                         const unsigned base = rmask ? 0u : ((unsigned)pl * (unsigned)plane + (unsigned)yo * (unsigned)W) * 4u;
 #pragma unroll
                         for (int j = 0; j < 2; ++j) {
@@ -346,7 +357,7 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     // argument); K67's curve stores only make the wait stricter than needed.
     int L = 0, S = 0;
     if (stg == 0) { L = (KIND == K12) ? 2 : (2 * NSA + ((HALO && sw == 0) ? NSA : 0)); }   // K345: NSA = 1
-    else if (KIND == K67) L = sw == 2 ? 6 : (sw == 3 ? 8 : 0);
+    else if (KIND == K67) L = IE_K67_CURVE2 ? (sw == 3 ? 14 : 0) : (sw == 2 ? 6 : (sw == 3 ? 8 : 0));
     const int wait_base = L ? (PF - 1) * L : -1;
     (void)S;
 
@@ -556,6 +567,53 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
         }
     };
 
+    // The same on 192 threads: stage-B waves 0..2 take colour channel c = sw each, thread = columns lane and lane + 64, arithmetic in
+    // packed fp32 (v_pk_mul / v_pk_add / v_pk_fma: half the vector instructions for everything but the two transcendentals per tanh).
+    // The fourth stage-B wave issues all of the stage's DMA instead, stage A (72 MFMAs per wave and row) carries no curve work.
+    auto curve_consume2 = [&](int s_fin) __attribute__((always_inline)) {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        const int yo = ys - 5 + s_fin;
+        const int c = sw, q0 = lane, q1 = lane + 64;
+        const bool row_ok = (yo >= ys) && (yo < ye);
+        const bool ok0 = row_ok && q0 >= MARG && xc0 + q0 < W, ok1 = row_ok && q1 < TW - MARG && xc0 + q1 < W;
+        const float* sp = (const float*)(smem + OFF_STAGE + (s_fin & 1) * STAGE_SLOT_B);
+        const float* ip = (const float*)(smem + OFF_IMG + (s_fin % NRI) * IMG_SLOT_B);
+        f2 v = {ip[c * TW + q0], ip[c * TW + q1]};
+        f2 r[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = 3 * i + c, rot = 16 * ((k >> 2) & 1);
+            const f2 a = {sp[k * TW + ((q0 + rot) & (TW - 1))], sp[k * TW + ((q1 + rot) & (TW - 1))]};
+            if constexpr (IE_EXP & 2048) { r[i] = a; continue; }
+            const f2 a2 = a * 2.885390081777927f;                                             // exp(2x) = exp2(x * 2 / ln 2)
+            const f2 e = {__builtin_amdgcn_exp2f(a2[0]), __builtin_amdgcn_exp2f(a2[1])};
+            const f2 d = e + 1.0f;
+            const f2 rc = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+            r[i] = __builtin_elementwise_fma(f2{-2.0f, -2.0f}, rc, f2{1.0f, 1.0f});          // 1 - 2 / (exp(2x) + 1), like ie_tanh_fast
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v = __builtin_elementwise_fma(r[i], __builtin_elementwise_fma(v, v, -v), v);   // ie_curve_step_fma on both columns
+        const size_t pix = (size_t)yo * W + xc0;
+        if (p.enhanced) {
+            float* ep = p.enhanced + ((size_t)n * 3 + c) * plane + pix;
+            if (ok0) ep[q0] = v[0];
+            if (ok1) ep[q1] = v[1];
+        }
+        if (p.u8) {
+            unsigned char* up = p.u8 + ((size_t)n * plane + pix) * 3 + c;
+            if (ok0) up[(size_t)q0 * 3] = ie_quant_u8(v[0]);
+            if (ok1) up[(size_t)q1 * 3] = ie_quant_u8(v[1]);
+        }
+        if (p.adjust) {
+            float* ap = p.adjust + (size_t)n * 24 * plane + pix;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (ok0) ap[(size_t)(3 * i + c) * plane + q0] = r[i][0];
+                if (ok1) ap[(size_t)(3 * i + c) * plane + q1] = r[i][1];
+            }
+        }
+    };
+
     // K12 stage A: e_conv1 on the MFMA.  Every landed fp32 image row is converted once into a 16-bit
     // pixel-interleaved row [px][R,G,B,0] (hi part, and for bf16 the lo = x - hi part, so the fp32
     // pixel survives bf16's 8 mantissa bits).  K layout of the two K=32 MFMAs per 16-pixel tile:
@@ -714,7 +772,7 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
             IE_T(ts2);
             issue(t + PF);
             if (t >= 2) a_emit(accO, t);
-            if constexpr (KIND == K67 && !(IE_EXP & 1024)) { if (t >= 7) curve_consume(t - 2); }
+            if constexpr (KIND == K67 && !(IE_EXP & 1024) && !IE_K67_CURVE2) { if (t >= 7) curve_consume(t - 2); }
         }
         IE_STEP_TAIL();
     };
@@ -737,7 +795,10 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
         } else if constexpr (KIND == K345) {
             if constexpr (!G::OUT) { if (t >= 10) IE_B_STORE(accN, ys - 10 + t, rsDb, true); }
         } else {
-            if constexpr (!(IE_EXP & 1024)) { if (t >= 7) curve_consume(t - 2); }
+            if constexpr (!(IE_EXP & 1024)) {
+                if constexpr (IE_K67_CURVE2) { if (t >= 7 && sw < 3) curve_consume2(t - 2); }
+                else { if (t >= 7) curve_consume(t - 2); }
+            }
             if (t >= 6) stage_write(accN, (t - 1) & 1);
         }
         const char* ra_row = smem + OFF_RA + ((t + RPB) % NRH) * ROW_B;     // written by stage A at step t-RPB
