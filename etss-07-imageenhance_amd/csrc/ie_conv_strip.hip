@@ -20,11 +20,13 @@ constexpr int ROW_PX = TW + 2;
 constexpr int PXB = 64;                    // bytes of one 32-channel chunk of a pixel
 constexpr int SRC_ROW_B = ROW_PX * PXB;    // one ring row of one chunk
 constexpr unsigned OOB = 0x80000000u;
-constexpr int NR = 4, PF = NR - 1;
+// ring slots (input rows resident in LDS): 4, or 3 with four K chunks (LDS: 4 chunks x 8.3 KB per row)
+template <int NCH> struct SGeom { static constexpr int NR = NCH == 4 ? 3 : 4, PF = NR - 1; };
 
 struct SConvParams {
-    const void* src[2];      // K chunk c: tensor base,
-    int ps[2], coff[2];      //            pixel stride and the chunk's byte offset inside a pixel
+    const void* src[2];      // the one or two source tensors (virtual concat)
+    int tps[2];              // their pixel strides in bytes
+    int tsel[4], coff[4];    // K chunk c: which tensor, and the chunk's byte offset inside a pixel
     const void* wpk;         // ie_mconv_pack_weights image: [chunk][tap][16 NCF rows][32 k], 16-byte pieces swizzled by (row >> 1) & 3
     const float* bias;       // [Cout] or null
     void* dst;               // NHWC T, Cout channels
@@ -37,7 +39,7 @@ __device__ __forceinline__ void wait_vm(int n) {
 #define IE_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
     switch (n) {
     IE_W(1) IE_W(2) IE_W(3) IE_W(4) IE_W(5) IE_W(6) IE_W(7) IE_W(8) IE_W(9) IE_W(10) IE_W(11) IE_W(12) IE_W(13) IE_W(14) IE_W(15) IE_W(16)
-    IE_W(17) IE_W(18) IE_W(19) IE_W(20)
+    IE_W(17) IE_W(18) IE_W(19) IE_W(20) IE_W(21) IE_W(22) IE_W(23) IE_W(24) IE_W(25) IE_W(26) IE_W(27) IE_W(28) IE_W(29) IE_W(30)
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
 #undef IE_W
@@ -46,6 +48,7 @@ __device__ __forceinline__ void wait_vm(int n) {
 template <typename T, int NCH, int NCF, int ACT>
 __device__ __forceinline__ void sconv3_body(const SConvParams& p) {
     using frag = ie_u32x4;
+    constexpr int NR = SGeom<NCH>::NR, PF = SGeom<NCH>::PF;
     constexpr int NW = NCF * 2;                   // waves
     constexpr int PPW = 8 / NW > 0 ? 8 / NW : 1;  // body DMA pieces (16 pixels x 64 B) per wave, chunk and row
     constexpr int SLOT_B = SRC_ROW_B * NCH;
@@ -78,9 +81,9 @@ __device__ __forceinline__ void sconv3_body(const SConvParams& p) {
     auto mk = [&](const void* base, size_t bytes) __attribute__((always_inline)) {
         return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
     };
-    const size_t fb0 = (size_t)H * W * p.ps[0], fb1 = (size_t)H * W * p.ps[NCH - 1];
+    const size_t fb0 = (size_t)H * W * p.tps[0], fb1 = (size_t)H * W * p.tps[1];
     const auto rs0 = mk((const char*)p.src[0] + (size_t)n * fb0, fb0);
-    const auto rs1 = mk((const char*)p.src[NCH - 1] + (size_t)n * fb1, fb1);
+    const auto rs1 = mk((const char*)p.src[1] + (size_t)n * fb1, fb1);
     const size_t fbo = (size_t)H * W * OPB;
     const auto rsd = mk((char*)p.dst + (size_t)n * fbo, fbo);
 
@@ -121,21 +124,22 @@ __device__ __forceinline__ void sconv3_body(const SConvParams& p) {
         char* slot = smem + (it % NR) * SLOT_B;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            const unsigned ps = (unsigned)p.ps[c], co = (unsigned)p.coff[c];
+            const bool t0 = p.tsel[c] == 0;
+            const unsigned ps = (unsigned)p.tps[t0 ? 0 : 1], co = (unsigned)p.coff[c];
             const unsigned row_b = (unsigned)yi * (unsigned)W * ps;
 #pragma unroll
             for (int j = 0; j < PPW; ++j) {
                 if (PPW * wave + j >= 8) break;
                 const unsigned off = (row_ok && px_q[j] >= 0) ? row_b + (unsigned)px_q[j] * ps + co + (unsigned)px_s[j] : OOB;
                 char* dstb = slot + c * SRC_ROW_B + (PPW * wave + j) * 1024;
-                if (c == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (__attribute__((address_space(3))) void*)dstb, 16, (int)off, 0, 0, 0);
+                if (t0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (__attribute__((address_space(3))) void*)dstb, 16, (int)off, 0, 0, 0);
                 else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (__attribute__((address_space(3))) void*)dstb, 16, (int)off, 0, 0, 0);
             }
             if (wave == NW - 1) {          // halo columns: (128 >> 1) & 3 == (129 >> 1) & 3 == 0, position == channel piece
                 const unsigned off = (row_ok && halo_x >= 0) ? row_b + (unsigned)halo_x * ps + co + (unsigned)((lane & 3) * 16) : OOB;
                 char* dstb = slot + c * SRC_ROW_B + TW * PXB;
                 if (lane < 8) {
-                    if (c == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (__attribute__((address_space(3))) void*)dstb, 16, (int)off, 0, 0, 0);
+                    if (t0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (__attribute__((address_space(3))) void*)dstb, 16, (int)off, 0, 0, 0);
                     else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (__attribute__((address_space(3))) void*)dstb, 16, (int)off, 0, 0, 0);
                 }
             }
@@ -263,10 +267,12 @@ IE_DEF_SCONV(f16_c32_o32, _Float16, 1, 2)
 IE_DEF_SCONV(f16_c32_o64, _Float16, 1, 4)
 IE_DEF_SCONV(f16_c64_o32, _Float16, 2, 2)
 IE_DEF_SCONV(f16_c64_o64, _Float16, 2, 4)
+IE_DEF_SCONV(f16_c128_o64, _Float16, 4, 4)
 IE_DEF_SCONV(bf16_c32_o32, __bf16, 1, 2)
 IE_DEF_SCONV(bf16_c32_o64, __bf16, 1, 4)
 IE_DEF_SCONV(bf16_c64_o32, __bf16, 2, 2)
 IE_DEF_SCONV(bf16_c64_o64, __bf16, 2, 4)
+IE_DEF_SCONV(bf16_c128_o64, __bf16, 4, 4)
 
 SConvFn pick_kernel(bool h, int nch, int ncf, int act) {
 #define IE_PICK_ACT(TAG) return act == IE_ACT_RELU ? sconv3_##TAG##_relu : (act == IE_ACT_LRELU ? sconv3_##TAG##_lrelu : sconv3_##TAG##_none)
@@ -274,11 +280,13 @@ SConvFn pick_kernel(bool h, int nch, int ncf, int act) {
         if (nch == 1 && ncf == 2) IE_PICK_ACT(f16_c32_o32);
         if (nch == 1 && ncf == 4) IE_PICK_ACT(f16_c32_o64);
         if (nch == 2 && ncf == 2) IE_PICK_ACT(f16_c64_o32);
+        if (nch == 4) IE_PICK_ACT(f16_c128_o64);
         IE_PICK_ACT(f16_c64_o64);
     }
     if (nch == 1 && ncf == 2) IE_PICK_ACT(bf16_c32_o32);
     if (nch == 1 && ncf == 4) IE_PICK_ACT(bf16_c32_o64);
     if (nch == 2 && ncf == 2) IE_PICK_ACT(bf16_c64_o32);
+    if (nch == 4) IE_PICK_ACT(bf16_c128_o64);
     IE_PICK_ACT(bf16_c64_o64);
 #undef IE_PICK_ACT
 }
@@ -294,22 +302,23 @@ bool ie_sconv3_applicable(int nsrc, const int* cs, int Cout, int kh, int kw, int
     if (act != IE_ACT_NONE && act != IE_ACT_RELU && act != IE_ACT_LRELU) return false;
     if (Cout != 32 && Cout != 64) return false;
     if (W < 64) return false;                                                          // a 128-column strip would be mostly padding
-    if (nsrc == 1) return cs[0] == 32 || cs[0] == 64;
-    return nsrc == 2 && cs[0] == 32 && cs[1] == 32;
+    static const int wide = getenv("IE_SCONV_WIDE") ? atoi(getenv("IE_SCONV_WIDE")) : 1;   // four K chunks (128 input channels), Cout 64 only
+    if (nsrc == 1) return cs[0] == 32 || cs[0] == 64 || (wide && cs[0] == 128 && Cout == 64);
+    if (nsrc != 2) return false;
+    return (cs[0] == 32 && cs[1] == 32) || (wide && cs[0] == 64 && cs[1] == 64 && Cout == 64);
 }
 
 int ie_sconv3_launch(const void* const* srcs, const int* cs, int nsrc, const void* wpk, const float* bias, void* dst, int dtype, int N, int H, int W,
                      int Cout, int act, float slope, int pad_mode, hipStream_t st) {
     SConvParams p;
     memset(&p, 0, sizeof(p));
-    const int nch = nsrc == 2 ? 2 : cs[0] / 32;
-    for (int c = 0; c < nch; ++c) {
-        p.src[c] = srcs[nsrc == 2 ? c : 0];
-        p.ps[c] = (nsrc == 2 ? 32 : cs[0]) * 2;
-        p.coff[c] = nsrc == 2 ? 0 : c * 64;
-    }
+    int nch = 0;
+    p.src[0] = srcs[0]; p.src[1] = srcs[nsrc - 1];
+    p.tps[0] = cs[0] * 2; p.tps[1] = cs[nsrc - 1] * 2;
+    for (int s = 0; s < nsrc; ++s)
+        for (int c0 = 0; c0 < cs[s]; c0 += 32) { p.tsel[nch] = s; p.coff[nch] = c0 * 2; ++nch; }
     p.wpk = wpk; p.bias = bias; p.dst = dst; p.N = N; p.H = H; p.W = W; p.slope = slope; p.replicate = pad_mode == IE_PAD_REPLICATE;
-    if ((double)H * W * 128.0 >= 2147483647.0) IE_FAIL(IE_ERR_UNSUPPORTED, "ie_sconv3: frame too large for 31-bit offsets");
+    if ((double)H * W * 256.0 >= 2147483647.0) IE_FAIL(IE_ERR_UNSUPPORTED, "ie_sconv3: frame too large for 31-bit offsets");
     p.strips = ie_cdiv(W, TW);
     // Row chunks per strip: the grid should fill whole rounds of the chip's resident workgroup slots (a 2.1-round grid runs 3 rounds),
     // while every chunk pays 3 rows of pipeline fill.  Score = slot fill x useful-row fraction; 8-wave workgroups (Cout 64) sit one
@@ -332,7 +341,7 @@ int ie_sconv3_launch(const void* const* srcs, const int* cs, int nsrc, const voi
     }
     const long long blocks = (long long)p.strips * p.chunks * N;
     if (blocks <= 0 || blocks > 0x7fffffffLL) IE_FAIL(IE_ERR_INVALID, "ie_sconv3: bad grid");
-    const size_t lds = (size_t)NR * SRC_ROW_B * nch + 2 * (size_t)TW * (Cout * 2);
+    const size_t lds = (size_t)(nch == 4 ? 3 : 4) * SRC_ROW_B * nch + 2 * (size_t)TW * (Cout * 2);
     const int ncf = Cout / 16;
     SConvFn fn = pick_kernel(dtype == IE_F16, nch, ncf, act);
     static SConvFn granted[24] = {nullptr};

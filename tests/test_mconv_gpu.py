@@ -45,6 +45,9 @@ STRIP_CASES = [
     dict(cs=[32, 32], co=64, k=3, p=1),
     dict(cs=[64], co=32, k=3, p=1, act="lrelu", mode="replicate"),
     dict(cs=[32], co=64, k=3, p=1, act="relu"),                       # down1 of U-Net-32
+    dict(cs=[64, 64], co=64, k=3, p=1, act="relu"),                   # decoder concat [skip, up] of U-Net-64: four K chunks
+    dict(cs=[128], co=64, k=3, p=1),
+    dict(cs=[64, 64], co=64, k=3, p=1, act="relu", mode="replicate"), # retinexnet/model.py:62-64
 ]
 
 

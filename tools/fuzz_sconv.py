@@ -15,8 +15,8 @@ bad = 0
 worst = 0.0
 for case in range(n_cases):
     dt = rnd.choice([torch.float16, torch.bfloat16])
-    cs = rnd.choice([[32], [64], [32, 32]])
-    co = rnd.choice([32, 64])
+    cs = rnd.choice([[32], [64], [32, 32], [64, 64], [128]])
+    co = 64 if sum(cs) == 128 else rnd.choice([32, 64])
     mode = rnd.choice(["zeros", "zeros", "replicate"])
     act = rnd.choice(["none", "relu", "lrelu"])
     n = rnd.randint(1, 3)
