@@ -35,6 +35,7 @@ struct MConvParams {
     int N, H, W, Cout, kh, kw, pad, pad_mode, sub, act, clamp, out_f32;
     int Ho, Wo;                  // stride-1 output extent
     int Hs, Ws;                  // stored extent (= Ho, Wo, or the sub-sampled size)
+    int shuf_c;                  // fused PixelShuffle(2): channels of the shuffled output (Cout = 4 shuf_c, rows packed as [i][j][c]); 0 = off
     int tiles_x, tiles_y, cout_tiles, total_blocks;
     int taps_stage, nstages;     // weight staging: taps per LDS stage
     float slope, lo, hi;
@@ -462,9 +463,13 @@ __device__ __forceinline__ void mconv3_epilogue(const MConvParams& p, ie_f32x4 (
         // interior tile of a plain Conv(+BN)+ReLU layer -- nearly all of the work: no masks; per accumulator tile 2 packed adds,
         // 2 cvt_pk (+ 2 packed max), one store through a wave-uniform base pointer and a 32-bit lane offset
         if (p.sub == 1 && full && !p.res && !p.clamp && !p.out_f32 && oy0 + TH3 <= p.Ho && ox0 + TW <= p.Wo) {
-            const char* tile = (const char*)((T*)p.dst + (((size_t)n * p.Hs + oy0 + r0) * p.Ws + ox0) * p.Cout);
+            // fused PixelShuffle(2) (edsr.py:88-123): the weight rows were packed as [i][j][c], so this wave's 16-cout fragment is 16
+            // consecutive channels c of ONE sub-pixel (i, j): out[2 oy + i][2 ox + j][c]
+            const int SC = p.shuf_c ? p.shuf_c : p.Cout, SS = p.shuf_c ? 2 : 1;
+            const int ij = p.shuf_c ? co0 / SC : 0, c0 = p.shuf_c ? co0 - ij * SC : co0;
+            const char* tile = (const char*)((T*)p.dst + (((size_t)n * SS * p.Hs + SS * (oy0 + r0) + (ij >> 1)) * (SS * p.Ws) + SS * ox0 + (ij & 1)) * SC);
             const unsigned lane_off = (unsigned)((l16 * p.Cout + co) * (int)sizeof(T));
-            const unsigned row_b = (unsigned)p.Ws * (unsigned)p.Cout * (unsigned)sizeof(T), half_b = 16u * (unsigned)p.Cout * (unsigned)sizeof(T);
+            const unsigned row_b = (unsigned)(SS * SS) * (unsigned)p.Ws * (unsigned)SC * (unsigned)sizeof(T), half_b = 16u * (unsigned)p.Cout * (unsigned)sizeof(T);
             const ie_f32x2 b01 = {bv[0], bv[1]}, b23 = {bv[2], bv[3]};
             // the two column halves of a row are stored by ONE instruction: lanes kc / kc+1 exchange halves (v_permlane16_swap), so
             // even-kc lanes hold couts 4kc..4kc+7 of the left-half pixel and odd-kc lanes couts 4(kc-1)..+7 of the right-half pixel:
@@ -472,7 +477,7 @@ __device__ __forceinline__ void mconv3_epilogue(const MConvParams& p, ie_f32x4 (
 #ifdef IE_MEXP_FULL_LINES   // timing experiment (wrong results, Cout = 64): the same bytes, but every store instruction writes 1 KiB of whole lines
             const unsigned lane_off16 = (unsigned)(((co0 >> 4) & 3) * 1024 + (kc * 16 + l16) * 16);
 #else
-            const unsigned lane_off16 = (unsigned)(((l16 + 16 * (kc & 1)) * p.Cout + co0 + 4 * (kc & 2)) * (int)sizeof(T));
+            const unsigned lane_off16 = (unsigned)(((l16 + 16 * (kc & 1)) * SS * SC + c0 + 4 * (kc & 2)) * (int)sizeof(T));
 #endif
             (void)half_b; (void)lane_off;
 #pragma unroll
@@ -495,10 +500,12 @@ __device__ __forceinline__ void mconv3_epilogue(const MConvParams& p, ie_f32x4 (
         // fast path (every hot layer): one 64-bit base per lane, wave-uniform row / half offsets, 8 VALU + 1 store per tile
         const int ox_a = ox0 + l16;
         const bool live_x[2] = {ox_a < p.Wo, ox_a + 16 < p.Wo};
-        T* dst = (T*)p.dst + ((((size_t)n * p.Hs + oy0 + r0) * p.Ws + ox_a) * p.Cout + co);
+        const int SC = p.shuf_c ? p.shuf_c : p.Cout, SS = p.shuf_c ? 2 : 1;
+        const int ij = p.shuf_c ? co / SC : 0, cc = p.shuf_c ? co - ij * SC : co;
+        T* dst = (T*)p.dst + ((((size_t)n * SS * p.Hs + SS * (oy0 + r0) + (ij >> 1)) * (SS * p.Ws) + SS * ox_a + (ij & 1)) * SC + cc);
         const float slope = p.slope;
-        const unsigned row_stride = (unsigned)p.Ws * (unsigned)p.Cout;       // elements
-        const unsigned half_stride = 16u * (unsigned)p.Cout;
+        const unsigned row_stride = (unsigned)(SS * SS) * (unsigned)p.Ws * (unsigned)SC;       // elements
+        const unsigned half_stride = 16u * (unsigned)SS * (unsigned)SC;
         const int rows_live = p.Ho - (oy0 + r0);                             // wave-uniform
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -521,7 +528,11 @@ __device__ __forceinline__ void mconv3_epilogue(const MConvParams& p, ie_f32x4 (
             sy = oy / p.sub; sx = ox / p.sub;
         }
         if (!live) continue;
-        const size_t o = (((size_t)n * p.Hs + sy) * p.Ws + sx) * p.Cout + co;
+        size_t o = (((size_t)n * p.Hs + sy) * p.Ws + sx) * p.Cout + co;
+        if (p.shuf_c) {
+            const int ij = co / p.shuf_c, cc = co - ij * p.shuf_c;
+            o = (((size_t)n * 2 * p.Hs + 2 * sy + (ij >> 1)) * (2 * p.Ws) + 2 * sx + (ij & 1)) * p.shuf_c + cc;
+        }
         float v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = act_fast<ACT>(acc[t][j] + bv[j], p.slope);
@@ -921,8 +932,8 @@ IE_EXPORT int ie_mconv_nhwc(ie_mconv_desc* d, const void* const* srcs, const int
     Plan pl;
     int rc = make_plan(channels, d->nsrc, d->Cout, d->kh, d->kw, &pl, "ie_mconv_nhwc");
     if (rc != IE_OK) return rc;
-    if (ie_sconv3_applicable(d->nsrc, channels, d->Cout, d->kh, d->kw, d->stride, d->pad, d->pad_mode, d->act, residual != nullptr, d->clamp != 0,
-                             d->out_dtype == IE_F32, d->W)) {
+    if (!d->pixel_shuffle && ie_sconv3_applicable(d->nsrc, channels, d->Cout, d->kh, d->kw, d->stride, d->pad, d->pad_mode, d->act, residual != nullptr,
+                                                  d->clamp != 0, d->out_dtype == IE_F32, d->W)) {
         // narrow 3x3 layers: the strip kernel (weights in registers for the whole launch, an output row stored every step)
         for (int s = 0; s < d->nsrc; ++s)
             if (!srcs[s]) IE_FAIL(IE_ERR_INVALID, "ie_mconv_nhwc: source %d is null", s);
@@ -951,6 +962,12 @@ IE_EXPORT int ie_mconv_nhwc(ie_mconv_desc* d, const void* const* srcs, const int
     if (p.Ho <= 0 || p.Wo <= 0) IE_FAIL(IE_ERR_INVALID, "ie_mconv_nhwc: empty output");
     p.Hs = (d->H + 2 * d->pad - d->kh) / d->stride + 1; p.Ws = (d->W + 2 * d->pad - d->kw) / d->stride + 1;
     d->Ho = p.Hs; d->Wo = p.Ws;
+    if (d->pixel_shuffle) {
+        if (d->pixel_shuffle != 2 || d->kh != 3 || d->kw != 3 || d->stride != 1 || (d->Cout & 63) || pl.thin || d->out_dtype == IE_F32 || residual)
+            IE_FAIL(IE_ERR_UNSUPPORTED, "ie_mconv_nhwc: fused PixelShuffle needs r = 2, a 3x3 stride-1 conv, Cout a multiple of 64, 16-bit output, no residual");
+        p.shuf_c = d->Cout / 4;
+        d->Ho = 2 * p.Hs; d->Wo = 2 * p.Ws;
+    }
     p.tiles_x = ie_cdiv(p.Wo, TW); p.tiles_y = ie_cdiv(p.Ho, TH); p.cout_tiles = pl.cout_tiles;
     const long logical = (long)p.tiles_x * p.tiles_y * p.cout_tiles * d->N;
     p.total_blocks = (int)((logical + 7) / 8 * 8);

@@ -75,17 +75,20 @@ class _GraphModel(ImageEnhancementModel):
         return w, b
 
     def _conv(self, srcs, name, bn=None, stride=1, pad=1, pad_mode="zeros", act="none", slope=0.0, residual=None, clamp=None,
-              out_f32=False, cout_pad=None, valid=None, negate=False, cout=None):
+              out_f32=False, cout_pad=None, valid=None, negate=False, cout=None, shuffle=0):
         """Conv2d ``name`` (+ folded eval BatchNorm ``bn``) over the channel concat of ``srcs`` in the model's compute dtype.
         On the 16-bit path sources may carry zero-padded channels (a 3-channel image stored as 8): the weights of the missing
         input channels are zero; ``cout_pad`` pads the output channels the same way (zero weights and bias)."""
         if isinstance(srcs, torch.Tensor):
             srcs = [srcs]
         if self.compute_dtype == "f32":
-            return ops.conv2d(srcs, self._cw(name, bn, negate, cout), stride=stride, pad=pad, pad_mode=pad_mode, act=act, slope=slope,
-                              residual=residual, clamp=clamp)
+            y = ops.conv2d(srcs, self._cw(name, bn, negate, cout), stride=stride, pad=pad, pad_mode=pad_mode, act=act, slope=slope,
+                           residual=residual, clamp=clamp)
+            return ops.pixel_shuffle(y, shuffle) if shuffle else y
         split = tuple(int(t.shape[1]) for t in srcs)
-        key = ("mconv", name, bn, split, cout_pad, None if valid is None else tuple(valid), negate, cout)
+        w_ = self._params[f"{name}.weight"]
+        fuse = bool(shuffle) and shuffle == 2 and w_.shape[2] == 3 and w_.shape[0] % 64 == 0 and stride == 1 and residual is None and not out_f32
+        key = ("mconv", name, bn, split, cout_pad, None if valid is None else tuple(valid), negate, cout, fuse)
         if self._dev_cache is None:
             self._dev_cache = {}
         if key not in self._dev_cache:
@@ -103,9 +106,10 @@ class _GraphModel(ImageEnhancementModel):
                 extra = cout_pad - w.shape[0]
                 w = torch.cat([w, torch.zeros(extra, *w.shape[1:])], 0)
                 b = None if b is None else torch.cat([b, torch.zeros(extra)], 0)
-            self._dev_cache[key] = ops.MConvWeights(w, b, split, self._tdt, self.device, cin_map)
-        return ops.mconv2d(srcs, self._dev_cache[key], stride=stride, pad=pad, pad_mode=pad_mode, act=act, slope=slope,
-                           residual=residual, clamp=clamp, out_f32=out_f32)
+            self._dev_cache[key] = ops.MConvWeights(w, b, split, self._tdt, self.device, cin_map, shuffle=2 if fuse else 0)
+        y = ops.mconv2d(srcs, self._dev_cache[key], stride=stride, pad=pad, pad_mode=pad_mode, act=act, slope=slope,
+                        residual=residual, clamp=clamp, out_f32=out_f32)
+        return ops.pixel_shuffle(y, shuffle) if (shuffle and not fuse) else y
 
     def _ds_block(self, prefix, srcs, act, out_f32=False, slope=0.0):
         """DepthwiseSeparableConv2d ``prefix`` (dsconv.py:106-149: ``prefix.dw_conv`` 3x3 depthwise + ``prefix.pw_conv`` 1x1) over the channel
@@ -802,7 +806,7 @@ class UNet(_GraphModel):
         if self.upsampler == "bilinear":
             x1 = ops.upsample2x_bilinear(x1)
         else:
-            x1 = ops.pixel_shuffle(self._conv(x1, f"up{k}.up.0"), 2)
+            x1 = self._conv(x1, f"up{k}.up.0", shuffle=2)           # conv3x3 + PixelShuffle(2), fused into the conv's epilogue on the 16-bit path
         dy, dx = x2.shape[2] - x1.shape[2], x2.shape[3] - x1.shape[3]
         x1 = ops.pad(x1, dy // 2, dy - dy // 2, dx // 2, dx - dx // 2)
         return self._dc(f"up{k}.conv", [x2, x1])

@@ -707,8 +707,16 @@ class MConvWeights:
     of 8; weights of padded input channels are zero).  ``cin_map``: for every source, the indices (into the checkpoint's
     Cin) its channels correspond to, or -1 for padding channels."""
 
-    def __init__(self, w_oihw: torch.Tensor, bias, split, dtype, device, cin_map=None):
+    def __init__(self, w_oihw: torch.Tensor, bias, split, dtype, device, cin_map=None, shuffle: int = 0):
         w = w_oihw.detach().to("cpu", torch.float32)
+        self.shuffle = int(shuffle)
+        if self.shuffle:                  # fused PixelShuffle(2): output rows in [i][j][c] order (row (2i + j) C + c <- checkpoint row 4c + 2i + j)
+            if self.shuffle != 2 or w.shape[0] % 4:
+                raise capi.IEError("MConvWeights: fused pixel shuffle needs r = 2 and Cout divisible by 4")
+            c4 = w.shape[0] // 4
+            perm = torch.arange(w.shape[0]).reshape(c4, 4).t().reshape(-1)
+            w = w[perm]
+            bias = None if bias is None else bias.detach().to("cpu", torch.float32)[perm]
         self.cout, cin, self.kh, self.kw = w.shape
         self.split = [int(s) for s in split]
         if cin_map is not None:
@@ -746,12 +754,16 @@ def mconv2d(srcs, mw: MConvWeights, stride=1, pad=1, pad_mode="zeros", act="none
         raise capi.IEError(f"mconv2d: sources carry channels {cs}, weights were packed for {mw.split}")
     n, _, h, w = srcs[0].shape
     odt = torch.float32 if out_f32 else mw.dtype
+    sh = int(getattr(mw, "shuffle", 0))
     d = capi.MConvDesc(n, h, w, len(srcs), mw.cout, mw.kh, mw.kw, stride, pad, capi.PAD[pad_mode], capi.ACT[act], slope,
                        0 if clamp is None else 1, 0.0 if clamp is None else clamp[0], 0.0 if clamp is None else clamp[1],
-                       IE_DT[mw.dtype], IE_DT[odt], 0, 0)
+                       IE_DT[mw.dtype], IE_DT[odt], 0, 0, sh)
     ho = (h + 2 * pad - mw.kh) // stride + 1
     wo = (w + 2 * pad - mw.kw) // stride + 1
-    out = torch.empty((n, mw.cout, ho, wo), device=srcs[0].device, dtype=odt, memory_format=CL)
+    if sh:                                # conv + PixelShuffle(sh) in one kernel: (N, Cout / 4, 2 Ho, 2 Wo)
+        out = torch.empty((n, mw.cout // (sh * sh), ho * sh, wo * sh), device=srcs[0].device, dtype=odt, memory_format=CL)
+    else:
+        out = torch.empty((n, mw.cout, ho, wo), device=srcs[0].device, dtype=odt, memory_format=CL)
     _count_macs(n, ho, wo, mw.cout, sum(cs), mw.kh, mw.kw)
     if residual is not None:
         _chk16(residual)

@@ -155,6 +155,8 @@ typedef struct ie_mconv_desc {
     int in_dtype;          /* IE_F16 | IE_BF16 */
     int out_dtype;         /* in_dtype | IE_F32 */
     int Ho, Wo;            /* out */
+    int pixel_shuffle;     /* 0, or 2: fused nn.PixelShuffle(2) of the Upsampler (edsr.py:88-123) -- the weights must have been packed with
+                              their output rows in [i][j][c] order (row i*2C + j*C + c <- checkpoint row 4c + 2i + j); dst is (N, 2Ho', 2Wo', Cout/4) */
 } ie_mconv_desc;
 size_t ie_mconv_packed_bytes(const int* channels, int nsrc, int Cout, int kh, int kw);
 int ie_mconv_pack_weights(const float* w_oihw_host, const int* channels, int nsrc, int Cout, int kh, int kw, int dtype,

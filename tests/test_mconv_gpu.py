@@ -155,3 +155,25 @@ def test_device_weight_packing_matches_host(cs, co, k):
                 dev_g = ops.MConvWeightsDev(hwio, None, cs, co, k, k, tdt, mode="dgrad", src_index=si)
                 assert dev_g.cout == c and dev_g.split == [co] and torch.equal(host_g.w, dev_g.w)
             base += c
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("ci,c,shape", [(64, 32, (2, 37, 45)), (128, 64, (1, 20, 70)), (32, 16, (2, 9, 33))])
+def test_fused_pixel_shuffle(ci, c, shape, dt):
+    """Upsampler of the PixelShuffle decoder (edsr.py:88-123): conv3x3(ci -> 4c) + nn.PixelShuffle(2) in one kernel -- the weight rows are
+    packed in [i][j][c] order and the epilogue scatters every 16-channel fragment to its sub-pixel."""
+    tdt = ops.TORCH_DT[dt]
+    n, h, w = shape
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(n, ci, h, w, generator=g).to(tdt)
+    wt = (torch.randn(4 * c, ci, 3, 3, generator=g) / (ci * 9) ** 0.5).to(tdt).float()
+    b = torch.randn(4 * c, generator=g)
+    ref = F.pixel_shuffle(F.relu(F.conv2d(x.float(), wt, b, padding=1)), 2)
+    mw = ops.MConvWeights(wt, b, [ci], tdt, "cuda", shuffle=2)
+    out = ops.mconv2d(x.cuda().contiguous(memory_format=CL), mw, act="relu")
+    assert tuple(out.shape) == (n, c, 2 * h, 2 * w) and out.dtype == tdt
+    assert rel_err(out.float().cpu(), ref) <= (1.5e-3 if dt == "f16" else 1e-2)
+    if (4 * c) % 64:
+        return
+    with pytest.raises(capi.IEError):                                   # 1x1 convs do not take the fused form
+        ops.mconv2d(x.cuda().contiguous(memory_format=CL), ops.MConvWeights(wt[:, :, :1, :1].contiguous(), b, [ci], tdt, "cuda", shuffle=2), pad=0)
