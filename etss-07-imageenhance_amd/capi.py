@@ -70,7 +70,8 @@ class MConvDesc(C.Structure):
     _fields_ = [("N", C.c_int), ("H", C.c_int), ("W", C.c_int), ("nsrc", C.c_int), ("Cout", C.c_int), ("kh", C.c_int),
                 ("kw", C.c_int), ("stride", C.c_int), ("pad", C.c_int), ("pad_mode", C.c_int), ("act", C.c_int),
                 ("slope", C.c_float), ("clamp", C.c_int), ("clamp_lo", C.c_float), ("clamp_hi", C.c_float),
-                ("in_dtype", C.c_int), ("out_dtype", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int), ("pixel_shuffle", C.c_int)]
+                ("in_dtype", C.c_int), ("out_dtype", C.c_int), ("Ho", C.c_int), ("Wo", C.c_int),
+                ("src_h", C.c_int * 8), ("src_w", C.c_int * 8), ("pixel_shuffle", C.c_int)]
 
 
 _lib = None

@@ -35,6 +35,7 @@ struct MConvParams {
     int N, H, W, Cout, kh, kw, pad, pad_mode, sub, act, clamp, out_f32;
     int Ho, Wo;                  // stride-1 output extent
     int Hs, Ws;                  // stored extent (= Ho, Wo, or the sub-sampled size)
+    int sh[IE_CONV_MAX_SRC], sw[IE_CONV_MAX_SRC];   // stored size of source s (== H, W unless the conv reads it through a nearest-neighbour up-sampling)
     int shuf_c;                  // fused PixelShuffle(2): channels of the shuffled output (Cout = 4 shuf_c, rows packed as [i][j][c]); 0 = off
     int tiles_x, tiles_y, cout_tiles, total_blocks;
     int taps_stage, nstages;     // weight staging: taps per LDS stage
@@ -166,7 +167,10 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(MConvParams p) {
 
     for (int ch = 0; ch < p.nchunks; ++ch) {
         const int s = p.chunk_tab[ch] >> 16, c0 = p.chunk_tab[ch] & 0xffff, Cs = p.cs[s];
-        const size_t frame_b = (size_t)p.H * p.W * Cs * sizeof(T);
+        const int SH = p.sh[s], SW = p.sw[s];
+        const bool up = SH != p.H || SW != p.W;        // F.interpolate(size=(H, W)) in front of the conv (retinexnet/model.py:79-86), folded into the addressing
+        const float fy = (float)SH / (float)p.H, fx = (float)SW / (float)p.W;
+        const size_t frame_b = (size_t)SH * SW * Cs * sizeof(T);
         const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.src[s] + (size_t)n * frame_b), 0, (int)frame_b, 0x00020000);
         __syncthreads();                        // the previous chunk's fragments have been read
         // input halo tile by LDS-DMA: lane -> (pixel q, 16-byte slot); the slot holds channel piece slot ^ ((q>>1)&3).
@@ -179,7 +183,8 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(MConvParams p) {
             bool ok = (c0 + j * 8 < Cs) && (q < TPX);
             if (p.pad_mode == IE_PAD_REPLICATE) { iy = min(max(iy, 0), p.H - 1); ix = min(max(ix, 0), p.W - 1); }
             else ok = ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            const unsigned off = ok ? (unsigned)(((unsigned)(iy * p.W + ix) * (unsigned)Cs + (unsigned)(c0 + j * 8)) * sizeof(T)) : OOB;
+            if (up) { iy = min((int)floorf(iy * fy), SH - 1); ix = min((int)floorf(ix * fx), SW - 1); }     // legacy nearest: src = floor(dst * in / out)
+            const unsigned off = ok ? (unsigned)(((unsigned)(iy * SW + ix) * (unsigned)Cs + (unsigned)(c0 + j * 8)) * sizeof(T)) : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(in_lds + d * 1024), 16, (int)off, 0, 0, 0);
         }
         for (int st = 0; st < p.nstages; ++st) {
@@ -938,14 +943,19 @@ IE_EXPORT int ie_mconv_nhwc(ie_mconv_desc* d, const void* const* srcs, const int
         for (int s = 0; s < d->nsrc; ++s)
             if (!srcs[s]) IE_FAIL(IE_ERR_INVALID, "ie_mconv_nhwc: source %d is null", s);
         d->Ho = d->H; d->Wo = d->W;
-        return ie_sconv3_launch(srcs, channels, d->nsrc, packed_w, bias, dst, d->in_dtype, d->N, d->H, d->W, d->Cout, d->act, d->slope, d->pad_mode, (hipStream_t)stream);
+        return ie_sconv3_launch(srcs, channels, d->nsrc, packed_w, bias, dst, d->in_dtype, d->N, d->H, d->W, d->Cout, d->act, d->slope, d->pad_mode,
+                                d->src_h, d->src_w, (hipStream_t)stream);
     }
     MConvParams p;
     memset(&p, 0, sizeof(p));
+    bool any_up = false;
     for (int s = 0; s < d->nsrc; ++s) {
         if (!srcs[s]) IE_FAIL(IE_ERR_INVALID, "ie_mconv_nhwc: source %d is null", s);
         p.src[s] = srcs[s]; p.cs[s] = channels[s];
+        p.sh[s] = d->src_h[s] > 0 ? d->src_h[s] : d->H; p.sw[s] = d->src_w[s] > 0 ? d->src_w[s] : d->W;
+        any_up = any_up || p.sh[s] != d->H || p.sw[s] != d->W;
     }
+    if (any_up && pl.thin) IE_FAIL(IE_ERR_UNSUPPORTED, "ie_mconv_nhwc: an up-sampled source cannot be the 8-channel image source");
 #ifdef IE_MSTAMP
     p.stamps = g_mconv_stamps;
 #endif
@@ -980,7 +990,8 @@ IE_EXPORT int ie_mconv_nhwc(ie_mconv_desc* d, const void* const* srcs, const int
     void (*fn)(MConvParams) = nullptr;
     const bool h = d->in_dtype == IE_F16;
     const bool k3 = d->kh == 3 && d->kw == 3;
-    static const int use_v1 = getenv("IE_MCONV_V1") ? atoi(getenv("IE_MCONV_V1")) : 0;     // A/B switch: single-buffered LDS-weights kernel
+    static const int use_v1_env = getenv("IE_MCONV_V1") ? atoi(getenv("IE_MCONV_V1")) : 0;     // A/B switch: single-buffered LDS-weights kernel
+    const int use_v1 = use_v1_env || any_up;      // nearest-up-sampled sources: the strip kernel (above) or this one fold them into their addressing
     size_t lds_bytes = lds;
     int slot;
     int th3 = TH, wgs_per_cu = 2;

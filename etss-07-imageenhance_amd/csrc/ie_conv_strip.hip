@@ -26,6 +26,7 @@ template <int NCH> struct SGeom { static constexpr int NR = NCH == 4 ? 3 : 4, PF
 struct SConvParams {
     const void* src[2];      // the one or two source tensors (virtual concat)
     int tps[2];              // their pixel strides in bytes
+    int th[2], tw[2];        // their stored sizes: (H, W), or smaller = read through a nearest-neighbour up-sampling to (H, W)
     int tsel[4], coff[4];    // K chunk c: which tensor, and the chunk's byte offset inside a pixel
     const void* wpk;         // ie_mconv_pack_weights image: [chunk][tap][16 NCF rows][32 k], 16-byte pieces swizzled by (row >> 1) & 3
     const float* bias;       // [Cout] or null
@@ -81,7 +82,7 @@ __device__ __forceinline__ void sconv3_body(const SConvParams& p) {
     auto mk = [&](const void* base, size_t bytes) __attribute__((always_inline)) {
         return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
     };
-    const size_t fb0 = (size_t)H * W * p.tps[0], fb1 = (size_t)H * W * p.tps[1];
+    const size_t fb0 = (size_t)p.th[0] * p.tw[0] * p.tps[0], fb1 = (size_t)p.th[1] * p.tw[1] * p.tps[1];
     const auto rs0 = mk((const char*)p.src[0] + (size_t)n * fb0, fb0);
     const auto rs1 = mk((const char*)p.src[1] + (size_t)n * fb1, fb1);
     const size_t fbo = (size_t)H * W * OPB;
@@ -103,19 +104,26 @@ __device__ __forceinline__ void sconv3_body(const SConvParams& p) {
 
     // ---- DMA geometry: piece m = 16 pixels x 64 B of one chunk; 16-byte position (lane & 3) of ring pixel q holds channel piece
     //      (lane & 3) ^ ((q >> 1) & 3), so the B-operand reads are bank-conflict free at every tap offset ------------------------
-    int px_q[PPW];          // ring pixel of this lane in piece j
+    // F.interpolate(size=(H, W)) in front of the conv, folded into the addressing: source column = min(floor(x * in / out), in - 1), per tensor
+    const float fx0 = (float)p.tw[0] / (float)W, fx1 = (float)p.tw[1] / (float)W, fy0 = (float)p.th[0] / (float)H, fy1 = (float)p.th[1] / (float)H;
+    auto map_x = [&](int x, int t) __attribute__((always_inline)) {
+        return x < 0 ? -1 : (p.tw[t] == W ? x : min((int)floorf(x * (t ? fx1 : fx0)), p.tw[t] - 1));
+    };
+    int px_q[2][PPW];       // source pixel of this lane in piece j, per tensor (-1: outside the image)
     int px_s[PPW];          // source 16-byte piece
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
         const int q = (PPW * wave + j) * 16 + (lane >> 2);
-        px_q[j] = (x0 + q < W) ? x0 + q : (p.replicate ? W - 1 : -1);
+        const int x = (x0 + q < W) ? x0 + q : (p.replicate ? W - 1 : -1);
+        px_q[0][j] = map_x(x, 0); px_q[1][j] = map_x(x, 1);
         px_s[j] = ((lane & 3) ^ ((q >> 1) & 3)) * 16;
     }
-    int halo_x;
+    int halo_x[2];
     {
         int x = (lane < 4) ? (x0 - 1) : (x0 + TW);
         if (p.replicate) x = min(max(x, 0), W - 1);
-        halo_x = (lane < 8 && x >= 0 && x < W) ? x : -1;
+        x = (lane < 8 && x >= 0 && x < W) ? x : -1;
+        halo_x[0] = map_x(x, 0); halo_x[1] = map_x(x, 1);
     }
     auto issue_row = [&](int it) __attribute__((always_inline)) {
         int yi = ys - 1 + it;
@@ -125,18 +133,20 @@ __device__ __forceinline__ void sconv3_body(const SConvParams& p) {
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const bool t0 = p.tsel[c] == 0;
-            const unsigned ps = (unsigned)p.tps[t0 ? 0 : 1], co = (unsigned)p.coff[c];
-            const unsigned row_b = (unsigned)yi * (unsigned)W * ps;
+            const int ti = t0 ? 0 : 1;
+            const unsigned ps = (unsigned)p.tps[ti], co = (unsigned)p.coff[c];
+            const int ysrc = p.th[ti] == H ? yi : min((int)floorf(yi * (ti ? fy1 : fy0)), p.th[ti] - 1);
+            const unsigned row_b = (unsigned)ysrc * (unsigned)p.tw[ti] * ps;
 #pragma unroll
             for (int j = 0; j < PPW; ++j) {
                 if (PPW * wave + j >= 8) break;
-                const unsigned off = (row_ok && px_q[j] >= 0) ? row_b + (unsigned)px_q[j] * ps + co + (unsigned)px_s[j] : OOB;
+                const unsigned off = (row_ok && px_q[ti][j] >= 0) ? row_b + (unsigned)px_q[ti][j] * ps + co + (unsigned)px_s[j] : OOB;
                 char* dstb = slot + c * SRC_ROW_B + (PPW * wave + j) * 1024;
                 if (t0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (__attribute__((address_space(3))) void*)dstb, 16, (int)off, 0, 0, 0);
                 else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (__attribute__((address_space(3))) void*)dstb, 16, (int)off, 0, 0, 0);
             }
             if (wave == NW - 1) {          // halo columns: (128 >> 1) & 3 == (129 >> 1) & 3 == 0, position == channel piece
-                const unsigned off = (row_ok && halo_x >= 0) ? row_b + (unsigned)halo_x * ps + co + (unsigned)((lane & 3) * 16) : OOB;
+                const unsigned off = (row_ok && halo_x[ti] >= 0) ? row_b + (unsigned)halo_x[ti] * ps + co + (unsigned)((lane & 3) * 16) : OOB;
                 char* dstb = slot + c * SRC_ROW_B + TW * PXB;
                 if (lane < 8) {
                     if (t0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, (__attribute__((address_space(3))) void*)dstb, 16, (int)off, 0, 0, 0);
@@ -309,12 +319,14 @@ bool ie_sconv3_applicable(int nsrc, const int* cs, int Cout, int kh, int kw, int
 }
 
 int ie_sconv3_launch(const void* const* srcs, const int* cs, int nsrc, const void* wpk, const float* bias, void* dst, int dtype, int N, int H, int W,
-                     int Cout, int act, float slope, int pad_mode, hipStream_t st) {
+                     int Cout, int act, float slope, int pad_mode, const int* src_h, const int* src_w, hipStream_t st) {
     SConvParams p;
     memset(&p, 0, sizeof(p));
     int nch = 0;
     p.src[0] = srcs[0]; p.src[1] = srcs[nsrc - 1];
     p.tps[0] = cs[0] * 2; p.tps[1] = cs[nsrc - 1] * 2;
+    p.th[0] = (src_h && src_h[0] > 0) ? src_h[0] : H; p.tw[0] = (src_w && src_w[0] > 0) ? src_w[0] : W;
+    p.th[1] = (src_h && src_h[nsrc - 1] > 0) ? src_h[nsrc - 1] : H; p.tw[1] = (src_w && src_w[nsrc - 1] > 0) ? src_w[nsrc - 1] : W;
     for (int s = 0; s < nsrc; ++s)
         for (int c0 = 0; c0 < cs[s]; c0 += 32) { p.tsel[nch] = s; p.coff[nch] = c0 * 2; ++nch; }
     p.wpk = wpk; p.bias = bias; p.dst = dst; p.N = N; p.H = H; p.W = W; p.slope = slope; p.replicate = pad_mode == IE_PAD_REPLICATE;

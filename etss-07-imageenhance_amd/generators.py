@@ -1303,11 +1303,16 @@ class RetinexNet(_GraphModel):
         out1 = c(out0, "net2_conv1_1", stride=2, pad_mode=R, act="relu")
         out2 = c(out1, "net2_conv1_2", stride=2, pad_mode=R, act="relu")
         out3 = c(out2, "net2_conv1_3", stride=2, pad_mode=R, act="relu")
-        sz = lambda t: (t.shape[2], t.shape[3])
-        d1 = c([ops.resize(out3, sz(out2), "nearest"), out2], "net2_deconv1_1", pad_mode=R, act="relu")
-        d2 = c([ops.resize(d1, sz(out1), "nearest"), out1], "net2_deconv1_2", pad_mode=R, act="relu")
-        d3 = c([ops.resize(d2, sz(out0), "nearest"), out0], "net2_deconv1_3", pad_mode=R, act="relu")
-        fus = c([ops.resize(d1, sz(rl), "nearest"), ops.resize(d2, sz(rl), "nearest"), d3], "net2_fusion",
+        # F.interpolate(x, size=...) (nearest) in front of a conv: its own pass on the fp32 path; on the 16-bit path the conv kernels read
+        # the small tensor through the up-sampling (ops.mconv2d: a source smaller than the largest one)
+        if self.compute_dtype == "f32":
+            rs = lambda t, ref: ops.resize(t, (ref.shape[2], ref.shape[3]), "nearest")
+        else:
+            rs = lambda t, ref: t
+        d1 = c([rs(out3, out2), out2], "net2_deconv1_1", pad_mode=R, act="relu")
+        d2 = c([rs(d1, out1), out1], "net2_deconv1_2", pad_mode=R, act="relu")
+        d3 = c([rs(d2, out0), out0], "net2_deconv1_3", pad_mode=R, act="relu")
+        fus = c([rs(d1, rl), rs(d2, rl), d3], "net2_fusion",
                 pad=1, pad_mode=R)                                                 # 1x1 with replicate padding 1: (H+2, W+2)
         return c(fus, "net2_output", pad=0, out_f32=True)                          # 3x3 valid -> (H, W), fp32
 

@@ -752,12 +752,19 @@ def mconv2d(srcs, mw: MConvWeights, stride=1, pad=1, pad_mode="zeros", act="none
     cs = [int(s.shape[1]) for s in srcs]
     if cs != mw.split:
         raise capi.IEError(f"mconv2d: sources carry channels {cs}, weights were packed for {mw.split}")
-    n, _, h, w = srcs[0].shape
+    n = srcs[0].shape[0]
+    # sources smaller than the largest one are read through a nearest-neighbour up-sampling to its size, folded into the kernel's
+    # addressing (F.interpolate(x, size=...) in front of the conv: retinexnet/model.py:79-86)
+    h, w = max(int(s.shape[2]) for s in srcs), max(int(s.shape[3]) for s in srcs)
     odt = torch.float32 if out_f32 else mw.dtype
     sh = int(getattr(mw, "shuffle", 0))
     d = capi.MConvDesc(n, h, w, len(srcs), mw.cout, mw.kh, mw.kw, stride, pad, capi.PAD[pad_mode], capi.ACT[act], slope,
                        0 if clamp is None else 1, 0.0 if clamp is None else clamp[0], 0.0 if clamp is None else clamp[1],
-                       IE_DT[mw.dtype], IE_DT[odt], 0, 0, sh)
+                       IE_DT[mw.dtype], IE_DT[odt], 0, 0)
+    d.pixel_shuffle = sh
+    for i, s_ in enumerate(srcs):
+        if (int(s_.shape[2]), int(s_.shape[3])) != (h, w):
+            d.src_h[i], d.src_w[i] = int(s_.shape[2]), int(s_.shape[3])
     ho = (h + 2 * pad - mw.kh) // stride + 1
     wo = (w + 2 * pad - mw.kw) // stride + 1
     if sh:                                # conv + PixelShuffle(sh) in one kernel: (N, Cout / 4, 2 Ho, 2 Wo)

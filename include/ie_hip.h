@@ -155,6 +155,9 @@ typedef struct ie_mconv_desc {
     int in_dtype;          /* IE_F16 | IE_BF16 */
     int out_dtype;         /* in_dtype | IE_F32 */
     int Ho, Wo;            /* out */
+    int src_h[IE_CONV_MAX_SRC], src_w[IE_CONV_MAX_SRC];   /* stored size of source s, or 0 = (H, W).  A smaller source is read through a
+                              nearest-neighbour up-sampling to (H, W) -- F.interpolate(x, size=(H, W)) in front of the conv (retinexnet/model.py:79-86) --
+                              folded into the kernel's addressing: src = min(floor(dst * in / out), in - 1) */
     int pixel_shuffle;     /* 0, or 2: fused nn.PixelShuffle(2) of the Upsampler (edsr.py:88-123) -- the weights must have been packed with
                               their output rows in [i][j][c] order (row i*2C + j*C + c <- checkpoint row 4c + 2i + j); dst is (N, 2Ho', 2Wo', Cout/4) */
 } ie_mconv_desc;

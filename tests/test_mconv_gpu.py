@@ -177,3 +177,29 @@ def test_fused_pixel_shuffle(ci, c, shape, dt):
         return
     with pytest.raises(capi.IEError):                                   # 1x1 convs do not take the fused form
         ops.mconv2d(x.cuda().contiguous(memory_format=CL), ops.MConvWeights(wt[:, :, :1, :1].contiguous(), b, [ci], tdt, "cuda", shuffle=2), pad=0)
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("case", [
+    dict(cs=[64, 64], co=64, k=3, p=1, mode="replicate", act="relu", hw=(36, 150), small=[(18, 75), None]),     # retinexnet/model.py:79-80 (strip kernel)
+    dict(cs=[32, 32], co=32, k=3, p=1, mode="zeros", act="none", hw=(21, 131), small=[None, (7, 44)]),           # odd ratios
+    dict(cs=[64, 64], co=64, k=3, p=1, mode="replicate", act="relu", hw=(20, 40), small=[(10, 20), None]),       # narrow image: tiled kernel
+    dict(cs=[64, 64, 64], co=64, k=1, p=1, mode="replicate", act="none", hw=(24, 40), small=[(6, 10), (12, 20), None]),   # model.py:84-87 fusion
+], ids=["strip-c128", "strip-c64-odd", "tiled-3x3", "fusion-1x1"])
+def test_nearest_upsampled_sources(case, dt):
+    """A source smaller than the conv's image is read through F.interpolate(x, size=...) (nearest) folded into the kernel's addressing."""
+    tdt = ops.TORCH_DT[dt]
+    n, (h, w) = 2, case["hw"]
+    g = torch.Generator().manual_seed(23)
+    xs = [torch.randn(n, c, *(sm if sm else (h, w)), generator=g).to(tdt) for c, sm in zip(case["cs"], case["small"])]
+    cin, k, p = sum(case["cs"]), case["k"], case["p"]
+    wt = (torch.randn(case["co"], cin, k, k, generator=g) / (cin * k * k) ** 0.5).to(tdt).float()
+    b = torch.randn(case["co"], generator=g)
+    xcat = torch.cat([F.interpolate(x.float(), size=(h, w)) if sm else x.float() for x, sm in zip(xs, case["small"])], 1)
+    xp = F.pad(xcat, (p,) * 4, mode="replicate") if case["mode"] == "replicate" else xcat
+    ref = F.conv2d(xp, wt, b, padding=0 if case["mode"] == "replicate" else p)
+    ref = F.relu(ref) if case["act"] == "relu" else ref
+    mw = ops.MConvWeights(wt, b, case["cs"], tdt, "cuda")
+    out = ops.mconv2d([x.cuda().contiguous(memory_format=CL) for x in xs], mw, pad=p, pad_mode=case["mode"], act=case["act"])
+    assert tuple(out.shape) == tuple(ref.shape)
+    assert rel_err(out.float().cpu(), ref) <= (1.5e-3 if dt == "f16" else 1e-2)
