@@ -173,11 +173,13 @@ __device__ __forceinline__ void sconv3_body(const SConvParams& p) {
 
     // ---- epilogue -----------------------------------------------------------------------------------------------------------------
     auto swz = [&](int q) __attribute__((always_inline)) { return NPC == 8 ? (q & 7) : ((q >> 1) & 3); };
-    int park_off[4];            // this lane's 8 bytes (couts 16cf + 4kq ..) of tile nt inside a parked row
+    // lanes l / l+16 exchange halves (v_permlane16_swap), so a lane parks 16 bytes (8 output channels) of ONE pixel: even kq -> tile 2j,
+    // odd kq -> tile 2j+1; ds_write_b128 serves 8 lanes per LDS cycle = 8 consecutive pixels x 16 bytes, every bank once
+    int park_off[2];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const int q = 64 * ph + 16 * nt + p16, c = 2 * cf + (kq >> 1);
-        park_off[nt] = q * OPB + ((c ^ swz(q)) << 4) + (kq & 1) * 8;
+    for (int j = 0; j < 2; ++j) {
+        const int q = 64 * ph + 16 * (2 * j + (kq & 1)) + p16, c = 2 * cf + (kq >> 1);
+        park_off[j] = q * OPB + ((c ^ swz(q)) << 4);
     }
     unsigned st_col[SPW];       // store instruction j of this wave: PPI pixels x OPB bytes, lane = (pixel, 16-byte piece)
     int st_lds[SPW];
@@ -205,8 +207,20 @@ __device__ __forceinline__ void sconv3_body(const SConvParams& p) {
                 pk[nt][1] = ie_pack2<T>(acc[nt][2], acc[nt][3]);
             }
         }
+#ifdef IE_PARK_B64       // A/B: 8-byte pieces straight from the accumulators (two-way bank conflicts between pixels q and q+8)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) *(ie_u32x2*)(oslot + park_off[nt]) = pk[nt];
+        for (int nt = 0; nt < 4; ++nt) {
+            const int q = 64 * ph + 16 * nt + p16, c = 2 * cf + (kq >> 1);
+            *(ie_u32x2*)(oslot + q * OPB + ((c ^ swz(q)) << 4) + (kq & 1) * 8) = pk[nt];
+        }
+#else
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const auto sx = __builtin_amdgcn_permlane16_swap(pk[2 * j][0], pk[2 * j + 1][0], false, false);
+            const auto sy = __builtin_amdgcn_permlane16_swap(pk[2 * j][1], pk[2 * j + 1][1], false, false);
+            *(ie_u32x4*)(oslot + park_off[j]) = ie_u32x4{sx[0], sy[0], sx[1], sy[1]};
+        }
+#endif
     };
 
     // ---- one input row into the three live accumulator sets (output rows yi+1, yi, yi-1) -------------------------------------------

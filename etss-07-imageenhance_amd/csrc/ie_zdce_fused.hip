@@ -57,6 +57,9 @@ enum { K12 = 12, K45 = 45, K67 = 67, K345 = 345 };
                           // stage B's DMA.  Half the vector instructions, but measured 9.6 against 7.6 ms: three waves then carry a twice as long
                           // serial chain (transcendental latency) while five wait at the barrier -- the curve wants MORE lanes, not fewer.
 #endif
+#ifndef IE_EMIT_B128
+#define IE_EMIT_B128 1    // hand-off rows leave the accumulators as 16-byte pieces (lanes l / l+16 exchange halves, ds_write_b128: 8 pixels x
+#endif                    // 16 bytes per lane group = every bank once) instead of 8-byte pieces (ds_write_b64: pixels q and q+8 share a bank pair)
 #ifndef IE_K345_OUT
 #define IE_K345_OUT 0     // 1: K345 parks its x5 rows in LDS and stores whole lines like K12 (measured slower: 7.42 vs 7.0 ms -- the kernel is
 #endif                    // MFMA-dense and its writes are half of K12's, so the extra LDS traffic costs more than the write path gives back)
@@ -426,6 +429,27 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     auto a_emit_to = [&](auto tg, const ie_f32x4 (&acc)[4], char* slot, int ra, bool relu = true) __attribute__((always_inline)) {
         using TE = typename decltype(tg)::type;
         const bool row_in = (ra >= 0) && (ra < H);
+        if constexpr (IE_EMIT_B128) {
+#pragma unroll
+            for (int nt = 0; nt < 4; nt += 2) {
+                ie_u32x2 pk[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    pk[h][0] = relu ? ie_pack2_relu<TE>(acc[nt + h][0], acc[nt + h][1]) : ie_pack2<TE>(acc[nt + h][0], acc[nt + h][1]);
+                    pk[h][1] = relu ? ie_pack2_relu<TE>(acc[nt + h][2], acc[nt + h][3]) : ie_pack2<TE>(acc[nt + h][2], acc[nt + h][3]);
+                }
+                // even-kq lanes end with couts 4kq .. 4kq+7 of tile nt, odd-kq lanes with couts 4(kq-1) .. +7 of tile nt+1
+                const auto sx = __builtin_amdgcn_permlane16_swap(pk[0][0], pk[1][0], false, false);
+                const auto sy = __builtin_amdgcn_permlane16_swap(pk[0][1], pk[1][1], false, false);
+                const int q = 64 * ph + 16 * (nt + (kq & 1)) + p16;
+                const int x = xc0 + q;
+                const bool in_img = row_in && x >= 0 && x < W;
+                const ie_u32x4 v = {in_img ? sx[0] : 0u, in_img ? sy[0] : 0u, in_img ? sx[1] : 0u, in_img ? sy[1] : 0u};
+                const int c = 2 * ch + (kq >> 1);      // 16-byte chunk holding couts 16ch + 8 (kq>>1) .. +7
+                *(ie_u32x4*)(slot + q * PXB + ((c ^ ((q >> 1) & 3)) << 4)) = v;
+            }
+            return;
+        }
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             const int q = 64 * ph + 16 * nt + p16;
@@ -446,6 +470,8 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     unsigned st_col[2];     // byte offset of this lane's 16-byte store of piece 2 sw + j inside an output row, or OOB
     int st_lds[2];          // ... and where that chunk sits in the parked row
     int em_off[4];          // hand-off write of tile nt: byte offset inside the ring slot
+    int em16_off[2];        // ... of tile pair j as 16-byte pieces (after the lane exchange: even kq -> tile 2j, odd kq -> tile 2j+1)
+    unsigned em16_in = 0;   // bit j: this lane's pixel of pair j lies inside the image
     unsigned em_in = 0;     // bit nt: tile nt's column lies inside the image
     if constexpr (KIND == K12 || KIND == K345) {
 #pragma unroll
@@ -466,10 +492,24 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
             em_off[nt] = q * PXB + ((c ^ ((q >> 1) & 3)) << 4) + (kq & 1) * 8;
             em_in |= (x >= 0 && x < W) ? (1u << nt) : 0u;
         }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int q = 64 * ph + 16 * (2 * j + (kq & 1)) + p16, x = xc0 + q, c = 2 * ch + (kq >> 1);
+            em16_off[j] = q * PXB + ((c ^ ((q >> 1) & 3)) << 4);
+            em16_in |= (x >= 0 && x < W) ? (1u << j) : 0u;
+        }
     }
 #define IE_PACK_TILE(TT, A, RELU)                                                                                          \
     ie_u32x2{(RELU) ? ie_pack2_relu<TT>((A)[0], (A)[1]) : ie_pack2<TT>((A)[0], (A)[1]),                                    \
              (RELU) ? ie_pack2_relu<TT>((A)[2], (A)[3]) : ie_pack2<TT>((A)[2], (A)[3])}
+// tile pair J of a packed row into an LDS row image as 16-byte pieces (conflict-free ds_write_b128); ZERO: blank pixels outside the image
+#define IE_PARK_PAIR(SLOT, P0, P1, J, KEEP)                                                                               \
+    do {                                                                                                                  \
+        auto sx_ = __builtin_amdgcn_permlane16_swap((P0)[0], (P1)[0], false, false);                                      \
+        auto sy_ = __builtin_amdgcn_permlane16_swap((P0)[1], (P1)[1], false, false);                                      \
+        const bool k_ = (KEEP);                                                                                           \
+        *(ie_u32x4*)((SLOT) + em16_off[J]) = ie_u32x4{k_ ? sx_[0] : 0u, k_ ? sy_[0] : 0u, k_ ? sx_[1] : 0u, k_ ? sy_[1] : 0u}; \
+    } while (0)
 #define IE_STORE_PAIR(RS, P0, P1, J, ROWB, RMASK)                                                                          \
     do {                                                                                                                  \
         auto sx_ = __builtin_amdgcn_permlane16_swap((P0)[0], (P1)[0], false, false);                                      \
@@ -865,10 +905,11 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
         ln[0] = *(const ie_u32x4*)(islot + st_lds[0]);
         ln[1] = *(const ie_u32x4*)(islot + st_lds[1]);
         auto fill = [&](int s) __attribute__((always_inline)) {
-            if (s == 0) { pk[1] = IE_PACK_TILE(TO, accN[1], true); *(ie_u32x2*)(oslot + em_off[0]) = pk[0]; }
-            if (s == 1) *(ie_u32x2*)(oslot + em_off[1]) = pk[1];
-            if (s == 3) { pk[2] = IE_PACK_TILE(TO, accN[2], true); *(ie_u32x2*)(oslot + em_off[2]) = pk[2]; }
-            if (s == 6) { pk[3] = IE_PACK_TILE(TO, accN[3], true); *(ie_u32x2*)(oslot + em_off[3]) = pk[3]; }
+            if (s == 0) pk[1] = IE_PACK_TILE(TO, accN[1], true);
+            if (s == 1) IE_PARK_PAIR(oslot, pk[0], pk[1], 0, true);
+            if (s == 3) pk[2] = IE_PACK_TILE(TO, accN[2], true);
+            if (s == 6) pk[3] = IE_PACK_TILE(TO, accN[3], true);
+            if (s == 7) IE_PARK_PAIR(oslot, pk[2], pk[3], 1, true);
             if constexpr (!(IE_EXP & 16)) {
                 if (s == 10) __builtin_amdgcn_raw_buffer_store_b128(ln[0], rsDb, (int)((row_b + st_col[0]) | rmask), 0, 0);
                 if (s == 12) __builtin_amdgcn_raw_buffer_store_b128(ln[1], rsDb, (int)((row_b + st_col[1]) | rmask), 0, 0);
@@ -903,7 +944,7 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
         const int ra = ys - 3 - LAG_A - 1 + t;                      // x1 row computed at step t-1
         const bool row_in = (ra >= 0) && (ra < H);
         char* eslot = smem + OFF_RA + (t % NRH) * ROW_B;
-        ie_u32x2 pk[4], ek = {0u, 0u};
+        ie_u32x2 pk[4], ek = {0u, 0u}, ek1 = {0u, 0u};
         constexpr int PARTS = (ie_elem<TH>::dtype == IE_BF16) ? 2 : 1;
         ie_u32x4 c0[PARTS][4], c1[PARTS][4];
         const int pxo = (64 * ph + p16 + 2 * (kq & 1)) * 8;
@@ -922,23 +963,21 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
         ln[0] = *(const ie_u32x4*)(islot + st_lds[0]);
         ln[1] = *(const ie_u32x4*)(islot + st_lds[1]);
         auto fill = [&](int s) __attribute__((always_inline)) {
-            if (s == 0) { pk[1] = IE_PACK_TILE(TO, pN[1], false); *(ie_u32x2*)(oslot + em_off[0]) = pk[0]; }
-            if (s == 1) *(ie_u32x2*)(oslot + em_off[1]) = pk[1];
-            if (s == 3) { pk[2] = IE_PACK_TILE(TO, pN[2], false); *(ie_u32x2*)(oslot + em_off[2]) = pk[2]; }
-            if (s == 6) { pk[3] = IE_PACK_TILE(TO, pN[3], false); *(ie_u32x2*)(oslot + em_off[3]) = pk[3]; }
+            if (s == 0) pk[1] = IE_PACK_TILE(TO, pN[1], false);
+            if (s == 1) IE_PARK_PAIR(oslot, pk[0], pk[1], 0, true);
+            if (s == 3) pk[2] = IE_PACK_TILE(TO, pN[2], false);
+            if (s == 5) pk[3] = IE_PACK_TILE(TO, pN[3], false);
+            if (s == 6) IE_PARK_PAIR(oslot, pk[2], pk[3], 1, true);
             if constexpr (!(IE_EXP & 16)) {
                 if (s == 7) __builtin_amdgcn_raw_buffer_store_b128(ln[0], rsDa, (int)((row_b + st_col[0]) | rmask), 0, 0);
                 if (s == 8) __builtin_amdgcn_raw_buffer_store_b128(ln[1], rsDa, (int)((row_b + st_col[1]) | rmask), 0, 0);
             }
             if constexpr (!(IE_EXP & 4)) {
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    if (s == 9 + 3 * nt) ek = IE_PACK_TILE(TH, eN[nt], true);
-                    if (s == 10 + 3 * nt) {
-                        const bool in_img = row_in && ((em_in >> nt) & 1u);
-                        ek[0] = in_img ? ek[0] : 0u; ek[1] = in_img ? ek[1] : 0u;
-                        *(ie_u32x2*)(eslot + em_off[nt]) = ek;
-                    }
+                for (int j = 0; j < 2; ++j) {
+                    if (s == 9 + 5 * j) ek = IE_PACK_TILE(TH, eN[2 * j], true);
+                    if (s == 10 + 5 * j) ek1 = IE_PACK_TILE(TH, eN[2 * j + 1], true);
+                    if (s == 11 + 5 * j) IE_PARK_PAIR(eslot, ek, ek1, j, row_in && ((em16_in >> j) & 1u));
                 }
             }
             if (s == 21) issue(t + PF);
@@ -1002,6 +1041,7 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
 #undef IE_B_STORE
 #undef IE_PACK_TILE
 #undef IE_STORE_PAIR
+#undef IE_PARK_PAIR
 #undef IE_SB
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef IE_STAMP
