@@ -30,6 +30,7 @@ typedef __attribute__((ext_vector_type(16))) float ie_f32x16;
 typedef __attribute__((ext_vector_type(4))) float ie_f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int ie_u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int ie_u32x2;
+typedef __attribute__((ext_vector_type(8))) unsigned short ie_u16x8;
 
 #ifdef __HIPCC__
 // Element-type traits for the 16-bit MFMA paths.

@@ -31,4 +31,5 @@ int ie_det_workspace(size_t bytes, void** out);
 bool ie_sconv3_applicable(int nsrc, const int* cs, int Cout, int kh, int kw, int stride, int pad, int pad_mode, int act, bool residual, bool clamp,
                           bool out_f32, int W);
 int ie_sconv3_launch(const void* const* srcs, const int* cs, int nsrc, const void* wpk, const float* bias, void* dst, int dtype, int N, int H, int W,
-                     int Cout, int act, float slope, int pad_mode, const int* src_h, const int* src_w, hipStream_t st);
+                     int Cout, int act, float slope, int pad_mode, const int* src_h, const int* src_w, void* pool_dst, hipStream_t st);
+// pool_dst: null, or the 2x2 max-pooled copy of dst written by the same launch (ReLU layers only)

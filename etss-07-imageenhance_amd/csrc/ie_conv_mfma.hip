@@ -927,8 +927,28 @@ IE_EXPORT int ie_mconv_pack_weights(const float* w_oihw_host, const int* channel
     return IE_OK;
 }
 
+static int mconv_impl(ie_mconv_desc* d, const void* const* srcs, const int* channels, const void* packed_w, const float* bias, const void* residual,
+                      void* dst, void* pool_dst, bool* pooled, void* stream);
+
 IE_EXPORT int ie_mconv_nhwc(ie_mconv_desc* d, const void* const* srcs, const int* channels, const void* packed_w, const float* bias,
                             const void* residual, void* dst, void* stream) {
+    return mconv_impl(d, srcs, channels, packed_w, bias, residual, dst, nullptr, nullptr, stream);
+}
+
+// Conv (+ bias + ReLU) and the nn.MaxPool2d(2) behind it (unet.py:70-72 `Down` = MaxPool2d(2) -> DoubleConv): the strip kernel writes the pooled
+// copy from the rows it has parked in LDS; every other shape runs the conv and then the streaming pool kernel.
+IE_EXPORT int ie_mconv_pool_nhwc(ie_mconv_desc* d, const void* const* srcs, const int* channels, const void* packed_w, const float* bias, void* dst,
+                                 void* pool_dst, void* stream) {
+    if (!pool_dst) IE_FAIL(IE_ERR_INVALID, "ie_mconv_pool_nhwc: null pointer");
+    if (d && (d->pixel_shuffle || d->out_dtype != d->in_dtype || d->stride != 1)) IE_FAIL(IE_ERR_UNSUPPORTED, "ie_mconv_pool_nhwc: stride 1, same-type output, no pixel shuffle");
+    bool pooled = false;
+    int rc = mconv_impl(d, srcs, channels, packed_w, bias, nullptr, dst, pool_dst, &pooled, stream);
+    if (rc != IE_OK || pooled) return rc;
+    return ie_maxpool2x2_nhwc(dst, pool_dst, d->in_dtype, d->N, d->Ho, d->Wo, d->Cout, stream);
+}
+
+static int mconv_impl(ie_mconv_desc* d, const void* const* srcs, const int* channels, const void* packed_w, const float* bias, const void* residual,
+                      void* dst, void* pool_dst, bool* pooled, void* stream) {
     if (!d || !srcs || !channels || !packed_w || !dst) IE_FAIL(IE_ERR_INVALID, "ie_mconv_nhwc: null pointer");
     if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->pad < 0 || (d->stride != 1 && d->stride != 2))
         IE_FAIL(IE_ERR_INVALID, "ie_mconv_nhwc: bad shape (stride must be 1 or 2)");
@@ -943,8 +963,11 @@ IE_EXPORT int ie_mconv_nhwc(ie_mconv_desc* d, const void* const* srcs, const int
         for (int s = 0; s < d->nsrc; ++s)
             if (!srcs[s]) IE_FAIL(IE_ERR_INVALID, "ie_mconv_nhwc: source %d is null", s);
         d->Ho = d->H; d->Wo = d->W;
+        static const int fuse = getenv("IE_SCONV_POOL") ? atoi(getenv("IE_SCONV_POOL")) : 1;      // A/B: 0 = the separate pool kernel
+        void* pd = (pool_dst && fuse && d->act == IE_ACT_RELU && d->H >= 2 && d->W >= 2) ? pool_dst : nullptr;
+        if (pooled) *pooled = pd != nullptr;
         return ie_sconv3_launch(srcs, channels, d->nsrc, packed_w, bias, dst, d->in_dtype, d->N, d->H, d->W, d->Cout, d->act, d->slope, d->pad_mode,
-                                d->src_h, d->src_w, (hipStream_t)stream);
+                                d->src_h, d->src_w, pd, (hipStream_t)stream);
     }
     MConvParams p;
     memset(&p, 0, sizeof(p));

@@ -31,6 +31,7 @@ struct SConvParams {
     const void* wpk;         // ie_mconv_pack_weights image: [chunk][tap][16 NCF rows][32 k], 16-byte pieces swizzled by (row >> 1) & 3
     const float* bias;       // [Cout] or null
     void* dst;               // NHWC T, Cout channels
+    void* pool;              // POOL kernels: the 2x2 max-pooled copy of dst, NHWC T [N, H/2, W/2, Cout] (nn.MaxPool2d(2) behind the conv: unet.py:70-72)
     int N, H, W, rows_per_block, strips, chunks;
     int replicate;           // padding_mode="replicate": out-of-image rows / columns are clamped to the edge instead of reading zeros
     float slope;
@@ -46,7 +47,7 @@ __device__ __forceinline__ void wait_vm(int n) {
 #undef IE_W
 }
 
-template <typename T, int NCH, int NCF, int ACT>
+template <typename T, int NCH, int NCF, int ACT, bool POOL = false>
 __device__ __forceinline__ void sconv3_body(const SConvParams& p) {
     using frag = ie_u32x4;
     constexpr int NR = SGeom<NCH>::NR, PF = SGeom<NCH>::PF;
@@ -62,6 +63,11 @@ __device__ __forceinline__ void sconv3_body(const SConvParams& p) {
     constexpr int NPC = OPB / 16;                 // 16-byte pieces per pixel (4 or 8)
     constexpr int PPI = 64 / NPC;                 // pixels per store instruction (16 or 8)
     constexpr int SPW = (TW / PPI) / NW;          // store instructions per wave and row (2)
+    // POOL: a third parked row, so that rows 2k and 2k+1 are both in LDS when the later one leaves; every lane then owns one 16-byte
+    // piece of the 64 pooled pixels (NW x 64 lanes = 64 pixels x NPC pieces) and the pooled row leaves as whole lines too.  The
+    // activation is ReLU, so the packed 16-bit values order like unsigned integers.
+    static_assert(!POOL || ACT == IE_ACT_RELU, "the fused max-pool compares non-negative values as integers");
+    static_assert(NW * 64 == (TW / 2) * NPC, "one pooled piece per lane");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -87,6 +93,9 @@ __device__ __forceinline__ void sconv3_body(const SConvParams& p) {
     const auto rs1 = mk((const char*)p.src[1] + (size_t)n * fb1, fb1);
     const size_t fbo = (size_t)H * W * OPB;
     const auto rsd = mk((char*)p.dst + (size_t)n * fbo, fbo);
+    const int Hp = H >> 1, Wp = W >> 1;
+    const size_t fbp = (size_t)Hp * Wp * OPB;
+    const auto rsp = mk(POOL ? (char*)p.pool + (size_t)n * fbp : (char*)p.dst, POOL ? fbp : 0);
 
     // ---- weights of this wave's 16 output channels into registers ---------------------------------------------------------
     frag wA[NCH * 9];
@@ -189,6 +198,10 @@ __device__ __forceinline__ void sconv3_body(const SConvParams& p) {
         st_col[j] = (xo < W) ? (unsigned)(xo * OPB + c * 16) : OOB;
         st_lds[j] = q * OPB + ((c ^ swz(q)) << 4);
     }
+    // POOL: this lane's piece of the pooled row: pooled pixel xp (source pixels 2xp, 2xp+1 of the strip), 16-byte piece pc
+    const int pl_xp = tid / NPC, pl_c = tid % NPC;
+    const int pl_lds0 = (2 * pl_xp) * OPB + ((pl_c ^ swz(2 * pl_xp)) << 4), pl_lds1 = (2 * pl_xp + 1) * OPB + ((pl_c ^ swz(2 * pl_xp + 1)) << 4);
+    const unsigned pl_col = ((x0 >> 1) + pl_xp < Wp) ? (unsigned)(((x0 >> 1) + pl_xp) * OPB + pl_c * 16) : OOB;
     auto park = [&](const ie_f32x4 (&acc)[4], char* oslot) __attribute__((always_inline)) {
         ie_u32x2 pk[4];
 #pragma unroll
@@ -248,7 +261,7 @@ __device__ __forceinline__ void sconv3_body(const SConvParams& p) {
     };
     auto step = [&](int it, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4]) __attribute__((always_inline)) {
         // ops younger than row `it`'s DMA: the (PF-1) L loads of the rows behind it and the SPW (possibly out-of-range) stores every step issues
-        if (L) wait_vm(wait_n + SPW * (it < PF ? it : PF));
+        if (L) wait_vm(wait_n + (SPW + (POOL ? 1 : 0)) * (it < PF ? it : PF));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this wave's parked pieces of the previous step
         __builtin_amdgcn_s_barrier();
         issue_row(it + PF);
@@ -256,15 +269,30 @@ __device__ __forceinline__ void sconv3_body(const SConvParams& p) {
         const int yo = ys - 4 + it;
         const unsigned rmask = ((yo >= ys) && (yo < ye)) ? 0u : OOB;
         const unsigned row_b = rmask ? 0u : (unsigned)yo * (unsigned)W * OPB;
-        const char* islot = smem + OFF_OUT + ((it + 1) & 1) * OUT_ROW_B;
+        const char* islot = smem + OFF_OUT + (POOL ? (it + 2) % 3 : (it + 1) & 1) * OUT_ROW_B;
         ie_u32x4 ln[SPW];
 #pragma unroll
         for (int j = 0; j < SPW; ++j) ln[j] = *(const ie_u32x4*)(islot + st_lds[j]);
+        // POOL: rows yo-1 (parked two steps ago) and yo make pooled row (yo-1)/2 when yo is odd (ys is even)
+        ie_u16x8 pv = {0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned pmask = OOB, prow_b = 0u;
+        if constexpr (POOL) {
+            if ((yo & 1) && (yo - 1 >= ys) && (yo < ye)) {
+                const char* jslot = smem + OFF_OUT + ((it + 1) % 3) * OUT_ROW_B;
+                const ie_u16x8 v0 = *(const ie_u16x8*)(jslot + pl_lds0), v1 = *(const ie_u16x8*)(jslot + pl_lds1);
+                const ie_u16x8 v2 = *(const ie_u16x8*)(islot + pl_lds0), v3 = *(const ie_u16x8*)(islot + pl_lds1);
+                pv = __builtin_elementwise_max(__builtin_elementwise_max(v0, v1), __builtin_elementwise_max(v2, v3));
+                pmask = 0u;
+                prow_b = (unsigned)(yo >> 1) * (unsigned)Wp * OPB;
+            }
+        }
         // the row finished in the previous step is parked before its accumulator set is restarted by this step's MFMAs
-        park(accN, smem + OFF_OUT + (it & 1) * OUT_ROW_B);
+        park(accN, smem + OFF_OUT + (POOL ? it % 3 : it & 1) * OUT_ROW_B);
         row_mfma(it, accN, accM, accO);
 #pragma unroll
         for (int j = 0; j < SPW; ++j) __builtin_amdgcn_raw_buffer_store_b128(ln[j], rsd, (int)((row_b + st_col[j]) | rmask), 0, 0);
+        if constexpr (POOL)       // every step issues it (out of range when there is no pooled row): the counted waits stay uniform
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ie_u32x4, pv), rsp, (int)((prow_b + pl_col) | pmask), 0, 0);
     };
 
 #pragma unroll
@@ -286,7 +314,8 @@ typedef void (*SConvFn)(SConvParams);
 #define IE_DEF_SCONV(TAG, T, NCH, NCF)                                                                                              \
     __global__ __launch_bounds__(NCF * 128) void sconv3_##TAG##_none(SConvParams p) { sconv3_body<T, NCH, NCF, IE_ACT_NONE>(p); }    \
     __global__ __launch_bounds__(NCF * 128) void sconv3_##TAG##_relu(SConvParams p) { sconv3_body<T, NCH, NCF, IE_ACT_RELU>(p); }    \
-    __global__ __launch_bounds__(NCF * 128) void sconv3_##TAG##_lrelu(SConvParams p) { sconv3_body<T, NCH, NCF, IE_ACT_LRELU>(p); }
+    __global__ __launch_bounds__(NCF * 128) void sconv3_##TAG##_lrelu(SConvParams p) { sconv3_body<T, NCH, NCF, IE_ACT_LRELU>(p); } \
+    __global__ __launch_bounds__(NCF * 128) void sconv3_##TAG##_relu_pool(SConvParams p) { sconv3_body<T, NCH, NCF, IE_ACT_RELU, true>(p); }
 IE_DEF_SCONV(f16_c32_o32, _Float16, 1, 2)
 IE_DEF_SCONV(f16_c32_o64, _Float16, 1, 4)
 IE_DEF_SCONV(f16_c64_o32, _Float16, 2, 2)
@@ -298,8 +327,8 @@ IE_DEF_SCONV(bf16_c64_o32, __bf16, 2, 2)
 IE_DEF_SCONV(bf16_c64_o64, __bf16, 2, 4)
 IE_DEF_SCONV(bf16_c128_o64, __bf16, 4, 4)
 
-SConvFn pick_kernel(bool h, int nch, int ncf, int act) {
-#define IE_PICK_ACT(TAG) return act == IE_ACT_RELU ? sconv3_##TAG##_relu : (act == IE_ACT_LRELU ? sconv3_##TAG##_lrelu : sconv3_##TAG##_none)
+SConvFn pick_kernel(bool h, int nch, int ncf, int act, bool pool) {
+#define IE_PICK_ACT(TAG) return pool ? sconv3_##TAG##_relu_pool : (act == IE_ACT_RELU ? sconv3_##TAG##_relu : (act == IE_ACT_LRELU ? sconv3_##TAG##_lrelu : sconv3_##TAG##_none))
     if (h) {
         if (nch == 1 && ncf == 2) IE_PICK_ACT(f16_c32_o32);
         if (nch == 1 && ncf == 4) IE_PICK_ACT(f16_c32_o64);
@@ -333,7 +362,7 @@ bool ie_sconv3_applicable(int nsrc, const int* cs, int Cout, int kh, int kw, int
 }
 
 int ie_sconv3_launch(const void* const* srcs, const int* cs, int nsrc, const void* wpk, const float* bias, void* dst, int dtype, int N, int H, int W,
-                     int Cout, int act, float slope, int pad_mode, const int* src_h, const int* src_w, hipStream_t st) {
+                     int Cout, int act, float slope, int pad_mode, const int* src_h, const int* src_w, void* pool_dst, hipStream_t st) {
     SConvParams p;
     memset(&p, 0, sizeof(p));
     int nch = 0;
@@ -343,7 +372,8 @@ int ie_sconv3_launch(const void* const* srcs, const int* cs, int nsrc, const voi
     p.th[1] = (src_h && src_h[nsrc - 1] > 0) ? src_h[nsrc - 1] : H; p.tw[1] = (src_w && src_w[nsrc - 1] > 0) ? src_w[nsrc - 1] : W;
     for (int s = 0; s < nsrc; ++s)
         for (int c0 = 0; c0 < cs[s]; c0 += 32) { p.tsel[nch] = s; p.coff[nch] = c0 * 2; ++nch; }
-    p.wpk = wpk; p.bias = bias; p.dst = dst; p.N = N; p.H = H; p.W = W; p.slope = slope; p.replicate = pad_mode == IE_PAD_REPLICATE;
+    if (pool_dst && (act != IE_ACT_RELU || H < 2 || W < 2)) IE_FAIL(IE_ERR_UNSUPPORTED, "ie_sconv3: the fused 2x2 max-pool needs a ReLU conv of at least 2x2 pixels");
+    p.wpk = wpk; p.bias = bias; p.dst = dst; p.pool = pool_dst; p.N = N; p.H = H; p.W = W; p.slope = slope; p.replicate = pad_mode == IE_PAD_REPLICATE;
     if ((double)H * W * 256.0 >= 2147483647.0) IE_FAIL(IE_ERR_UNSUPPORTED, "ie_sconv3: frame too large for 31-bit offsets");
     p.strips = ie_cdiv(W, TW);
     // Row chunks per strip: the grid should fill whole rounds of the chip's resident workgroup slots (a 2.1-round grid runs 3 rounds),
@@ -355,7 +385,8 @@ int ie_sconv3_launch(const void* const* srcs, const int* cs, int nsrc, const voi
         int best_c = 1;
         double best = -1.0;
         for (int c = 1; c <= H / 16 + 1 && c <= 64; ++c) {
-            const int rpb = ie_cdiv(H, c);
+            int rpb = ie_cdiv(H, c);
+            if (pool_dst) rpb += rpb & 1;            // row pairs stay inside one chunk
             const int cc = ie_cdiv(H, rpb);
             const long long blocks = base * cc;
             const long long rounds = (blocks + slots - 1) / slots;
@@ -363,14 +394,15 @@ int ie_sconv3_launch(const void* const* srcs, const int* cs, int nsrc, const voi
             if (score > best + 1e-9) { best = score; best_c = cc; }
         }
         p.rows_per_block = ie_cdiv(H, best_c);
+        if (pool_dst) p.rows_per_block += p.rows_per_block & 1;
         p.chunks = ie_cdiv(H, p.rows_per_block);
     }
     const long long blocks = (long long)p.strips * p.chunks * N;
     if (blocks <= 0 || blocks > 0x7fffffffLL) IE_FAIL(IE_ERR_INVALID, "ie_sconv3: bad grid");
-    const size_t lds = (size_t)(nch == 4 ? 3 : 4) * SRC_ROW_B * nch + 2 * (size_t)TW * (Cout * 2);
+    const size_t lds = (size_t)(nch == 4 ? 3 : 4) * SRC_ROW_B * nch + (pool_dst ? 3 : 2) * (size_t)TW * (Cout * 2);
     const int ncf = Cout / 16;
-    SConvFn fn = pick_kernel(dtype == IE_F16, nch, ncf, act);
-    static SConvFn granted[24] = {nullptr};
+    SConvFn fn = pick_kernel(dtype == IE_F16, nch, ncf, act, pool_dst != nullptr);
+    static SConvFn granted[48] = {nullptr};
     bool done = false;
     for (auto f : granted) done = done || f == fn;
     if (!done) {

@@ -75,7 +75,7 @@ class _GraphModel(ImageEnhancementModel):
         return w, b
 
     def _conv(self, srcs, name, bn=None, stride=1, pad=1, pad_mode="zeros", act="none", slope=0.0, residual=None, clamp=None,
-              out_f32=False, cout_pad=None, valid=None, negate=False, cout=None, shuffle=0):
+              out_f32=False, cout_pad=None, valid=None, negate=False, cout=None, shuffle=0, pool=False):
         """Conv2d ``name`` (+ folded eval BatchNorm ``bn``) over the channel concat of ``srcs`` in the model's compute dtype.
         On the 16-bit path sources may carry zero-padded channels (a 3-channel image stored as 8): the weights of the missing
         input channels are zero; ``cout_pad`` pads the output channels the same way (zero weights and bias)."""
@@ -84,6 +84,8 @@ class _GraphModel(ImageEnhancementModel):
         if self.compute_dtype == "f32":
             y = ops.conv2d(srcs, self._cw(name, bn, negate, cout), stride=stride, pad=pad, pad_mode=pad_mode, act=act, slope=slope,
                            residual=residual, clamp=clamp)
+            if pool:                      # ``pool=True``: (y, nn.MaxPool2d(2)(y)) -- one launch on the 16-bit path where the strip kernel covers the layer
+                return y, ops.maxpool2x2(y)
             return ops.pixel_shuffle(y, shuffle) if shuffle else y
         split = tuple(int(t.shape[1]) for t in srcs)
         w_ = self._params[f"{name}.weight"]
@@ -108,7 +110,7 @@ class _GraphModel(ImageEnhancementModel):
                 b = None if b is None else torch.cat([b, torch.zeros(extra)], 0)
             self._dev_cache[key] = ops.MConvWeights(w, b, split, self._tdt, self.device, cin_map, shuffle=2 if fuse else 0)
         y = ops.mconv2d(srcs, self._dev_cache[key], stride=stride, pad=pad, pad_mode=pad_mode, act=act, slope=slope,
-                        residual=residual, clamp=clamp, out_f32=out_f32)
+                        residual=residual, clamp=clamp, out_f32=out_f32, pool=pool)
         return ops.pixel_shuffle(y, shuffle) if (shuffle and not fuse) else y
 
     def _ds_block(self, prefix, srcs, act, out_f32=False, slope=0.0):
@@ -798,9 +800,10 @@ class UNet(_GraphModel):
                 self._params[k] = 1.0 + torch.randn(self._params[k].shape, generator=g) * 0.02
         self._on_params_change()
 
-    def _dc(self, name, srcs):
+    def _dc(self, name, srcs, pool=False):
+        """DoubleConv; ``pool=True`` also returns the MaxPool2d(2) the next ``Down`` starts with (unet.py:70-72)."""
         x = self._conv(srcs, f"{name}.conv1", f"{name}.norm1", act="relu")
-        return self._conv(x, f"{name}.conv2", f"{name}.norm2", act="relu")
+        return self._conv(x, f"{name}.conv2", f"{name}.norm2", act="relu", pool=pool)
 
     def _up(self, k, x1, x2):
         if self.upsampler == "bilinear":
@@ -813,11 +816,11 @@ class UNet(_GraphModel):
 
     def forward(self, datapoint: dict, *args, **kwargs) -> dict:
         x = self._input_any(datapoint)
-        x1 = self._dc("inc", [x])
-        x2 = self._dc("down1.conv", [ops.maxpool2x2(x1)])
-        x3 = self._dc("down2.conv", [ops.maxpool2x2(x2)])
-        x4 = self._dc("down3.conv", [ops.maxpool2x2(x3)])
-        x5 = self._dc("down4.conv", [ops.maxpool2x2(x4)])
+        x1, p1 = self._dc("inc", [x], pool=True)
+        x2, p2 = self._dc("down1.conv", [p1], pool=True)
+        x3, p3 = self._dc("down2.conv", [p2], pool=True)
+        x4, p4 = self._dc("down3.conv", [p3], pool=True)
+        x5 = self._dc("down4.conv", [p4])
         y = self._up(1, x5, x4)
         y = self._up(2, y, x3)
         y = self._up(3, y, x2)

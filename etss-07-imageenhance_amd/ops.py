@@ -741,8 +741,9 @@ class MConvWeights:
 
 
 def mconv2d(srcs, mw: MConvWeights, stride=1, pad=1, pad_mode="zeros", act="none", slope=0.0, residual=None, clamp=None,
-            out_f32=False) -> torch.Tensor:
-    """16-bit Conv2d over the channel concat of ``srcs`` on the matrix cores."""
+            out_f32=False, pool=False):
+    """16-bit Conv2d over the channel concat of ``srcs`` on the matrix cores.  ``pool=True`` also returns ``F.max_pool2d(out, 2)``
+    (written by the same launch for the narrow ReLU layers): ``(out, pooled)``."""
     if isinstance(srcs, torch.Tensor):
         srcs = [srcs]
     for s in srcs:
@@ -778,6 +779,14 @@ def mconv2d(srcs, mw: MConvWeights, stride=1, pad=1, pad_mode="zeros", act="none
             raise capi.IEError("mconv2d: residual shape mismatch")
     ptrs = (C.c_void_p * len(srcs))(*[s.data_ptr() for s in srcs])
     chans = (C.c_int * len(srcs))(*cs)
+    if pool:
+        if residual is not None or clamp is not None or out_f32 or sh or stride != 1:
+            raise capi.IEError("mconv2d: pool=True takes a plain stride-1 conv (no residual / clamp / fp32 output / pixel shuffle)")
+        pooled = torch.empty((n, mw.cout, ho // 2, wo // 2), device=srcs[0].device, dtype=odt, memory_format=CL)
+        with torch.cuda.device(out.device):
+            capi.check(capi.lib().ie_mconv_pool_nhwc(C.byref(d), ptrs, chans, capi.ptr(mw.w), capi.ptr(mw.b), capi.ptr(out), capi.ptr(pooled),
+                                                     capi.current_stream()), "ie_mconv_pool_nhwc")
+        return out, pooled
     with torch.cuda.device(out.device):
         capi.check(capi.lib().ie_mconv_nhwc(C.byref(d), ptrs, chans, capi.ptr(mw.w), capi.ptr(mw.b), capi.ptr(residual), capi.ptr(out),
                                             capi.current_stream()), "ie_mconv_nhwc")

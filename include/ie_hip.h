@@ -180,6 +180,13 @@ int ie_mconv_nhwc(ie_mconv_desc* d, const void* const* srcs_dev, const int* chan
 int ie_dsconv_nhwc(ie_mconv_desc* d, const void* const* srcs_dev, const int* channels, const float* dw_w_dev, const float* dw_b_dev,
                    const void* packed_pw_dev, const float* pw_bias_dev, void* dst_dev, void* stream);
 
+/* ie_mconv_nhwc (stride 1, same-type output, no residual / clamp / pixel shuffle) that ALSO writes the nn.MaxPool2d(2) of its output,
+ * pool_dst_dev = NHWC [N, Ho/2, Wo/2, Cout]: the U-Net encoder's `Down` = MaxPool2d(2) -> DoubleConv (reference unet.py:70-72) reads the
+ * pooled copy, the skip connection the full one.  One launch for the narrow ReLU layers the strip kernel covers; the conv followed by
+ * ie_maxpool2x2_nhwc otherwise (same results). */
+int ie_mconv_pool_nhwc(ie_mconv_desc* d, const void* const* srcs_dev, const int* channels, const void* packed_w_dev, const float* bias_dev,
+                       void* dst_dev, void* pool_dst_dev, void* stream);
+
 /* ---- 16-bit (IE_F16 / IE_BF16) NHWC streaming ops between the matrix-core convolutions; IE_F32 forwards to the *_f32
  * entry points above.  On the 16-bit path channel counts are multiples of 8 (a thread moves 8 channels = 16 bytes). */
 int ie_maxpool2x2_nhwc(const void* x_dev, void* y_dev, int dtype, int N, int H, int W, int C, void* stream);

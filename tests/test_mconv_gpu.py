@@ -59,6 +59,30 @@ def test_strip_conv_vs_torch(c, dt, shape):
 
 
 @pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 37, 150), (1, 200, 64), (3, 6, 129), (1, 270, 480), (2, 2, 66)], ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("cs,co,act", [([32], 32, "relu"), ([64], 64, "relu"), ([32], 64, "relu"), ([32, 32], 32, "relu"), ([64, 64], 64, "relu"),
+                                       ([64], 64, "none"), ([128], 128, "relu")], ids=lambda v: str(v).replace(" ", ""))
+def test_conv_with_fused_maxpool(cs, co, act, dt, shape):
+    """ie_mconv_pool_nhwc (unet.py:70-72, MaxPool2d(2) behind the DoubleConv): the full-resolution output is the plain conv's, bit for bit,
+    and the pooled copy is F.max_pool2d of it, bit for bit -- from the strip kernel's parked rows (first five cases; odd heights and widths
+    drop the last row / column like torch) or from the conv followed by the pool kernel (no ReLU / wide layers)."""
+    tdt = ops.TORCH_DT[dt]
+    n, h, w = shape
+    g = torch.Generator().manual_seed(23)
+    xs = [torch.randn(n, ci, h, w, generator=g).to(tdt).cuda().contiguous(memory_format=CL) for ci in cs]
+    cin = sum(cs)
+    wt = (torch.randn(co, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).to(tdt).float()
+    mw = ops.MConvWeights(wt, torch.randn(co, generator=g), cs, tdt, "cuda")
+    plain = ops.mconv2d(xs, mw, act=act)
+    out, pooled = ops.mconv2d(xs, mw, act=act, pool=True)
+    assert torch.equal(out, plain)
+    assert tuple(pooled.shape) == (n, co, h // 2, w // 2)
+    assert torch.equal(pooled.float().cpu(), F.max_pool2d(plain.float().cpu(), 2))
+    with pytest.raises(capi.IEError):
+        ops.mconv2d(xs, mw, act=act, pool=True, out_f32=True)
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
 @pytest.mark.parametrize("c", CASES, ids=_id)
 def test_mconv_vs_torch(c, dt, shape=(2, 37, 45)):
     tdt = ops.TORCH_DT[dt]
