@@ -30,6 +30,13 @@ int ie_det_workspace(size_t bytes, void** out);
 // reading ie_mconv_pack_weights' image.  ie_mconv_nhwc asks `applicable` first.
 bool ie_sconv3_applicable(int nsrc, const int* cs, int Cout, int kh, int kw, int stride, int pad, int pad_mode, int act, bool residual, bool clamp,
                           bool out_f32, int W);
+struct ie_sconv_tail {      // 1x1 conv of the ReLU'd rows, fused into the strip kernel (the conv's own output is not written)
+    const void* w;          // [16][Cout] 16-bit, rows >= cout zero
+    const float* b;         // [16]
+    float* dst;             // NCHW fp32 [N, cout, H, W]
+    int cout, clamp;
+    float lo, hi;
+};
 int ie_sconv3_launch(const void* const* srcs, const int* cs, int nsrc, const void* wpk, const float* bias, void* dst, int dtype, int N, int H, int W,
-                     int Cout, int act, float slope, int pad_mode, const int* src_h, const int* src_w, void* pool_dst, hipStream_t st);
+                     int Cout, int act, float slope, int pad_mode, const int* src_h, const int* src_w, void* pool_dst, const ie_sconv_tail* tail, hipStream_t st);
 // pool_dst: null, or the 2x2 max-pooled copy of dst written by the same launch (ReLU layers only)

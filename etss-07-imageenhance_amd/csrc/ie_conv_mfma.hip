@@ -947,6 +947,36 @@ IE_EXPORT int ie_mconv_pool_nhwc(ie_mconv_desc* d, const void* const* srcs, cons
     return ie_maxpool2x2_nhwc(dst, pool_dst, d->in_dtype, d->N, d->Ho, d->Wo, d->Cout, stream);
 }
 
+// Conv3x3 (+ bias + ReLU) -> 1x1 conv (+ bias, optional clamp) -> NCHW fp32, one launch: the U-Net head (unet.py:186-195 `outc` behind the last
+// DoubleConv).  The 3x3 conv's rows never reach HBM; the 1x1 contracts them on the matrix cores while they are parked in LDS.
+static bool tail_ok(const ie_mconv_desc* d, const int* channels, int tail_cout) {
+    static const int on = getenv("IE_SCONV_TAIL") ? atoi(getenv("IE_SCONV_TAIL")) : 1;           // A/B: 0 = the two separate convs
+    return on && d && channels && !d->pixel_shuffle && d->act == IE_ACT_RELU && (d->W & 3) == 0 && tail_cout >= 1 && tail_cout <= 16 && !d->clamp &&
+           d->out_dtype == d->in_dtype &&
+           ie_sconv3_applicable(d->nsrc, channels, d->Cout, d->kh, d->kw, d->stride, d->pad, d->pad_mode, d->act, false, false, false, d->W) &&
+           (double)tail_cout * d->H * d->W * 4.0 < 2147483647.0;
+}
+
+IE_EXPORT int ie_mconv_tail_applicable(const ie_mconv_desc* d, const int* channels, int tail_cout) { return tail_ok(d, channels, tail_cout) ? 1 : 0; }
+
+IE_EXPORT int ie_mconv_tail_nhwc(ie_mconv_desc* d, const void* const* srcs, const int* channels, const void* packed_w, const float* bias,
+                                 const void* tail_w, const float* tail_bias, int tail_cout, int clamp, float clamp_lo, float clamp_hi, float* dst_nchw,
+                                 void* stream) {
+    if (!d || !srcs || !channels || !packed_w || !tail_w || !tail_bias || !dst_nchw) IE_FAIL(IE_ERR_INVALID, "ie_mconv_tail_nhwc: null pointer");
+    if (d->N <= 0 || d->H <= 0 || d->W <= 0) IE_FAIL(IE_ERR_INVALID, "ie_mconv_tail_nhwc: bad shape");
+    if ((d->in_dtype != IE_F16 && d->in_dtype != IE_BF16)) IE_FAIL(IE_ERR_UNSUPPORTED, "ie_mconv_tail_nhwc: in_dtype must be f16/bf16");
+    if (!tail_ok(d, channels, tail_cout))
+        IE_FAIL(IE_ERR_UNSUPPORTED, "ie_mconv_tail_nhwc: needs a strip-kernel layer (3x3, stride 1, pad 1, Cout 32/64, ReLU) with W %% 4 == 0 -- ask "
+                                    "ie_mconv_tail_applicable first");
+    for (int s = 0; s < d->nsrc; ++s)
+        if (!srcs[s]) IE_FAIL(IE_ERR_INVALID, "ie_mconv_tail_nhwc: source %d is null", s);
+    d->Ho = d->H; d->Wo = d->W;
+    ie_sconv_tail t;
+    t.w = tail_w; t.b = tail_bias; t.dst = dst_nchw; t.cout = tail_cout; t.clamp = clamp; t.lo = clamp_lo; t.hi = clamp_hi;
+    return ie_sconv3_launch(srcs, channels, d->nsrc, packed_w, bias, nullptr, d->in_dtype, d->N, d->H, d->W, d->Cout, d->act, d->slope, d->pad_mode,
+                            d->src_h, d->src_w, nullptr, &t, (hipStream_t)stream);
+}
+
 static int mconv_impl(ie_mconv_desc* d, const void* const* srcs, const int* channels, const void* packed_w, const float* bias, const void* residual,
                       void* dst, void* pool_dst, bool* pooled, void* stream) {
     if (!d || !srcs || !channels || !packed_w || !dst) IE_FAIL(IE_ERR_INVALID, "ie_mconv_nhwc: null pointer");
@@ -967,7 +997,7 @@ static int mconv_impl(ie_mconv_desc* d, const void* const* srcs, const int* chan
         void* pd = (pool_dst && fuse && d->act == IE_ACT_RELU && d->H >= 2 && d->W >= 2) ? pool_dst : nullptr;
         if (pooled) *pooled = pd != nullptr;
         return ie_sconv3_launch(srcs, channels, d->nsrc, packed_w, bias, dst, d->in_dtype, d->N, d->H, d->W, d->Cout, d->act, d->slope, d->pad_mode,
-                                d->src_h, d->src_w, pd, (hipStream_t)stream);
+                                d->src_h, d->src_w, pd, nullptr, (hipStream_t)stream);
     }
     MConvParams p;
     memset(&p, 0, sizeof(p));

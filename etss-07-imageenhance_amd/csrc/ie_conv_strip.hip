@@ -32,6 +32,13 @@ struct SConvParams {
     const float* bias;       // [Cout] or null
     void* dst;               // NHWC T, Cout channels
     void* pool;              // POOL kernels: the 2x2 max-pooled copy of dst, NHWC T [N, H/2, W/2, Cout] (nn.MaxPool2d(2) behind the conv: unet.py:70-72)
+    // TAIL kernels: a 1x1 conv (tail_c <= 16 output channels, optional clamp) of the ReLU'd rows while they sit in LDS; only ITS result leaves,
+    // NCHW fp32 [N, tail_c, H, W] -- the U-Net head `outc` behind the last DoubleConv (unet.py:186-195).  dst is not written.
+    const void* tail_w;      // [16][Cout] T, rows >= tail_c zero
+    const float* tail_b;     // [16]
+    float* tail_dst;
+    int tail_c, tail_clamp;
+    float tail_lo, tail_hi;
     int N, H, W, rows_per_block, strips, chunks;
     int replicate;           // padding_mode="replicate": out-of-image rows / columns are clamped to the edge instead of reading zeros
     float slope;
@@ -47,7 +54,7 @@ __device__ __forceinline__ void wait_vm(int n) {
 #undef IE_W
 }
 
-template <typename T, int NCH, int NCF, int ACT, bool POOL = false>
+template <typename T, int NCH, int NCF, int ACT, bool POOL = false, bool TAIL = false>
 __device__ __forceinline__ void sconv3_body(const SConvParams& p) {
     using frag = ie_u32x4;
     constexpr int NR = SGeom<NCH>::NR, PF = SGeom<NCH>::PF;
@@ -68,6 +75,10 @@ __device__ __forceinline__ void sconv3_body(const SConvParams& p) {
     // activation is ReLU, so the packed 16-bit values order like unsigned integers.
     static_assert(!POOL || ACT == IE_ACT_RELU, "the fused max-pool compares non-negative values as integers");
     static_assert(NW * 64 == (TW / 2) * NPC, "one pooled piece per lane");
+    static_assert(!TAIL || (ACT == IE_ACT_RELU && !POOL), "the 1x1 tail follows a ReLU layer");
+    constexpr int TKB = NCF / 2;                  // TAIL: 32-channel blocks of the 1x1 conv's K (= this conv's Cout)
+    constexpr int TT = 8 / NW;                    // TAIL: 16-pixel tiles of the strip per wave; TT * TKB == 2
+    constexpr int NST = TAIL ? TT : SPW + (POOL ? 1 : 0);       // store instructions a wave issues per step
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -96,6 +107,8 @@ __device__ __forceinline__ void sconv3_body(const SConvParams& p) {
     const int Hp = H >> 1, Wp = W >> 1;
     const size_t fbp = (size_t)Hp * Wp * OPB;
     const auto rsp = mk(POOL ? (char*)p.pool + (size_t)n * fbp : (char*)p.dst, POOL ? fbp : 0);
+    const size_t fbt = (size_t)p.tail_c * H * W * 4;
+    const auto rst = mk(TAIL ? (char*)p.tail_dst + (size_t)n * fbt : (char*)p.dst, TAIL ? fbt : 0);
 
     // ---- weights of this wave's 16 output channels into registers ---------------------------------------------------------
     frag wA[NCH * 9];
@@ -202,6 +215,25 @@ __device__ __forceinline__ void sconv3_body(const SConvParams& p) {
     const int pl_xp = tid / NPC, pl_c = tid % NPC;
     const int pl_lds0 = (2 * pl_xp) * OPB + ((pl_c ^ swz(2 * pl_xp)) << 4), pl_lds1 = (2 * pl_xp + 1) * OPB + ((pl_c ^ swz(2 * pl_xp + 1)) << 4);
     const unsigned pl_col = ((x0 >> 1) + pl_xp < Wp) ? (unsigned)(((x0 >> 1) + pl_xp) * OPB + pl_c * 16) : OOB;
+    // TAIL: the parked row is the A operand (a lane = one pixel, 8 channels), the 1x1 weights the B operand (a lane = one output channel):
+    // D leaves with lane (p16 = output channel, kq) holding pixels 4kq .. 4kq+3 of the tile -- 16 contiguous bytes of an NCHW plane
+    frag tW[TKB];
+    float tl_bias = 0.f;
+    int tl_lds[TT][TKB];
+    unsigned tl_col[TT];
+    if constexpr (TAIL) {
+#pragma unroll
+        for (int bk = 0; bk < TKB; ++bk) tW[bk] = *(const frag*)((const char*)p.tail_w + p16 * OPB + bk * 64 + kq * 16);
+        tl_bias = p.tail_b[p16];
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            const int q = 16 * (TT * wave + t) + p16;
+#pragma unroll
+            for (int bk = 0; bk < TKB; ++bk) tl_lds[t][bk] = q * OPB + (((4 * bk + kq) ^ swz(q)) << 4);
+            const int xo = x0 + 16 * (TT * wave + t) + 4 * kq;          // W % 4 == 0: the four pixels are inside or outside together
+            tl_col[t] = (p16 < p.tail_c && xo < W) ? (unsigned)((p16 * H * W + xo) * 4) : OOB;
+        }
+    }
     auto park = [&](const ie_f32x4 (&acc)[4], char* oslot) __attribute__((always_inline)) {
         ie_u32x2 pk[4];
 #pragma unroll
@@ -261,7 +293,7 @@ __device__ __forceinline__ void sconv3_body(const SConvParams& p) {
     };
     auto step = [&](int it, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4]) __attribute__((always_inline)) {
         // ops younger than row `it`'s DMA: the (PF-1) L loads of the rows behind it and the SPW (possibly out-of-range) stores every step issues
-        if (L) wait_vm(wait_n + (SPW + (POOL ? 1 : 0)) * (it < PF ? it : PF));
+        if (L) wait_vm(wait_n + NST * (it < PF ? it : PF));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this wave's parked pieces of the previous step
         __builtin_amdgcn_s_barrier();
         issue_row(it + PF);
@@ -271,8 +303,16 @@ __device__ __forceinline__ void sconv3_body(const SConvParams& p) {
         const unsigned row_b = rmask ? 0u : (unsigned)yo * (unsigned)W * OPB;
         const char* islot = smem + OFF_OUT + (POOL ? (it + 2) % 3 : (it + 1) & 1) * OUT_ROW_B;
         ie_u32x4 ln[SPW];
+        frag ta[TT][TKB];
+        if constexpr (TAIL) {
 #pragma unroll
-        for (int j = 0; j < SPW; ++j) ln[j] = *(const ie_u32x4*)(islot + st_lds[j]);
+            for (int t = 0; t < TT; ++t)
+#pragma unroll
+                for (int bk = 0; bk < TKB; ++bk) ta[t][bk] = *(const frag*)(islot + tl_lds[t][bk]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < SPW; ++j) ln[j] = *(const ie_u32x4*)(islot + st_lds[j]);
+        }
         // POOL: rows yo-1 (parked two steps ago) and yo make pooled row (yo-1)/2 when yo is odd (ys is even)
         ie_u16x8 pv = {0, 0, 0, 0, 0, 0, 0, 0};
         unsigned pmask = OOB, prow_b = 0u;
@@ -289,8 +329,23 @@ __device__ __forceinline__ void sconv3_body(const SConvParams& p) {
         // the row finished in the previous step is parked before its accumulator set is restarted by this step's MFMAs
         park(accN, smem + OFF_OUT + (POOL ? it % 3 : it & 1) * OUT_ROW_B);
         row_mfma(it, accN, accM, accO);
+        if constexpr (TAIL) {
+            const unsigned trow_b = rmask ? 0u : (unsigned)yo * (unsigned)W * 4u;
 #pragma unroll
-        for (int j = 0; j < SPW; ++j) __builtin_amdgcn_raw_buffer_store_b128(ln[j], rsd, (int)((row_b + st_col[j]) | rmask), 0, 0);
+            for (int t = 0; t < TT; ++t) {
+                ie_f32x4 o = {tl_bias, tl_bias, tl_bias, tl_bias};
+#pragma unroll
+                for (int bk = 0; bk < TKB; ++bk) o = ie_mfma16_raw<T>(ta[t][bk], tW[bk], o);
+                if (p.tail_clamp) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = fminf(fmaxf(o[i], p.tail_lo), p.tail_hi);
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ie_u32x4, o), rst, (int)((trow_b + tl_col[t]) | rmask), 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < SPW; ++j) __builtin_amdgcn_raw_buffer_store_b128(ln[j], rsd, (int)((row_b + st_col[j]) | rmask), 0, 0);
+        }
         if constexpr (POOL)       // every step issues it (out of range when there is no pooled row): the counted waits stay uniform
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ie_u32x4, pv), rsp, (int)((prow_b + pl_col) | pmask), 0, 0);
     };
@@ -315,7 +370,8 @@ typedef void (*SConvFn)(SConvParams);
     __global__ __launch_bounds__(NCF * 128) void sconv3_##TAG##_none(SConvParams p) { sconv3_body<T, NCH, NCF, IE_ACT_NONE>(p); }    \
     __global__ __launch_bounds__(NCF * 128) void sconv3_##TAG##_relu(SConvParams p) { sconv3_body<T, NCH, NCF, IE_ACT_RELU>(p); }    \
     __global__ __launch_bounds__(NCF * 128) void sconv3_##TAG##_lrelu(SConvParams p) { sconv3_body<T, NCH, NCF, IE_ACT_LRELU>(p); } \
-    __global__ __launch_bounds__(NCF * 128) void sconv3_##TAG##_relu_pool(SConvParams p) { sconv3_body<T, NCH, NCF, IE_ACT_RELU, true>(p); }
+    __global__ __launch_bounds__(NCF * 128) void sconv3_##TAG##_relu_pool(SConvParams p) { sconv3_body<T, NCH, NCF, IE_ACT_RELU, true>(p); } \
+    __global__ __launch_bounds__(NCF * 128) void sconv3_##TAG##_relu_tail(SConvParams p) { sconv3_body<T, NCH, NCF, IE_ACT_RELU, false, true>(p); }
 IE_DEF_SCONV(f16_c32_o32, _Float16, 1, 2)
 IE_DEF_SCONV(f16_c32_o64, _Float16, 1, 4)
 IE_DEF_SCONV(f16_c64_o32, _Float16, 2, 2)
@@ -327,8 +383,8 @@ IE_DEF_SCONV(bf16_c64_o32, __bf16, 2, 2)
 IE_DEF_SCONV(bf16_c64_o64, __bf16, 2, 4)
 IE_DEF_SCONV(bf16_c128_o64, __bf16, 4, 4)
 
-SConvFn pick_kernel(bool h, int nch, int ncf, int act, bool pool) {
-#define IE_PICK_ACT(TAG) return pool ? sconv3_##TAG##_relu_pool : (act == IE_ACT_RELU ? sconv3_##TAG##_relu : (act == IE_ACT_LRELU ? sconv3_##TAG##_lrelu : sconv3_##TAG##_none))
+SConvFn pick_kernel(bool h, int nch, int ncf, int act, bool pool, bool tail) {
+#define IE_PICK_ACT(TAG) return tail ? sconv3_##TAG##_relu_tail : pool ? sconv3_##TAG##_relu_pool : (act == IE_ACT_RELU ? sconv3_##TAG##_relu : (act == IE_ACT_LRELU ? sconv3_##TAG##_lrelu : sconv3_##TAG##_none))
     if (h) {
         if (nch == 1 && ncf == 2) IE_PICK_ACT(f16_c32_o32);
         if (nch == 1 && ncf == 4) IE_PICK_ACT(f16_c32_o64);
@@ -362,7 +418,7 @@ bool ie_sconv3_applicable(int nsrc, const int* cs, int Cout, int kh, int kw, int
 }
 
 int ie_sconv3_launch(const void* const* srcs, const int* cs, int nsrc, const void* wpk, const float* bias, void* dst, int dtype, int N, int H, int W,
-                     int Cout, int act, float slope, int pad_mode, const int* src_h, const int* src_w, void* pool_dst, hipStream_t st) {
+                     int Cout, int act, float slope, int pad_mode, const int* src_h, const int* src_w, void* pool_dst, const ie_sconv_tail* tail, hipStream_t st) {
     SConvParams p;
     memset(&p, 0, sizeof(p));
     int nch = 0;
@@ -373,6 +429,12 @@ int ie_sconv3_launch(const void* const* srcs, const int* cs, int nsrc, const voi
     for (int s = 0; s < nsrc; ++s)
         for (int c0 = 0; c0 < cs[s]; c0 += 32) { p.tsel[nch] = s; p.coff[nch] = c0 * 2; ++nch; }
     if (pool_dst && (act != IE_ACT_RELU || H < 2 || W < 2)) IE_FAIL(IE_ERR_UNSUPPORTED, "ie_sconv3: the fused 2x2 max-pool needs a ReLU conv of at least 2x2 pixels");
+    if (tail) {
+        if (pool_dst || act != IE_ACT_RELU || (W & 3) || tail->cout < 1 || tail->cout > 16 || !tail->w || !tail->b || !tail->dst)
+            IE_FAIL(IE_ERR_UNSUPPORTED, "ie_sconv3: the fused 1x1 tail needs a ReLU conv, W %% 4 == 0 and at most 16 tail channels");
+        if ((double)tail->cout * H * W * 4.0 >= 2147483647.0) IE_FAIL(IE_ERR_UNSUPPORTED, "ie_sconv3: tail frame too large for 31-bit offsets");
+        p.tail_w = tail->w; p.tail_b = tail->b; p.tail_dst = tail->dst; p.tail_c = tail->cout; p.tail_clamp = tail->clamp; p.tail_lo = tail->lo; p.tail_hi = tail->hi;
+    }
     p.wpk = wpk; p.bias = bias; p.dst = dst; p.pool = pool_dst; p.N = N; p.H = H; p.W = W; p.slope = slope; p.replicate = pad_mode == IE_PAD_REPLICATE;
     if ((double)H * W * 256.0 >= 2147483647.0) IE_FAIL(IE_ERR_UNSUPPORTED, "ie_sconv3: frame too large for 31-bit offsets");
     p.strips = ie_cdiv(W, TW);
@@ -401,8 +463,8 @@ int ie_sconv3_launch(const void* const* srcs, const int* cs, int nsrc, const voi
     if (blocks <= 0 || blocks > 0x7fffffffLL) IE_FAIL(IE_ERR_INVALID, "ie_sconv3: bad grid");
     const size_t lds = (size_t)(nch == 4 ? 3 : 4) * SRC_ROW_B * nch + (pool_dst ? 3 : 2) * (size_t)TW * (Cout * 2);
     const int ncf = Cout / 16;
-    SConvFn fn = pick_kernel(dtype == IE_F16, nch, ncf, act, pool_dst != nullptr);
-    static SConvFn granted[48] = {nullptr};
+    SConvFn fn = pick_kernel(dtype == IE_F16, nch, ncf, act, pool_dst != nullptr, tail != nullptr);
+    static SConvFn granted[64] = {nullptr};
     bool done = false;
     for (auto f : granted) done = done || f == fn;
     if (!done) {

@@ -113,6 +113,30 @@ class _GraphModel(ImageEnhancementModel):
                         residual=residual, clamp=clamp, out_f32=out_f32, pool=pool)
         return ops.pixel_shuffle(y, shuffle) if (shuffle and not fuse) else y
 
+    def _conv_tail(self, srcs, name, bn, tail_name, clamp=None):
+        """``clamp(conv1x1 tail_name (relu(conv3x3 name + folded bn)))`` as NCHW fp32 in ONE launch on the 16-bit path (the 3x3 layer's output
+        never reaches HBM), or None where the one-launch form does not cover the pair (fp32 path, wide layers, W % 4 != 0)."""
+        if self.compute_dtype == "f32":
+            return None
+        if isinstance(srcs, torch.Tensor):
+            srcs = [srcs]
+        split = tuple(int(t.shape[1]) for t in srcs)
+        if self._dev_cache is None:
+            self._dev_cache = {}
+        wshape = self._params[f"{name}.weight"].shape
+        if sum(split) != wshape[1] or wshape[2] != 3 or self._params[f"{tail_name}.weight"].shape[0] > 16:     # e.g. a 34-class segmentation head
+            return None
+        key = ("mconv", name, bn, split, None, None, False, None, False)
+        if key not in self._dev_cache:
+            self._dev_cache[key] = ops.MConvWeights(*self._wb(name, bn), split, self._tdt, self.device)
+        tkey = ("mtail", tail_name)
+        if tkey not in self._dev_cache:
+            self._dev_cache[tkey] = ops.MTailWeights(self._params[f"{tail_name}.weight"], self._params.get(f"{tail_name}.bias"), self._tdt, self.device)
+        mw, tw = self._dev_cache[key], self._dev_cache[tkey]
+        if not ops.mconv2d_tail_applicable(srcs, mw, tw):
+            return None
+        return ops.mconv2d_tail(srcs, mw, tw, clamp=clamp)
+
     def _ds_block(self, prefix, srcs, act, out_f32=False, slope=0.0):
         """DepthwiseSeparableConv2d ``prefix`` (dsconv.py:106-149: ``prefix.dw_conv`` 3x3 depthwise + ``prefix.pw_conv`` 1x1) over the channel
         concat of ``srcs``, + activation.  Depthwise over the concat == depthwise per source with the matching weight slice."""
@@ -805,13 +829,24 @@ class UNet(_GraphModel):
         x = self._conv(srcs, f"{name}.conv1", f"{name}.norm1", act="relu")
         return self._conv(x, f"{name}.conv2", f"{name}.norm2", act="relu", pool=pool)
 
-    def _up(self, k, x1, x2):
+    def _dc_head(self, name, srcs, clamp):
+        """The last DoubleConv + ``outc`` (1x1) + clamp -> NCHW fp32; conv2 and outc are one launch where the strip kernel covers conv2."""
+        x = self._conv(srcs, f"{name}.conv1", f"{name}.norm1", act="relu")
+        y = self._conv_tail(x, f"{name}.conv2", f"{name}.norm2", "outc.conv", clamp=clamp)
+        if y is not None:
+            return y
+        x = self._conv(x, f"{name}.conv2", f"{name}.norm2", act="relu")
+        return ops.to_nchw(self._conv(x, "outc.conv", pad=0, clamp=clamp, out_f32=True))
+
+    def _up(self, k, x1, x2, head=False):
         if self.upsampler == "bilinear":
             x1 = ops.upsample2x_bilinear(x1)
         else:
             x1 = self._conv(x1, f"up{k}.up.0", shuffle=2)           # conv3x3 + PixelShuffle(2), fused into the conv's epilogue on the 16-bit path
         dy, dx = x2.shape[2] - x1.shape[2], x2.shape[3] - x1.shape[3]
         x1 = ops.pad(x1, dy // 2, dy - dy // 2, dx // 2, dx - dx // 2)
+        if head:
+            return self._dc_head(f"up{k}.conv", [x2, x1], clamp=(0.0, 1.0) if self.enhance else None)
         return self._dc(f"up{k}.conv", [x2, x1])
 
     def forward(self, datapoint: dict, *args, **kwargs) -> dict:
@@ -824,10 +859,9 @@ class UNet(_GraphModel):
         y = self._up(1, x5, x4)
         y = self._up(2, y, x3)
         y = self._up(3, y, x2)
-        y = self._up(4, y, x1)
-        y = self._conv(y, "outc.conv", pad=0, clamp=(0.0, 1.0) if self.enhance else None, out_f32=True)
+        y = self._up(4, y, x1, head=True)                 # ... + outc + clamp, NCHW fp32
         out = OrderedDict()
-        out["enhanced" if self.enhance else "semantic"] = ops.to_nchw(y)
+        out["enhanced" if self.enhance else "semantic"] = y
         return out
 
     supports_mixed_training = True

@@ -793,6 +793,71 @@ def mconv2d(srcs, mw: MConvWeights, stride=1, pad=1, pad_mode="zeros", act="none
     return out
 
 
+class MTailWeights:
+    """A 1x1 Conv2d (at most 16 output channels) that ie_mconv_tail_nhwc contracts behind a narrow 3x3 ReLU layer: 16-bit [16][Cin]
+    (rows >= Cout zero) + fp32 bias [16]."""
+
+    def __init__(self, w_oihw: torch.Tensor, bias, dtype, device):
+        w = w_oihw.detach().to("cpu", torch.float32)
+        if w.dim() != 4 or w.shape[2] != 1 or w.shape[3] != 1 or w.shape[0] > 16:
+            raise capi.IEError("MTailWeights: a 1x1 conv with at most 16 output channels")
+        self.cout, self.cin, self.dtype = int(w.shape[0]), int(w.shape[1]), dtype
+        wz = torch.zeros(16, self.cin)
+        wz[:self.cout] = w[:, :, 0, 0]
+        bz = torch.zeros(16)
+        if bias is not None:
+            bz[:self.cout] = bias.detach().to("cpu", torch.float32)
+        self.w, self.b = wz.to(device, dtype).contiguous(), bz.to(device).contiguous()
+
+
+def _mconv_desc(srcs, mw, pad, pad_mode, act, slope):
+    cs = [int(s.shape[1]) for s in srcs]
+    n = srcs[0].shape[0]
+    h, w = max(int(s.shape[2]) for s in srcs), max(int(s.shape[3]) for s in srcs)
+    d = capi.MConvDesc(n, h, w, len(srcs), mw.cout, mw.kh, mw.kw, 1, pad, capi.PAD[pad_mode], capi.ACT[act], slope, 0, 0.0, 0.0,
+                       IE_DT[mw.dtype], IE_DT[mw.dtype], 0, 0)
+    for i, s_ in enumerate(srcs):
+        if (int(s_.shape[2]), int(s_.shape[3])) != (h, w):
+            d.src_h[i], d.src_w[i] = int(s_.shape[2]), int(s_.shape[3])
+    return d, cs, n, h, w
+
+
+def mconv2d_tail_applicable(srcs, mw: MConvWeights, tail: MTailWeights, pad=1, pad_mode="zeros", act="relu") -> bool:
+    """Does the one-launch form (3x3 ReLU conv -> 1x1 conv -> NCHW fp32) cover this layer pair?"""
+    if isinstance(srcs, torch.Tensor):
+        srcs = [srcs]
+    if getattr(mw, "shuffle", 0) or tail.cin != mw.cout or tail.dtype != mw.dtype:
+        return False
+    d, cs, *_ = _mconv_desc(srcs, mw, pad, pad_mode, act, 0.0)
+    return bool(capi.lib().ie_mconv_tail_applicable(C.byref(d), (C.c_int * len(cs))(*cs), tail.cout))
+
+
+def mconv2d_tail(srcs, mw: MConvWeights, tail: MTailWeights, pad=1, pad_mode="zeros", act="relu", clamp=None) -> torch.Tensor:
+    """``clamp(conv1x1(relu(conv3x3(cat(srcs)))))`` as NCHW fp32 in one launch (the U-Net head: unet.py:186-195); the 3x3 layer's
+    output never reaches HBM.  Raises where ``mconv2d_tail_applicable`` says no."""
+    if isinstance(srcs, torch.Tensor):
+        srcs = [srcs]
+    for s in srcs:
+        _chk16(s)
+        if s.dtype != mw.dtype:
+            raise capi.IEError("mconv2d_tail: source dtype differs from the packed weights")
+    if tail.cin != mw.cout or tail.dtype != mw.dtype:
+        raise capi.IEError("mconv2d_tail: the 1x1 weights do not match the 3x3 layer")
+    d, cs, n, h, w = _mconv_desc(srcs, mw, pad, pad_mode, act, 0.0)
+    if cs != mw.split:
+        raise capi.IEError(f"mconv2d_tail: sources carry channels {cs}, weights were packed for {mw.split}")
+    out = torch.empty((n, tail.cout, h, w), device=srcs[0].device, dtype=torch.float32)
+    _count_macs(n, h, w, mw.cout, sum(cs), mw.kh, mw.kw)
+    _count_macs(n, h, w, tail.cout, mw.cout, 1, 1)
+    ptrs = (C.c_void_p * len(srcs))(*[s.data_ptr() for s in srcs])
+    chans = (C.c_int * len(srcs))(*cs)
+    with torch.cuda.device(out.device):
+        capi.check(capi.lib().ie_mconv_tail_nhwc(C.byref(d), ptrs, chans, capi.ptr(mw.w), capi.ptr(mw.b), capi.ptr(tail.w), capi.ptr(tail.b), tail.cout,
+                                                 0 if clamp is None else 1, 0.0 if clamp is None else clamp[0], 0.0 if clamp is None else clamp[1],
+                                                 capi.ptr(out), capi.current_stream()), "ie_mconv_tail_nhwc")
+    return out
+
+
 def depthwise3x3_16(x, w_tap_c: torch.Tensor, bias, act="none", slope=0.0) -> torch.Tensor:
     """16-bit depthwise 3x3 (zero padding 1): ``w_tap_c`` fp32 device tensor [9, C]."""
     _chk16(x)

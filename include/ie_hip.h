@@ -187,6 +187,16 @@ int ie_dsconv_nhwc(ie_mconv_desc* d, const void* const* srcs_dev, const int* cha
 int ie_mconv_pool_nhwc(ie_mconv_desc* d, const void* const* srcs_dev, const int* channels, const void* packed_w_dev, const float* bias_dev,
                        void* dst_dev, void* pool_dst_dev, void* stream);
 
+/* 3x3 conv (+ bias + ReLU) -> 1x1 conv (+ bias, optional clamp) -> NCHW fp32 in one launch: the U-Net head `outc` behind the last DoubleConv
+ * (reference unet.py:186-195, 163).  d describes the 3x3 layer (packed_w_dev / bias_dev as for ie_mconv_nhwc; its output is never written);
+ * tail_w_dev: the 1x1 weights as 16-bit [16][d->Cout] (rows >= tail_cout zero), tail_bias_dev: fp32 [16]; dst: [N, tail_cout, H, W] fp32.
+ * Covered: the strip-kernel layers (k 3, stride 1, pad 1, Cout 32 / 64, ReLU) with W % 4 == 0 and tail_cout <= 16 -- ie_mconv_tail_applicable
+ * says (1 / 0); anything else is IE_ERR_UNSUPPORTED (run ie_mconv_nhwc twice). */
+int ie_mconv_tail_applicable(const ie_mconv_desc* d, const int* channels, int tail_cout);
+int ie_mconv_tail_nhwc(ie_mconv_desc* d, const void* const* srcs_dev, const int* channels, const void* packed_w_dev, const float* bias_dev,
+                       const void* tail_w_dev, const float* tail_bias_dev, int tail_cout, int clamp, float clamp_lo, float clamp_hi,
+                       float* dst_nchw_dev, void* stream);
+
 /* ---- 16-bit (IE_F16 / IE_BF16) NHWC streaming ops between the matrix-core convolutions; IE_F32 forwards to the *_f32
  * entry points above.  On the 16-bit path channel counts are multiples of 8 (a thread moves 8 channels = 16 bytes). */
 int ie_maxpool2x2_nhwc(const void* x_dev, void* y_dev, int dtype, int N, int H, int W, int C, void* stream);

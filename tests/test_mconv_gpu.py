@@ -83,6 +83,49 @@ def test_conv_with_fused_maxpool(cs, co, act, dt, shape):
 
 
 @pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 37, 152), (1, 200, 64), (3, 5, 132), (1, 270, 480)], ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("cs,co,ct,clamp", [([32], 32, 3, (0.0, 1.0)), ([64], 64, 3, None), ([32, 32], 32, 3, (0.0, 1.0)), ([64], 32, 16, None),
+                                            ([64, 64], 64, 1, (-0.5, 0.5))], ids=lambda v: str(v).replace(" ", ""))
+def test_conv_with_fused_1x1_tail(cs, co, ct, clamp, dt, shape):
+    """ie_mconv_tail_nhwc (the U-Net head, unet.py:186-195): 3x3 ReLU conv -> 1x1 conv -> clamp -> NCHW fp32 in one launch equals the two
+    ie_mconv_nhwc calls (same 16-bit rounding of the intermediate, same matrix-core contraction; fp32 summation order may differ)."""
+    tdt = ops.TORCH_DT[dt]
+    n, h, w = shape
+    g = torch.Generator().manual_seed(29)
+    xs = [torch.randn(n, ci, h, w, generator=g).to(tdt).cuda().contiguous(memory_format=CL) for ci in cs]
+    cin = sum(cs)
+    wt = (torch.randn(co, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).to(tdt).float()
+    mw = ops.MConvWeights(wt, torch.randn(co, generator=g), cs, tdt, "cuda")
+    w1 = (torch.randn(ct, co, 1, 1, generator=g) / co ** 0.5).to(tdt).float()
+    b1 = torch.randn(ct, generator=g) * 0.1
+    tail = ops.MTailWeights(w1, b1, tdt, "cuda")
+    assert ops.mconv2d_tail_applicable(xs, mw, tail)
+    got = ops.mconv2d_tail(xs, mw, tail, clamp=clamp)
+    mid = ops.mconv2d(xs, mw, act="relu")
+    want = ops.to_nchw(ops.mconv2d(mid, ops.MConvWeights(w1, b1, [co], tdt, "cuda"), pad=0, clamp=clamp, out_f32=True))
+    assert tuple(got.shape) == (n, ct, h, w) and got.dtype == torch.float32 and got.is_contiguous()
+    assert rel_err(got.cpu(), want.cpu()) <= 2e-6
+    ref = F.conv2d(F.relu(F.conv2d(torch.cat([x.float().cpu() for x in xs], 1), wt, mw.b.cpu(), padding=1)).to(tdt).float(), w1, b1)
+    ref = ref if clamp is None else ref.clamp(*clamp)
+    assert rel_err(got.cpu(), ref) <= (3e-3 if dt == "f16" else 2e-2)       # a 1-ulp difference in the rounded intermediate is amplified by the 1x1
+
+
+def test_fused_1x1_tail_refusals():
+    g = torch.Generator().manual_seed(1)
+    mk = lambda c, w: torch.randn(1, c, 8, w, generator=g).half().cuda().contiguous(memory_format=CL)
+    mw = ops.MConvWeights(torch.randn(32, 32, 3, 3, generator=g), None, [32], torch.float16, "cuda")
+    tail = ops.MTailWeights(torch.randn(3, 32, 1, 1, generator=g), None, torch.float16, "cuda")
+    assert not ops.mconv2d_tail_applicable(mk(32, 150), mw, tail)                 # W % 4 != 0
+    assert not ops.mconv2d_tail_applicable(mk(32, 152), mw, tail, act="none")     # the tail contracts ReLU'd rows
+    wide = ops.MConvWeights(torch.randn(128, 32, 3, 3, generator=g), None, [32], torch.float16, "cuda")
+    assert not ops.mconv2d_tail_applicable(mk(32, 152), wide, ops.MTailWeights(torch.randn(3, 128, 1, 1, generator=g), None, torch.float16, "cuda"))
+    with pytest.raises(capi.IEError):
+        ops.mconv2d_tail(mk(32, 150), mw, tail)
+    with pytest.raises(capi.IEError):
+        ops.MTailWeights(torch.randn(17, 32, 1, 1), None, torch.float16, "cuda")
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
 @pytest.mark.parametrize("c", CASES, ids=_id)
 def test_mconv_vs_torch(c, dt, shape=(2, 37, 45)):
     tdt = ops.TORCH_DT[dt]
