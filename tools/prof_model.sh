@@ -7,4 +7,4 @@ rows=list(csv.reader(open(sys.argv[1])))
 for r in rows[:14]:
     print(r[0][:70], r[1:5])
 PY
-rm -rf $O/kt
+cp "$f" $O/kernel_stats_${1:-unet32}.csv; rm -rf $O/kt
