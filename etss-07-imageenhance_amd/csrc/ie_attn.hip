@@ -92,19 +92,19 @@ __global__ void stats_mean_kernel(const double* __restrict__ stats, float* __res
 
 // y = act(x * scale[n][c] + shift[n][c]); shift may be NULL
 template <typename T>
-__global__ void channel_affine_kernel(const T* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+__global__ void channel_affine_kernel(const T* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift, const T* __restrict__ res,
                                       T* __restrict__ y, size_t hwc, int C, int act, float slope, size_t total) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const size_t n = i / hwc;
     const int c = (int)(i % C);
     const float v = (float)x[i] * scale[n * C + c] + (shift ? shift[n * C + c] : 0.f);
-    y[i] = (T)ie_act_apply(v, act, slope);
+    y[i] = (T)(ie_act_apply(v, act, slope) + (res ? (float)res[i] : 0.f));
 }
 
 template <typename T>
-__global__ void channel_affine_v8_kernel(const T* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift, T* __restrict__ y,
-                                         size_t hwc8, int C8, int act, float slope, size_t total8) {
+__global__ void channel_affine_v8_kernel(const T* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                                         const T* __restrict__ res, T* __restrict__ y, size_t hwc8, int C8, int act, float slope, size_t total8) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;       // one 8-channel group
     if (i >= total8) return;
     const size_t n = i / hwc8;
@@ -113,9 +113,10 @@ __global__ void channel_affine_v8_kernel(const T* __restrict__ x, const float* _
     const t8 v = *(const t8*)(x + i * 8);
     const float* sc = scale + n * (size_t)C8 * 8 + c0;
     const float* sh = shift ? shift + n * (size_t)C8 * 8 + c0 : nullptr;
-    t8 o;
+    t8 o, r;
+    if (res) r = *(const t8*)(res + i * 8);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) o[k] = (T)ie_act_apply((float)v[k] * sc[k] + (sh ? sh[k] : 0.f), act, slope);
+    for (int k = 0; k < 8; ++k) o[k] = (T)(ie_act_apply((float)v[k] * sc[k] + (sh ? sh[k] : 0.f), act, slope) + (res ? (float)r[k] : 0.f));
     *(t8*)(y + i * 8) = o;
 }
 
@@ -191,33 +192,39 @@ IE_EXPORT int ie_stats_mean_f32(const double* stats, float* mean, int N, int C, 
     return IE_OK;
 }
 template <typename T>
-static int channel_affine_impl(const void* x, const float* scale, const float* shift, void* y, int N, int H, int W, int C, int act, float slope,
-                               void* stream) {
+static int channel_affine_impl(const void* x, const float* scale, const float* shift, const void* res, void* y, int N, int H, int W, int C, int act,
+                               float slope, void* stream) {
     if (!x || !scale || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0) IE_FAIL(IE_ERR_INVALID, "ie_channel_affine_nhwc: bad args");
     const size_t hwc = (size_t)H * W * C, total = hwc * N;
     if constexpr (sizeof(T) == 2) {
         if ((C & 7) == 0) {
-            hipLaunchKernelGGL(channel_affine_v8_kernel<T>, dim3(nblk(total / 8)), dim3(256), 0, (hipStream_t)stream, (const T*)x, scale, shift, (T*)y,
-                               hwc / 8, C / 8, act, slope, total / 8);
+            hipLaunchKernelGGL(channel_affine_v8_kernel<T>, dim3(nblk(total / 8)), dim3(256), 0, (hipStream_t)stream, (const T*)x, scale, shift, (const T*)res,
+                               (T*)y, hwc / 8, C / 8, act, slope, total / 8);
             IE_LAUNCH_CHECK();
             return IE_OK;
         }
     }
-    hipLaunchKernelGGL(channel_affine_kernel<T>, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, (const T*)x, scale, shift, (T*)y, hwc, C, act,
-                       slope, total);
+    hipLaunchKernelGGL(channel_affine_kernel<T>, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, (const T*)x, scale, shift, (const T*)res, (T*)y, hwc,
+                       C, act, slope, total);
     IE_LAUNCH_CHECK();
     return IE_OK;
 }
 IE_EXPORT int ie_channel_affine_nhwc_f32(const float* x, const float* scale, const float* shift, float* y, int N, int H, int W, int C, int act,
                                          float slope, void* stream) {
-    return channel_affine_impl<float>(x, scale, shift, y, N, H, W, C, act, slope, stream);
+    return channel_affine_impl<float>(x, scale, shift, nullptr, y, N, H, W, C, act, slope, stream);
 }
 IE_EXPORT int ie_channel_affine_nhwc(const void* x, const float* scale, const float* shift, void* y, int dtype, int N, int H, int W, int C, int act,
                                      float slope, void* stream) {
+    return ie_channel_affine_add_nhwc(x, scale, shift, nullptr, y, dtype, N, H, W, C, act, slope, stream);
+}
+// act(x * scale[n, c] + shift[n, c]) + res: the channel-attention block's gate and its skip connection in one pass (mprnet.py:156-161:
+// `y = self.CA(y); y += x`), one rounding of the fp32 sum
+IE_EXPORT int ie_channel_affine_add_nhwc(const void* x, const float* scale, const float* shift, const void* res, void* y, int dtype, int N, int H, int W,
+                                         int C, int act, float slope, void* stream) {
     switch (dtype) {
-    case IE_F32: return channel_affine_impl<float>(x, scale, shift, y, N, H, W, C, act, slope, stream);
-    case IE_F16: return channel_affine_impl<_Float16>(x, scale, shift, y, N, H, W, C, act, slope, stream);
-    case IE_BF16: return channel_affine_impl<__bf16>(x, scale, shift, y, N, H, W, C, act, slope, stream);
+    case IE_F32: return channel_affine_impl<float>(x, scale, shift, res, y, N, H, W, C, act, slope, stream);
+    case IE_F16: return channel_affine_impl<_Float16>(x, scale, shift, res, y, N, H, W, C, act, slope, stream);
+    case IE_BF16: return channel_affine_impl<__bf16>(x, scale, shift, res, y, N, H, W, C, act, slope, stream);
     default: IE_FAIL(IE_ERR_INVALID, "ie_channel_affine_nhwc: bad dtype");
     }
 }

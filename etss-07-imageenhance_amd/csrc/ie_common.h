@@ -72,6 +72,15 @@ template <typename T> __device__ __forceinline__ unsigned ie_pack2(float lo, flo
     const ie_f32x2 v = {lo, hi};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, t2));
 }
+// the two halves of a dword of 2 x T as floats
+template <typename T> __device__ __forceinline__ float ie_unpack_lo(unsigned v) {
+    typedef __attribute__((ext_vector_type(2))) T t2;
+    return (float)__builtin_bit_cast(t2, v)[0];
+}
+template <typename T> __device__ __forceinline__ float ie_unpack_hi(unsigned v) {
+    typedef __attribute__((ext_vector_type(2))) T t2;
+    return (float)__builtin_bit_cast(t2, v)[1];
+}
 // ... followed by ReLU on the packed pair: negative 16-bit floats have the sign bit set, i.e. are
 // negative as int16, so ReLU == v_pk_max_i16(x, 0) (-0.0 -> +0.0; 2 instructions per 2 outputs).
 template <typename T> __device__ __forceinline__ unsigned ie_pack2_relu(float lo, float hi) {

@@ -464,10 +464,10 @@ __device__ __forceinline__ void mconv3_epilogue(const MConvParams& p, ie_f32x4 (
     const int co = co0 + kc * 4;
     if (co >= p.Cout) return;
     const bool full = ((p.Cout & 3) == 0) && (co + 3 < p.Cout);
-    if constexpr (ACT == IE_ACT_RELU || ACT == IE_ACT_NONE) {
-        // interior tile of a plain Conv(+BN)+ReLU layer -- nearly all of the work: no masks; per accumulator tile 2 packed adds,
-        // 2 cvt_pk (+ 2 packed max), one store through a wave-uniform base pointer and a 32-bit lane offset
-        if (p.sub == 1 && full && !p.res && !p.clamp && !p.out_f32 && oy0 + TH3 <= p.Ho && ox0 + TW <= p.Wo) {
+    if constexpr (ACT == IE_ACT_RELU || ACT == IE_ACT_NONE || ACT == IE_ACT_LRELU) {
+        // interior tile of a plain Conv(+BN)+ReLU / LeakyReLU layer (+ residual add: hinet.py:77, llunetpp.py) -- nearly all of the work: no
+        // masks; per accumulator tile 2 packed adds, 2 cvt_pk (+ 2 packed max), one store through a wave-uniform base pointer and a 32-bit lane offset
+        if (p.sub == 1 && full && !(p.res && p.shuf_c) && !p.clamp && !p.out_f32 && oy0 + TH3 <= p.Ho && ox0 + TW <= p.Wo) {
             // fused PixelShuffle(2) (edsr.py:88-123): the weight rows were packed as [i][j][c], so this wave's 16-cout fragment is 16
             // consecutive channels c of ONE sub-pixel (i, j): out[2 oy + i][2 ox + j][c]
             const int SC = p.shuf_c ? p.shuf_c : p.Cout, SS = p.shuf_c ? 2 : 1;
@@ -485,13 +485,36 @@ __device__ __forceinline__ void mconv3_epilogue(const MConvParams& p, ie_f32x4 (
             const unsigned lane_off16 = (unsigned)(((l16 + 16 * (kc & 1)) * SS * SC + c0 + 4 * (kc & 2)) * (int)sizeof(T));
 #endif
             (void)half_b; (void)lane_off;
+            // residual: read in the layout of the store (16 bytes = 8 channels of one pixel per lane), swapped back to the accumulator layout
+            // (the swap is its own inverse) and added in fp32 behind the activation, before the one rounding
+            const char* rtile = p.res ? (const char*)p.res + (tile - (const char*)p.dst) : nullptr;
+            ie_u32x4 rnext = {0u, 0u, 0u, 0u};          // one row pair ahead: the accumulators leave little room (128 of 256 VGPRs)
+            if (rtile) rnext = *(const ie_u32x4*)(rtile + lane_off16);
+            const float slope = p.slope;
 #pragma unroll
             for (int t = 0; t < NT; t += 2) {
                 ie_u32x2 o[2];
+                ie_u32x2 rp[2] = {ie_u32x2{0u, 0u}, ie_u32x2{0u, 0u}};
+                if (rtile) {
+                    const ie_u32x4 rc = rnext;
+                    if (t + 2 < NT) rnext = *(const ie_u32x4*)(rtile + (unsigned)((t >> 1) + 1) * row_b + lane_off16);
+                    const auto rx = __builtin_amdgcn_permlane16_swap(rc[0], rc[2], false, false);
+                    const auto ry = __builtin_amdgcn_permlane16_swap(rc[1], rc[3], false, false);
+                    rp[0] = ie_u32x2{rx[0], ry[0]}; rp[1] = ie_u32x2{rx[1], ry[1]};
+                }
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const ie_f32x2 v01 = ie_f32x2{acc[t + h][0], acc[t + h][1]} + b01, v23 = ie_f32x2{acc[t + h][2], acc[t + h][3]} + b23;
-                    if constexpr (ACT == IE_ACT_RELU) o[h] = ie_u32x2{ie_pack2_relu<T>(v01[0], v01[1]), ie_pack2_relu<T>(v23[0], v23[1])};
+                    ie_f32x2 v01 = ie_f32x2{acc[t + h][0], acc[t + h][1]} + b01, v23 = ie_f32x2{acc[t + h][2], acc[t + h][3]} + b23;
+                    if constexpr (ACT == IE_ACT_LRELU) {
+                        v01[0] = v01[0] > 0.f ? v01[0] : v01[0] * slope; v01[1] = v01[1] > 0.f ? v01[1] : v01[1] * slope;
+                        v23[0] = v23[0] > 0.f ? v23[0] : v23[0] * slope; v23[1] = v23[1] > 0.f ? v23[1] : v23[1] * slope;
+                    }
+                    if (rtile) {
+                        if constexpr (ACT == IE_ACT_RELU) { v01[0] = fmaxf(v01[0], 0.f); v01[1] = fmaxf(v01[1], 0.f); v23[0] = fmaxf(v23[0], 0.f); v23[1] = fmaxf(v23[1], 0.f); }
+                        v01[0] += ie_unpack_lo<T>(rp[h][0]); v01[1] += ie_unpack_hi<T>(rp[h][0]);
+                        v23[0] += ie_unpack_lo<T>(rp[h][1]); v23[1] += ie_unpack_hi<T>(rp[h][1]);
+                        o[h] = ie_u32x2{ie_pack2<T>(v01[0], v01[1]), ie_pack2<T>(v23[0], v23[1])};
+                    } else if constexpr (ACT == IE_ACT_RELU) o[h] = ie_u32x2{ie_pack2_relu<T>(v01[0], v01[1]), ie_pack2_relu<T>(v23[0], v23[1])};
                     else o[h] = ie_u32x2{ie_pack2<T>(v01[0], v01[1]), ie_pack2<T>(v23[0], v23[1])};
                 }
                 const auto sx = __builtin_amdgcn_permlane16_swap(o[0][0], o[1][0], false, false);
@@ -951,7 +974,7 @@ IE_EXPORT int ie_mconv_pool_nhwc(ie_mconv_desc* d, const void* const* srcs, cons
 // DoubleConv).  The 3x3 conv's rows never reach HBM; the 1x1 contracts them on the matrix cores while they are parked in LDS.
 static bool tail_ok(const ie_mconv_desc* d, const int* channels, int tail_cout) {
     static const int on = getenv("IE_SCONV_TAIL") ? atoi(getenv("IE_SCONV_TAIL")) : 1;           // A/B: 0 = the two separate convs
-    return on && d && channels && !d->pixel_shuffle && d->act == IE_ACT_RELU && (d->W & 3) == 0 && tail_cout >= 1 && tail_cout <= 16 && !d->clamp &&
+    return on && d && channels && !d->pixel_shuffle && d->stride == 1 && d->act == IE_ACT_RELU && (d->W & 3) == 0 && tail_cout >= 1 && tail_cout <= 16 && !d->clamp &&
            d->out_dtype == d->in_dtype &&
            ie_sconv3_applicable(d->nsrc, channels, d->Cout, d->kh, d->kw, d->stride, d->pad, d->pad_mode, d->act, false, false, false, d->W) &&
            (double)tail_cout * d->H * d->W * 4.0 < 2147483647.0;
@@ -974,7 +997,7 @@ IE_EXPORT int ie_mconv_tail_nhwc(ie_mconv_desc* d, const void* const* srcs, cons
     ie_sconv_tail t;
     t.w = tail_w; t.b = tail_bias; t.dst = dst_nchw; t.cout = tail_cout; t.clamp = clamp; t.lo = clamp_lo; t.hi = clamp_hi;
     return ie_sconv3_launch(srcs, channels, d->nsrc, packed_w, bias, nullptr, d->in_dtype, d->N, d->H, d->W, d->Cout, d->act, d->slope, d->pad_mode,
-                            d->src_h, d->src_w, nullptr, &t, (hipStream_t)stream);
+                            d->src_h, d->src_w, nullptr, &t, 1, (hipStream_t)stream);
 }
 
 static int mconv_impl(ie_mconv_desc* d, const void* const* srcs, const int* channels, const void* packed_w, const float* bias, const void* residual,
@@ -992,12 +1015,12 @@ static int mconv_impl(ie_mconv_desc* d, const void* const* srcs, const int* chan
         // narrow 3x3 layers: the strip kernel (weights in registers for the whole launch, an output row stored every step)
         for (int s = 0; s < d->nsrc; ++s)
             if (!srcs[s]) IE_FAIL(IE_ERR_INVALID, "ie_mconv_nhwc: source %d is null", s);
-        d->Ho = d->H; d->Wo = d->W;
+        d->Ho = (d->H + d->stride - 1) / d->stride; d->Wo = (d->W + d->stride - 1) / d->stride;       // k 3, pad 1: ceil(H / stride)
         static const int fuse = getenv("IE_SCONV_POOL") ? atoi(getenv("IE_SCONV_POOL")) : 1;      // A/B: 0 = the separate pool kernel
-        void* pd = (pool_dst && fuse && d->act == IE_ACT_RELU && d->H >= 2 && d->W >= 2) ? pool_dst : nullptr;
+        void* pd = (pool_dst && fuse && d->act == IE_ACT_RELU && d->H >= 2 && d->W >= 2 && d->stride == 1) ? pool_dst : nullptr;
         if (pooled) *pooled = pd != nullptr;
         return ie_sconv3_launch(srcs, channels, d->nsrc, packed_w, bias, dst, d->in_dtype, d->N, d->H, d->W, d->Cout, d->act, d->slope, d->pad_mode,
-                                d->src_h, d->src_w, pd, nullptr, (hipStream_t)stream);
+                                d->src_h, d->src_w, pd, nullptr, d->stride, (hipStream_t)stream);
     }
     MConvParams p;
     memset(&p, 0, sizeof(p));

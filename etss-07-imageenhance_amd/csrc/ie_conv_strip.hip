@@ -40,6 +40,7 @@ struct SConvParams {
     int tail_c, tail_clamp;
     float tail_lo, tail_hi;
     int N, H, W, rows_per_block, strips, chunks;
+    int sub;                 // 1, or 2 = stride 2: every row / column is computed, the even ones are stored (Ho = ceil(H/2), Wo = ceil(W/2))
     int replicate;           // padding_mode="replicate": out-of-image rows / columns are clamped to the edge instead of reading zeros
     float slope;
 };
@@ -102,7 +103,8 @@ __device__ __forceinline__ void sconv3_body(const SConvParams& p) {
     const size_t fb0 = (size_t)p.th[0] * p.tw[0] * p.tps[0], fb1 = (size_t)p.th[1] * p.tw[1] * p.tps[1];
     const auto rs0 = mk((const char*)p.src[0] + (size_t)n * fb0, fb0);
     const auto rs1 = mk((const char*)p.src[1] + (size_t)n * fb1, fb1);
-    const size_t fbo = (size_t)H * W * OPB;
+    const int sub = p.sub, Wo = (W + sub - 1) / sub;
+    const size_t fbo = (size_t)((H + sub - 1) / sub) * Wo * OPB;
     const auto rsd = mk((char*)p.dst + (size_t)n * fbo, fbo);
     const int Hp = H >> 1, Wp = W >> 1;
     const size_t fbp = (size_t)Hp * Wp * OPB;
@@ -208,7 +210,7 @@ __device__ __forceinline__ void sconv3_body(const SConvParams& p) {
 #pragma unroll
     for (int j = 0; j < SPW; ++j) {
         const int q = (SPW * wave + j) * PPI + lane / NPC, c = lane % NPC, xo = x0 + q;
-        st_col[j] = (xo < W) ? (unsigned)(xo * OPB + c * 16) : OOB;
+        st_col[j] = (xo < W && (sub == 1 || !(xo & 1))) ? (unsigned)((xo / sub) * OPB + c * 16) : OOB;
         st_lds[j] = q * OPB + ((c ^ swz(q)) << 4);
     }
     // POOL: this lane's piece of the pooled row: pooled pixel xp (source pixels 2xp, 2xp+1 of the strip), 16-byte piece pc
@@ -299,8 +301,8 @@ __device__ __forceinline__ void sconv3_body(const SConvParams& p) {
         issue_row(it + PF);
         // the row parked in the previous step (finished two steps ago)
         const int yo = ys - 4 + it;
-        const unsigned rmask = ((yo >= ys) && (yo < ye)) ? 0u : OOB;
-        const unsigned row_b = rmask ? 0u : (unsigned)yo * (unsigned)W * OPB;
+        const unsigned rmask = ((yo >= ys) && (yo < ye) && (sub == 1 || !(yo & 1))) ? 0u : OOB;
+        const unsigned row_b = rmask ? 0u : (unsigned)(yo / sub) * (unsigned)Wo * OPB;
         const char* islot = smem + OFF_OUT + (POOL ? (it + 2) % 3 : (it + 1) & 1) * OUT_ROW_B;
         ie_u32x4 ln[SPW];
         frag ta[TT][TKB];
@@ -406,7 +408,10 @@ SConvFn pick_kernel(bool h, int nch, int ncf, int act, bool pool, bool tail) {
 bool ie_sconv3_applicable(int nsrc, const int* cs, int Cout, int kh, int kw, int stride, int pad, int pad_mode, int act, bool residual, bool clamp,
                           bool out_f32, int W) {
     static const int off = getenv("IE_SCONV") ? !atoi(getenv("IE_SCONV")) : 0;      // IE_SCONV=0: A/B switch back to the tiled kernel
-    if (off || kh != 3 || kw != 3 || stride != 1 || pad != 1 || residual || clamp || out_f32) return false;
+    // stride 2 (retinexnet/model.py:60-62) = the stride-1 rows with the even rows / columns stored: 4x the MFMA work at the strip kernel's rate
+    // beats the generic kernel, which computes the same positions at a lower one (RetinexNet 1080p: 0.52 -> 0.30 ms)
+    static const int s2 = getenv("IE_SCONV_S2") ? atoi(getenv("IE_SCONV_S2")) : 1;
+    if (off || kh != 3 || kw != 3 || (stride != 1 && !(stride == 2 && s2)) || pad != 1 || residual || clamp || out_f32) return false;
     if (pad_mode != IE_PAD_ZEROS && pad_mode != IE_PAD_REPLICATE) return false;
     if (act != IE_ACT_NONE && act != IE_ACT_RELU && act != IE_ACT_LRELU) return false;
     if (Cout != 32 && Cout != 64) return false;
@@ -418,7 +423,7 @@ bool ie_sconv3_applicable(int nsrc, const int* cs, int Cout, int kh, int kw, int
 }
 
 int ie_sconv3_launch(const void* const* srcs, const int* cs, int nsrc, const void* wpk, const float* bias, void* dst, int dtype, int N, int H, int W,
-                     int Cout, int act, float slope, int pad_mode, const int* src_h, const int* src_w, void* pool_dst, const ie_sconv_tail* tail, hipStream_t st) {
+                     int Cout, int act, float slope, int pad_mode, const int* src_h, const int* src_w, void* pool_dst, const ie_sconv_tail* tail, int stride, hipStream_t st) {
     SConvParams p;
     memset(&p, 0, sizeof(p));
     int nch = 0;
@@ -429,6 +434,8 @@ int ie_sconv3_launch(const void* const* srcs, const int* cs, int nsrc, const voi
     for (int s = 0; s < nsrc; ++s)
         for (int c0 = 0; c0 < cs[s]; c0 += 32) { p.tsel[nch] = s; p.coff[nch] = c0 * 2; ++nch; }
     if (pool_dst && (act != IE_ACT_RELU || H < 2 || W < 2)) IE_FAIL(IE_ERR_UNSUPPORTED, "ie_sconv3: the fused 2x2 max-pool needs a ReLU conv of at least 2x2 pixels");
+    if (stride != 1 && (stride != 2 || pool_dst || tail)) IE_FAIL(IE_ERR_UNSUPPORTED, "ie_sconv3: stride 1, or 2 without a fused pool / tail");
+    p.sub = stride;
     if (tail) {
         if (pool_dst || act != IE_ACT_RELU || (W & 3) || tail->cout < 1 || tail->cout > 16 || !tail->w || !tail->b || !tail->dst)
             IE_FAIL(IE_ERR_UNSUPPORTED, "ie_sconv3: the fused 1x1 tail needs a ReLU conv, W %% 4 == 0 and at most 16 tail channels");

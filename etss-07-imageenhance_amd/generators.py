@@ -679,7 +679,7 @@ class MPRNet(_GraphModel):
         # the gate is a two-layer perceptron on the pooled vector: fp32 on every path (C/4 channels need not be a multiple of 8)
         a = ops.conv2d(ops.global_avg_pool(y), self._cw(f"{name}.CA.conv_du.0"), pad=0, act="relu")
         a = ops.conv2d(a, self._cw(f"{name}.CA.conv_du.2"), pad=0, act="sigmoid")
-        return ops.add(ops.channel_affine(y, a.reshape(a.shape[0], a.shape[1])), t)
+        return ops.channel_affine(y, a.reshape(a.shape[0], a.shape[1]), residual=t)          # y * gate + x (mprnet.py:156-161), one pass
 
     def _cabs(self, name, t, k=2):
         for i in range(k):

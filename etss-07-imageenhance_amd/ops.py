@@ -296,14 +296,19 @@ def channel_stats(x) -> torch.Tensor:
     return st
 
 
-def channel_affine(x, scale, shift=None, act="none", slope=0.0) -> torch.Tensor:
-    """act(x * scale[n, c] + shift[n, c]) with (N, C) fp32 coefficient tensors; x fp32 or 16-bit (result in x's type)."""
+def channel_affine(x, scale, shift=None, act="none", slope=0.0, residual=None) -> torch.Tensor:
+    """act(x * scale[n, c] + shift[n, c]) (+ residual, same pass, one rounding) with (N, C) fp32 coefficient tensors; x fp32 or 16-bit
+    (result in x's type)."""
     _chk_any(x)
     n, c, h, w = x.shape
+    if residual is not None:
+        _chk_any(residual)
+        if residual.dtype != x.dtype or tuple(residual.shape) != tuple(x.shape):
+            raise capi.IEError("channel_affine: residual must match x")
     y = torch.empty_like(x, memory_format=CL)
     with torch.cuda.device(x.device):
-        capi.check(capi.lib().ie_channel_affine_nhwc(capi.ptr(x), capi.ptr(scale), capi.ptr(shift), capi.ptr(y), _dt(x), n, h, w, c, capi.ACT[act], slope,
-                                                     capi.current_stream()), "ie_channel_affine_nhwc")
+        capi.check(capi.lib().ie_channel_affine_add_nhwc(capi.ptr(x), capi.ptr(scale), capi.ptr(shift), capi.ptr(residual), capi.ptr(y), _dt(x), n, h, w, c,
+                                                         capi.ACT[act], slope, capi.current_stream()), "ie_channel_affine_add_nhwc")
     return y
 
 

@@ -415,6 +415,10 @@ int ie_channel_affine_nhwc_f32(const float* x_dev, const float* scale_dev, const
 int ie_channel_stats_nhwc(const void* x_dev, int dtype, double* stats_dev, int N, int H, int W, int C, void* stream);
 int ie_channel_affine_nhwc(const void* x_dev, const float* scale_dev, const float* shift_dev, void* y_dev, int dtype, int N, int H, int W, int C,
                            int act, float slope, void* stream);
+/* y = act(x * scale + shift) + res in one pass, one rounding of the fp32 sum (res_dev may be NULL): the channel-attention block's gate and its
+ * skip connection (mprnet.py:156-161 `y = self.CA(y); y += x`). */
+int ie_channel_affine_add_nhwc(const void* x_dev, const float* scale_dev, const float* shift_dev, const void* res_dev, void* y_dev, int dtype, int N,
+                               int H, int W, int C, int act, float slope, void* stream);
 int ie_simam_nhwc(const void* x_dev, const double* stats_dev, void* y_dev, int dtype, int N, int H, int W, int C, float lambda, void* stream);
 /* SimAM (src/mon/nn/modules/attention.py:1156-1182) from the statistics of its own input. */
 int ie_simam_nhwc_f32(const float* x_dev, const double* stats_dev, float* y_dev, int N, int H, int W, int C, float lambda, void* stream);

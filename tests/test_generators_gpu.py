@@ -515,6 +515,7 @@ def test_lllinet_vs_oracle_and_stat_layers():
     assert (ops.to_nchw(ops.global_avg_pool(xn)).cpu() - x.mean((2, 3), keepdim=True)).abs().max() <= 1e-6
     sc = torch.rand(2, 24, generator=g)
     assert torch.equal(ops.to_nchw(ops.channel_affine(xn, sc.cuda())).cpu(), x * sc[:, :, None, None])
+    assert (ops.to_nchw(ops.channel_affine(xn, sc.cuda(), residual=ops.to_nhwc((x * 0.5).cuda()))).cpu() - (x * sc[:, :, None, None] + x * 0.5)).abs().max() <= 1e-6
     m = mon_amd.MODELS.build(name="lllinet", seed=9).to("cuda")
     sd = m.state_dict()
     for k in sd:                                                        # non-trivial norm parameters and blend ratios
@@ -602,3 +603,7 @@ def test_channel_stats_and_affine_16bit(dt):
         y = ops.channel_affine(xd, sc.cuda(), sh.cuda(), "lrelu", 0.2)
         ref = F.leaky_relu(x.float() * sc[:, :, None, None] + sh[:, :, None, None], 0.2)
         assert y.dtype == dt and rel_err(y.float().cpu(), ref) <= (1.5e-3 if dt == torch.float16 else 1e-2)
+        # the gate and the skip connection of a channel-attention block in one pass (mprnet.py:156-161): exactly the fp32 sum, rounded once
+        rs = torch.randn(3, c, h, w, generator=g).to(dt)
+        y2 = ops.channel_affine(xd, sc.cuda(), None, residual=rs.cuda().contiguous(memory_format=torch.channels_last))
+        assert y2.dtype == dt and torch.equal(y2.float().cpu(), (x.float() * sc[:, :, None, None] + rs.float()).to(dt).float())

@@ -48,6 +48,9 @@ STRIP_CASES = [
     dict(cs=[64, 64], co=64, k=3, p=1, act="relu"),                   # decoder concat [skip, up] of U-Net-64: four K chunks
     dict(cs=[128], co=64, k=3, p=1),
     dict(cs=[64, 64], co=64, k=3, p=1, act="relu", mode="replicate"), # retinexnet/model.py:62-64
+    dict(cs=[64], co=64, k=3, p=1, s=2, act="relu", mode="replicate"),  # retinexnet/model.py:60: stride 2 = the even rows / columns of the strip kernel
+    dict(cs=[32], co=32, k=3, p=1, s=2),
+    dict(cs=[32, 32], co=64, k=3, p=1, s=2, act="lrelu"),
 ]
 
 
