@@ -20,8 +20,12 @@ constexpr int ROW_PX = TW + 2;
 constexpr int PXB = 64;                    // bytes of one 32-channel chunk of a pixel
 constexpr int SRC_ROW_B = ROW_PX * PXB;    // one ring row of one chunk
 constexpr unsigned OOB = 0x80000000u;
-// ring slots (input rows resident in LDS): 4, or 3 with four K chunks (LDS: 4 chunks x 8.3 KB per row)
-template <int NCH> struct SGeom { static constexpr int NR = NCH == 4 ? 3 : 4, PF = NR - 1; };
+// ring slots (input rows resident in LDS): 4, or 3 with four K chunks (LDS: 4 chunks x 8.3 KB per row) and for 64 -> 32 channels, whose
+// four-wave workgroup then fits twice on a CU (66 KB instead of 83 KB of LDS: one wave per SIMD is too few to hide the row barrier)
+#ifndef IE_SC_NR_C64O32
+#define IE_SC_NR_C64O32 3
+#endif
+template <int NCH, int NCF> struct SGeom { static constexpr int NR = NCH == 4 ? 3 : ((NCH == 2 && NCF == 2) ? IE_SC_NR_C64O32 : 4), PF = NR - 1; };
 
 struct SConvParams {
     const void* src[2];      // the one or two source tensors (virtual concat)
@@ -58,7 +62,7 @@ __device__ __forceinline__ void wait_vm(int n) {
 template <typename T, int NCH, int NCF, int ACT, bool POOL = false, bool TAIL = false>
 __device__ __forceinline__ void sconv3_body(const SConvParams& p) {
     using frag = ie_u32x4;
-    constexpr int NR = SGeom<NCH>::NR, PF = SGeom<NCH>::PF;
+    constexpr int NR = SGeom<NCH, NCF>::NR, PF = SGeom<NCH, NCF>::PF;
     constexpr int NW = NCF * 2;                   // waves
     constexpr int PPW = 8 / NW > 0 ? 8 / NW : 1;  // body DMA pieces (16 pixels x 64 B) per wave, chunk and row
     constexpr int SLOT_B = SRC_ROW_B * NCH;
@@ -468,8 +472,8 @@ int ie_sconv3_launch(const void* const* srcs, const int* cs, int nsrc, const voi
     }
     const long long blocks = (long long)p.strips * p.chunks * N;
     if (blocks <= 0 || blocks > 0x7fffffffLL) IE_FAIL(IE_ERR_INVALID, "ie_sconv3: bad grid");
-    const size_t lds = (size_t)(nch == 4 ? 3 : 4) * SRC_ROW_B * nch + (pool_dst ? 3 : 2) * (size_t)TW * (Cout * 2);
     const int ncf = Cout / 16;
+    const size_t lds = (size_t)(nch == 4 ? 3 : ((nch == 2 && ncf == 2) ? IE_SC_NR_C64O32 : 4)) * SRC_ROW_B * nch + (pool_dst ? 3 : 2) * (size_t)TW * (Cout * 2);
     SConvFn fn = pick_kernel(dtype == IE_F16, nch, ncf, act, pool_dst != nullptr, tail != nullptr);
     static SConvFn granted[64] = {nullptr};
     bool done = false;
