@@ -22,6 +22,15 @@ constexpr int SRC_ROW_B = ROW_PX * PXB;    // one ring row of one chunk
 constexpr unsigned OOB = 0x80000000u;
 // ring slots (input rows resident in LDS): 4, or 3 with four K chunks (LDS: 4 chunks x 8.3 KB per row) and for 64 -> 32 channels, whose
 // four-wave workgroup then fits twice on a CU (66 KB instead of 83 KB of LDS: one wave per SIMD is too few to hide the row barrier)
+#ifndef IE_SC_EARLY_ST
+#define IE_SC_EARLY_ST 1
+#endif
+#ifndef IE_SC_EARLY_ALL
+#define IE_SC_EARLY_ALL 0
+#endif
+#ifndef IE_SC_AHEAD4
+#define IE_SC_AHEAD4 2
+#endif
 #ifndef IE_SC_NR_C64O32
 #define IE_SC_NR_C64O32 3
 #endif
@@ -203,19 +212,19 @@ __device__ __forceinline__ void sconv3_body(const SConvParams& p) {
     auto swz = [&](int q) __attribute__((always_inline)) { return NPC == 8 ? (q & 7) : ((q >> 1) & 3); };
     // lanes l / l+16 exchange halves (v_permlane16_swap), so a lane parks 16 bytes (8 output channels) of ONE pixel: even kq -> tile 2j,
     // odd kq -> tile 2j+1; ds_write_b128 serves 8 lanes per LDS cycle = 8 consecutive pixels x 16 bytes, every bank once
-    int park_off[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int q = 64 * ph + 16 * (2 * j + (kq & 1)) + p16, c = 2 * cf + (kq >> 1);
-        park_off[j] = q * OPB + ((c ^ swz(q)) << 4);
+    int park_off0;              // j = 1 is 32 pixels on: the same swizzle, a constant 32 * OPB bytes away (kept out of a register)
+    {
+        const int q = 64 * ph + 16 * (kq & 1) + p16, c = 2 * cf + (kq >> 1);
+        park_off0 = q * OPB + ((c ^ swz(q)) << 4);
     }
     unsigned st_col[SPW];       // store instruction j of this wave: PPI pixels x OPB bytes, lane = (pixel, 16-byte piece)
-    int st_lds[SPW];
+    int st_lds0;                // instruction j reads PPI pixels on: the same swizzle (PPI is 8 or 16), a constant PPI * OPB bytes away
+    static_assert(SPW == 2 && (PPI == 8 || PPI == 16), "store geometry");
 #pragma unroll
     for (int j = 0; j < SPW; ++j) {
         const int q = (SPW * wave + j) * PPI + lane / NPC, c = lane % NPC, xo = x0 + q;
         st_col[j] = (xo < W && (sub == 1 || !(xo & 1))) ? (unsigned)((xo / sub) * OPB + c * 16) : OOB;
-        st_lds[j] = q * OPB + ((c ^ swz(q)) << 4);
+        if (j == 0) st_lds0 = q * OPB + ((c ^ swz(q)) << 4);
     }
     // POOL: this lane's piece of the pooled row: pooled pixel xp (source pixels 2xp, 2xp+1 of the strip), 16-byte piece pc
     const int pl_xp = tid / NPC, pl_c = tid % NPC;
@@ -269,7 +278,7 @@ __device__ __forceinline__ void sconv3_body(const SConvParams& p) {
         for (int j = 0; j < 2; ++j) {
             const auto sx = __builtin_amdgcn_permlane16_swap(pk[2 * j][0], pk[2 * j + 1][0], false, false);
             const auto sy = __builtin_amdgcn_permlane16_swap(pk[2 * j][1], pk[2 * j + 1][1], false, false);
-            *(ie_u32x4*)(oslot + park_off[j]) = ie_u32x4{sx[0], sy[0], sx[1], sy[1]};
+            *(ie_u32x4*)(oslot + park_off0 + j * 32 * OPB) = ie_u32x4{sx[0], sy[0], sx[1], sy[1]};
         }
 #endif
     };
@@ -289,13 +298,15 @@ __device__ __forceinline__ void sconv3_body(const SConvParams& p) {
                     accM[nt] = ie_mfma16_raw<T>(wA[c * 9 + 1 * 3 + kx], bx, accM[nt]);
                     accO[nt] = ie_mfma16_raw<T>(wA[c * 9 + 2 * 3 + kx], bx, accO[nt]);
                 }
-        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+        // pixel fragments read ahead of the MFMAs that consume them: 3, or 2 with four K chunks (4 VGPRs each; that kernel has none to spare)
+        constexpr int AHEAD = NCH == 4 ? IE_SC_AHEAD4 : 3;
+        __builtin_amdgcn_sched_group_barrier(0x100, AHEAD, 0);
 #pragma unroll
-        for (int f = 0; f < NCH * 12 - 3; ++f) {
+        for (int f = 0; f < NCH * 12 - AHEAD; ++f) {
             __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 3 * AHEAD, 0);
     };
     auto step = [&](int it, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4]) __attribute__((always_inline)) {
         // ops younger than row `it`'s DMA: the (PF-1) L loads of the rows behind it and the SPW (possibly out-of-range) stores every step issues
@@ -317,7 +328,7 @@ __device__ __forceinline__ void sconv3_body(const SConvParams& p) {
                 for (int bk = 0; bk < TKB; ++bk) ta[t][bk] = *(const frag*)(islot + tl_lds[t][bk]);
         } else {
 #pragma unroll
-            for (int j = 0; j < SPW; ++j) ln[j] = *(const ie_u32x4*)(islot + st_lds[j]);
+            for (int j = 0; j < SPW; ++j) ln[j] = *(const ie_u32x4*)(islot + st_lds0 + j * PPI * OPB);
         }
         // POOL: rows yo-1 (parked two steps ago) and yo make pooled row (yo-1)/2 when yo is odd (ys is even)
         ie_u16x8 pv = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -334,8 +345,15 @@ __device__ __forceinline__ void sconv3_body(const SConvParams& p) {
         }
         // the row finished in the previous step is parked before its accumulator set is restarted by this step's MFMAs
         park(accN, smem + OFF_OUT + (POOL ? it % 3 : it & 1) * OUT_ROW_B);
+        // four K chunks: 144 weight + 48 accumulator VGPRs leave no room to carry the row's 8 store registers across the MFMAs (they spilled)
+        constexpr bool EARLY_ST = IE_SC_EARLY_ST && (NCH == 4 || IE_SC_EARLY_ALL) && !TAIL;
+        if constexpr (EARLY_ST) {
+#pragma unroll
+            for (int j = 0; j < SPW; ++j) __builtin_amdgcn_raw_buffer_store_b128(ln[j], rsd, (int)((row_b + st_col[j]) | rmask), 0, 0);
+        }
         row_mfma(it, accN, accM, accO);
-        if constexpr (TAIL) {
+        if constexpr (EARLY_ST) {
+        } else if constexpr (TAIL) {
             const unsigned trow_b = rmask ? 0u : (unsigned)yo * (unsigned)W * 4u;
 #pragma unroll
             for (int t = 0; t < TT; ++t) {
