@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Random-shape parity sweep of the strip form of the narrow 3x3 layers (ie_conv_strip.hip, reached through ie_mconv_nhwc) against torch
 CPU fp32 on the same 16-bit-rounded operands: image sizes around the strip / row-chunk boundaries, every channel / activation / padding
-combination the kernel covers.   python tools/fuzz_sconv.py [seed] [cases]"""
+combination the kernel covers, stride 2, and the fused forms on the rows parked in LDS (2x2 max-pool: bit-exact against F.max_pool2d of
+the plain launch; 1x1 tail: against the two-launch form).   python tools/fuzz_sconv.py [seed] [cases]"""
 import os, random, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -29,15 +30,34 @@ for case in range(n_cases):
     b = torch.randn(co, generator=g) if rnd.random() < 0.7 else None
     xcat = torch.cat([x.float() for x in xs], 1)
     xp = F.pad(xcat, (1,) * 4, mode="replicate") if mode == "replicate" else xcat
-    ref = F.conv2d(xp, wt, b, padding=0 if mode == "replicate" else 1)
+    stride = rnd.choice([1, 1, 1, 2])
+    ref = F.conv2d(xp, wt, b, stride=stride, padding=0 if mode == "replicate" else 1)
     ref = {"none": lambda t: t, "relu": F.relu, "lrelu": lambda t: F.leaky_relu(t, 0.2)}[act](ref)
     mw = ops.MConvWeights(wt, b, cs, dt, "cuda")
-    out = ops.mconv2d([x.cuda().contiguous(memory_format=CL) for x in xs], mw, pad=1, pad_mode=mode, act=act, slope=0.2)
+    xd = [x.cuda().contiguous(memory_format=CL) for x in xs]
+    out = ops.mconv2d(xd, mw, stride=stride, pad=1, pad_mode=mode, act=act, slope=0.2)
+    if stride == 1 and h >= 2:                                  # fused 2x2 max-pool (strip kernel for ReLU layers, conv + pool kernel otherwise)
+        o2, pooled = ops.mconv2d(xd, mw, pad=1, pad_mode=mode, act=act, slope=0.2, pool=True)
+        if not (torch.equal(o2, out) and torch.equal(pooled.float().cpu(), F.max_pool2d(out.float().cpu(), 2))):
+            bad += 1
+            print(f"FAIL pool case {case}: dt={dt} cs={cs} co={co} n={n} h={h} w={w} mode={mode} act={act}")
+    if stride == 1 and act == "relu" and w % 4 == 0:            # fused 1x1 tail
+        ct = rnd.choice([1, 3, 16])
+        w1 = (torch.randn(ct, co, 1, 1, generator=g) / co ** 0.5).to(dt).float()
+        b1 = torch.randn(ct, generator=g) * 0.1
+        tail = ops.MTailWeights(w1, b1, dt, "cuda")
+        if ops.mconv2d_tail_applicable(xd, mw, tail, pad_mode=mode):
+            got = ops.mconv2d_tail(xd, mw, tail, pad_mode=mode, clamp=(0.0, 1.0) if ct == 3 else None)
+            want = ops.to_nchw(ops.mconv2d(out, ops.MConvWeights(w1, b1, [co], dt, "cuda"), pad=0, clamp=(0.0, 1.0) if ct == 3 else None, out_f32=True))
+            e2 = float((got - want).abs().max() / want.abs().max().clamp_min(1e-6))
+            if not e2 <= 2e-6:
+                bad += 1
+                print(f"FAIL tail case {case}: dt={dt} cs={cs} co={co} n={n} h={h} w={w} mode={mode} ct={ct} err={e2:.3e}")
     err = float((out.float().cpu() - ref).abs().max() / ref.abs().max().clamp_min(1e-6))
     tol = 2e-3 if dt == torch.float16 else 1.2e-2
     worst = max(worst, err / tol)
     if not (err <= tol) or tuple(out.shape) != tuple(ref.shape):
         bad += 1
-        print(f"FAIL case {case}: dt={dt} cs={cs} co={co} n={n} h={h} w={w} mode={mode} act={act} bias={b is not None} err={err:.3e}")
+        print(f"FAIL case {case}: dt={dt} cs={cs} co={co} n={n} h={h} w={w} mode={mode} act={act} stride={stride} bias={b is not None} err={err:.3e}")
 print(f"{n_cases} cases, {bad} failures, worst err / tol {worst:.3f}")
 sys.exit(1 if bad else 0)
