@@ -69,6 +69,20 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict
     for (int c = 0; c < Cp; ++c) d[c] = from_f32<T>(c < C ? s[(size_t)c * plane] : 0.f);
 }
 
+// The 16-bit image layout every matrix-core model starts from: up to 8 channels (RGB + zeros) = one 16-byte pixel, one store per thread, so
+// a store instruction covers 1 KiB of whole lines (four pixels per thread = 16-byte pieces 64 bytes apart per instruction measured 4x slower).
+template <typename T>
+__global__ void nchw_to_nhwc8_kernel(const float* __restrict__ src, T* __restrict__ dst, int C, size_t plane, size_t total_px) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total_px) return;
+    const size_t n = i / plane, pix = i % plane;
+    const float* s = src + n * C * plane + pix;
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = c < C ? s[(size_t)c * plane] : 0.f;
+    *(ie_u32x4*)(dst + i * 8) = ie_u32x4{ie_pack2<T>(v[0], v[1]), ie_pack2<T>(v[2], v[3]), ie_pack2<T>(v[4], v[5]), ie_pack2<T>(v[6], v[7])};
+}
+
 template <typename T>
 __global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict__ dst, int C, int Cp, size_t plane,
                                     size_t total_px) {
@@ -180,8 +194,14 @@ IE_EXPORT int ie_nchw_f32_to_nhwc(const float* src, void* dst, ie_dtype dt, int 
     hipStream_t st = (hipStream_t)stream;
     switch (dt) {
     case IE_F32: hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, grid_for(total, 256), 256, 0, st, src, (float*)dst, C, Cp, plane, total); break;
-    case IE_F16: hipLaunchKernelGGL(nchw_to_nhwc_kernel<_Float16>, grid_for(total, 256), 256, 0, st, src, (_Float16*)dst, C, Cp, plane, total); break;
-    case IE_BF16: hipLaunchKernelGGL(nchw_to_nhwc_kernel<__bf16>, grid_for(total, 256), 256, 0, st, src, (__bf16*)dst, C, Cp, plane, total); break;
+    case IE_F16:
+        if (Cp == 8) hipLaunchKernelGGL(nchw_to_nhwc8_kernel<_Float16>, grid_for(total, 256), 256, 0, st, src, (_Float16*)dst, C, plane, total);
+        else hipLaunchKernelGGL(nchw_to_nhwc_kernel<_Float16>, grid_for(total, 256), 256, 0, st, src, (_Float16*)dst, C, Cp, plane, total);
+        break;
+    case IE_BF16:
+        if (Cp == 8) hipLaunchKernelGGL(nchw_to_nhwc8_kernel<__bf16>, grid_for(total, 256), 256, 0, st, src, (__bf16*)dst, C, plane, total);
+        else hipLaunchKernelGGL(nchw_to_nhwc_kernel<__bf16>, grid_for(total, 256), 256, 0, st, src, (__bf16*)dst, C, Cp, plane, total);
+        break;
     default: IE_FAIL(IE_ERR_UNSUPPORTED, "ie_nchw_f32_to_nhwc: dtype %d", (int)dt);
     }
     IE_LAUNCH_CHECK();
