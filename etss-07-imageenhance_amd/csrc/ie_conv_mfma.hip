@@ -1010,8 +1010,9 @@ static int mconv_impl(ie_mconv_desc* d, const void* const* srcs, const int* chan
     Plan pl;
     int rc = make_plan(channels, d->nsrc, d->Cout, d->kh, d->kw, &pl, "ie_mconv_nhwc");
     if (rc != IE_OK) return rc;
-    if (!d->pixel_shuffle && ie_sconv3_applicable(d->nsrc, channels, d->Cout, d->kh, d->kw, d->stride, d->pad, d->pad_mode, d->act, residual != nullptr,
-                                                  d->clamp != 0, d->out_dtype == IE_F32, d->W)) {
+    if (!d->pixel_shuffle && (double)d->H * d->W * 256.0 < 2147483647.0 &&        // the strip kernel addresses a frame with 31-bit buffer offsets
+        ie_sconv3_applicable(d->nsrc, channels, d->Cout, d->kh, d->kw, d->stride, d->pad, d->pad_mode, d->act, residual != nullptr, d->clamp != 0,
+                             d->out_dtype == IE_F32, d->W)) {
         // narrow 3x3 layers: the strip kernel (weights in registers for the whole launch, an output row stored every step)
         for (int s = 0; s < d->nsrc; ++s)
             if (!srcs[s]) IE_FAIL(IE_ERR_INVALID, "ie_mconv_nhwc: source %d is null", s);
