@@ -68,7 +68,7 @@ __device__ __forceinline__ void wait_vm(int n) {
 #undef IE_W
 }
 
-template <typename T, int NCH, int NCF, int ACT, bool POOL = false, bool TAIL = false>
+template <typename T, int NCH, int NCF, int ACT, bool POOL = false, bool TAIL = false, bool SUB2 = false>
 __device__ __forceinline__ void sconv3_body(const SConvParams& p) {
     using frag = ie_u32x4;
     constexpr int NR = SGeom<NCH, NCF>::NR, PF = SGeom<NCH, NCF>::PF;
@@ -286,6 +286,50 @@ __device__ __forceinline__ void sconv3_body(const SConvParams& p) {
     // ---- one input row into the three live accumulator sets (output rows yi+1, yi, yi-1) -------------------------------------------
     auto row_mfma = [&](int it, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4]) __attribute__((always_inline)) {
         const char* slot = smem + (it % NR) * SLOT_B;
+        if constexpr (SUB2) {
+            // stride 2: only the even output rows leave.  An odd input row feeds the even rows above and below it (accN, accO), an even one
+            // its own row (accM): 1.5 of the 3 MFMAs per fragment on average; the skipped sets hold odd rows that are parked but never stored.
+            const bool odd = ((ys - 1 + it) & 1) != 0;
+            if (odd) {
+#pragma unroll
+                for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt) {
+                            const int off = (kx == 0 && nt == 0) ? rd_first : (kx == 2 && nt == 3) ? rd_last : rd_base[kx] + 1024 * nt;
+                            const frag bx = *(const frag*)(slot + c * SRC_ROW_B + off);
+                            accN[nt] = ie_mfma16_raw<T>(wA[c * 9 + 0 * 3 + kx], bx, (c == 0 && kx == 0) ? bias4 : accN[nt]);
+                            accO[nt] = ie_mfma16_raw<T>(wA[c * 9 + 2 * 3 + kx], bx, accO[nt]);
+                        }
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+                for (int f = 0; f < NCH * 12 - 3; ++f) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+            } else {
+#pragma unroll
+                for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt) {
+                            const int off = (kx == 0 && nt == 0) ? rd_first : (kx == 2 && nt == 3) ? rd_last : rd_base[kx] + 1024 * nt;
+                            const frag bx = *(const frag*)(slot + c * SRC_ROW_B + off);
+                            accM[nt] = ie_mfma16_raw<T>(wA[c * 9 + 1 * 3 + kx], bx, accM[nt]);
+                        }
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+                for (int f = 0; f < NCH * 12 - 4; ++f) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int c = 0; c < NCH; ++c)
 #pragma unroll
@@ -396,6 +440,10 @@ typedef void (*SConvFn)(SConvParams);
     __global__ __launch_bounds__(NCF * 128) void sconv3_##TAG##_lrelu(SConvParams p) { sconv3_body<T, NCH, NCF, IE_ACT_LRELU>(p); } \
     __global__ __launch_bounds__(NCF * 128) void sconv3_##TAG##_relu_pool(SConvParams p) { sconv3_body<T, NCH, NCF, IE_ACT_RELU, true>(p); } \
     __global__ __launch_bounds__(NCF * 128) void sconv3_##TAG##_relu_tail(SConvParams p) { sconv3_body<T, NCH, NCF, IE_ACT_RELU, false, true>(p); }
+// stride 2 with the odd rows' MFMAs skipped: the shape RetinexNet uses (retinexnet/model.py:60-62); other stride-2 shapes run the plain kernels
+// (every row computed, the even ones stored)
+__global__ __launch_bounds__(512) void sconv3_f16_c64_o64_relu_s2(SConvParams p) { sconv3_body<_Float16, 2, 4, IE_ACT_RELU, false, false, true>(p); }
+__global__ __launch_bounds__(512) void sconv3_bf16_c64_o64_relu_s2(SConvParams p) { sconv3_body<__bf16, 2, 4, IE_ACT_RELU, false, false, true>(p); }
 IE_DEF_SCONV(f16_c32_o32, _Float16, 1, 2)
 IE_DEF_SCONV(f16_c32_o64, _Float16, 1, 4)
 IE_DEF_SCONV(f16_c64_o32, _Float16, 2, 2)
@@ -493,6 +541,8 @@ int ie_sconv3_launch(const void* const* srcs, const int* cs, int nsrc, const voi
     const int ncf = Cout / 16;
     const size_t lds = (size_t)(nch == 4 ? 3 : ((nch == 2 && ncf == 2) ? IE_SC_NR_C64O32 : 4)) * SRC_ROW_B * nch + (pool_dst ? 3 : 2) * (size_t)TW * (Cout * 2);
     SConvFn fn = pick_kernel(dtype == IE_F16, nch, ncf, act, pool_dst != nullptr, tail != nullptr);
+    static const int s2skip = getenv("IE_SCONV_S2SKIP") ? atoi(getenv("IE_SCONV_S2SKIP")) : 1;      // A/B: 0 = every row computed
+    if (stride == 2 && s2skip && nch == 2 && ncf == 4 && act == IE_ACT_RELU) fn = dtype == IE_F16 ? sconv3_f16_c64_o64_relu_s2 : sconv3_bf16_c64_o64_relu_s2;
     static SConvFn granted[64] = {nullptr};
     bool done = false;
     for (auto f : granted) done = done || f == fn;
