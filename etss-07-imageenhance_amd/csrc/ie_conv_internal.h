@@ -30,6 +30,8 @@ int ie_det_workspace(size_t bytes, void** out);
 // reading ie_mconv_pack_weights' image.  ie_mconv_nhwc asks `applicable` first.
 bool ie_sconv3_applicable(int nsrc, const int* cs, int Cout, int kh, int kw, int stride, int pad, int pad_mode, int act, bool residual, bool clamp,
                           bool out_f32, int W);
+int ie_sconv3_first_launch(const void* img8, const void* w1, const float* b1, const void* wpk2, const float* b2, void* dst, void* pool_dst, int dtype,
+                           int N, int H, int W, int C, hipStream_t st);
 struct ie_sconv_tail {      // 1x1 conv of the ReLU'd rows, fused into the strip kernel (the conv's own output is not written)
     const void* w;          // [16][Cout] 16-bit, rows >= cout zero
     const float* b;         // [16]

@@ -1000,6 +1000,21 @@ IE_EXPORT int ie_mconv_tail_nhwc(ie_mconv_desc* d, const void* const* srcs, cons
                             d->src_h, d->src_w, nullptr, &t, 1, (hipStream_t)stream);
 }
 
+// The first DoubleConv of a U-Net + the MaxPool2d(2) behind it in one launch (unet.py:43-48, 70-72, 152): conv1 = the network's first conv on the
+// 8-channel image (its rows are computed inside the kernel, one row ahead of the second conv, and never reach HBM), conv2 = C -> C.
+IE_EXPORT int ie_mconv_first_applicable(int C, int H, int W) {
+    static const int on = getenv("IE_SCONV_FIRST") ? atoi(getenv("IE_SCONV_FIRST")) : 1;          // A/B: 0 = thin conv + strip conv
+    return (on && (C == 32 || C == 64) && H >= 2 && W >= 64 && (double)H * W * 256.0 < 2147483647.0) ? 1 : 0;
+}
+
+IE_EXPORT int ie_mconv_first_pool_nhwc(int dtype, int N, int H, int W, int C, const void* img8, const void* packed_w1, const float* bias1,
+                                       const void* packed_w2, const float* bias2, void* dst, void* pool_dst, void* stream) {
+    if (!img8 || !packed_w1 || !packed_w2 || !dst || !pool_dst || N <= 0) IE_FAIL(IE_ERR_INVALID, "ie_mconv_first_pool_nhwc: null pointer / bad batch");
+    if (dtype != IE_F16 && dtype != IE_BF16) IE_FAIL(IE_ERR_UNSUPPORTED, "ie_mconv_first_pool_nhwc: f16 / bf16");
+    if (!ie_mconv_first_applicable(C, H, W)) IE_FAIL(IE_ERR_UNSUPPORTED, "ie_mconv_first_pool_nhwc: C 32 / 64, H >= 2, W >= 64 -- ask ie_mconv_first_applicable first");
+    return ie_sconv3_first_launch(img8, packed_w1, bias1, packed_w2, bias2, dst, pool_dst, dtype, N, H, W, C, (hipStream_t)stream);
+}
+
 static int mconv_impl(ie_mconv_desc* d, const void* const* srcs, const int* channels, const void* packed_w, const float* bias, const void* residual,
                       void* dst, void* pool_dst, bool* pooled, void* stream) {
     if (!d || !srcs || !channels || !packed_w || !dst) IE_FAIL(IE_ERR_INVALID, "ie_mconv_nhwc: null pointer");

@@ -53,6 +53,12 @@ struct SConvParams {
     int tail_c, tail_clamp;
     float tail_lo, tail_hi;
     int N, H, W, rows_per_block, strips, chunks;
+    // FIRST kernels: the conv's input rows are not read from HBM but computed in the kernel, one row ahead, by the layer in front of it --
+    // the network's first conv (8-channel image -> 32 NCH channels, 3x3, zero padding, bias + ReLU; unet.py:43-48 `inc`): the first DoubleConv
+    // in one launch, its intermediate never in HBM.
+    const void* img;         // NHWC 8-channel image (16 bytes per pixel)
+    const void* w1;          // ie_mconv_pack_weights image of the first conv (thin form: [ky][32 NCH rows][k = kx * 8 + channel])
+    const float* b1;         // [32 NCH] or null
     int sub;                 // 1, or 2 = stride 2: every row / column is computed, the even ones are stored (Ho = ceil(H/2), Wo = ceil(W/2))
     int replicate;           // padding_mode="replicate": out-of-image rows / columns are clamped to the edge instead of reading zeros
     float slope;
@@ -68,7 +74,7 @@ __device__ __forceinline__ void wait_vm(int n) {
 #undef IE_W
 }
 
-template <typename T, int NCH, int NCF, int ACT, bool POOL = false, bool TAIL = false, bool SUB2 = false>
+template <typename T, int NCH, int NCF, int ACT, bool POOL = false, bool TAIL = false, bool SUB2 = false, bool FIRST = false>
 __device__ __forceinline__ void sconv3_body(const SConvParams& p) {
     using frag = ie_u32x4;
     constexpr int NR = SGeom<NCH, NCF>::NR, PF = SGeom<NCH, NCF>::PF;
@@ -93,6 +99,11 @@ __device__ __forceinline__ void sconv3_body(const SConvParams& p) {
     constexpr int TKB = NCF / 2;                  // TAIL: 32-channel blocks of the 1x1 conv's K (= this conv's Cout)
     constexpr int TT = 8 / NW;                    // TAIL: 16-pixel tiles of the strip per wave; TT * TKB == 2
     constexpr int NST = TAIL ? TT : SPW + (POOL ? 1 : 0);       // store instructions a wave issues per step
+    // FIRST: image rows (132 pixels x 16 bytes, three 1-KiB DMA instructions) in their own ring; image row k = ys - 2 + k; the input row of
+    // step it + 1 (x1 row ys + it) comes from image rows k = it + 1 .. it + 3 while the DMA of row it + 3 + PF is in flight
+    constexpr int NF1 = 2 * NCH, IMG_SLOT_B = 3072, NRI = PF + 3;
+    constexpr int OFF_IMG = OFF_OUT + (POOL ? 3 : 2) * OUT_ROW_B;
+    static_assert(!FIRST || (NW == 2 * NF1 && ACT == IE_ACT_RELU && !SUB2 && !TAIL), "FIRST: one conv1 fragment and half of the nine tiles per wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -192,8 +203,64 @@ __device__ __forceinline__ void sconv3_body(const SConvParams& p) {
             }
         }
     };
-    const int L = (PPW * wave < 8 ? PPW : 0) * NCH + (wave == NW - 1 ? NCH : 0);
+    const int L = FIRST ? (wave < 3 ? 1 : 0) : (PPW * wave < 8 ? PPW : 0) * NCH + (wave == NW - 1 ? NCH : 0);
     const int wait_n = (PF - 1) * L;
+
+    // ---- FIRST: the image ring and the first conv --------------------------------------------------------------------------------
+    const size_t fbi = (size_t)H * W * 16;
+    const auto rsi = mk(FIRST ? (const char*)p.img + (size_t)n * fbi : (const char*)p.dst, FIRST ? fbi : 0);
+    auto issue_img = [&](int k) __attribute__((always_inline)) {
+        if (wave >= 3) return;
+        const int m = ys - 2 + k, j = 64 * wave + lane, x = x0 - 2 + j;        // image row, pixel of the slot, image column
+        const bool ok = m >= 0 && m < H && j < 132 && x >= 0 && x < W;
+        const unsigned off = ok ? (unsigned)((m * W + x) * 16) : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsi, (__attribute__((address_space(3))) void*)(smem + OFF_IMG + (k % NRI) * IMG_SLOT_B + wave * 1024), 16,
+                                                 (int)off, 0, 0, 0);
+    };
+    // this wave: conv1 cout fragment f1 (16 of the 32 NCH channels), tiles 5 tg1 .. 5 tg1 + 4 of the nine 16-pixel tiles of a ring row (eight of
+    // the body, one with the two halo pixels).  K = 32 = (kx 0..3) x 8 channels (the fourth tap has zero weights): lane (p16, kq) reads the 16
+    // bytes of image pixel x - 1 + kq, one MFMA per kernel row -- the thin kernel's contraction (same order: ky 0, 1, 2; bias and ReLU behind it)
+    const int f1 = wave % NF1, tg1 = wave / NF1;
+    frag w1f[3];
+    float b1v[4] = {0.f, 0.f, 0.f, 0.f};
+    int img_off[5], ring_off[5];
+    unsigned colok = 0;
+    if constexpr (FIRST) {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+            w1f[ky] = *(const frag*)((const char*)p.w1 + ((size_t)(ky * 16 * NF1 + 16 * f1 + p16)) * 64 + ((kq ^ ((p16 >> 1) & 3)) << 4));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) b1v[i] = p.b1 ? p.b1[16 * f1 + 4 * kq + i] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int t = 5 * tg1 + u;
+            const int q = t < 8 ? 16 * t + p16 : 128 + (p16 & 1);                  // ring pixel (tile 8: lanes p16 >= 2 shadow the two halo pixels, no write)
+            const int rel = q < 128 ? q : (q == 128 ? -1 : 128);                     // column relative to x0
+            img_off[u] = (rel + 1 + kq) * 16;
+            const int c = f1 >> 1, piece = 2 * (f1 & 1) + (kq >> 1);
+            ring_off[u] = c * SRC_ROW_B + q * PXB + ((piece ^ ((q >> 1) & 3)) << 4) + (kq & 1) * 8;
+            const int x = x0 + rel;
+            if (x >= 0 && x < W && t < 9 && (t < 8 || p16 < 2)) colok |= 1u << u;
+        }
+    }
+    auto conv1_row = [&](int it) __attribute__((always_inline)) {          // x1 row ys + it -> ring slot (it + 1) % NR, from image rows k = it + 1 .. it + 3
+        const int r = ys + it;
+        const bool rv = r >= 0 && r < H;                                     // rows outside the image are the second conv's zero padding, not conv1 of padding
+        char* slot = smem + ((it + 1) % NR) * SLOT_B;
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            if (5 * tg1 + u >= 9) break;
+            ie_f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const frag bx = *(const frag*)(smem + OFF_IMG + ((it + 1 + ky) % NRI) * IMG_SLOT_B + img_off[u]);
+                a = ie_mfma16_raw<T>(w1f[ky], bx, a);
+            }
+            ie_u32x2 o = {ie_pack2_relu<T>(a[0] + b1v[0], a[1] + b1v[1]), ie_pack2_relu<T>(a[2] + b1v[2], a[3] + b1v[3])};
+            if (!rv || !((colok >> u) & 1u)) o = ie_u32x2{0u, 0u};
+            if (5 * tg1 + u < 8 || p16 < 2) *(ie_u32x2*)(slot + ring_off[u]) = o;
+        }
+    };
 
     // ---- LDS read offsets of the B operand ------------------------------------------------------------------------------------
     auto lds_px = [&](int q) __attribute__((always_inline)) { return q * PXB + ((kq ^ ((q >> 1) & 3)) << 4); };
@@ -357,7 +424,8 @@ __device__ __forceinline__ void sconv3_body(const SConvParams& p) {
         if (L) wait_vm(wait_n + NST * (it < PF ? it : PF));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this wave's parked pieces of the previous step
         __builtin_amdgcn_s_barrier();
-        issue_row(it + PF);
+        if constexpr (FIRST) issue_img(it + 3 + PF);
+        else issue_row(it + PF);
         // the row parked in the previous step (finished two steps ago)
         const int yo = ys - 4 + it;
         const unsigned rmask = ((yo >= ys) && (yo < ye) && (sub == 1 || !(yo & 1))) ? 0u : OOB;
@@ -416,10 +484,19 @@ __device__ __forceinline__ void sconv3_body(const SConvParams& p) {
         }
         if constexpr (POOL)       // every step issues it (out of range when there is no pooled row): the counted waits stay uniform
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ie_u32x4, pv), rsp, (int)((prow_b + pl_col) | pmask), 0, 0);
+        if constexpr (FIRST) conv1_row(it);      // next step's input row; the ring slot it fills was last read two steps ago
     };
 
+    if constexpr (FIRST) {
 #pragma unroll
-    for (int it = 0; it < PF; ++it) issue_row(it);
+        for (int k = 0; k < PF + 3; ++k) issue_img(k);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        conv1_row(-1);                           // x1 row ys - 1 for step 0 (the barrier at the head of step 0 publishes it)
+    } else {
+#pragma unroll
+        for (int it = 0; it < PF; ++it) issue_row(it);
+    }
     ie_f32x4 a0[4], a1[4], a2[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) { a0[nt] = bias4; a1[nt] = bias4; a2[nt] = bias4; }
@@ -440,6 +517,11 @@ typedef void (*SConvFn)(SConvParams);
     __global__ __launch_bounds__(NCF * 128) void sconv3_##TAG##_lrelu(SConvParams p) { sconv3_body<T, NCH, NCF, IE_ACT_LRELU>(p); } \
     __global__ __launch_bounds__(NCF * 128) void sconv3_##TAG##_relu_pool(SConvParams p) { sconv3_body<T, NCH, NCF, IE_ACT_RELU, true>(p); } \
     __global__ __launch_bounds__(NCF * 128) void sconv3_##TAG##_relu_tail(SConvParams p) { sconv3_body<T, NCH, NCF, IE_ACT_RELU, false, true>(p); }
+// the first DoubleConv of a U-Net (3 -> 32 / 64 -> 32 / 64 channels, + pooled copy) in one launch
+__global__ __launch_bounds__(256) void sconv3_f16_c32_o32_relu_pool_first(SConvParams p) { sconv3_body<_Float16, 1, 2, IE_ACT_RELU, true, false, false, true>(p); }
+__global__ __launch_bounds__(256) void sconv3_bf16_c32_o32_relu_pool_first(SConvParams p) { sconv3_body<__bf16, 1, 2, IE_ACT_RELU, true, false, false, true>(p); }
+__global__ __launch_bounds__(512) void sconv3_f16_c64_o64_relu_pool_first(SConvParams p) { sconv3_body<_Float16, 2, 4, IE_ACT_RELU, true, false, false, true>(p); }
+__global__ __launch_bounds__(512) void sconv3_bf16_c64_o64_relu_pool_first(SConvParams p) { sconv3_body<__bf16, 2, 4, IE_ACT_RELU, true, false, false, true>(p); }
 // stride 2 with the odd rows' MFMAs skipped: the shape RetinexNet uses (retinexnet/model.py:60-62); other stride-2 shapes run the plain kernels
 // (every row computed, the even ones stored)
 __global__ __launch_bounds__(512) void sconv3_f16_c64_o64_relu_s2(SConvParams p) { sconv3_body<_Float16, 2, 4, IE_ACT_RELU, false, false, true>(p); }
@@ -490,6 +572,53 @@ bool ie_sconv3_applicable(int nsrc, const int* cs, int Cout, int kh, int kw, int
     if (nsrc == 1) return cs[0] == 32 || cs[0] == 64 || (wide && cs[0] == 128 && Cout == 64);
     if (nsrc != 2) return false;
     return (cs[0] == 32 && cs[1] == 32) || (wide && cs[0] == 64 && cs[1] == 64 && Cout == 64);
+}
+
+// The first DoubleConv (+ 2x2 max-pool) of a U-Net in one launch: conv1 8 -> C (thin packing), conv2 C -> C, C = 32 or 64, both 3x3 / zero padding /
+// bias / ReLU.  img8: NHWC 8-channel image; dst: NHWC C channels; pool_dst: its pooled copy.
+int ie_sconv3_first_launch(const void* img8, const void* w1, const float* b1, const void* wpk2, const float* b2, void* dst, void* pool_dst, int dtype,
+                           int N, int H, int W, int C, hipStream_t st) {
+    if (!img8 || !w1 || !wpk2 || !dst || !pool_dst || (C != 32 && C != 64) || H < 2 || W < 64 || N <= 0) IE_FAIL(IE_ERR_UNSUPPORTED, "ie_sconv3_first: C 32 / 64, W >= 64, H >= 2");
+    if ((double)H * W * 256.0 >= 2147483647.0) IE_FAIL(IE_ERR_UNSUPPORTED, "ie_sconv3_first: frame too large for 31-bit offsets");
+    SConvParams p;
+    memset(&p, 0, sizeof(p));
+    const int nch = C / 32, ncf = C / 16;
+    p.img = img8; p.w1 = w1; p.b1 = b1; p.wpk = wpk2; p.bias = b2; p.dst = dst; p.pool = pool_dst; p.N = N; p.H = H; p.W = W; p.sub = 1;
+    p.th[0] = p.th[1] = H; p.tw[0] = p.tw[1] = W;
+    p.strips = ie_cdiv(W, TW);
+    {
+        const int slots = 256 * (C == 64 ? 1 : 2);
+        const long long base = (long long)p.strips * N;
+        int best_c = 1;
+        double best = -1.0;
+        for (int c = 1; c <= H / 16 + 1 && c <= 64; ++c) {
+            int rpb = ie_cdiv(H, c);
+            rpb += rpb & 1;
+            const int cc = ie_cdiv(H, rpb);
+            const long long blocks = base * cc;
+            const long long rounds = (blocks + slots - 1) / slots;
+            const double score = (double)blocks / (double)(rounds * slots) * ((double)rpb / (double)(rpb + 4));
+            if (score > best + 1e-9) { best = score; best_c = cc; }
+        }
+        p.rows_per_block = ie_cdiv(H, best_c);
+        p.rows_per_block += p.rows_per_block & 1;
+        p.chunks = ie_cdiv(H, p.rows_per_block);
+    }
+    const long long blocks = (long long)p.strips * p.chunks * N;
+    if (blocks <= 0 || blocks > 0x7fffffffLL) IE_FAIL(IE_ERR_INVALID, "ie_sconv3_first: bad grid");
+    const size_t lds = (size_t)4 * SRC_ROW_B * nch + 3 * (size_t)TW * (C * 2) + (size_t)6 * 3072;       // NR = 4 (PF = 3), three parked rows, NRI = PF + 3 image rows
+    SConvFn fn = C == 32 ? (dtype == IE_F16 ? sconv3_f16_c32_o32_relu_pool_first : sconv3_bf16_c32_o32_relu_pool_first)
+                         : (dtype == IE_F16 ? sconv3_f16_c64_o64_relu_pool_first : sconv3_bf16_c64_o64_relu_pool_first);
+    static SConvFn granted[4] = {nullptr};
+    bool done = false;
+    for (auto f : granted) done = done || f == fn;
+    if (!done) {
+        IE_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        for (auto& f : granted) if (!f) { f = fn; break; }
+    }
+    hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(ncf * 128), lds, st, p);
+    IE_LAUNCH_CHECK();
+    return IE_OK;
 }
 
 int ie_sconv3_launch(const void* const* srcs, const int* cs, int nsrc, const void* wpk, const float* bias, void* dst, int dtype, int N, int H, int W,

@@ -113,6 +113,23 @@ class _GraphModel(ImageEnhancementModel):
                         residual=residual, clamp=clamp, out_f32=out_f32, pool=pool)
         return ops.pixel_shuffle(y, shuffle) if (shuffle and not fuse) else y
 
+    def _mw_plain(self, split, name, bn=None):
+        """The cached ie_mconv_nhwc weights of conv ``name`` (+ folded ``bn``) for sources of ``split`` channels -- the entry ``_conv`` builds
+        for a plain call (an image source carried as 8 channels gets zero weights for the padding channels)."""
+        split = tuple(int(c) for c in split)
+        key = ("mconv", name, bn, split, None, None, False, None, False)
+        if self._dev_cache is None:
+            self._dev_cache = {}
+        if key not in self._dev_cache:
+            w, b = self._wb(name, bn)
+            cin_map = None
+            if sum(split) != w.shape[1]:
+                if len(split) != 1 or w.shape[1] > split[0]:
+                    raise capi.IEError(f"{name}: sources carry {split} channels, weights expect {w.shape[1]}")
+                cin_map = list(range(w.shape[1])) + [-1] * (split[0] - w.shape[1])
+            self._dev_cache[key] = ops.MConvWeights(w, b, split, self._tdt, self.device, cin_map)
+        return self._dev_cache[key]
+
     def _conv_tail(self, srcs, name, bn, tail_name, clamp=None):
         """``clamp(conv1x1 tail_name (relu(conv3x3 name + folded bn)))`` as NCHW fp32 in ONE launch on the 16-bit path (the 3x3 layer's output
         never reaches HBM), or None where the one-launch form does not cover the pair (fp32 path, wide layers, W % 4 != 0)."""
@@ -851,7 +868,14 @@ class UNet(_GraphModel):
 
     def forward(self, datapoint: dict, *args, **kwargs) -> dict:
         x = self._input_any(datapoint)
-        x1, p1 = self._dc("inc", [x], pool=True)
+        x1 = None
+        if self.compute_dtype != "f32" and x.shape[1] == 8:       # the first DoubleConv + its pool as one launch (conv1's output stays in the kernel)
+            mw1 = self._mw_plain((8,), "inc.conv1", "inc.norm1")
+            mw2 = self._mw_plain((self._f[0],), "inc.conv2", "inc.norm2")
+            if ops.mconv2d_first_pool_applicable(x, mw1, mw2):
+                x1, p1 = ops.mconv2d_first_pool(x, mw1, mw2)
+        if x1 is None:
+            x1, p1 = self._dc("inc", [x], pool=True)
         x2, p2 = self._dc("down1.conv", [p1], pool=True)
         x3, p3 = self._dc("down2.conv", [p2], pool=True)
         x4, p4 = self._dc("down3.conv", [p3], pool=True)

@@ -798,6 +798,32 @@ def mconv2d(srcs, mw: MConvWeights, stride=1, pad=1, pad_mode="zeros", act="none
     return out
 
 
+def mconv2d_first_pool_applicable(x8, mw1: MConvWeights, mw2: MConvWeights) -> bool:
+    """Does the one-launch first DoubleConv (+ pool) cover these two layers?  (8-channel image, 3x3 -> C -> C with C 32 / 64, ReLU both)"""
+    c = mw1.cout
+    if not (mw1.split == [8] and mw2.split == [c] and mw2.cout == c and mw1.kh == mw1.kw == mw2.kh == mw2.kw == 3 and mw1.dtype == mw2.dtype == x8.dtype
+            and not getattr(mw1, "shuffle", 0) and not getattr(mw2, "shuffle", 0) and x8.shape[1] == 8):
+        return False
+    return bool(capi.lib().ie_mconv_first_applicable(c, int(x8.shape[2]), int(x8.shape[3])))
+
+
+def mconv2d_first_pool(x8, mw1: MConvWeights, mw2: MConvWeights):
+    """``y = relu(conv2(relu(conv1(x8))))`` and ``F.max_pool2d(y, 2)`` in one launch (unet.py:43-48, 70-72, 152); the conv1 output never reaches HBM."""
+    _chk16(x8)
+    if not mconv2d_first_pool_applicable(x8, mw1, mw2):
+        raise capi.IEError("mconv2d_first_pool: not covered (8-channel image, 3x3 convs 8 -> C -> C with C 32 / 64, W >= 64)")
+    n, _, h, w = x8.shape
+    c = mw1.cout
+    out = torch.empty((n, c, h, w), device=x8.device, dtype=x8.dtype, memory_format=CL)
+    pooled = torch.empty((n, c, h // 2, w // 2), device=x8.device, dtype=x8.dtype, memory_format=CL)
+    _count_macs(n, h, w, c, 8, 3, 3)
+    _count_macs(n, h, w, c, c, 3, 3)
+    with torch.cuda.device(out.device):
+        capi.check(capi.lib().ie_mconv_first_pool_nhwc(IE_DT[x8.dtype], n, h, w, c, capi.ptr(x8), capi.ptr(mw1.w), capi.ptr(mw1.b), capi.ptr(mw2.w),
+                                                       capi.ptr(mw2.b), capi.ptr(out), capi.ptr(pooled), capi.current_stream()), "ie_mconv_first_pool_nhwc")
+    return out, pooled
+
+
 class MTailWeights:
     """A 1x1 Conv2d (at most 16 output channels) that ie_mconv_tail_nhwc contracts behind a narrow 3x3 ReLU layer: 16-bit [16][Cin]
     (rows >= Cout zero) + fp32 bias [16]."""

@@ -187,6 +187,15 @@ int ie_dsconv_nhwc(ie_mconv_desc* d, const void* const* srcs_dev, const int* cha
 int ie_mconv_pool_nhwc(ie_mconv_desc* d, const void* const* srcs_dev, const int* channels, const void* packed_w_dev, const float* bias_dev,
                        void* dst_dev, void* pool_dst_dev, void* stream);
 
+/* The first DoubleConv of a U-Net and the MaxPool2d(2) behind it in one launch (reference unet.py:43-48 DoubleConvBlock, :70-72 Down, :152 `inc`):
+ * conv1 = 3x3 / zero padding 1 / bias / ReLU on the 8-channel 16-bit image (img8_dev: NHWC, 16 bytes per pixel; packed_w1_dev from
+ * ie_mconv_pack_weights with channels = {8}, Cout = C), conv2 = 3x3 C -> C / bias / ReLU (packed_w2_dev: channels = {C}).  C = 32 or 64; the
+ * C-channel intermediate is computed row by row inside the kernel and never reaches HBM.  dst_dev: NHWC [N,H,W,C]; pool_dst_dev: [N,H/2,W/2,C].
+ * ie_mconv_first_applicable says (1 / 0) whether a shape is covered; the caller otherwise runs ie_mconv_nhwc + ie_mconv_pool_nhwc. */
+int ie_mconv_first_applicable(int C, int H, int W);
+int ie_mconv_first_pool_nhwc(int dtype, int N, int H, int W, int C, const void* img8_dev, const void* packed_w1_dev, const float* bias1_dev,
+                             const void* packed_w2_dev, const float* bias2_dev, void* dst_dev, void* pool_dst_dev, void* stream);
+
 /* 3x3 conv (+ bias + ReLU) -> 1x1 conv (+ bias, optional clamp) -> NCHW fp32 in one launch: the U-Net head `outc` behind the last DoubleConv
  * (reference unet.py:186-195, 163).  d describes the 3x3 layer (packed_w_dev / bias_dev as for ie_mconv_nhwc; its output is never written);
  * tail_w_dev: the 1x1 weights as 16-bit [16][d->Cout] (rows >= tail_cout zero), tail_bias_dev: fp32 [16]; dst: [N, tail_cout, H, W] fp32.

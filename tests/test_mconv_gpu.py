@@ -113,6 +113,31 @@ def test_conv_with_fused_1x1_tail(cs, co, ct, clamp, dt, shape):
     assert rel_err(got.cpu(), ref) <= (3e-3 if dt == "f16" else 2e-2)       # a 1-ulp difference in the rounded intermediate is amplified by the 1x1
 
 
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 37, 150), (1, 200, 64), (3, 6, 129), (1, 270, 480), (2, 2, 66)], ids=lambda s: "x".join(map(str, s)))
+@pytest.mark.parametrize("c", [32, 64])
+def test_first_double_conv_with_pool(c, dt, shape):
+    """ie_mconv_first_pool_nhwc (unet.py:43-48, 70-72, 152): first conv (8-channel image -> C) + second conv (C -> C) + 2x2 max-pool in one
+    launch equals the thin-kernel conv followed by the strip conv with its fused pool -- the same contraction order, roundings and padding
+    (the intermediate's rows outside the image are zeros, not conv1 of the padding), so bit for bit."""
+    tdt = ops.TORCH_DT[dt]
+    n, h, w = shape
+    g = torch.Generator().manual_seed(31)
+    img = torch.rand(n, 3, h, w, generator=g)
+    x8 = ops.to_nhwc16(img.cuda(), tdt, 8)
+    w1 = (torch.randn(c, 3, 3, 3, generator=g) / 27 ** 0.5).to(tdt).float()
+    w2 = (torch.randn(c, c, 3, 3, generator=g) / (c * 9) ** 0.5).to(tdt).float()
+    mw1 = ops.MConvWeights(w1, torch.randn(c, generator=g) * 0.2, [8], tdt, "cuda", cin_map=[0, 1, 2, -1, -1, -1, -1, -1])
+    mw2 = ops.MConvWeights(w2, torch.randn(c, generator=g) * 0.2, [c], tdt, "cuda")
+    assert ops.mconv2d_first_pool_applicable(x8, mw1, mw2)
+    out, pooled = ops.mconv2d_first_pool(x8, mw1, mw2)
+    mid = ops.mconv2d(x8, mw1, act="relu")
+    want, want_p = ops.mconv2d(mid, mw2, act="relu", pool=True)
+    assert torch.equal(out, want) and torch.equal(pooled, want_p)
+    ref = F.relu(F.conv2d(F.relu(F.conv2d(x8[:, :3].float().cpu(), w1, mw1.b.cpu(), padding=1)).to(tdt).float(), w2, mw2.b.cpu(), padding=1))
+    assert rel_err(out.float().cpu(), ref) <= (3e-3 if dt == "f16" else 2e-2)
+
+
 def test_fused_1x1_tail_refusals():
     g = torch.Generator().manual_seed(1)
     mk = lambda c, w: torch.randn(1, c, 8, w, generator=g).half().cuda().contiguous(memory_format=CL)
