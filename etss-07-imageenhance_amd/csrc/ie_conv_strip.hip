@@ -25,6 +25,9 @@ constexpr unsigned OOB = 0x80000000u;
 #ifndef IE_SC_EARLY_ST
 #define IE_SC_EARLY_ST 1
 #endif
+#ifndef IE_SC_FIRST_EARLY
+#define IE_SC_FIRST_EARLY 1
+#endif
 #ifndef IE_SC_EARLY_ALL
 #define IE_SC_EARLY_ALL 0
 #endif
@@ -458,6 +461,11 @@ __device__ __forceinline__ void sconv3_body(const SConvParams& p) {
         // the row finished in the previous step is parked before its accumulator set is restarted by this step's MFMAs
         park(accN, smem + OFF_OUT + (POOL ? it % 3 : it & 1) * OUT_ROW_B);
         // four K chunks: 144 weight + 48 accumulator VGPRs leave no room to carry the row's 8 store registers across the MFMAs (they spilled)
+        if constexpr (FIRST && IE_SC_FIRST_EARLY) {      // next step's input row, ahead of this row's MFMAs (its LDS-read -> MFMA -> write chains then run under them)
+            __builtin_amdgcn_sched_barrier(0);
+            conv1_row(it);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         constexpr bool EARLY_ST = IE_SC_EARLY_ST && (NCH == 4 || IE_SC_EARLY_ALL) && !TAIL;
         if constexpr (EARLY_ST) {
 #pragma unroll
@@ -484,7 +492,7 @@ __device__ __forceinline__ void sconv3_body(const SConvParams& p) {
         }
         if constexpr (POOL)       // every step issues it (out of range when there is no pooled row): the counted waits stay uniform
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ie_u32x4, pv), rsp, (int)((prow_b + pl_col) | pmask), 0, 0);
-        if constexpr (FIRST) conv1_row(it);      // next step's input row; the ring slot it fills was last read two steps ago
+        if constexpr (FIRST && !IE_SC_FIRST_EARLY) conv1_row(it);      // next step's input row; the ring slot it fills was last read two steps ago
     };
 
     if constexpr (FIRST) {

@@ -59,5 +59,22 @@ for case in range(n_cases):
     if not (err <= tol) or tuple(out.shape) != tuple(ref.shape):
         bad += 1
         print(f"FAIL case {case}: dt={dt} cs={cs} co={co} n={n} h={h} w={w} mode={mode} act={act} stride={stride} bias={b is not None} err={err:.3e}")
+# the first DoubleConv (+ pool) in one launch against thin conv + strip conv (+ fused pool): bit for bit
+for case in range(n_cases // 4):
+    dt = rnd.choice([torch.float16, torch.bfloat16])
+    c = rnd.choice([32, 64])
+    n = rnd.randint(1, 3)
+    h = rnd.choice([2, 3, 5, 16, 17, 23, 24, 25, 47, 48, 49, rnd.randint(2, 120)])
+    w = rnd.choice([64, 65, 127, 128, 129, 130, 255, 256, 257, rnd.randint(64, 400)])
+    g = torch.Generator().manual_seed(5000 + case)
+    x8 = ops.to_nhwc16(torch.rand(n, 3, h, w, generator=g).cuda(), dt, 8)
+    mw1 = ops.MConvWeights((torch.randn(c, 3, 3, 3, generator=g) / 27 ** 0.5), torch.randn(c, generator=g) * 0.2 if rnd.random() < 0.7 else None, [8], dt, "cuda",
+                           cin_map=[0, 1, 2, -1, -1, -1, -1, -1])
+    mw2 = ops.MConvWeights((torch.randn(c, c, 3, 3, generator=g) / (c * 9) ** 0.5), torch.randn(c, generator=g) * 0.2, [c], dt, "cuda")
+    out, pooled = ops.mconv2d_first_pool(x8, mw1, mw2)
+    want, want_p = ops.mconv2d(ops.mconv2d(x8, mw1, act="relu"), mw2, act="relu", pool=True)
+    if not (torch.equal(out, want) and torch.equal(pooled, want_p)):
+        bad += 1
+        print(f"FAIL first case {case}: dt={dt} c={c} n={n} h={h} w={w}")
 print(f"{n_cases} cases, {bad} failures, worst err / tol {worst:.3f}")
 sys.exit(1 if bad else 0)
