@@ -782,47 +782,73 @@ class UNet(_GraphModel):
     1x1 ``outc``.  BatchNorm runs in eval mode (running statistics) folded into the conv weights.
 
     Engine extras (BASELINE config 3/5): ``base_channels`` (64 -> U-Net-64, 32 -> U-Net-32), ``upsampler``
-    ``"bilinear"`` (reference) or ``"pixelshuffle"`` (conv3x3(C -> 4*C/2... ) + PixelShuffle(2), edsr.py:88-123),
-    ``enhance=True`` returns ``enhanced = clamp(outc, 0, 1)`` (llunetpp.py:241-242) instead of ``semantic``."""
+    ``"bilinear"`` (reference default, unet.py:82-83), ``"convtranspose"`` (the reference's ``bilinear=False`` branch, unet.py:85-86:
+    ``upK.up`` = ConvTranspose2d(in, in // 2, 2, 2), un-halved widths) or ``"pixelshuffle"`` (conv3x3(C -> 4*C/2... ) +
+    PixelShuffle(2), edsr.py:88-123), ``enhance=True`` returns ``enhanced = clamp(outc, 0, 1)`` (llunetpp.py:241-242) instead of
+    ``semantic``, ``conv_bias=True`` gives the 3x3 convs a bias like the original modules the reference tree also ships
+    (mon_extra/vision/enhance/llie/mtfe/unet_parts.py:15-21); checkpoints in that file's key spelling (``*.double_conv.{0,1,3,4}``,
+    ``downK.maxpool_conv.1``) load directly."""
 
     arch = "unet"
     tasks = [Task.SEGMENT, Task.LLIE]
     schemes = [Scheme.SUPERVISED]
 
     def __init__(self, in_channels: int = 3, num_classes: int = 34, weights: Any = None, base_channels: int = 64,
-                 upsampler: str = "bilinear", enhance: bool = False, seed: int = None, *args, **kwargs):
+                 upsampler: str = "bilinear", enhance: bool = False, conv_bias: bool = False, seed: int = None, *args, **kwargs):
         kwargs.pop("name", None)
         super().__init__(name="unet", in_channels=in_channels, num_classes=num_classes, weights=weights, *args, **kwargs)
         if isinstance(self.weights, dict):
             in_channels = self.weights.get("in_channels", in_channels)
             num_classes = self.weights.get("num_classes", num_classes)
-        if upsampler not in ("bilinear", "pixelshuffle"):
-            raise ValueError(f"`upsampler` must be 'bilinear' or 'pixelshuffle', but got {upsampler}.")
+        if upsampler not in ("bilinear", "pixelshuffle", "convtranspose"):
+            raise ValueError(f"`upsampler` must be 'bilinear', 'convtranspose' or 'pixelshuffle', but got {upsampler}.")
         self.in_channels, self.out_channels = in_channels, num_classes
-        self.base_channels, self.upsampler, self.enhance = base_channels, upsampler, enhance
+        self.base_channels, self.upsampler, self.enhance, self.conv_bias = base_channels, upsampler, enhance, bool(conv_bias)
         self.predicting = True
         f = [base_channels * m for m in (1, 2, 4, 8, 16)]
         self._f = f
+        factor = 1 if upsampler == "convtranspose" else 2      # unet.py:153: factor = 2 if bilinear else 1
 
         def dc(name, ci, co, mid=None):
             mid = mid or co
             P = self._params
             P[f"{name}.conv1.weight"] = torch.zeros(mid, ci, 3, 3)
             P[f"{name}.conv2.weight"] = torch.zeros(co, mid, 3, 3)
+            if self.conv_bias:
+                P[f"{name}.conv1.bias"], P[f"{name}.conv2.bias"] = torch.zeros(mid), torch.zeros(co)
             for nm, c in (("norm1", mid), ("norm2", co)):
                 P[f"{name}.{nm}.weight"], P[f"{name}.{nm}.bias"] = torch.ones(c), torch.zeros(c)
                 P[f"{name}.{nm}.running_mean"], P[f"{name}.{nm}.running_var"] = torch.zeros(c), torch.ones(c)
 
         dc("inc", in_channels, f[0])
-        dc("down1.conv", f[0], f[1]); dc("down2.conv", f[1], f[2]); dc("down3.conv", f[2], f[3]); dc("down4.conv", f[3], f[4] // 2)
-        dc("up1.conv", f[4], f[3] // 2, f[4] // 2); dc("up2.conv", f[3], f[2] // 2, f[3] // 2)
-        dc("up3.conv", f[2], f[1] // 2, f[2] // 2); dc("up4.conv", f[1], f[0], f[1] // 2)
+        dc("down1.conv", f[0], f[1]); dc("down2.conv", f[1], f[2]); dc("down3.conv", f[2], f[3]); dc("down4.conv", f[3], f[4] // factor)
+        for k, (ci, co) in zip((1, 2, 3, 4), ((f[4], f[3] // factor), (f[3], f[2] // factor), (f[2], f[1] // factor), (f[1], f[0]))):
+            if upsampler == "convtranspose":      # unet.py:85-86: ConvTranspose2d(in, in // 2, 2, 2) + DoubleConv(in, out)
+                self._params[f"up{k}.up.weight"], self._params[f"up{k}.up.bias"] = torch.zeros(ci, ci // 2, 2, 2), torch.zeros(ci // 2)
+                dc(f"up{k}.conv", ci, co)
+            else:                                 # unet.py:82-83: DoubleConv(in, out, mid = in // 2)
+                dc(f"up{k}.conv", ci, co, ci // 2)
         if upsampler == "pixelshuffle":       # Upsampler(scale 2): conv3x3(C -> 4C) + PixelShuffle(2), per decoder level
             for k, c in zip((1, 2, 3, 4), (f[4] // 2, f[3] // 2, f[2] // 2, f[1] // 2)):
                 self._params[f"up{k}.up.0.weight"] = torch.zeros(4 * c, c, 3, 3)
                 self._params[f"up{k}.up.0.bias"] = torch.zeros(4 * c)
         self._params["outc.conv.weight"], self._params["outc.conv.bias"] = torch.zeros(num_classes, f[0], 1, 1), torch.zeros(num_classes)
         self._finish_init(seed)
+
+    _SEQ_KEYS = {"0": "conv1", "1": "norm1", "3": "conv2", "4": "norm2"}
+
+    def map_key(self, k: str) -> str:
+        """The original U-Net modules' spelling (mon_extra/vision/enhance/llie/mtfe/unet_parts.py:8-40: ``double_conv`` Sequential
+        with conv / BN at 0,1,3,4 and ``downK.maxpool_conv.1``) -> mon's (unet.py:42-47, 66)."""
+        parts = k.replace(".maxpool_conv.1.", ".conv.").split(".")
+        if "double_conv" in parts:
+            i = parts.index("double_conv")
+            if i + 1 < len(parts) and parts[i + 1] in self._SEQ_KEYS:
+                parts[i:i + 2] = [self._SEQ_KEYS[parts[i + 1]]]
+        return ".".join(parts)
+
+    def conv_transpose_keys(self):
+        return [k for k in self._params if k.endswith(".up.weight") and self.upsampler == "convtranspose"]
 
     def load_state_dict(self, state_dict: dict, strict: bool = True):
         sd = {k: v for k, v in state_dict.items() if not k.endswith("num_batches_tracked")}
@@ -832,7 +858,7 @@ class UNet(_GraphModel):
         g = self._gen(seed)
         for k in list(self._params):
             if k.endswith(".weight") and self._params[k].dim() == 4:
-                self._init_conv(k[:-7], g)
+                self._init_conv(k[:-7], g)        # (a ConvTranspose2d weight is (Cin, Cout, 2, 2): torch's fan_in for it is Cout * 4 = shape[1] * 4 too)
             elif k.endswith("running_mean"):      # seeded non-trivial BN statistics so that eval-mode BN is exercised
                 self._params[k] = torch.randn(self._params[k].shape, generator=g) * 0.1
             elif k.endswith("running_var"):
@@ -858,6 +884,8 @@ class UNet(_GraphModel):
     def _up(self, k, x1, x2, head=False):
         if self.upsampler == "bilinear":
             x1 = ops.upsample2x_bilinear(x1)
+        elif self.upsampler == "convtranspose":
+            x1 = self._conv_transpose2x2(x1, f"up{k}.up")
         else:
             x1 = self._conv(x1, f"up{k}.up.0", shuffle=2)           # conv3x3 + PixelShuffle(2), fused into the conv's epilogue on the 16-bit path
         dy, dx = x2.shape[2] - x1.shape[2], x2.shape[3] - x1.shape[3]
@@ -912,6 +940,9 @@ class UNet(_GraphModel):
         def up(k, a, skip):
             if self.upsampler == "bilinear":
                 a = T.t_resize(tape, a, (a.shape[2] * 2, a.shape[3] * 2), "bilinear_align")
+            elif self.upsampler == "convtranspose":      # fp32 detour on the 16-bit graph, like HINet's
+                a = T.t_conv_transpose2x2(tape, T.t_cast(tape, a, torch.float32) if mixed else a, store, f"up{k}.up")
+                a = T.t_cast(tape, a, tdt) if mixed else a
             else:
                 a = T.t_pixel_shuffle(tape, T.t_conv(tape, a, store.conv(f"up{k}.up.0"), *store.conv_grads(f"up{k}.up.0")), 2)
             dy, dx = skip.shape[2] - a.shape[2], skip.shape[3] - a.shape[3]

@@ -6,8 +6,11 @@
                        PINNED by tests/golden/llunetpp_*.npz (reference file mon_extra/.../llunet++/model.py)
   lllinet_forward      src/mon/vision/enhance/llie/lllinet/lllinet.py:97-260 (+ normalization.py:177-224, attention.py:1156-1182): parity unpinned.
   unet_forward         src/mon/vision/segment/unet/unet.py:35-197 with line 51's typo read as conv1; eval-mode BN.
-                       parity unpinned (the reference class does not run as shipped); leaf ops are torch's.
-  unet_ps variant      + Upsampler conv3x3 + nn.PixelShuffle(2) (nn/modules/encoder/edsr.py:88-123): parity unpinned.
+                       PINNED by tests/golden/unet_mtfe_*.npz: the reference tree's pure-torch twin of the same topology,
+                       mon_extra/vision/enhance/llie/mtfe/unet_model.py + unet_parts.py (bilinear and ConvTranspose2d decoders,
+                       convs with bias, keys ``*.double_conv.{0,1,3,4}`` -> unet_from_mtfe_keys), run in the build container.
+  unet_ps variant      + Upsampler conv3x3 + nn.PixelShuffle(2) (nn/modules/encoder/edsr.py:88-123): the encoder / DoubleConv /
+                       pad / cat / head around it are the pinned ones; the upsampler leaf itself is parity unpinned.
   zero_ig_enhance      src/mon/vision/enhance/llie/zero_ig/zero_ig.py:307-348 (Enhance)
   zero_ig_denoise      zero_ig.py:257-304 (Denoise1 / Denoise2)
   zero_ig_forward      zero_ig.py:434-452 (ZeroIG.forward, predicting branch)
@@ -15,7 +18,9 @@
                        Enhancer, Denoise_1, Denoise_2 and Finetunemodel.forward run in the build container)
   hinet_forward        src/mon/vision/enhance/multitask/hinet/hinet.py:34-198, 322-362
                        PINNED by tests/golden/hinet_*.npz (reference file mon_extra/.../hinet/basicsr/models/archs/hinet_arch.py)
-  rrdnet_forward       src/mon/vision/enhance/llie/rrdnet/rrdnet.py:208-289: parity unpinned (mon not importable, no mon_extra twin).
+  rrdnet_forward       src/mon/vision/enhance/llie/rrdnet/rrdnet.py:208-289: the three stacks + sigmoid / sigmoid / tanh are PINNED by
+                       tests/golden/rrdnet_*.npz (reference file mon_extra/vision/enhance/llie/rrdnet/model/RRDNet.py, same
+                       Sequential keys); the recombination of :271-279 is five torch ops on those pinned maps.
   zsn2n_forward        src/mon/vision/enhance/denoise/zsn2n/zsn2n.py:73-124: parity unpinned (same).
   retinexnet_forward   src/mon_extra/vision/enhance/llie/retinexnet/model.py:21-90,199-238: parity unpinned (file
                        imports cv2/thop/mon and hard-codes .cuda()); single Decom pass, S = R * I_delta.
@@ -175,7 +180,25 @@ def _dc(sd, n, x):
     return F.relu(_bn(sd, f"{n}.norm2", _c(sd, f"{n}.conv2", x)))
 
 
-def unet_forward(sd: dict, x: torch.Tensor, upsampler: str = "bilinear", enhance: bool = False) -> dict:
+def unet_from_mtfe_keys(sd: dict) -> dict:
+    """Checkpoint keys of the original U-Net modules (mon_extra/.../mtfe/unet_parts.py:8-77: ``double_conv`` Sequential with
+    conv / BN at indices 0,1,3,4, ``downK.maxpool_conv.1``) -> mon's spelling (unet.py:42-47,66: conv1/norm1/conv2/norm2, ``downK.conv``)."""
+    idx = {"0": "conv1", "1": "norm1", "3": "conv2", "4": "norm2"}
+    out = {}
+    for k, v in sd.items():
+        if k.endswith("num_batches_tracked"):
+            continue
+        parts = k.replace(".maxpool_conv.1.", ".conv.").split(".")
+        if "double_conv" in parts:
+            i = parts.index("double_conv")
+            parts[i:i + 2] = [idx[parts[i + 1]]]
+        out[".".join(parts)] = v
+    return out
+
+
+def unet_forward(sd: dict, x: torch.Tensor, upsampler: str = "bilinear", enhance: bool = False, taps: bool = False) -> dict:
+    """unet.py:172-197.  ``upsampler``: "bilinear" (unet.py:82-83), "convtranspose" (unet.py:85-86, the ``bilinear=False`` branch:
+    ``upK.up`` = ConvTranspose2d(in, in // 2, 2, 2)), or "pixelshuffle" (edsr.py:88-123).  Convs may carry a bias (the original modules do)."""
     x1 = _dc(sd, "inc", x)
     x2 = _dc(sd, "down1.conv", F.max_pool2d(x1, 2))
     x3 = _dc(sd, "down2.conv", F.max_pool2d(x2, 2))
@@ -185,6 +208,8 @@ def unet_forward(sd: dict, x: torch.Tensor, upsampler: str = "bilinear", enhance
     def up(k, a, skip):
         if upsampler == "bilinear":
             a = F.interpolate(a, scale_factor=2, mode="bilinear", align_corners=True)
+        elif upsampler == "convtranspose":
+            a = F.conv_transpose2d(a, sd[f"up{k}.up.weight"], sd.get(f"up{k}.up.bias"), stride=2)
         else:
             a = F.pixel_shuffle(_c(sd, f"up{k}.up.0", a), 2)
         dy, dx = skip.shape[2] - a.shape[2], skip.shape[3] - a.shape[3]
@@ -192,7 +217,10 @@ def unet_forward(sd: dict, x: torch.Tensor, upsampler: str = "bilinear", enhance
         return _dc(sd, f"up{k}.conv", torch.cat([skip, a], 1))
     y = up(1, x5, x4); y = up(2, y, x3); y = up(3, y, x2); y = up(4, y, x1)
     y = _c(sd, "outc.conv", y, padding=0)
-    return {"enhanced": torch.clamp(y, 0, 1)} if enhance else {"semantic": y}
+    out = {"enhanced": torch.clamp(y, 0, 1)} if enhance else {"semantic": y}
+    if taps:
+        out.update(inc=x1, bottleneck=x5)
+    return out
 
 
 # ---- Zero-IG Enhance -------------------------------------------------------------------------------------------

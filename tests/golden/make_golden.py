@@ -8,6 +8,8 @@ the pure-torch reference files
     src/mon_extra/vision/enhance/llie/llunet++/model.py      (NestedUNet)
     src/mon_extra/vision/enhance/multitask/hinet/basicsr/models/archs/hinet_arch.py   (HINet)
     src/mon_extra/vision/enhance/llie/zero_ig/model.py       (Enhancer, Denoise_1, Denoise_2, Finetunemodel.forward)
+    src/mon_extra/vision/enhance/llie/mtfe/unet_model.py     (UNet: DoubleConv / Down / Up / OutConv of unet_parts.py)
+    src/mon_extra/vision/enhance/llie/rrdnet/model/RRDNet.py (RRDNet)
 loads seeded weights into them, runs their forward on CPU fp32 and stores
 inputs / weights / outputs as small fixtures.  The fixtures are data only; no
 reference source is copied.  Usage:  python tests/golden/make_golden.py
@@ -177,9 +179,62 @@ def gen_zero_ig():
           "| denoise mean", float(h3.mean()))
 
 
+def gen_unet():
+    """U-Net: the reference tree's pure-torch twin of src/mon/vision/segment/unet/unet.py:35-197 (same DoubleConv / Down /
+    Up(bilinear align_corners=True | ConvTranspose2d, pad, cat[skip, up]) / OutConv topology; mon's copy does not run as
+    shipped, line 51).  Widths 16..256, convs WITH bias, keys ``*.double_conv.{0,1,3,4}``.  Eval-mode BatchNorm with
+    non-trivial running statistics; odd frames so the decoder's zero pad is exercised.  Weights are regenerated from the
+    seed (tests/helpers.seeded_bn_state_dict); input / output / one intermediate travel."""
+    from tests.helpers import seeded_bn_state_dict
+    udir = os.path.join(REF, "src/mon_extra/vision/enhance/llie/mtfe")
+    sys.path.insert(0, udir)
+    try:
+        mod = _load("src/mon_extra/vision/enhance/llie/mtfe/unet_model.py", "ref_mtfe_unet")
+    finally:
+        sys.path.remove(udir)
+    for tag, bilinear, seed, (n, h, w) in (("bilinear", True, 61, (2, 33, 47)), ("convt", False, 62, (1, 35, 50))):
+        net = mod.UNet(3, 3, bilinear=bilinear)
+        shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+        sd = seeded_bn_state_dict(shapes, seed)
+        net.load_state_dict(sd, strict=True)
+        net.eval()
+        x = torch.rand(n, 3, h, w, generator=torch.Generator().manual_seed(seed + 100))
+        with torch.no_grad():
+            y = net(x)
+            x1 = net.inc(x)
+            x5 = net.down4(net.down3(net.down2(net.down1(x1))))
+        path = os.path.join(HERE, f"unet_mtfe_{tag}_seed{seed}_{n}x{h}x{w}.npz")
+        np.savez_compressed(path, image=x.numpy(), logits=y.numpy(), inc=x1.numpy(), bottleneck=x5.numpy(), seed=np.array(seed),
+                            bilinear=np.array(bilinear), key_order=np.array(list(shapes.keys())),
+                            key_shapes=np.array([str(s) for s in shapes.values()]))
+        print("wrote", path, os.path.getsize(path) // 1024, "KiB | params", sum(v.numel() for k, v in sd.items() if v.dim() > 0),
+              "| logits range", float(y.min()), float(y.max()), "in [0,1]:", float(((y > 0) & (y < 1)).float().mean()))
+
+
+def gen_rrdnet():
+    """RRDNet: the original repository's module (three 5-layer stacks, sigmoid / sigmoid / tanh) == mon's RRDNet_RE stacks
+    (rrdnet.py:208-240, same Sequential indices) -- the Retinex recombination of rrdnet.py:271-279 is applied to ITS outputs
+    with torch ops here (pow, sub, div, mul, clamp), so ``enhanced`` is pinned through the reference's own three maps."""
+    mod = _load("src/mon_extra/vision/enhance/llie/rrdnet/model/RRDNet.py", "ref_rrdnet")
+    net = mod.RRDNet()
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sd = _seeded(shapes, seed=71)
+    net.load_state_dict(sd, strict=True)
+    net.eval()
+    x = torch.rand(2, 3, 37, 53, generator=torch.Generator().manual_seed(72)) * 0.6 + 0.05
+    with torch.no_grad():
+        illumination, reflectance, noise = net(x)
+    out = {f"w.{k}": v.numpy() for k, v in sd.items()}
+    out.update(image=x.numpy(), illumination=illumination.numpy(), reflectance=reflectance.numpy(), noise=noise.numpy())
+    path = os.path.join(HERE, "rrdnet_seed71_2x37x53.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB | params", sum(v.numel() for v in sd.values()),
+          "| illumination", float(illumination.min()), float(illumination.max()), "noise |max|", float(noise.abs().max()))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["zero_dce", "zero_dcepp", "llunetpp", "hinet", "zero_ig"]
+    which = sys.argv[1:] or ["zero_dce", "zero_dcepp", "llunetpp", "hinet", "zero_ig", "unet", "rrdnet"]
     if "zero_dce" in which:
         gen_zero_dce()
     if "zero_dcepp" in which:
@@ -190,3 +245,7 @@ if __name__ == "__main__":
         gen_hinet()
     if "zero_ig" in which:
         gen_zero_ig()
+    if "unet" in which:
+        gen_unet()
+    if "rrdnet" in which:
+        gen_rrdnet()

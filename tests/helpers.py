@@ -52,3 +52,25 @@ def seeded_state_dict(shapes: dict, seed: int, std=None) -> dict:
     if "final.bias" in sd:
         sd["final.bias"] = sd["final.bias"] + 0.45
     return sd
+
+
+def seeded_bn_state_dict(shapes: dict, seed: int) -> dict:
+    """``seeded_state_dict`` for networks with BatchNorm: a valid, non-trivial eval-mode state (running_var in [0.5, 1.5),
+    running_mean ~ N(0, 0.1), scale ~ N(1, 0.1)) for every norm layer, whatever its key spelling (``*.norm1.*`` or the
+    ``nn.Sequential`` indices of the original U-Net); ``num_batches_tracked`` = 0."""
+    sd = seeded_state_dict({k: s for k, s in shapes.items() if len(tuple(s)) > 0}, seed)
+    g = torch.Generator().manual_seed(seed + 7919)
+    for k, shp in shapes.items():
+        shp = tuple(shp)
+        if k.endswith("running_var"):
+            sd[k] = torch.rand(shp, generator=g) + 0.5
+        elif k.endswith("running_mean"):
+            sd[k] = torch.randn(shp, generator=g) * 0.1
+        elif k.endswith("num_batches_tracked"):
+            sd[k] = torch.tensor(0)
+        elif k.endswith(".weight") and len(shp) == 1 and (k[:-6] + "running_var") in shapes:
+            sd[k] = 1.0 + torch.randn(shp, generator=g) * 0.1
+    if "outc.conv.weight" in sd:          # U-Net head: spread the logits over [0, 1] and beyond so a clamp behind it bites on both sides
+        sd["outc.conv.weight"] = sd["outc.conv.weight"] * 6.0
+        sd["outc.conv.bias"] = sd["outc.conv.bias"] + 0.45
+    return sd

@@ -12,7 +12,7 @@ import torch.nn.functional as F
 import mon_amd
 from mon_amd import ops
 from oracle import generators as og
-from tests.helpers import GOLDEN, rel_err, seeded_state_dict
+from tests.helpers import GOLDEN, rel_err, seeded_bn_state_dict, seeded_state_dict
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -59,6 +59,43 @@ def test_unet_vs_oracle(cfg):
     ref = og.unet_forward(m.state_dict(), x, cfg["upsampler"], cfg["enhance"])[key]
     assert tuple(out[key].shape) == tuple(ref.shape)
     assert rel_err(out[key].cpu(), ref) <= TOL
+
+
+def _unet_golden(path):
+    g = np.load(path)
+    shapes = {str(k): ast.literal_eval(str(s)) for k, s in zip(g["key_order"], g["key_shapes"])}
+    return g, seeded_bn_state_dict(shapes, int(g["seed"])), "bilinear" if bool(g["bilinear"]) else "convtranspose"
+
+
+@pytest.mark.parametrize("dt,tol", [("f32", TOL), ("f16", 1e-3), ("bf16", 1.5e-2)])
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "unet_mtfe_*.npz"))), ids=lambda p: os.path.basename(p)[10:-4])
+def test_unet_golden(path, dt, tol):
+    """The engine's U-Net against the outputs of the reference tree's own runnable U-Net (mtfe/unet_model.py; same topology as
+    unet.py:35-197), checkpoint in the original key spelling, both decoders, odd frames."""
+    g, sd_ref, upsampler = _unet_golden(path)
+    x = torch.from_numpy(g["image"]).cuda()
+    m = mon_amd.MODELS.build(name="unet", base_channels=16, num_classes=3, conv_bias=True, upsampler=upsampler, weights=dict(sd_ref),
+                             compute_dtype=dt).to("cuda")
+    out = m.forward({"image": x})["semantic"].cpu()
+    assert tuple(out.shape) == g["logits"].shape and rel_err(out, g["logits"]) <= tol
+    e = mon_amd.MODELS.build(name="unet", base_channels=16, num_classes=3, conv_bias=True, upsampler=upsampler, weights=dict(sd_ref),
+                             compute_dtype=dt, enhance=True).to("cuda")
+    enh = e.forward({"image": x})["enhanced"].cpu()
+    assert rel_err(enh, np.clip(g["logits"], 0, 1)) <= tol and float(enh.min()) == 0.0
+
+
+@pytest.mark.parametrize("dt,tol", [("f32", TOL), ("f16", 1e-3), ("bf16", 1.5e-2)])
+def test_rrdnet_golden(dt, tol):
+    g = np.load(os.path.join(GOLDEN, "rrdnet_seed71_2x37x53.npz"))
+    sd_ref = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w.")}
+    m = mon_amd.MODELS.build(name="rrdnet_re", weights=dict(sd_ref), compute_dtype=dt).to("cuda")
+    x = torch.from_numpy(g["image"])
+    out = m.forward({"image": x.cuda()})
+    for k in ("illumination", "reflectance", "noise"):
+        assert rel_err(out[k].cpu(), g[k]) <= tol, k
+    ill, noise = torch.from_numpy(g["illumination"]), torch.from_numpy(g["noise"])
+    want = torch.clamp(torch.pow(ill, 0.4) * ((x - noise) / ill), 0, 1)          # rrdnet.py:271-279 on the reference's own maps
+    assert rel_err(out["enhanced"].cpu(), want) <= tol
 
 
 def test_unet_loads_reference_style_checkpoint(tmp_path):

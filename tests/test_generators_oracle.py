@@ -10,7 +10,7 @@ import torch
 
 import mon_amd
 from oracle import generators as og
-from tests.helpers import GOLDEN, seeded_state_dict
+from tests.helpers import GOLDEN, seeded_bn_state_dict, seeded_state_dict
 
 
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "zero_dcepp_*.npz"))), ids=lambda p: os.path.basename(p)[11:-4])
@@ -124,3 +124,41 @@ def test_hinet_structure_and_oracle_runs():
     assert list(out) == ["stage1", "enhanced"] and out["enhanced"].shape == x.shape
     with pytest.raises(mon_amd.capi.IEError):
         small.forward({"image": x})            # no CPU execution path
+
+
+def _unet_golden(path):
+    g = np.load(path)
+    shapes = {str(k): ast.literal_eval(str(s)) for k, s in zip(g["key_order"], g["key_shapes"])}
+    return g, seeded_bn_state_dict(shapes, int(g["seed"])), "bilinear" if bool(g["bilinear"]) else "convtranspose"
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "unet_mtfe_*.npz"))), ids=lambda p: os.path.basename(p)[10:-4])
+def test_unet_restatement_matches_reference(path):
+    """oracle.unet_forward (unet.py:35-197) against the outputs of the reference tree's own runnable U-Net of the same topology
+    (mon_extra/.../mtfe/unet_model.py + unet_parts.py): both decoders, odd frames (decoder zero pad), eval BatchNorm, conv biases."""
+    g, sd_ref, upsampler = _unet_golden(path)
+    assert len(glob.glob(os.path.join(GOLDEN, "unet_mtfe_*.npz"))) == 2
+    m = mon_amd.MODELS.build(name="unet", base_channels=16, num_classes=3, conv_bias=True, upsampler=upsampler, weights=dict(sd_ref))
+    sd = m.state_dict()                                          # original key spelling -> mon spelling through the model's own mapping
+    assert "down3.conv.norm2.running_var" in sd and "inc.conv1.bias" in sd
+    assert set(sd) == set(og.unet_from_mtfe_keys(sd_ref))
+    assert m.params == sum(v.numel() for v in sd_ref.values() if v.dim() > 0)   # (counts the BatchNorm buffers too)
+    out = og.unet_forward(sd, torch.from_numpy(g["image"]), upsampler, taps=True)
+    assert np.abs(out["inc"].numpy() - g["inc"]).max() <= 1e-6
+    assert np.abs(out["bottleneck"].numpy() - g["bottleneck"]).max() <= 1e-6
+    assert np.abs(out["semantic"].numpy() - g["logits"]).max() <= 1e-6
+    assert (g["logits"] < 0).any() and (g["logits"] > 0.3).any()  # a clamp(0, 1) behind it bites, and the output is not flat
+
+
+def test_rrdnet_restatement_matches_reference():
+    """oracle.rrdnet_forward's three stacks against the reference's own RRDNet module (mon_extra/.../rrdnet/model/RRDNet.py)."""
+    g = np.load(os.path.join(GOLDEN, "rrdnet_seed71_2x37x53.npz"))
+    sd_ref = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w.")}
+    m = mon_amd.MODELS.build(name="rrdnet_re", weights=dict(sd_ref))
+    assert set(m.state_dict()) == set(sd_ref)
+    x = torch.from_numpy(g["image"])
+    out = og.rrdnet_forward(m.state_dict(), x, 0.4)
+    for k in ("illumination", "reflectance", "noise"):
+        assert np.abs(out[k].numpy() - g[k]).max() <= 1e-6, k
+    want = torch.clamp(torch.pow(torch.from_numpy(g["illumination"]), 0.4) * ((x - torch.from_numpy(g["noise"])) / torch.from_numpy(g["illumination"])), 0, 1)
+    assert torch.equal(out["enhanced"], want)
