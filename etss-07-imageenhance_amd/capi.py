@@ -19,7 +19,7 @@ DTYPES = {"f32": IE_F32, "fp32": IE_F32, "float32": IE_F32, "f16": IE_F16, "fp16
 ACT = {"none": 0, "relu": 1, "lrelu": 2, "tanh": 3, "sigmoid": 4}
 PAD = {"zeros": 0, "replicate": 1}
 SUMSQ_WS_DOUBLES = 2048
-VAR_SYNC_STAGE, VAR_NARROW_STORE, VAR_NO_DMA, VAR_UNFUSED, VAR_PURE_BF16, VAR_NO_K345 = 1, 2, 4, 8, 16, 32
+VAR_SYNC_STAGE, VAR_NARROW_STORE, VAR_NO_DMA, VAR_UNFUSED, VAR_PURE_BF16, VAR_NO_K345, VAR_K67_LEGACY = 1, 2, 4, 8, 16, 32, 64
 
 # every exported symbol of include/ie_hip.h (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
@@ -75,6 +75,7 @@ class MConvDesc(C.Structure):
 
 
 _lib = None
+ABI_VERSION = 2          # == IE_ABI_VERSION of include/ie_hip.h
 
 
 def lib():
@@ -88,6 +89,10 @@ def lib():
     L = C.CDLL(LIB_PATH)
     vp, ip, fp = C.c_void_p, C.c_int, C.c_float
     L.ie_abi_version.restype = ip
+    # (IE_HIP_LIB_ABI_OK=1: diagnostics only -- timing an older build whose struct layouts are known to match, tools/ab_bench.py)
+    if L.ie_abi_version() != ABI_VERSION and not os.environ.get("IE_HIP_LIB_ABI_OK"):      # the ctypes structs below mirror ONE layout of include/ie_hip.h
+        raise IEError(f"{LIB_PATH} reports ABI version {L.ie_abi_version()}, this loader was written against {ABI_VERSION}: "
+                      f"rebuild the library (csrc/build.sh) -- a stale build would misread ie_mconv_desc.")
     L.ie_last_error.restype = C.c_char_p
     L.ie_device_info.argtypes = [ip, C.c_char_p, ip, C.POINTER(ip), C.POINTER(C.c_size_t)]
     L.ie_nchw_f32_to_nhwc.argtypes = [vp, vp, ip, ip, ip, ip, ip, ip, vp]

@@ -10,8 +10,18 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno
 KEY=$(printf '%s' "$FLAGS" | md5sum | cut -c1-10)
 OBJ=_obj/$KEY
 mkdir -p "$OBJ"
-# signature of the csrc/ie_*.h headers a source includes (transitively).  The public ABI header include/ie_hip.h is NOT part of it
-# (new declarations would recompile every file, ~4 minutes): after changing one of ITS structs, enums or macros run with IE_FORCE=1.
+# signature of the csrc/ie_*.h headers a source includes (transitively) + the LAYOUT part of the public ABI header include/ie_hip.h:
+# its struct / enum bodies and #define lines (a changed ie_mconv_desc must recompile every object that reads one), not its function
+# declarations (a new entry point would otherwise recompile every file, ~4 minutes).
+ABI_SIG=$(python3 - <<'PY'
+import hashlib, re
+src = open("../../include/ie_hip.h").read()
+src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+src = re.sub(r"//[^\n]*", "", src)
+parts = re.findall(r"typedef\s+(?:struct|enum)\b[^{;]*\{.*?\}\s*\w+\s*;", src, flags=re.S) + re.findall(r"^[ \t]*#[ \t]*define[^\n]*", src, flags=re.M)
+print(hashlib.md5(" ".join(" ".join(p.split()) for p in parts).encode()).hexdigest()[:16])
+PY
+)
 hdr_sig() {
     local seen="" todo="$1" f inc
     while [ -n "$todo" ]; do
@@ -23,7 +33,7 @@ hdr_sig() {
             [ -f "$inc" ] && todo="$todo $inc"
         done
     done
-    cat $seen | md5sum | cut -c1-16
+    { cat $seen; echo "$ABI_SIG"; } | md5sum | cut -c1-16
 }
 todo=""
 for s in $SRCS; do

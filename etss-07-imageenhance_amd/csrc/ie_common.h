@@ -92,6 +92,18 @@ template <typename T> __device__ __forceinline__ unsigned ie_pack2_relu(float lo
 // tanh as 1 - 2/(exp(2x)+1) on the hardware exp2/rcp units: absolute error
 // <= ~3e-7 (the LE curve consumes r as a multiplier, so absolute error is what
 // matters); saturates correctly to +-1.
+// `s_waitcnt vmcnt` takes an immediate.  A wave-uniform count that is only known at run time used to go through a 30-way switch -- a
+// compare / branch tree of 10-15 scalar branches in EVERY step of the strip kernels.  The steady-state value of a loop is a compile-time
+// constant per wave class, so: test the one or two hot constants first and fall back to the caller's switch (prologue steps) otherwise.
+template <int K> __device__ __forceinline__ void ie_wait_vm_imm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K) : "memory"); }
+template <int H0, int H1 = -1, int H2 = -1, typename F> __device__ __forceinline__ void ie_wait_vm_hot(int n, F&& cold) {
+    if (n < 0) return;                       // this wave has nothing in flight to wait for
+    if (n == H0) { ie_wait_vm_imm<(H0 < 0 ? 0 : (H0 > 63 ? 63 : H0))>(); return; }
+    if constexpr (H1 >= 0) { if (n == H1) { ie_wait_vm_imm<(H1 > 63 ? 63 : (H1 < 0 ? 0 : H1))>(); return; } }
+    if constexpr (H2 >= 0) { if (n == H2) { ie_wait_vm_imm<(H2 > 63 ? 63 : (H2 < 0 ? 0 : H2))>(); return; } }
+    cold(n);
+}
+
 __device__ __forceinline__ float ie_tanh_fast(float x) {
     const float e = __builtin_amdgcn_exp2f(x * 2.885390081777927f); // exp(2x)
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);

@@ -424,7 +424,10 @@ __device__ __forceinline__ void sconv3_body(const SConvParams& p) {
     };
     auto step = [&](int it, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4]) __attribute__((always_inline)) {
         // ops younger than row `it`'s DMA: the (PF-1) L loads of the rows behind it and the SPW (possibly out-of-range) stores every step issues
-        if (L) wait_vm(wait_n + NST * (it < PF ? it : PF));
+        // steady-state counts per wave class (a regular wave; the wave that also loads the halo columns): compile-time, tested first
+        constexpr int HOT0 = FIRST ? (PF - 1) + NST * PF : (PF - 1) * PPW * NCH + NST * PF;
+        constexpr int HOT1 = FIRST ? -1 : (PF - 1) * (PPW * NCH + NCH) + NST * PF;
+        if (L) ie_wait_vm_hot<HOT0, HOT1>(wait_n + NST * (it < PF ? it : PF), [](int n_) __attribute__((always_inline)) { wait_vm(n_); });
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this wave's parked pieces of the previous step
         __builtin_amdgcn_s_barrier();
         if constexpr (FIRST) issue_img(it + 3 + PF);

@@ -41,11 +41,14 @@ constexpr unsigned OOB = 0x80000000u;
 #endif
 constexpr int PF_DEFAULT = IE_PF; // rows of DMA issued ahead (K67 is LDS-limited to 3)
 
-enum { K12 = 12, K45 = 45, K67 = 67, K345 = 345 };
+enum { K12 = 12, K45 = 45, K67 = 67, K345 = 345, K67N = 670 };   // K67N: K67 with the curve in stage B's registers (below)
 
 #ifndef IE_EXP
 #define IE_EXP 0      // timing experiments (wrong results): 1 no image DMA / row conversion, 2 e_conv1 without LDS reads, 4 no hand-off write,
 #endif                // 8 MFMA streams without LDS reads, 16 no K12 stores, 32 no e_conv1 at all, 64 raw-accumulator stores (no epilogue VALU), 128 K12 stores forced out of range; K67: 1024 no curve, 2048 curve without tanh, 4096 no image DMA, 8192 no P DMA
+#ifndef IE_HOTWAIT
+#define IE_HOTWAIT 7      // bit 0: K12, bit 1: K345, bit 2: the others -- steady-state vmcnt waits tested first (ie_wait_vm_hot), A-B switch
+#endif
 #ifndef IE_K12_RPB
 #define IE_K12_RPB 1
 #endif
@@ -69,9 +72,10 @@ template <int KIND> struct FusedGeom {
     // is as long as its MFMA time, and its rings are small: it runs TWO rows between barriers (the stages then talk through rows
     // that are one barrier period old, so every hand-off lags RPB rows and the rings hold 2 RPB slots).
     static constexpr int RPB = (KIND == K12) ? IE_K12_RPB : 1;
-    static constexpr int PF = (KIND == K67) ? 3 : (KIND == K12 && RPB > 1 ? 5 : PF_DEFAULT);   // rows of DMA issued ahead
+    static constexpr bool IS67 = (KIND == K67 || KIND == K67N);
+    static constexpr int PF = IS67 ? 3 : (KIND == K12 && RPB > 1 ? 5 : PF_DEFAULT);   // rows of DMA issued ahead
     static constexpr int ROW_B = ROW_PX * 64;
-    static constexpr int NSA = (KIND == K67) ? 2 : ((KIND == K45 || KIND == K345) ? 1 : 0);     // stage A HBM sources (K12: image)
+    static constexpr int NSA = IS67 ? 2 : ((KIND == K45 || KIND == K345) ? 1 : 0);     // stage A HBM sources (K12: image)
     static constexpr int NRA = (KIND == K45) ? PF + 3 : PF + 1;   // slots of the A rings (K45: B re-reads x3 two rows later)
     static constexpr int NRB = PF + 1;                            // K67: P ring of stage B
     static constexpr int NR3 = 4;                                 // K345: x3 ring (written at step t, read by e_conv4 at t+1 and e_conv5 at t+3)
@@ -81,14 +85,19 @@ template <int KIND> struct FusedGeom {
     // K12 streamed form: every epilogue (hand-off write, stores) is deferred by one step and rides between the MFMAs of the next
     static constexpr int DEF = (KIND == K12 && IE_K12_STREAM) ? 1 : 0;
     static constexpr int LAG_H = LAG_B + DEF;                     // rows between stage A computing a hand-off row and its consumers reading it, minus one
-    static constexpr int NRI = (KIND == K12) ? PF + RPB : PF + 3; // fp32 image ring slots (K67: kept until the deferred curve)
+    // fp32 image ring slots (K67: kept until the deferred curve; K67N: DMA'd PF steps ahead of the step whose curve reads it).
+    // (Tried for K67N: the fp32 pixel riding in the unused bytes 48..59 of K12's P record instead of a ring of its own -- one 64-byte line per
+    // pixel, no image read in the last kernel.  K12 + 0.45 ms per 64 frames for the six LDS reads and eight selects per wave and row in its
+    // stage A stream against 0 measurable for these DMAs here: not kept.)
+    static constexpr int NRI = (KIND == K12) ? PF + RPB : (KIND == K67N ? PF + 1 : PF + 3);
     static constexpr int NRC = 2 + LAG_A + RPB;                   // K12: converted image rows (3 being read + RPB being written)
-    static constexpr int IMG_SLOT_B = 2048;                       // 3 planes x 132 px fp32 (K12) / 3 x 128 (K67)
+    static constexpr int IMG_PLANE67N = 144 * 4;                   // K67N: plane pitch 144 floats -> colours 0 / 1 of a pixel on different banks
+    static constexpr int IMG_SLOT_B = (KIND == K67N) ? 3 * IMG_PLANE67N : 2048;   // 3 planes x 132 px fp32 (K12) / 3 x 128 (K67)
     static constexpr int CV_PLANE_B = 1088;                       // K12: converted image row, [136 px][RGB0] 16-bit
     static constexpr int CV_SLOT_B = 2 * CV_PLANE_B;              //      hi plane + lo plane
     static constexpr int STAGE_SLOT_B = 24 * TW * 4;              // K67: tanh(r) staging [24][128] fp32, double buffered
     static constexpr int A_RING_B = NSA * NRA * ROW_B;
-    static constexpr int B_RING_B = (KIND == K67) ? NRB * ROW_B : 0;
+    static constexpr int B_RING_B = IS67 ? NRB * ROW_B : 0;
     static constexpr int R3_B = (KIND == K345) ? NR3 * ROW_B : 0;
     static constexpr int RA_B = NRH * ROW_B;
     static constexpr int IMG_B = (KIND == K45 || KIND == K345) ? 0 : NRI * IMG_SLOT_B;
@@ -100,7 +109,10 @@ template <int KIND> struct FusedGeom {
     // bytes of each pixel (its 16 output channels), and half-line writes cost the write path twice (profiles/r02/k12_experiments_2.log).
     static constexpr int OUT = (DEF || (KIND == K345 && IE_K345_OUT)) ? 1 : 0;
     static constexpr int OUT_B = OUT ? (KIND == K12 ? 2 : 1) * 2 * ROW_B : 0;     // (two tensors x) two slots
-    static constexpr int LDS_B = A_RING_B + B_RING_B + R3_B + RA_B + IMG_B + CV_B + STAGE_B + DUMP_B + OUT_B;
+    // K67N: the curve's fp32 results of a row, [3 colours][132] (pixel q at float q + 2, so the 124 stored pixels start 16-byte aligned), two slots
+    static constexpr int OUTF_PLANE_B = 132 * 4, OUTF_SLOT_B = 4 * OUTF_PLANE_B;      // (a fourth plane: where the idle lane group kq = 3 writes, branch-free)
+    static constexpr int OUTF_B = (KIND == K67N) ? 2 * OUTF_SLOT_B : 0;
+    static constexpr int LDS_B = A_RING_B + B_RING_B + R3_B + RA_B + IMG_B + CV_B + STAGE_B + DUMP_B + OUT_B + OUTF_B;
 };
 
 struct FusedParams {
@@ -153,8 +165,9 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     constexpr int PXB = 32 * 2;                             // 64 B per pixel per tensor
     constexpr int ROW_B = G::ROW_B;                         // one ring row of one tensor
     constexpr int NSA = G::NSA;
-    constexpr int NFB = (KIND == K45 || KIND == K12 || KIND == K345) ? 18 : 9;         // stage B weight fragments (K12: e_conv2 + e_conv7a)
-    constexpr int NW = (KIND == K67) ? 18 : NFB;                     // weight fragments held per wave (K12 stage A: 2, K67 / K345 stage A: 18)
+    constexpr bool IS67 = G::IS67;
+    constexpr int NFB = (KIND == K45 || KIND == K12 || KIND == K345 || KIND == K67N) ? 18 : 9;         // stage B weight fragments (K12: e_conv2 + e_conv7a; K67N: both 16-row tiles of e_conv7b)
+    constexpr int NW = IS67 ? 18 : NFB;                     // weight fragments held per wave (K12 stage A: 2, K67 / K345 stage A: 18)
     // K67 and K345 load NO halo columns for stage A's HBM rows (one 8-lane LDS-DMA instruction per tensor and row on the
     // stage's busiest wave): the outermost computed column of stage A is then wrong too and one more column a side is dropped.
     // At 1920 columns the strip count stays 16 (124- and 122-column pitches).
@@ -167,7 +180,8 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     constexpr int IMG_SLOT_B = G::IMG_SLOT_B, CV_PLANE_B = G::CV_PLANE_B, CV_SLOT_B = G::CV_SLOT_B, STAGE_SLOT_B = G::STAGE_SLOT_B;
     constexpr int OFF_BRING = G::A_RING_B, OFF_R3 = OFF_BRING + G::B_RING_B, OFF_RA = OFF_R3 + G::R3_B, OFF_IMG = OFF_RA + G::RA_B,
                   OFF_CV = OFF_IMG + G::IMG_B, OFF_STAGE = OFF_CV + G::CV_B, OFF_DUMP = OFF_STAGE + G::STAGE_B, OFF_OUT = OFF_DUMP + G::DUMP_B;
-    (void)OFF_DUMP; (void)OFF_OUT;
+    constexpr int OFF_OUTF = OFF_OUT + G::OUT_B;
+    (void)OFF_DUMP; (void)OFF_OUT; (void)OFF_OUTF;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -185,7 +199,7 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     const int xc0 = strip * TSK - MARG;                     // image column of computed column 0
     const int ys = p.y_begin + chunk * p.rows_per_block;
     const int ye = min(ys + p.rows_per_block, p.y_end);
-    const int n_steps = (ye - ys) + 6 + LAG_A + LAG_H + G::OUT + (KIND == K67 ? 1 : 0) + (KIND == K345 ? 4 : 0);
+    const int n_steps = (ye - ys) + 6 + LAG_A + LAG_H + G::OUT + (IS67 ? 1 : 0) + (KIND == K345 ? 4 : 0);
     constexpr int A_ROW0 = (KIND == K345) ? 4 : 2;          // stage A's HBM input row at step t is ys - A_ROW0 + t
     const int H = p.H, W = p.W;
     const size_t plane = (size_t)H * W;
@@ -197,16 +211,20 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     };
     const auto rsA0 = mk((const char*)(NSA >= 1 ? p.a_src0 : p.b_w) + (NSA >= 1 ? (size_t)n * frame_b : 0), frame_b);
     const auto rsA1 = mk((const char*)(NSA >= 2 ? p.a_src1 : p.b_w) + (NSA >= 2 ? (size_t)n * frame_b : 0), frame_b);
-    const auto rsB = mk((const char*)(KIND == K67 ? p.b_src : p.b_w) + (KIND == K67 ? (size_t)n * frame_b : 0), frame_b);
+    const auto rsB = mk((const char*)(IS67 ? p.b_src : p.b_w) + (IS67 ? (size_t)n * frame_b : 0), frame_b);
     const auto rsI = mk((const char*)((KIND != K45 && KIND != K345) ? (const void*)(p.img + (size_t)n * 3 * plane) : p.b_w), 3 * plane * 4);
     const auto rsDa = mk((char*)(KIND == K12 ? p.a_dst : (void*)p.b_w) + (KIND == K12 ? (size_t)n * frame_b : 0), frame_b);
-    const auto rsDb = mk((char*)(KIND != K67 ? p.b_dst : (void*)p.b_w) + (KIND != K67 ? (size_t)n * frame_b : 0), frame_b);
+    const auto rsDb = mk((char*)(!IS67 ? p.b_dst : (void*)p.b_w) + (!IS67 ? (size_t)n * frame_b : 0), frame_b);
+    // K67N: the three outputs through buffer descriptors (an out-of-range offset drops a masked lane's store; absent outputs get an empty range)
+    const auto rsE = mk((KIND == K67N && p.enhanced) ? (const void*)(p.enhanced + (size_t)n * 3 * plane) : p.b_w, (KIND == K67N && p.enhanced) ? 3 * plane * 4 : 0);
+    const auto rsJ = mk((KIND == K67N && p.adjust) ? (const void*)(p.adjust + (size_t)n * 24 * plane) : p.b_w, (KIND == K67N && p.adjust) ? 24 * plane * 4 : 0);
+    const auto rsU = mk((KIND == K67N && p.u8) ? (const void*)(p.u8 + (size_t)n * 3 * plane) : p.b_w, (KIND == K67N && p.u8) ? 3 * plane : 0);
 
     // ---- weights of this wave's stage into registers -------------------------------------------
     frag wv[NW];
     {
         const int nfr = stg ? NFB : (KIND == K12 ? 2 : 9 * NSA);   // fragments per cout half
-        const frag* wp = (const frag*)(stg ? p.b_w : p.a_w) + (size_t)ch * nfr * 64;
+        const frag* wp = (const frag*)(stg ? p.b_w : p.a_w) + ((KIND == K67N && stg) ? 0 : (size_t)ch * nfr * 64);     // K67N stage B: both tiles, [tile][tap]
 #pragma unroll
         for (int f = 0; f < NW; ++f) wv[f] = wp[(f < nfr ? f : 0) * 64 + lane];
         if constexpr (KIND == K345) {       // stage A: e_conv3 in wv[0..8], e_conv4 in wv[9..17]
@@ -228,7 +246,7 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     {
         const float* bp = stg ? p.b_bias : p.a_bias;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) bias4[i] = (KIND == K67 && stg) ? 0.f : bp[16 * ch + 4 * kq + i];
+        for (int i = 0; i < 4; ++i) bias4[i] = (IS67 && stg) ? 0.f : bp[16 * ch + 4 * kq + i];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             bias4p[i] = (KIND == K12) ? p.b2_bias[16 * ch + 4 * kq + i] : ((KIND == K345 && stg == 0) ? p.a2_bias[16 * ch + 4 * kq + i] : 0.f);
@@ -315,6 +333,25 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
                 }
             }
         } else {
+            if constexpr (KIND == K67N) {
+                // the P' row that seeds the output row started at step t: wave sw reads (and therefore loads) only its own 32 pixels = pieces 2 sw, 2 sw + 1
+                const int y = ys - 3 + t;
+                const unsigned rmask = ((y >= 0) && (y < H)) ? 0u : OOB;
+                const unsigned row_b = rmask ? 0u : (unsigned)y * (unsigned)W * PXB;
+                char* slot = smem + OFF_BRING + (t % NRB) * ROW_B;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) IE_DMA_PIECE(rsB, slot, 2 * sw + j, row_b, rmask);
+                if (sw < 3) {     // plane sw of the fp32 image row whose curve runs at step t (y = ys-6+t), read there by all four waves
+                    const int yi = ys - 6 + t;
+                    const unsigned imask = ((yi >= ys) && (yi < ye)) ? 0u : OOB;
+                    const unsigned base = imask ? 0u : ((unsigned)sw * (unsigned)plane + (unsigned)yi * (unsigned)W) * 4u;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                            rsI, (__attribute__((address_space(3))) void*)(smem + OFF_IMG + (t % NRI) * IMG_SLOT_B + sw * G::IMG_PLANE67N + j * 256),
+                            4, (int)((base + img67_off[j]) | imask), 0, 0, 0);
+                }
+            }
             if constexpr (KIND == K67) {
                 // Waves 4 and 5 carry the curve of colour channel 2 and are the slowest of the step (in-kernel stamps); waves 6 and 7
                 // idle a third of it, so THEY issue all of stage B's DMA: the P row that seeds the output row started at step t
@@ -361,6 +398,7 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     int L = 0, S = 0;
     if (stg == 0) { L = (KIND == K12) ? 2 : (2 * NSA + ((HALO && sw == 0) ? NSA : 0)); }   // K345: NSA = 1
     else if (KIND == K67) L = IE_K67_CURVE2 ? (sw == 3 ? 14 : 0) : (sw == 2 ? 6 : (sw == 3 ? 8 : 0));
+    else if (KIND == K67N) L = sw < 3 ? 4 : 2;
     const int wait_base = L ? (PF - 1) * L : -1;
     (void)S;
 
@@ -375,6 +413,27 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
         rd_first = lds_px(xf < 0 ? (HALO ? TW : 0) : xf);             // without halo DMA: any loaded pixel (the column is dropped)
         const int xl = 64 * ph + 48 + p16 + 1;
         rd_last = lds_px(xl >= TW ? (HALO ? TW + 1 : TW - 1) : xl);
+    }
+
+    // K67N stage B: wave sw owns columns 32 sw .. 32 sw + 31 (two 16-pixel tiles nt) and BOTH 16-row tiles of e_conv7
+    int rdn[2][3] = {{0, 0, 0}, {0, 0, 0}};   // pixel fragment of tile nt at tap column kx (the two out-of-strip columns are clamped: dropped columns)
+    int sd_off[2] = {0, 0};                   // this lane's 16 bytes of seeds in a P ring row: chunk kq of its pixel
+    int im_off[2] = {0, 0};                   // ... and its colour of the fp32 pixel in an image ring row
+    int of_off[2] = {0, 0};                   // where its curve result goes in the fp32 output row
+    if constexpr (KIND == K67N) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int q = 32 * sw + 16 * nt + p16;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                int qq = q + kx - 1;
+                qq = qq < 0 ? 0 : (qq > TW - 1 ? TW - 1 : qq);
+                rdn[nt][kx] = lds_px(qq);
+            }
+            sd_off[nt] = q * PXB + ((kq ^ ((q >> 1) & 3)) << 4);
+            im_off[nt] = (kq < 3 ? kq : 2) * G::IMG_PLANE67N + q * 4;
+            of_off[nt] = kq * G::OUTF_PLANE_B + (q + 2) * 4;        // (kq = 3: the spare plane)
+        }
     }
 
     // one source row into the three live accumulator sets.  The set started by this row (accN, ky = 0) takes its initial value
@@ -758,12 +817,15 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     // Each stage runs its OWN loop (the wave-uniform `stg` branch is taken once, outside): the register allocator then sees two
     // independent live ranges -- stage A's second accumulator family (K345) or stage B's (K12) is not carried through the other
     // stage's loop -- and both loops execute exactly one s_barrier per step.
-#define IE_STEP_HEAD(WAITN)                                                                                         \
+    // HOT0 / HOT1: the steady-state values of WAITN (compile-time; tested first, the 30-way switch is the prologue's path)
+#define IE_STEP_HEAD(WAITN, HOT0, HOT1)                                                                            \
         unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;                                                     \
         (void)ts0; (void)ts1; (void)ts2; (void)ts3;                                                                \
         IE_T(ts0);                                                                                                 \
         if (RPB == 1 || (t % RPB) == 0) {                                                                          \
-        wait_vm(WAITN);                                                                                      \
+        if constexpr (IE_HOTWAIT & (KIND == K12 ? 1 : (KIND == K345 ? 2 : 4)))                                       \
+            ie_wait_vm_hot<(HOT0), (HOT1)>((WAITN), [](int n_) __attribute__((always_inline)) { wait_vm(n_); });    \
+        else wait_vm(WAITN);                                                                                       \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* this wave's LDS writes of step t-1 (hand-off, staging) */ \
         __builtin_amdgcn_s_barrier();                                                                              \
         }                                                                                                          \
@@ -778,7 +840,8 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
                       ie_f32x4 (&pO)[4]) __attribute__((always_inline)) {
         // K12: at the barrier before rows t .. t+RPB-1 the image DMA of row t+RPB-1 must have landed.  Ops younger than it: the
         // 2 (PF-RPB) loads of the rows behind it plus, for each of the min(t, PF-RPB+1) row steps since it was issued, two P stores.
-        IE_STEP_HEAD(KIND == K12 ? 2 * (PF - RPB) + 2 * (t < PF - RPB + 1 ? t : PF - RPB + 1) : wait_base);
+        IE_STEP_HEAD(KIND == K12 ? 2 * (PF - RPB) + 2 * (t < PF - RPB + 1 ? t : PF - RPB + 1) : wait_base,
+                     (KIND == K12 ? 2 * (PF - RPB) + 2 * (PF - RPB + 1) : (PF - 1) * 2 * NSA), ((HALO && KIND != K12) ? (PF - 1) * 3 * NSA : -1));
         if constexpr (KIND == K12) {
             // e_conv1 on the converted image rows -> x1 row ys-4+t (accO); the x1 half of e_conv7 on the x1 row emitted at step t-1
             // (ys-5+t) -> P row ys-6+t complete in pO.  With e_conv7a here and e_conv2 on stage B the two waves of a SIMD carry 44 and
@@ -820,7 +883,7 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     // afterwards), then its MFMAs.  The two stages share each SIMD, so B's epilogue VALU runs under A's MFMAs and A's tail under B's.
     auto step_b = [&](int t, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4], ie_f32x4 (&pN)[4], ie_f32x4 (&pM)[4],
                       ie_f32x4 (&pO)[4]) __attribute__((always_inline)) {
-        IE_STEP_HEAD(wait_base);
+        IE_STEP_HEAD(wait_base, (KIND == K67 ? (PF - 1) * 6 : -1), (KIND == K67 ? (PF - 1) * 8 : -1));
         issue(t + PF);
         IE_T(ts2);
         // accN (and pN) still hold the output row finished at step t-1: ys-5-LAG_A+(t-1)
@@ -884,9 +947,154 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     };
 
 
+    // ---- K67N stage B: the x6 half of e_conv7 (seeded by P) + tanh + LE curve, all in registers -------------------------------
+    // e_conv7's 24 output rows are permuted on the host (ie_zdce_plan.hip, chan_k67): row 4 kq + i of 16-row tile j is curve map
+    // r_{4j+i} of colour kq (kq = 3: zero rows).  A wave owns both tiles on 32 columns, so after the MFMAs lane (p16, kq) holds ALL EIGHT
+    // r_i of colour kq of its pixel, in iteration order (tile 0 regs 0..3, tile 1 regs 0..3): tanh and the eight curve steps
+    // (zero_dce.py:183-188) run straight off the accumulators -- no fp32 park in LDS, no second pass over it, no curve work on stage A.
+    // accN[2 j + nt] = tile j, pixel tile nt.  The row's results are staged in LDS as fp32 [colour][pixel] and leave one step later as
+    // 16-byte vectors (one 496-byte run per colour and strip row).  P is read in the same permuted order (K12 writes position
+    // 8 kq + 4 j + i of a pixel's 64-byte line): one ds_read_b128 seeds both tiles.
+    // The step is ONE MFMA stream (tools/micro/coissue.hip: a wave's vector work is nearly free between its own MFMAs, two issue
+    // slots per 16x16x32 MFMA, and costs its full length as a phase of its own): the 96 tanh / curve operations of the row finished at
+    // step t-1 ride as fillers pinned behind fixed MFMAs; only the 16 scalings that read that row's accumulators (the first MFMAs
+    // restart them from the seeds) and the seed conversions come first.
+    // Timeline: row y = ys-3+t is seeded at step t, finished at step t+2, its curve runs at step t+3 (accN again), stored at t+4.
+    auto step_b67n = [&](int t, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4]) __attribute__((always_inline)) {
+        IE_STEP_HEAD(wait_base, (PF - 1) * 4, (PF - 1) * 2);     // waves 4-6: two P pieces + two image pieces per row, wave 7: two P pieces; stores in between only make it stricter
+        IE_T(ts2);
+        typedef __attribute__((ext_vector_type(8))) TH th8;
+        const char* ps = smem + OFF_BRING + (t % NRB) * ROW_B;
+        const char* ims = smem + OFF_IMG + (t % NRI) * IMG_SLOT_B;
+        const th8 sv0 = *(const th8*)(ps + sd_off[0]), sv1 = *(const th8*)(ps + sd_off[1]);     // seeds of the output row started now (P row ys-3+t)
+        float v0 = *(const float*)(ims + im_off[0]), v1 = *(const float*)(ims + im_off[1]);     // fp32 pixel of the row finished at step t-1 (y = ys-6+t)
+        {   // (1) the row staged at step t-1 leaves
+            const int yo = ys - 7 + t;
+            const bool row_ok = (yo >= ys) && (yo < ye);
+            const char* os = smem + OFF_OUTF + ((t + 1) & 1) * G::OUTF_SLOT_B;
+            const int xs = xc0 + MARG;                                  // first stored column of the strip (a multiple of 4)
+            if (p.enhanced) {
+                if ((W & 3) == 0) {       // wave sw < 3: colour sw, lane l < 31: pixels 4 l .. 4 l + 3 of the 124 stored ones
+                    const ie_u32x4 v = *(const ie_u32x4*)(os + (sw < 3 ? sw : 0) * G::OUTF_PLANE_B + 16 + 16 * (lane < 31 ? lane : 0));
+                    const int x = xs + 4 * lane;
+                    const bool ok = row_ok && sw < 3 && lane < 31 && x < W;
+                    const unsigned off = ok ? (unsigned)(((size_t)sw * plane + (size_t)yo * W + x) * 4) : OOB;
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rsE, (int)off, 0, 0);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int q = lane + 64 * k, x = xc0 + q;
+                        const float v = *(const float*)(os + (sw < 3 ? sw : 0) * G::OUTF_PLANE_B + (q + 2) * 4);
+                        const bool ok = row_ok && sw < 3 && q >= MARG && q < TW - MARG && x < W;
+                        const unsigned off = ok ? (unsigned)(((size_t)sw * plane + (size_t)yo * W + x) * 4) : OOB;
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsE, (int)off, 0, 0);
+                    }
+                }
+            }
+            if (p.u8 && sw == 3) {        // HWC bytes: 372 per strip row, wave 7 quantises them from the staged fp32 values
+                const int nbytes = row_ok ? min(TSK, W - xs) * 3 : 0;
+                if ((W & 3) == 0) {
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int d = lane + 64 * k;
+                        unsigned pk = 0;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int b = 4 * d + e, pxr = b / 3, c = b - 3 * pxr;
+                            const float v = *(const float*)(os + c * G::OUTF_PLANE_B + ((pxr < TSK ? pxr : 0) + MARG + 2) * 4);
+                            pk |= (unsigned)ie_quant_u8(v) << (8 * e);
+                        }
+                        const unsigned off = (4 * d < nbytes) ? (unsigned)(((size_t)yo * W + xs) * 3 + 4 * d) : OOB;
+                        __builtin_amdgcn_raw_buffer_store_b32(pk, rsU, (int)off, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        const int b = lane + 64 * k, pxr = b / 3, c = b - 3 * pxr;
+                        const float v = *(const float*)(os + c * G::OUTF_PLANE_B + ((pxr < TSK ? pxr : 0) + MARG + 2) * 4);
+                        const unsigned off = (b < nbytes) ? (unsigned)(((size_t)yo * W + xs) * 3 + b) : OOB;
+                        __builtin_amdgcn_raw_buffer_store_b8(ie_quant_u8(v), rsU, (int)off, 0, 0);
+                    }
+                }
+            }
+        }
+        issue(t + PF);       // (2)
+        // (3) the finished row's accumulators are read ONCE (exp(2x) = exp2(x * 2 / ln 2), ie_tanh_fast); the seeds replace them
+        float m0[8], m1[8], r0[8], r1[8];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                m0[4 * j + i] = accN[2 * j][i] * 2.885390081777927f;
+                m1[4 * j + i] = accN[2 * j + 1][i] * 2.885390081777927f;
+            }
+        ie_f32x4 sd[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { sd[0][i] = (float)sv0[i]; sd[2][i] = (float)sv0[4 + i]; sd[1][i] = (float)sv1[i]; sd[3][i] = (float)sv1[4 + i]; }
+        // (4) x6 row ys-4+t (handed over by stage A at step t-1) into the three live sets of both tiles, 36 MFMAs; filler o of 96:
+        //     k = o / 12 (curve iteration), op = (o % 12) / 2, pixel tile = o % 2
+        float e0 = 0.f, e1 = 0.f, u0 = 0.f, u1 = 0.f;
+        auto op = [&](int o) __attribute__((always_inline)) {
+            const int k = o / 12, w = (o % 12) >> 1, nt = o & 1;
+            float& e = nt ? e1 : e0; float& u = nt ? u1 : u0; float& v = nt ? v1 : v0;
+            float* mm = nt ? m1 : m0; float* rr = nt ? r1 : r0;
+            if (w == 0) e = __builtin_amdgcn_exp2f(mm[k]);
+            if (w == 1) e = e + 1.0f;
+            if (w == 2) e = __builtin_amdgcn_rcpf(e);
+            if (w == 3) rr[k] = __builtin_fmaf(e, -2.0f, 1.0f);
+            if (w == 4) u = __builtin_fmaf(v, v, -v);
+            if (w == 5) v = __builtin_fmaf(rr[k], u, v);
+        };
+        const char* ra_row = smem + OFF_RA + ((t + RPB) % NRH) * ROW_B;
+        frag bx[6];
+        auto rd = [&](int g) __attribute__((always_inline)) { bx[g] = *(const frag*)(ra_row + rdn[g & 1][g >> 1]); };
+        rd(0); rd(1); rd(2);
+        IE_SB();
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {
+            const int kx = g >> 1, nt = g & 1;
+            if (g + 3 < 6) rd(g + 3);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int s0 = 6 * g + 3 * j;                  // MFMA index of this triplet's first
+                accN[2 * j + nt] = ie_mfma16_raw<TH>(wv[9 * j + 0 * 3 + kx], bx[g], kx == 0 ? sd[2 * j + nt] : accN[2 * j + nt]);
+#pragma unroll
+                for (int o = (s0 * 8) / 3; o < ((s0 + 1) * 8) / 3; ++o) op(o);
+                IE_SB();
+                accM[2 * j + nt] = ie_mfma16_raw<TH>(wv[9 * j + 1 * 3 + kx], bx[g], accM[2 * j + nt]);
+#pragma unroll
+                for (int o = ((s0 + 1) * 8) / 3; o < ((s0 + 2) * 8) / 3; ++o) op(o);
+                IE_SB();
+                accO[2 * j + nt] = ie_mfma16_raw<TH>(wv[9 * j + 2 * 3 + kx], bx[g], accO[2 * j + nt]);
+#pragma unroll
+                for (int o = ((s0 + 2) * 8) / 3; o < ((s0 + 3) * 8) / 3; ++o) op(o);
+                IE_SB();
+            }
+        }
+        {   // (5) the curve's results into the fp32 output row; the 24 curve maps (optional) straight to HBM: NCHW fp32, plane 3 i + colour
+            char* ow = smem + OFF_OUTF + (t & 1) * G::OUTF_SLOT_B;
+            *(float*)(ow + of_off[0]) = v0;
+            *(float*)(ow + of_off[1]) = v1;
+            if (p.adjust) {
+                const int yc = ys - 6 + t;
+                const bool rowc = (yc >= ys) && (yc < ye);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const int q = 32 * sw + 16 * nt + p16, x = xc0 + q;
+                    const bool ok = rowc && kq < 3 && q >= MARG && q < TW - MARG && x < W;
+                    const unsigned base = ok ? (unsigned)(((size_t)kq * plane + (size_t)yc * W + x) * 4) : OOB;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(nt ? r1[k] : r0[k]), rsJ, (int)(ok ? base + (unsigned)((size_t)(3 * k) * plane * 4) : OOB), 0, 0);
+                }
+            }
+        }
+        IE_STEP_TAIL();
+    };
+
     // Stage B: e_conv2.  accN = the x2 row finished at step t-1.  Fillers: its pack + store, and the conversion of image row R(t).
     auto step_b12 = [&](int t, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4]) __attribute__((always_inline)) {
-        IE_STEP_HEAD(wait_base);
+        IE_STEP_HEAD(wait_base, -1, -1);      // (stage B of K12 issues no loads: wait_base < 0)
         IE_T(ts2);
         const int yo = ys - 6 - LAG_A - LAG_H - G::OUT + t;    // the row parked at step t-1 (finished at step t-2)
         const unsigned rmask = ((yo >= ys) && (yo < ye) && !((IE_EXP & 128) && p.N > 0)) ? 0u : OOB;   // IE_EXP 128: every store out of range (same instructions, no HBM writes)
@@ -933,7 +1141,7 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     auto step_a12 = [&](int t, ie_f32x4 (&eN)[4], ie_f32x4 (&eO)[4], ie_f32x4 (&pN)[4], ie_f32x4 (&pM)[4], ie_f32x4 (&pO)[4]) __attribute__((always_inline)) {
         // at the barrier the image DMA of row t+RPB-1 must have landed.  Per step this wave issues two P stores, then two loads:
         // ops younger than that DMA = 2 (PF-RPB) prologue loads + 2 per elapsed step, 4 (PF-RPB) in the steady state
-        IE_STEP_HEAD(2 * (PF - RPB) + 2 * (t < PF - RPB ? t : PF - RPB));
+        IE_STEP_HEAD(2 * (PF - RPB) + 2 * (t < PF - RPB ? t : PF - RPB), 4 * (PF - RPB), -1);
         IE_T(ts2);
         const int yo = ys - 6 - LAG_A - LAG_H - G::OUT + t;    // the P row parked at step t-1 (finished at step t-2)
         const unsigned rmask = ((yo >= ys) && (yo < ye) && !((IE_EXP & 128) && p.N > 0)) ? 0u : OOB;   // IE_EXP 128: every store out of range (same instructions, no HBM writes)
@@ -1023,13 +1231,21 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
                 if (t + 2 < n_steps) step_b12(t + 2, a1, a2, a0);
             }
         }
+    } else if (KIND == K67N && stg == 1) {
+        if constexpr (KIND == K67N) {
+            for (int t = 0; t < n_steps; t += 3) {
+                step_b67n(t, a0, a1, a2);
+                if (t + 1 < n_steps) step_b67n(t + 1, a2, a0, a1);
+                if (t + 2 < n_steps) step_b67n(t + 2, a1, a2, a0);
+            }
+        }
     } else if (stg == 0) {
         for (int t = 0; t < n_steps; t += 3) {
             step_a(t, a0, a1, a2, q0, q1, q2);
             if (t + 1 < n_steps) step_a(t + 1, a2, a0, a1, q2, q0, q1);
             if (t + 2 < n_steps) step_a(t + 2, a1, a2, a0, q1, q2, q0);
         }
-    } else {
+    } else if constexpr (KIND != K67N) {
         for (int t = 0; t < n_steps; t += 3) {
             step_b(t, a0, a1, a2, q0, q1, q2);
             if (t + 1 < n_steps) step_b(t + 1, a2, a0, a1, q2, q0, q1);
@@ -1065,6 +1281,10 @@ IE_DEF_FUSED(zdce_k45_conv4_conv5_bf16, __bf16, __bf16, __bf16, __bf16, K45)
 IE_DEF_FUSED(zdce_k67_conv6_conv7_curve_bf16, __bf16, __bf16, __bf16, __bf16, K67)
 // the "bf16" schedule's last kernel: x2 (fp16) and x5 (bf16) in, x6 / P / e_conv7b in fp16
 IE_DEF_FUSED(zdce_k67_conv6_conv7_curve_mix, _Float16, __bf16, _Float16, _Float16, K67)
+// K67N: the shipped form (curve in stage B's registers; rocprof names zdce_k67n_*)
+IE_DEF_FUSED(zdce_k67n_conv6_conv7_curve_f16, _Float16, _Float16, _Float16, _Float16, K67N)
+IE_DEF_FUSED(zdce_k67n_conv6_conv7_curve_bf16, __bf16, __bf16, __bf16, __bf16, K67N)
+IE_DEF_FUSED(zdce_k67n_conv6_conv7_curve_mix, _Float16, __bf16, _Float16, _Float16, K67N)
 #undef IE_DEF_FUSED
 #define IE_DEF_FUSED3(NAME, TA0, T3, TH, TO) \
     __global__ __launch_bounds__(512, 2) void NAME(FusedParams p) { zdce_fused2_body<TA0, TA0, TH, TO, K345, T3>(p); }
@@ -1084,14 +1304,15 @@ static int launch_fused_t(FusedFn fn, const ZdceFusedLaunch& a, hipStream_t st) 
     p.N = a.N; p.H = a.H; p.W = a.W; p.y_begin = a.y_begin; p.y_end = a.y_end; p.rows_per_block = a.rows_per_block;
     p.n_begin = a.n_begin;
     p.stamps = (unsigned long long*)a.stamps;
-    p.strips = ie_cdiv(a.W, KIND == K345 ? TW - 6 : (KIND == K67 ? TW - 4 : TS));
+    p.strips = ie_cdiv(a.W, KIND == K345 ? TW - 6 : ((KIND == K67 || KIND == K67N) ? TW - 4 : TS));
+    if (KIND == K67N && a.adjust && (size_t)a.H * a.W * 24 * 4 >= 0x7fffffffull) IE_FAIL(IE_ERR_UNSUPPORTED, "zdce fused: frame too large for 31-bit offsets into `adjust`");
     p.chunks = ie_cdiv(a.y_end - a.y_begin, a.rows_per_block);
     const long long blocks = (long long)p.strips * p.chunks * a.n_count;
     if (blocks <= 0 || blocks > 0x7fffffffLL) IE_FAIL(IE_ERR_INVALID, "zdce fused: bad grid %lld", blocks);
     if ((size_t)a.H * a.W * 32 * 2 >= 0x7fffffffull) IE_FAIL(IE_ERR_UNSUPPORTED, "zdce fused: frame too large for 31-bit offsets");
     const size_t lds = FusedGeom<KIND>::LDS_B;
     // the dynamic-LDS limit is a per-function attribute: set it once per kernel
-    static FusedFn attr_done[8] = {nullptr};
+    static FusedFn attr_done[16] = {nullptr};
     bool done = false;
     for (FusedFn f : attr_done) done = done || (f == fn);
     if (!done) {
@@ -1117,6 +1338,10 @@ int ie_zdce_launch_fused(const ZdceFusedLaunch& a, hipStream_t st) {
         if (h_all) return launch_fused_t<K67>(zdce_k67_conv6_conv7_curve_f16, a, st);
         if (b_all) return launch_fused_t<K67>(zdce_k67_conv6_conv7_curve_bf16, a, st);
         if (a.dt_a0 == IE_F16 && a.dt_a1 == IE_BF16 && a.dt_h == IE_F16) return launch_fused_t<K67>(zdce_k67_conv6_conv7_curve_mix, a, st);
+    } else if (a.kind == 670) {
+        if (h_all) return launch_fused_t<K67N>(zdce_k67n_conv6_conv7_curve_f16, a, st);
+        if (b_all) return launch_fused_t<K67N>(zdce_k67n_conv6_conv7_curve_bf16, a, st);
+        if (a.dt_a0 == IE_F16 && a.dt_a1 == IE_BF16 && a.dt_h == IE_F16) return launch_fused_t<K67N>(zdce_k67n_conv6_conv7_curve_mix, a, st);
     } else if (a.kind == 345) {      // dt_a0 = x2, dt_a1 = x3 (LDS), dt_h = x4 (LDS), dt_o = x5
         if (h_all) return launch_fused_t<K345>(zdce_k345_conv3_conv4_conv5_f16, a, st);
         if (b_all) return launch_fused_t<K345>(zdce_k345_conv3_conv4_conv5_bf16, a, st);

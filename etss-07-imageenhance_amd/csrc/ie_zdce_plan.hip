@@ -52,6 +52,7 @@ struct ie_zdce_plan {
     size_t off_w1m = 0;   // e_conv1 as MFMA A fragments (fused K12 kernel)
     size_t off_w27 = 0;   // K12 stage B: e_conv2 fragments followed by the x1 half of e_conv7
     size_t off_w7b = 0;   // K67 stage B: the x6 half of e_conv7
+    size_t off_b7p = 0;   // e_conv7's bias in K12's row order (what P is seeded with)
     // workspace
     char* ws = nullptr;
     size_t ws_bytes = 0;
@@ -217,11 +218,20 @@ IE_EXPORT int ie_zdce_finalize(ie_zdce_plan* p, void* stream) {
     if (dt != IE_F32) {
         // e_conv7([x1, x6]) = W7a * x1 + W7b * x6.  K12 computes P = W7a*x1 + bias7 next to e_conv2 (one fragment
         // buffer [hc][e_conv2 9 | e_conv7a 9]), K67 adds W7b * x6.  Same fragment order as above.
-        auto pack9 = [&](std::vector<unsigned short>& hw, size_t base, int hc, const float* w, int Co, int Ci, int ci0, int sdt) {
+        // e_conv7's rows are PERMUTED for the shipped last kernel (K67N, ie_zdce_fused.hip): its stage B wants lane (pixel, kq) of the
+        // two 16-row MFMA tiles to hold the eight curve maps r_0..r_7 of ONE colour kq, so row 4 kq + i of tile j is channel 3 (4 j + i) + kq
+        // (r_i of colour c is channel 3 i + c, zero_dce.py:183-188; kq = 3: zero rows).  K12 writes P so that the 16 bytes a lane seeds both
+        // tiles from are contiguous: position 8 kq + 4 j + i of the 64-byte P' record holds that same channel; positions 24..31 are zero
+        // rows whose bytes K12 replaces by the pixel's fp32 R, G, B (step_a12).  IE_ZDCE_VAR_K67_LEGACY keeps channel order.
+        const bool legacy67 = (p->cfg.variant & IE_ZDCE_VAR_K67_LEGACY) != 0;
+        auto chan_k12 = [&](int pos) { return legacy67 ? (pos < 24 ? pos : -1) : (pos < 24 ? 3 * (4 * ((pos >> 2) & 1) + (pos & 3)) + (pos >> 3) : -1); };
+        auto chan_k67 = [&](int row) { const int j = row >> 4, m = row & 15; return legacy67 ? (row < 24 ? row : -1) : ((m >> 2) < 3 ? 3 * (4 * j + (m & 3)) + (m >> 2) : -1); };
+        auto chan_id = [&](int row) { return row; };
+        auto pack9 = [&](std::vector<unsigned short>& hw, size_t base, int hc, const float* w, int Co, int Ci, int ci0, int sdt, auto&& row_chan) {
             for (int t = 0; t < 9; ++t) for (int lane = 0; lane < 64; ++lane) for (int j = 0; j < 8; ++j) {
-                const int co = 16 * hc + (lane & 15);
+                const int co = row_chan(16 * hc + (lane & 15));
                 const int ci = ci0 + 8 * (lane >> 4) + j;
-                const float v = co < Co ? w[((size_t)co * Ci + ci) * 9 + t] : 0.f;
+                const float v = (co >= 0 && co < Co) ? w[((size_t)co * Ci + ci) * 9 + t] : 0.f;
                 hw[base + ((size_t)t * 64 + lane) * 8 + j] = sdt == IE_F16 ? f32_to_f16_bits(v) : f32_to_bf16_bits(v);
             }
         };
@@ -230,8 +240,8 @@ IE_EXPORT int ie_zdce_finalize(ie_zdce_plan* p, void* stream) {
         {
             std::vector<unsigned short> hw((size_t)2 * 18 * 64 * 8, 0);
             for (int hc = 0; hc < 2; ++hc) {
-                pack9(hw, ((size_t)hc * 18 + 0) * 64 * 8, hc, p->w[1].data(), 32, 32, 0, p->xdt[1]);
-                pack9(hw, ((size_t)hc * 18 + 9) * 64 * 8, hc, p->w[6].data(), 24, 64, 0, p->xdt[1]);
+                pack9(hw, ((size_t)hc * 18 + 0) * 64 * 8, hc, p->w[1].data(), 32, 32, 0, p->xdt[1], chan_id);
+                pack9(hw, ((size_t)hc * 18 + 9) * 64 * 8, hc, p->w[6].data(), 24, 64, 0, p->xdt[1], chan_k12);
             }
             const char* q = (const char*)hw.data();
             host.insert(host.end(), q, q + hw.size() * 2);
@@ -240,9 +250,17 @@ IE_EXPORT int ie_zdce_finalize(ie_zdce_plan* p, void* stream) {
         p->off_w7b = host.size();
         {
             std::vector<unsigned short> hw((size_t)2 * 9 * 64 * 8, 0);
-            for (int hc = 0; hc < 2; ++hc) pack9(hw, (size_t)hc * 9 * 64 * 8, hc, p->w[6].data(), 24, 64, 32, p->xdt[6]);
+            for (int hc = 0; hc < 2; ++hc) pack9(hw, (size_t)hc * 9 * 64 * 8, hc, p->w[6].data(), 24, 64, 32, p->xdt[6], chan_k67);
             const char* q = (const char*)hw.data();
             host.insert(host.end(), q, q + hw.size() * 2);
+        }
+        align(256);
+        p->off_b7p = host.size();
+        {
+            std::vector<float> hb(32, 0.f);
+            for (int pos = 0; pos < 32; ++pos) { const int c = chan_k12(pos); hb[pos] = c >= 0 ? p->b[6][c] : 0.f; }
+            const char* q = (const char*)hb.data();
+            host.insert(host.end(), q, q + 32 * 4);
         }
     }
     if (p->d_w) { (void)hipFree(p->d_w); p->d_w = nullptr; }
@@ -361,7 +379,7 @@ static int forward_mfma(ie_zdce_plan* p, const float* image, float* enhanced, fl
             auto fused = [&](int kind, int prof_layer) -> int {
                 // diagnostic (wrong results): IE_ZDCE_ONLY=12|345|67 launches just that kernel, e.g. to time it without its neighbours' power draw
                 static const int only = getenv("IE_ZDCE_ONLY") ? atoi(getenv("IE_ZDCE_ONLY")) : 0;
-                if (only && only != kind) return IE_OK;
+                if (only && only != kind && !(only == 67 && kind == 670)) return IE_OK;    // (67 selects either form of the last kernel)
                 ProfScope ps(p, prof_layer, st);
                 ZdceFusedLaunch a;
                 memset(&a, 0, sizeof(a));
@@ -369,7 +387,7 @@ static int forward_mfma(ie_zdce_plan* p, const float* image, float* enhanced, fl
                 a.img = image;
                 a.stamps = g_ie_stamps ? (void*)((unsigned long long*)g_ie_stamps + (size_t)(kind == 12 ? 0 : (kind == 45 || kind == 345) ? 1 : 2) * (1u << 20)) : nullptr;
                 if (kind == 12) {
-                    a.a_w = p->d_w + p->off_w1m; a.a_bias = B_(0); a.b_w = p->d_w + p->off_w27; a.b_bias = B_(1); a.b2_bias = B_(6);
+                    a.a_w = p->d_w + p->off_w1m; a.a_bias = B_(0); a.b_w = p->d_w + p->off_w27; a.b_bias = B_(1); a.b2_bias = (const float*)(p->d_w + p->off_b7p);
                     a.a_dst = x[1]; a.b_dst = x[2]; a.y_begin = lo(2); a.y_end = hi(2);   // x[1] holds P = W7a*x1 + bias7, not x1
                     a.dt_h = a.dt_a0 = a.dt_a1 = p->xdt[1]; a.dt_o = p->xdt[2];            // (P takes x2's element type = x6's)
                 } else if (kind == 45) {
@@ -403,7 +421,7 @@ static int forward_mfma(ie_zdce_plan* p, const float* image, float* enhanced, fl
                 } else if (rc == IE_OK) {
                     rc = fused(345, 4);        // e_conv3 + e_conv4 + e_conv5: x3 and x4 never reach HBM
                 }
-                if (rc == IE_OK) rc = fused(67, 6);
+                if (rc == IE_OK) rc = fused((p->cfg.variant & IE_ZDCE_VAR_K67_LEGACY) ? 67 : 670, 6);
             }
             if (rc) return rc;
         }
@@ -520,6 +538,7 @@ IE_EXPORT int ie_zdce_profile_forward(ie_zdce_plan* p, const float* image, float
     const bool fused = p->cfg.compute_dtype != IE_F32 && !(p->cfg.variant & IE_ZDCE_VAR_UNFUSED);
     const bool k345 = fused && !(p->cfg.variant & IE_ZDCE_VAR_NO_K345);
     for (int l = 0; l < NL; ++l) { ms[l] = 0.f; names[l] = k345 ? kFused3Names[l] : (fused ? kFusedNames[l] : kLayerNames[l]); if (launches) launches[l] = 0; }
+    if (fused && !(p->cfg.variant & IE_ZDCE_VAR_K67_LEGACY)) names[6] = "zdce_k67n_conv6_conv7_curve";
     for (size_t i = 0; i < p->ev_layer.size(); ++i) {
         float t = 0.f;
         IE_HIP_CHECK(hipEventElapsedTime(&t, p->ev[2 * i], p->ev[2 * i + 1]));
