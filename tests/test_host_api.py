@@ -99,7 +99,7 @@ def test_capi_library_exports_every_declared_symbol():
     lib = capi.lib()
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} not exported by {capi.LIB_PATH}"
-    assert lib.ie_abi_version() == 1
+    assert lib.ie_abi_version() == capi.ABI_VERSION
 
 
 def test_sharding_ranges():
