@@ -41,13 +41,26 @@ constexpr unsigned OOB = 0x80000000u;
 #endif
 constexpr int PF_DEFAULT = IE_PF; // rows of DMA issued ahead (K67 is LDS-limited to 3)
 
-enum { K12 = 12, K45 = 45, K67 = 67, K345 = 345, K67N = 670 };   // K67N: K67 with the curve in stage B's registers (below)
+enum { K12 = 12, K45 = 45, K67 = 67, K345 = 345, K67N = 670, K67F = 671 };   // K67N: K67 with the curve in stage B's registers (below); K67F: K67N
+                                                                              // compiled for `enhanced` fp32 as the only output and W % 4 == 0 (no output-mode branches)
 
 #ifndef IE_EXP
 #define IE_EXP 0      // timing experiments (wrong results): 1 no image DMA / row conversion, 2 e_conv1 without LDS reads, 4 no hand-off write,
 #endif                // 8 MFMA streams without LDS reads, 16 no K12 stores, 32 no e_conv1 at all, 64 raw-accumulator stores (no epilogue VALU), 128 K12 stores forced out of range; K67: 1024 no curve, 2048 curve without tanh, 4096 no image DMA, 8192 no P DMA
 #ifndef IE_HOTWAIT
 #define IE_HOTWAIT 7      // bit 0: K12, bit 1: K345, bit 2: the others -- steady-state vmcnt waits tested first (ie_wait_vm_hot), A-B switch
+#endif
+#ifndef IE_K67N_STREAM_A
+#define IE_K67N_STREAM_A 0   // 1: K67N stage A as ONE pair of MFMA streams per step: the hand-off write of the row finished a step earlier and the
+#endif                       // step's four LDS-DMA pieces ride as fillers behind fixed MFMAs (0: MFMAs, then DMA issue, then the hand-off write)
+#ifndef IE_K67N_PA
+#define IE_K67N_PA 0      // 1: the P row's eight LDS-DMA pieces are issued by stage A (two per wave) instead of stage B (measured slower: 6.86 against 6.65 ms)
+#endif
+#if IE_K67N_STREAM_A && IE_K67N_PA
+#error "IE_K67N_STREAM_A issues only stage A's own rows: build it with -DIE_K67N_PA=0"
+#endif
+#ifndef IE_K67N_PRIO
+#define IE_K67N_PRIO 0
 #endif
 #ifndef IE_K12_RPB
 #define IE_K12_RPB 1
@@ -72,7 +85,8 @@ template <int KIND> struct FusedGeom {
     // is as long as its MFMA time, and its rings are small: it runs TWO rows between barriers (the stages then talk through rows
     // that are one barrier period old, so every hand-off lags RPB rows and the rings hold 2 RPB slots).
     static constexpr int RPB = (KIND == K12) ? IE_K12_RPB : 1;
-    static constexpr bool IS67 = (KIND == K67 || KIND == K67N);
+    static constexpr bool IS67N = (KIND == K67N || KIND == K67F);
+    static constexpr bool IS67 = (KIND == K67 || IS67N);
     static constexpr int PF = IS67 ? 3 : (KIND == K12 && RPB > 1 ? 5 : PF_DEFAULT);   // rows of DMA issued ahead
     static constexpr int ROW_B = ROW_PX * 64;
     static constexpr int NSA = IS67 ? 2 : ((KIND == K45 || KIND == K345) ? 1 : 0);     // stage A HBM sources (K12: image)
@@ -84,15 +98,16 @@ template <int KIND> struct FusedGeom {
     static constexpr int LAG_B = RPB - 1;                         // extra rows stage B runs behind stage A
     // K12 streamed form: every epilogue (hand-off write, stores) is deferred by one step and rides between the MFMAs of the next
     static constexpr int DEF = (KIND == K12 && IE_K12_STREAM) ? 1 : 0;
-    static constexpr int LAG_H = LAG_B + DEF;                     // rows between stage A computing a hand-off row and its consumers reading it, minus one
+    static constexpr int DEFA = (IS67N && IE_K67N_STREAM_A) ? 1 : 0;   // K67N: stage A's hand-off write is deferred by one step
+    static constexpr int LAG_H = LAG_B + DEF + DEFA;              // rows between stage A computing a hand-off row and its consumers reading it, minus one
     // fp32 image ring slots (K67: kept until the deferred curve; K67N: DMA'd PF steps ahead of the step whose curve reads it).
     // (Tried for K67N: the fp32 pixel riding in the unused bytes 48..59 of K12's P record instead of a ring of its own -- one 64-byte line per
     // pixel, no image read in the last kernel.  K12 + 0.45 ms per 64 frames for the six LDS reads and eight selects per wave and row in its
     // stage A stream against 0 measurable for these DMAs here: not kept.)
-    static constexpr int NRI = (KIND == K12) ? PF + RPB : (KIND == K67N ? PF + 1 : PF + 3);
+    static constexpr int NRI = (KIND == K12) ? PF + RPB : (IS67N ? PF + 1 : PF + 3);
     static constexpr int NRC = 2 + LAG_A + RPB;                   // K12: converted image rows (3 being read + RPB being written)
     static constexpr int IMG_PLANE67N = 144 * 4;                   // K67N: plane pitch 144 floats -> colours 0 / 1 of a pixel on different banks
-    static constexpr int IMG_SLOT_B = (KIND == K67N) ? 3 * IMG_PLANE67N : 2048;   // 3 planes x 132 px fp32 (K12) / 3 x 128 (K67)
+    static constexpr int IMG_SLOT_B = IS67N ? 3 * IMG_PLANE67N : 2048;   // 3 planes x 132 px fp32 (K12) / 3 x 128 (K67)
     static constexpr int CV_PLANE_B = 1088;                       // K12: converted image row, [136 px][RGB0] 16-bit
     static constexpr int CV_SLOT_B = 2 * CV_PLANE_B;              //      hi plane + lo plane
     static constexpr int STAGE_SLOT_B = 24 * TW * 4;              // K67: tanh(r) staging [24][128] fp32, double buffered
@@ -111,7 +126,7 @@ template <int KIND> struct FusedGeom {
     static constexpr int OUT_B = OUT ? (KIND == K12 ? 2 : 1) * 2 * ROW_B : 0;     // (two tensors x) two slots
     // K67N: the curve's fp32 results of a row, [3 colours][132] (pixel q at float q + 2, so the 124 stored pixels start 16-byte aligned), two slots
     static constexpr int OUTF_PLANE_B = 132 * 4, OUTF_SLOT_B = 4 * OUTF_PLANE_B;      // (a fourth plane: where the idle lane group kq = 3 writes, branch-free)
-    static constexpr int OUTF_B = (KIND == K67N) ? 2 * OUTF_SLOT_B : 0;
+    static constexpr int OUTF_B = IS67N ? 2 * OUTF_SLOT_B : 0;
     static constexpr int LDS_B = A_RING_B + B_RING_B + R3_B + RA_B + IMG_B + CV_B + STAGE_B + DUMP_B + OUT_B + OUTF_B;
 };
 
@@ -165,8 +180,9 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     constexpr int PXB = 32 * 2;                             // 64 B per pixel per tensor
     constexpr int ROW_B = G::ROW_B;                         // one ring row of one tensor
     constexpr int NSA = G::NSA;
-    constexpr bool IS67 = G::IS67;
-    constexpr int NFB = (KIND == K45 || KIND == K12 || KIND == K345 || KIND == K67N) ? 18 : 9;         // stage B weight fragments (K12: e_conv2 + e_conv7a; K67N: both 16-row tiles of e_conv7b)
+    constexpr bool IS67 = G::IS67, IS67N = G::IS67N, FAST67 = (KIND == K67F);
+    (void)FAST67;
+    constexpr int NFB = (KIND == K45 || KIND == K12 || KIND == K345 || IS67N) ? 18 : 9;         // stage B weight fragments (K12: e_conv2 + e_conv7a; K67N: both 16-row tiles of e_conv7b)
     constexpr int NW = IS67 ? 18 : NFB;                     // weight fragments held per wave (K12 stage A: 2, K67 / K345 stage A: 18)
     // K67 and K345 load NO halo columns for stage A's HBM rows (one 8-lane LDS-DMA instruction per tensor and row on the
     // stage's busiest wave): the outermost computed column of stage A is then wrong too and one more column a side is dropped.
@@ -216,15 +232,15 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     const auto rsDa = mk((char*)(KIND == K12 ? p.a_dst : (void*)p.b_w) + (KIND == K12 ? (size_t)n * frame_b : 0), frame_b);
     const auto rsDb = mk((char*)(!IS67 ? p.b_dst : (void*)p.b_w) + (!IS67 ? (size_t)n * frame_b : 0), frame_b);
     // K67N: the three outputs through buffer descriptors (an out-of-range offset drops a masked lane's store; absent outputs get an empty range)
-    const auto rsE = mk((KIND == K67N && p.enhanced) ? (const void*)(p.enhanced + (size_t)n * 3 * plane) : p.b_w, (KIND == K67N && p.enhanced) ? 3 * plane * 4 : 0);
-    const auto rsJ = mk((KIND == K67N && p.adjust) ? (const void*)(p.adjust + (size_t)n * 24 * plane) : p.b_w, (KIND == K67N && p.adjust) ? 24 * plane * 4 : 0);
-    const auto rsU = mk((KIND == K67N && p.u8) ? (const void*)(p.u8 + (size_t)n * 3 * plane) : p.b_w, (KIND == K67N && p.u8) ? 3 * plane : 0);
+    const auto rsE = mk((IS67N && p.enhanced) ? (const void*)(p.enhanced + (size_t)n * 3 * plane) : p.b_w, (IS67N && p.enhanced) ? 3 * plane * 4 : 0);
+    const auto rsJ = mk((IS67N && p.adjust) ? (const void*)(p.adjust + (size_t)n * 24 * plane) : p.b_w, (IS67N && p.adjust) ? 24 * plane * 4 : 0);
+    const auto rsU = mk((IS67N && p.u8) ? (const void*)(p.u8 + (size_t)n * 3 * plane) : p.b_w, (IS67N && p.u8) ? 3 * plane : 0);
 
     // ---- weights of this wave's stage into registers -------------------------------------------
     frag wv[NW];
     {
         const int nfr = stg ? NFB : (KIND == K12 ? 2 : 9 * NSA);   // fragments per cout half
-        const frag* wp = (const frag*)(stg ? p.b_w : p.a_w) + ((KIND == K67N && stg) ? 0 : (size_t)ch * nfr * 64);     // K67N stage B: both tiles, [tile][tap]
+        const frag* wp = (const frag*)(stg ? p.b_w : p.a_w) + ((IS67N && stg) ? 0 : (size_t)ch * nfr * 64);     // K67N stage B: both tiles, [tile][tap]
 #pragma unroll
         for (int f = 0; f < NW; ++f) wv[f] = wp[(f < nfr ? f : 0) * 64 + lane];
         if constexpr (KIND == K345) {       // stage A: e_conv3 in wv[0..8], e_conv4 in wv[9..17]
@@ -320,6 +336,14 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
         if (stg == 0) {
             if constexpr (NSA >= 1) IE_DMA_ROW(rsA0, smem + (t % NRA) * ROW_B, ys - A_ROW0 + t);
             if constexpr (NSA >= 2) IE_DMA_ROW(rsA1, smem + NRA * ROW_B + (t % NRA) * ROW_B, ys - A_ROW0 + t);
+            if constexpr (IS67N && IE_K67N_PA) {      // the P row that seeds stage B's output row started at step t
+                const int y = ys - 3 - G::DEFA + t;
+                const unsigned rmask = ((y >= 0) && (y < H)) ? 0u : OOB;
+                const unsigned row_b = rmask ? 0u : (unsigned)y * (unsigned)W * PXB;
+                char* slot = smem + OFF_BRING + (t % NRB) * ROW_B;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) IE_DMA_PIECE(rsB, slot, 2 * sw + j, row_b, rmask);
+            }
             if constexpr (KIND == K12 && !(IE_EXP & 1)) {
                 const int y = ys - 2 + t;
                 const unsigned rmask = ((y >= 0) && (y < H)) ? 0u : OOB;
@@ -333,16 +357,18 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
                 }
             }
         } else {
-            if constexpr (KIND == K67N) {
-                // the P' row that seeds the output row started at step t: wave sw reads (and therefore loads) only its own 32 pixels = pieces 2 sw, 2 sw + 1
-                const int y = ys - 3 + t;
+            if constexpr (IS67N) {
+                if constexpr (!IE_K67N_PA) {
+                // the P row that seeds the output row started at step t: wave sw reads (and therefore loads) only its own 32 pixels = pieces 2 sw, 2 sw + 1
+                const int y = ys - 3 - G::DEFA + t;
                 const unsigned rmask = ((y >= 0) && (y < H)) ? 0u : OOB;
                 const unsigned row_b = rmask ? 0u : (unsigned)y * (unsigned)W * PXB;
                 char* slot = smem + OFF_BRING + (t % NRB) * ROW_B;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) IE_DMA_PIECE(rsB, slot, 2 * sw + j, row_b, rmask);
+                }
                 if (sw < 3) {     // plane sw of the fp32 image row whose curve runs at step t (y = ys-6+t), read there by all four waves
-                    const int yi = ys - 6 + t;
+                    const int yi = ys - 6 - G::DEFA + t;
                     const unsigned imask = ((yi >= ys) && (yi < ye)) ? 0u : OOB;
                     const unsigned base = imask ? 0u : ((unsigned)sw * (unsigned)plane + (unsigned)yi * (unsigned)W) * 4u;
 #pragma unroll
@@ -396,9 +422,9 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     // exactly two (possibly out-of-range = dropped) P stores per step after its two loads, which its wait adds in (IE_STEP_HEAD's
     // argument); K67's curve stores only make the wait stricter than needed.
     int L = 0, S = 0;
-    if (stg == 0) { L = (KIND == K12) ? 2 : (2 * NSA + ((HALO && sw == 0) ? NSA : 0)); }   // K345: NSA = 1
+    if (stg == 0) { L = (KIND == K12) ? 2 : (2 * NSA + ((HALO && sw == 0) ? NSA : 0)) + ((IS67N && IE_K67N_PA) ? 2 : 0); }   // K345: NSA = 1
     else if (KIND == K67) L = IE_K67_CURVE2 ? (sw == 3 ? 14 : 0) : (sw == 2 ? 6 : (sw == 3 ? 8 : 0));
-    else if (KIND == K67N) L = sw < 3 ? 4 : 2;
+    else if (IS67N) L = (sw < 3 ? 2 : 0) + (IE_K67N_PA ? 0 : 2);
     const int wait_base = L ? (PF - 1) * L : -1;
     (void)S;
 
@@ -420,7 +446,14 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     int sd_off[2] = {0, 0};                   // this lane's 16 bytes of seeds in a P ring row: chunk kq of its pixel
     int im_off[2] = {0, 0};                   // ... and its colour of the fp32 pixel in an image ring row
     int of_off[2] = {0, 0};                   // where its curve result goes in the fp32 output row
-    if constexpr (KIND == K67N) {
+    unsigned est_off = OOB;                   // enhanced, W % 4 == 0: byte offset of this lane's 16-byte store inside a row of its colour plane, or OOB
+    int est_lds = 0;                          // ... and where those four pixels sit in the staged output row
+    if constexpr (IS67N) {
+        {   // wave sw < 3 stores colour sw; lane l < 31: pixels 4 l .. 4 l + 3 of the strip's 124 stored ones (first stored column = a multiple of 4)
+            const int x = xc0 + MARG + 4 * lane;
+            est_off = (sw < 3 && lane < 31 && x < W) ? (unsigned)(((size_t)sw * plane + x) * 4) : OOB;
+            est_lds = (sw < 3 ? sw : 0) * G::OUTF_PLANE_B + 16 + 16 * (lane < 31 ? lane : 0);
+        }
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             const int q = 32 * sw + 16 * nt + p16;
@@ -532,7 +565,7 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     int em16_off[2];        // ... of tile pair j as 16-byte pieces (after the lane exchange: even kq -> tile 2j, odd kq -> tile 2j+1)
     unsigned em16_in = 0;   // bit j: this lane's pixel of pair j lies inside the image
     unsigned em_in = 0;     // bit nt: tile nt's column lies inside the image
-    if constexpr (KIND == K12 || KIND == K345) {
+    if constexpr (KIND == K12 || KIND == K345 || IS67N) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             {   // piece m = 2 sw + j of the parked row: 16 pixels x 64 bytes, lane = (pixel, 16-byte chunk)
@@ -841,7 +874,7 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
         // K12: at the barrier before rows t .. t+RPB-1 the image DMA of row t+RPB-1 must have landed.  Ops younger than it: the
         // 2 (PF-RPB) loads of the rows behind it plus, for each of the min(t, PF-RPB+1) row steps since it was issued, two P stores.
         IE_STEP_HEAD(KIND == K12 ? 2 * (PF - RPB) + 2 * (t < PF - RPB + 1 ? t : PF - RPB + 1) : wait_base,
-                     (KIND == K12 ? 2 * (PF - RPB) + 2 * (PF - RPB + 1) : (PF - 1) * 2 * NSA), ((HALO && KIND != K12) ? (PF - 1) * 3 * NSA : -1));
+                     (KIND == K12 ? 2 * (PF - RPB) + 2 * (PF - RPB + 1) : (PF - 1) * (2 * NSA + ((IS67N && IE_K67N_PA) ? 2 : 0))), ((HALO && KIND != K12) ? (PF - 1) * 3 * NSA : -1));
         if constexpr (KIND == K12) {
             // e_conv1 on the converted image rows -> x1 row ys-4+t (accO); the x1 half of e_conv7 on the x1 row emitted at step t-1
             // (ys-5+t) -> P row ys-6+t complete in pO.  With e_conv7a here and e_conv2 on stage B the two waves of a SIMD carry 44 and
@@ -947,50 +980,88 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     };
 
 
+    // ---- K67N stage A, streamed: e_conv6 on [x2, x5] as two 36-MFMA streams.  accN still holds the x6 row finished at step t-1 (y = ys-4+t):
+    // tile nt is packed (ReLU, 16-bit) just before the MFMA that restarts accumulator tile nt with the bias as its C operand, the two
+    // 16-byte hand-off writes per lane, the four LDS-DMA pieces of row t+PF and nothing else ride behind fixed MFMAs.
+    auto step_a67n = [&](int t, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4]) __attribute__((always_inline)) {
+        IE_STEP_HEAD(wait_base, (PF - 1) * (2 * NSA + (IE_K67N_PA ? 2 : 0)), -1);
+        IE_T(ts2);
+        const int ra = ys - 4 + t;                             // the x6 row in accN
+        const bool row_in = (ra >= 0) && (ra < H);
+        char* eslot = smem + OFF_RA + (t % NRH) * ROW_B;       // read by stage B at step t+1
+        const int yd = ys - A_ROW0 + t + PF;                   // the x2 / x5 row DMA'd now
+        const unsigned dmask = ((yd >= 0) && (yd < H)) ? 0u : OOB;
+        const unsigned drow = dmask ? 0u : (unsigned)yd * (unsigned)W * PXB;
+        char* d0 = smem + ((t + PF) % NRA) * ROW_B;
+        char* d1 = d0 + NRA * ROW_B;
+        ie_u32x2 pk[4];
+        pk[0] = IE_PACK_TILE(TH, accN[0], true);
+        auto dma = [&](int src, int j) __attribute__((always_inline)) {
+            const unsigned off = (drow + body_xoff[j]) | dmask;
+            if (src == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA0, (__attribute__((address_space(3))) void*)(d0 + (2 * sw + j) * 1024), 16, (int)off, 0, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA1, (__attribute__((address_space(3))) void*)(d1 + (2 * sw + j) * 1024), 16, (int)off, 0, 0, 0);
+        };
+        auto fill = [&](int s) __attribute__((always_inline)) {
+            if (s == 0) pk[1] = IE_PACK_TILE(TH, accN[1], true);
+            if (s == 1) IE_PARK_PAIR(eslot, pk[0], pk[1], 0, row_in && (em16_in & 1u));
+            if (s == 3) pk[2] = IE_PACK_TILE(TH, accN[2], true);
+            if (s == 6) pk[3] = IE_PACK_TILE(TH, accN[3], true);
+            if (s == 7) IE_PARK_PAIR(eslot, pk[2], pk[3], 1, row_in && ((em16_in >> 1) & 1u));
+            if (s == 12) dma(0, 0);
+            if (s == 18) dma(0, 1);
+            if (s == 24) dma(1, 0);
+            if (s == 30) dma(1, 1);
+        };
+        auto nofill = [&](int) __attribute__((always_inline)) {};
+        mfma_stream(ie_tag<TA0>{}, smem + (t % NRA) * ROW_B, 0, accN, accM, accO, true, bias4, fill);
+        mfma_stream(ie_tag<TA1>{}, smem + NRA * ROW_B + (t % NRA) * ROW_B, 9, accN, accM, accO, false, bias4, nofill);
+        IE_STEP_TAIL();
+    };
+
     // ---- K67N stage B: the x6 half of e_conv7 (seeded by P) + tanh + LE curve, all in registers -------------------------------
     // e_conv7's 24 output rows are permuted on the host (ie_zdce_plan.hip, chan_k67): row 4 kq + i of 16-row tile j is curve map
-    // r_{4j+i} of colour kq (kq = 3: zero rows).  A wave owns both tiles on 32 columns, so after the MFMAs lane (p16, kq) holds ALL EIGHT
-    // r_i of colour kq of its pixel, in iteration order (tile 0 regs 0..3, tile 1 regs 0..3): tanh and the eight curve steps
+    // r_{4j+i} of colour kq (kq = 3: zero rows), and scaled by 2 / ln 2 (bias and the x1 half behind P too), so the accumulators hold
+    // log2(e) * 2x: exp(2x) is one v_exp.  A wave owns both tiles on 32 columns: after the MFMAs lane (p16, kq) holds ALL EIGHT r_i of
+    // colour kq of its pixel, in iteration order (tile 0 regs 0..3, tile 1 regs 0..3): tanh and the eight curve steps
     // (zero_dce.py:183-188) run straight off the accumulators -- no fp32 park in LDS, no second pass over it, no curve work on stage A.
-    // accN[2 j + nt] = tile j, pixel tile nt.  The row's results are staged in LDS as fp32 [colour][pixel] and leave one step later as
+    // acc[2 j + nt] = tile j, pixel tile nt.  The row's results are staged in LDS as fp32 [colour][pixel] and leave one step later as
     // 16-byte vectors (one 496-byte run per colour and strip row).  P is read in the same permuted order (K12 writes position
     // 8 kq + 4 j + i of a pixel's 64-byte line): one ds_read_b128 seeds both tiles.
-    // The step is ONE MFMA stream (tools/micro/coissue.hip: a wave's vector work is nearly free between its own MFMAs, two issue
-    // slots per 16x16x32 MFMA, and costs its full length as a phase of its own): the 96 tanh / curve operations of the row finished at
-    // step t-1 ride as fillers pinned behind fixed MFMAs; only the 16 scalings that read that row's accumulators (the first MFMAs
-    // restart them from the seeds) and the seed conversions come first.
-    // Timeline: row y = ys-3+t is seeded at step t, finished at step t+2, its curve runs at step t+3 (accN again), stored at t+4.
-    auto step_b67n = [&](int t, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4]) __attribute__((always_inline)) {
-        IE_STEP_HEAD(wait_base, (PF - 1) * 4, (PF - 1) * 2);     // waves 4-6: two P pieces + two image pieces per row, wave 7: two P pieces; stores in between only make it stricter
+    // The step is ONE MFMA stream (a wave's vector work is nearly free between its own MFMAs, two issue slots per 16x16x32 MFMA, and
+    // costs its full length as a phase of its own; the SIMD's vector issue port -- 8 cycles per MFMA, 4 per vector, 8 per
+    // transcendental instruction, both waves -- is what bounds this kernel, not the matrix pipe): the 96 tanh / curve operations of the
+    // row finished at step t-1 ride as fillers pinned behind fixed MFMAs.  FOUR accumulator sets rotate: the finished row (accF) is
+    // only read while the set freed a step earlier (accN) takes the seeds -- no copy of either.
+    // Timeline: row y = ys-3+t is seeded at step t, finished at step t+2, its curve runs at step t+3 (accF), stored at t+4.
+    auto step_b67n = [&](int t, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4], const ie_f32x4 (&accF)[4]) __attribute__((always_inline)) {
+        IE_STEP_HEAD(wait_base, (PF - 1) * (IE_K67N_PA ? 2 : 4), (PF - 1) * 2);     // waves 4-6: two image pieces per row (+ two P pieces each unless stage A loads P); stores in between only make it stricter
         IE_T(ts2);
         typedef __attribute__((ext_vector_type(8))) TH th8;
         const char* ps = smem + OFF_BRING + (t % NRB) * ROW_B;
         const char* ims = smem + OFF_IMG + (t % NRI) * IMG_SLOT_B;
         const th8 sv0 = *(const th8*)(ps + sd_off[0]), sv1 = *(const th8*)(ps + sd_off[1]);     // seeds of the output row started now (P row ys-3+t)
         float v0 = *(const float*)(ims + im_off[0]), v1 = *(const float*)(ims + im_off[1]);     // fp32 pixel of the row finished at step t-1 (y = ys-6+t)
+        IE_TX0();
         {   // (1) the row staged at step t-1 leaves
-            const int yo = ys - 7 + t;
+            const int yo = ys - 7 - G::DEFA + t;
             const bool row_ok = (yo >= ys) && (yo < ye);
             const char* os = smem + OFF_OUTF + ((t + 1) & 1) * G::OUTF_SLOT_B;
             const int xs = xc0 + MARG;                                  // first stored column of the strip (a multiple of 4)
-            if (p.enhanced) {
-                if ((W & 3) == 0) {       // wave sw < 3: colour sw, lane l < 31: pixels 4 l .. 4 l + 3 of the 124 stored ones
-                    const ie_u32x4 v = *(const ie_u32x4*)(os + (sw < 3 ? sw : 0) * G::OUTF_PLANE_B + 16 + 16 * (lane < 31 ? lane : 0));
-                    const int x = xs + 4 * lane;
-                    const bool ok = row_ok && sw < 3 && lane < 31 && x < W;
-                    const unsigned off = ok ? (unsigned)(((size_t)sw * plane + (size_t)yo * W + x) * 4) : OOB;
-                    __builtin_amdgcn_raw_buffer_store_b128(v, rsE, (int)off, 0, 0);
-                } else {
+            if (FAST67 || (p.enhanced && (W & 3) == 0)) {
+                const ie_u32x4 v = *(const ie_u32x4*)(os + est_lds);
+                const unsigned rmask = row_ok ? 0u : OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(v, rsE, (int)((est_off + (rmask ? 0u : (unsigned)yo * (unsigned)W * 4u)) | rmask), 0, 0);
+            } else if (p.enhanced) {
 #pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        const int q = lane + 64 * k, x = xc0 + q;
-                        const float v = *(const float*)(os + (sw < 3 ? sw : 0) * G::OUTF_PLANE_B + (q + 2) * 4);
-                        const bool ok = row_ok && sw < 3 && q >= MARG && q < TW - MARG && x < W;
-                        const unsigned off = ok ? (unsigned)(((size_t)sw * plane + (size_t)yo * W + x) * 4) : OOB;
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsE, (int)off, 0, 0);
-                    }
+                for (int k = 0; k < 2; ++k) {
+                    const int q = lane + 64 * k, x = xc0 + q;
+                    const float v = *(const float*)(os + (sw < 3 ? sw : 0) * G::OUTF_PLANE_B + (q + 2) * 4);
+                    const bool ok = row_ok && sw < 3 && q >= MARG && q < TW - MARG && x < W;
+                    const unsigned off = ok ? (unsigned)(((size_t)sw * plane + (size_t)yo * W + x) * 4) : OOB;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsE, (int)off, 0, 0);
                 }
             }
+            if constexpr (!FAST67) {
             if (p.u8 && sw == 3) {        // HWC bytes: 372 per strip row, wave 7 quantises them from the staged fp32 values
                 const int nbytes = row_ok ? min(TSK, W - xs) * 3 : 0;
                 if ((W & 3) == 0) {
@@ -1017,39 +1088,52 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
                     }
                 }
             }
-        }
-        issue(t + PF);       // (2)
-        // (3) the finished row's accumulators are read ONCE (exp(2x) = exp2(x * 2 / ln 2), ie_tanh_fast); the seeds replace them
-        float m0[8], m1[8], r0[8], r1[8];
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                m0[4 * j + i] = accN[2 * j][i] * 2.885390081777927f;
-                m1[4 * j + i] = accN[2 * j + 1][i] * 2.885390081777927f;
             }
-        ie_f32x4 sd[4];
+        }
+        IE_TX(0);
+        issue(t + PF);       // (2)
+        IE_TX(1);
+        // (3) seeds into the free set
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { sd[0][i] = (float)sv0[i]; sd[2][i] = (float)sv0[4 + i]; sd[1][i] = (float)sv1[i]; sd[3][i] = (float)sv1[4 + i]; }
+        for (int i = 0; i < 4; ++i) { accN[0][i] = (float)sv0[i]; accN[2][i] = (float)sv0[4 + i]; accN[1][i] = (float)sv1[i]; accN[3][i] = (float)sv1[4 + i]; }
         // (4) x6 row ys-4+t (handed over by stage A at step t-1) into the three live sets of both tiles, 36 MFMAs; filler o of 96:
-        //     k = o / 12 (curve iteration), op = (o % 12) / 2, pixel tile = o % 2
+        //     k = o / 12 (curve iteration), op = (o % 12) / 2, pixel tile = o % 2;  tanh(x) = 1 - 2 / (exp(2x) + 1) (ie_tanh_fast)
         float e0 = 0.f, e1 = 0.f, u0 = 0.f, u1 = 0.f;
+        // the 24 curve maps (optional output, general variant only) leave straight from the lane that computed them: NCHW fp32, plane 3 i + colour
+        unsigned aj_off[2] = {OOB, OOB};
+        if constexpr (!FAST67) {
+            if (p.adjust) {
+                const int yc = ys - 6 - G::DEFA + t;
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const int q = 32 * sw + 16 * nt + p16, x = xc0 + q;
+                    const bool ok = (yc >= ys) && (yc < ye) && kq < 3 && q >= MARG && q < TW - MARG && x < W;
+                    aj_off[nt] = ok ? (unsigned)(((size_t)kq * plane + (size_t)yc * W + x) * 4) : OOB;
+                }
+            }
+        }
         auto op = [&](int o) __attribute__((always_inline)) {
             const int k = o / 12, w = (o % 12) >> 1, nt = o & 1;
             float& e = nt ? e1 : e0; float& u = nt ? u1 : u0; float& v = nt ? v1 : v0;
-            float* mm = nt ? m1 : m0; float* rr = nt ? r1 : r0;
-            if (w == 0) e = __builtin_amdgcn_exp2f(mm[k]);
+            if (w == 0) e = __builtin_amdgcn_exp2f(accF[2 * (k >> 2) + nt][k & 3]);
             if (w == 1) e = e + 1.0f;
             if (w == 2) e = __builtin_amdgcn_rcpf(e);
-            if (w == 3) rr[k] = __builtin_fmaf(e, -2.0f, 1.0f);
+            if (w == 3) {
+                e = __builtin_fmaf(e, -2.0f, 1.0f);       // r_k
+                if constexpr (!FAST67) {                  // (an absent `adjust` has an empty descriptor range and out-of-range offsets: the store is dropped)
+                    const unsigned off = aj_off[nt] == OOB ? OOB : aj_off[nt] + (unsigned)((size_t)(3 * k) * plane * 4);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(e), rsJ, (int)off, 0, 0);
+                }
+            }
             if (w == 4) u = __builtin_fmaf(v, v, -v);
-            if (w == 5) v = __builtin_fmaf(rr[k], u, v);
+            if (w == 5) v = __builtin_fmaf(e, u, v);
         };
         const char* ra_row = smem + OFF_RA + ((t + RPB) % NRH) * ROW_B;
         frag bx[6];
         auto rd = [&](int g) __attribute__((always_inline)) { bx[g] = *(const frag*)(ra_row + rdn[g & 1][g >> 1]); };
         rd(0); rd(1); rd(2);
         IE_SB();
+        IE_TX(2);
 #pragma unroll
         for (int g = 0; g < 6; ++g) {
             const int kx = g >> 1, nt = g & 1;
@@ -1057,7 +1141,7 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int s0 = 6 * g + 3 * j;                  // MFMA index of this triplet's first
-                accN[2 * j + nt] = ie_mfma16_raw<TH>(wv[9 * j + 0 * 3 + kx], bx[g], kx == 0 ? sd[2 * j + nt] : accN[2 * j + nt]);
+                accN[2 * j + nt] = ie_mfma16_raw<TH>(wv[9 * j + 0 * 3 + kx], bx[g], accN[2 * j + nt]);
 #pragma unroll
                 for (int o = (s0 * 8) / 3; o < ((s0 + 1) * 8) / 3; ++o) op(o);
                 IE_SB();
@@ -1071,23 +1155,11 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
                 IE_SB();
             }
         }
+        IE_TX(3);
         {   // (5) the curve's results into the fp32 output row; the 24 curve maps (optional) straight to HBM: NCHW fp32, plane 3 i + colour
             char* ow = smem + OFF_OUTF + (t & 1) * G::OUTF_SLOT_B;
             *(float*)(ow + of_off[0]) = v0;
             *(float*)(ow + of_off[1]) = v1;
-            if (p.adjust) {
-                const int yc = ys - 6 + t;
-                const bool rowc = (yc >= ys) && (yc < ye);
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    const int q = 32 * sw + 16 * nt + p16, x = xc0 + q;
-                    const bool ok = rowc && kq < 3 && q >= MARG && q < TW - MARG && x < W;
-                    const unsigned base = ok ? (unsigned)(((size_t)kq * plane + (size_t)yc * W + x) * 4) : OOB;
-#pragma unroll
-                    for (int k = 0; k < 8; ++k)
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(nt ? r1[k] : r0[k]), rsJ, (int)(ok ? base + (unsigned)((size_t)(3 * k) * plane * 4) : OOB), 0, 0);
-                }
-            }
         }
         IE_STEP_TAIL();
     };
@@ -1231,12 +1303,24 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
                 if (t + 2 < n_steps) step_b12(t + 2, a1, a2, a0);
             }
         }
-    } else if (KIND == K67N && stg == 1) {
-        if constexpr (KIND == K67N) {
+    } else if (IS67N && stg == 1) {
+        if constexpr (IS67N) {
+#if IE_K67N_PRIO
+            __builtin_amdgcn_s_setprio(IE_K67N_PRIO);    // stage B (the younger half of the workgroup) is the longer chain of a step
+#endif
+            for (int t = 0; t < n_steps; t += 4) {      // (N, M, O, F) -> (F, N, M, O)
+                step_b67n(t, a0, a1, a2, q0);
+                if (t + 1 < n_steps) step_b67n(t + 1, q0, a0, a1, a2);
+                if (t + 2 < n_steps) step_b67n(t + 2, a2, q0, a0, a1);
+                if (t + 3 < n_steps) step_b67n(t + 3, a1, a2, q0, a0);
+            }
+        }
+    } else if (IS67N && IE_K67N_STREAM_A && stg == 0) {
+        if constexpr (IS67N) {
             for (int t = 0; t < n_steps; t += 3) {
-                step_b67n(t, a0, a1, a2);
-                if (t + 1 < n_steps) step_b67n(t + 1, a2, a0, a1);
-                if (t + 2 < n_steps) step_b67n(t + 2, a1, a2, a0);
+                step_a67n(t, a0, a1, a2);
+                if (t + 1 < n_steps) step_a67n(t + 1, a2, a0, a1);
+                if (t + 2 < n_steps) step_a67n(t + 2, a1, a2, a0);
             }
         }
     } else if (stg == 0) {
@@ -1245,7 +1329,7 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
             if (t + 1 < n_steps) step_a(t + 1, a2, a0, a1, q2, q0, q1);
             if (t + 2 < n_steps) step_a(t + 2, a1, a2, a0, q1, q2, q0);
         }
-    } else if constexpr (KIND != K67N) {
+    } else if constexpr (!IS67N) {
         for (int t = 0; t < n_steps; t += 3) {
             step_b(t, a0, a1, a2, q0, q1, q2);
             if (t + 1 < n_steps) step_b(t + 1, a2, a0, a1, q2, q0, q1);
@@ -1285,6 +1369,10 @@ IE_DEF_FUSED(zdce_k67_conv6_conv7_curve_mix, _Float16, __bf16, _Float16, _Float1
 IE_DEF_FUSED(zdce_k67n_conv6_conv7_curve_f16, _Float16, _Float16, _Float16, _Float16, K67N)
 IE_DEF_FUSED(zdce_k67n_conv6_conv7_curve_bf16, __bf16, __bf16, __bf16, __bf16, K67N)
 IE_DEF_FUSED(zdce_k67n_conv6_conv7_curve_mix, _Float16, __bf16, _Float16, _Float16, K67N)
+// ... compiled for `enhanced` fp32 as the only output and W % 4 == 0 (what the throughput path asks for)
+IE_DEF_FUSED(zdce_k67n_conv6_conv7_curve_e_f16, _Float16, _Float16, _Float16, _Float16, K67F)
+IE_DEF_FUSED(zdce_k67n_conv6_conv7_curve_e_bf16, __bf16, __bf16, __bf16, __bf16, K67F)
+IE_DEF_FUSED(zdce_k67n_conv6_conv7_curve_e_mix, _Float16, __bf16, _Float16, _Float16, K67F)
 #undef IE_DEF_FUSED
 #define IE_DEF_FUSED3(NAME, TA0, T3, TH, TO) \
     __global__ __launch_bounds__(512, 2) void NAME(FusedParams p) { zdce_fused2_body<TA0, TA0, TH, TO, K345, T3>(p); }
@@ -1304,7 +1392,7 @@ static int launch_fused_t(FusedFn fn, const ZdceFusedLaunch& a, hipStream_t st) 
     p.N = a.N; p.H = a.H; p.W = a.W; p.y_begin = a.y_begin; p.y_end = a.y_end; p.rows_per_block = a.rows_per_block;
     p.n_begin = a.n_begin;
     p.stamps = (unsigned long long*)a.stamps;
-    p.strips = ie_cdiv(a.W, KIND == K345 ? TW - 6 : ((KIND == K67 || KIND == K67N) ? TW - 4 : TS));
+    p.strips = ie_cdiv(a.W, KIND == K345 ? TW - 6 : ((KIND == K67 || KIND == K67N || KIND == K67F) ? TW - 4 : TS));
     if (KIND == K67N && a.adjust && (size_t)a.H * a.W * 24 * 4 >= 0x7fffffffull) IE_FAIL(IE_ERR_UNSUPPORTED, "zdce fused: frame too large for 31-bit offsets into `adjust`");
     p.chunks = ie_cdiv(a.y_end - a.y_begin, a.rows_per_block);
     const long long blocks = (long long)p.strips * p.chunks * a.n_count;
@@ -1312,7 +1400,7 @@ static int launch_fused_t(FusedFn fn, const ZdceFusedLaunch& a, hipStream_t st) 
     if ((size_t)a.H * a.W * 32 * 2 >= 0x7fffffffull) IE_FAIL(IE_ERR_UNSUPPORTED, "zdce fused: frame too large for 31-bit offsets");
     const size_t lds = FusedGeom<KIND>::LDS_B;
     // the dynamic-LDS limit is a per-function attribute: set it once per kernel
-    static FusedFn attr_done[16] = {nullptr};
+    static FusedFn attr_done[24] = {nullptr};
     bool done = false;
     for (FusedFn f : attr_done) done = done || (f == fn);
     if (!done) {
@@ -1338,6 +1426,10 @@ int ie_zdce_launch_fused(const ZdceFusedLaunch& a, hipStream_t st) {
         if (h_all) return launch_fused_t<K67>(zdce_k67_conv6_conv7_curve_f16, a, st);
         if (b_all) return launch_fused_t<K67>(zdce_k67_conv6_conv7_curve_bf16, a, st);
         if (a.dt_a0 == IE_F16 && a.dt_a1 == IE_BF16 && a.dt_h == IE_F16) return launch_fused_t<K67>(zdce_k67_conv6_conv7_curve_mix, a, st);
+    } else if (a.kind == 670 && a.enhanced && !a.adjust && !a.u8 && (a.W & 3) == 0 && ((size_t)a.enhanced & 15) == 0) {
+        if (h_all) return launch_fused_t<K67F>(zdce_k67n_conv6_conv7_curve_e_f16, a, st);
+        if (b_all) return launch_fused_t<K67F>(zdce_k67n_conv6_conv7_curve_e_bf16, a, st);
+        if (a.dt_a0 == IE_F16 && a.dt_a1 == IE_BF16 && a.dt_h == IE_F16) return launch_fused_t<K67F>(zdce_k67n_conv6_conv7_curve_e_mix, a, st);
     } else if (a.kind == 670) {
         if (h_all) return launch_fused_t<K67N>(zdce_k67n_conv6_conv7_curve_f16, a, st);
         if (b_all) return launch_fused_t<K67N>(zdce_k67n_conv6_conv7_curve_bf16, a, st);

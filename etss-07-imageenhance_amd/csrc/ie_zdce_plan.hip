@@ -227,11 +227,14 @@ IE_EXPORT int ie_zdce_finalize(ie_zdce_plan* p, void* stream) {
         auto chan_k12 = [&](int pos) { return legacy67 ? (pos < 24 ? pos : -1) : (pos < 24 ? 3 * (4 * ((pos >> 2) & 1) + (pos & 3)) + (pos >> 3) : -1); };
         auto chan_k67 = [&](int row) { const int j = row >> 4, m = row & 15; return legacy67 ? (row < 24 ? row : -1) : ((m >> 2) < 3 ? 3 * (4 * j + (m & 3)) + (m >> 2) : -1); };
         auto chan_id = [&](int row) { return row; };
-        auto pack9 = [&](std::vector<unsigned short>& hw, size_t base, int hc, const float* w, int Co, int Ci, int ci0, int sdt, auto&& row_chan) {
+        // ... and SCALED by 2 / ln 2 (weights, bias, hence P): the accumulators then hold log2(e) * 2x and tanh(x) = 1 - 2 / (exp2(acc) + 1) needs no
+        // multiply in the kernel (one vector instruction less per curve map and pixel).  The product is rounded to 16 bits once, like the weight itself.
+        const float s7 = legacy67 ? 1.0f : 2.885390081777927f;
+        auto pack9 = [&](std::vector<unsigned short>& hw, size_t base, int hc, const float* w, int Co, int Ci, int ci0, int sdt, auto&& row_chan, float scale = 1.0f) {
             for (int t = 0; t < 9; ++t) for (int lane = 0; lane < 64; ++lane) for (int j = 0; j < 8; ++j) {
                 const int co = row_chan(16 * hc + (lane & 15));
                 const int ci = ci0 + 8 * (lane >> 4) + j;
-                const float v = (co >= 0 && co < Co) ? w[((size_t)co * Ci + ci) * 9 + t] : 0.f;
+                const float v = (co >= 0 && co < Co) ? scale * w[((size_t)co * Ci + ci) * 9 + t] : 0.f;
                 hw[base + ((size_t)t * 64 + lane) * 8 + j] = sdt == IE_F16 ? f32_to_f16_bits(v) : f32_to_bf16_bits(v);
             }
         };
@@ -241,7 +244,7 @@ IE_EXPORT int ie_zdce_finalize(ie_zdce_plan* p, void* stream) {
             std::vector<unsigned short> hw((size_t)2 * 18 * 64 * 8, 0);
             for (int hc = 0; hc < 2; ++hc) {
                 pack9(hw, ((size_t)hc * 18 + 0) * 64 * 8, hc, p->w[1].data(), 32, 32, 0, p->xdt[1], chan_id);
-                pack9(hw, ((size_t)hc * 18 + 9) * 64 * 8, hc, p->w[6].data(), 24, 64, 0, p->xdt[1], chan_k12);
+                pack9(hw, ((size_t)hc * 18 + 9) * 64 * 8, hc, p->w[6].data(), 24, 64, 0, p->xdt[1], chan_k12, s7);
             }
             const char* q = (const char*)hw.data();
             host.insert(host.end(), q, q + hw.size() * 2);
@@ -250,7 +253,7 @@ IE_EXPORT int ie_zdce_finalize(ie_zdce_plan* p, void* stream) {
         p->off_w7b = host.size();
         {
             std::vector<unsigned short> hw((size_t)2 * 9 * 64 * 8, 0);
-            for (int hc = 0; hc < 2; ++hc) pack9(hw, (size_t)hc * 9 * 64 * 8, hc, p->w[6].data(), 24, 64, 32, p->xdt[6], chan_k67);
+            for (int hc = 0; hc < 2; ++hc) pack9(hw, (size_t)hc * 9 * 64 * 8, hc, p->w[6].data(), 24, 64, 32, p->xdt[6], chan_k67, s7);
             const char* q = (const char*)hw.data();
             host.insert(host.end(), q, q + hw.size() * 2);
         }
@@ -258,7 +261,7 @@ IE_EXPORT int ie_zdce_finalize(ie_zdce_plan* p, void* stream) {
         p->off_b7p = host.size();
         {
             std::vector<float> hb(32, 0.f);
-            for (int pos = 0; pos < 32; ++pos) { const int c = chan_k12(pos); hb[pos] = c >= 0 ? p->b[6][c] : 0.f; }
+            for (int pos = 0; pos < 32; ++pos) { const int c = chan_k12(pos); hb[pos] = c >= 0 ? s7 * p->b[6][c] : 0.f; }
             const char* q = (const char*)hb.data();
             host.insert(host.end(), q, q + 32 * 4);
         }

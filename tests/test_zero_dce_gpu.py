@@ -106,6 +106,38 @@ def test_kernel_variants_bit_identical(variant, dtype, base):
     assert torch.equal(a["enhanced"], b["enhanced"]) and torch.equal(a["adjust"], b["adjust"])
 
 
+@pytest.mark.parametrize("dtype", ["f16", "bf16", "bf16_pure"])
+@pytest.mark.parametrize("shape", [(2, 37, 132), (1, 140, 256), (3, 9, 260), (1, 5, 4)])
+def test_last_kernel_output_modes_agree(shape, dtype):
+    """The last kernel is compiled twice: for `enhanced` alone with W % 4 == 0 (zdce_k67n_*_e_*, the throughput path) and for any
+    combination of outputs / any width.  Same arithmetic: the same bits, whichever outputs are asked for."""
+    n, h, w = shape
+    sd = o_zdce.init_state_dict(seed=13, gain=3.0)
+    x = torch.rand(n, 3, h, w, generator=torch.Generator().manual_seed(8)).cuda()
+    m = _model(sd, dtype)
+    only = m.enhance(x)["enhanced"].clone()                           # fast form
+    both = m.enhance(x, want_adjust=True)                             # general form
+    assert torch.equal(only, both["enhanced"])
+    q = m.enhance(x, want_enhanced=True, want_u8=True)                # general form, uint8 HWC beside it
+    assert torch.equal(only, q["enhanced"])
+    assert torch.equal(q["u8"].cpu(), o_zdce.to_uint8_save_image(only.cpu()))
+    u = m.enhance(x, want_enhanced=False, want_u8=True)               # uint8 alone
+    assert torch.equal(u["u8"], q["u8"])
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16", "bf16_pure"])
+def test_last_kernel_round2_form(dtype):
+    """IE_ZDCE_VAR_K67_LEGACY (e_conv7 rows in channel order, unscaled; tanh + curve on fp32 rows parked in LDS) against the shipped
+    form (rows permuted and scaled by 2 / ln 2 on the host, curve in registers): both inside the bound, and close to each other."""
+    sd, g = load_golden(zero_dce_goldens()[-1])
+    x = torch.from_numpy(g["image"]).cuda()
+    a = _model(sd, dtype).forward({"image": x})
+    b = _model(sd, dtype, capi.VAR_K67_LEGACY).forward({"image": x})
+    tol = _tol(zero_dce_goldens()[-1], dtype)
+    assert rel_err(b["enhanced"].cpu(), g["enhanced"]) <= tol and rel_err(a["enhanced"].cpu(), g["enhanced"]) <= tol
+    assert rel_err(a["enhanced"].cpu(), b["enhanced"].cpu()) <= tol and rel_err(a["adjust"].cpu(), b["adjust"].cpu()) <= 5 * tol
+
+
 @pytest.mark.parametrize("shape", [(1, 1, 1), (1, 3, 5), (2, 2, 129), (1, 17, 128), (3, 9, 257), (1, 130, 64)])
 @pytest.mark.parametrize("dtype", ["f32", "f16"])
 def test_ragged_and_tiny_shapes(shape, dtype):
