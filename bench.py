@@ -49,6 +49,174 @@ PRECISION = {
 }
 
 
+# what `dtype` says for each --dtype: the arithmetic the path multiplies in (fp32 accumulate everywhere).  "bf16" selects the MIXED
+# schedule of DESIGN.md 4a for Zero-DCE (x3 / x4 / x5 bf16; x1 / x2 / x6 / P and their weights fp16), so the label names both.
+DTYPE_LABEL = {"bf16": "bf16+f16", "bf16_pure": "bf16", "f16": "f16"}
+# the BASELINE.json configs reachable through `--workload` (N = frames per GPU per step, weak scaling)
+WORKLOADS = {
+    "zero_dce": dict(batch=BATCH_PER_GPU, dtype="bf16"),
+    "retinexnet": dict(batch=32, dtype="f16", gflop_per_frame=1374.5, model=dict(name="retinexnet"),
+                       what="retinexnet batch={n}/GPU 1920x1080 (BASELINE.json configs[3]: 256 frames over 8 GPUs)"),
+    "unet64_train": dict(batch=8, dtype="bf16", gflop_per_frame=3 * 2530.0, model=dict(name="unet", base_channels=64, num_classes=3, enhance=True),
+                         what="unet64 training step (L1+SSIM, Adam, clip 0.1) batch={n}/GPU 1920x1080 (BASELINE.json configs[4])"),
+}
+
+
+def _conv_census(torch, ops, fn):
+    """HIP events around every matrix-core conv call of one pass of ``fn`` (tools/conv_census.py): {shape key: [calls, ms, flop]}."""
+    import collections
+    rec = collections.OrderedDict()
+    orig = ops.mconv2d
+
+    def logged(srcs, mw, stride=1, pad=1, **kw):
+        s_ = [srcs] if isinstance(srcs, torch.Tensor) else list(srcs)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig(srcs, mw, stride=stride, pad=pad, **kw)
+        e1.record()
+        e1.synchronize()
+        o = out[0] if isinstance(out, tuple) else out
+        key = "conv{}x{} {}->{} s{} @{}x{}".format(mw.kh, mw.kw, "+".join(str(int(t.shape[1])) for t in s_), mw.cout, stride, int(s_[0].shape[2]), int(s_[0].shape[3]))
+        r = rec.setdefault(key, [0, 0.0, 0.0])
+        r[0] += 1
+        r[1] += e0.elapsed_time(e1)
+        r[2] += 2.0 * o.shape[0] * o.shape[2] * o.shape[3] * o.shape[1] * sum(int(t.shape[1]) for t in s_) * mw.kh * mw.kw
+        return out
+
+    ops.mconv2d = logged
+    try:
+        fn()
+        torch.cuda.synchronize()
+    finally:
+        ops.mconv2d = orig
+    return rec
+
+
+def run_generator_workload(args, ctx):
+    """`--workload retinexnet | unet64_train`: the same contract as the headline (W untimed + K timed steps between barriers,
+    max over ranks, whole-job frames/s), one JSON line on rank 0."""
+    torch, mon_amd, dist, dev, rank, world = ctx["torch"], ctx["mon_amd"], ctx["dist"], ctx["dev"], ctx["rank"], ctx["world"]
+    from mon_amd import ops
+    wl = WORKLOADS[args.workload]
+    n = args.batch
+    train = args.workload == "unet64_train"
+    model = mon_amd.MODELS.build(seed=1, compute_dtype="f32" if train else args.dtype, **wl["model"]).to(dev)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    if train:
+        tr = mon_amd.Trainer(model, optimizer={"name": "adam", "lr": 1e-4}, loss={"name": "l1_ssim_loss"}, gradient_clip_val=0.1, compute_dtype=args.dtype)
+        tgt = torch.rand((n, 3, H, W), generator=g, device=dev)
+        img = (tgt ** 2.2 * 0.4).contiguous()
+        step = lambda: tr.training_step({"image": img, "ref_image": tgt})      # noqa: E731
+    else:
+        x = torch.rand((n, 3, H, W), generator=g, device=dev)
+        step = lambda: model.forward({"image": x})                              # noqa: E731
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    def timed(k):
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            step()
+        sync_all()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=ctx["red_dev"])
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    for _ in range(args.warmup):
+        step()
+    dt = timed(args.steps)
+    ms_per_step = dt / args.steps * 1e3
+    value = n * world * args.steps / dt
+    comm = None
+    if train and world > 1:
+        # the exchange step by itself, and the step without it / without the overlap (same K, same barriers)
+        tr.sync_gradients = False
+        ms_no = timed(args.steps) / args.steps * 1e3
+        tr.sync_gradients, tr.overlap_allreduce = True, False
+        ms_serial = timed(args.steps) / args.steps * 1e3
+        tr.overlap_allreduce = True
+        sync_all()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            dist.all_reduce(tr.store.grads)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        comm = {"allreduce_ms": round(e0.elapsed_time(e1) / 5, 3), "allreduce_bytes": int(tr.store.grads.numel() * 4),
+                "ms_per_step_without_allreduce": round(ms_no, 3), "ms_per_step_allreduce_after_backward": round(ms_serial, 3),
+                "ms_per_step_overlapped": round(ms_per_step, 3), "backend": dist.get_backend()}
+    if rank != 0:
+        return None
+    # ---- roofline of the dominant conv shape: HIP events around every matrix-core conv call of one more pass ------------------
+    peak_frac = value / world * wl["gflop_per_frame"] * 1e9 / (PEAK_MFMA_TFLOPS * 1e12)
+    roofline = {"kernel": None, "bound": "mfma", "achieved": round(value / world * wl["gflop_per_frame"] / 1e3, 1), "peak": PEAK_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(peak_frac, 4), "traffic": None, "model_mfma_frac": round(peak_frac, 4),
+                "note": "whole-step algorithmic FLOPs (SURVEY 8d) / step time"}
+    try:
+        if train:
+            tr.sync_gradients = False          # rank 0 alone runs this extra pass: no collective in it
+        rec = _conv_census(torch, ops, step)
+        key, (calls, ms, flop) = max(rec.items(), key=lambda kv: kv[1][1])
+        tot = sum(r[1] for r in rec.values())
+        ach = flop / (ms * 1e-3) / 1e12
+        roofline.update({"kernel": "ie_mconv_nhwc " + key, "achieved": round(ach, 1), "frac": round(ach / PEAK_MFMA_TFLOPS, 4),
+                         "avg_launch_ms": round(ms / calls, 4), "launches_per_step": calls, "share_of_conv_time": round(ms / tot, 3),
+                         "conv_ms_per_step": round(tot, 2),
+                         "note": "dominant conv shape of the step: algorithmic FLOPs (2*MAC) / HIP-event time around its ie_mconv_nhwc calls"
+                                 + (" (forward and data-gradient calls; the weight-gradient kernel is outside this census)" if train else "")})
+    except Exception as e:       # noqa: BLE001
+        roofline["census_error"] = str(e)[:200]
+    cpu_baseline = parity = None
+    if world == 1 and not args.no_cpu_baseline:
+        ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        torch.set_num_threads(max(1, ncpu))
+        from oracle import generators as o_gen
+        if train:
+            # a bounded sample of the same step on the host: forward + autograd backward of the oracle graph on a 270x480 crop
+            # (1/16 of a frame), scaled by area -- the reference has no CPU trainer for this config, so this is a "port"
+            from oracle import train as o_train
+            sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+            xs_, ts_ = img[:1, :, :270, :480].cpu(), tgt[:1, :, :270, :480].cpu()
+            t0 = time.perf_counter()
+            o_train.training_steps(sd0, [(xs_, ts_)], lambda p_, b_, x_: o_train.unet_forward_train(p_, b_, x_, "bilinear", True),
+                                   lambda a_, b_: o_train.l1_ssim_loss(a_, b_), lr=1e-4, clip=0.1)
+            sec = (time.perf_counter() - t0) * 16
+            cpu_baseline = {"value": round(1.0 / sec, 5), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port", "cpu_model": _cpu_model(),
+                            "sample": "one optimiser step of oracle/train.py (torch autograd, fp32) on one 270x480 crop, time x 16"}
+        else:
+            xs_ = x[:1].cpu()
+            sd_ = {k: v.clone() for k, v in model.state_dict().items()}
+            with torch.no_grad():
+                o_gen.retinexnet_forward(sd_, xs_[:, :, :64, :64])
+                t0 = time.perf_counter()
+                ref = o_gen.retinexnet_forward(sd_, xs_)["enhanced"]
+                sec = time.perf_counter() - t0
+            got = model.forward({"image": x[:1]})["enhanced"].cpu()
+            cpu_baseline = {"value": round(1.0 / sec, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port", "cpu_model": _cpu_model(),
+                            "sample": "one 1920x1080 frame, torch CPU restatement (oracle/generators.py retinexnet_forward), one run after a 64x64 warm-up"}
+            parity = {"max_rel_err": float(f"{float((got - ref).abs().max() / ref.abs().max()):.3e}")}
+    line = {"metric": "train_images_per_sec_1080p" if train else "enhanced_images_per_sec_1080p", "value": round(value, 2), "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": wl["what"].format(n=n), "frames_per_gpu": n, "global_batch": n * world, "height": H, "width": W,
+                       "precision": f"{args.dtype} storage of activations" + (" and their gradients; fp32 master weights, statistics, weight gradients, Adam" if train else "; fp32 accumulate"),
+                       "parallelism": (f"data parallel over {world} GPU(s): one flat-buffer gradient all-reduce per step, decoder half overlapped with the encoder's backward"
+                                       if train else f"frames sharded over {world} GPU(s), no collective"),
+                       "tflops_per_gpu": round(value / world * wl["gflop_per_frame"] / 1e3, 1)},
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity}
+    if comm is not None:
+        line["comm"] = comm
+    return line
+
+
 def _spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (torch.distributed.run, one process per
     GPU) BEFORE this process touches the GPU, and hand their exit code back.  Rank 0 of the children prints the JSON line."""
@@ -82,13 +250,20 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="frames per GPU per step")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "bf16_pure", "f16"])
+    ap.add_argument("--workload", default="zero_dce", choices=sorted(WORKLOADS),
+                    help="zero_dce = BASELINE.json configs[1] (the headline, default); retinexnet = configs[3] (32 frames per GPU, frames "
+                         "sharded over the ranks, no collective); unet64_train = configs[4] (U-Net-64, L1+SSIM, 8 frames per GPU, one RCCL "
+                         "all-reduce of the flat gradient buffer per step, its tail overlapped with the encoder's backward pass)")
+    ap.add_argument("--batch", type=int, default=None, help="frames per GPU per step (default: the workload's BASELINE.json batch)")
+    ap.add_argument("--dtype", default=None, choices=["bf16", "bf16_pure", "f16"], help="default: bf16 (zero_dce: the mixed fp16 / bf16 schedule), f16 for retinexnet")
     ap.add_argument("--output", default="f32", choices=["f32", "u8"], help="enhanced as fp32 NCHW or uint8 NHWC")
     ap.add_argument("--variant", type=int, default=0, help="kernel variant bitmask (capi.VAR_*), A-B runs only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the short side measurements of the other BASELINE configs")
     args = ap.parse_args()
+    wl = WORKLOADS[args.workload]
+    args.batch = args.batch or wl["batch"]
+    args.dtype = args.dtype or wl["dtype"]
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(_spawn_ranks(args.gpus))      # no GPU call has happened in this process
@@ -122,6 +297,16 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
         assert dist.get_world_size() == args.gpus and dist.get_backend() == backend
     red_dev = dev if backend == "nccl" else torch.device("cpu")
+
+    if args.workload != "zero_dce":
+        ctx = dict(rank=rank, world=world, dev=dev, dist=dist, red_dev=red_dev, torch=torch, mon_amd=mon_amd, capi=capi)
+        line = run_generator_workload(args, ctx)
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     from oracle import zero_dce as o_zdce      # only for the seeded weight rule + the CPU baseline leg
     sd = o_zdce.init_state_dict(seed=1, gain=3.0)
@@ -351,7 +536,7 @@ def main():
         line = {
             "metric": "enhanced_images_per_sec_1080p", "value": round(value, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.dtype == "bf16_pure" else args.dtype, "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_LABEL[args.dtype], "data": "synthetic",
             "config": {"workload": f"zero_dce_re batch={n}/GPU {W}x{H} (BASELINE.json configs[1])", "frames_per_gpu": n,
                        "global_batch": n * world, "height": H, "width": W, "precision": PRECISION[args.dtype], "input": "NCHW fp32 in HBM",
                        "output": "enhanced NCHW fp32" if args.output == "f32" else "enhanced NHWC uint8",

@@ -89,9 +89,12 @@ template <typename T> __device__ __forceinline__ unsigned ie_pack2_relu(float lo
     return __builtin_bit_cast(unsigned, __builtin_elementwise_max(s, z));
 }
 
-// tanh as 1 - 2/(exp(2x)+1) on the hardware exp2/rcp units: absolute error
-// <= ~3e-7 (the LE curve consumes r as a multiplier, so absolute error is what
-// matters); saturates correctly to +-1.
+// MODE.FP16_OVFL (hwreg MODE bit 23): a conversion to fp16 that overflows gives +-65504 instead of +-inf for the rest of the wave's life
+// (true infinities stay infinite; tools/micro/fp16_ovfl.hip checks v_cvt_pk_f16_f32 and v_cvt_f16_f32 on gfx950).  The Zero-DCE plan's
+// "bf16" schedule stores x1 / x2 / x6 / P in fp16 for precision; with this bit an out-of-range activation saturates like a bf16 one would
+// merely lose precision, instead of poisoning everything behind it with inf - inf = NaN.  One scalar instruction per wave, no cost per value.
+__device__ __forceinline__ void ie_fp16_saturate_on() { __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1); }
+
 // `s_waitcnt vmcnt` takes an immediate.  A wave-uniform count that is only known at run time used to go through a 30-way switch -- a
 // compare / branch tree of 10-15 scalar branches in EVERY step of the strip kernels.  The steady-state value of a loop is a compile-time
 // constant per wave class, so: test the one or two hot constants first and fall back to the caller's switch (prologue steps) otherwise.
@@ -104,6 +107,9 @@ template <int H0, int H1 = -1, int H2 = -1, typename F> __device__ __forceinline
     cold(n);
 }
 
+// tanh as 1 - 2/(exp(2x)+1) on the hardware exp2/rcp units: absolute error
+// <= ~3e-7 (the LE curve consumes r as a multiplier, so absolute error is what
+// matters); saturates correctly to +-1.
 __device__ __forceinline__ float ie_tanh_fast(float x) {
     const float e = __builtin_amdgcn_exp2f(x * 2.885390081777927f); // exp(2x)
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);

@@ -200,6 +200,7 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     (void)OFF_DUMP; (void)OFF_OUT; (void)OFF_OUTF;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
+    ie_fp16_saturate_on();
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

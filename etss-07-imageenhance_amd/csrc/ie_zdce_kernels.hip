@@ -85,6 +85,7 @@ __global__ __launch_bounds__(NWAVE * 64, (NSRC == 1 ? 3 : 2)) void zdce_conv3x3_
     constexpr int STAGE_B = 24 * TW * 4;                // EPI_CURVE: tanh(r) staging [24][128] fp32
     constexpr int IMG_SLOT_B = 3 * TW * 4;              // EPI_CURVE: image row slice [3][128] fp32
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    ie_fp16_saturate_on();
     char* const stage = smem + RING_B;
     char* const imgring = smem + RING_B + STAGE_B;
 
@@ -400,6 +401,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void zdce_conv1_kernel(const float* __restrict__ img, const float* __restrict__ wk,
                                                          const float* __restrict__ bias, T* __restrict__ dst, int N,
                                                          int H, int W, int y_begin, int y_end, int n_begin) {
+    ie_fp16_saturate_on();
     const int x = blockIdx.x * 256 + threadIdx.x;
     const int y = y_begin + blockIdx.y;
     const int n = n_begin + blockIdx.z;

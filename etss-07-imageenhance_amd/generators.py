@@ -956,6 +956,12 @@ class UNet(_GraphModel):
         x3 = dc("down2.conv", [T.t_maxpool(tape, x2)])
         x4 = dc("down3.conv", [T.t_maxpool(tape, x3)])
         x5 = dc("down4.conv", [T.t_maxpool(tape, x4)])
+        # gradient bucket boundary ("overlapped with wgrad of earlier layers"): everything from here on is the decoder + head,
+        # whose parameters sit behind the encoder's in the flat buffer and whose gradients are complete first in the backward pass
+        dec = [o for k, (o, _, _, _) in store.index.items() if k.startswith(("up", "outc"))]
+        enc = [o for k, (o, _, _, _) in store.index.items() if not k.startswith(("up", "outc"))]
+        if dec and enc and min(dec) > max(enc):
+            tape.mark_grad_bucket(min(dec))
         y = up(1, x5, x4); y = up(2, y, x3); y = up(3, y, x2); y = up(4, y, x1)
         if mixed:                                      # head computed as 16 output channels; the clamp and the loss run in fp32
             y = T.t_conv(tape, y, store.conv("outc.conv"), *store.conv_grads("outc.conv"), pad=0, cout_pad=16)

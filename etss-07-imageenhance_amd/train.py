@@ -61,6 +61,16 @@ class Tape:
     def record(self, fn):
         self._fns.append(fn)
 
+    def mark_grad_bucket(self, offset: int):
+        """Forward-order mark: every parameter used AFTER this point lives at flat-buffer offsets >= ``offset``.  When the backward pass
+        comes back to the mark those gradients are final, and ``on_grad_bucket`` (the trainer's early all-reduce) is called with it."""
+        def fire():
+            if self.on_grad_bucket is not None:
+                self.on_grad_bucket(int(offset))
+        self._fns.append(fire)
+
+    on_grad_bucket = None
+
     def backward(self):
         for fn in reversed(self._fns):
             fn()
@@ -543,6 +553,12 @@ class Trainer:
         if not isinstance(self.loss, Loss):
             raise TypeError("`loss` must be a mon_amd.losses.Loss or its config dict")
         self.group = process_group
+        # data parallel step: the gradients behind the model's bucket mark (the decoder's -- their backward runs first) are all-reduced
+        # on the collective's own stream while the rest of the backward pass (the encoder's data / weight gradients) still runs
+        self.overlap_allreduce = True
+        self.sync_gradients = True               # False: skip the exchange (timing the step without it)
+        self._pending = []                        # [(async work handle)], first bucket offset
+        self._bucket_off = None
         if deterministic:                     # process-wide switch of the library (capi.set_deterministic)
             capi.set_deterministic(True)
         cd = {capi.IE_F32: "f32", capi.IE_F16: "f16", capi.IE_BF16: "bf16"}[capi.DTYPES[str(compute_dtype).lower()]]
@@ -634,13 +650,32 @@ class Trainer:
             g = torch.empty_like(pred, memory_format=CL)
             loss.backward_into(g, False, self.loss_scale)
             tape.seed(pred, g)
+        self._pending, self._bucket_off = [], None
+        tape.on_grad_bucket = self._early_allreduce if (self.overlap_allreduce and self.sync_gradients and self._world() > 1) else None
         tape.backward()
+
+    def _early_allreduce(self, offset: int):
+        import torch.distributed as dist
+        if self._bucket_off is not None or offset <= 0 or offset >= self.store.numel:
+            return                                # one early bucket per step
+        self._bucket_off = offset
+        self._pending.append(dist.all_reduce(self.store.grads[offset:], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def optimizer_step(self):
         """DDP mean of the gradients (one flat all-reduce over RCCL) -> clip_grad_norm_ -> Adam, three launches."""
         from .sharding import allreduce_gradients
         st = self.store
-        scale = allreduce_gradients(st.grads, self.group) / self.loss_scale
+        if not self.sync_gradients:
+            scale = 1.0 / self.loss_scale
+        elif self._pending:                       # the tail went out during the backward pass: now the head, then wait for both
+            import torch.distributed as dist
+            self._pending.append(dist.all_reduce(st.grads[:self._bucket_off], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            for w in self._pending:
+                w.wait()
+            self._pending = []
+            scale = 1.0 / self._world() / self.loss_scale
+        else:
+            scale = allreduce_gradients(st.grads, self.group) / self.loss_scale
         L = capi.lib()
         with torch.cuda.device(self.device):
             sumsq = None

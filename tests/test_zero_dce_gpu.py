@@ -125,6 +125,25 @@ def test_last_kernel_output_modes_agree(shape, dtype):
     assert torch.equal(u["u8"], q["u8"])
 
 
+@pytest.mark.parametrize("variant", [0, capi.VAR_UNFUSED])
+@pytest.mark.parametrize("dtype", ["bf16", "f16"])
+def test_fp16_tensors_saturate_instead_of_overflowing(dtype, variant):
+    """The "bf16" schedule keeps x1 / x2 / x6 / P in fp16 (max 65504).  Activations beyond that must saturate, not become inf: a
+    checkpoint whose first layer has a huge gain (x1 ~ 1e6) followed by a tiny one still gives finite outputs (an inf in x1 turns
+    into inf - inf = NaN two layers later).  The kernels set MODE.FP16_OVFL for that (ie_fp16_saturate_on)."""
+    sd = o_zdce.init_state_dict(seed=21, gain=3.0)
+    sd["e_conv1.weight"] = sd["e_conv1.weight"] * 3e6
+    sd["e_conv2.weight"] = sd["e_conv2.weight"] * 1e-6
+    sd["e_conv7.weight"] = torch.cat([sd["e_conv7.weight"][:, :32] * 1e-6, sd["e_conv7.weight"][:, 32:]], 1)     # its x1 half sees x1 too
+    x = torch.rand(2, 3, 40, 136, generator=torch.Generator().manual_seed(2)) * 0.9 + 0.1
+    ref = o_zdce.forward(sd, x)
+    assert float(o_zdce.forward(sd, x, return_features=True)["_features"][0].max()) > 2e5          # x1 really is out of fp16's range
+    out = _model(sd, dtype, variant).forward({"image": x.cuda()})
+    e, a = out["enhanced"].cpu(), out["adjust"].cpu()
+    assert bool(torch.isfinite(e).all()) and bool(torch.isfinite(a).all()) and float(a.abs().max()) <= 1.0
+    assert tuple(e.shape) == tuple(ref["enhanced"].shape)
+
+
 @pytest.mark.parametrize("dtype", ["f16", "bf16", "bf16_pure"])
 def test_last_kernel_round2_form(dtype):
     """IE_ZDCE_VAR_K67_LEGACY (e_conv7 rows in channel order, unscaled; tanh + curve on fp32 rows parked in LDS) against the shipped
@@ -285,8 +304,31 @@ def test_bench_two_ranks_one_device():
                         "--no-extras", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 4 and line["dtype"] == "bf16" and line["value"] > 0
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 4 and line["dtype"] == "bf16+f16" and line["value"] > 0
     assert line["roofline"]["bound"] == "mfma" and 0 < line["roofline"]["frac"] < 1
+
+
+@pytest.mark.parametrize("workload", ["retinexnet", "unet64_train"])
+def test_bench_other_workloads_two_ranks_one_device(workload):
+    """bench.py --workload retinexnet / unet64_train --gpus 2 (BASELINE.json configs 4 and 5 through the driver's command), rehearsed
+    with two gloo ranks on this box's one GPU: frames sharded with no collective; the training step exchanges the flat gradient
+    buffer (its decoder half during the backward pass) and reports the exchange beside the step time."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, IE_BENCH_BACKEND="gloo", IE_BENCH_ONE_DEVICE="1")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", workload, "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--batch", "1"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 2 and line["value"] > 0 and line["scaling"] == "weak"
+    assert line["roofline"]["bound"] == "mfma" and 0 < line["roofline"]["frac"] < 1 and line["roofline"]["kernel"].startswith("ie_mconv_nhwc")
+    if workload == "unet64_train":
+        c = line["comm"]
+        assert c["allreduce_bytes"] > 60e6 and c["allreduce_ms"] > 0 and c["ms_per_step_without_allreduce"] > 0
+        assert line["metric"] == "train_images_per_sec_1080p"
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
