@@ -438,20 +438,9 @@ def main():
                 except Exception as e:
                     extras[f"zero_dce_{od}_1080p_frames_per_s"] = f"failed: {e}"[:200]
                 torch.cuda.empty_cache()
-            # BASELINE.json configs[2] (U-Net-32, batch 32) and configs[3] (RetinexNet, 32 frames per GPU) at their stated batch sizes
-            for tag, cfg, nfr in (("unet32_bf16_1080p_batch32_frames_per_s", dict(name="unet", base_channels=32, num_classes=3, enhance=True), 32),
-                                  ("unet32_pixelshuffle_bf16_1080p_batch32_frames_per_s", dict(name="unet", base_channels=32, num_classes=3, enhance=True, upsampler="pixelshuffle"), 32),
-                                  ("retinexnet_bf16_1080p_batch32_frames_per_s", dict(name="retinexnet"), 32)):
-                try:
-                    m2 = mon_amd.MODELS.build(seed=1, compute_dtype="bf16", **cfg).to(dev)
-                    xi = torch.rand(nfr, 3, H, W, device=dev)
-                    extras[tag] = round(nfr / timed(lambda: m2.forward({"image": xi}), 3), 1)
-                    del m2, xi
-                except Exception as e:                       # a side measurement must never take the headline line down
-                    extras[tag] = f"failed: {e}"[:200]
-                torch.cuda.empty_cache()
-            # the same two models with fp16 storage (same kernels, v_mfma_f32_16x16x32_f16): the configuration that is on the matrix cores AND
-            # inside the 1e-3 bound -- throughput at batch 32 and the error of one 1080p frame against the CPU fp32 oracle
+            # BASELINE.json configs[2] (U-Net-32, batch 32) and configs[3] (RetinexNet, 32 frames per GPU) at their stated batch sizes, FIRST in the
+            # configuration that is on the matrix cores AND inside the 1e-3 bound (fp16 storage, v_mfma_f32_16x16x32_f16): throughput at batch 32 and
+            # the error of one 1080p frame against the CPU fp32 oracle
             if xs is not None:
                 from oracle import generators as o_gen
                 for tag, cfg, ref_fn in (("unet32_f16", dict(name="unet", base_channels=32, num_classes=3, enhance=True),
@@ -467,6 +456,18 @@ def main():
                     except Exception as e:
                         extras[f"{tag}_1080p_batch32_frames_per_s"] = f"failed: {e}"[:200]
                     torch.cuda.empty_cache()
+            # ... then the same models with bf16 storage (same kernels and rate; 2e-3 .. 4e-3 of the fp32 result: outside the bound, for reference)
+            for tag, cfg, nfr in (("unet32_bf16_1080p_batch32_frames_per_s", dict(name="unet", base_channels=32, num_classes=3, enhance=True), 32),
+                                  ("unet32_pixelshuffle_bf16_1080p_batch32_frames_per_s", dict(name="unet", base_channels=32, num_classes=3, enhance=True, upsampler="pixelshuffle"), 32),
+                                  ("retinexnet_bf16_1080p_batch32_frames_per_s", dict(name="retinexnet"), 32)):
+                try:
+                    m2 = mon_amd.MODELS.build(seed=1, compute_dtype="bf16", **cfg).to(dev)
+                    xi = torch.rand(nfr, 3, H, W, device=dev)
+                    extras[tag] = round(nfr / timed(lambda: m2.forward({"image": xi}), 3), 1)
+                    del m2, xi
+                except Exception as e:                       # a side measurement must never take the headline line down
+                    extras[tag] = f"failed: {e}"[:200]
+                torch.cuda.empty_cache()
             # BASELINE.json configs[4]'s step (U-Net-64, L1+SSIM, Adam + clip) at its 8 frames per GPU: the 16-bit graph, and the
             # fp32 parity graph at 2 frames
             for tag, cdt, nb in (("unet64_train_l1ssim_fp32_1080p_batch2_frames_per_s", "f32", 2), ("unet64_train_l1ssim_bf16_1080p_batch8_frames_per_s", "bf16", 8)):

@@ -266,7 +266,7 @@ def test_hinet_vs_oracle(cfg):
 
 
 # ---- 16-bit matrix-core path (compute_dtype f16 / bf16): same graphs, ie_mconv_nhwc + the 16-bit streaming ops ----------
-TOL16 = {"f16": 1.5e-3, "bf16": 1.5e-2}       # measured 4e-4 / 6e-3 (tools/gen16_diag.py); BASELINE bound for fp32 parity is 1e-3
+TOL16 = {"f16": 1e-3, "bf16": 1.5e-2}         # fp16: the BASELINE bound itself (measured 3e-4 U-Net, 4e-4 RetinexNet; tools/gen16_diag.py); bf16 measured 2e-3 .. 6e-3
 
 
 @pytest.mark.parametrize("dt", ["f16", "bf16"])
