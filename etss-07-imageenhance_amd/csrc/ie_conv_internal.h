@@ -39,6 +39,7 @@ struct ie_sconv_tail {      // 1x1 conv of the ReLU'd rows, fused into the strip
     int cout, clamp;
     float lo, hi;
 };
+bool ie_sconv3_fused_ok(int nsrc, const int* cs);
 int ie_sconv3_launch(const void* const* srcs, const int* cs, int nsrc, const void* wpk, const float* bias, void* dst, int dtype, int N, int H, int W,
                      int Cout, int act, float slope, int pad_mode, const int* src_h, const int* src_w, void* pool_dst, const ie_sconv_tail* tail, int stride, hipStream_t st);
 // pool_dst: null, or the 2x2 max-pooled copy of dst written by the same launch (ReLU layers only)

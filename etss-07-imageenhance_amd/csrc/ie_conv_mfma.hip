@@ -648,18 +648,32 @@ __global__ __launch_bounds__(256, TH3 == 16 ? 2 : 3) void mconv3_kernel(MConvPar
     constexpr int NDW = ND / 4;                 // DMA instructions per wave per tile
     constexpr bool IL_DMA = RW > 1;             // interleave the DMA issue with the MFMAs (the 128-accumulator variant has no VGPRs to spare)
     // per tile and DMA slot: bits 0-27 = pixel index in the frame (replicate: clamped; all ones = out of range -> zeros),
-    // bits 28-29 = the column swizzle (c>>1)&3 of the halo pixel this lane fills
-    unsigned slot[NDW];
+    // bits 28-29 = the column swizzle (c>>1)&3 of the halo pixel this lane fills.  The four lanes of a quad fill the four 16-byte pieces
+    // of ONE pixel, so a slot's word is the same in all four: lane j of the quad keeps the words of slots j, j + 4, j + 8, ... and
+    // hands them to its quad with a DPP broadcast when the slot's instruction is issued -- ceil(NDW / 4) registers instead of NDW
+    // (ten at TH3 = 16: with 128 accumulators they were the ones spilled, and their reloads sat in front of every chunk's DMA issue).
+    constexpr int NDQ = (NDW + 3) / 4;
+    unsigned slotq[NDQ];
     auto set_tile_pixels = [&](const Tile& t) __attribute__((always_inline)) {
 #pragma unroll
-        for (int k = 0; k < NDW; ++k) {
+        for (int i = 0; i < NDQ; ++i) {
+            const int k = 4 * i + (lane & 3);
             const int q = (wave + 4 * k) * 16 + (lane >> 2);
             const int r = q / TWH, c = q - r * TWH;
             int iy = t.oy0 + r - p.pad, ix = t.ox0 + c - p.pad;
-            bool ok = q < TPX;
+            bool ok = q < TPX && k < NDW;
             if (p.pad_mode == IE_PAD_REPLICATE) { iy = min(max(iy, 0), p.H - 1); ix = min(max(ix, 0), p.W - 1); }
             else ok = ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            slot[k] = (ok ? (unsigned)(iy * p.W + ix) : 0x0fffffffu) | ((unsigned)((c >> 1) & 3) << 28);
+            slotq[i] = (ok ? (unsigned)(iy * p.W + ix) : 0x0fffffffu) | ((unsigned)((c >> 1) & 3) << 28);
+        }
+    };
+    auto slot_of = [&](int k) __attribute__((always_inline)) {      // k is a compile-time constant at every call site
+        const unsigned v = slotq[k >> 2];
+        switch (k & 3) {      // quad_perm broadcast of lane (k & 3) of each quad
+        case 0: return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x00, 0xf, 0xf, true);
+        case 1: return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x55, 0xf, 0xf, true);
+        case 2: return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xaa, 0xf, 0xf, true);
+        default: return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xff, 0xf, 0xf, true);
         }
     };
     struct CDesc { const char* base; unsigned info; };
@@ -671,8 +685,9 @@ __global__ __launch_bounds__(256, TH3 == 16 ? 2 : 3) void mconv3_kernel(MConvPar
         const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(d.base + (size_t)frame * frame_px * cs_b), (short)cs_b, (int)frame_px, 0x00020000);
         unsigned char* buf = smem + bufsel * BUF_B + wave * 1024;
         const int rem = (int)(cs_b - c0_b);                     // bytes of this chunk that exist in the source (>= 64: whole chunk)
-        const int voff = (int)(((lane & 3) ^ (slot[k] >> 28)) << 4);         // this lane's channel piece of the pixel (column swizzle)
-        const int vi = voff < rem ? (int)(slot[k] & 0x0fffffffu) : 0x0fffffff;   // short chunk: missing channel pieces read as zeros
+        const unsigned sk = slot_of(k);
+        const int voff = (int)(((lane & 3) ^ (sk >> 28)) << 4);              // this lane's channel piece of the pixel (column swizzle)
+        const int vi = voff < rem ? (int)(sk & 0x0fffffffu) : 0x0fffffff;        // short chunk: missing channel pieces read as zeros
         __builtin_amdgcn_struct_ptr_buffer_load_lds(rs, (lds_ptr)(buf + k * 4096), 16, vi, voff, (int)c0_b, 0, 0);
     };
     auto issue_dma = [&](int frame, const CDesc& d, unsigned bufsel) __attribute__((always_inline)) {
@@ -975,7 +990,7 @@ IE_EXPORT int ie_mconv_pool_nhwc(ie_mconv_desc* d, const void* const* srcs, cons
 static bool tail_ok(const ie_mconv_desc* d, const int* channels, int tail_cout) {
     static const int on = getenv("IE_SCONV_TAIL") ? atoi(getenv("IE_SCONV_TAIL")) : 1;           // A/B: 0 = the two separate convs
     return on && d && channels && !d->pixel_shuffle && d->stride == 1 && d->act == IE_ACT_RELU && (d->W & 3) == 0 && tail_cout >= 1 && tail_cout <= 16 && !d->clamp &&
-           d->out_dtype == d->in_dtype &&
+           d->out_dtype == d->in_dtype && ie_sconv3_fused_ok(d->nsrc, channels) &&
            ie_sconv3_applicable(d->nsrc, channels, d->Cout, d->kh, d->kw, d->stride, d->pad, d->pad_mode, d->act, false, false, false, d->W) &&
            (double)tail_cout * d->H * d->W * 4.0 < 2147483647.0;
 }
@@ -1033,7 +1048,7 @@ static int mconv_impl(ie_mconv_desc* d, const void* const* srcs, const int* chan
             if (!srcs[s]) IE_FAIL(IE_ERR_INVALID, "ie_mconv_nhwc: source %d is null", s);
         d->Ho = (d->H + d->stride - 1) / d->stride; d->Wo = (d->W + d->stride - 1) / d->stride;       // k 3, pad 1: ceil(H / stride)
         static const int fuse = getenv("IE_SCONV_POOL") ? atoi(getenv("IE_SCONV_POOL")) : 1;      // A/B: 0 = the separate pool kernel
-        void* pd = (pool_dst && fuse && d->act == IE_ACT_RELU && d->H >= 2 && d->W >= 2 && d->stride == 1) ? pool_dst : nullptr;
+        void* pd = (pool_dst && fuse && d->act == IE_ACT_RELU && d->H >= 2 && d->W >= 2 && d->stride == 1 && ie_sconv3_fused_ok(d->nsrc, channels)) ? pool_dst : nullptr;
         if (pooled) *pooled = pd != nullptr;
         return ie_sconv3_launch(srcs, channels, d->nsrc, packed_w, bias, dst, d->in_dtype, d->N, d->H, d->W, d->Cout, d->act, d->slope, d->pad_mode,
                                 d->src_h, d->src_w, pd, nullptr, d->stride, (hipStream_t)stream);

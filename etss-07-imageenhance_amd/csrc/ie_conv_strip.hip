@@ -522,10 +522,12 @@ __device__ __forceinline__ void sconv3_body(const SConvParams& p) {
 
 typedef void (*SConvFn)(SConvParams);
 // Concrete kernels (hipcc 7.2 dropped host stubs of kernel templates in this file; readable names in rocprof traces as a bonus).
-#define IE_DEF_SCONV(TAG, T, NCH, NCF)                                                                                              \
+#define IE_DEF_SCONV_PLAIN(TAG, T, NCH, NCF)                                                                                        \
     __global__ __launch_bounds__(NCF * 128) void sconv3_##TAG##_none(SConvParams p) { sconv3_body<T, NCH, NCF, IE_ACT_NONE>(p); }    \
     __global__ __launch_bounds__(NCF * 128) void sconv3_##TAG##_relu(SConvParams p) { sconv3_body<T, NCH, NCF, IE_ACT_RELU>(p); }    \
-    __global__ __launch_bounds__(NCF * 128) void sconv3_##TAG##_lrelu(SConvParams p) { sconv3_body<T, NCH, NCF, IE_ACT_LRELU>(p); } \
+    __global__ __launch_bounds__(NCF * 128) void sconv3_##TAG##_lrelu(SConvParams p) { sconv3_body<T, NCH, NCF, IE_ACT_LRELU>(p); }
+#define IE_DEF_SCONV(TAG, T, NCH, NCF)                                                                                              \
+    IE_DEF_SCONV_PLAIN(TAG, T, NCH, NCF)                                                                                            \
     __global__ __launch_bounds__(NCF * 128) void sconv3_##TAG##_relu_pool(SConvParams p) { sconv3_body<T, NCH, NCF, IE_ACT_RELU, true>(p); } \
     __global__ __launch_bounds__(NCF * 128) void sconv3_##TAG##_relu_tail(SConvParams p) { sconv3_body<T, NCH, NCF, IE_ACT_RELU, false, true>(p); }
 // the first DoubleConv of a U-Net (3 -> 32 / 64 -> 32 / 64 channels, + pooled copy) in one launch
@@ -541,31 +543,42 @@ IE_DEF_SCONV(f16_c32_o32, _Float16, 1, 2)
 IE_DEF_SCONV(f16_c32_o64, _Float16, 1, 4)
 IE_DEF_SCONV(f16_c64_o32, _Float16, 2, 2)
 IE_DEF_SCONV(f16_c64_o64, _Float16, 2, 4)
-IE_DEF_SCONV(f16_c128_o64, _Float16, 4, 4)
+// four K chunks: plain forms only -- the fused-pool / fused-head forms of this shape spilled 18 / 26 VGPRs into the counted-vmcnt loop (a reload
+// there drains the LDS-DMA queue); ie_sconv3_fused_ok() sends such calls to the two-launch path
+IE_DEF_SCONV_PLAIN(f16_c128_o64, _Float16, 4, 4)
 IE_DEF_SCONV(bf16_c32_o32, __bf16, 1, 2)
 IE_DEF_SCONV(bf16_c32_o64, __bf16, 1, 4)
 IE_DEF_SCONV(bf16_c64_o32, __bf16, 2, 2)
 IE_DEF_SCONV(bf16_c64_o64, __bf16, 2, 4)
-IE_DEF_SCONV(bf16_c128_o64, __bf16, 4, 4)
+IE_DEF_SCONV_PLAIN(bf16_c128_o64, __bf16, 4, 4)
 
 SConvFn pick_kernel(bool h, int nch, int ncf, int act, bool pool, bool tail) {
+#define IE_PICK_PLAIN(TAG) return (tail || pool) ? (SConvFn) nullptr : (act == IE_ACT_RELU ? sconv3_##TAG##_relu : (act == IE_ACT_LRELU ? sconv3_##TAG##_lrelu : sconv3_##TAG##_none))
 #define IE_PICK_ACT(TAG) return tail ? sconv3_##TAG##_relu_tail : pool ? sconv3_##TAG##_relu_pool : (act == IE_ACT_RELU ? sconv3_##TAG##_relu : (act == IE_ACT_LRELU ? sconv3_##TAG##_lrelu : sconv3_##TAG##_none))
     if (h) {
         if (nch == 1 && ncf == 2) IE_PICK_ACT(f16_c32_o32);
         if (nch == 1 && ncf == 4) IE_PICK_ACT(f16_c32_o64);
         if (nch == 2 && ncf == 2) IE_PICK_ACT(f16_c64_o32);
-        if (nch == 4) IE_PICK_ACT(f16_c128_o64);
+        if (nch == 4) IE_PICK_PLAIN(f16_c128_o64);
         IE_PICK_ACT(f16_c64_o64);
     }
     if (nch == 1 && ncf == 2) IE_PICK_ACT(bf16_c32_o32);
     if (nch == 1 && ncf == 4) IE_PICK_ACT(bf16_c32_o64);
     if (nch == 2 && ncf == 2) IE_PICK_ACT(bf16_c64_o32);
-    if (nch == 4) IE_PICK_ACT(bf16_c128_o64);
+    if (nch == 4) IE_PICK_PLAIN(bf16_c128_o64);
     IE_PICK_ACT(bf16_c64_o64);
 #undef IE_PICK_ACT
+#undef IE_PICK_PLAIN
 }
 
 }  // namespace
+
+// ... and its fused max-pool / fused 1x1 head forms?  (Every shape but the four-chunk one.)
+bool ie_sconv3_fused_ok(int nsrc, const int* cs) {
+    int cin = 0;
+    for (int s = 0; s < nsrc; ++s) cin += cs[s];
+    return cin <= 64;
+}
 
 // Does the strip kernel cover this call?  (ie_mconv_nhwc asks before it builds its own launch.)
 bool ie_sconv3_applicable(int nsrc, const int* cs, int Cout, int kh, int kw, int stride, int pad, int pad_mode, int act, bool residual, bool clamp,
@@ -681,6 +694,7 @@ int ie_sconv3_launch(const void* const* srcs, const int* cs, int nsrc, const voi
     const int ncf = Cout / 16;
     const size_t lds = (size_t)(nch == 4 ? 3 : ((nch == 2 && ncf == 2) ? IE_SC_NR_C64O32 : 4)) * SRC_ROW_B * nch + (pool_dst ? 3 : 2) * (size_t)TW * (Cout * 2);
     SConvFn fn = pick_kernel(dtype == IE_F16, nch, ncf, act, pool_dst != nullptr, tail != nullptr);
+    if (!fn) IE_FAIL(IE_ERR_UNSUPPORTED, "ie_sconv3: the fused max-pool / head forms cover Cin <= 64 (ask ie_sconv3_fused_ok)");
     static const int s2skip = getenv("IE_SCONV_S2SKIP") ? atoi(getenv("IE_SCONV_S2SKIP")) : 1;      // A/B: 0 = every row computed
     if (stride == 2 && s2skip && nch == 2 && ncf == 4 && act == IE_ACT_RELU) fn = dtype == IE_F16 ? sconv3_f16_c64_o64_relu_s2 : sconv3_bf16_c64_o64_relu_s2;
     static SConvFn granted[64] = {nullptr};
