@@ -646,7 +646,12 @@ __global__ __launch_bounds__(256, TH3 == 16 ? 2 : 3) void mconv3_kernel(MConvPar
     // work of a DMA instruction is nil: vindex (pixel or "out of range" -> zeros) is computed once per tile, the channel
     // piece offset once per kernel, the chunk's first channel goes into the scalar offset.
     constexpr int NDW = ND / 4;                 // DMA instructions per wave per tile
-    constexpr bool IL_DMA = RW > 1;             // interleave the DMA issue with the MFMAs (the 128-accumulator variant has no VGPRs to spare)
+#ifndef IE_MCONV_IL1
+#define IE_MCONV_IL1 0
+#endif
+    // interleave the DMA issue with the MFMAs.  (The 128-accumulator variant RW = 1 had no VGPRs to spare for it until the DMA slot words moved
+    // into quads: 232 VGPRs without, see slotq.)
+    constexpr bool IL_DMA = RW > 1 || IE_MCONV_IL1;
     // per tile and DMA slot: bits 0-27 = pixel index in the frame (replicate: clamped; all ones = out of range -> zeros),
     // bits 28-29 = the column swizzle (c>>1)&3 of the halo pixel this lane fills.  The four lanes of a quad fill the four 16-byte pieces
     // of ONE pixel, so a slot's word is the same in all four: lane j of the quad keeps the words of slots j, j + 4, j + 8, ... and

@@ -559,8 +559,10 @@ class Trainer:
         self.sync_gradients = True               # False: skip the exchange (timing the step without it)
         self._pending = []                        # [(async work handle)], first bucket offset
         self._bucket_off = None
-        if deterministic:                     # process-wide switch of the library (capi.set_deterministic)
-            capi.set_deterministic(True)
+        # process-wide switch of the library (capi.set_deterministic): turned on here, restored by ``close()`` (or use the trainer as a context manager)
+        self._prev_deterministic = None
+        if deterministic:
+            self._prev_deterministic = capi.set_deterministic(True)      # returns the previous setting
         cd = {capi.IE_F32: "f32", capi.IE_F16: "f16", capi.IE_BF16: "bf16"}[capi.DTYPES[str(compute_dtype).lower()]]
         if cd != "f32" and not getattr(model, "supports_mixed_training", False):
             raise capi.IEError(f"{model.__class__.__name__} has no 16-bit training graph")
@@ -578,6 +580,19 @@ class Trainer:
         self._sumsq_ws = torch.zeros(capi.SUMSQ_WS_DOUBLES, device=self.device, dtype=torch.float64)
         model.predicting = False
         model.train()
+
+    def close(self):
+        """Give the library's process-wide deterministic switch back to what it was before this trainer turned it on."""
+        if self._prev_deterministic is not None:
+            capi.set_deterministic(bool(self._prev_deterministic))
+            self._prev_deterministic = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
     @property
     def step(self) -> int:
@@ -726,15 +741,27 @@ class Trainer:
                                          "exp_avg": self.store.export(st.exp_avg), "exp_avg_sq": self.store.export(st.exp_avg_sq)}]
             ckpt["gradient_clip_val"] = self.clip
         import os
-        os.makedirs(os.path.dirname(os.path.abspath(str(path))) or ".", exist_ok=True)
-        torch.save(ckpt, str(path))
+        import torch.distributed as dist
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        if not multi or dist.get_rank(self.group) == 0:       # data parallel: the replicas are bit-identical, rank 0 writes (Lightning's rank_zero_only)
+            os.makedirs(os.path.dirname(os.path.abspath(str(path))) or ".", exist_ok=True)
+            torch.save(ckpt, str(path))
+        if multi:
+            dist.barrier(group=self.group)                     # nobody reads the file before it is complete
         return str(path)
 
     def load_checkpoint(self, path):
         """Resume: parameters, BatchNorm buffers, Adam moments and the step counter; the next step continues bit-identically."""
         ckpt = torch.load(str(path), map_location="cpu", weights_only=True)     # dicts / lists / numbers / strings / tensors only
         st = self.store
-        opt = ckpt["optimizer_states"][0]
+        if "state_dict" not in ckpt:              # a bare state_dict (the reference's weight files, nn/model.py:129-130)
+            ckpt = {"state_dict": ckpt}
+        if not ckpt.get("optimizer_states"):
+            # weights-only file (ModelCheckpoint's .pt twin, save_weights_only): parameters and buffers are taken, the optimiser starts afresh
+            # -- zero moments, step 0 -- instead of a KeyError; this trainer's own hyper-parameters stay
+            opt = None
+        else:
+            opt = ckpt["optimizer_states"][0]
 
         def put(flat, tensors):
             for k, (o, n, shape, is_conv) in st.index.items():
@@ -746,12 +773,16 @@ class Trainer:
                 else:
                     flat[o:o + n].copy_(t.reshape(-1))
         put(st.params, ckpt["state_dict"])
-        put(st.exp_avg, opt["exp_avg"])
-        put(st.exp_avg_sq, opt["exp_avg_sq"])
         for k in st.buffers:
             st.buffers[k].copy_(ckpt["state_dict"][k])
-        self.step = int(ckpt["global_step"])
-        self.lr, self.betas, self.eps, self.weight_decay = float(opt["lr"]), tuple(opt["betas"]), float(opt["eps"]), float(opt["weight_decay"])
+        if opt is None:
+            st.exp_avg.zero_(); st.exp_avg_sq.zero_()
+            self.step = 0
+        else:
+            put(st.exp_avg, opt["exp_avg"])
+            put(st.exp_avg_sq, opt["exp_avg_sq"])
+            self.step = int(ckpt["global_step"])
+            self.lr, self.betas, self.eps, self.weight_decay = float(opt["lr"]), tuple(opt["betas"]), float(opt["eps"]), float(opt["weight_decay"])
         st.repack16()                             # 16-bit graph: packed weight images made before the load are stale
         return self
 

@@ -51,10 +51,12 @@ def _frame_u8(frame, denormalize: bool = False) -> np.ndarray:
     else:
         raise ValueError(f"`image` must be a `torch.Tensor` or `numpy.ndarray`, but got {type(frame)}.")
     if a.dtype != np.uint8:
+        # the reference's rule is the explicit flag (utils.py:782-795: ``denormalize`` -> x * 255, then the uint8 cast); float frames without it are
+        # taken to be in [0, 255] already.  No guessing from the data: a [0, 1] frame with one pixel at 1.01 must not turn black.
         a = a.astype(np.float32)
-        if denormalize or float(a.max(initial=0.0)) <= 1.0:
+        if denormalize:
             a = np.clip(a, 0.0, 1.0) * 255.0
-        a = a.astype(np.uint8)                          # utils.py:795: truncation
+        a = np.clip(a, 0.0, 255.0).astype(np.uint8)     # utils.py:795: truncation (clipped first: a float above 255 would wrap)
     return np.ascontiguousarray(a)
 
 
@@ -67,11 +69,11 @@ class VideoLoader(abc.ABC):
         self.root, self.to_tensor, self.verbose = pathlib.Path(root), to_tensor, verbose
         self.num_frames, self.index = 0, 0
         self.get_data()
-        if len(self) <= 0 and not getattr(self, "is_stream", False):
+        if self.num_frames <= 0 and not getattr(self, "is_stream", False):
             raise RuntimeError("No datapoints in the dataset.")          # video.py:129-131
 
     def __len__(self) -> int:
-        return self.num_frames
+        return max(int(self.num_frames), 0)               # a stream reports -1 frames (video.py:251): len() must not raise for it
 
     def __iter__(self):
         self.reset()
@@ -92,16 +94,34 @@ class VideoLoader(abc.ABC):
         return {"frame": frame, "meta": meta}
 
     def batches(self, batch_size: int):
-        """Stacks of up to ``batch_size`` frames as one (N, H, W, 3) uint8 tensor + their metas (predict.py:70-90 batching)."""
+        """Stacks of up to ``batch_size`` frames as one (N, H, W, 3) uint8 tensor + their metas (predict.py:70-90 batching).  Walks the
+        source front to back through ``get_frame`` until it ends -- a stream (``num_frames`` = -1) has no length to count to."""
         buf, metas = [], []
-        for i in range(len(self)):
-            d = self[i] if not self.to_tensor else {"frame": self.get_frame(i), "meta": self[i]["meta"]}
-            buf.append(torch.from_numpy(d["frame"])); metas.append(d["meta"])
+        i = 0
+        while self.num_frames < 0 or i < self.num_frames:
+            try:
+                frame = self.get_frame(i)
+            except IndexError:
+                break                                   # end of a stream
+            buf.append(torch.from_numpy(frame))
+            metas.append({"id": i, "name": f"{self.root.stem}_{i:06d}", "path": self.root, "shape": tuple(frame.shape)})
+            i += 1
             if len(buf) == batch_size:
                 yield torch.stack(buf), metas
                 buf, metas = [], []
         if buf:
             yield torch.stack(buf), metas
+
+    # frame geometry: every loader sets frame_height / frame_width in get_data()
+    frame_height = frame_width = 0
+
+    @property
+    def shape(self):
+        return self.frame_height, self.frame_width, 3
+
+    @property
+    def imgsz(self):
+        return self.frame_height, self.frame_width
 
     def reset(self):
         self.index = 0
@@ -134,14 +154,6 @@ class FrameSequenceLoader(VideoLoader):
             raise IOError("Error when reading input stream or video file!")      # video.py:239
         f0 = self.get_frame(0) if self.num_frames else np.zeros((0, 0, 3), np.uint8)
         self.frame_height, self.frame_width = int(f0.shape[0]), int(f0.shape[1])
-
-    @property
-    def shape(self):
-        return self.frame_height, self.frame_width, 3
-
-    @property
-    def imgsz(self):
-        return self.frame_height, self.frame_width
 
     def get_frame(self, index: int) -> np.ndarray:
         from PIL import Image

@@ -227,6 +227,25 @@ def test_video_frame_sequence_round_trip(tmp_path):
         video.FrameSequenceLoader(tmp_path / "missing.gif")
     with pytest.raises(ValueError):
         video._frame_u8("not a frame")
+    # float frames: the explicit flag decides (to_image_nparray, utils.py:782-795), not the data -- a [0, 1] frame with a pixel at 1.01 stays bright
+    f = np.full((2, 3, 3), 0.5, np.float32); f[0, 0, 0] = 1.01
+    assert video._frame_u8(f, denormalize=True).max() == 255 and video._frame_u8(f, denormalize=True)[1, 1, 1] == 127
+    assert video._frame_u8(f * 200.0).max() == 202 and video._frame_u8(np.array([[[300.0, -4.0, 7.9]]], np.float32)).tolist() == [[[255, 0, 7]]]
+    # batches(): front to back through get_frame until the source ends -- also for a source that does not know its length (a stream)
+    got = [b for b, _ in ld.batches(2)]
+    assert [int(b.shape[0]) for b in got] == [2, 2, 1] and got[0].dtype == torch.uint8
+    class Stream(video.VideoLoader):                                   # what VideoLoaderCV is for a "://" source: no length, frames until read() fails
+        is_stream = True
+
+        def get_data(self):
+            self.num_frames, self.frame_height, self.frame_width = -1, 24, 40
+
+        def get_frame(self, index):
+            if index >= len(frames):
+                raise IndexError(index)
+            return frames[index]
+    st = Stream(tmp_path / "clip")
+    assert st.imgsz == (24, 40) and sum(int(b.shape[0]) for b, _ in st.batches(4)) == 5
     try:
         import cv2  # noqa: F401
     except ImportError:
