@@ -497,7 +497,7 @@ def main():
         # ---- CPU baseline (oracle, "port") + parity of this very configuration on one frame ----------------------------------
         if world == 1 and not args.no_cpu_baseline:
             ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-            torch.set_num_threads(max(1, min(ncpu, 64)))
+            torch.set_num_threads(max(1, ncpu))             # every host core this process may use; `cores` reports the number
             def cpu_rate(batch):
                 with torch.no_grad():
                     o_zdce.forward(sd, batch)               # warm-up

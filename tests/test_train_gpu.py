@@ -703,6 +703,36 @@ def test_checkpoint_resume_continues_bit_identically(tmp_path):
     assert torch.equal(m.state_dict()["inc.conv1.weight"], ck["state_dict"]["inc.conv1.weight"])
 
 
+def test_resume_from_weights_only_checkpoint(tmp_path):
+    """ModelCheckpoint's .pt twins (and save_weights_only files) carry no optimiser state: resuming from one takes the weights and the
+    BatchNorm buffers, starts Adam afresh (zero moments, step 0) and keeps the trainer's own hyper-parameters -- not a KeyError.  A
+    deterministic trainer gives the library's process-wide switch back on close()."""
+    from mon_amd import capi
+    batches = _batches(2, 32, 48, 2, seed=14)
+    mk = lambda seed, **kw: mon_amd.Trainer(_unet("bilinear", seed=seed), optimizer={"lr": 2e-3, "eps": 1e-3}, loss={"name": "l1_ssim_loss"},
+                                            gradient_clip_val=0.1, **kw)
+    a = mk(31)
+    a.training_step({"image": batches[0][0], "ref_image": batches[0][1]})
+    path = a.save_checkpoint(tmp_path / "w.pt", weights_only=True)
+    assert "optimizer_states" not in torch.load(path, map_location="cpu", weights_only=False)
+    b = mk(32).load_checkpoint(path)
+    assert b.step == 0 and b.lr == 2e-3 and float(b.store.exp_avg.abs().max()) == 0.0
+    sa, sb = a.state_dict(), b.state_dict()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    bare = tmp_path / "bare.pt"
+    torch.save(sa, bare)                                                   # the reference's plain weight files (nn/model.py:129-130)
+    c = mk(33).load_checkpoint(bare)
+    assert all(torch.equal(sa[k], v) for k, v in c.state_dict().items())
+    c.training_step({"image": batches[1][0], "ref_image": batches[1][1]})
+    assert c.step == 1
+    assert capi.set_deterministic(False) is False
+    with mk(34, deterministic=True) as d:
+        assert capi.lib().ie_get_deterministic() == 1
+        d.training_step({"image": batches[1][0], "ref_image": batches[1][1]})
+    assert capi.lib().ie_get_deterministic() == 0
+
+
 def test_checkpoint_load_refreshes_16bit_weights(tmp_path):
     """Loading a checkpoint into a trainer that has already stepped on the 16-bit graph must refresh the packed weight images: its
     next forward equals that of a fresh trainer loaded from the same file."""
