@@ -83,12 +83,27 @@ def _conv_census(torch, ops, fn):
         r[2] += 2.0 * o.shape[0] * o.shape[2] * o.shape[3] * o.shape[1] * sum(int(t.shape[1]) for t in s_) * mw.kh * mw.kw
         return out
 
-    ops.mconv2d = logged
+    orig_pair = ops.mconv2d_pair
+
+    def logged_pair(x, mwa, mwb, pad_mode="zeros"):        # two stacked 3x3 layers in one launch (ie_mconv_pair_nhwc)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig_pair(x, mwa, mwb, pad_mode=pad_mode)
+        e1.record()
+        e1.synchronize()
+        key = "pair of conv3x3 {}->{}->{} @{}x{} (ie_mconv_pair_nhwc)".format(int(x.shape[1]), mwa.cout, mwb.cout, int(x.shape[2]), int(x.shape[3]))
+        r = rec.setdefault(key, [0, 0.0, 0.0])
+        r[0] += 1
+        r[1] += e0.elapsed_time(e1)
+        r[2] += 2.0 * out.shape[0] * out.shape[2] * out.shape[3] * 9 * (int(x.shape[1]) * mwa.cout + mwa.cout * mwb.cout)
+        return out
+
+    ops.mconv2d, ops.mconv2d_pair = logged, logged_pair
     try:
         fn()
         torch.cuda.synchronize()
     finally:
-        ops.mconv2d = orig
+        ops.mconv2d, ops.mconv2d_pair = orig, orig_pair
     return rec
 
 
@@ -167,7 +182,7 @@ def run_generator_workload(args, ctx):
         key, (calls, ms, flop) = max(rec.items(), key=lambda kv: kv[1][1])
         tot = sum(r[1] for r in rec.values())
         ach = flop / (ms * 1e-3) / 1e12
-        roofline.update({"kernel": "ie_mconv_nhwc " + key, "achieved": round(ach, 1), "frac": round(ach / PEAK_MFMA_TFLOPS, 4),
+        roofline.update({"kernel": key if key.startswith("pair") else "ie_mconv_nhwc " + key, "achieved": round(ach, 1), "frac": round(ach / PEAK_MFMA_TFLOPS, 4),
                          "avg_launch_ms": round(ms / calls, 4), "launches_per_step": calls, "share_of_conv_time": round(ms / tot, 3),
                          "conv_ms_per_step": round(tot, 2),
                          "note": "dominant conv shape of the step: algorithmic FLOPs (2*MAC) / HIP-event time around its ie_mconv_nhwc calls"

@@ -43,3 +43,6 @@ bool ie_sconv3_fused_ok(int nsrc, const int* cs);
 int ie_sconv3_launch(const void* const* srcs, const int* cs, int nsrc, const void* wpk, const float* bias, void* dst, int dtype, int N, int H, int W,
                      int Cout, int act, float slope, int pad_mode, const int* src_h, const int* src_w, void* pool_dst, const ie_sconv_tail* tail, int stride, hipStream_t st);
 // pool_dst: null, or the 2x2 max-pooled copy of dst written by the same launch (ReLU layers only)
+// two stacked Conv3x3(64 -> 64) + bias + ReLU layers, the intermediate in LDS only (ie_conv_pair.hip)
+int ie_sconv3x2_launch(const void* src, const void* w_a, const float* bias_a, const void* w_b, const float* bias_b, void* dst, int dtype, int N, int H, int W,
+                       int pad_mode, hipStream_t st);

@@ -1390,7 +1390,15 @@ class RetinexNet(_GraphModel):
         if self.compute_dtype != "f32":
             xin = ops.cast(xin, self._tdt, 8)
         f = c(xin, "net1_conv0", pad=4, pad_mode=R)
-        for i in (0, 2, 4, 6, 8):
+        layers = [0, 2, 4, 6, 8]
+        while layers:
+            i = layers.pop(0)
+            if self.compute_dtype != "f32" and layers:      # two 64 -> 64 layers per launch, the one between them in LDS only (ie_conv_pair.hip)
+                mwa, mwb = self._mw_plain((self.channels,), f"net1_convs.{i}"), self._mw_plain((self.channels,), f"net1_convs.{layers[0]}")
+                if ops.mconv2d_pair_applicable(f, mwa, mwb, pad_mode=R):
+                    f = ops.mconv2d_pair(f, mwa, mwb, pad_mode=R)
+                    layers.pop(0)
+                    continue
             f = c(f, f"net1_convs.{i}", pad_mode=R, act="relu")
         # 16-bit path: R and L leave in fp32 (16 bytes per pixel either way): S = R * I_delta multiplies by R itself, not by its 16-bit
         # rounding -- that rounding alone was 7e-4 of the 1e-3 bound (tools/retinex_attrib.py)

@@ -925,6 +925,34 @@ def dsconv2d(srcs, dw_w: torch.Tensor, dw_b, pw: MConvWeights, act="none", slope
     return out
 
 
+def mconv2d_pair_applicable(x, mwa: MConvWeights, mwb: MConvWeights, pad_mode="zeros", act_a="relu", act_b="relu") -> bool:
+    """Can ``relu(conv_b(relu(conv_a(x))))`` -- two stacked 3x3 / stride 1 / padding 1 layers -- run as ONE launch with the intermediate in LDS only?"""
+    if not isinstance(x, torch.Tensor) or x.dim() != 4 or mwa.dtype != mwb.dtype or x.dtype != mwa.dtype:
+        return False
+    if mwa.split != [int(x.shape[1])] or mwb.split != [mwa.cout] or getattr(mwa, "shuffle", 0) or getattr(mwb, "shuffle", 0):
+        return False
+    if (mwa.kh, mwa.kw, mwb.kh, mwb.kw) != (3, 3, 3, 3):
+        return False
+    return bool(capi.lib().ie_mconv_pair_applicable(int(x.shape[1]), mwa.cout, mwb.cout, 3, 3, 1, 1, capi.PAD[pad_mode], capi.ACT[act_a], capi.ACT[act_b],
+                                                    int(x.shape[3])))
+
+
+def mconv2d_pair(x, mwa: MConvWeights, mwb: MConvWeights, pad_mode="zeros"):
+    """``relu(conv_b(relu(conv_a(x))))`` in one launch (ie_mconv_pair_nhwc): the same bits as two ``mconv2d(..., act="relu")`` calls, without the
+    intermediate tensor's trip through HBM.  Raises where ``mconv2d_pair_applicable`` says no."""
+    _chk16(x)
+    if not mconv2d_pair_applicable(x, mwa, mwb, pad_mode):
+        raise capi.IEError("mconv2d_pair: two 3x3 / stride 1 / padding 1 / ReLU layers 64 -> 64 -> 64 on a 16-bit NHWC tensor with W >= 64")
+    n, c, h, w = (int(v) for v in x.shape)
+    out = torch.empty((n, mwb.cout, h, w), device=x.device, dtype=x.dtype, memory_format=CL)
+    _count_macs(n, h, w, mwa.cout, c, 3, 3)
+    _count_macs(n, h, w, mwb.cout, mwa.cout, 3, 3)
+    with torch.cuda.device(x.device):
+        capi.check(capi.lib().ie_mconv_pair_nhwc(capi.ptr(x), capi.ptr(mwa.w), capi.ptr(mwa.b), capi.ptr(mwb.w), capi.ptr(mwb.b), capi.ptr(out),
+                                                 IE_DT[x.dtype], n, h, w, capi.PAD[pad_mode], capi.current_stream()), "ie_mconv_pair_nhwc")
+    return out
+
+
 class MConvWeightsDev:
     """Packed weights for ie_mconv_nhwc produced ON THE DEVICE from the trainer's HWIO fp32 master weights (``repack()`` after every
     optimiser step).  ``mode="forward"``: the conv over sources ``split``; ``mode="dgrad"``: the data-gradient conv of source

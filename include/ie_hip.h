@@ -208,6 +208,15 @@ int ie_mconv_tail_nhwc(ie_mconv_desc* d, const void* const* srcs_dev, const int*
                        const void* tail_w_dev, const float* tail_bias_dev, int tail_cout, int clamp, float clamp_lo, float clamp_hi,
                        float* dst_nchw_dev, void* stream);
 
+/* Two stacked 3x3 convolutions C -> C -> C (stride 1, padding 1, + bias + ReLU each) in one launch, the intermediate tensor never in HBM:
+ * replaces two consecutive torch.nn.Conv2d + ReLU of a plain conv stack (reference: DecomNet's `net1_convs`, retinexnet/model.py:28-33; replicate padding
+ * pads the INTERMEDIATE of the second layer, as the reference does).  packed_w_a / packed_w_b: ie_mconv_pack_weights images of the two layers (one source
+ * of C channels each); src / dst: NHWC, C channels, dtype IE_F16 / IE_BF16.  Bit-identical to two ie_mconv_nhwc calls.  Covered: C = 64, W >= 64 --
+ * ie_mconv_pair_applicable says (1 / 0); anything else is IE_ERR_UNSUPPORTED. */
+int ie_mconv_pair_applicable(int cin, int cmid, int cout, int kh, int kw, int stride, int pad, int pad_mode, int act_a, int act_b, int W);
+int ie_mconv_pair_nhwc(const void* src_dev, const void* packed_w_a_dev, const float* bias_a_dev, const void* packed_w_b_dev, const float* bias_b_dev,
+                       void* dst_dev, int dtype, int N, int H, int W, int pad_mode, void* stream);
+
 /* ---- 16-bit (IE_F16 / IE_BF16) NHWC streaming ops between the matrix-core convolutions; IE_F32 forwards to the *_f32
  * entry points above.  On the 16-bit path channel counts are multiples of 8 (a thread moves 8 channels = 16 bytes). */
 int ie_maxpool2x2_nhwc(const void* x_dev, void* y_dev, int dtype, int N, int H, int W, int C, void* stream);

@@ -121,6 +121,27 @@ def test_conv_with_fused_1x1_tail(cs, co, ct, clamp, dt, shape):
 
 
 @pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("pad_mode", ["zeros", "replicate"])
+@pytest.mark.parametrize("shape", [(2, 37, 150), (1, 200, 64), (3, 6, 129), (1, 270, 480), (2, 1, 66), (1, 2, 253), (1, 131, 126)], ids=lambda s: "x".join(map(str, s)))
+def test_two_stacked_convs_in_one_launch(shape, pad_mode, dt):
+    """ie_mconv_pair_nhwc (DecomNet's Conv3x3(64, 64) + ReLU stack, retinexnet/model.py:28-33): two layers in one launch, the intermediate in LDS
+    only, equal two ie_mconv_nhwc calls bit for bit -- the same contraction order and the same single rounding of the intermediate; replicate
+    padding pads the intermediate of the second layer like the reference's second Conv2d does."""
+    tdt = ops.TORCH_DT[dt]
+    n, h, w = shape
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(n, 64, h, w, generator=g).to(tdt).cuda().contiguous(memory_format=CL)
+    mws = [ops.MConvWeights((torch.randn(64, 64, 3, 3, generator=g) / 24.0).to(tdt).float(), torch.randn(64, generator=g) * 0.2, [64], tdt, "cuda") for _ in range(2)]
+    assert ops.mconv2d_pair_applicable(x, mws[0], mws[1], pad_mode=pad_mode)
+    got = ops.mconv2d_pair(x, mws[0], mws[1], pad_mode=pad_mode)
+    mid = ops.mconv2d(x, mws[0], pad_mode=pad_mode, act="relu")
+    want = ops.mconv2d(mid, mws[1], pad_mode=pad_mode, act="relu")
+    assert tuple(got.shape) == tuple(want.shape) and got.dtype == want.dtype
+    assert torch.equal(got, want)
+    assert not ops.mconv2d_pair_applicable(x[:, :32].contiguous(memory_format=CL), mws[0], mws[1])
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
 @pytest.mark.parametrize("shape", [(2, 37, 150), (1, 200, 64), (3, 6, 129), (1, 270, 480), (2, 2, 66)], ids=lambda s: "x".join(map(str, s)))
 @pytest.mark.parametrize("c", [32, 64])
 def test_first_double_conv_with_pool(c, dt, shape):

@@ -324,7 +324,7 @@ def test_bench_other_workloads_two_ranks_one_device(workload):
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 2 and line["value"] > 0 and line["scaling"] == "weak"
-    assert line["roofline"]["bound"] == "mfma" and 0 < line["roofline"]["frac"] < 1 and line["roofline"]["kernel"].startswith("ie_mconv_nhwc")
+    assert line["roofline"]["bound"] == "mfma" and 0 < line["roofline"]["frac"] < 1 and ("ie_mconv" in line["roofline"]["kernel"])
     if workload == "unet64_train":
         c = line["comm"]
         assert c["allreduce_bytes"] > 60e6 and c["allreduce_ms"] > 0 and c["ms_per_step_without_allreduce"] > 0
