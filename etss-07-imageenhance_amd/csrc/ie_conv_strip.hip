@@ -34,6 +34,9 @@ constexpr unsigned OOB = 0x80000000u;
 #ifndef IE_SC_AHEAD4
 #define IE_SC_AHEAD4 2
 #endif
+#ifndef IE_SC_PINNED
+#define IE_SC_PINNED 1      // explicit read-ahead + pinned MFMA order in the strip kernels' row loop (0: the sched_group_barrier pipeline of rounds 1 - 2)
+#endif
 #ifndef IE_SC_NR_C64O32
 #define IE_SC_NR_C64O32 3
 #endif
@@ -400,6 +403,35 @@ __device__ __forceinline__ void sconv3_body(const SConvParams& p) {
             }
             return;
         }
+        if constexpr (IE_SC_PINNED && NCH < 4) {
+        // Pinned order (round 3): the fragment reads run AHEAD fragments before their three MFMAs, through a small ring of fragment registers, and a
+        // sched_barrier after every fragment keeps it that way.  The sched_group_barrier pipeline below asked for the same thing, but the listing
+        // showed `ds_read_b128 ; s_waitcnt lgkmcnt(0) ; 3 x v_mfma` into ONE reused register quad for every fragment of every strip kernel: the full
+        // LDS latency in front of each MFMA triplet (53 % MFMA-busy on 64 -> 64).
+        {
+            constexpr int AHEAD = 3;
+            constexpr int NG = NCH * 12;
+            frag bx[AHEAD + 1];
+            auto rdf = [&](int g) __attribute__((always_inline)) {       // g = (chunk, kx, tile): compile-time at every call
+                const int c = g / 12, kx = (g % 12) >> 2, nt = g & 3;
+                const int off = (kx == 0 && nt == 0) ? rd_first : (kx == 2 && nt == 3) ? rd_last : rd_base[kx] + 1024 * nt;
+                bx[g % (AHEAD + 1)] = *(const frag*)(slot + c * SRC_ROW_B + off);
+            };
+#pragma unroll
+            for (int g = 0; g < AHEAD; ++g) rdf(g);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const int c = g / 12, kx = (g % 12) >> 2, nt = g & 3;
+                if (g + AHEAD < NG) rdf(g + AHEAD);
+                const frag b_ = bx[g % (AHEAD + 1)];
+                accN[nt] = ie_mfma16_raw<T>(wA[c * 9 + 0 * 3 + kx], b_, (c == 0 && kx == 0) ? bias4 : accN[nt]);
+                accM[nt] = ie_mfma16_raw<T>(wA[c * 9 + 1 * 3 + kx], b_, accM[nt]);
+                accO[nt] = ie_mfma16_raw<T>(wA[c * 9 + 2 * 3 + kx], b_, accO[nt]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        } else {      // four K chunks: no registers for a fragment ring (256 VGPRs, 2 spilled with one fragment of look-ahead): the round-2 pipeline
 #pragma unroll
         for (int c = 0; c < NCH; ++c)
 #pragma unroll
@@ -421,6 +453,7 @@ __device__ __forceinline__ void sconv3_body(const SConvParams& p) {
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
         __builtin_amdgcn_sched_group_barrier(0x008, 3 * AHEAD, 0);
+        }
     };
     auto step = [&](int it, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4]) __attribute__((always_inline)) {
         // ops younger than row `it`'s DMA: the (PF-1) L loads of the rows behind it and the SPW (possibly out-of-range) stores every step issues
