@@ -37,6 +37,8 @@ constexpr int OFF_H = NRA * SLOT_B, OFF_OUT = OFF_H + NRH * SLOT_B, LDS_B = OFF_
 struct PairParams {
     const void* src; const void* wa; const float* ba; const void* wb; const float* bb; void* dst;
     int N, H, W, rows_per_block, strips, chunks, replicate;
+    int cout_b, act_b;       // thin second layer (CB == 16): its real output channels (4, 8, 12 or 16) and activation; dst is fp32 NHWC then
+    void* dst16;             // thin: optional second copy of the output as 16-bit NHWC padded to 8 channels (cout_b == 4), or null
 };
 
 __device__ __forceinline__ void wait_vm_cold(int n) {
@@ -53,8 +55,12 @@ __device__ __forceinline__ void wait_vm_cold(int n) {
     }
 }
 
-template <typename T>
+// CB = 64: the second layer is 64 -> 64 + ReLU, 16-bit output.  CB = 16: the second layer is thin (64 -> cout_b <= 16, any activation, fp32 output):
+// its four waves split the strip by pixel tiles (two each) instead of by output channels, and a finished row leaves straight from the accumulators --
+// lane (pixel, kq) holds channels 4 kq .. 4 kq + 3 of its pixel, 16 contiguous bytes of the fp32 NHWC row.
+template <typename T, int CB>
 __device__ __forceinline__ void sconv3x2_body(const PairParams& p) {
+    constexpr bool THIN = CB == 16;
     using frag = ie_u32x4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -77,23 +83,26 @@ __device__ __forceinline__ void sconv3x2_body(const PairParams& p) {
     };
     const size_t frame_b = (size_t)H * W * OPB;
     const auto rsS = mk((const char*)p.src + (size_t)n * frame_b, frame_b);
-    const auto rsD = mk((char*)p.dst + (size_t)n * frame_b, frame_b);
+    const size_t dframe_b = THIN ? (size_t)H * W * p.cout_b * 4 : frame_b;
+    const auto rsD = mk((char*)p.dst + (size_t)n * dframe_b, dframe_b);
 
     // ---- this wave's 18 weight fragments and 4 biases ----------------------------------------------------------------------------------
     frag wv[18];
     {
         const char* wp = (const char*)(stg ? p.wb : p.wa);
+        const int wrows = (THIN && stg) ? 16 : 64, wcf = (THIN && stg) ? 0 : cf;      // the thin layer's image has one 16-row fragment per (chunk, tap)
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int t = 0; t < 9; ++t)
-                wv[c * 9 + t] = *(const frag*)(wp + ((size_t)(c * 9 + t) * 64 + cf * 16 + p16) * 64 + ((kq ^ ((p16 >> 1) & 3)) << 4));
+                wv[c * 9 + t] = *(const frag*)(wp + ((size_t)(c * 9 + t) * wrows + wcf * 16 + p16) * 64 + ((kq ^ ((p16 >> 1) & 3)) << 4));
     }
     ie_f32x4 bias4;
     {
         const float* bp = stg ? p.bb : p.ba;
+        const int c0 = (THIN && stg) ? 4 * kq : 16 * cf + 4 * kq, cmax = (THIN && stg) ? p.cout_b : 64;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) bias4[i] = bp ? bp[16 * cf + 4 * kq + i] : 0.f;
+        for (int i = 0; i < 4; ++i) bias4[i] = (bp && c0 + i < cmax) ? bp[c0 + i] : 0.f;
     }
 
     // ---- stage A: LDS-DMA of the input rows.  Piece m = 16 pixels x 64 B of one chunk; position (lane & 3) of ring pixel q holds channel piece
@@ -157,6 +166,36 @@ __device__ __forceinline__ void sconv3x2_body(const PairParams& p) {
 #pragma unroll
         for (int nt = 0; nt < 8; ++nt) rd2[nt] = lds_px(fix(16 * nt + p16 + 1));
     }
+    // thin stage B: wave cf covers tiles 2 cf, 2 cf + 1; six offsets (kx, tile), the same clamping rules
+    int rdt[3][2];
+    if constexpr (THIN) {
+        const int qlo = max(0, -xc0), qhi = max(min(TW - 1, W - 1 - xc0), qlo);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int q = 16 * (2 * cf + j) + p16 + kx - 1;
+                rdt[kx][j] = lds_px(rep ? min(max(q, qlo), qhi) : min(max(q, 0), TW - 1));
+            }
+    }
+    auto row_mfma_t = [&](const char* slot, ie_f32x4 (&accN)[2], ie_f32x4 (&accM)[2], ie_f32x4 (&accO)[2]) __attribute__((always_inline)) {
+        frag bx[4];
+        auto rdf = [&](int g) __attribute__((always_inline)) {         // g = (chunk, kx, tile of the wave)
+            const int c = g / 6, kx = (g % 6) >> 1, j = g & 1;
+            bx[g & 3] = *(const frag*)(slot + c * CH_ROW_B + rdt[kx][j]);
+        };
+        rdf(0); rdf(1); rdf(2);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 12; ++g) {
+            const int c = g / 6, kx = (g % 6) >> 1, j = g & 1;
+            if (g + 3 < 12) rdf(g + 3);
+            accN[j] = ie_mfma16_raw<T>(wv[c * 9 + 0 * 3 + kx], bx[g & 3], (c == 0 && kx == 0) ? bias4 : accN[j]);
+            accM[j] = ie_mfma16_raw<T>(wv[c * 9 + 1 * 3 + kx], bx[g & 3], accM[j]);
+            accO[j] = ie_mfma16_raw<T>(wv[c * 9 + 2 * 3 + kx], bx[g & 3], accO[j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
     // one row into the three live accumulator sets (ky = 0: the set this row starts takes the bias as its first C operand)
     // The order is pinned (sched_barrier after every fragment's three MFMAs) with the fragment reads three ahead of their use: left to itself the
     // scheduler chained the 144 MFMAs per accumulator and waited lgkmcnt(0) behind every read.
@@ -242,6 +281,54 @@ __device__ __forceinline__ void sconv3x2_body(const PairParams& p) {
             if (t + 1 < n_steps) step_a(t + 1, a2, a0, a1);
             if (t + 2 < n_steps) step_a(t + 2, a1, a2, a0);
         }
+    } else if constexpr (THIN) {
+        // Thin stage B, step t: the same schedule; accN holds output row ys - 7 + t (finished at step t - 1), which leaves now, straight from the registers
+        unsigned st_f32[2], st_16[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int q = 16 * (2 * cf + j) + p16, x = xc0 + q;
+            const bool ok = q >= 1 && q <= TS && x < W;
+            st_f32[j] = (ok && 4 * kq < p.cout_b) ? (unsigned)(x * p.cout_b * 4 + kq * 16) : OOB;
+            st_16[j] = (ok && kq == 0) ? (unsigned)(x * 16) : OOB;
+        }
+        const size_t f16_b = (size_t)H * W * 16;
+        const auto rsD16 = mk(p.dst16 ? (char*)p.dst16 + (size_t)n * f16_b : (char*)p.dst, p.dst16 ? f16_b : 0);
+        const bool dual = p.dst16 != nullptr;
+        const int act = p.act_b;
+        ie_f32x4 t0[2], t1[2], t2[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { t0[j] = bias4; t1[j] = bias4; t2[j] = bias4; }
+        auto step_bt = [&](int t, ie_f32x4 (&accN)[2], ie_f32x4 (&accM)[2], ie_f32x4 (&accO)[2]) __attribute__((always_inline)) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            {
+                const int yo = ys - 7 + t;
+                const unsigned rmask = (yo >= ys && yo < ye) ? 0u : OOB;
+                const unsigned yrow = rmask ? 0u : (unsigned)yo * (unsigned)W;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    ie_f32x4 v;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {            // the hardware exp2 / rcp forms ie_mconv_nhwc's epilogue uses; `act` is wave-uniform
+                        const float a = accN[j][i];
+                        v[i] = act == IE_ACT_SIGMOID ? ie_sigmoid_fast(a) : act == IE_ACT_TANH ? ie_tanh_fast(a) : act == IE_ACT_RELU ? fmaxf(a, 0.f) : a;
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ie_u32x4, v), rsD, (int)((yrow * (unsigned)(p.cout_b * 4) + st_f32[j]) | rmask), 0, 0);
+                    if (dual)
+                        __builtin_amdgcn_raw_buffer_store_b128(ie_u32x4{ie_pack2<T>(v[0], v[1]), ie_pack2<T>(v[2], v[3]), 0u, 0u}, rsD16,
+                                                               (int)((yrow * 16u + st_16[j]) | rmask), 0, 0);
+                }
+            }
+            int mc = ys - 5 + t;
+            if (rep) mc = min(max(mc, 0), H - 1);
+            const int ta = mc - ys + 3;
+            row_mfma_t(smem + OFF_H + ((ta < 0 ? 0 : ta) % NRH) * SLOT_B, accN, accM, accO);
+        };
+        for (int t = 0; t < n_steps; t += 3) {
+            step_bt(t, t0, t1, t2);
+            if (t + 1 < n_steps) step_bt(t + 1, t2, t0, t1);
+            if (t + 2 < n_steps) step_bt(t + 2, t1, t2, t0);
+        }
     } else {
         // Stage B, step t: consumes the intermediate's row mc = clamp(ys - 5 + t) (written by stage A at its step mc - ys + 3), finishing output row
         // ys - 6 + t; accN still holds the row finished at step t - 1 (parked now), the row parked at step t - 1 leaves now.
@@ -274,21 +361,31 @@ __device__ __forceinline__ void sconv3x2_body(const PairParams& p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-__global__ __launch_bounds__(512) void sconv3x2_f16_c64_c64_c64_relu(PairParams p) { sconv3x2_body<_Float16>(p); }
-__global__ __launch_bounds__(512) void sconv3x2_bf16_c64_c64_c64_relu(PairParams p) { sconv3x2_body<__bf16>(p); }
+__global__ __launch_bounds__(512) void sconv3x2_f16_c64_c64_c64_relu(PairParams p) { sconv3x2_body<_Float16, 64>(p); }
+__global__ __launch_bounds__(512) void sconv3x2_bf16_c64_c64_c64_relu(PairParams p) { sconv3x2_body<__bf16, 64>(p); }
+__global__ __launch_bounds__(512) void sconv3x2_f16_c64_c64_thin_f32(PairParams p) { sconv3x2_body<_Float16, 16>(p); }
+__global__ __launch_bounds__(512) void sconv3x2_bf16_c64_c64_thin_f32(PairParams p) { sconv3x2_body<__bf16, 16>(p); }
 
 }  // namespace
 
 // Two Conv3x3(64 -> 64, stride 1, padding 1 zeros | replicate) + bias + ReLU layers in one launch.  w_a / w_b: ie_mconv_pack_weights images of the two layers
 // (one 64-channel source each).  src / dst: NHWC, 64 channels, 16-bit.
+// cout_b = 64: as above.  cout_b in {4, 8, 12, 16}: the second layer is thin -- dst is fp32 NHWC with cout_b channels, act_b its activation (none / relu /
+// sigmoid / tanh), dst16 an optional 16-bit NHWC copy padded to 8 channels (cout_b == 4).
 int ie_sconv3x2_launch(const void* src, const void* w_a, const float* bias_a, const void* w_b, const float* bias_b, void* dst, int dtype, int N, int H, int W,
-                       int pad_mode, hipStream_t st) {
+                       int pad_mode, int cout_b, int act_b, void* dst16, hipStream_t st) {
     if (!src || !w_a || !w_b || !dst || N <= 0 || H < 1 || W < 64) IE_FAIL(IE_ERR_UNSUPPORTED, "ie_sconv3x2: 64 channels, W >= 64");
+    const bool thin = cout_b != 64;
+    if (thin && (cout_b < 4 || cout_b > 16 || (cout_b & 3) || (dst16 && cout_b != 4)))
+        IE_FAIL(IE_ERR_UNSUPPORTED, "ie_sconv3x2: thin second layer needs 4, 8, 12 or 16 output channels (4 with a 16-bit copy), got %d", cout_b);
+    if (thin && act_b != IE_ACT_NONE && act_b != IE_ACT_RELU && act_b != IE_ACT_SIGMOID && act_b != IE_ACT_TANH)
+        IE_FAIL(IE_ERR_UNSUPPORTED, "ie_sconv3x2: activation %d of the thin layer", act_b);
     if (dtype != IE_F16 && dtype != IE_BF16) IE_FAIL(IE_ERR_UNSUPPORTED, "ie_sconv3x2: f16 / bf16");
     if ((double)H * W * 128.0 >= 2147483647.0) IE_FAIL(IE_ERR_UNSUPPORTED, "ie_sconv3x2: frame too large for 31-bit offsets");
     PairParams p;
     memset(&p, 0, sizeof(p));
     p.src = src; p.wa = w_a; p.ba = bias_a; p.wb = w_b; p.bb = bias_b; p.dst = dst; p.N = N; p.H = H; p.W = W; p.replicate = pad_mode == IE_PAD_REPLICATE;
+    p.cout_b = cout_b; p.act_b = act_b; p.dst16 = thin ? dst16 : nullptr;
     p.strips = ie_cdiv(W, TS);
     {
         // row chunks: whole rounds of the chip's 256 workgroup slots (one 8-wave workgroup per CU), few apron rows (8 steps per chunk)
@@ -309,12 +406,14 @@ int ie_sconv3x2_launch(const void* src, const void* w_a, const float* bias_a, co
     const long long blocks = (long long)p.strips * p.chunks * N;
     if (blocks <= 0 || blocks > 0x7fffffffLL) IE_FAIL(IE_ERR_INVALID, "ie_sconv3x2: bad grid");
     typedef void (*Fn)(PairParams);
-    Fn fn = dtype == IE_F16 ? sconv3x2_f16_c64_c64_c64_relu : sconv3x2_bf16_c64_c64_c64_relu;
-    static Fn granted[2] = {nullptr, nullptr};
-    if (granted[0] != fn && granted[1] != fn) {
+    const int fi = (dtype == IE_F16 ? 0 : 1) + (thin ? 2 : 0);
+    static const Fn fns[4] = {sconv3x2_f16_c64_c64_c64_relu, sconv3x2_bf16_c64_c64_c64_relu, sconv3x2_f16_c64_c64_thin_f32, sconv3x2_bf16_c64_c64_thin_f32};
+    const Fn fn = fns[fi];
+    static bool granted[4] = {false, false, false, false};
+    if (!granted[fi]) {
         hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
         if (e != hipSuccess) IE_FAIL(IE_ERR_HIP, "hipFuncSetAttribute(lds=%d): %s", LDS_B, hipGetErrorString(e));
-        (granted[0] ? granted[1] : granted[0]) = fn;
+        granted[fi] = true;
     }
     void* args[] = {(void*)&p};
     IE_HIP_CHECK(hipLaunchKernel((const void*)fn, dim3((unsigned)blocks), dim3(512), args, LDS_B, st));
@@ -331,5 +430,19 @@ IE_EXPORT int ie_mconv_pair_applicable(int cin, int cmid, int cout, int kh, int 
 IE_EXPORT int ie_mconv_pair_nhwc(const void* src, const void* packed_w_a, const float* bias_a, const void* packed_w_b, const float* bias_b, void* dst,
                                  int dtype, int N, int H, int W, int pad_mode, void* stream) {
     if (pad_mode != IE_PAD_ZEROS && pad_mode != IE_PAD_REPLICATE) IE_FAIL(IE_ERR_INVALID, "ie_mconv_pair_nhwc: pad_mode %d", pad_mode);
-    return ie_sconv3x2_launch(src, packed_w_a, bias_a, packed_w_b, bias_b, dst, dtype, N, H, W, pad_mode, (hipStream_t)stream);
+    return ie_sconv3x2_launch(src, packed_w_a, bias_a, packed_w_b, bias_b, dst, dtype, N, H, W, pad_mode, 64, IE_ACT_RELU, nullptr, (hipStream_t)stream);
+}
+
+IE_EXPORT int ie_mconv_pair_thin_applicable(int cin, int cmid, int cout, int kh, int kw, int stride, int pad, int pad_mode, int act_a, int act_b, int W) {
+    static const int off = getenv("IE_SCONV_PAIR") ? !atoi(getenv("IE_SCONV_PAIR")) : 0;
+    return (!off && cin == 64 && cmid == 64 && cout >= 4 && cout <= 16 && !(cout & 3) && kh == 3 && kw == 3 && stride == 1 && pad == 1 &&
+            (pad_mode == IE_PAD_ZEROS || pad_mode == IE_PAD_REPLICATE) && act_a == IE_ACT_RELU &&
+            (act_b == IE_ACT_NONE || act_b == IE_ACT_RELU || act_b == IE_ACT_SIGMOID || act_b == IE_ACT_TANH) && W >= 64) ? 1 : 0;
+}
+
+IE_EXPORT int ie_mconv_pair_thin_nhwc(const void* src, const void* packed_w_a, const float* bias_a, const void* packed_w_b, const float* bias_b, float* dst_f32,
+                                      void* dst16_8ch, int dtype, int N, int H, int W, int cout_b, int act_b, int pad_mode, void* stream) {
+    if (pad_mode != IE_PAD_ZEROS && pad_mode != IE_PAD_REPLICATE) IE_FAIL(IE_ERR_INVALID, "ie_mconv_pair_thin_nhwc: pad_mode %d", pad_mode);
+    if (cout_b == 64) IE_FAIL(IE_ERR_INVALID, "ie_mconv_pair_thin_nhwc: 64 output channels is ie_mconv_pair_nhwc");
+    return ie_sconv3x2_launch(src, packed_w_a, bias_a, packed_w_b, bias_b, dst_f32, dtype, N, H, W, pad_mode, cout_b, act_b, dst16_8ch, (hipStream_t)stream);
 }

@@ -172,7 +172,55 @@ __global__ void pad_replicate_backward_kernel(const float* __restrict__ dy, floa
     dx[i] = (accumulate ? dx[i] : 0.f) + s;
 }
 
+// DecomNet's input in one pass (model.py:45-46: input_max = max over channels; input_img = cat(input_max, input_im)): fp32 NCHW image -> 16-bit NHWC padded
+// to 8 channels [max, R, G, B, 0, 0, 0, 0], one 16-byte store per pixel.
+template <typename T>
+__global__ void decom_input_kernel(const float* __restrict__ src, T* __restrict__ dst, size_t plane, size_t total_px) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total_px) return;
+    const size_t n = i / plane, pix = i % plane;
+    const float* s = src + n * 3 * plane + pix;
+    const float r = s[0], g = s[plane], b = s[2 * plane];
+    const float m = fmaxf(fmaxf(r, g), b);
+    *(ie_u32x4*)(dst + i * 8) = ie_u32x4{ie_pack2<T>(m, r), ie_pack2<T>(g, b), 0u, 0u};
+}
+
+// The model's outputs in one pass (model.py:72-74, 229-231): rl = (R, L) fp32 pixel-major 4 floats, I_delta fp32 one float per pixel ->
+// R (N,3,H,W), L (N,1,H,W), S = R * I_delta (N,3,H,W), all NCHW fp32.  A thread = one pixel: plane-wise coalesced stores.
+__global__ void outputs_kernel(const float* __restrict__ rl, const float* __restrict__ idl, float* __restrict__ R, float* __restrict__ L,
+                               float* __restrict__ S, size_t plane, size_t total_px) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total_px) return;
+    const size_t n = i / plane, pix = i % plane;
+    const ie_f32x4 v = *(const ie_f32x4*)(rl + 4 * i);
+    const float d = idl[i];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        if (R) R[(n * 3 + c) * plane + pix] = v[c];
+        S[(n * 3 + c) * plane + pix] = v[c] * d;
+    }
+    if (L) L[i] = v[3];
+}
+
 }  // namespace
+
+IE_EXPORT int ie_retinex_decom_input(const float* x_nchw, void* dst_nhwc8, int dtype, int N, int H, int W, void* stream) {
+    if (!x_nchw || !dst_nhwc8 || N <= 0 || H <= 0 || W <= 0) IE_FAIL(IE_ERR_INVALID, "ie_retinex_decom_input: bad args");
+    const size_t plane = (size_t)H * W, total = plane * N;
+    if (dtype == IE_F16) hipLaunchKernelGGL(decom_input_kernel<_Float16>, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, x_nchw, (_Float16*)dst_nhwc8, plane, total);
+    else if (dtype == IE_BF16) hipLaunchKernelGGL(decom_input_kernel<__bf16>, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, x_nchw, (__bf16*)dst_nhwc8, plane, total);
+    else IE_FAIL(IE_ERR_UNSUPPORTED, "ie_retinex_decom_input: dtype %d (IE_F16 / IE_BF16)", dtype);
+    IE_LAUNCH_CHECK();
+    return IE_OK;
+}
+
+IE_EXPORT int ie_retinex_outputs_f32(const float* rl_nhwc4, const float* i_delta, float* R_nchw, float* L_nchw, float* S_nchw, int N, int H, int W, void* stream) {
+    if (!rl_nhwc4 || !i_delta || !S_nchw || N <= 0 || H <= 0 || W <= 0) IE_FAIL(IE_ERR_INVALID, "ie_retinex_outputs_f32: bad args");
+    const size_t plane = (size_t)H * W, total = plane * N;
+    hipLaunchKernelGGL(outputs_kernel, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, rl_nhwc4, i_delta, R_nchw, L_nchw, S_nchw, plane, total);
+    IE_LAUNCH_CHECK();
+    return IE_OK;
+}
 
 IE_EXPORT int ie_retinex_recon_f32(const float* R, int r_stride, const float* I, int i_stride, const float* T, float weight, float* dR, float* dI,
                                    double* loss, int N, int H, int W, void* stream) {

@@ -1383,12 +1383,14 @@ class RetinexNet(_GraphModel):
                 self._init_conv(k[:-7], g)
         self._on_params_change()
 
-    def decom(self, x):
-        """x: fp32 NHWC image.  Returns DecomNet's sigmoid output: channels 0-2 = R, 3 = L (16-bit path: padded to 8)."""
+    def decom(self, x, copy16=False):
+        """x: fp32 NHWC image (fp32 path) or DecomNet's 16-bit 8-channel input ``[max_c, R, G, B, 0..]`` (16-bit path, ops.retinex_decom_input).
+        Returns DecomNet's sigmoid output, fp32 NHWC: channels 0-2 = R, 3 = L; with ``copy16`` also its 16-bit copy padded to 8 channels."""
         R, c = "replicate", self._conv
-        xin = ops.max_concat(x)                                                    # [max_c(x), x], model.py:45-46
-        if self.compute_dtype != "f32":
-            xin = ops.cast(xin, self._tdt, 8)
+        if self.compute_dtype == "f32":
+            xin = ops.max_concat(x)                                                # [max over channels, x], model.py:45-46
+        else:
+            xin = x
         f = c(xin, "net1_conv0", pad=4, pad_mode=R)
         layers = [0, 2, 4, 6, 8]
         while layers:
@@ -1399,10 +1401,15 @@ class RetinexNet(_GraphModel):
                     f = ops.mconv2d_pair(f, mwa, mwb, pad_mode=R)
                     layers.pop(0)
                     continue
+            if self.compute_dtype != "f32" and not layers:  # the last 64 -> 64 layer and net1_recon (64 -> 4, sigmoid, fp32 out) in one launch
+                mwa, mwb = self._mw_plain((self.channels,), f"net1_convs.{i}"), self._mw_plain((self.channels,), "net1_recon")
+                if ops.mconv2d_pair_thin_applicable(f, mwa, mwb, pad_mode=R, act_b="sigmoid"):
+                    return ops.mconv2d_pair_thin(f, mwa, mwb, pad_mode=R, act_b="sigmoid", copy16=copy16)
             f = c(f, f"net1_convs.{i}", pad_mode=R, act="relu")
         # 16-bit path: R and L leave in fp32 (16 bytes per pixel either way): S = R * I_delta multiplies by R itself, not by its 16-bit
         # rounding -- that rounding alone was 7e-4 of the 1e-3 bound (tools/retinex_attrib.py)
-        return c(f, "net1_recon", pad_mode=R, act="sigmoid", out_f32=self.compute_dtype != "f32")
+        rl = c(f, "net1_recon", pad_mode=R, act="sigmoid", out_f32=self.compute_dtype != "f32")
+        return (rl, ops.cast(rl, self._tdt, 8)) if copy16 else rl
 
     def relight(self, rl):
         """rl: cat(R, L) == the 4-channel sigmoid output of DecomNet (model.py:72)."""
@@ -1531,12 +1538,27 @@ class RetinexNet(_GraphModel):
         return outputs
 
     def forward(self, datapoint: dict, *args, **kwargs) -> dict:
+        out = OrderedDict()
+        if self.compute_dtype != "f32":
+            # 16-bit path: the image enters as DecomNet's 8-channel 16-bit input in one pass, DecomNet's last launch writes (R, L) in fp32 AND as
+            # RelightNet's 16-bit input, and the four NCHW outputs leave in one pass (ie_retinex_decom_input / ie_retinex_outputs_f32)
+            self.assert_datapoint(datapoint)
+            self._require_cuda()
+            x = datapoint.get("image")
+            x = x[None] if x.dim() == 3 else x
+            if x.dim() != 4 or x.shape[1] != self.in_channels:
+                raise ValueError(f"`image` must be (N,{self.in_channels},H,W), but got {tuple(x.shape)}.")
+            rl, rl16 = self.decom(ops.retinex_decom_input(x.to(self.device, torch.float32), self._tdt), copy16=True)
+            i_delta = self.relight(rl16)
+            out["reflectance"], out["illumination"], s = ops.retinex_outputs(rl, i_delta)
+            out["illumination_delta"] = i_delta.contiguous()                        # (N,1,H,W): NHWC and NCHW are the same bytes
+            out["enhanced"] = s
+            return out
         x = self._input(datapoint)
-        rl = self.decom(x)                                                         # fp32, 4 channels (both paths)
-        i_delta = self.relight(rl if self.compute_dtype == "f32" else ops.cast(rl, self._tdt, 8))
+        rl = self.decom(x)
+        i_delta = self.relight(rl)
         rl_nchw = ops.to_nchw(rl)
         s = ops.mul_prefix(rl, i_delta)
-        out = OrderedDict()
         out["reflectance"] = rl_nchw[:, 0:3]
         out["illumination"] = rl_nchw[:, 3:4]
         out["illumination_delta"] = ops.to_nchw(i_delta)

@@ -953,6 +953,64 @@ def mconv2d_pair(x, mwa: MConvWeights, mwb: MConvWeights, pad_mode="zeros"):
     return out
 
 
+def mconv2d_pair_thin_applicable(x, mwa: MConvWeights, mwb: MConvWeights, pad_mode="zeros", act_a="relu", act_b="none") -> bool:
+    """Can ``act_b(conv_b(relu(conv_a(x))))`` with a thin conv_b (4 .. 16 output channels, fp32 output) run as ONE launch?"""
+    if not isinstance(x, torch.Tensor) or x.dim() != 4 or mwa.dtype != mwb.dtype or x.dtype != mwa.dtype:
+        return False
+    if mwa.split != [int(x.shape[1])] or mwb.split != [mwa.cout] or getattr(mwa, "shuffle", 0) or getattr(mwb, "shuffle", 0):
+        return False
+    if (mwa.kh, mwa.kw, mwb.kh, mwb.kw) != (3, 3, 3, 3):
+        return False
+    return bool(capi.lib().ie_mconv_pair_thin_applicable(int(x.shape[1]), mwa.cout, mwb.cout, 3, 3, 1, 1, capi.PAD[pad_mode], capi.ACT[act_a], capi.ACT[act_b],
+                                                         int(x.shape[3])))
+
+
+def mconv2d_pair_thin(x, mwa: MConvWeights, mwb: MConvWeights, pad_mode="zeros", act_b="none", copy16=False):
+    """``act_b(conv_b(relu(conv_a(x))))`` in one launch (ie_mconv_pair_thin_nhwc): conv_b has 4 .. 16 output channels and leaves in fp32.
+    ``copy16=True`` (4 output channels only) also returns the output as the compute dtype padded to 8 channels (what the next 16-bit
+    network reads), written by the same launch: ``(out_f32, out16)``."""
+    _chk16(x)
+    if not mconv2d_pair_thin_applicable(x, mwa, mwb, pad_mode, "relu", act_b):
+        raise capi.IEError("mconv2d_pair_thin: Conv3x3(64,64)+ReLU then Conv3x3(64, 4..16) on a 16-bit NHWC tensor with W >= 64")
+    n, c, h, w = (int(v) for v in x.shape)
+    out = torch.empty((n, mwb.cout, h, w), device=x.device, dtype=torch.float32, memory_format=CL)
+    out16 = torch.empty((n, 8, h, w), device=x.device, dtype=x.dtype, memory_format=CL) if copy16 else None
+    _count_macs(n, h, w, mwa.cout, c, 3, 3)
+    _count_macs(n, h, w, mwb.cout, mwa.cout, 3, 3)
+    with torch.cuda.device(x.device):
+        capi.check(capi.lib().ie_mconv_pair_thin_nhwc(capi.ptr(x), capi.ptr(mwa.w), capi.ptr(mwa.b), capi.ptr(mwb.w), capi.ptr(mwb.b), capi.ptr(out),
+                                                      capi.ptr(out16) if copy16 else None, IE_DT[x.dtype], n, h, w, mwb.cout, capi.ACT[act_b],
+                                                      capi.PAD[pad_mode], capi.current_stream()), "ie_mconv_pair_thin_nhwc")
+    return (out, out16) if copy16 else out
+
+
+def retinex_decom_input(x_nchw: torch.Tensor, dtype) -> torch.Tensor:
+    """fp32 NCHW RGB -> ``cat(max_c(x), x)`` as 16-bit NHWC padded to 8 channels, one pass (RetinexNet DecomNet's input, model.py:45-46)."""
+    if x_nchw.dim() != 4 or x_nchw.shape[1] != 3 or x_nchw.dtype != torch.float32 or not x_nchw.is_cuda:
+        raise ValueError("retinex_decom_input: (N,3,H,W) fp32 CUDA tensor")
+    x_nchw = x_nchw.contiguous()
+    n, _, h, w = (int(v) for v in x_nchw.shape)
+    y = torch.empty((n, 8, h, w), device=x_nchw.device, dtype=dtype, memory_format=CL)
+    with torch.cuda.device(x_nchw.device):
+        capi.check(capi.lib().ie_retinex_decom_input(capi.ptr(x_nchw), capi.ptr(y), IE_DT[dtype], n, h, w, capi.current_stream()), "ie_retinex_decom_input")
+    return y
+
+
+def retinex_outputs(rl, i_delta):
+    """DecomNet's (R, L) (fp32 NHWC, 4 channels) and I_delta (fp32, 1 channel) -> NCHW fp32 ``(R, L, S = R * I_delta)`` in one pass."""
+    _chk(rl); _chk(i_delta)
+    n, c, h, w = (int(v) for v in rl.shape)
+    if c != 4 or tuple(i_delta.shape) != (n, 1, h, w):
+        raise ValueError("retinex_outputs: rl (N,4,H,W) and i_delta (N,1,H,W), fp32 NHWC")
+    R = torch.empty((n, 3, h, w), device=rl.device, dtype=torch.float32)
+    L = torch.empty((n, 1, h, w), device=rl.device, dtype=torch.float32)
+    S = torch.empty((n, 3, h, w), device=rl.device, dtype=torch.float32)
+    with torch.cuda.device(rl.device):
+        capi.check(capi.lib().ie_retinex_outputs_f32(capi.ptr(rl), capi.ptr(i_delta), capi.ptr(R), capi.ptr(L), capi.ptr(S), n, h, w, capi.current_stream()),
+                   "ie_retinex_outputs_f32")
+    return R, L, S
+
+
 class MConvWeightsDev:
     """Packed weights for ie_mconv_nhwc produced ON THE DEVICE from the trainer's HWIO fp32 master weights (``repack()`` after every
     optimiser step).  ``mode="forward"``: the conv over sources ``split``; ``mode="dgrad"``: the data-gradient conv of source

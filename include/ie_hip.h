@@ -216,6 +216,13 @@ int ie_mconv_tail_nhwc(ie_mconv_desc* d, const void* const* srcs_dev, const int*
 int ie_mconv_pair_applicable(int cin, int cmid, int cout, int kh, int kw, int stride, int pad, int pad_mode, int act_a, int act_b, int W);
 int ie_mconv_pair_nhwc(const void* src_dev, const void* packed_w_a_dev, const float* bias_a_dev, const void* packed_w_b_dev, const float* bias_b_dev,
                        void* dst_dev, int dtype, int N, int H, int W, int pad_mode, void* stream);
+/* The same with a THIN second layer: Conv3x3(C -> C) + ReLU, then Conv3x3(C -> cout_b) + act_b, cout_b in {4, 8, 12, 16}, act_b in none / relu / sigmoid /
+ * tanh -- the end of a plain conv stack (reference: DecomNet's last `net1_convs` layer + `net1_recon` + sigmoid, retinexnet/model.py:33-36,52-56).
+ * dst_f32: fp32 NHWC with cout_b channels.  dst16_8ch_dev: null, or a second copy of the output as dtype NHWC padded to 8 channels (cout_b == 4 only) -- what
+ * the next 16-bit network reads (RelightNet's input), written by the same launch.  fp32 accumulation; agrees with ie_mconv_nhwc x 2 to fp32 rounding. */
+int ie_mconv_pair_thin_applicable(int cin, int cmid, int cout, int kh, int kw, int stride, int pad, int pad_mode, int act_a, int act_b, int W);
+int ie_mconv_pair_thin_nhwc(const void* src_dev, const void* packed_w_a_dev, const float* bias_a_dev, const void* packed_w_b_dev, const float* bias_b_dev,
+                            float* dst_f32_dev, void* dst16_8ch_dev, int dtype, int N, int H, int W, int cout_b, int act_b, int pad_mode, void* stream);
 
 /* ---- 16-bit (IE_F16 / IE_BF16) NHWC streaming ops between the matrix-core convolutions; IE_F32 forwards to the *_f32
  * entry points above.  On the 16-bit path channel counts are multiples of 8 (a thread moves 8 channels = 16 bytes). */
@@ -352,6 +359,12 @@ int ie_paste_nhwc(const void* src_dev, void* dst_dev, int dtype, int N, int H, i
  *   recon    mean |R * I - T|                      (model.py:216-221: recon_loss_*, recon_loss_mutal_*, relight_loss)
  *   l1_detached  mean |A - B|, gradient to A only  (model.py:220: equal_R_loss against R_high.detach())
  *   smooth   mean over the (H+1) x (W+1) grid of |gx I| exp(-10 avg3x3 |gx gray(R)|) + the same along y   (model.py:240-260) */
+/* RetinexNet's inference ends as single passes.  decom_input: fp32 NCHW RGB -> DecomNet's input cat(max_c(x), x) (model.py:45-46) as dtype (IE_F16 /
+ * IE_BF16) NHWC padded to 8 channels.  outputs: rl = DecomNet's (R, L) output, fp32 pixel-major 4 floats, i_delta fp32 one float per pixel ->
+ * R (N,3,H,W), L (N,1,H,W) (either may be NULL) and S = R * I_delta (N,3,H,W) (model.py:72-74, 229-231), NCHW fp32. */
+int ie_retinex_decom_input(const float* x_nchw_dev, void* dst_nhwc8_dev, int dtype, int N, int H, int W, void* stream);
+int ie_retinex_outputs_f32(const float* rl_nhwc4_dev, const float* i_delta_dev, float* R_nchw_dev, float* L_nchw_dev, float* S_nchw_dev, int N, int H, int W,
+                           void* stream);
 int ie_retinex_recon_f32(const float* R_dev, int r_stride, const float* I_dev, int i_stride, const float* T_dev, float weight, float* dR_dev,
                          float* dI_dev, double* loss_dev, int N, int H, int W, void* stream);
 int ie_l1_detached_f32(const float* A_dev, const float* B_dev, int stride, int C, float weight, float* dA_dev, double* loss_dev, size_t npx, void* stream);

@@ -142,6 +142,42 @@ def test_two_stacked_convs_in_one_launch(shape, pad_mode, dt):
 
 
 @pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("pad_mode", ["zeros", "replicate"])
+@pytest.mark.parametrize("cout,act", [(4, "sigmoid"), (8, "none"), (16, "tanh"), (12, "relu")])
+@pytest.mark.parametrize("shape", [(2, 37, 150), (1, 200, 64), (3, 6, 129), (2, 1, 66), (1, 2, 253), (1, 131, 126)], ids=lambda s: "x".join(map(str, s)))
+def test_stacked_conv_with_thin_second_layer(shape, cout, act, pad_mode, dt):
+    """ie_mconv_pair_thin_nhwc (DecomNet's last Conv3x3(64, 64) + ReLU and `net1_recon` Conv3x3(64, 4) + sigmoid, retinexnet/model.py:33-36,52-56) in one
+    launch: the fp32 output equals two ie_mconv_nhwc calls to fp32 rounding (same 16-bit intermediate, fp32 accumulation in another order), the optional
+    16-bit 8-channel copy is that output rounded once."""
+    tdt = ops.TORCH_DT[dt]
+    n, h, w = shape
+    g = torch.Generator().manual_seed(37)
+    x = torch.randn(n, 64, h, w, generator=g).to(tdt).cuda().contiguous(memory_format=CL)
+    wa = (torch.randn(64, 64, 3, 3, generator=g) / 24.0).to(tdt).float()
+    wb = (torch.randn(cout, 64, 3, 3, generator=g) / 24.0).to(tdt).float()
+    mwa = ops.MConvWeights(wa, torch.randn(64, generator=g) * 0.2, [64], tdt, "cuda")
+    mwb = ops.MConvWeights(wb, torch.randn(cout, generator=g) * 0.2, [64], tdt, "cuda")
+    assert ops.mconv2d_pair_thin_applicable(x, mwa, mwb, pad_mode=pad_mode, act_b=act)
+    copy16 = cout == 4
+    got = ops.mconv2d_pair_thin(x, mwa, mwb, pad_mode=pad_mode, act_b=act, copy16=copy16)
+    got, got16 = got if copy16 else (got, None)
+    mid = ops.mconv2d(x, mwa, pad_mode=pad_mode, act="relu")
+    want = ops.mconv2d(mid, mwb, pad_mode=pad_mode, act=act, out_f32=True)
+    assert tuple(got.shape) == (n, cout, h, w) and got.dtype == torch.float32 and got.is_contiguous(memory_format=CL)
+    assert rel_err(got.cpu(), want.cpu()) <= 2e-6
+    if copy16:
+        assert tuple(got16.shape) == (n, 8, h, w) and got16.dtype == tdt
+        assert torch.equal(got16[:, :cout].float(), got.to(tdt).float()) and not got16[:, cout:].any()
+    # against torch on the same 16-bit-rounded intermediate
+    pm = "replicate" if pad_mode == "replicate" else "constant"
+    cv = lambda t, w_, b_: F.conv2d(F.pad(t, (1, 1, 1, 1), mode=pm), w_, b_)
+    ref = cv(F.relu(cv(x.float().cpu(), wa, mwa.b.cpu())).to(tdt).float(), wb, mwb.b.cpu())
+    ref = {"sigmoid": torch.sigmoid, "tanh": torch.tanh, "relu": F.relu, "none": lambda t: t}[act](ref)
+    assert rel_err(got.cpu(), ref) <= (3e-3 if dt == "f16" else 2e-2)
+    assert not ops.mconv2d_pair_thin_applicable(x, mwa, ops.MConvWeights(torch.randn(24, 64, 3, 3, generator=g), None, [64], tdt, "cuda"))
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
 @pytest.mark.parametrize("shape", [(2, 37, 150), (1, 200, 64), (3, 6, 129), (1, 270, 480), (2, 2, 66)], ids=lambda s: "x".join(map(str, s)))
 @pytest.mark.parametrize("c", [32, 64])
 def test_first_double_conv_with_pool(c, dt, shape):

@@ -6,7 +6,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from mon_amd import capi, image
+from mon_amd import capi, image, ops
 from oracle import c_oracle
 from tests.helpers import rel_err
 
@@ -159,3 +159,21 @@ def test_conv_f32_large_tiles(co, cs):
     ref = F.relu(F.conv2d(torch.cat(xs, 1), w, b, padding=1))
     out = ops.conv2d([ops.to_nhwc(x.cuda()) for x in xs], ops.ConvWeights(w, b, "cuda"), act="relu")
     assert rel_err(ops.to_nchw(out).cpu(), ref) <= 2e-5
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+def test_retinex_single_pass_ends(dt):
+    """ie_retinex_decom_input == cat(max_c(x), x) rounded once to 16 bits, padded to 8 channels (retinexnet/model.py:45-46);
+    ie_retinex_outputs_f32 == (R, L, R * I_delta) as NCHW fp32, bit for bit (model.py:72-74, 229-231)."""
+    tdt = ops.TORCH_DT[dt]
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(2, 3, 19, 37, generator=g)
+    y = ops.retinex_decom_input(x.cuda(), tdt)
+    want = torch.cat([x.max(1, keepdim=True)[0], x, torch.zeros(2, 4, 19, 37)], 1).to(tdt)
+    assert tuple(y.shape) == (2, 8, 19, 37) and y.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(y.cpu().float(), want.float())
+    rl = torch.rand(2, 4, 19, 37, generator=g)
+    idl = torch.rand(2, 1, 19, 37, generator=g) * 3
+    R, L, S = ops.retinex_outputs(ops.to_nhwc(rl.cuda()), ops.to_nhwc(idl.cuda()))
+    assert R.is_contiguous() and L.is_contiguous() and S.is_contiguous()
+    assert torch.equal(R.cpu(), rl[:, :3]) and torch.equal(L.cpu(), rl[:, 3:]) and torch.equal(S.cpu(), rl[:, :3] * idl)
