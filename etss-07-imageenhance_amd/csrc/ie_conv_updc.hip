@@ -1,0 +1,363 @@
+// The last decoder level of a 32-channel U-Net in ONE launch (unet.py:75-112, 186-195): cat([skip, up]) -> Conv3x3(64 -> 32) + BN + ReLU -> Conv3x3(32 -> 32) + BN
+// + ReLU -> Conv1x1(32 -> classes) (+ clamp) -> NCHW fp32.  With `bilinear` the x2 up-sampling (align_corners=True, unet.py:82-83) happens inside as well: the
+// kernel reads the HALF-resolution tensor and the full-resolution `up` tensor never exists.
+//
+// Why: at 1080p this level is HBM-bound as separate launches -- resize (16 B/px read, 64 written), conv1 (128 read, 64 written: 4.9 TB/s measured), conv2 + head
+// (64 read, 12 written): 348 bytes per pixel for 55 kFLOP.  Fused it moves 64 + 16 + 12 = 92 and is bound by the matrix pipe.
+//
+// Structure = ie_conv_pair.hip at 32 channels: 8 waves = 2 stages x (2 output-channel fragments x 2 halves of the strip's 8 pixel tiles); weights in registers for
+// the whole launch (stage A 18 fragments: 2 K chunks [skip, up] x 9 taps; stage B 9); stage A marches down the strip on rows of an LDS ring, three rotating
+// accumulator sets (ky = 0, 1, 2), and hands each finished row of the intermediate (ReLU, 16 bits) to stage B through a second ring; stage B parks its finished
+// rows as whole pixel lines, and the 1x1 head contracts a parked row one step later (the parked row is the MFMA's A operand, so a lane ends up holding four
+// consecutive pixels of one output plane).  One s_barrier per step.  126 of the strip's 128 computed columns are stored.
+//
+// The skip chunk of the ring arrives by LDS-DMA (stage A's waves).  The up chunk: by LDS-DMA too (up given at full resolution), or, with `bilinear`, written by
+// stage B's waves -- they have half of stage A's MFMA work -- from a small ring of half-resolution rows (their own LDS-DMA): every 16-byte piece of the ring row
+// (8 channels of one pixel) is a weighted sum of four half-resolution pieces with fp32 weights and one rounding (v_fma_mix).
+#include "ie_conv_internal.h"
+#include <stdlib.h>
+#include <string.h>
+#include <type_traits>
+
+namespace {
+
+constexpr int TW = 128, TS = 126, ROW_PX = TW + 4;      // 128 body pixels, the two halo pixels, two spare ones (one 4-byte-per-lane DMA covers the four)
+constexpr int PXB = 64;                       // one pixel of a 32-channel 16-bit tensor = one K chunk of a pixel
+constexpr int CH_ROW_B = ROW_PX * PXB;        // 8,448
+constexpr int SLOT_A = 2 * CH_ROW_B;          // stage A's ring row: skip chunk, up chunk
+constexpr unsigned OOB = 0x80000000u;
+constexpr int PF = 3, NRA = PF + 1, NRH = 3;
+constexpr int PARK_B = TW * PXB;              // 8,192
+constexpr int LOW_PX = 80, LOW_ROW_B = LOW_PX * PXB, NRL = 4;      // half-resolution staging: five 1 KiB DMA pieces per row, four rows
+constexpr int OFF_H = NRA * SLOT_A;                     //  67,584
+constexpr int OFF_PARK = OFF_H + NRH * CH_ROW_B;        //  92,928
+constexpr int OFF_LOW = OFF_PARK + 2 * PARK_B;          // 109,312
+constexpr int OFF_DUMMY = OFF_LOW + NRL * LOW_ROW_B;    // 129,792: 16 bytes per lane of one wave for the masked-off lanes of the halo pieces
+constexpr int LDS_B = OFF_DUMMY + 1024;                 // 130,816
+
+struct UpdcParams {
+    const void* skip; const void* up; const void* wa; const float* ba; const void* wb; const float* bb; const void* tail_w; const float* tail_b; float* dst;
+    int N, H, W, h, w, rows_per_block, strips, chunks, tail_c, tail_clamp;
+    float lo, hi, sy, sx;
+};
+
+__device__ __forceinline__ void wait_vm_cold(int n) {
+    switch (n) {
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+template <typename T, bool BILIN>
+__device__ __forceinline__ void updc_body(const UpdcParams& p) {
+    using frag = ie_u32x4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p16 = lane & 15, kq = lane >> 4;
+    const int stg = wave >> 2, w4 = wave & 3, cf = w4 & 1, hf = w4 >> 1;      // stage; 16-cout fragment; half of the strip (pixel tiles 4 hf .. 4 hf + 3)
+
+    int b = blockIdx.x;
+    const int strip = b % p.strips; b /= p.strips;
+    const int chunk = b % p.chunks; b /= p.chunks;
+    const int n = b;
+    const int xc0 = strip * TS - 1;                   // image column of computed column 0
+    const int H = p.H, W = p.W;
+    const int ys = chunk * p.rows_per_block, ye = min(ys + p.rows_per_block, H);
+    const int n_steps = (ye - ys) + 8;
+
+    auto mk = [&](const void* base, size_t bytes) __attribute__((always_inline)) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+    };
+    const size_t frame_b = (size_t)H * W * PXB;
+    const size_t up_frame_b = BILIN ? (size_t)p.h * p.w * PXB : frame_b;
+    const auto rsS = mk((const char*)p.skip + (size_t)n * frame_b, frame_b);
+    const auto rsU = mk((const char*)p.up + (size_t)n * up_frame_b, up_frame_b);
+    const size_t dst_b = (size_t)p.tail_c * H * W * 4;
+    const auto rsD = mk((char*)p.dst + (size_t)n * dst_b, dst_b);
+
+    // ---- this wave's weight fragments (stage A: 2 chunks x 9 taps, stage B: 9 taps) and 4 biases; images of ie_mconv_pack_weights (Cout 32: 32 rows per tap) ----
+    frag wv[18];
+    {
+        const char* wp = (const char*)(stg ? p.wb : p.wa);
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+                wv[c * 9 + t] = (stg && c) ? frag{0u, 0u, 0u, 0u} : *(const frag*)(wp + ((size_t)(c * 9 + t) * 32 + cf * 16 + p16) * 64 + ((kq ^ ((p16 >> 1) & 3)) << 4));
+    }
+    ie_f32x4 bias4;
+    {
+        const float* bp = stg ? p.bb : p.ba;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bias4[i] = bp ? bp[16 * cf + 4 * kq + i] : 0.f;
+    }
+
+    // ---- stage A: LDS-DMA of the input rows.  Piece m = 16 pixels x 64 B of one chunk; position (lane & 3) of ring pixel q holds channel piece
+    //      (lane & 3) ^ ((q >> 1) & 3).  Wave w4 loads pieces 2 w4, 2 w4 + 1 of the skip chunk (and of the up chunk when it comes at full resolution); wave 3 also
+    //      the halo pixels (ring pixels 128, 129) as ONE 4-byte-per-lane DMA with every lane active (see ie_conv_pair.hip for why not `if (lane < 8)`).
+    unsigned body_off[2], halo_off;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int q = (2 * w4 + j) * 16 + (lane >> 2);
+        const int x = xc0 + q;
+        body_off[j] = (x >= 0 && x < W) ? (unsigned)(x * PXB + (((lane & 3) ^ ((q >> 1) & 3)) << 4)) : OOB;
+    }
+    {
+        const int hp = lane >> 4;
+        const int x = hp == 0 ? (xc0 - 1) : (xc0 + TW);
+        halo_off = (hp < 2 && x >= 0 && x < W) ? (unsigned)(x * PXB + (lane & 15) * 4) : OOB;
+    }
+    auto issue = [&](int t) __attribute__((always_inline)) {        // input row of stage A's step t
+        const int yi = ys - 2 + t;
+        const unsigned rmask = (yi >= 0 && yi < H) ? 0u : OOB;
+        const unsigned row_b = rmask ? 0u : (unsigned)yi * (unsigned)W * PXB;
+        char* slot = smem + (t % NRA) * SLOT_A;
+#pragma unroll
+        for (int c = 0; c < (BILIN ? 1 : 2); ++c) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (c == 0)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsS, (__attribute__((address_space(3))) void*)(slot + (2 * w4 + j) * 1024), 16,
+                                                             (int)((row_b + body_off[j]) | rmask), 0, 0, 0);
+                else
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsU, (__attribute__((address_space(3))) void*)(slot + CH_ROW_B + (2 * w4 + j) * 1024), 16,
+                                                             (int)((row_b + body_off[j]) | rmask), 0, 0, 0);
+            }
+            if (w4 == 3) {        // wave-uniform
+                if (c == 0)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsS, (__attribute__((address_space(3))) void*)(slot + TW * PXB), 4, (int)((row_b + halo_off) | rmask), 0, 0, 0);
+                else
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsU, (__attribute__((address_space(3))) void*)(slot + CH_ROW_B + TW * PXB), 4,
+                                                             (int)((row_b + halo_off) | rmask), 0, 0, 0);
+            }
+        }
+    };
+    constexpr int NSRC_DMA = BILIN ? 1 : 2;
+
+    // ---- fragment read offsets: lane (p16, kq) of the wave's tile j at tap column kx reads chunk piece kq of ring pixel 16 (4 hf + j) + p16 + kx - 1.  The swizzle
+    //      term repeats every 8 pixels, so tile j's offset is tile 1's + 1024 (j - 1) -- an immediate -- except: tile 0 (its own registers: pixel -1 of the strip is
+    //      the halo pixel 128) and the last tile at kx = 2 (pixel 128 of the strip is the halo pixel 129).  Stage B reads the intermediate, which has no halo
+    //      columns: its outermost columns are dropped, those reads only have to stay inside the row.
+    auto lds_px = [&](int q) __attribute__((always_inline)) { return q * PXB + ((kq ^ ((q >> 1) & 3)) << 4); };
+    int rd1[3], rd0[3], rd23;
+    {
+        auto fix = [&](int q) __attribute__((always_inline)) {
+            if (stg == 0) return q < 0 ? TW : (q >= TW ? TW + 1 : q);
+            return min(max(q, 0), TW - 1);
+        };
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            rd1[kx] = lds_px(16 * (4 * hf + 1) + p16 + kx - 1);
+            rd0[kx] = lds_px(fix(16 * (4 * hf) + p16 + kx - 1));
+        }
+        rd23 = lds_px(fix(16 * (4 * hf + 3) + p16 + 1));
+    }
+    // one row into the three live accumulator sets (ky = 0: the set this row starts takes the bias as its first C operand); NCK K chunks.
+    // The order is pinned, fragment reads three ahead of their MFMAs (ie_conv_pair.hip: left alone the scheduler waits lgkmcnt(0) behind every read).
+    auto row_mfma = [&](const char* slot, auto nck_tag, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4]) __attribute__((always_inline)) {
+        constexpr int NCK = decltype(nck_tag)::value, NG = NCK * 12;
+        frag bx[4];
+        auto rdf = [&](int g) __attribute__((always_inline)) {         // g = (chunk, kx, tile), compile-time at every call
+            const int c = g / 12, kx = (g % 12) >> 2, j = g & 3;
+            const int off = j == 0 ? rd0[kx] : ((kx == 2 && j == 3) ? rd23 : rd1[kx] + 1024 * (j - 1));
+            bx[g & 3] = *(const frag*)(slot + c * CH_ROW_B + off);
+        };
+        rdf(0); rdf(1); rdf(2);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int c = g / 12, kx = (g % 12) >> 2, j = g & 3;
+            if (g + 3 < NG) rdf(g + 3);
+            accN[j] = ie_mfma16_raw<T>(wv[c * 9 + 0 * 3 + kx], bx[g & 3], (c == 0 && kx == 0) ? bias4 : accN[j]);
+            accM[j] = ie_mfma16_raw<T>(wv[c * 9 + 1 * 3 + kx], bx[g & 3], accM[j]);
+            accO[j] = ie_mfma16_raw<T>(wv[c * 9 + 2 * 3 + kx], bx[g & 3], accO[j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    using two = std::integral_constant<int, 2>;
+    using one = std::integral_constant<int, 1>;
+
+    // ---- epilogues: tile pair jj (the wave's tiles 2 jj, 2 jj + 1) of a finished row as 16-byte pieces (lanes l / l + 16 exchange halves): after the exchange
+    //      even kq -> tile 2 jj, odd kq -> tile 2 jj + 1; the lane holds couts 16 cf + 8 (kq >> 1) .. + 7 of ONE pixel = channel piece 2 cf + (kq >> 1)
+    int em_off;                    // pair 0; pair 1 is 32 pixels on (the swizzle repeats every 8 pixels)
+    unsigned em_in = 0;            // bit jj: the lane's pixel of pair jj is inside the image
+    {
+        const int q = 16 * (4 * hf + (kq & 1)) + p16;
+        em_off = q * PXB + (((2 * cf + (kq >> 1)) ^ ((q >> 1) & 3)) << 4);
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int x = xc0 + q + 32 * jj;
+            em_in |= (x >= 0 && x < W) ? (1u << jj) : 0u;
+        }
+    }
+    auto put_row = [&](const ie_f32x4 (&acc)[4], char* base, unsigned keep) __attribute__((always_inline)) {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const ie_u32x2 a = {ie_pack2_relu<T>(acc[2 * jj][0], acc[2 * jj][1]), ie_pack2_relu<T>(acc[2 * jj][2], acc[2 * jj][3])};
+            const ie_u32x2 b2 = {ie_pack2_relu<T>(acc[2 * jj + 1][0], acc[2 * jj + 1][1]), ie_pack2_relu<T>(acc[2 * jj + 1][2], acc[2 * jj + 1][3])};
+            const auto sx = __builtin_amdgcn_permlane16_swap(a[0], b2[0], false, false);
+            const auto sy = __builtin_amdgcn_permlane16_swap(a[1], b2[1], false, false);
+            const bool k = (keep >> jj) & 1u;
+            *(ie_u32x4*)(base + em_off + jj * 32 * PXB) = ie_u32x4{k ? sx[0] : 0u, k ? sy[0] : 0u, k ? sx[1] : 0u, k ? sy[1] : 0u};
+        }
+    };
+
+    ie_f32x4 a0[4], a1[4], a2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { a0[j] = bias4; a1[j] = bias4; a2[j] = bias4; }
+
+    if (stg == 0) {
+        // Stage A, step t: input row ys - 2 + t; the intermediate's row m = ys - 3 + t is finished (accO) and written into hand-off slot t % NRH.  Rows and columns
+        // of the intermediate outside the image are layer b's zero padding: written as zeros.
+#pragma unroll
+        for (int t = 0; t < PF; ++t) issue(t);
+        auto step_a = [&](int t, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4]) __attribute__((always_inline)) {
+            if (w4 == 3) ie_wait_vm_imm<(PF - 1) * 3 * NSRC_DMA>();
+            else ie_wait_vm_imm<(PF - 1) * 2 * NSRC_DMA>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            row_mfma(smem + (t % NRA) * SLOT_A, two{}, accN, accM, accO);
+            issue(t + PF);
+            const int m = ys - 3 + t;
+            put_row(accO, smem + OFF_H + (t % NRH) * CH_ROW_B, (m >= 0 && m < H) ? em_in : 0u);
+        };
+        for (int t = 0; t < n_steps; t += 3) {
+            step_a(t, a0, a1, a2);
+            if (t + 1 < n_steps) step_a(t + 1, a2, a0, a1);
+            if (t + 2 < n_steps) step_a(t + 2, a1, a2, a0);
+        }
+    } else {
+        // Stage B, step t: consumes the intermediate's row ys - 5 + t (stage A's step t - 2), finishing layer b's row ys - 6 + t; accN still holds the row finished at
+        // step t - 1 (parked now), and the row parked at step t - 1 (ys - 8 + t) goes through the 1x1 head and leaves.
+        // head: tiles 2 w4, 2 w4 + 1 of the parked row; A operand = the row (lane = pixel p16, channels 8 kq ..), B operand = the 1x1 weights [16][32] (lane = output
+        // channel p16); D: lane (p16 = output channel, kq) holds pixels 4 kq .. 4 kq + 3 of the tile
+        const frag tW = *(const frag*)((const char*)p.tail_w + p16 * PXB + kq * 16);
+        const float tl_bias = p.tail_b[p16];
+        int tl_lds[2];
+        unsigned tl_col[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int q = 16 * (2 * w4 + t) + p16;
+            tl_lds[t] = q * PXB + ((kq ^ ((q >> 1) & 3)) << 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int qo = 16 * (2 * w4 + t) + 4 * kq + i, xo = xc0 + qo;
+                tl_col[t][i] = (p16 < p.tail_c && qo >= 1 && qo <= TS && xo < W) ? (unsigned)((p16 * H * W + xo) * 4) : OOB;
+            }
+        }
+        // park: the same 16-byte pieces as the hand-off rows, pixel line = 64 bytes
+        int pk_off;
+        {
+            const int q = 16 * (4 * hf + (kq & 1)) + p16;
+            pk_off = q * PXB + (((2 * cf + (kq >> 1)) ^ ((q >> 1) & 3)) << 4);
+        }
+        auto park_row = [&](const ie_f32x4 (&acc)[4], char* base) __attribute__((always_inline)) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const ie_u32x2 a = {ie_pack2_relu<T>(acc[2 * jj][0], acc[2 * jj][1]), ie_pack2_relu<T>(acc[2 * jj][2], acc[2 * jj][3])};
+                const ie_u32x2 b2 = {ie_pack2_relu<T>(acc[2 * jj + 1][0], acc[2 * jj + 1][1]), ie_pack2_relu<T>(acc[2 * jj + 1][2], acc[2 * jj + 1][3])};
+                const auto sx = __builtin_amdgcn_permlane16_swap(a[0], b2[0], false, false);
+                const auto sy = __builtin_amdgcn_permlane16_swap(a[1], b2[1], false, false);
+                *(ie_u32x4*)(base + pk_off + jj * 32 * PXB) = ie_u32x4{sx[0], sy[0], sx[1], sy[1]};
+            }
+        };
+        auto step_b = [&](int t, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4]) __attribute__((always_inline)) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const int yo = ys - 8 + t;
+            const unsigned rmask = (yo >= ys && yo < ye) ? 0u : OOB;
+            const unsigned trow_b = rmask ? 0u : (unsigned)yo * (unsigned)W * 4u;
+            const char* islot = smem + OFF_PARK + ((t + 1) & 1) * PARK_B;
+            frag ta[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) ta[i] = *(const frag*)(islot + tl_lds[i]);
+            park_row(accN, smem + OFF_PARK + (t & 1) * PARK_B);
+            row_mfma(smem + OFF_H + ((t + 1) % NRH) * CH_ROW_B, one{}, accN, accM, accO);       // stage A's step t - 2 wrote slot (t - 2) % NRH == (t + 1) % NRH
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ie_f32x4 o = {tl_bias, tl_bias, tl_bias, tl_bias};
+                o = ie_mfma16_raw<T>(ta[i], tW, o);
+                if (p.tail_clamp) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = fminf(fmaxf(o[e], p.lo), p.hi);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float oe = o[e];       // (__builtin_bit_cast straight on the vector ELEMENT o[e] compiled to element 0 four times: hipcc 7.2)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, oe), rsD, (int)((trow_b + tl_col[i][e]) | rmask), 0, 0);
+                }
+            }
+        };
+        for (int t = 0; t < n_steps; t += 3) {
+            step_b(t, a0, a1, a2);
+            if (t + 1 < n_steps) step_b(t + 1, a2, a0, a1);
+            if (t + 2 < n_steps) step_b(t + 2, a1, a2, a0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+__global__ __launch_bounds__(512) void unet_updc32_head_f16(UpdcParams p) { updc_body<_Float16, false>(p); }
+__global__ __launch_bounds__(512) void unet_updc32_head_bf16(UpdcParams p) { updc_body<__bf16, false>(p); }
+
+}  // namespace
+
+// ---- C ABI -------------------------------------------------------------------------------------------------------------------------------
+IE_EXPORT int ie_unet_up_head_applicable(int C, int tail_cout, int H, int W, int up_h, int up_w) {
+    static const int off = getenv("IE_UNET_UPHEAD") ? !atoi(getenv("IE_UNET_UPHEAD")) : 0;       // IE_UNET_UPHEAD=0: A/B switch back to separate launches
+    if (off || C != 32 || tail_cout < 1 || tail_cout > 16 || H < 1 || W < 64 || (double)H * W * 64.0 >= 2147483647.0 || (double)H * W * tail_cout * 4.0 >= 2147483647.0)
+        return 0;
+    return (up_h == H && up_w == W) ? 1 : 0;
+}
+
+IE_EXPORT int ie_unet_up_head_nhwc(const void* skip, const void* up, int up_h, int up_w, const void* packed_w_a, const float* bias_a, const void* packed_w_b,
+                                   const float* bias_b, const void* tail_w, const float* tail_bias, int tail_cout, int clamp, float clamp_lo, float clamp_hi,
+                                   float* dst_nchw, int dtype, int N, int H, int W, void* stream) {
+    if (!skip || !up || !packed_w_a || !packed_w_b || !tail_w || !tail_bias || !dst_nchw || N <= 0) IE_FAIL(IE_ERR_INVALID, "ie_unet_up_head_nhwc: null pointer / bad batch");
+    if (dtype != IE_F16 && dtype != IE_BF16) IE_FAIL(IE_ERR_UNSUPPORTED, "ie_unet_up_head_nhwc: f16 / bf16");
+    if (!ie_unet_up_head_applicable(32, tail_cout, H, W, up_h, up_w))
+        IE_FAIL(IE_ERR_UNSUPPORTED, "ie_unet_up_head_nhwc: 32 channels, W >= 64, `up` at the skip's resolution -- ask ie_unet_up_head_applicable first");
+    UpdcParams p;
+    memset(&p, 0, sizeof(p));
+    p.skip = skip; p.up = up; p.wa = packed_w_a; p.ba = bias_a; p.wb = packed_w_b; p.bb = bias_b; p.tail_w = tail_w; p.tail_b = tail_bias; p.dst = dst_nchw;
+    p.N = N; p.H = H; p.W = W; p.h = up_h; p.w = up_w; p.tail_c = tail_cout; p.tail_clamp = clamp; p.lo = clamp_lo; p.hi = clamp_hi;
+    p.sy = H > 1 ? (float)(up_h - 1) / (float)(H - 1) : 0.f;
+    p.sx = W > 1 ? (float)(up_w - 1) / (float)(W - 1) : 0.f;
+    p.strips = ie_cdiv(W, TS);
+    {
+        // row chunks: whole rounds of the chip's 256 workgroup slots (one 8-wave workgroup per CU), few apron rows (8 steps per chunk)
+        const int slots = 256;
+        const long long base = (long long)p.strips * N;
+        int best_c = 1;
+        double best = -1.0;
+        for (int c = 1; c <= H && c <= 64; ++c) {
+            const int rpb = ie_cdiv(H, c), cc = ie_cdiv(H, rpb);
+            const long long blocks = base * cc;
+            const long long rounds = (blocks + slots - 1) / slots;
+            const double score = (double)blocks / (double)(rounds * slots) * ((double)rpb / (double)(rpb + 8));
+            if (score > best + 1e-9) { best = score; best_c = cc; }
+        }
+        p.rows_per_block = ie_cdiv(H, best_c);
+        p.chunks = ie_cdiv(H, p.rows_per_block);
+    }
+    const long long blocks = (long long)p.strips * p.chunks * N;
+    if (blocks <= 0 || blocks > 0x7fffffffLL) IE_FAIL(IE_ERR_INVALID, "ie_unet_up_head_nhwc: bad grid");
+    typedef void (*Fn)(UpdcParams);
+    const int fi = dtype == IE_F16 ? 0 : 1;
+    static const Fn fns[2] = {unet_updc32_head_f16, unet_updc32_head_bf16};
+    static bool granted[2] = {false, false};
+    if (!granted[fi]) {
+        hipError_t e = hipFuncSetAttribute((const void*)fns[fi], hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
+        if (e != hipSuccess) IE_FAIL(IE_ERR_HIP, "hipFuncSetAttribute(lds=%d): %s", LDS_B, hipGetErrorString(e));
+        granted[fi] = true;
+    }
+    void* args[] = {(void*)&p};
+    IE_HIP_CHECK(hipLaunchKernel((const void*)fns[fi], dim3((unsigned)blocks), dim3(512), args, LDS_B, (hipStream_t)stream));
+    return IE_OK;
+}

@@ -881,7 +881,31 @@ class UNet(_GraphModel):
         x = self._conv(x, f"{name}.conv2", f"{name}.norm2", act="relu")
         return ops.to_nchw(self._conv(x, "outc.conv", pad=0, clamp=clamp, out_f32=True))
 
+    def _up_head_fused(self, k, x1, x2, clamp):
+        """The last decoder level + ``outc`` as one launch (ie_unet_up_head_nhwc): DoubleConv over cat([skip, up]) and the 1x1 head; with the bilinear
+        upsampler and an exactly doubled size the x2 up-sampling happens inside too (``x1`` goes in at half resolution).  None where it does not apply."""
+        if self.compute_dtype == "f32" or self._params["outc.conv.weight"].shape[0] > 16:
+            return None
+        name = f"up{k}.conv"
+        c = int(x2.shape[1])
+        if int(x1.shape[1]) != c or tuple(self._params[f"{name}.conv1.weight"].shape[:2]) != (c, 2 * c):
+            return None
+        mwa = self._mw_plain((c, c), f"{name}.conv1", f"{name}.norm1")
+        mwb = self._mw_plain((c,), f"{name}.conv2", f"{name}.norm2")
+        tkey = ("mtail", "outc.conv")
+        if tkey not in self._dev_cache:
+            self._dev_cache[tkey] = ops.MTailWeights(self._params["outc.conv.weight"], self._params.get("outc.conv.bias"), self._tdt, self.device)
+        tw = self._dev_cache[tkey]
+        if not ops.unet_up_head_applicable(x2, x1, mwa, mwb, tw):
+            return None
+        return ops.unet_up_head(x2, x1, mwa, mwb, tw, clamp=clamp)
+
     def _up(self, k, x1, x2, head=False):
+        clamp = (0.0, 1.0) if self.enhance else None
+        if head and self.upsampler == "bilinear":         # half-resolution x1 straight into the fused level (where the kernel covers the in-kernel up-sampling)
+            y = self._up_head_fused(k, x1, x2, clamp)
+            if y is not None:
+                return y
         if self.upsampler == "bilinear":
             x1 = ops.upsample2x_bilinear(x1)
         elif self.upsampler == "convtranspose":
@@ -891,7 +915,10 @@ class UNet(_GraphModel):
         dy, dx = x2.shape[2] - x1.shape[2], x2.shape[3] - x1.shape[3]
         x1 = ops.pad(x1, dy // 2, dy - dy // 2, dx // 2, dx - dx // 2)
         if head:
-            return self._dc_head(f"up{k}.conv", [x2, x1], clamp=(0.0, 1.0) if self.enhance else None)
+            y = self._up_head_fused(k, x1, x2, clamp)
+            if y is not None:
+                return y
+            return self._dc_head(f"up{k}.conv", [x2, x1], clamp=clamp)
         return self._dc(f"up{k}.conv", [x2, x1])
 
     def forward(self, datapoint: dict, *args, **kwargs) -> dict:

@@ -984,6 +984,38 @@ def mconv2d_pair_thin(x, mwa: MConvWeights, mwb: MConvWeights, pad_mode="zeros",
     return (out, out16) if copy16 else out
 
 
+def unet_up_head_applicable(skip, up, mwa: MConvWeights, mwb: MConvWeights, tail: MTailWeights) -> bool:
+    """Can the last decoder level (cat -> DoubleConv -> 1x1 head) run as one launch (ie_unet_up_head_nhwc)?  ``up``: the skip's resolution or half of it."""
+    if skip.dim() != 4 or up.dim() != 4 or skip.dtype != up.dtype or skip.dtype != mwa.dtype or mwb.dtype != mwa.dtype or tail.dtype != mwa.dtype:
+        return False
+    c = int(skip.shape[1])
+    if int(up.shape[1]) != c or mwa.split != [c, c] or mwa.cout != c or mwb.split != [c] or mwb.cout != c or tail.cin != c:
+        return False
+    if (mwa.kh, mwa.kw, mwb.kh, mwb.kw) != (3, 3, 3, 3) or getattr(mwa, "shuffle", 0) or getattr(mwb, "shuffle", 0):
+        return False
+    return bool(capi.lib().ie_unet_up_head_applicable(c, tail.cout, int(skip.shape[2]), int(skip.shape[3]), int(up.shape[2]), int(up.shape[3])))
+
+
+def unet_up_head(skip, up, mwa: MConvWeights, mwb: MConvWeights, tail: MTailWeights, clamp=None):
+    """``conv1x1(relu(conv_b(relu(conv_a(cat([skip, up]))))))`` (+ clamp) -> NCHW fp32 in one launch; a half-resolution ``up`` is up-sampled x2
+    (bilinear, align_corners=True) inside the kernel."""
+    _chk16(skip); _chk16(up)
+    if not unet_up_head_applicable(skip, up, mwa, mwb, tail):
+        raise capi.IEError("unet_up_head: 32-channel 16-bit NHWC sources, W >= 64, `up` at the skip's resolution or exactly half of it")
+    n, c, h, w = (int(v) for v in skip.shape)
+    out = torch.empty((n, tail.cout, h, w), device=skip.device, dtype=torch.float32)
+    _count_macs(n, h, w, c, 2 * c, 3, 3)
+    _count_macs(n, h, w, c, c, 3, 3)
+    _count_macs(n, h, w, tail.cout, c, 1, 1)
+    lo, hi = clamp if clamp is not None else (0.0, 0.0)
+    with torch.cuda.device(skip.device):
+        capi.check(capi.lib().ie_unet_up_head_nhwc(capi.ptr(skip), capi.ptr(up), int(up.shape[2]), int(up.shape[3]), capi.ptr(mwa.w), capi.ptr(mwa.b),
+                                                   capi.ptr(mwb.w), capi.ptr(mwb.b), capi.ptr(tail.w), capi.ptr(tail.b), tail.cout, int(clamp is not None),
+                                                   float(lo), float(hi), capi.ptr(out), IE_DT[skip.dtype], n, h, w, capi.current_stream()),
+                   "ie_unet_up_head_nhwc")
+    return out
+
+
 def retinex_decom_input(x_nchw: torch.Tensor, dtype) -> torch.Tensor:
     """fp32 NCHW RGB -> ``cat(max_c(x), x)`` as 16-bit NHWC padded to 8 channels, one pass (RetinexNet DecomNet's input, model.py:45-46)."""
     if x_nchw.dim() != 4 or x_nchw.shape[1] != 3 or x_nchw.dtype != torch.float32 or not x_nchw.is_cuda:

@@ -224,6 +224,19 @@ int ie_mconv_pair_thin_applicable(int cin, int cmid, int cout, int kh, int kw, i
 int ie_mconv_pair_thin_nhwc(const void* src_dev, const void* packed_w_a_dev, const float* bias_a_dev, const void* packed_w_b_dev, const float* bias_b_dev,
                             float* dst_f32_dev, void* dst16_8ch_dev, int dtype, int N, int H, int W, int cout_b, int act_b, int pad_mode, void* stream);
 
+/* The last decoder level of a C-channel U-Net + its head in one launch: replaces, in reference terms (unet.py:75-112 `Up.forward`, :186-195 `outc`),
+ *   x = cat([skip, up], 1); x = relu(bn(conv3x3(x)))  [2C -> C];  x = relu(bn(conv3x3(x)))  [C -> C];  y = conv1x1(x)  [C -> tail_cout]  (+ clamp)
+ * with BatchNorm folded into the weights.  skip: NHWC C channels dtype.  up: the second source of the concatenation, NHWC C channels -- at the skip's
+ * resolution (up_h == H, up_w == W), or at HALF resolution (H == 2 up_h, W == 2 up_w): then the kernel also does the reference's bilinear x2 up-sampling
+ * (nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True), unet.py:82-83) while it fills its LDS rows, and the up-sampled tensor never exists.
+ * packed_w_a: ie_mconv_pack_weights(channels {C, C}, Cout C); packed_w_b: channels {C}, Cout C; tail_w: 16-bit [16][C] (rows >= tail_cout zero), tail_bias
+ * fp32 [16].  dst: NCHW fp32 (N, tail_cout, H, W).  Covered: C = 32, W >= 64 -- ie_unet_up_head_applicable says (1 / 0).  Agrees with the separate
+ * launches to fp32 rounding (same 16-bit roundings of both intermediates; the in-kernel up-sampling rounds once, like ie_resize_nhwc). */
+int ie_unet_up_head_applicable(int C, int tail_cout, int H, int W, int up_h, int up_w);
+int ie_unet_up_head_nhwc(const void* skip_dev, const void* up_dev, int up_h, int up_w, const void* packed_w_a_dev, const float* bias_a_dev,
+                         const void* packed_w_b_dev, const float* bias_b_dev, const void* tail_w_dev, const float* tail_bias_dev, int tail_cout, int clamp,
+                         float clamp_lo, float clamp_hi, float* dst_nchw_dev, int dtype, int N, int H, int W, void* stream);
+
 /* ---- 16-bit (IE_F16 / IE_BF16) NHWC streaming ops between the matrix-core convolutions; IE_F32 forwards to the *_f32
  * entry points above.  On the 16-bit path channel counts are multiples of 8 (a thread moves 8 channels = 16 bytes). */
 int ie_maxpool2x2_nhwc(const void* x_dev, void* y_dev, int dtype, int N, int H, int W, int C, void* stream);

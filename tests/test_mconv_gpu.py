@@ -178,6 +178,38 @@ def test_stacked_conv_with_thin_second_layer(shape, cout, act, pad_mode, dt):
 
 
 @pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("classes,clamp", [(3, (0.0, 1.0)), (16, None), (1, (-0.5, 0.5))])
+@pytest.mark.parametrize("shape", [(2, 38, 150), (1, 200, 64), (3, 6, 130), (2, 2, 66), (1, 2, 254), (1, 132, 126), (1, 270, 480)], ids=lambda s: "x".join(map(str, s)))
+def test_unet_last_level_in_one_launch(shape, classes, clamp, dt):
+    """ie_unet_up_head_nhwc (unet.py:75-112 `Up.forward` after the up-sampling, :186-195 `outc`): cat([skip, up]) -> DoubleConv(64, 32, mid 32) -> Conv1x1 ->
+    clamp -> NCHW fp32 in one launch equals the separate launches (ie_mconv_nhwc + ie_mconv_tail_nhwc): the same 16-bit roundings of both
+    intermediates, fp32 accumulation in another order."""
+    tdt = ops.TORCH_DT[dt]
+    n, h, w = shape
+    g = torch.Generator().manual_seed(41)
+    skip = torch.randn(n, 32, h, w, generator=g).to(tdt).cuda().contiguous(memory_format=CL)
+    up = torch.randn(n, 32, h, w, generator=g).to(tdt).cuda().contiguous(memory_format=CL)
+    wa = (torch.randn(32, 64, 3, 3, generator=g) / 24.0).to(tdt).float()
+    wb = (torch.randn(32, 32, 3, 3, generator=g) / 17.0).to(tdt).float()
+    mwa = ops.MConvWeights(wa, torch.randn(32, generator=g) * 0.2, [32, 32], tdt, "cuda")
+    mwb = ops.MConvWeights(wb, torch.randn(32, generator=g) * 0.2, [32], tdt, "cuda")
+    w1 = (torch.randn(classes, 32, 1, 1, generator=g) / 32 ** 0.5).to(tdt).float()
+    b1 = torch.randn(classes, generator=g) * 0.1
+    tail = ops.MTailWeights(w1, b1, tdt, "cuda")
+    assert ops.unet_up_head_applicable(skip, up, mwa, mwb, tail)
+    got = ops.unet_up_head(skip, up, mwa, mwb, tail, clamp=clamp)
+    assert tuple(got.shape) == (n, classes, h, w) and got.dtype == torch.float32 and got.is_contiguous()
+    mid = ops.mconv2d([skip, up], mwa, act="relu")
+    x2 = ops.mconv2d(mid, mwb, act="relu")
+    want = ops.to_nchw(ops.mconv2d(x2, ops.MConvWeights(w1, b1, [32], tdt, "cuda"), pad=0, clamp=clamp, out_f32=True))
+    assert rel_err(got.cpu(), want.cpu()) <= 2e-6
+    ref = F.relu(F.conv2d(torch.cat([skip.float().cpu(), up.float().cpu()], 1), wa, mwa.b.cpu(), padding=1)).to(tdt).float()
+    ref = F.conv2d(F.relu(F.conv2d(ref, wb, mwb.b.cpu(), padding=1)).to(tdt).float(), w1, b1)
+    ref = ref if clamp is None else ref.clamp(*clamp)
+    assert rel_err(got.cpu(), ref) <= (3e-3 if dt == "f16" else 2e-2)
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
 @pytest.mark.parametrize("shape", [(2, 37, 150), (1, 200, 64), (3, 6, 129), (1, 270, 480), (2, 2, 66)], ids=lambda s: "x".join(map(str, s)))
 @pytest.mark.parametrize("c", [32, 64])
 def test_first_double_conv_with_pool(c, dt, shape):
