@@ -9,7 +9,7 @@
 // the whole launch (stage A 18 fragments: 2 K chunks [skip, up] x 9 taps; stage B 9); stage A marches down the strip on rows of an LDS ring, three rotating
 // accumulator sets (ky = 0, 1, 2), and hands each finished row of the intermediate (ReLU, 16 bits) to stage B through a second ring; stage B parks its finished
 // rows as whole pixel lines, and the 1x1 head contracts a parked row one step later (the parked row is the MFMA's A operand, so a lane ends up holding four
-// consecutive pixels of one output plane).  One s_barrier per step.  126 of the strip's 128 computed columns are stored.
+// consecutive pixels of one output plane).  One s_barrier per step.  124 of the strip's 128 computed columns are stored.
 //
 // The skip chunk of the ring arrives by LDS-DMA (stage A's waves).  The up chunk: by LDS-DMA too (up given at full resolution), or, with `bilinear`, written by
 // stage B's waves -- they have half of stage A's MFMA work -- from a small ring of half-resolution rows (their own LDS-DMA): every 16-byte piece of the ring row
@@ -21,7 +21,7 @@
 
 namespace {
 
-constexpr int TW = 128, TS = 126, ROW_PX = TW + 4;      // 128 body pixels, the two halo pixels, two spare ones (one 4-byte-per-lane DMA covers the four)
+constexpr int TW = 128, TS = 124, ROW_PX = TW;          // 128 computed columns, no halo columns: layer a is valid on columns 1 .. 126, layer b on 2 .. 125
 constexpr int PXB = 64;                       // one pixel of a 32-channel 16-bit tensor = one K chunk of a pixel
 constexpr int CH_ROW_B = ROW_PX * PXB;        // 8,448
 constexpr int SLOT_A = 2 * CH_ROW_B;          // stage A's ring row: skip chunk, up chunk
@@ -32,8 +32,7 @@ constexpr int LOW_PX = 80, LOW_ROW_B = LOW_PX * PXB, NRL = 4;      // half-resol
 constexpr int OFF_H = NRA * SLOT_A;                     //  67,584
 constexpr int OFF_PARK = OFF_H + NRH * CH_ROW_B;        //  92,928
 constexpr int OFF_LOW = OFF_PARK + 2 * PARK_B;          // 109,312
-constexpr int OFF_DUMMY = OFF_LOW + NRL * LOW_ROW_B;    // 129,792: 16 bytes per lane of one wave for the masked-off lanes of the halo pieces
-constexpr int LDS_B = OFF_DUMMY + 1024;                 // 130,816
+constexpr int LDS_B = OFF_LOW + NRL * LOW_ROW_B;
 
 struct UpdcParams {
     const void* skip; const void* up; const void* wa; const float* ba; const void* wb; const float* bb; const void* tail_w; const float* tail_b; float* dst;
@@ -53,6 +52,22 @@ __device__ __forceinline__ void wait_vm_cold(int n) {
     }
 }
 
+// w00 * a + w01 * b + w10 * c + w11 * d on the eight 16-bit values of a 16-byte piece, fp32 arithmetic, one rounding.  (Measured and dropped for fp16:
+// v_fma_mix_f32 / v_fma_mixlo_f16 / v_fma_mixhi_f16, which read the halves in place and write the rounded half -- 8 instructions per dword instead of 8
+// converts + 4 packed-fp32 FMAs + a pack, but slower on gfx950: the level ran 1,378 frames/s of U-Net-32 with them against 1,45x with this expression.)
+template <typename T>
+__device__ __forceinline__ ie_u32x4 blend8(ie_u32x4 va, ie_u32x4 vb, ie_u32x4 vc, ie_u32x4 vd, float w00, float w01, float w10, float w11) {
+    ie_u32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        // one fixed chain of FMAs: left to contract the sum itself, the compiler chose differently in the three unrolled copies of the step -- the same pixel then
+        // rounded differently depending on where its row fell in a chunk (found by the batch-independence test at 1080p)
+        const float l = __builtin_fmaf(w11, ie_unpack_lo<T>(vd[k]), __builtin_fmaf(w10, ie_unpack_lo<T>(vc[k]), __builtin_fmaf(w01, ie_unpack_lo<T>(vb[k]), w00 * ie_unpack_lo<T>(va[k]))));
+        const float u = __builtin_fmaf(w11, ie_unpack_hi<T>(vd[k]), __builtin_fmaf(w10, ie_unpack_hi<T>(vc[k]), __builtin_fmaf(w01, ie_unpack_hi<T>(vb[k]), w00 * ie_unpack_hi<T>(va[k]))));
+        o[k] = ie_pack2<T>(l, u);
+    }
+    return o;
+}
 template <typename T, bool BILIN>
 __device__ __forceinline__ void updc_body(const UpdcParams& p) {
     using frag = ie_u32x4;
@@ -66,7 +81,7 @@ __device__ __forceinline__ void updc_body(const UpdcParams& p) {
     const int strip = b % p.strips; b /= p.strips;
     const int chunk = b % p.chunks; b /= p.chunks;
     const int n = b;
-    const int xc0 = strip * TS - 1;                   // image column of computed column 0
+    const int xc0 = strip * TS - 2;                   // image column of computed column 0
     const int H = p.H, W = p.W;
     const int ys = chunk * p.rows_per_block, ye = min(ys + p.rows_per_block, H);
     const int n_steps = (ye - ys) + 8;
@@ -99,19 +114,15 @@ __device__ __forceinline__ void updc_body(const UpdcParams& p) {
     }
 
     // ---- stage A: LDS-DMA of the input rows.  Piece m = 16 pixels x 64 B of one chunk; position (lane & 3) of ring pixel q holds channel piece
-    //      (lane & 3) ^ ((q >> 1) & 3).  Wave w4 loads pieces 2 w4, 2 w4 + 1 of the skip chunk (and of the up chunk when it comes at full resolution); wave 3 also
-    //      the halo pixels (ring pixels 128, 129) as ONE 4-byte-per-lane DMA with every lane active (see ie_conv_pair.hip for why not `if (lane < 8)`).
-    unsigned body_off[2], halo_off;
+    //      (lane & 3) ^ ((q >> 1) & 3).  Wave w4 loads pieces 2 w4, 2 w4 + 1 of the skip chunk (and of the up chunk when it comes at full resolution).  No halo
+    //      columns: the outermost computed column of each layer is simply not used by the next (4 of 128 columns lost, no halo DMA and -- with the in-kernel
+    //      up-sampling -- no third, nearly empty pass over the row for 8 halo pieces).
+    unsigned body_off[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int q = (2 * w4 + j) * 16 + (lane >> 2);
         const int x = xc0 + q;
         body_off[j] = (x >= 0 && x < W) ? (unsigned)(x * PXB + (((lane & 3) ^ ((q >> 1) & 3)) << 4)) : OOB;
-    }
-    {
-        const int hp = lane >> 4;
-        const int x = hp == 0 ? (xc0 - 1) : (xc0 + TW);
-        halo_off = (hp < 2 && x >= 0 && x < W) ? (unsigned)(x * PXB + (lane & 15) * 4) : OOB;
     }
     auto issue = [&](int t) __attribute__((always_inline)) {        // input row of stage A's step t
         const int yi = ys - 2 + t;
@@ -119,38 +130,25 @@ __device__ __forceinline__ void updc_body(const UpdcParams& p) {
         const unsigned row_b = rmask ? 0u : (unsigned)yi * (unsigned)W * PXB;
         char* slot = smem + (t % NRA) * SLOT_A;
 #pragma unroll
-        for (int c = 0; c < (BILIN ? 1 : 2); ++c) {
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsS, (__attribute__((address_space(3))) void*)(slot + (2 * w4 + j) * 1024), 16,
+                                                     (int)((row_b + body_off[j]) | rmask), 0, 0, 0);
+        if constexpr (!BILIN) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                if (c == 0)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsS, (__attribute__((address_space(3))) void*)(slot + (2 * w4 + j) * 1024), 16,
-                                                             (int)((row_b + body_off[j]) | rmask), 0, 0, 0);
-                else
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsU, (__attribute__((address_space(3))) void*)(slot + CH_ROW_B + (2 * w4 + j) * 1024), 16,
-                                                             (int)((row_b + body_off[j]) | rmask), 0, 0, 0);
-            }
-            if (w4 == 3) {        // wave-uniform
-                if (c == 0)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsS, (__attribute__((address_space(3))) void*)(slot + TW * PXB), 4, (int)((row_b + halo_off) | rmask), 0, 0, 0);
-                else
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsU, (__attribute__((address_space(3))) void*)(slot + CH_ROW_B + TW * PXB), 4,
-                                                             (int)((row_b + halo_off) | rmask), 0, 0, 0);
-            }
+            for (int j = 0; j < 2; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsU, (__attribute__((address_space(3))) void*)(slot + CH_ROW_B + (2 * w4 + j) * 1024), 16,
+                                                         (int)((row_b + body_off[j]) | rmask), 0, 0, 0);
         }
     };
     constexpr int NSRC_DMA = BILIN ? 1 : 2;
 
     // ---- fragment read offsets: lane (p16, kq) of the wave's tile j at tap column kx reads chunk piece kq of ring pixel 16 (4 hf + j) + p16 + kx - 1.  The swizzle
-    //      term repeats every 8 pixels, so tile j's offset is tile 1's + 1024 (j - 1) -- an immediate -- except: tile 0 (its own registers: pixel -1 of the strip is
-    //      the halo pixel 128) and the last tile at kx = 2 (pixel 128 of the strip is the halo pixel 129).  Stage B reads the intermediate, which has no halo
-    //      columns: its outermost columns are dropped, those reads only have to stay inside the row.
+    //      term repeats every 8 pixels, so tile j's offset is tile 1's + 1024 (j - 1) -- an immediate -- except tile 0 (its own registers) and the last tile at
+    //      kx = 2: pixels -1 and 128 do not exist, those reads are clamped into the row (they only feed the unused outermost column).
     auto lds_px = [&](int q) __attribute__((always_inline)) { return q * PXB + ((kq ^ ((q >> 1) & 3)) << 4); };
     int rd1[3], rd0[3], rd23;
     {
-        auto fix = [&](int q) __attribute__((always_inline)) {
-            if (stg == 0) return q < 0 ? TW : (q >= TW ? TW + 1 : q);
-            return min(max(q, 0), TW - 1);
-        };
+        auto fix = [&](int q) __attribute__((always_inline)) { return min(max(q, 0), TW - 1); };
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
             rd1[kx] = lds_px(16 * (4 * hf + 1) + p16 + kx - 1);
@@ -217,9 +215,9 @@ __device__ __forceinline__ void updc_body(const UpdcParams& p) {
         // of the intermediate outside the image are layer b's zero padding: written as zeros.
 #pragma unroll
         for (int t = 0; t < PF; ++t) issue(t);
+        if constexpr (BILIN) __builtin_amdgcn_s_barrier();          // stage B's prologue barrier (its staging rows have landed)
         auto step_a = [&](int t, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4]) __attribute__((always_inline)) {
-            if (w4 == 3) ie_wait_vm_imm<(PF - 1) * 3 * NSRC_DMA>();
-            else ie_wait_vm_imm<(PF - 1) * 2 * NSRC_DMA>();
+            ie_wait_vm_imm<(PF - 1) * 2 * NSRC_DMA>();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             row_mfma(smem + (t % NRA) * SLOT_A, two{}, accN, accM, accO);
@@ -248,7 +246,7 @@ __device__ __forceinline__ void updc_body(const UpdcParams& p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int qo = 16 * (2 * w4 + t) + 4 * kq + i, xo = xc0 + qo;
-                tl_col[t][i] = (p16 < p.tail_c && qo >= 1 && qo <= TS && xo < W) ? (unsigned)((p16 * H * W + xo) * 4) : OOB;
+                tl_col[t][i] = (p16 < p.tail_c && qo >= 2 && qo <= TS + 1 && xo < W) ? (unsigned)((p16 * H * W + xo) * 4) : OOB;
             }
         }
         // park: the same 16-byte pieces as the hand-off rows, pixel line = 64 bytes
@@ -267,9 +265,100 @@ __device__ __forceinline__ void updc_body(const UpdcParams& p) {
                 *(ie_u32x4*)(base + pk_off + jj * 32 * PXB) = ie_u32x4{sx[0], sy[0], sx[1], sy[1]};
             }
         };
+        // ---- bilinear: stage B's waves fill the up chunk of stage A's ring rows from a staging ring of half-resolution rows ------------------------------
+        // Full-resolution row y, column x: fy = y * sy, y0 = floor(fy), wy = fy - y0, y1 = min(y0 + 1, h - 1), the same along x (torch's align_corners=True
+        // source index, upsample_bilinear2d); value = sum of the four neighbours with fp32 weights, rounded once.  Rows / columns outside the image get zero
+        // weights: they are conv a's zero padding.
+        // A lane owns two 16-byte pieces of the ring row: pixel q = (e * 256 + 64 w4 + lane) >> 2, channel piece c = lane & 3, e = 0, 1.
+        int lo0[2], lo1[2], rw[2];
+        float cw0[2], cw1[2];
+        unsigned low_src[2];
+        int lxs = 0;
+        if constexpr (BILIN) {
+            const int xmin = max(xc0, 0);
+            lxs = (int)((float)xmin * p.sx);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+#pragma clang fp contract(off)
+                const int idx = e * 256 + w4 * 64 + lane, rq = idx >> 2, c = idx & 3, x = xc0 + rq;
+                const bool ok = x >= 0 && x < W;
+                const int xcl = min(max(x, 0), W - 1);
+                const float fx = (float)xcl * p.sx;
+                const int x0 = (int)fx, x1 = min(x0 + 1, p.w - 1);
+                const float wx = fx - (float)x0;
+                lo0[e] = (x0 - lxs) * PXB + c * 16;
+                lo1[e] = (x1 - lxs) * PXB + c * 16;
+                cw0[e] = ok ? 1.f - wx : 0.f;
+                cw1[e] = ok ? wx : 0.f;
+                rw[e] = CH_ROW_B + rq * PXB + ((c ^ ((rq >> 1) & 3)) << 4);
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {          // staging pieces: wave w4 loads piece w4, wave 0 also piece 4 (16 pixels x 64 B each)
+                const int px = (m ? 4 : w4) * 16 + (lane >> 2), lx = lxs + px;
+                low_src[m] = lx < p.w ? (unsigned)(lx * PXB + (lane & 3) * 16) : OOB;
+            }
+        }
+        auto low_rows = [&](int y, int& y0, int& y1, float& wy0, float& wy1) __attribute__((always_inline)) {      // wave-uniform
+#pragma clang fp contract(off)       // fy is a ROUNDED product (torch: src = scale * dst); contracted into fy - y0 in only some of the step's unrolled copies, the same row
+                                     // got a different weight depending on where it fell in a chunk (found by the batch-independence test at 1080p)
+            const bool ok = y >= 0 && y < H;
+            const int ycl = min(max(y, 0), H - 1);
+            const float fy = (float)ycl * p.sy;
+            y0 = (int)fy;
+            y1 = min(y0 + 1, p.h - 1);
+            const float wy = fy - (float)y0;
+            wy0 = ok ? 1.f - wy : 0.f;
+            wy1 = ok ? wy : 0.f;
+        };
+        auto issue_low = [&](int r) __attribute__((always_inline)) {        // half-resolution row r (inside the tensor) into staging slot r % NRL
+            char* slot = smem + OFF_LOW + (r % NRL) * LOW_ROW_B;
+            const unsigned row_b = (unsigned)r * (unsigned)p.w * PXB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsU, (__attribute__((address_space(3))) void*)(slot + w4 * 1024), 16, (int)(row_b + low_src[0]), 0, 0, 0);
+            if (w4 == 0)          // wave-uniform
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsU, (__attribute__((address_space(3))) void*)(slot + 4 * 1024), 16, (int)(row_b + low_src[1]), 0, 0, 0);
+        };
+        auto interp_row = [&](int y, char* aslot) __attribute__((always_inline)) {       // full-resolution row y -> the up chunk of ring slot `aslot`
+            int y0, y1;
+            float wy0, wy1;
+            low_rows(y, y0, y1, wy0, wy1);
+            const char* r0 = smem + OFF_LOW + (y0 % NRL) * LOW_ROW_B;
+            const char* r1 = smem + OFF_LOW + (y1 % NRL) * LOW_ROW_B;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const ie_u32x4 va = *(const ie_u32x4*)(r0 + lo0[e]), vb = *(const ie_u32x4*)(r0 + lo1[e]);
+                const ie_u32x4 vc = *(const ie_u32x4*)(r1 + lo0[e]), vd = *(const ie_u32x4*)(r1 + lo1[e]);
+                const float w00 = wy0 * cw0[e], w01 = wy0 * cw1[e], w10 = wy1 * cw0[e], w11 = wy1 * cw1[e];
+                const ie_u32x4 o = blend8<T>(va, vb, vc, vd, w00, w01, w10, w11);
+                *(ie_u32x4*)(aslot + rw[e]) = o;
+            }
+        };
+        constexpr int NST_B = 8;                       // the head's store instructions per step of a wave
+        if constexpr (BILIN) {
+            // prologue: four staging rows from the first one the rows ys - 2 .. ys + 2 need; then stage A's first three ring rows (ys - 2, ys - 1, ys)
+            int y0, y1;
+            float wa_, wb_;
+            low_rows(ys - 2, y0, y1, wa_, wb_);
+#pragma unroll
+            for (int r = 0; r < NRL; ++r) issue_low(min(y0 + r, p.h - 1));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int t = 0; t < PF; ++t) interp_row(ys - 2 + t, smem + (t % NRA) * SLOT_A);
+        }
         auto step_b = [&](int t, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4]) __attribute__((always_inline)) {
+            if constexpr (BILIN) {       // the staging row issued at step t - 2 has landed: behind it 2 x NST_B stores and step t - 1's DMA
+                if (w4 == 0) ie_wait_vm_imm<2 * NST_B + 2>();
+                else ie_wait_vm_imm<2 * NST_B + 1>();
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
+            if constexpr (BILIN) {
+                interp_row(ys + 1 + t, smem + ((t + PF) % NRA) * SLOT_A);          // stage A's input row of step t + 3
+                int y0, y1;
+                float wa_, wb_;
+                low_rows(ys + 3 + t, y0, y1, wa_, wb_);
+                issue_low(y1);                                                        // the new staging row of step t + 2 (re-issued while it repeats: uniform counts)
+            }
             const int yo = ys - 8 + t;
             const unsigned rmask = (yo >= ys && yo < ye) ? 0u : OOB;
             const unsigned trow_b = rmask ? 0u : (unsigned)yo * (unsigned)W * 4u;
@@ -305,6 +394,8 @@ __device__ __forceinline__ void updc_body(const UpdcParams& p) {
 
 __global__ __launch_bounds__(512) void unet_updc32_head_f16(UpdcParams p) { updc_body<_Float16, false>(p); }
 __global__ __launch_bounds__(512) void unet_updc32_head_bf16(UpdcParams p) { updc_body<__bf16, false>(p); }
+__global__ __launch_bounds__(512) void unet_updc32_bilinear_head_f16(UpdcParams p) { updc_body<_Float16, true>(p); }
+__global__ __launch_bounds__(512) void unet_updc32_bilinear_head_bf16(UpdcParams p) { updc_body<__bf16, true>(p); }
 
 }  // namespace
 
@@ -313,7 +404,9 @@ IE_EXPORT int ie_unet_up_head_applicable(int C, int tail_cout, int H, int W, int
     static const int off = getenv("IE_UNET_UPHEAD") ? !atoi(getenv("IE_UNET_UPHEAD")) : 0;       // IE_UNET_UPHEAD=0: A/B switch back to separate launches
     if (off || C != 32 || tail_cout < 1 || tail_cout > 16 || H < 1 || W < 64 || (double)H * W * 64.0 >= 2147483647.0 || (double)H * W * tail_cout * 4.0 >= 2147483647.0)
         return 0;
-    return (up_h == H && up_w == W) ? 1 : 0;
+    if (up_h == H && up_w == W) return 1;
+    static const int nobil = getenv("IE_UNET_UPHEAD_BILINEAR") ? !atoi(getenv("IE_UNET_UPHEAD_BILINEAR")) : 0;       // =0: A/B, up-sample in its own launch
+    return (!nobil && up_h >= 2 && up_w >= 2 && H == 2 * up_h && W == 2 * up_w) ? 1 : 0;
 }
 
 IE_EXPORT int ie_unet_up_head_nhwc(const void* skip, const void* up, int up_h, int up_w, const void* packed_w_a, const float* bias_a, const void* packed_w_b,
@@ -322,7 +415,7 @@ IE_EXPORT int ie_unet_up_head_nhwc(const void* skip, const void* up, int up_h, i
     if (!skip || !up || !packed_w_a || !packed_w_b || !tail_w || !tail_bias || !dst_nchw || N <= 0) IE_FAIL(IE_ERR_INVALID, "ie_unet_up_head_nhwc: null pointer / bad batch");
     if (dtype != IE_F16 && dtype != IE_BF16) IE_FAIL(IE_ERR_UNSUPPORTED, "ie_unet_up_head_nhwc: f16 / bf16");
     if (!ie_unet_up_head_applicable(32, tail_cout, H, W, up_h, up_w))
-        IE_FAIL(IE_ERR_UNSUPPORTED, "ie_unet_up_head_nhwc: 32 channels, W >= 64, `up` at the skip's resolution -- ask ie_unet_up_head_applicable first");
+        IE_FAIL(IE_ERR_UNSUPPORTED, "ie_unet_up_head_nhwc: 32 channels, W >= 64, `up` at the skip's resolution or exactly half of it -- ask ie_unet_up_head_applicable first");
     UpdcParams p;
     memset(&p, 0, sizeof(p));
     p.skip = skip; p.up = up; p.wa = packed_w_a; p.ba = bias_a; p.wb = packed_w_b; p.bb = bias_b; p.tail_w = tail_w; p.tail_b = tail_bias; p.dst = dst_nchw;
@@ -349,9 +442,9 @@ IE_EXPORT int ie_unet_up_head_nhwc(const void* skip, const void* up, int up_h, i
     const long long blocks = (long long)p.strips * p.chunks * N;
     if (blocks <= 0 || blocks > 0x7fffffffLL) IE_FAIL(IE_ERR_INVALID, "ie_unet_up_head_nhwc: bad grid");
     typedef void (*Fn)(UpdcParams);
-    const int fi = dtype == IE_F16 ? 0 : 1;
-    static const Fn fns[2] = {unet_updc32_head_f16, unet_updc32_head_bf16};
-    static bool granted[2] = {false, false};
+    const int fi = (dtype == IE_F16 ? 0 : 1) + ((up_h != H || up_w != W) ? 2 : 0);
+    static const Fn fns[4] = {unet_updc32_head_f16, unet_updc32_head_bf16, unet_updc32_bilinear_head_f16, unet_updc32_bilinear_head_bf16};
+    static bool granted[4] = {false, false, false, false};
     if (!granted[fi]) {
         hipError_t e = hipFuncSetAttribute((const void*)fns[fi], hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
         if (e != hipSuccess) IE_FAIL(IE_ERR_HIP, "hipFuncSetAttribute(lds=%d): %s", LDS_B, hipGetErrorString(e));

@@ -210,6 +210,38 @@ def test_unet_last_level_in_one_launch(shape, classes, clamp, dt):
 
 
 @pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 38, 150), (1, 200, 64), (3, 6, 130), (2, 4, 66), (1, 4, 254), (1, 132, 126), (1, 270, 480), (1, 64, 504)], ids=lambda s: "x".join(map(str, s)))
+def test_unet_last_level_with_the_upsampling_inside(shape, dt):
+    """ie_unet_up_head_nhwc with a HALF-resolution second source (unet.py:82-83, 97-112: nn.Upsample(scale_factor=2, bilinear, align_corners=True), cat,
+    DoubleConv, outc): the bilinear x2 up-sampling happens while the kernel fills its LDS rows.  Equals the up-sampling launch + the fused level up to
+    the rare 16-bit rounding flip of an up-sampled value (fp32 weights in another association), and torch on the same 16-bit inputs."""
+    tdt = ops.TORCH_DT[dt]
+    n, h, w = shape
+    g = torch.Generator().manual_seed(43)
+    skip = torch.randn(n, 32, h, w, generator=g).to(tdt).cuda().contiguous(memory_format=CL)
+    low = torch.randn(n, 32, h // 2, w // 2, generator=g).to(tdt).cuda().contiguous(memory_format=CL)
+    wa = (torch.randn(32, 64, 3, 3, generator=g) / 24.0).to(tdt).float()
+    wb = (torch.randn(32, 32, 3, 3, generator=g) / 17.0).to(tdt).float()
+    mwa = ops.MConvWeights(wa, torch.randn(32, generator=g) * 0.2, [32, 32], tdt, "cuda")
+    mwb = ops.MConvWeights(wb, torch.randn(32, generator=g) * 0.2, [32], tdt, "cuda")
+    w1 = (torch.randn(3, 32, 1, 1, generator=g) / 32 ** 0.5).to(tdt).float()
+    b1 = torch.randn(3, generator=g) * 0.1
+    tail = ops.MTailWeights(w1, b1, tdt, "cuda")
+    assert ops.unet_up_head_applicable(skip, low, mwa, mwb, tail)
+    got = ops.unet_up_head(skip, low, mwa, mwb, tail, clamp=(0.0, 1.0))
+    up = ops.upsample2x_bilinear(low)
+    want = ops.unet_up_head(skip, up, mwa, mwb, tail, clamp=(0.0, 1.0))
+    assert tuple(got.shape) == (n, 3, h, w)
+    assert rel_err(got.cpu(), want.cpu()) <= (1e-3 if dt == "f16" else 2e-2)       # bf16: a flipped up-sampled value is 4e-3 of itself
+    upr = F.interpolate(low.float().cpu(), scale_factor=2, mode="bilinear", align_corners=True).to(tdt).float()
+    ref = F.relu(F.conv2d(torch.cat([skip.float().cpu(), upr], 1), wa, mwa.b.cpu(), padding=1)).to(tdt).float()
+    ref = F.conv2d(F.relu(F.conv2d(ref, wb, mwb.b.cpu(), padding=1)).to(tdt).float(), w1, b1).clamp(0.0, 1.0)
+    assert rel_err(got.cpu(), ref) <= (3e-3 if dt == "f16" else 2e-2)
+    odd = torch.randn(n, 32, h // 2 - 1, w // 2, generator=g).to(tdt).cuda().contiguous(memory_format=CL)
+    assert not ops.unet_up_head_applicable(skip, odd, mwa, mwb, tail)       # not exactly half: the caller up-samples and pads (unet.py:99-104)
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
 @pytest.mark.parametrize("shape", [(2, 37, 150), (1, 200, 64), (3, 6, 129), (1, 270, 480), (2, 2, 66)], ids=lambda s: "x".join(map(str, s)))
 @pytest.mark.parametrize("c", [32, 64])
 def test_first_double_conv_with_pool(c, dt, shape):
