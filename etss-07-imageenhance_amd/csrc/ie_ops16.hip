@@ -133,6 +133,25 @@ __global__ void cast_kernel(const S* __restrict__ src, D* __restrict__ dst, int 
     dst[i] = c < Cs ? (D)(float)src[px * Cs + c] : (D)0.f;
 }
 
+// torch.cat(srcs, dim=1) of up to four fp32 NHWC tensors, converted to D and zero-padded to Cd channels in one pass (a thread = one output element)
+struct CatSrcs { const float* p[4]; int c[4]; int n; };
+template <typename D>
+__global__ void concat_cast_kernel(CatSrcs s, D* __restrict__ dst, int Cd, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int c = (int)(i % Cd);
+    const size_t px = i / Cd;
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (k < s.n) {
+            if (c >= 0 && c < s.c[k]) v = s.p[k][px * s.c[k] + c];
+            c -= s.c[k];
+        }
+    }
+    dst[i] = (D)v;
+}
+
 // pure dtype conversion (same channel count): 8 elements per thread, vector loads and stores, no index arithmetic
 template <typename S, typename D>
 __global__ void cast8_kernel(const S* __restrict__ src, D* __restrict__ dst, size_t total8) {
@@ -357,6 +376,29 @@ IE_EXPORT int ie_cast_nhwc(const void* src, int src_dtype, int Cs, void* dst, in
     case IE_BF16: return cast_from((const __bf16*)src, dst, dst_dtype, Cs, Cd, total, st);
     default: IE_FAIL(IE_ERR_INVALID, "ie_cast_nhwc: bad source dtype");
     }
+}
+
+IE_EXPORT int ie_concat_cast_nhwc(const float* const* srcs, const int* channels, int nsrc, void* dst, int dst_dtype, int Cd, size_t npix, void* stream) {
+    if (!srcs || !channels || !dst || nsrc < 1 || nsrc > 4 || npix == 0 || Cd <= 0) IE_FAIL(IE_ERR_INVALID, "ie_concat_cast_nhwc: bad args (1 .. 4 sources)");
+    CatSrcs s;
+    int sum = 0;
+    for (int k = 0; k < 4; ++k) {
+        s.p[k] = k < nsrc ? srcs[k] : nullptr; s.c[k] = k < nsrc ? channels[k] : 0;
+        if (k < nsrc && (!srcs[k] || channels[k] <= 0)) IE_FAIL(IE_ERR_INVALID, "ie_concat_cast_nhwc: source %d", k);
+        sum += s.c[k];
+    }
+    s.n = nsrc;
+    if (sum > Cd) IE_FAIL(IE_ERR_INVALID, "ie_concat_cast_nhwc: %d source channels do not fit %d", sum, Cd);
+    const size_t total = npix * Cd;
+    hipStream_t st = (hipStream_t)stream;
+    switch (dst_dtype) {
+    case IE_F32: hipLaunchKernelGGL(concat_cast_kernel<float>, dim3(nblk(total)), dim3(256), 0, st, s, (float*)dst, Cd, total); break;
+    case IE_F16: hipLaunchKernelGGL(concat_cast_kernel<_Float16>, dim3(nblk(total)), dim3(256), 0, st, s, (_Float16*)dst, Cd, total); break;
+    case IE_BF16: hipLaunchKernelGGL(concat_cast_kernel<__bf16>, dim3(nblk(total)), dim3(256), 0, st, s, (__bf16*)dst, Cd, total); break;
+    default: IE_FAIL(IE_ERR_INVALID, "ie_concat_cast_nhwc: bad destination dtype");
+    }
+    IE_LAUNCH_CHECK();
+    return IE_OK;
 }
 
 IE_EXPORT int ie_instnorm_nhwc(const void* x, const float* gamma, const float* beta, void* y, int dtype, double* stats_ws, int N, int H, int W,

@@ -1298,8 +1298,6 @@ class GCENet(_GraphModel):
                  weights: Any = None, seed: int = None, debug: bool = False, *args, **kwargs):
         kwargs.pop("name", None)
         super().__init__(name="gcenet", in_channels=in_channels, weights=weights, *args, **kwargs)
-        if self.compute_dtype != "f32":
-            raise capi.IEError("gcenet: only the fp32 path is built (compute_dtype='f32')")
         self.num_channels, self.num_iters, self.dba_eps, self.gf_radius, self.gf_eps = num_channels, num_iters, dba_eps, gf_radius, gf_eps
         self.bam_gamma, self.bam_ksize, self.use_depth, self.use_edge, self.debug = bam_gamma, bam_ksize, use_depth, use_edge, debug
         ci0 = in_channels + (1 if use_depth else 0) + (1 if use_edge else 0)
@@ -1340,6 +1338,10 @@ class GCENet(_GraphModel):
             edge = ops.threshold_of_max(ops.sobel(depth if depth is not None else self._gray(image), 1e-6), self.dba_eps)
             srcs.append(edge)
         B = lambda k, ss, act="lrelu", f32=False: self._ds_block(f"en.e_conv{k}.conv", ss, act, f32, 0.2)
+        if self.compute_dtype != "f32":
+            # 16-bit path: EnhanceNet (the seven DSConv blocks) on the matrix cores, its input cat([image, depth, edge]) as one 8-channel 16-bit tensor;
+            # the priors in front of it and everything behind the curve map (bam, LE-curve, guided filter) stay fp32 -- they are per-pixel streaming passes
+            srcs = [ops.concat_cast(srcs, self._tdt, 8)]
         x1 = B(1, srcs); x2 = B(2, [x1]); x3 = B(3, [x2]); x4 = B(4, [x3])
         x5 = B(5, [x3, x4]); x6 = B(6, [x2, x5])
         adjust = B(7, [x1, x6], "tanh", True)

@@ -203,6 +203,22 @@ def cast(x, dtype, channels=None) -> torch.Tensor:
     return y
 
 
+def concat_cast(srcs, dtype, channels) -> torch.Tensor:
+    """``torch.cat(srcs, 1)`` of fp32 NHWC tensors, converted to ``dtype`` and zero-padded to ``channels`` channels in one pass (ie_concat_cast_nhwc)."""
+    for t in srcs:
+        _chk(t)
+    n, _, h, w = srcs[0].shape
+    if any(tuple(t.shape[0:1] + t.shape[2:]) != (n, h, w) for t in srcs):
+        raise ValueError("concat_cast: sources must share N, H, W")
+    y = empty_nhwc(n, int(channels), h, w, srcs[0].device, dtype)
+    ptrs = (C.c_void_p * len(srcs))(*[capi.ptr(t) for t in srcs])
+    chans = (C.c_int * len(srcs))(*[int(t.shape[1]) for t in srcs])
+    with torch.cuda.device(y.device):
+        capi.check(capi.lib().ie_concat_cast_nhwc(ptrs, chans, len(srcs), capi.ptr(y), _dt(y), int(channels), n * h * w, capi.current_stream()),
+                   "ie_concat_cast_nhwc")
+    return y
+
+
 class ConvT2x2Weights:
     def __init__(self, w_iohw: torch.Tensor, bias, device):
         w = w_iohw.detach().to(torch.float32)                 # (Cin, Cout, 2, 2)

@@ -253,6 +253,9 @@ int ie_dwconv3x3_nhwc(const void* x_dev, const float* w_tap_c_dev, const float* 
 /* dst[p][c] = c < Cs ? (dst type) src[p][c] : 0 for c < Cd: dtype conversion and channel padding / cropping in one pass
  * (e.g. DecomNet's 4-channel fp32 input -> 8-channel bf16; a 16-bit map -> the fp32 tensor handed back to the caller). */
 int ie_cast_nhwc(const void* src_dev, int src_dtype, int Cs, void* dst_dev, int dst_dtype, int Cd, size_t npix, void* stream);
+/* torch.cat(srcs, dim=1) of 1 .. 4 fp32 NHWC tensors + the same conversion / zero padding to Cd channels, one pass: the input of a network whose first layer
+ * reads a concatenation (reference: GCENet's EnhanceNet, gcenet.py:283-290: cat([image, depth, edge])) as ONE 8-channel 16-bit tensor. */
+int ie_concat_cast_nhwc(const float* const* srcs_dev, const int* channels, int nsrc, void* dst_dev, int dst_dtype, int Cd, size_t npix, void* stream);
 /* ie_instnorm_nhwc_f32 for 16-bit tensors (statistics in fp64 from the 16-bit values, one rounding on store);
  * stats_ws_dev: >= 3*N*c_count doubles; c_begin and c_count multiples of 8. */
 int ie_instnorm_nhwc(const void* x_dev, const float* gamma_dev, const float* beta_dev, void* y_dev, int dtype, double* stats_ws_dev,

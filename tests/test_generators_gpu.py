@@ -506,6 +506,29 @@ def test_gcenet_vs_oracle():
     assert rel_err(got, want) <= 1e-3
 
 
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+def test_gcenet_16bit_vs_oracle(dt):
+    """GCENet with EnhanceNet on the matrix cores (16-bit activations, fp32 accumulation): the curve map within the 16-bit bound of the oracle's, the
+    enhanced image behind 15 curve iterations and the guided filter likewise; the priors (edge, bam) are the fp32 path's, bit for bit."""
+    from oracle import filters as of
+    m = mon_amd.MODELS.build(name="gcenet", seed=3, debug=True, compute_dtype=dt).to("cuda")
+    sd = {k: (v * 8 if k.endswith("weight") else v) for k, v in m.state_dict().items()}
+    m.load_state_dict(sd)
+    x = _smooth(2, 3, 48, 72, seed=8, lo=0.02, hi=0.6)
+    depth = _smooth(2, 1, 48, 72, seed=9)
+    out, ref = m.forward({"image": x.cuda(), "depth": depth.cuda()}), of.gcenet_forward(sd, x, depth)
+    assert torch.equal(out["edge"].cpu(), ref["edge"]) and rel_err(out["bam"].cpu(), ref["bam"]) <= 1e-6
+    tol = 2e-3 if dt == "f16" else 1.5e-2
+    assert rel_err(out["adjust"].cpu(), ref["adjust"]) <= tol
+    assert rel_err(out["enhanced"].cpu(), ref["enhanced"]) <= tol
+    m32 = mon_amd.MODELS.build(name="gcenet", weights=sd, debug=True).to("cuda")
+    assert rel_err(out["adjust"].cpu(), m32.forward({"image": x.cuda(), "depth": depth.cuda()})["adjust"].cpu()) <= tol
+    nodepth = mon_amd.MODELS.build(name="gcenet", seed=3, use_depth=False, use_edge=False, bam_gamma=0.0, compute_dtype=dt).to("cuda")
+    got = nodepth.forward({"image": x.cuda()})["enhanced"].cpu()
+    want = of.gcenet_forward(nodepth.state_dict(), x, None, use_depth=False, use_edge=False, bam_gamma=0.0)["enhanced"]
+    assert rel_err(got, want) <= tol
+
+
 # ---- BASELINE.json configs[2] / configs[3] at their frame size: properties that need no CPU reference ---------------------------------
 @pytest.mark.parametrize("cfg", [dict(name="unet", base_channels=32, num_classes=3, enhance=True, upsampler="pixelshuffle"),
                                  dict(name="unet", base_channels=32, num_classes=3, enhance=True),
