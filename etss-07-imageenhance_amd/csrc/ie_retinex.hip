@@ -174,7 +174,7 @@ __global__ void pad_replicate_backward_kernel(const float* __restrict__ dy, floa
 
 // DecomNet's input in one pass (model.py:45-46: input_max = max over channels; input_img = cat(input_max, input_im)): fp32 NCHW image -> 16-bit NHWC padded
 // to 8 channels [max, R, G, B, 0, 0, 0, 0], one 16-byte store per pixel.
-template <typename T>
+template <typename T, int CP>
 __global__ void decom_input_kernel(const float* __restrict__ src, T* __restrict__ dst, size_t plane, size_t total_px) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total_px) return;
@@ -182,7 +182,8 @@ __global__ void decom_input_kernel(const float* __restrict__ src, T* __restrict_
     const float* s = src + n * 3 * plane + pix;
     const float r = s[0], g = s[plane], b = s[2 * plane];
     const float m = fmaxf(fmaxf(r, g), b);
-    *(ie_u32x4*)(dst + i * 8) = ie_u32x4{ie_pack2<T>(m, r), ie_pack2<T>(g, b), 0u, 0u};
+    if constexpr (CP == 8) *(ie_u32x4*)(dst + i * 8) = ie_u32x4{ie_pack2<T>(m, r), ie_pack2<T>(g, b), 0u, 0u};
+    else *(ie_u32x2*)(dst + i * 4) = ie_u32x2{ie_pack2<T>(m, r), ie_pack2<T>(g, b)};
 }
 
 // The model's outputs in one pass (model.py:72-74, 229-231): rl = (R, L) fp32 pixel-major 4 floats, I_delta fp32 one float per pixel ->
@@ -204,11 +205,14 @@ __global__ void outputs_kernel(const float* __restrict__ rl, const float* __rest
 
 }  // namespace
 
-IE_EXPORT int ie_retinex_decom_input(const float* x_nchw, void* dst_nhwc8, int dtype, int N, int H, int W, void* stream) {
-    if (!x_nchw || !dst_nhwc8 || N <= 0 || H <= 0 || W <= 0) IE_FAIL(IE_ERR_INVALID, "ie_retinex_decom_input: bad args");
+IE_EXPORT int ie_retinex_decom_input(const float* x_nchw, void* dst_nhwc, int dtype, int cpad, int N, int H, int W, void* stream) {
+    if (!x_nchw || !dst_nhwc || N <= 0 || H <= 0 || W <= 0 || (cpad != 4 && cpad != 8)) IE_FAIL(IE_ERR_INVALID, "ie_retinex_decom_input: bad args (cpad 4 or 8)");
     const size_t plane = (size_t)H * W, total = plane * N;
-    if (dtype == IE_F16) hipLaunchKernelGGL(decom_input_kernel<_Float16>, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, x_nchw, (_Float16*)dst_nhwc8, plane, total);
-    else if (dtype == IE_BF16) hipLaunchKernelGGL(decom_input_kernel<__bf16>, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, x_nchw, (__bf16*)dst_nhwc8, plane, total);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == IE_F16 && cpad == 8) hipLaunchKernelGGL((decom_input_kernel<_Float16, 8>), dim3(nblk(total)), dim3(256), 0, st, x_nchw, (_Float16*)dst_nhwc, plane, total);
+    else if (dtype == IE_F16) hipLaunchKernelGGL((decom_input_kernel<_Float16, 4>), dim3(nblk(total)), dim3(256), 0, st, x_nchw, (_Float16*)dst_nhwc, plane, total);
+    else if (dtype == IE_BF16 && cpad == 8) hipLaunchKernelGGL((decom_input_kernel<__bf16, 8>), dim3(nblk(total)), dim3(256), 0, st, x_nchw, (__bf16*)dst_nhwc, plane, total);
+    else if (dtype == IE_BF16) hipLaunchKernelGGL((decom_input_kernel<__bf16, 4>), dim3(nblk(total)), dim3(256), 0, st, x_nchw, (__bf16*)dst_nhwc, plane, total);
     else IE_FAIL(IE_ERR_UNSUPPORTED, "ie_retinex_decom_input: dtype %d (IE_F16 / IE_BF16)", dtype);
     IE_LAUNCH_CHECK();
     return IE_OK;

@@ -20,6 +20,7 @@ allocates).  This is the parity path (fp32, VALU conv); the MFMA path exists for
 from __future__ import annotations
 
 import math
+import os
 from collections import OrderedDict
 from typing import Any
 
@@ -1420,7 +1421,15 @@ class RetinexNet(_GraphModel):
             xin = ops.max_concat(x)                                                # [max over channels, x], model.py:45-46
         else:
             xin = x
-        f = c(xin, "net1_conv0", pad=4, pad_mode=R)
+        if xin.shape[1] == 4 and self.compute_dtype != "f32":      # the 4-channel 16-bit input: the 9x9 strip kernel (ie_conv_first9.hip)
+            key = ("conv9x9c4", "net1_conv0")
+            if self._dev_cache is None:
+                self._dev_cache = {}
+            if key not in self._dev_cache:
+                self._dev_cache[key] = ops.Conv9x9C4Weights(self._params["net1_conv0.weight"], self._params["net1_conv0.bias"], self._tdt, self.device)
+            f = ops.conv9x9_c4(xin, self._dev_cache[key])
+        else:
+            f = c(xin, "net1_conv0", pad=4, pad_mode=R)
         layers = [0, 2, 4, 6, 8]
         while layers:
             i = layers.pop(0)
@@ -1577,7 +1586,8 @@ class RetinexNet(_GraphModel):
             x = x[None] if x.dim() == 3 else x
             if x.dim() != 4 or x.shape[1] != self.in_channels:
                 raise ValueError(f"`image` must be (N,{self.in_channels},H,W), but got {tuple(x.shape)}.")
-            rl, rl16 = self.decom(ops.retinex_decom_input(x.to(self.device, torch.float32), self._tdt), copy16=True)
+            c4 = self.channels == 64 and os.environ.get("IE_RETINEX_CONV9", "1") != "0"      # (IE_RETINEX_CONV9=0: A/B switch back to the tiled thin-source kernel)
+            rl, rl16 = self.decom(ops.retinex_decom_input(x.to(self.device, torch.float32), self._tdt, 4 if c4 else 8), copy16=True)
             i_delta = self.relight(rl16)
             out["reflectance"], out["illumination"], s = ops.retinex_outputs(rl, i_delta)
             out["illumination_delta"] = i_delta.contiguous()                        # (N,1,H,W): NHWC and NCHW are the same bytes

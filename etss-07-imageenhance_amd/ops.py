@@ -1032,16 +1032,46 @@ def unet_up_head(skip, up, mwa: MConvWeights, mwb: MConvWeights, tail: MTailWeig
     return out
 
 
-def retinex_decom_input(x_nchw: torch.Tensor, dtype) -> torch.Tensor:
-    """fp32 NCHW RGB -> ``cat(max_c(x), x)`` as 16-bit NHWC padded to 8 channels, one pass (RetinexNet DecomNet's input, model.py:45-46)."""
+def retinex_decom_input(x_nchw: torch.Tensor, dtype, channels: int = 8) -> torch.Tensor:
+    """fp32 NCHW RGB -> ``cat(max_c(x), x)`` as 16-bit NHWC with 4 channels or padded to 8, one pass (RetinexNet DecomNet's input, model.py:45-46)."""
     if x_nchw.dim() != 4 or x_nchw.shape[1] != 3 or x_nchw.dtype != torch.float32 or not x_nchw.is_cuda:
         raise ValueError("retinex_decom_input: (N,3,H,W) fp32 CUDA tensor")
     x_nchw = x_nchw.contiguous()
     n, _, h, w = (int(v) for v in x_nchw.shape)
-    y = torch.empty((n, 8, h, w), device=x_nchw.device, dtype=dtype, memory_format=CL)
+    y = torch.empty((n, int(channels), h, w), device=x_nchw.device, dtype=dtype, memory_format=CL)
     with torch.cuda.device(x_nchw.device):
-        capi.check(capi.lib().ie_retinex_decom_input(capi.ptr(x_nchw), capi.ptr(y), IE_DT[dtype], n, h, w, capi.current_stream()), "ie_retinex_decom_input")
+        capi.check(capi.lib().ie_retinex_decom_input(capi.ptr(x_nchw), capi.ptr(y), IE_DT[dtype], int(channels), n, h, w, capi.current_stream()),
+                   "ie_retinex_decom_input")
     return y
+
+
+class Conv9x9C4Weights:
+    """Fragment image of a Conv2d(4, 64, 9, padding=4, replicate) for ie_conv9x9_c4_nhwc (+ fp32 bias)."""
+
+    def __init__(self, w_oihw: torch.Tensor, bias, dtype, device):
+        w = w_oihw.detach().to("cpu", torch.float32).contiguous()
+        if tuple(w.shape) != (64, 4, 9, 9):
+            raise capi.IEError(f"Conv9x9C4Weights: (64, 4, 9, 9) expected, got {tuple(w.shape)}")
+        self.dtype = dtype
+        L = capi.lib()
+        self.w = torch.empty(int(L.ie_conv9x9_c4_packed_bytes()), device=device, dtype=torch.uint8)
+        with torch.cuda.device(self.w.device):
+            capi.check(L.ie_conv9x9_c4_pack_weights(capi.ptr(w), IE_DT[dtype], capi.ptr(self.w), capi.current_stream()), "ie_conv9x9_c4_pack_weights")
+        self.b = None if bias is None else bias.detach().to(device, torch.float32).contiguous()
+
+
+def conv9x9_c4(x4, cw: Conv9x9C4Weights):
+    """Conv2d(4, 64, 9, padding 4 replicate) on a 4-channel 16-bit NHWC image (ie_conv9x9_c4_nhwc); no activation."""
+    _chk16(x4)
+    n, c, h, w = (int(v) for v in x4.shape)
+    if c != 4 or x4.dtype != cw.dtype:
+        raise capi.IEError("conv9x9_c4: a 4-channel NHWC tensor of the weights' dtype")
+    out = torch.empty((n, 64, h, w), device=x4.device, dtype=x4.dtype, memory_format=CL)
+    _count_macs(n, h, w, 64, 4, 9, 9)
+    with torch.cuda.device(x4.device):
+        capi.check(capi.lib().ie_conv9x9_c4_nhwc(capi.ptr(x4), capi.ptr(cw.w), capi.ptr(cw.b), capi.ptr(out), IE_DT[x4.dtype], n, h, w, capi.current_stream()),
+                   "ie_conv9x9_c4_nhwc")
+    return out
 
 
 def retinex_outputs(rl, i_delta):

@@ -224,6 +224,14 @@ int ie_mconv_pair_thin_applicable(int cin, int cmid, int cout, int kh, int kw, i
 int ie_mconv_pair_thin_nhwc(const void* src_dev, const void* packed_w_a_dev, const float* bias_a_dev, const void* packed_w_b_dev, const float* bias_b_dev,
                             float* dst_f32_dev, void* dst16_8ch_dev, int dtype, int N, int H, int W, int cout_b, int act_b, int pad_mode, void* stream);
 
+/* Conv2d(4, 64, kernel_size 9, padding 4, padding_mode="replicate") on a 4-channel 16-bit NHWC image (reference: DecomNet's `net1_conv0`,
+ * retinexnet/model.py:26, whose input is cat(max_c(x), x)): a strip kernel with K = 8 kx taps x 4 channels per MFMA and nine rotating accumulator sets.
+ * pack_weights: (64, 4, 9, 9) fp32 OIHW on the host -> the kernel's fragment image (packed_bytes() bytes on the device).  src: NHWC 4 channels dtype;
+ * dst: NHWC 64 channels dtype; no activation; fp32 accumulation. */
+size_t ie_conv9x9_c4_packed_bytes(void);
+int ie_conv9x9_c4_pack_weights(const float* w_oihw_host, int dtype, void* dst_dev, void* stream);
+int ie_conv9x9_c4_nhwc(const void* src4_dev, const void* packed_w_dev, const float* bias_dev, void* dst_dev, int dtype, int N, int H, int W, void* stream);
+
 /* The last decoder level of a C-channel U-Net + its head in one launch: replaces, in reference terms (unet.py:75-112 `Up.forward`, :186-195 `outc`),
  *   x = cat([skip, up], 1); x = relu(bn(conv3x3(x)))  [2C -> C];  x = relu(bn(conv3x3(x)))  [C -> C];  y = conv1x1(x)  [C -> tail_cout]  (+ clamp)
  * with BatchNorm folded into the weights.  skip: NHWC C channels dtype.  up: the second source of the concatenation, NHWC C channels -- at the skip's
@@ -376,9 +384,9 @@ int ie_paste_nhwc(const void* src_dev, void* dst_dev, int dtype, int N, int H, i
  *   l1_detached  mean |A - B|, gradient to A only  (model.py:220: equal_R_loss against R_high.detach())
  *   smooth   mean over the (H+1) x (W+1) grid of |gx I| exp(-10 avg3x3 |gx gray(R)|) + the same along y   (model.py:240-260) */
 /* RetinexNet's inference ends as single passes.  decom_input: fp32 NCHW RGB -> DecomNet's input cat(max_c(x), x) (model.py:45-46) as dtype (IE_F16 /
- * IE_BF16) NHWC padded to 8 channels.  outputs: rl = DecomNet's (R, L) output, fp32 pixel-major 4 floats, i_delta fp32 one float per pixel ->
+ * IE_BF16) NHWC with cpad = 4 channels (what ie_conv9x9_c4_nhwc reads) or padded to cpad = 8 (what ie_mconv_nhwc reads).  outputs: rl = DecomNet's (R, L) output, fp32 pixel-major 4 floats, i_delta fp32 one float per pixel ->
  * R (N,3,H,W), L (N,1,H,W) (either may be NULL) and S = R * I_delta (N,3,H,W) (model.py:72-74, 229-231), NCHW fp32. */
-int ie_retinex_decom_input(const float* x_nchw_dev, void* dst_nhwc8_dev, int dtype, int N, int H, int W, void* stream);
+int ie_retinex_decom_input(const float* x_nchw_dev, void* dst_nhwc_dev, int dtype, int cpad, int N, int H, int W, void* stream);
 int ie_retinex_outputs_f32(const float* rl_nhwc4_dev, const float* i_delta_dev, float* R_nchw_dev, float* L_nchw_dev, float* S_nchw_dev, int N, int H, int W,
                            void* stream);
 int ie_retinex_recon_f32(const float* R_dev, int r_stride, const float* I_dev, int i_stride, const float* T_dev, float weight, float* dR_dev,

@@ -242,6 +242,29 @@ def test_unet_last_level_with_the_upsampling_inside(shape, dt):
 
 
 @pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 37, 150), (1, 200, 64), (3, 6, 129), (2, 1, 66), (1, 3, 253), (1, 131, 30), (1, 270, 480)], ids=lambda s: "x".join(map(str, s)))
+def test_first_9x9_conv_on_a_4_channel_image(shape, dt):
+    """ie_conv9x9_c4_nhwc (DecomNet's `net1_conv0`, retinexnet/model.py:26: Conv2d(4, 64, 9, padding=4, padding_mode="replicate")): the strip kernel with nine
+    rotating accumulator sets against torch on the same 16-bit-rounded inputs and weights, and against the tiled kernel on the 8-channel carrier."""
+    tdt = ops.TORCH_DT[dt]
+    n, h, w = shape
+    g = torch.Generator().manual_seed(47)
+    img = torch.rand(n, 3, h, w, generator=g)
+    x4 = ops.retinex_decom_input(img.cuda(), tdt, 4)
+    x8 = ops.retinex_decom_input(img.cuda(), tdt, 8)
+    assert tuple(x4.shape) == (n, 4, h, w) and torch.equal(x4, x8[:, :4])
+    wt = (torch.randn(64, 4, 9, 9, generator=g) / 18.0).to(tdt).float()
+    bias = torch.randn(64, generator=g) * 0.2
+    got = ops.conv9x9_c4(x4, ops.Conv9x9C4Weights(wt, bias, tdt, "cuda"))
+    assert tuple(got.shape) == (n, 64, h, w) and got.dtype == tdt and got.is_contiguous(memory_format=CL)
+    ref = F.conv2d(F.pad(x4.float().cpu(), (4, 4, 4, 4), mode="replicate"), wt, bias)
+    assert rel_err(got.float().cpu(), ref) <= (1e-3 if dt == "f16" else 8e-3)          # one rounding of the stored result
+    mw = ops.MConvWeights(wt, bias, [8], tdt, "cuda", cin_map=[0, 1, 2, 3, -1, -1, -1, -1])
+    old = ops.mconv2d(x8, mw, pad=4, pad_mode="replicate")
+    assert rel_err(got.float().cpu(), old.float().cpu()) <= (1e-3 if dt == "f16" else 8e-3)
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
 @pytest.mark.parametrize("shape", [(2, 37, 150), (1, 200, 64), (3, 6, 129), (1, 270, 480), (2, 2, 66)], ids=lambda s: "x".join(map(str, s)))
 @pytest.mark.parametrize("c", [32, 64])
 def test_first_double_conv_with_pool(c, dt, shape):
