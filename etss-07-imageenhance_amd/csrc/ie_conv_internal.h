@@ -43,6 +43,11 @@ bool ie_sconv3_fused_ok(int nsrc, const int* cs);
 int ie_sconv3_launch(const void* const* srcs, const int* cs, int nsrc, const void* wpk, const float* bias, void* dst, int dtype, int N, int H, int W,
                      int Cout, int act, float slope, int pad_mode, const int* src_h, const int* src_w, void* pool_dst, const ie_sconv_tail* tail, int stride, hipStream_t st);
 // pool_dst: null, or the 2x2 max-pooled copy of dst written by the same launch (ReLU layers only)
+// 3x3 conv over <= 3 sources of 64 channels (each at its own resolution, nearest up-sampling folded in) with 1 .. 4 output channels, fp32 out (ie_conv_thin3.hip)
+bool ie_sconv3_thin3_applicable(int nsrc, const int* cs, int Cout, int kh, int kw, int stride, int pad, int pad_mode, int act, bool residual, bool clamp,
+                                bool out_f32, bool shuffle, int W);
+int ie_sconv3_thin3_launch(const void* const* srcs, int nsrc, const int* src_h, const int* src_w, const void* wpk, const float* bias, float* dst, int dtype, int N,
+                           int H, int W, int Cout, int act, int pad_mode, hipStream_t st);
 // two stacked Conv3x3(64 -> 64) + bias + ReLU layers, the intermediate in LDS only (ie_conv_pair.hip)
 int ie_sconv3x2_launch(const void* src, const void* w_a, const float* bias_a, const void* w_b, const float* bias_b, void* dst, int dtype, int N, int H, int W,
                        int pad_mode, int cout_b, int act_b, void* dst16, hipStream_t st);

@@ -1058,6 +1058,17 @@ static int mconv_impl(ie_mconv_desc* d, const void* const* srcs, const int* chan
         return ie_sconv3_launch(srcs, channels, d->nsrc, packed_w, bias, dst, d->in_dtype, d->N, d->H, d->W, d->Cout, d->act, d->slope, d->pad_mode,
                                 d->src_h, d->src_w, pd, nullptr, d->stride, (hipStream_t)stream);
     }
+    if (!pool_dst && (double)d->H * d->W * 256.0 < 2147483647.0 &&
+        ie_sconv3_thin3_applicable(d->nsrc, channels, d->Cout, d->kh, d->kw, d->stride, d->pad, d->pad_mode, d->act, residual != nullptr, d->clamp != 0,
+                                   d->out_dtype == IE_F32, d->pixel_shuffle != 0, d->W)) {
+        // thin output (1 .. 4 channels, fp32) over 64-channel sources: the HBM-bound strip form with one wave pair per source
+        for (int s = 0; s < d->nsrc; ++s)
+            if (!srcs[s]) IE_FAIL(IE_ERR_INVALID, "ie_mconv_nhwc: source %d is null", s);
+        d->Ho = d->H; d->Wo = d->W;
+        if (pooled) *pooled = false;
+        return ie_sconv3_thin3_launch(srcs, d->nsrc, d->src_h, d->src_w, packed_w, bias, (float*)dst, d->in_dtype, d->N, d->H, d->W, d->Cout, d->act, d->pad_mode,
+                                      (hipStream_t)stream);
+    }
     MConvParams p;
     memset(&p, 0, sizeof(p));
     bool any_up = false;

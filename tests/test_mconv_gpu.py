@@ -265,6 +265,30 @@ def test_first_9x9_conv_on_a_4_channel_image(shape, dt):
 
 
 @pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("pad_mode", ["zeros", "replicate"])
+@pytest.mark.parametrize("cout,act,scales", [(1, "none", (4, 2, 1)), (4, "sigmoid", (1,)), (3, "tanh", (2, 1)), (2, "relu", (1, 1, 1))])
+@pytest.mark.parametrize("shape", [(2, 36, 152), (1, 200, 64), (3, 8, 132), (2, 4, 68), (1, 4, 256), (1, 132, 128)], ids=lambda s: "x".join(map(str, s)))
+def test_thin_output_conv_over_sources_at_their_own_resolution(shape, cout, act, scales, pad_mode, dt):
+    """ie_mconv_nhwc's thin-output strip form (ie_conv_thin3.hip; RelightNet's tail, retinexnet/model.py:83-88: F.interpolate(nearest) of the coarser decoder
+    levels, cat, 1x1 fusion + 3x3 output composed into one 3x3 conv 192 -> 1): up to three 64-channel sources, each at 1 / scale of the output size, 1 .. 4
+    output channels in fp32 -- against torch on the same 16-bit inputs and weights."""
+    tdt = ops.TORCH_DT[dt]
+    n, h, w = shape
+    g = torch.Generator().manual_seed(53)
+    srcs = [torch.randn(n, 64, h // sc, w // sc, generator=g).to(tdt).cuda().contiguous(memory_format=CL) for sc in scales]
+    cin = 64 * len(scales)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).to(tdt).float()
+    bias = torch.randn(cout, generator=g) * 0.3
+    mw = ops.MConvWeights(wt, bias, [64] * len(scales), tdt, "cuda")
+    got = ops.mconv2d(srcs, mw, pad_mode=pad_mode, act=act, out_f32=True)
+    assert tuple(got.shape) == (n, cout, h, w) and got.dtype == torch.float32
+    up = torch.cat([F.interpolate(t.float().cpu(), size=(h, w), mode="nearest") for t in srcs], 1)
+    ref = F.conv2d(F.pad(up, (1, 1, 1, 1), mode="replicate" if pad_mode == "replicate" else "constant"), wt, bias)
+    ref = {"sigmoid": torch.sigmoid, "tanh": torch.tanh, "relu": F.relu, "none": lambda t: t}[act](ref)
+    assert rel_err(got.cpu(), ref) <= 2e-5                                    # fp32 accumulation of exact 16-bit products, fp32 out
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
 @pytest.mark.parametrize("shape", [(2, 37, 150), (1, 200, 64), (3, 6, 129), (1, 270, 480), (2, 2, 66)], ids=lambda s: "x".join(map(str, s)))
 @pytest.mark.parametrize("c", [32, 64])
 def test_first_double_conv_with_pool(c, dt, shape):
