@@ -299,7 +299,73 @@ __global__ void sobel_kernel(const float* __restrict__ x, float* __restrict__ y,
     y[i] = sqrtf(gx * gx + gy * gy + eps);
 }
 
+// core.RGBToHVI.rgb_to_hvi (src/mon/core/image/color.py:332-361; HVI-CIDNet's transform): hue by the reference's assignment order (the LAST matching
+// assignment wins: min == max -> 0, else R == max, else G == max, else B == max), saturation, intensity-dependent radius (sin(v pi / 2) + eps)^k.
+__global__ void rgb_to_hvi_kernel(const float* __restrict__ x, float* __restrict__ y, size_t npix, float k, float eps) {
+#pragma clang fp contract(off)
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    const float pi = 3.141592653589793f;
+    const float r = x[i * 3], g = x[i * 3 + 1], b = x[i * 3 + 2];
+    const float v = fmaxf(r, fmaxf(g, b)), mn = fminf(r, fminf(g, b));
+    const float d = v - mn + eps;
+    float hue;
+    if (mn == v) hue = 0.f;
+    else if (r == v) { hue = (g - b) / d; hue = hue - 6.f * floorf(hue / 6.f); }       // torch `%`: the divisor's sign
+    else if (g == v) hue = 2.f + (b - r) / d;
+    else hue = 4.f + (r - g) / d;
+    hue = hue / 6.f;
+    const float sat = v == 0.f ? 0.f : (v - mn) / (v + eps);
+    const float cs = powf(sinf(v * 0.5f * pi) + eps, k);
+    y[i * 3] = cs * sat * cosf(2.f * pi * hue);
+    y[i * 3 + 1] = cs * sat * sinf(2.f * pi * hue);
+    y[i * 3 + 2] = v;
+}
+
+// core.RGBToHVI.hvi_to_rgb (color.py:363-434, gated / gated2 off as constructed), optionally followed by clamp(0, 1) (lllinet.py:383-384)
+__global__ void hvi_to_rgb_kernel(const float* __restrict__ x, float* __restrict__ y, size_t npix, float k, float eps, int clamp01) {
+#pragma clang fp contract(off)
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    const float pi = 3.141592653589793f;
+    float H = fminf(fmaxf(x[i * 3], -1.f), 1.f), V = fminf(fmaxf(x[i * 3 + 1], -1.f), 1.f);
+    const float v = fminf(fmaxf(x[i * 3 + 2], 0.f), 1.f);
+    const float cs = powf(sinf(v * 0.5f * pi) + eps, k);
+    H = fminf(fmaxf(H / (cs + eps), -1.f), 1.f);
+    V = fminf(fmaxf(V / (cs + eps), -1.f), 1.f);
+    float h = atan2f(V, H) / (2.f * pi);
+    h = h - floorf(h);                                   // % 1
+    const float s = fminf(fmaxf(sqrtf(H * H + V * V), 0.f), 1.f);
+    const float hi = floorf(h * 6.f), f = h * 6.f - hi;
+    const float p = v * (1.f - s), q = v * (1.f - f * s), t = v * (1.f - (1.f - f) * s);
+    float R = 0.f, G = 0.f, B = 0.f;                     // hi == 6 (h rounding up to 1): the reference's zeros stay
+    switch ((int)hi) {
+    case 0: R = v; G = t; B = p; break;
+    case 1: R = q; G = v; B = p; break;
+    case 2: R = p; G = v; B = t; break;
+    case 3: R = p; G = q; B = v; break;
+    case 4: R = t; G = p; B = v; break;
+    case 5: R = v; G = p; B = q; break;
+    default: break;
+    }
+    if (clamp01) { R = fminf(fmaxf(R, 0.f), 1.f); G = fminf(fmaxf(G, 0.f), 1.f); B = fminf(fmaxf(B, 0.f), 1.f); }
+    y[i * 3] = R; y[i * 3 + 1] = G; y[i * 3 + 2] = B;
+}
+
 }  // namespace
+
+IE_EXPORT int ie_rgb_to_hvi_nhwc_f32(const float* x, float* hvi, size_t npix, float density_k, float eps, void* stream) {
+    if (!x || !hvi || npix == 0) IE_FAIL(IE_ERR_INVALID, "ie_rgb_to_hvi_nhwc_f32: bad args");
+    hipLaunchKernelGGL(rgb_to_hvi_kernel, dim3(nblk(npix)), dim3(256), 0, (hipStream_t)stream, x, hvi, npix, density_k, eps);
+    IE_LAUNCH_CHECK();
+    return IE_OK;
+}
+IE_EXPORT int ie_hvi_to_rgb_nhwc_f32(const float* hvi, float* rgb, size_t npix, float density_k, float eps, int clamp01, void* stream) {
+    if (!hvi || !rgb || npix == 0) IE_FAIL(IE_ERR_INVALID, "ie_hvi_to_rgb_nhwc_f32: bad args");
+    hipLaunchKernelGGL(hvi_to_rgb_kernel, dim3(nblk(npix)), dim3(256), 0, (hipStream_t)stream, hvi, rgb, npix, density_k, eps, clamp01);
+    IE_LAUNCH_CHECK();
+    return IE_OK;
+}
 
 IE_EXPORT int ie_rgb_to_hsv_nhwc_f32(const float* x, float* hsv, float* v, size_t npix, float eps, void* stream) {
     if (!x || (!hsv && !v) || npix == 0) IE_FAIL(IE_ERR_INVALID, "ie_rgb_to_hsv_nhwc_f32: bad args");

@@ -566,7 +566,11 @@ class LLLINet(_GraphModel):
         return c(x3, f"{b}.conv4", act="lrelu", slope=0.2, residual=x34)
 
     def forward(self, datapoint: dict, *args, **kwargs) -> dict:
-        x = self._input_any(datapoint)
+        y = self._body(self._input_any(datapoint), clamp=(0.0, 1.0))
+        return OrderedDict(enhanced=ops.to_nchw(y))
+
+    def _body(self, x, clamp):
+        """The UNet++ grid on the network input ``x`` (compute-dtype NHWC) -> ``final``'s output, fp32 NHWC, clamped if asked."""
         if x.shape[2] % 16 or x.shape[3] % 16:
             raise ValueError(f"LLLINet needs H and W divisible by 16 (got {x.shape[2]}x{x.shape[3]}); use infer(), which resizes to a "
                              f"multiple of 32 like the reference (vision/model.py:106).")
@@ -589,8 +593,41 @@ class LLLINet(_GraphModel):
         x1_3 = B("conv1_3", [x1_0, x1_1, x1_2, up(x2_2)])
         x0_3 = B("conv0_3", [x0_0, x0_1, x0_2, up(x1_2), up(x1_3)])
         x0_4 = B("conv0_4", [x0_0, x0_1, x0_2, x0_3, up(x1_3)])
-        y = self._conv(x0_4, "final", pad=0, clamp=(0.0, 1.0), out_f32=True)
-        return OrderedDict(enhanced=ops.to_nchw(y))
+        return self._conv(x0_4, "final", pad=0, clamp=clamp, out_f32=True)
+
+
+@MODELS.register(name="lllinet_hvi", arch="lllinet")
+class LLLINetHVI(LLLINet):
+    """LLLINetHVI (lllinet.py:262-388): the LLLINet grid between ``core.RGBToHVI.rgb_to_hvi`` and ``hvi_to_rgb`` (core/image/color.py:313-434, HVI-CIDNet's colour
+    space; ``ie_rgb_to_hvi_nhwc_f32`` / ``ie_hvi_to_rgb_nhwc_f32``), clamp to [0, 1] behind the inverse transform.  Extra checkpoint key ``trans.density_k`` (the
+    transform's learnable exponent, 0.2); ``hvi_weight`` / ``loss_weights`` are training hyper-parameters read from the checkpoint's dict like the reference does."""
+
+    def __init__(self, in_channels: int = 3, out_channels: int = 3, weights: Any = None, hvi_weight: float = 1.0, loss_weights=None, seed: int = None, *args, **kwargs):
+        kwargs.pop("name", None)
+        super().__init__(in_channels=in_channels, out_channels=out_channels, weights=weights, seed=seed, *args, **kwargs)
+        self.name = self.fullname = "lllinet_hvi"
+        if isinstance(self.weights, dict):
+            hvi_weight = self.weights.get("hvi_weight", hvi_weight)
+            loss_weights = self.weights.get("loss_weights", loss_weights)
+        self.hvi_weight, self.loss_weights = hvi_weight, loss_weights or [0.35, 0.10, 0.25, 0.30]
+
+    def _finish_init(self, seed):
+        self._params["trans.density_k"] = torch.full([1], 0.2)          # before weights are loaded / drawn: it is a checkpoint key
+        super()._finish_init(seed)
+
+    def init_weights(self, seed: int = None):
+        super().init_weights(seed)
+        self._params["trans.density_k"] = torch.full([1], 0.2)
+
+    def rgb_to_hvi(self, x):
+        return ops.rgb_to_hvi(x, float(self._params["trans.density_k"].reshape(-1)[0]))
+
+    def forward(self, datapoint: dict, *args, **kwargs) -> dict:
+        k = float(self._params["trans.density_k"].reshape(-1)[0])
+        hvi = ops.rgb_to_hvi(self._input(datapoint), k)                 # fp32 NHWC
+        x = hvi if self.compute_dtype == "f32" else ops.cast(hvi, self._tdt, 8)
+        y = self._body(x, clamp=None)
+        return OrderedDict(enhanced=ops.to_nchw(ops.hvi_to_rgb(y, k, clamp01=True)))
 
 
 # ----------------------------------------------------------------------------------------------------------------

@@ -408,6 +408,31 @@ def rgb_to_hsv(x, eps=1e-8, want_hsv=True, want_v=True):
     return hsv, v
 
 
+def rgb_to_hvi(x, density_k=0.2, eps=1e-8):
+    """core.RGBToHVI.rgb_to_hvi on an fp32 NHWC RGB tensor (ie_rgb_to_hvi_nhwc_f32)."""
+    _chk(x)
+    n, c, h, w = x.shape
+    if c != 3:
+        raise ValueError(f"rgb_to_hvi needs 3 channels, got {c}")
+    y = empty_nhwc(n, 3, h, w, x.device)
+    with torch.cuda.device(x.device):
+        capi.check(capi.lib().ie_rgb_to_hvi_nhwc_f32(capi.ptr(x), capi.ptr(y), n * h * w, float(density_k), float(eps), capi.current_stream()), "ie_rgb_to_hvi_nhwc_f32")
+    return y
+
+
+def hvi_to_rgb(x, density_k=0.2, eps=1e-8, clamp01=False):
+    """core.RGBToHVI.hvi_to_rgb (+ optional clamp to [0, 1]) on an fp32 NHWC tensor (ie_hvi_to_rgb_nhwc_f32)."""
+    _chk(x)
+    n, c, h, w = x.shape
+    if c != 3:
+        raise ValueError(f"hvi_to_rgb needs 3 channels, got {c}")
+    y = empty_nhwc(n, 3, h, w, x.device)
+    with torch.cuda.device(x.device):
+        capi.check(capi.lib().ie_hvi_to_rgb_nhwc_f32(capi.ptr(x), capi.ptr(y), n * h * w, float(density_k), float(eps), int(bool(clamp01)), capi.current_stream()),
+                   "ie_hvi_to_rgb_nhwc_f32")
+    return y
+
+
 def hsv_to_rgb(hsv, v_new=None):
     _chk(hsv)
     n, c, h, w = hsv.shape

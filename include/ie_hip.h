@@ -430,6 +430,10 @@ int ie_rgb_to_hsv_nhwc_f32(const float* rgb_dev, float* hsv_dev, float* v_dev, s
 /* core.hsv_to_rgb (:274-291 -> kornia.color.hsv_to_rgb); v_new_dev (1 ch, may be NULL) replaces the V channel first
  * (ZeroDCEV.replace_v_component, zero_dce_v.py:225-230). */
 int ie_hsv_to_rgb_nhwc_f32(const float* hsv_dev, const float* v_new_dev, float* rgb_dev, size_t npix, void* stream);
+/* core.RGBToHVI (src/mon/core/image/color.py:313-434, the HVI-CIDNet colour transform LLLINetHVI wraps its network in, lllinet.py:360-385): rgb_to_hvi and
+ * hvi_to_rgb on fp32 NHWC 3-channel tensors; density_k = the module's learnable `density_k` (0.2), eps 1e-8; clamp01: the clamp(0, 1) the model applies behind it. */
+int ie_rgb_to_hvi_nhwc_f32(const float* x_dev, float* hvi_dev, size_t npix, float density_k, float eps, void* stream);
+int ie_hvi_to_rgb_nhwc_f32(const float* hvi_dev, float* rgb_dev, size_t npix, float density_k, float eps, int clamp01, void* stream);
 /* y <- y + r_k (y^2 - y), k < iters, on a C-channel NHWC image with Ca = C*iters curve maps (Ca == C: one shared map);
  * bam_dev (1 ch, may be NULL): GCENet's brightness-attention form, gcenet.py:478-484 (bright = y (1 - bam), dark = y bam,
  * y = bright + dark + r (dark^2 - dark)). */

@@ -5,6 +5,7 @@
   llunetpp_forward     src/mon/vision/enhance/llie/llunetpp/llunetpp.py:97-137, 218-243
                        PINNED by tests/golden/llunetpp_*.npz (reference file mon_extra/.../llunet++/model.py)
   lllinet_forward      src/mon/vision/enhance/llie/lllinet/lllinet.py:97-260 (+ normalization.py:177-224, attention.py:1156-1182): parity unpinned.
+  lllinet_hvi_forward  lllinet.py:262-388 + core/image/color.py:313-434 (RGBToHVI): parity unpinned (the transform lives in `mon.core`, not importable here).
   unet_forward         src/mon/vision/segment/unet/unet.py:35-197 with line 51's typo read as conv1; eval-mode BN.
                        PINNED by tests/golden/unet_mtfe_*.npz: the reference tree's pure-torch twin of the same topology,
                        mon_extra/vision/enhance/llie/mtfe/unet_model.py + unet_parts.py (bilinear and ConvTranspose2d decoders,
@@ -149,8 +150,8 @@ def _lllinet_block(sd, b, x):
     return F.leaky_relu(_c(sd, f"{b}.conv4", x3), 0.2) + x34
 
 
-def lllinet_forward(sd: dict, x: torch.Tensor) -> dict:
-    """lllinet.py:229-260."""
+def lllinet_forward(sd: dict, x: torch.Tensor, clamp: bool = True) -> dict:
+    """lllinet.py:229-260 (``clamp=False``: the body alone, for LLLINetHVI which clamps behind its colour transform)."""
     B = lambda n, t: _lllinet_block(sd, n, t)
     pool = lambda t: F.max_pool2d(t, 2, 2)
     up = lambda t: F.interpolate(t, scale_factor=2, mode="bilinear", align_corners=True)
@@ -167,7 +168,61 @@ def lllinet_forward(sd: dict, x: torch.Tensor) -> dict:
     x1_3 = B("conv1_3", cat(x1_0, x1_1, x1_2, up(x2_2)))
     x0_3 = B("conv0_3", cat(x0_0, x0_1, x0_2, up(x1_2), up(x1_3)))
     x0_4 = B("conv0_4", cat(x0_0, x0_1, x0_2, x0_3, up(x1_3)))
-    return {"enhanced": torch.clamp(_c(sd, "final", x0_4, padding=0), 0, 1)}
+    y = _c(sd, "final", x0_4, padding=0)
+    return {"enhanced": torch.clamp(y, 0, 1) if clamp else y}
+
+
+# ---- HVI colour transform (core/image/color.py:313-434) and LLLINetHVI (lllinet.py:262-388) ---------------------------------------------
+def rgb_to_hvi(image: torch.Tensor, density_k: float = 0.2, eps: float = 1e-8) -> torch.Tensor:
+    """color.py:332-361, statement by statement (the masked assignments in the reference's order: the last match wins)."""
+    pi = 3.141592653589793
+    value = image.max(1)[0]
+    img_min = image.min(1)[0]
+    hue = torch.zeros_like(value)
+    m = image[:, 2] == value
+    hue[m] = 4.0 + ((image[:, 0] - image[:, 1]) / (value - img_min + eps))[m]
+    m = image[:, 1] == value
+    hue[m] = 2.0 + ((image[:, 2] - image[:, 0]) / (value - img_min + eps))[m]
+    m = image[:, 0] == value
+    hue[m] = (0.0 + ((image[:, 1] - image[:, 2]) / (value - img_min + eps))[m]) % 6
+    hue[img_min == value] = 0.0
+    hue = hue / 6.0
+    saturation = (value - img_min) / (value + eps)
+    saturation[value == 0] = 0
+    hue, saturation, value = hue.unsqueeze(1), saturation.unsqueeze(1), value.unsqueeze(1)
+    k = torch.full([1], density_k)
+    color_sensitive = ((value * 0.5 * pi).sin() + eps).pow(k)
+    cx, cy = (2.0 * pi * hue).cos(), (2.0 * pi * hue).sin()
+    return torch.cat([color_sensitive * saturation * cx, color_sensitive * saturation * cy, value], dim=1)
+
+
+def hvi_to_rgb(image: torch.Tensor, density_k: float = 0.2, eps: float = 1e-8) -> torch.Tensor:
+    """color.py:363-434 with gated = gated2 = False (as constructed); ``this_k`` = density_k.item()."""
+    pi = 3.141592653589793
+    H, V, I = image[:, 0], image[:, 1], image[:, 2]
+    H, V, I = torch.clamp(H, -1, 1), torch.clamp(V, -1, 1), torch.clamp(I, 0, 1)
+    v = I
+    color_sensitive = ((v * 0.5 * pi).sin() + eps).pow(density_k)
+    H = torch.clamp(H / (color_sensitive + eps), -1, 1)
+    V = torch.clamp(V / (color_sensitive + eps), -1, 1)
+    h = (torch.atan2(V, H) / (2 * pi)) % 1
+    s = torch.clamp(torch.sqrt(H ** 2 + V ** 2), 0, 1)
+    v = torch.clamp(v, 0, 1)
+    r, g, b = torch.zeros_like(h), torch.zeros_like(h), torch.zeros_like(h)
+    hi = torch.floor(h * 6.0)
+    f = h * 6.0 - hi
+    p, q, t = v * (1. - s), v * (1. - (f * s)), v * (1. - ((1. - f) * s))
+    for k, (rr, gg, bb) in enumerate([(v, t, p), (q, v, p), (p, v, t), (p, q, v), (t, p, v), (v, p, q)]):
+        m = hi == k
+        r[m], g[m], b[m] = rr[m], gg[m], bb[m]
+    return torch.stack([r, g, b], dim=1)
+
+
+def lllinet_hvi_forward(sd: dict, x: torch.Tensor) -> dict:
+    """lllinet.py:360-385: the LLLINet body on rgb_to_hvi(x), its (unclamped) output through hvi_to_rgb, clamp to [0, 1]."""
+    k = float(sd["trans.density_k"].reshape(-1)[0]) if "trans.density_k" in sd else 0.2
+    y = lllinet_forward(sd, rgb_to_hvi(x, k), clamp=False)["enhanced"]
+    return {"enhanced": torch.clamp(hvi_to_rgb(y, k), 0, 1), "hvi": rgb_to_hvi(x, k)}
 
 
 # ---- U-Net ----------------------------------------------------------------------------------------------------

@@ -562,6 +562,46 @@ def test_1080p_properties_unet32_retinexnet(cfg):
         assert torch.equal(crop[:, :, 10:-10, 10:-10], a["reflectance"][:1, :, 410:550, 710:990])
 
 
+def test_lllinet_hvi_vs_oracle():
+    """`lllinet_hvi` (lllinet.py:262-388): the HVI colour transform pair (core/image/color.py:313-434) against its restatement -- grey pixels, black pixels,
+    every hue sector, out-of-range inputs of the inverse -- and the model (transform -> LLLINet grid -> inverse -> clamp) on both execution paths."""
+    g = torch.Generator().manual_seed(21)
+    x = torch.rand(2, 3, 24, 40, generator=g)
+    x[0, :, 0, :8] = x[0, :1, 0, :8]                 # grey pixels: min == max
+    x[0, :, 1, :8] = 0.0                             # black pixels
+    x[1, 0, 2, :8] = 1.0                             # R is the maximum (the `% 6` branch, negative hue before the modulo where G < B)
+    hvi = ops.to_nchw(ops.rgb_to_hvi(ops.to_nhwc(x.cuda()), 0.2)).cpu()
+    assert (hvi - og.rgb_to_hvi(x, 0.2)).abs().max() <= 2e-6
+    y = torch.randn(2, 3, 24, 40, generator=g) * 0.8
+    y[:, 2] = y[:, 2].abs()
+    got = ops.to_nchw(ops.hvi_to_rgb(ops.to_nhwc(y.cuda()), 0.2)).cpu()
+    want = og.hvi_to_rgb(y, 0.2)
+    # the inverse is discontinuous where h * 6 crosses an integer: compare away from those pixels (1 ulp of atan2 decides the sector there)
+    pi = 3.141592653589793
+    Hc, Vc, v = y[:, 0].clamp(-1, 1), y[:, 1].clamp(-1, 1), y[:, 2].clamp(0, 1)
+    cs = ((v * 0.5 * pi).sin() + 1e-8).pow(0.2)
+    h6 = ((torch.atan2((Vc / (cs + 1e-8)).clamp(-1, 1), (Hc / (cs + 1e-8)).clamp(-1, 1)) / (2 * pi)) % 1) * 6
+    safe = ((h6 - h6.round()).abs() > 1e-4).unsqueeze(1).expand_as(got)
+    assert float(safe.float().mean()) > 0.99 and (got - want)[safe].abs().max() <= 5e-6
+    assert torch.equal(ops.to_nchw(ops.hvi_to_rgb(ops.to_nhwc(y.cuda()), 0.2, clamp01=True)).cpu(), got.clamp(0, 1))
+    # round trip on in-gamut colours
+    back = ops.to_nchw(ops.hvi_to_rgb(ops.rgb_to_hvi(ops.to_nhwc(x.cuda()), 0.2), 0.2)).cpu()
+    assert (back - x).abs().max() <= 2e-5
+    m = mon_amd.MODELS.build(name="lllinet_hvi", seed=9).to("cuda")
+    assert m.name == "lllinet_hvi" and "trans.density_k" in m.state_dict()
+    sd = m.state_dict()
+    img = _smooth(1, 3, 32, 48, seed=4, lo=0.05, hi=0.9)
+    ref = og.lllinet_hvi_forward(sd, img)["enhanced"]
+    out = m.forward({"image": img.cuda()})["enhanced"].cpu()
+    assert tuple(out.shape) == (1, 3, 32, 48) and float(out.min()) >= 0.0 and float(out.max()) <= 1.0
+    assert rel_err(out, ref) <= 1e-3
+    sd2 = dict(sd); sd2["trans.density_k"] = torch.full([1], 0.35)
+    m2 = mon_amd.MODELS.build(name="lllinet_hvi", weights=sd2).to("cuda")
+    assert rel_err(m2.forward({"image": img.cuda()})["enhanced"].cpu(), og.lllinet_hvi_forward(sd2, img)["enhanced"]) <= 1e-3
+    m16 = mon_amd.MODELS.build(name="lllinet_hvi", weights=dict(sd), compute_dtype="f16").to("cuda")
+    assert rel_err(m16.forward({"image": img.cuda()})["enhanced"].cpu(), ref) <= 3e-2
+
+
 def test_lllinet_vs_oracle_and_stat_layers():
     """LLLINet (learnable instance norm, SimAM, dense UNet++ wiring) against the restated reference forward; the statistics layers
     on their own against torch; the channel-attention pieces (global average pool + per-channel rescale, mprnet.py:51-82)."""
