@@ -38,7 +38,8 @@ struct PairParams {
     const void* src; const void* wa; const float* ba; const void* wb; const float* bb; void* dst;
     int N, H, W, rows_per_block, strips, chunks, replicate;
     int cout_b, act_b;       // thin second layer (CB == 16): its real output channels (4, 8, 12 or 16) and activation; dst is fp32 NHWC then
-    void* dst16;             // thin: optional second copy of the output as 16-bit NHWC padded to 8 channels (cout_b == 4), or null
+    void* dst16;             // thin: optional second copy of the output as 16-bit NHWC (cout_b == 4), with dst16_c = 4 channels or padded to 8, or null
+    int dst16_c;
 };
 
 __device__ __forceinline__ void wait_vm_cold(int n) {
@@ -289,9 +290,10 @@ __device__ __forceinline__ void sconv3x2_body(const PairParams& p) {
             const int q = 16 * (2 * cf + j) + p16, x = xc0 + q;
             const bool ok = q >= 1 && q <= TS && x < W;
             st_f32[j] = (ok && 4 * kq < p.cout_b) ? (unsigned)(x * p.cout_b * 4 + kq * 16) : OOB;
-            st_16[j] = (ok && kq == 0) ? (unsigned)(x * 16) : OOB;
+            st_16[j] = (ok && kq == 0) ? (unsigned)(x * 2 * p.dst16_c) : OOB;
         }
-        const size_t f16_b = (size_t)H * W * 16;
+        const size_t f16_b = (size_t)H * W * 2 * p.dst16_c;
+        const bool wide16 = p.dst16_c == 8;
         const auto rsD16 = mk(p.dst16 ? (char*)p.dst16 + (size_t)n * f16_b : (char*)p.dst, p.dst16 ? f16_b : 0);
         const bool dual = p.dst16 != nullptr;
         const int act = p.act_b;
@@ -314,9 +316,11 @@ __device__ __forceinline__ void sconv3x2_body(const PairParams& p) {
                         v[i] = act == IE_ACT_SIGMOID ? ie_sigmoid_fast(a) : act == IE_ACT_TANH ? ie_tanh_fast(a) : act == IE_ACT_RELU ? fmaxf(a, 0.f) : a;
                     }
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ie_u32x4, v), rsD, (int)((yrow * (unsigned)(p.cout_b * 4) + st_f32[j]) | rmask), 0, 0);
-                    if (dual)
-                        __builtin_amdgcn_raw_buffer_store_b128(ie_u32x4{ie_pack2<T>(v[0], v[1]), ie_pack2<T>(v[2], v[3]), 0u, 0u}, rsD16,
-                                                               (int)((yrow * 16u + st_16[j]) | rmask), 0, 0);
+                    if (dual) {          // wave-uniform
+                        const unsigned o16 = (yrow * (unsigned)(2 * p.dst16_c) + st_16[j]) | rmask;
+                        if (wide16) __builtin_amdgcn_raw_buffer_store_b128(ie_u32x4{ie_pack2<T>(v[0], v[1]), ie_pack2<T>(v[2], v[3]), 0u, 0u}, rsD16, (int)o16, 0, 0);
+                        else __builtin_amdgcn_raw_buffer_store_b64(ie_u32x2{ie_pack2<T>(v[0], v[1]), ie_pack2<T>(v[2], v[3])}, rsD16, (int)o16, 0, 0);
+                    }
                 }
             }
             int mc = ys - 5 + t;
@@ -373,7 +377,7 @@ __global__ __launch_bounds__(512) void sconv3x2_bf16_c64_c64_thin_f32(PairParams
 // cout_b = 64: as above.  cout_b in {4, 8, 12, 16}: the second layer is thin -- dst is fp32 NHWC with cout_b channels, act_b its activation (none / relu /
 // sigmoid / tanh), dst16 an optional 16-bit NHWC copy padded to 8 channels (cout_b == 4).
 int ie_sconv3x2_launch(const void* src, const void* w_a, const float* bias_a, const void* w_b, const float* bias_b, void* dst, int dtype, int N, int H, int W,
-                       int pad_mode, int cout_b, int act_b, void* dst16, hipStream_t st) {
+                       int pad_mode, int cout_b, int act_b, void* dst16, int dst16_c, hipStream_t st) {
     if (!src || !w_a || !w_b || !dst || N <= 0 || H < 1 || W < 64) IE_FAIL(IE_ERR_UNSUPPORTED, "ie_sconv3x2: 64 channels, W >= 64");
     const bool thin = cout_b != 64;
     if (thin && (cout_b < 4 || cout_b > 16 || (cout_b & 3) || (dst16 && cout_b != 4)))
@@ -385,7 +389,7 @@ int ie_sconv3x2_launch(const void* src, const void* w_a, const float* bias_a, co
     PairParams p;
     memset(&p, 0, sizeof(p));
     p.src = src; p.wa = w_a; p.ba = bias_a; p.wb = w_b; p.bb = bias_b; p.dst = dst; p.N = N; p.H = H; p.W = W; p.replicate = pad_mode == IE_PAD_REPLICATE;
-    p.cout_b = cout_b; p.act_b = act_b; p.dst16 = thin ? dst16 : nullptr;
+    p.cout_b = cout_b; p.act_b = act_b; p.dst16 = thin ? dst16 : nullptr; p.dst16_c = dst16_c == 4 ? 4 : 8;
     p.strips = ie_cdiv(W, TS);
     {
         // row chunks: whole rounds of the chip's 256 workgroup slots (one 8-wave workgroup per CU), few apron rows (8 steps per chunk)
@@ -430,7 +434,7 @@ IE_EXPORT int ie_mconv_pair_applicable(int cin, int cmid, int cout, int kh, int 
 IE_EXPORT int ie_mconv_pair_nhwc(const void* src, const void* packed_w_a, const float* bias_a, const void* packed_w_b, const float* bias_b, void* dst,
                                  int dtype, int N, int H, int W, int pad_mode, void* stream) {
     if (pad_mode != IE_PAD_ZEROS && pad_mode != IE_PAD_REPLICATE) IE_FAIL(IE_ERR_INVALID, "ie_mconv_pair_nhwc: pad_mode %d", pad_mode);
-    return ie_sconv3x2_launch(src, packed_w_a, bias_a, packed_w_b, bias_b, dst, dtype, N, H, W, pad_mode, 64, IE_ACT_RELU, nullptr, (hipStream_t)stream);
+    return ie_sconv3x2_launch(src, packed_w_a, bias_a, packed_w_b, bias_b, dst, dtype, N, H, W, pad_mode, 64, IE_ACT_RELU, nullptr, 8, (hipStream_t)stream);
 }
 
 IE_EXPORT int ie_mconv_pair_thin_applicable(int cin, int cmid, int cout, int kh, int kw, int stride, int pad, int pad_mode, int act_a, int act_b, int W) {
@@ -441,8 +445,9 @@ IE_EXPORT int ie_mconv_pair_thin_applicable(int cin, int cmid, int cout, int kh,
 }
 
 IE_EXPORT int ie_mconv_pair_thin_nhwc(const void* src, const void* packed_w_a, const float* bias_a, const void* packed_w_b, const float* bias_b, float* dst_f32,
-                                      void* dst16_8ch, int dtype, int N, int H, int W, int cout_b, int act_b, int pad_mode, void* stream) {
+                                      void* dst16, int dst16_channels, int dtype, int N, int H, int W, int cout_b, int act_b, int pad_mode, void* stream) {
     if (pad_mode != IE_PAD_ZEROS && pad_mode != IE_PAD_REPLICATE) IE_FAIL(IE_ERR_INVALID, "ie_mconv_pair_thin_nhwc: pad_mode %d", pad_mode);
     if (cout_b == 64) IE_FAIL(IE_ERR_INVALID, "ie_mconv_pair_thin_nhwc: 64 output channels is ie_mconv_pair_nhwc");
-    return ie_sconv3x2_launch(src, packed_w_a, bias_a, packed_w_b, bias_b, dst_f32, dtype, N, H, W, pad_mode, cout_b, act_b, dst16_8ch, (hipStream_t)stream);
+    if (dst16 && dst16_channels != 4 && dst16_channels != 8) IE_FAIL(IE_ERR_INVALID, "ie_mconv_pair_thin_nhwc: the 16-bit copy has 4 or 8 channels");
+    return ie_sconv3x2_launch(src, packed_w_a, bias_a, packed_w_b, bias_b, dst_f32, dtype, N, H, W, pad_mode, cout_b, act_b, dst16, dst16_channels, (hipStream_t)stream);
 }

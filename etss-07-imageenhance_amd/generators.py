@@ -1450,7 +1450,7 @@ class RetinexNet(_GraphModel):
                 self._init_conv(k[:-7], g)
         self._on_params_change()
 
-    def decom(self, x, copy16=False):
+    def decom(self, x, copy16=False, copy16_channels=8):
         """x: fp32 NHWC image (fp32 path) or DecomNet's 16-bit 8-channel input ``[max_c, R, G, B, 0..]`` (16-bit path, ops.retinex_decom_input).
         Returns DecomNet's sigmoid output, fp32 NHWC: channels 0-2 = R, 3 = L; with ``copy16`` also its 16-bit copy padded to 8 channels."""
         R, c = "replicate", self._conv
@@ -1479,17 +1479,25 @@ class RetinexNet(_GraphModel):
             if self.compute_dtype != "f32" and not layers:  # the last 64 -> 64 layer and net1_recon (64 -> 4, sigmoid, fp32 out) in one launch
                 mwa, mwb = self._mw_plain((self.channels,), f"net1_convs.{i}"), self._mw_plain((self.channels,), "net1_recon")
                 if ops.mconv2d_pair_thin_applicable(f, mwa, mwb, pad_mode=R, act_b="sigmoid"):
-                    return ops.mconv2d_pair_thin(f, mwa, mwb, pad_mode=R, act_b="sigmoid", copy16=copy16)
+                    return ops.mconv2d_pair_thin(f, mwa, mwb, pad_mode=R, act_b="sigmoid", copy16=copy16, copy16_channels=copy16_channels)
             f = c(f, f"net1_convs.{i}", pad_mode=R, act="relu")
         # 16-bit path: R and L leave in fp32 (16 bytes per pixel either way): S = R * I_delta multiplies by R itself, not by its 16-bit
         # rounding -- that rounding alone was 7e-4 of the 1e-3 bound (tools/retinex_attrib.py)
         rl = c(f, "net1_recon", pad_mode=R, act="sigmoid", out_f32=self.compute_dtype != "f32")
-        return (rl, ops.cast(rl, self._tdt, 8)) if copy16 else rl
+        return (rl, ops.cast(rl, self._tdt, copy16_channels)) if copy16 else rl
 
     def relight(self, rl):
         """rl: cat(R, L) == the 4-channel sigmoid output of DecomNet (model.py:72)."""
         R, c = "replicate", self._conv
-        out0 = c(rl, "net2_conv0_1", pad_mode=R)
+        if rl.shape[1] == 4 and self.compute_dtype != "f32":        # (R, L) as a 4-channel 16-bit tensor: the first-layer strip kernel at 3x3 (ie_conv_first9.hip)
+            key = ("conv3x3c4", "net2_conv0_1")
+            if self._dev_cache is None:
+                self._dev_cache = {}
+            if key not in self._dev_cache:
+                self._dev_cache[key] = ops.Conv9x9C4Weights(self._params["net2_conv0_1.weight"], self._params["net2_conv0_1.bias"], self._tdt, self.device)
+            out0 = ops.conv9x9_c4(rl, self._dev_cache[key])
+        else:
+            out0 = c(rl, "net2_conv0_1", pad_mode=R)
         out1 = c(out0, "net2_conv1_1", stride=2, pad_mode=R, act="relu")
         out2 = c(out1, "net2_conv1_2", stride=2, pad_mode=R, act="relu")
         out3 = c(out2, "net2_conv1_3", stride=2, pad_mode=R, act="relu")
@@ -1624,7 +1632,7 @@ class RetinexNet(_GraphModel):
             if x.dim() != 4 or x.shape[1] != self.in_channels:
                 raise ValueError(f"`image` must be (N,{self.in_channels},H,W), but got {tuple(x.shape)}.")
             c4 = self.channels == 64 and os.environ.get("IE_RETINEX_CONV9", "1") != "0"      # (IE_RETINEX_CONV9=0: A/B switch back to the tiled thin-source kernel)
-            rl, rl16 = self.decom(ops.retinex_decom_input(x.to(self.device, torch.float32), self._tdt, 4 if c4 else 8), copy16=True)
+            rl, rl16 = self.decom(ops.retinex_decom_input(x.to(self.device, torch.float32), self._tdt, 4 if c4 else 8), copy16=True, copy16_channels=4 if c4 else 8)
             i_delta = self.relight(rl16)
             out["reflectance"], out["illumination"], s = ops.retinex_outputs(rl, i_delta)
             out["illumination_delta"] = i_delta.contiguous()                        # (N,1,H,W): NHWC and NCHW are the same bytes

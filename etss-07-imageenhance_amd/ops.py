@@ -1006,21 +1006,21 @@ def mconv2d_pair_thin_applicable(x, mwa: MConvWeights, mwb: MConvWeights, pad_mo
                                                          int(x.shape[3])))
 
 
-def mconv2d_pair_thin(x, mwa: MConvWeights, mwb: MConvWeights, pad_mode="zeros", act_b="none", copy16=False):
+def mconv2d_pair_thin(x, mwa: MConvWeights, mwb: MConvWeights, pad_mode="zeros", act_b="none", copy16=False, copy16_channels=8):
     """``act_b(conv_b(relu(conv_a(x))))`` in one launch (ie_mconv_pair_thin_nhwc): conv_b has 4 .. 16 output channels and leaves in fp32.
-    ``copy16=True`` (4 output channels only) also returns the output as the compute dtype padded to 8 channels (what the next 16-bit
-    network reads), written by the same launch: ``(out_f32, out16)``."""
+    ``copy16=True`` (4 output channels only) also returns the output as the compute dtype with ``copy16_channels`` = 4 channels or padded
+    to 8 (what the next 16-bit network reads), written by the same launch: ``(out_f32, out16)``."""
     _chk16(x)
     if not mconv2d_pair_thin_applicable(x, mwa, mwb, pad_mode, "relu", act_b):
         raise capi.IEError("mconv2d_pair_thin: Conv3x3(64,64)+ReLU then Conv3x3(64, 4..16) on a 16-bit NHWC tensor with W >= 64")
     n, c, h, w = (int(v) for v in x.shape)
     out = torch.empty((n, mwb.cout, h, w), device=x.device, dtype=torch.float32, memory_format=CL)
-    out16 = torch.empty((n, 8, h, w), device=x.device, dtype=x.dtype, memory_format=CL) if copy16 else None
+    out16 = torch.empty((n, int(copy16_channels), h, w), device=x.device, dtype=x.dtype, memory_format=CL) if copy16 else None
     _count_macs(n, h, w, mwa.cout, c, 3, 3)
     _count_macs(n, h, w, mwb.cout, mwa.cout, 3, 3)
     with torch.cuda.device(x.device):
         capi.check(capi.lib().ie_mconv_pair_thin_nhwc(capi.ptr(x), capi.ptr(mwa.w), capi.ptr(mwa.b), capi.ptr(mwb.w), capi.ptr(mwb.b), capi.ptr(out),
-                                                      capi.ptr(out16) if copy16 else None, IE_DT[x.dtype], n, h, w, mwb.cout, capi.ACT[act_b],
+                                                      capi.ptr(out16) if copy16 else None, int(copy16_channels), IE_DT[x.dtype], n, h, w, mwb.cout, capi.ACT[act_b],
                                                       capi.PAD[pad_mode], capi.current_stream()), "ie_mconv_pair_thin_nhwc")
     return (out, out16) if copy16 else out
 
@@ -1071,31 +1071,32 @@ def retinex_decom_input(x_nchw: torch.Tensor, dtype, channels: int = 8) -> torch
 
 
 class Conv9x9C4Weights:
-    """Fragment image of a Conv2d(4, 64, 9, padding=4, replicate) for ie_conv9x9_c4_nhwc (+ fp32 bias)."""
+    """Fragment image of a Conv2d(4, 64, k, padding=k // 2, replicate), k = 9 or 3, for ie_conv9x9_c4_nhwc / ie_conv3x3_c4_nhwc (+ fp32 bias)."""
 
     def __init__(self, w_oihw: torch.Tensor, bias, dtype, device):
         w = w_oihw.detach().to("cpu", torch.float32).contiguous()
-        if tuple(w.shape) != (64, 4, 9, 9):
-            raise capi.IEError(f"Conv9x9C4Weights: (64, 4, 9, 9) expected, got {tuple(w.shape)}")
-        self.dtype = dtype
+        if tuple(w.shape) not in ((64, 4, 9, 9), (64, 4, 3, 3)):
+            raise capi.IEError(f"Conv9x9C4Weights: (64, 4, 9, 9) or (64, 4, 3, 3) expected, got {tuple(w.shape)}")
+        self.dtype, self.k = dtype, int(w.shape[2])
         L = capi.lib()
-        self.w = torch.empty(int(L.ie_conv9x9_c4_packed_bytes()), device=device, dtype=torch.uint8)
+        nbytes, pack = (L.ie_conv9x9_c4_packed_bytes, L.ie_conv9x9_c4_pack_weights) if self.k == 9 else (L.ie_conv3x3_c4_packed_bytes, L.ie_conv3x3_c4_pack_weights)
+        self.w = torch.empty(int(nbytes()), device=device, dtype=torch.uint8)
         with torch.cuda.device(self.w.device):
-            capi.check(L.ie_conv9x9_c4_pack_weights(capi.ptr(w), IE_DT[dtype], capi.ptr(self.w), capi.current_stream()), "ie_conv9x9_c4_pack_weights")
+            capi.check(pack(capi.ptr(w), IE_DT[dtype], capi.ptr(self.w), capi.current_stream()), "ie_conv%dx%d_c4_pack_weights" % (self.k, self.k))
         self.b = None if bias is None else bias.detach().to(device, torch.float32).contiguous()
 
 
 def conv9x9_c4(x4, cw: Conv9x9C4Weights):
-    """Conv2d(4, 64, 9, padding 4 replicate) on a 4-channel 16-bit NHWC image (ie_conv9x9_c4_nhwc); no activation."""
+    """Conv2d(4, 64, k, padding k // 2 replicate), k = 9 or 3 per the weights, on a 4-channel 16-bit NHWC image (ie_conv9x9_c4_nhwc / ie_conv3x3_c4_nhwc)."""
     _chk16(x4)
     n, c, h, w = (int(v) for v in x4.shape)
     if c != 4 or x4.dtype != cw.dtype:
         raise capi.IEError("conv9x9_c4: a 4-channel NHWC tensor of the weights' dtype")
     out = torch.empty((n, 64, h, w), device=x4.device, dtype=x4.dtype, memory_format=CL)
-    _count_macs(n, h, w, 64, 4, 9, 9)
+    _count_macs(n, h, w, 64, 4, cw.k, cw.k)
+    fn = capi.lib().ie_conv9x9_c4_nhwc if cw.k == 9 else capi.lib().ie_conv3x3_c4_nhwc
     with torch.cuda.device(x4.device):
-        capi.check(capi.lib().ie_conv9x9_c4_nhwc(capi.ptr(x4), capi.ptr(cw.w), capi.ptr(cw.b), capi.ptr(out), IE_DT[x4.dtype], n, h, w, capi.current_stream()),
-                   "ie_conv9x9_c4_nhwc")
+        capi.check(fn(capi.ptr(x4), capi.ptr(cw.w), capi.ptr(cw.b), capi.ptr(out), IE_DT[x4.dtype], n, h, w, capi.current_stream()), "ie_conv%dx%d_c4_nhwc" % (cw.k, cw.k))
     return out
 
 

@@ -218,11 +218,12 @@ int ie_mconv_pair_nhwc(const void* src_dev, const void* packed_w_a_dev, const fl
                        void* dst_dev, int dtype, int N, int H, int W, int pad_mode, void* stream);
 /* The same with a THIN second layer: Conv3x3(C -> C) + ReLU, then Conv3x3(C -> cout_b) + act_b, cout_b in {4, 8, 12, 16}, act_b in none / relu / sigmoid /
  * tanh -- the end of a plain conv stack (reference: DecomNet's last `net1_convs` layer + `net1_recon` + sigmoid, retinexnet/model.py:33-36,52-56).
- * dst_f32: fp32 NHWC with cout_b channels.  dst16_8ch_dev: null, or a second copy of the output as dtype NHWC padded to 8 channels (cout_b == 4 only) -- what
- * the next 16-bit network reads (RelightNet's input), written by the same launch.  fp32 accumulation; agrees with ie_mconv_nhwc x 2 to fp32 rounding. */
+ * dst_f32: fp32 NHWC with cout_b channels.  dst16_dev: null, or a second copy of the output as dtype NHWC with dst16_channels = 4 channels or zero-padded to 8
+ * (cout_b == 4 only) -- what the next 16-bit network reads (RelightNet's input: 4 for ie_conv3x3_c4_nhwc, 8 for ie_mconv_nhwc), written by the same launch.  fp32 accumulation; agrees with ie_mconv_nhwc x 2 to fp32 rounding. */
 int ie_mconv_pair_thin_applicable(int cin, int cmid, int cout, int kh, int kw, int stride, int pad, int pad_mode, int act_a, int act_b, int W);
 int ie_mconv_pair_thin_nhwc(const void* src_dev, const void* packed_w_a_dev, const float* bias_a_dev, const void* packed_w_b_dev, const float* bias_b_dev,
-                            float* dst_f32_dev, void* dst16_8ch_dev, int dtype, int N, int H, int W, int cout_b, int act_b, int pad_mode, void* stream);
+                            float* dst_f32_dev, void* dst16_dev, int dst16_channels, int dtype, int N, int H, int W, int cout_b, int act_b, int pad_mode,
+                            void* stream);
 
 /* Conv2d(4, 64, kernel_size 9, padding 4, padding_mode="replicate") on a 4-channel 16-bit NHWC image (reference: DecomNet's `net1_conv0`,
  * retinexnet/model.py:26, whose input is cat(max_c(x), x)): a strip kernel with K = 8 kx taps x 4 channels per MFMA and nine rotating accumulator sets.
@@ -231,6 +232,11 @@ int ie_mconv_pair_thin_nhwc(const void* src_dev, const void* packed_w_a_dev, con
 size_t ie_conv9x9_c4_packed_bytes(void);
 int ie_conv9x9_c4_pack_weights(const float* w_oihw_host, int dtype, void* dst_dev, void* stream);
 int ie_conv9x9_c4_nhwc(const void* src4_dev, const void* packed_w_dev, const float* bias_dev, void* dst_dev, int dtype, int N, int H, int W, void* stream);
+/* The same kernel at 3x3: Conv2d(4, 64, 3, padding=1, padding_mode="replicate") on a 4-channel image (reference: RelightNet's `net2_conv0_1` on cat(R, L),
+ * retinexnet/model.py:58); weights (64, 4, 3, 3). */
+size_t ie_conv3x3_c4_packed_bytes(void);
+int ie_conv3x3_c4_pack_weights(const float* w_oihw_host, int dtype, void* dst_dev, void* stream);
+int ie_conv3x3_c4_nhwc(const void* src4_dev, const void* packed_w_dev, const float* bias_dev, void* dst_dev, int dtype, int N, int H, int W, void* stream);
 
 /* The last decoder level of a C-channel U-Net + its head in one launch: replaces, in reference terms (unet.py:75-112 `Up.forward`, :186-195 `outc`),
  *   x = cat([skip, up], 1); x = relu(bn(conv3x3(x)))  [2C -> C];  x = relu(bn(conv3x3(x)))  [C -> C];  y = conv1x1(x)  [C -> tail_cout]  (+ clamp)

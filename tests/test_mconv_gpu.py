@@ -168,6 +168,8 @@ def test_stacked_conv_with_thin_second_layer(shape, cout, act, pad_mode, dt):
     if copy16:
         assert tuple(got16.shape) == (n, 8, h, w) and got16.dtype == tdt
         assert torch.equal(got16[:, :cout].float(), got.to(tdt).float()) and not got16[:, cout:].any()
+        _, got4 = ops.mconv2d_pair_thin(x, mwa, mwb, pad_mode=pad_mode, act_b=act, copy16=True, copy16_channels=4)
+        assert tuple(got4.shape) == (n, 4, h, w) and torch.equal(got4, got16[:, :4])
     # against torch on the same 16-bit-rounded intermediate
     pm = "replicate" if pad_mode == "replicate" else "constant"
     cv = lambda t, w_, b_: F.conv2d(F.pad(t, (1, 1, 1, 1), mode=pm), w_, b_)
@@ -262,6 +264,11 @@ def test_first_9x9_conv_on_a_4_channel_image(shape, dt):
     mw = ops.MConvWeights(wt, bias, [8], tdt, "cuda", cin_map=[0, 1, 2, 3, -1, -1, -1, -1])
     old = ops.mconv2d(x8, mw, pad=4, pad_mode="replicate")
     assert rel_err(got.float().cpu(), old.float().cpu()) <= (1e-3 if dt == "f16" else 8e-3)
+    # the same kernel at 3x3 (RelightNet's first layer, model.py:58)
+    w3 = (torch.randn(64, 4, 3, 3, generator=g) / 6.0).to(tdt).float()
+    got3 = ops.conv9x9_c4(x4, ops.Conv9x9C4Weights(w3, bias, tdt, "cuda"))
+    ref3 = F.conv2d(F.pad(x4.float().cpu(), (1, 1, 1, 1), mode="replicate"), w3, bias)
+    assert rel_err(got3.float().cpu(), ref3) <= (1e-3 if dt == "f16" else 8e-3)
 
 
 @pytest.mark.parametrize("dt", ["f16", "bf16"])
