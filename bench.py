@@ -98,12 +98,41 @@ def _conv_census(torch, ops, fn):
         r[2] += 2.0 * out.shape[0] * out.shape[2] * out.shape[3] * 9 * (int(x.shape[1]) * mwa.cout + mwa.cout * mwb.cout)
         return out
 
-    ops.mconv2d, ops.mconv2d_pair = logged, logged_pair
+    def timed(key, flop, call):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = call()
+        e1.record()
+        e1.synchronize()
+        r = rec.setdefault(key, [0, 0.0, 0.0])
+        r[0] += 1
+        r[1] += e0.elapsed_time(e1)
+        r[2] += flop
+        return out
+
+    orig_thin, orig_k, orig_up = ops.mconv2d_pair_thin, ops.conv9x9_c4, ops.unet_up_head
+
+    def logged_thin(x, mwa, mwb, **kw):                     # Conv3x3(C, C) + ReLU and a thin Conv3x3 behind it (ie_mconv_pair_thin_nhwc)
+        px = float(x.shape[0] * x.shape[2] * x.shape[3])
+        return timed("pair of conv3x3 {}->{}->{} @{}x{} (ie_mconv_pair_thin_nhwc)".format(int(x.shape[1]), mwa.cout, mwb.cout, int(x.shape[2]), int(x.shape[3])),
+                     2.0 * px * 9 * (int(x.shape[1]) * mwa.cout + mwa.cout * mwb.cout), lambda: orig_thin(x, mwa, mwb, **kw))
+
+    def logged_k(x4, cw):                                   # first layer on a 4-channel image (ie_conv9x9_c4_nhwc / ie_conv3x3_c4_nhwc)
+        px = float(x4.shape[0] * x4.shape[2] * x4.shape[3])
+        return timed("conv{0}x{0} 4->64 @{1}x{2} (ie_conv{0}x{0}_c4_nhwc)".format(cw.k, int(x4.shape[2]), int(x4.shape[3])), 2.0 * px * 64 * 4 * cw.k * cw.k,
+                     lambda: orig_k(x4, cw))
+
+    def logged_up(skip, up, mwa, mwb, tail, clamp=None):    # U-Net's last decoder level + head (ie_unet_up_head_nhwc)
+        px, c = float(skip.shape[0] * skip.shape[2] * skip.shape[3]), int(skip.shape[1])
+        return timed("up-sample + cat + DoubleConv({}->{}->{}) + 1x1 head @{}x{} (ie_unet_up_head_nhwc)".format(2 * c, c, c, int(skip.shape[2]), int(skip.shape[3])),
+                     2.0 * px * (9 * (2 * c * c + c * c) + c * tail.cout), lambda: orig_up(skip, up, mwa, mwb, tail, clamp=clamp))
+
+    ops.mconv2d, ops.mconv2d_pair, ops.mconv2d_pair_thin, ops.conv9x9_c4, ops.unet_up_head = logged, logged_pair, logged_thin, logged_k, logged_up
     try:
         fn()
         torch.cuda.synchronize()
     finally:
-        ops.mconv2d, ops.mconv2d_pair = orig, orig_pair
+        ops.mconv2d, ops.mconv2d_pair, ops.mconv2d_pair_thin, ops.conv9x9_c4, ops.unet_up_head = orig, orig_pair, orig_thin, orig_k, orig_up
     return rec
 
 
