@@ -68,6 +68,32 @@ __device__ __forceinline__ ie_u32x4 blend8(ie_u32x4 va, ie_u32x4 vb, ie_u32x4 vc
     }
     return o;
 }
+// fp16: the same sum as two v_dot2_f32_f16 per value pair -- (a, b) . (w00, w01) + (c, d) . (w10, w11), exact products, fp32 accumulation, one rounding of the
+// result -- on operands paired by v_perm_b32: 9 instructions per dword instead of 17.  The four weights enter as fp16 (the blend's weights are in [0, 1]: 2^-12
+// relative), which raises the rms error of an up-sampled value from 1.39e-4 to 1.94e-4 of full scale, its maximum unchanged (one fp16 ulp); the arithmetic of the
+// blend is 6 % of the whole U-Net-32 forward (1,415 - 1,437 frames/s at batch 32 with it against 1,507 - 1,522 without any: profiles/r03/updc_experiments.log).
+#ifndef IE_UPDC_DOT2
+#define IE_UPDC_DOT2 1
+#endif
+#if IE_UPDC_DOT2
+template <>
+__device__ __forceinline__ ie_u32x4 blend8<_Float16>(ie_u32x4 va, ie_u32x4 vb, ie_u32x4 vc, ie_u32x4 vd, float w00, float w01, float w10, float w11) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+    const h2 wab = __builtin_bit_cast(h2, ie_pack2<_Float16>(w00, w01)), wcd = __builtin_bit_cast(h2, ie_pack2<_Float16>(w10, w11));
+    ie_u32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned a = va[k], b = vb[k], c = vc[k], d = vd[k];
+        const h2 ab_lo = __builtin_bit_cast(h2, __builtin_amdgcn_perm(b, a, 0x05040100u)), ab_hi = __builtin_bit_cast(h2, __builtin_amdgcn_perm(b, a, 0x07060302u));
+        const h2 cd_lo = __builtin_bit_cast(h2, __builtin_amdgcn_perm(d, c, 0x05040100u)), cd_hi = __builtin_bit_cast(h2, __builtin_amdgcn_perm(d, c, 0x07060302u));
+        const float l = __builtin_amdgcn_fdot2(ab_lo, wab, __builtin_amdgcn_fdot2(cd_lo, wcd, 0.f, false), false);
+        const float u = __builtin_amdgcn_fdot2(ab_hi, wab, __builtin_amdgcn_fdot2(cd_hi, wcd, 0.f, false), false);
+        o[k] = ie_pack2<_Float16>(l, u);
+    }
+    return o;
+}
+#endif
+
 template <typename T, bool BILIN>
 __device__ __forceinline__ void updc_body(const UpdcParams& p) {
     using frag = ie_u32x4;
@@ -328,7 +354,12 @@ __device__ __forceinline__ void updc_body(const UpdcParams& p) {
                 const ie_u32x4 va = *(const ie_u32x4*)(r0 + lo0[e]), vb = *(const ie_u32x4*)(r0 + lo1[e]);
                 const ie_u32x4 vc = *(const ie_u32x4*)(r1 + lo0[e]), vd = *(const ie_u32x4*)(r1 + lo1[e]);
                 const float w00 = wy0 * cw0[e], w01 = wy0 * cw1[e], w10 = wy1 * cw0[e], w11 = wy1 * cw1[e];
+#if defined(IE_UPDC_EXP) && IE_UPDC_EXP == 1       // timing experiment: no blend arithmetic (wrong results)
+                const ie_u32x4 o = va ^ vb ^ vc ^ vd;
+                (void)w00; (void)w01; (void)w10; (void)w11;
+#else
                 const ie_u32x4 o = blend8<T>(va, vb, vc, vd, w00, w01, w10, w11);
+#endif
                 *(ie_u32x4*)(aslot + rw[e]) = o;
             }
         };

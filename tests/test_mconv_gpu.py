@@ -234,7 +234,9 @@ def test_unet_last_level_with_the_upsampling_inside(shape, dt):
     up = ops.upsample2x_bilinear(low)
     want = ops.unet_up_head(skip, up, mwa, mwb, tail, clamp=(0.0, 1.0))
     assert tuple(got.shape) == (n, 3, h, w)
-    assert rel_err(got.cpu(), want.cpu()) <= (1e-3 if dt == "f16" else 2e-2)       # bf16: a flipped up-sampled value is 4e-3 of itself
+    # fp16: the in-kernel blend takes its four weights as fp16 (v_dot2_f32_f16): an up-sampled value differs from ie_resize_nhwc's by up to one fp16 ulp;
+    # bf16: fp32 weights, a flipped up-sampled value is 4e-3 of itself
+    assert rel_err(got.cpu(), want.cpu()) <= (2e-3 if dt == "f16" else 2e-2)
     upr = F.interpolate(low.float().cpu(), scale_factor=2, mode="bilinear", align_corners=True).to(tdt).float()
     ref = F.relu(F.conv2d(torch.cat([skip.float().cpu(), upr], 1), wa, mwa.b.cpu(), padding=1)).to(tdt).float()
     ref = F.conv2d(F.relu(F.conv2d(ref, wb, mwb.b.cpu(), padding=1)).to(tdt).float(), w1, b1).clamp(0.0, 1.0)
