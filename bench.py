@@ -57,6 +57,8 @@ WORKLOADS = {
     "zero_dce": dict(batch=BATCH_PER_GPU, dtype="bf16"),
     "retinexnet": dict(batch=32, dtype="f16", gflop_per_frame=1374.5, model=dict(name="retinexnet"),
                        what="retinexnet batch={n}/GPU 1920x1080 (BASELINE.json configs[3]: 256 frames over 8 GPUs)"),
+    "unet32": dict(batch=32, dtype="f16", gflop_per_frame=634.5, model=dict(name="unet", base_channels=32, num_classes=3, enhance=True), oracle="unet",
+                   what="unet32 (bilinear decoder, enhance head) batch={n}/GPU 1920x1080 (BASELINE.json configs[2])"),
     "unet64_train": dict(batch=8, dtype="bf16", gflop_per_frame=3 * 2530.0, model=dict(name="unet", base_channels=64, num_classes=3, enhance=True),
                          what="unet64 training step (L1+SSIM, Adam, clip 0.1) batch={n}/GPU 1920x1080 (BASELINE.json configs[4])"),
 }
@@ -137,7 +139,7 @@ def _conv_census(torch, ops, fn):
 
 
 def run_generator_workload(args, ctx):
-    """`--workload retinexnet | unet64_train`: the same contract as the headline (W untimed + K timed steps between barriers,
+    """`--workload unet32 | retinexnet | unet64_train`: the same contract as the headline (W untimed + K timed steps between barriers,
     max over ranks, whole-job frames/s), one JSON line on rank 0."""
     torch, mon_amd, dist, dev, rank, world = ctx["torch"], ctx["mon_amd"], ctx["dist"], ctx["dev"], ctx["rank"], ctx["world"]
     from mon_amd import ops
@@ -211,7 +213,7 @@ def run_generator_workload(args, ctx):
         key, (calls, ms, flop) = max(rec.items(), key=lambda kv: kv[1][1])
         tot = sum(r[1] for r in rec.values())
         ach = flop / (ms * 1e-3) / 1e12
-        roofline.update({"kernel": key if key.startswith("pair") else "ie_mconv_nhwc " + key, "achieved": round(ach, 1), "frac": round(ach / PEAK_MFMA_TFLOPS, 4),
+        roofline.update({"kernel": key if "(ie_" in key else "ie_mconv_nhwc " + key, "achieved": round(ach, 1), "frac": round(ach / PEAK_MFMA_TFLOPS, 4),
                          "avg_launch_ms": round(ms / calls, 4), "launches_per_step": calls, "share_of_conv_time": round(ms / tot, 3),
                          "conv_ms_per_step": round(tot, 2),
                          "note": "dominant conv shape of the step: algorithmic FLOPs (2*MAC) / HIP-event time around its ie_mconv_nhwc calls"
@@ -238,14 +240,18 @@ def run_generator_workload(args, ctx):
         else:
             xs_ = x[:1].cpu()
             sd_ = {k: v.clone() for k, v in model.state_dict().items()}
+            if wl.get("oracle") == "unet":
+                o_fwd, o_name = (lambda sd__, t_: {"enhanced": o_gen.unet_forward(sd__, t_, enhance=True)["enhanced"]}), "unet_forward"
+            else:
+                o_fwd, o_name = o_gen.retinexnet_forward, "retinexnet_forward"
             with torch.no_grad():
-                o_gen.retinexnet_forward(sd_, xs_[:, :, :64, :64])
+                o_fwd(sd_, xs_[:, :, :64, :64])
                 t0 = time.perf_counter()
-                ref = o_gen.retinexnet_forward(sd_, xs_)["enhanced"]
+                ref = o_fwd(sd_, xs_)["enhanced"]
                 sec = time.perf_counter() - t0
             got = model.forward({"image": x[:1]})["enhanced"].cpu()
             cpu_baseline = {"value": round(1.0 / sec, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port", "cpu_model": _cpu_model(),
-                            "sample": "one 1920x1080 frame, torch CPU restatement (oracle/generators.py retinexnet_forward), one run after a 64x64 warm-up"}
+                            "sample": f"one 1920x1080 frame, torch CPU restatement (oracle/generators.py {o_name}), one run after a 64x64 warm-up"}
             parity = {"max_rel_err": float(f"{float((got - ref).abs().max() / ref.abs().max()):.3e}")}
     line = {"metric": "train_images_per_sec_1080p" if train else "enhanced_images_per_sec_1080p", "value": round(value, 2), "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,

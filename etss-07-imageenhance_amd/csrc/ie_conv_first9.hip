@@ -116,8 +116,8 @@ __device__ __forceinline__ void first9_body(const F9Params& p) {
 #pragma unroll
     for (int t = 0; t < PF; ++t) issue(t);
 
-    // step t, unrolled copy U (t % 9 == U): input row ys - 4 + t.  Output row o = (input row) - ky + 4 lives in set (U - ky + 9) % 9; ky = 0 starts its set from the
-    // bias; the set of ky = 8 (index (U + 1) % 9) is finished: output row ys - 8 + t.
+    // step t, unrolled copy U (t % KS == U): input row ys - HALO + t.  Output row o = (input row) - ky + HALO lives in set (U - ky + KS) % KS; ky = 0 starts its set
+    // from the bias; the set of ky = KS - 1 (index (U + 1) % KS) is finished: output row ys - (KS - 1) + t.
     auto step = [&](int t, auto u_tag) __attribute__((always_inline)) {
         constexpr int U = decltype(u_tag)::value;
         if (wave < 3) {
@@ -149,7 +149,7 @@ __device__ __forceinline__ void first9_body(const F9Params& p) {
             }
         }
         issue(t + PF);
-        {   // park the finished set (output row ys - 8 + t): no activation
+        {   // park the finished set (output row ys - (KS - 1) + t): no activation
             constexpr int S = (U + 1) % KS;
             const ie_u32x2 a = {ie_pack2<T>(acc[S][0][0], acc[S][0][1]), ie_pack2<T>(acc[S][0][2], acc[S][0][3])};
             const ie_u32x2 b2 = {ie_pack2<T>(acc[S][1][0], acc[S][1][1]), ie_pack2<T>(acc[S][1][2], acc[S][1][3])};

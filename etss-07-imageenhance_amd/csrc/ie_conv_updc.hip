@@ -40,18 +40,6 @@ struct UpdcParams {
     float lo, hi, sy, sx;
 };
 
-__device__ __forceinline__ void wait_vm_cold(int n) {
-    switch (n) {
-    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-}
-
 // w00 * a + w01 * b + w10 * c + w11 * d on the eight 16-bit values of a 16-byte piece, fp32 arithmetic, one rounding.  (Measured and dropped for fp16:
 // v_fma_mix_f32 / v_fma_mixlo_f16 / v_fma_mixhi_f16, which read the halves in place and write the rounded half -- 8 instructions per dword instead of 8
 // converts + 4 packed-fp32 FMAs + a pack, but slower on gfx950: the level ran 1,378 frames/s of U-Net-32 with them against 1,45x with this expression.)
