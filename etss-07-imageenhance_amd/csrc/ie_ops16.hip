@@ -89,6 +89,46 @@ __global__ void pad_v8(const T* __restrict__ x, T* __restrict__ y, int H, int W,
     st8(y + ((o.n * Ho + o.h) * Wo + o.w) * C + o.c, v);
 }
 
+// F.pad(x, (pad,) * 4, mode="replicate") on a 16-bit tensor, its adjoint (every border pixel of x collects the padding pixels that copied it: fp32 sum, one
+// rounding), and the zero insertion in front of a stride-2 convolution's data gradient (dst[n, 2h, 2w] = src[n, h, w], zeros elsewhere)
+template <typename T>
+__global__ void pad_replicate_v8(const T* __restrict__ x, T* __restrict__ y, int H, int W, int C, int pad, int Ho, int Wo, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const Idx o = split(i, Ho, Wo, C / 8);
+    const int h = min(max(o.h - pad, 0), H - 1), w = min(max(o.w - pad, 0), W - 1);
+    st8(y + ((o.n * Ho + o.h) * Wo + o.w) * C + o.c, ld8(x + ((o.n * H + h) * W + w) * C + o.c));
+}
+template <typename T>
+__global__ void pad_replicate_bwd_v8(const T* __restrict__ dy, T* __restrict__ dx, int H, int W, int C, int pad, int accumulate, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const Idx o = split(i, H, W, C / 8);
+    const int Hp = H + 2 * pad, Wp = W + 2 * pad;
+    const int h0 = o.h == 0 ? 0 : o.h + pad, h1 = o.h == H - 1 ? Hp - 1 : o.h + pad;
+    const int w0 = o.w == 0 ? 0 : o.w + pad, w1 = o.w == W - 1 ? Wp - 1 : o.w + pad;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    T* q = dx + ((o.n * H + o.h) * W + o.w) * C + o.c;
+    if (accumulate) unpack8<T>(ld8(q), acc);
+    for (int a = h0; a <= h1; ++a)
+        for (int b = w0; b <= w1; ++b) {
+            float v[8];
+            unpack8<T>(ld8(dy + ((o.n * Hp + a) * Wp + b) * C + o.c), v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] += v[k];
+        }
+    st8(q, pack8<T>(acc));
+}
+template <typename T>
+__global__ void zero_insert2_v8(const T* __restrict__ x, T* __restrict__ y, int H, int W, int C, int Ho, int Wo, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const Idx o = split(i, Ho, Wo, C / 8);
+    ie_u32x4 v = {0u, 0u, 0u, 0u};
+    if (!(o.h & 1) && !(o.w & 1) && (o.h >> 1) < H && (o.w >> 1) < W) v = ld8(x + ((o.n * H + (o.h >> 1)) * W + (o.w >> 1)) * C + o.c);
+    st8(y + ((o.n * Ho + o.h) * Wo + o.w) * C + o.c, v);
+}
+
 // y[n, h*r+i, w*r+j, c] = x[n, h, w, c*r*r + i*r + j]; thread = 8 output channels of one output pixel
 template <typename T>
 __global__ void pixel_shuffle_v8(const T* __restrict__ x, T* __restrict__ y, int H, int W, int Co, int r, size_t total) {
@@ -318,6 +358,38 @@ IE_EXPORT int ie_pad_nhwc(const void* x, void* y, int dtype, int N, int H, int W
     const size_t total = (size_t)N * Ho * Wo * (C / 8);
     if (dtype == IE_F16) hipLaunchKernelGGL(pad_v8<_Float16>, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, (_Float16*)y, H, W, C, top, left, Ho, Wo, total);
     else hipLaunchKernelGGL(pad_v8<__bf16>, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, (__bf16*)y, H, W, C, top, left, Ho, Wo, total);
+    IE_LAUNCH_CHECK();
+    return IE_OK;
+}
+
+IE_EXPORT int ie_pad_replicate_nhwc(const void* x, void* y, int dtype, int N, int H, int W, int C, int pad, void* stream) {
+    if (dtype == IE_F32) return ie_pad_replicate_nhwc_f32((const float*)x, (float*)y, N, H, W, C, pad, stream);
+    if (!x || !y || !is16(dtype) || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7) || pad < 0) IE_FAIL(IE_ERR_INVALID, "ie_pad_replicate_nhwc: bad args (C %% 8 == 0 on the 16-bit path)");
+    const int Ho = H + 2 * pad, Wo = W + 2 * pad;
+    const size_t total = (size_t)N * Ho * Wo * (C / 8);
+    if (dtype == IE_F16) hipLaunchKernelGGL(pad_replicate_v8<_Float16>, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, (_Float16*)y, H, W, C, pad, Ho, Wo, total);
+    else hipLaunchKernelGGL(pad_replicate_v8<__bf16>, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, (__bf16*)y, H, W, C, pad, Ho, Wo, total);
+    IE_LAUNCH_CHECK();
+    return IE_OK;
+}
+
+IE_EXPORT int ie_pad_replicate_backward_nhwc(const void* dy, void* dx, int dtype, int N, int H, int W, int C, int pad, int accumulate, void* stream) {
+    if (dtype == IE_F32) return ie_pad_replicate_backward_nhwc_f32((const float*)dy, (float*)dx, N, H, W, C, pad, accumulate, stream);
+    if (!dy || !dx || !is16(dtype) || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7) || pad < 0)
+        IE_FAIL(IE_ERR_INVALID, "ie_pad_replicate_backward_nhwc: bad args (C %% 8 == 0 on the 16-bit path)");
+    const size_t total = (size_t)N * H * W * (C / 8);
+    if (dtype == IE_F16) hipLaunchKernelGGL(pad_replicate_bwd_v8<_Float16>, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)dy, (_Float16*)dx, H, W, C, pad, accumulate, total);
+    else hipLaunchKernelGGL(pad_replicate_bwd_v8<__bf16>, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)dy, (__bf16*)dx, H, W, C, pad, accumulate, total);
+    IE_LAUNCH_CHECK();
+    return IE_OK;
+}
+
+IE_EXPORT int ie_zero_insert2_nhwc(const void* x, void* y, int dtype, int N, int H, int W, int C, int Ho, int Wo, void* stream) {
+    if (!x || !y || !is16(dtype) || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7) || Ho < 2 * H - 1 || Wo < 2 * W - 1)
+        IE_FAIL(IE_ERR_INVALID, "ie_zero_insert2_nhwc: 16-bit tensors, C %% 8 == 0, Ho >= 2 H - 1, Wo >= 2 W - 1");
+    const size_t total = (size_t)N * Ho * Wo * (C / 8);
+    if (dtype == IE_F16) hipLaunchKernelGGL(zero_insert2_v8<_Float16>, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, (_Float16*)y, H, W, C, Ho, Wo, total);
+    else hipLaunchKernelGGL(zero_insert2_v8<__bf16>, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, (__bf16*)y, H, W, C, Ho, Wo, total);
     IE_LAUNCH_CHECK();
     return IE_OK;
 }

@@ -1535,14 +1535,15 @@ class RetinexNet(_GraphModel):
     # RelightNet on loss_Relight.  Here: set ``train_phase`` and build one Trainer per phase (the other net's gradients and Adam moments
     # stay zero, so it does not move); ``Trainer.sync_to_model()`` hands the trained weights to the next phase / to inference.
     train_phase = "decom"
+    supports_mixed_training = True        # round 3: replicate padding and stride 2 on the 16-bit graph (ie_pad_replicate_nhwc, ie_zero_insert2_nhwc)
 
     def forward_train_loss(self, datapoint: dict, store, tape) -> dict:
         from . import train as T
         from .losses import LossResult
         if self.train_phase not in ("decom", "relight"):
             raise ValueError(f"`train_phase` must be 'decom' or 'relight', but got {self.train_phase!r}.")
-        if store.compute_dtype != "f32":
-            raise capi.IEError("retinexnet: the training graph runs on the fp32 path")
+        mixed = store.compute_dtype != "f32"          # 16-bit activations / gradients between fp32 edges (xin, (R, L), I_delta, the losses): see the `mixed` branches
+        tdt = ops.TORCH_DT[store.compute_dtype]
         if datapoint.get("ref_image") is None:
             raise ValueError("RetinexNet's training forward needs the normal-light frame as `ref_image` (model.py:199: input_high).")
         low = self._input(datapoint)
@@ -1555,19 +1556,24 @@ class RetinexNet(_GraphModel):
         tape_d, tape_r = (tape, T.Tape()) if decom_phase else (T.Tape(), tape)        # the other net runs on a tape that is never played back
         store.grads.zero_()                                                             # the idle net's gradients must read zero
 
-        def conv(tp, name, srcs, pad, act="none", stride=1):
+        def conv(tp, name, srcs, pad, act="none", stride=1, cout_pad=None):
             srcs = [T.t_pad_replicate(tp, t, pad) for t in (srcs if isinstance(srcs, (list, tuple)) else [srcs])]
-            return T.t_conv(tp, srcs, store.conv(name), *store.conv_grads(name), stride=stride, pad=0, act=act)
+            return T.t_conv(tp, srcs, store.conv(name), *store.conv_grads(name), stride=stride, pad=0, act=act, cout_pad=cout_pad if mixed else None)
 
         both = ops.empty_nhwc(2 * n, 3, h, w, low.device)                               # DecomNet on low and high in one batch (shared weights)
         both[:n].copy_(low); both[n:].copy_(high)
         xin = ops.max_concat(both)
         tape_d.no_grad(xin)
+        if mixed:
+            xin = T.t_cast(tape_d, xin, tdt, channels=16)                               # 4 channels carried as 16: the 9x9 first layer runs on the matrix cores too
         f = conv(tape_d, "net1_conv0", xin, 4)
         for i in (0, 2, 4, 6, 8):
             f = conv(tape_d, f"net1_convs.{i}", f, 1, "relu")
-        rl = conv(tape_d, "net1_recon", f, 1, "sigmoid")                                # (2N, 4, H, W): channels 0-2 = R, 3 = I
+        rl = conv(tape_d, "net1_recon", f, 1, "sigmoid", cout_pad=16)                   # (2N, 4, H, W): channels 0-2 = R, 3 = I (mixed: carried as 16)
         rl_low = rl[:n]
+        if mixed:
+            rl_low._ie_real = 4
+            rl = T.t_cast(tape_d, rl, torch.float32, channels=4)                        # the losses read (and seed) the fp32 copy
         tape_r.no_grad(rl_low)
         rs = lambda t, ref: T.t_resize(tape_r, t, (ref.shape[2], ref.shape[3]), "nearest")
         out0 = conv(tape_r, "net2_conv0_1", rl_low, 1)
@@ -1578,7 +1584,9 @@ class RetinexNet(_GraphModel):
         d2 = conv(tape_r, "net2_deconv1_2", [rs(d1, out1), out1], 1, "relu")
         d3 = conv(tape_r, "net2_deconv1_3", [rs(d2, out0), out0], 1, "relu")
         fus = conv(tape_r, "net2_fusion", [rs(d1, rl_low), rs(d2, rl_low), d3], 1)     # 1x1 with replicate padding 1: (H+2, W+2)
-        i_delta = conv(tape_r, "net2_output", fus, 0)                                   # 3x3 valid -> (N, 1, H, W)
+        i_delta = conv(tape_r, "net2_output", fus, 0, cout_pad=16)                      # 3x3 valid -> (N, 1, H, W) (mixed: carried as 16: an 8-channel tensor would be a "thin" source of its data-gradient conv)
+        if mixed:
+            i_delta = T.t_cast(tape_r, i_delta, torch.float32, channels=1)
 
         # ---- losses (model.py:216-238) and their gradients with respect to rl (decom phase) / i_delta (relight phase) ----------------
         L = capi.lib()
@@ -1607,11 +1615,12 @@ class RetinexNet(_GraphModel):
             capi.check(L.ie_l1_detached_f32(R_l, R_h, 4, 3, 0.01, dR_l, a_dec, n * h * w, st()), "ie_l1_detached_f32")    # equal_R_loss
             recon(R_l, 4, capi.ptr(i_delta), 1, high, 1.0, None, capi.ptr(d_delta), a_rel)                               # relight_loss
             smooth(capi.ptr(i_delta), 1, R_l, 3.0, capi.ptr(d_delta), None, a_rel)                                        # 3 * Ismooth_loss_delta
-        rl_nchw = ops.to_nchw(rl_low)
+        rl_low32 = rl[:n]
+        rl_nchw = ops.to_nchw(rl_low32)
         outputs = OrderedDict()
         outputs["reflectance"], outputs["illumination"] = rl_nchw[:, 0:3], rl_nchw[:, 3:4]
         outputs["illumination_delta"] = ops.to_nchw(i_delta)
-        outputs["enhanced"] = ops.to_nchw(ops.mul_prefix(rl_low, i_delta))
+        outputs["enhanced"] = ops.to_nchw(ops.mul_prefix(rl_low32, i_delta))
         outputs["loss_decom"], outputs["loss_relight"] = acc[0], acc[1]
 
         def seed(tape_, scale=1.0):

@@ -659,23 +659,35 @@ def crop_into(src, dst, top, left, accumulate):
 
 
 def pad_replicate(x, pad) -> torch.Tensor:
-    """F.pad(x, (pad,)*4, mode="replicate") on an fp32 NHWC tensor."""
-    _chk(x)
+    """F.pad(x, (pad,)*4, mode="replicate") on an NHWC tensor (fp32, or 16-bit with a multiple of 8 channels)."""
+    _chk_any(x)
     if pad == 0:
         return x
     n, c, h, w = x.shape
-    y = empty_nhwc(n, c, h + 2 * pad, w + 2 * pad, x.device)
+    y = empty_nhwc(n, c, h + 2 * pad, w + 2 * pad, x.device, x.dtype)
     with torch.cuda.device(x.device):
-        capi.check(capi.lib().ie_pad_replicate_nhwc_f32(capi.ptr(x), capi.ptr(y), n, h, w, c, pad, capi.current_stream()), "ie_pad_replicate_nhwc_f32")
+        capi.check(capi.lib().ie_pad_replicate_nhwc(capi.ptr(x), capi.ptr(y), _dt(x), n, h, w, c, pad, capi.current_stream()), "ie_pad_replicate_nhwc")
     return y
 
 
 def pad_replicate_backward_into(dy, dx, pad, accumulate):
-    _chk(dy); _chk(dx)
+    _chk_any(dy); _chk_any(dx)
+    if dy.dtype != dx.dtype:
+        raise capi.IEError("pad_replicate_backward_into: dy and dx must share a dtype")
     n, c, h, w = dx.shape
     with torch.cuda.device(dy.device):
-        capi.check(capi.lib().ie_pad_replicate_backward_nhwc_f32(capi.ptr(dy), capi.ptr(dx), n, h, w, c, pad, int(accumulate), capi.current_stream()),
-                   "ie_pad_replicate_backward_nhwc_f32")
+        capi.check(capi.lib().ie_pad_replicate_backward_nhwc(capi.ptr(dy), capi.ptr(dx), _dt(dy), n, h, w, c, pad, int(accumulate), capi.current_stream()),
+                   "ie_pad_replicate_backward_nhwc")
+
+
+def zero_insert2(x, ho, wo) -> torch.Tensor:
+    """dst[n, :, 2h, 2w] = x[n, :, h, w], zeros elsewhere, dst (N, C, ho, wo): the data gradient of a stride-2 convolution is a stride-1 convolution of this."""
+    _chk16(x)
+    n, c, h, w = (int(v) for v in x.shape)
+    y = torch.empty((n, c, int(ho), int(wo)), device=x.device, dtype=x.dtype, memory_format=CL)
+    with torch.cuda.device(x.device):
+        capi.check(capi.lib().ie_zero_insert2_nhwc(capi.ptr(x), capi.ptr(y), IE_DT[x.dtype], n, h, w, c, int(ho), int(wo), capi.current_stream()), "ie_zero_insert2_nhwc")
+    return y
 
 
 def crop(x, top, left, h, w) -> torch.Tensor:

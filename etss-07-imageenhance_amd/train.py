@@ -242,12 +242,13 @@ def t_cast(tape, x, dtype, channels=None):
     return y
 
 
-def t_conv16(tape, srcs, cw, dw, db, pad=1, cout_pad=None, act="none", slope=0.0):
-    """16-bit conv (stride 1, zero padding, activation fused into the forward epilogue): forward, data gradient and (3x3) weight
+def t_conv16(tape, srcs, cw, dw, db, pad=1, cout_pad=None, act="none", slope=0.0, stride=1):
+    """16-bit conv (stride 1 or 2, zero padding, activation fused into the forward epilogue): forward, data gradient and (3x3 stride 1) weight
     gradient on the matrix cores, weights packed on the device from the fp32 master copy; fp32 gradient accumulation.
-    ``cout_pad`` / sources wider than the layer's Cin: channel-padded edges (``ParamStore.conv16``)."""
+    ``cout_pad`` / sources wider than the layer's Cin: channel-padded edges (``ParamStore.conv16``).  Stride 2: the data gradient is the
+    stride-1 convolution of the zero-inserted output gradient (``ops.zero_insert2``) with the same flipped weights."""
     fwd, dgw, edge = cw.store.conv16(cw.name, [int(s.shape[1]) for s in srcs], cout_pad, [_real_c(s) for s in srcs])
-    y = ops.mconv2d(srcs, fwd, pad=pad, act=act, slope=slope)
+    y = ops.mconv2d(srcs, fwd, stride=stride, pad=pad, act=act, slope=slope)
     if cout_pad and cout_pad != cw.cout:
         y._ie_real = cw.cout
 
@@ -258,15 +259,18 @@ def t_conv16(tape, srcs, cw, dw, db, pad=1, cout_pad=None, act="none", slope=0.0
         if act != "none":
             ops.act_backward_into(dy, y, dy, act, slope)          # in place: this op owns the gradient buffer of its output
         if edge is None:
-            ops.conv2d_wgrad(srcs, dy, cw, dw, db, 1, pad, "zeros")
+            ops.conv2d_wgrad(srcs, dy, cw, dw, db, stride, pad, "zeros")
         else:
             ev = ops.ConvWeightsView(edge.w, edge.b, fwd.cout, sum(fwd.split), cw.kh, cw.kw)
-            ops.conv2d_wgrad(srcs, dy, ev, edge.dw, edge.db if db is not None else None, 1, pad, "zeros")
+            ops.conv2d_wgrad(srcs, dy, ev, edge.dw, edge.db if db is not None else None, stride, pad, "zeros")
             edge.scatter_grads(dw, db)
+        dyz = None
         for i, src in enumerate(srcs):
             if tape.is_no_grad(src):
                 continue
-            g = ops.mconv2d([dy], dgw[i], pad=cw.kh - 1 - pad)
+            if stride == 2 and dyz is None:          # (H + 2 pad - k + 1) rows: the stride-1 full convolution of it has the source's H rows
+                dyz = ops.zero_insert2(dy, int(src.shape[2]) + 2 * pad - cw.kh + 1, int(src.shape[3]) + 2 * pad - cw.kw + 1)
+            g = ops.mconv2d([dy if stride == 1 else dyz], dgw[i], pad=cw.kh - 1 - pad)
             if tape.grad(src) is not None:
                 _accumulate(tape.grad(src), g)
             else:
@@ -280,9 +284,9 @@ def t_conv(tape, srcs, cw, dw, db, stride=1, pad=1, pad_mode="zeros", act="none"
     if isinstance(srcs, torch.Tensor):
         srcs = [srcs]
     if srcs[0].dtype != torch.float32:
-        if stride != 1 or pad_mode != "zeros":
-            raise capi.IEError("the 16-bit training conv supports stride 1 and zero padding")
-        return t_conv16(tape, srcs, cw, dw, db, pad, cout_pad, act, slope)
+        if stride not in (1, 2) or pad_mode != "zeros":
+            raise capi.IEError("the 16-bit training conv supports stride 1 / 2 and zero padding (replicate padding: t_pad_replicate in front of it)")
+        return t_conv16(tape, srcs, cw, dw, db, pad, cout_pad, act, slope, stride)
     y = ops.conv2d(srcs, cw, stride=stride, pad=pad, pad_mode=pad_mode, act=act, slope=slope)
 
     def bwd():
@@ -392,6 +396,10 @@ def t_pad_replicate(tape, x, pad):
     if pad == 0:
         return x
     y = ops.pad_replicate(x, pad)
+    if _real_c(x) < x.shape[1]:
+        y._ie_real = _real_c(x)
+    if tape.is_no_grad(x):
+        return tape.no_grad(y)
 
     def bwd():
         dy = tape.grad(y)

@@ -405,6 +405,12 @@ int ie_retinex_smooth_f32(const float* I_dev, int i_stride, const float* R_dev, 
  * pass of a padding_mode="replicate" convolution (model.py:26-66) is the zero-padding one on the explicitly padded input */
 int ie_pad_replicate_nhwc_f32(const float* x_dev, float* y_dev, int N, int H, int W, int C, int pad, void* stream);
 int ie_pad_replicate_backward_nhwc_f32(const float* dy_dev, float* dx_dev, int N, int H, int W, int C, int pad, int accumulate, void* stream);
+/* The same pair for IE_F16 / IE_BF16 tensors (C a multiple of 8; IE_F32 forwards to the entry points above), and the zero insertion in front of the data gradient
+ * of a stride-2 convolution (dst[n, 2h, 2w, :] = src[n, h, w, :], zeros elsewhere; dst (N, Ho, Wo, C), Ho >= 2 H - 1): with them RetinexNet's replicate-padded and
+ * strided layers (retinexnet/model.py:26-66) train on the 16-bit matrix-core graph -- dX = conv(zero_insert(dY), W flipped, padding k - 1 - p). */
+int ie_pad_replicate_nhwc(const void* x_dev, void* y_dev, int dtype, int N, int H, int W, int C, int pad, void* stream);
+int ie_pad_replicate_backward_nhwc(const void* dy_dev, void* dx_dev, int dtype, int N, int H, int W, int C, int pad, int accumulate, void* stream);
+int ie_zero_insert2_nhwc(const void* x_dev, void* y_dev, int dtype, int N, int H, int W, int C, int Ho, int Wo, void* stream);
 
 /* ---- zero-reference training of Zero-DCE: the losses of zero_dce.py:34-79 and the LE-curve backward --------- */
 /* floats of scratch ie_zref_image_losses_f32 needs for an (N,3,H,W) batch. */

@@ -177,3 +177,29 @@ def test_retinex_single_pass_ends(dt):
     R, L, S = ops.retinex_outputs(ops.to_nhwc(rl.cuda()), ops.to_nhwc(idl.cuda()))
     assert R.is_contiguous() and L.is_contiguous() and S.is_contiguous()
     assert torch.equal(R.cpu(), rl[:, :3]) and torch.equal(L.cpu(), rl[:, 3:]) and torch.equal(S.cpu(), rl[:, :3] * idl)
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+def test_16bit_replicate_pad_and_zero_insert(dt):
+    """ie_pad_replicate_nhwc / its adjoint / ie_zero_insert2_nhwc on 16-bit tensors: the pieces that put RetinexNet's replicate-padded and stride-2 layers on the
+    16-bit training graph.  The pad is a copy (bit-exact); its adjoint sums the copies in fp32 and rounds once; <conv_s2(x), dy> == <x, conv_s1(zero_insert(dy))>."""
+    tdt = ops.TORCH_DT[dt]
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(2, 16, 9, 13, generator=g).to(tdt)
+    xn = x.cuda().contiguous(memory_format=torch.channels_last)
+    y = ops.pad_replicate(xn, 3)
+    assert torch.equal(y.float().cpu(), F.pad(x.float(), (3, 3, 3, 3), mode="replicate"))
+    dy = torch.randn(2, 16, 15, 19, generator=g).to(tdt)
+    xf = x.float().requires_grad_(True)
+    F.pad(xf, (3, 3, 3, 3), mode="replicate").backward(dy.float())
+    dx = torch.zeros_like(xn)
+    ops.pad_replicate_backward_into(dy.cuda().contiguous(memory_format=torch.channels_last), dx, 3, False)
+    assert rel_err(dx.float().cpu(), xf.grad) <= (1e-3 if dt == "f16" else 8e-3)
+    base = torch.randn_like(x).cuda().contiguous(memory_format=torch.channels_last)
+    dx2 = base.clone()
+    ops.pad_replicate_backward_into(dy.cuda().contiguous(memory_format=torch.channels_last), dx2, 3, True)
+    assert rel_err(dx2.float().cpu(), xf.grad + base.float().cpu()) <= (2e-3 if dt == "f16" else 1.6e-2)
+    z = ops.zero_insert2(xn, 18, 27)
+    want = torch.zeros(2, 16, 18, 27)
+    want[:, :, 0:17:2, 0:25:2] = x.float()
+    assert torch.equal(z.float().cpu(), want)

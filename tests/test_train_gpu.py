@@ -512,8 +512,6 @@ def test_trainer_requires_target_and_graph():
     rn = mon_amd.MODELS.build(name="zsn2n", seed=1).to("cuda")               # no training graph (yet)
     with pytest.raises(capi.IEError):
         mon_amd.Trainer(rn)
-    with pytest.raises(capi.IEError):                                          # RetinexNet trains on the fp32 graph only
-        mon_amd.Trainer(mon_amd.MODELS.build(name="retinexnet", seed=1).to("cuda"), compute_dtype="bf16")
 
 
 # ---- data-parallel step: 2 ranks on the one GPU of the test box, gloo carries the flat gradient buffer ---------------------
@@ -830,8 +828,6 @@ def test_unet_mixed_precision_training_step(dt, min_cos, min_layer, upsampler):
     for k, ref in final.items():
         if "running_" in k:
             assert float((sd1[k] - ref).abs().max()) < 2e-2 * max(1.0, float(ref.abs().max())), k
-    with pytest.raises(capi.IEError):
-        mon_amd.Trainer(mon_amd.MODELS.build(name="retinexnet", seed=1).to("cuda"), compute_dtype="bf16")
 
 
 @pytest.mark.parametrize("dt,min_cos", [("f16", 0.995), ("bf16", 0.97)])
@@ -1074,6 +1070,45 @@ def test_retinexnet_training_phase_matches_torch(phase):
             assert torch.equal(sd1[k], sd0[k]), k
     with pytest.raises(ValueError):
         tr.training_step({"image": low})
+
+
+@pytest.mark.parametrize("phase", ["decom", "relight"])
+@pytest.mark.parametrize("dt,min_cos", [("f16", 0.995), ("bf16", 0.96)])
+def test_retinexnet_mixed_precision_training_step(phase, dt, min_cos):
+    """RetinexNet on the 16-bit graph (round 3): replicate padding as its own 16-bit op in front of pad-0 matrix-core convolutions, the 9x9 first layer on a
+    16-channel carrier, stride-2 layers whose data gradient is the stride-1 convolution of the zero-inserted output gradient, nearest resizes, fp32 edges for
+    (R, L), I_delta and the losses (retinexnet/model.py:199-260).  Loss values and the direction of the phase's gradient against torch float64 autograd."""
+    from oracle import generators as og
+    model = mon_amd.MODELS.build(name="retinexnet", channels=16, seed=71).to("cuda")
+    model.train_phase = phase
+    sd0 = model.state_dict()
+    g = torch.Generator().manual_seed(72)
+    high = torch.rand(2, 3, 24, 40, generator=g)
+    low = (high ** 2.2 * 0.3).contiguous()
+    own = "net1_" if phase == "decom" else "net2_"
+    params = {k: v.double().clone().requires_grad_(True) for k, v in sd0.items()}
+    ref = og.retinexnet_losses(params, low.double(), high.double())
+    ref["loss_" + phase].backward()
+    grads = {k: v.grad.clone().float() for k, v in params.items() if k.startswith(own)}
+    tr = mon_amd.Trainer(model, optimizer={"name": "adam", "lr": 1e-4, "eps": 1e-3}, gradient_clip_val=None, compute_dtype=dt)
+    out = tr.training_step({"image": low, "ref_image": high})
+    tol = 2e-3 if dt == "f16" else 2e-2
+    for k in ("loss_decom", "loss_relight"):
+        want = float(ref[k].detach())
+        assert abs(float(out[k]) - want) <= tol * max(abs(want), 0.05), k
+    assert rel_err(out["enhanced"].cpu(), ref["enhanced"].detach().float()) <= (3e-3 if dt == "f16" else 3e-2)
+    got = tr.gradients()
+    ga = torch.cat([got[k].flatten() for k in grads])
+    gb = torch.cat([grads[k].flatten() for k in grads])
+    cos = float((ga * gb).sum() / (ga.norm() * gb.norm()))
+    assert cos >= min_cos, cos
+    assert 0.8 <= float(ga.norm() / gb.norm()) <= 1.25
+    for k in sd0:
+        if not k.startswith(own):
+            assert float(got[k].abs().max()) == 0.0, k
+    sd1 = tr.state_dict()
+    assert any(not torch.equal(sd1[k], sd0[k]) for k in sd0 if k.startswith(own))
+    assert all(torch.equal(sd1[k], sd0[k]) for k in sd0 if not k.startswith(own))
 
 
 @pytest.mark.parametrize("dt,min_cos", [("f16", 0.9995), ("bf16", 0.995)])

@@ -1,0 +1,27 @@
+#!/usr/bin/env python
+"""RetinexNet training step (phase decom / relight) at 1080p on the fp32 and the 16-bit graph: frames/s.  Usage: python tools/bench_retinex_train.py [frames]"""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import mon_amd
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+g = torch.Generator(device="cuda").manual_seed(3)
+high = torch.rand((n, 3, 1080, 1920), generator=g, device="cuda")
+low = (high ** 2.2 * 0.3).contiguous()
+for dt in ("f32", "bf16", "f16"):
+    for phase in ("decom", "relight"):
+        model = mon_amd.MODELS.build(name="retinexnet", seed=1).to("cuda")
+        model.train_phase = phase
+        tr = mon_amd.Trainer(model, optimizer={"name": "adam", "lr": 1e-4}, gradient_clip_val=None, compute_dtype=dt)
+        for _ in range(2):
+            tr.training_step({"image": low, "ref_image": high})
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            out = tr.training_step({"image": low, "ref_image": high})
+        torch.cuda.synchronize(); d = (time.perf_counter() - t0) / reps
+        print(json.dumps({"model": "retinexnet", "phase": phase, "graph": dt, "frames": n, "ms_per_step": round(d * 1e3, 1), "frames_per_s": round(n / d, 2),
+                          "loss": round(float(out["loss"]), 5)}), flush=True)
+        del tr, model
+        torch.cuda.empty_cache()
