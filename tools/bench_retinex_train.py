@@ -6,18 +6,21 @@ import torch
 import mon_amd
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+only = sys.argv[2:]          # e.g. "bf16 relight": one configuration per process (fresh allocator state)
 g = torch.Generator(device="cuda").manual_seed(3)
 high = torch.rand((n, 3, 1080, 1920), generator=g, device="cuda")
 low = (high ** 2.2 * 0.3).contiguous()
 for dt in ("f32", "bf16", "f16"):
     for phase in ("decom", "relight"):
+        if only and (dt not in only or phase not in only):
+            continue
         model = mon_amd.MODELS.build(name="retinexnet", seed=1).to("cuda")
         model.train_phase = phase
         tr = mon_amd.Trainer(model, optimizer={"name": "adam", "lr": 1e-4}, gradient_clip_val=None, compute_dtype=dt)
-        for _ in range(2):
+        for _ in range(3):
             tr.training_step({"image": low, "ref_image": high})
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        reps = 3
+        reps = 5
         for _ in range(reps):
             out = tr.training_step({"image": low, "ref_image": high})
         torch.cuda.synchronize(); d = (time.perf_counter() - t0) / reps
