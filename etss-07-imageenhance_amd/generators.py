@@ -1758,9 +1758,9 @@ class HINet_RE(_GraphModel):
     def forward_train(self, x, store, tape):
         """Training graph of hinet.py:34-198, 322-362 on the taped ops; returns ``stage1`` and ``enhanced`` (NHWC fp32), whose losses the
         trainer sums (hinet.py:311-320).  16-bit graph (``Trainer(compute_dtype="bf16" | "f16")``): every stride-1 convolution, the
-        half instance norms, adds and the attention product run on 16-bit tensors (RGB carried as 16 channels); the two layer kinds the
-        matrix-core training kernels do not cover -- Conv4x4 stride 2 and ConvTranspose 2x2 -- take an fp32 detour (cast, fp32 kernels
-        for forward / data / weight gradient, cast back), their share of the FLOPs is a few per cent."""
+        half instance norms, adds and the attention product run on 16-bit tensors (RGB carried as 16 channels), since round 3 the Conv4x4
+        stride-2 layers too (data gradient = stride-1 conv of the zero-inserted output gradient, train.t_conv16); ConvTranspose 2x2 still takes
+        an fp32 detour (cast, fp32 kernels for forward / data / weight gradient, cast back): a few per cent of the FLOPs."""
         from . import train as T
         m = 2 ** (self.depth - 1)
         if x.shape[2] % m or x.shape[3] % m:
@@ -1775,7 +1775,7 @@ class HINet_RE(_GraphModel):
             x = T.t_cast(tape, x, tdt, channels=16)
 
         def conv(name, srcs, pad=1, act="none", stride=1, cout_pad=None):
-            if mixed and stride != 1:
+            if mixed and stride != 1 and os.environ.get("IE_HINET_S2_FP32") == "1":      # A/B: the round-2 fp32 detour of the Conv4x4 stride-2 layers
                 srcs = [T.t_cast(tape, t, torch.float32) for t in srcs]
                 y = T.t_conv(tape, srcs, store.conv(name), *store.conv_grads(name), stride=stride, pad=pad, act=act, slope=s_)
                 return T.t_cast(tape, y, tdt)
