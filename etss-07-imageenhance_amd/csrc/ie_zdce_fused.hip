@@ -41,7 +41,8 @@ constexpr unsigned OOB = 0x80000000u;
 #endif
 constexpr int PF_DEFAULT = IE_PF; // rows of DMA issued ahead (K67 is LDS-limited to 3)
 
-enum { K12 = 12, K45 = 45, K67 = 67, K345 = 345, K67N = 670, K67F = 671 };   // K67N: K67 with the curve in stage B's registers (below); K67F: K67N
+enum { K12 = 12, K45 = 45, K67 = 67, K345 = 345, K67N = 670, K67F = 671, K67U = 672 };   // K67U: K67N compiled for the uint8 HWC output alone (the u8 pipeline, ie_zdce_forward_u8)
+//   // K67N: K67 with the curve in stage B's registers (below); K67F: K67N
                                                                               // compiled for `enhanced` fp32 as the only output and W % 4 == 0 (no output-mode branches)
 
 #ifndef IE_EXP
@@ -85,7 +86,7 @@ template <int KIND> struct FusedGeom {
     // is as long as its MFMA time, and its rings are small: it runs TWO rows between barriers (the stages then talk through rows
     // that are one barrier period old, so every hand-off lags RPB rows and the rings hold 2 RPB slots).
     static constexpr int RPB = (KIND == K12) ? IE_K12_RPB : 1;
-    static constexpr bool IS67N = (KIND == K67N || KIND == K67F);
+    static constexpr bool IS67N = (KIND == K67N || KIND == K67F || KIND == K67U);
     static constexpr bool IS67 = (KIND == K67 || IS67N);
     static constexpr int PF = IS67 ? 3 : (KIND == K12 && RPB > 1 ? 5 : PF_DEFAULT);   // rows of DMA issued ahead
     static constexpr int ROW_B = ROW_PX * 64;
@@ -180,8 +181,8 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     constexpr int PXB = 32 * 2;                             // 64 B per pixel per tensor
     constexpr int ROW_B = G::ROW_B;                         // one ring row of one tensor
     constexpr int NSA = G::NSA;
-    constexpr bool IS67 = G::IS67, IS67N = G::IS67N, FAST67 = (KIND == K67F);
-    (void)FAST67;
+    constexpr bool IS67 = G::IS67, IS67N = G::IS67N, FAST67 = (KIND == K67F), U8ONLY = (KIND == K67U), LEAN67 = FAST67 || U8ONLY;
+    (void)FAST67; (void)U8ONLY; (void)LEAN67;
     constexpr int NFB = (KIND == K45 || KIND == K12 || KIND == K345 || IS67N) ? 18 : 9;         // stage B weight fragments (K12: e_conv2 + e_conv7a; K67N: both 16-row tiles of e_conv7b)
     constexpr int NW = IS67 ? 18 : NFB;                     // weight fragments held per wave (K12 stage A: 2, K67 / K345 stage A: 18)
     // K67 and K345 load NO halo columns for stage A's HBM rows (one 8-lane LDS-DMA instruction per tensor and row on the
@@ -1048,7 +1049,24 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
             const bool row_ok = (yo >= ys) && (yo < ye);
             const char* os = smem + OFF_OUTF + ((t + 1) & 1) * G::OUTF_SLOT_B;
             const int xs = xc0 + MARG;                                  // first stored column of the strip (a multiple of 4)
-            if (FAST67 || (p.enhanced && (W & 3) == 0)) {
+            if constexpr (U8ONLY) {        // HWC bytes: 372 per strip row (W % 4 == 0: dword stores), wave 7 quantises them from the staged fp32 values
+                if (sw == 3) {
+                    const int nbytes = row_ok ? min(TSK, W - xs) * 3 : 0;
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int d = lane + 64 * k;
+                        unsigned pk = 0;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int b = 4 * d + e, pxr = b / 3, c = b - 3 * pxr;
+                            const float v = *(const float*)(os + c * G::OUTF_PLANE_B + ((pxr < TSK ? pxr : 0) + MARG + 2) * 4);
+                            pk |= (unsigned)ie_quant_u8(v) << (8 * e);
+                        }
+                        const unsigned off = (4 * d < nbytes) ? (unsigned)(((size_t)yo * W + xs) * 3 + 4 * d) : OOB;
+                        __builtin_amdgcn_raw_buffer_store_b32(pk, rsU, (int)off, 0, 0);
+                    }
+                }
+            } else if (FAST67 || (p.enhanced && (W & 3) == 0)) {
                 const ie_u32x4 v = *(const ie_u32x4*)(os + est_lds);
                 const unsigned rmask = row_ok ? 0u : OOB;
                 __builtin_amdgcn_raw_buffer_store_b128(v, rsE, (int)((est_off + (rmask ? 0u : (unsigned)yo * (unsigned)W * 4u)) | rmask), 0, 0);
@@ -1062,7 +1080,7 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsE, (int)off, 0, 0);
                 }
             }
-            if constexpr (!FAST67) {
+            if constexpr (!LEAN67) {
             if (p.u8 && sw == 3) {        // HWC bytes: 372 per strip row, wave 7 quantises them from the staged fp32 values
                 const int nbytes = row_ok ? min(TSK, W - xs) * 3 : 0;
                 if ((W & 3) == 0) {
@@ -1102,7 +1120,7 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
         float e0 = 0.f, e1 = 0.f, u0 = 0.f, u1 = 0.f;
         // the 24 curve maps (optional output, general variant only) leave straight from the lane that computed them: NCHW fp32, plane 3 i + colour
         unsigned aj_off[2] = {OOB, OOB};
-        if constexpr (!FAST67) {
+        if constexpr (!LEAN67) {
             if (p.adjust) {
                 const int yc = ys - 6 - G::DEFA + t;
 #pragma unroll
@@ -1121,7 +1139,7 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
             if (w == 2) e = __builtin_amdgcn_rcpf(e);
             if (w == 3) {
                 e = __builtin_fmaf(e, -2.0f, 1.0f);       // r_k
-                if constexpr (!FAST67) {                  // (an absent `adjust` has an empty descriptor range and out-of-range offsets: the store is dropped)
+                if constexpr (!LEAN67) {                  // (an absent `adjust` has an empty descriptor range and out-of-range offsets: the store is dropped)
                     const unsigned off = aj_off[nt] == OOB ? OOB : aj_off[nt] + (unsigned)((size_t)(3 * k) * plane * 4);
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(e), rsJ, (int)off, 0, 0);
                 }
@@ -1374,6 +1392,9 @@ IE_DEF_FUSED(zdce_k67n_conv6_conv7_curve_mix, _Float16, __bf16, _Float16, _Float
 IE_DEF_FUSED(zdce_k67n_conv6_conv7_curve_e_f16, _Float16, _Float16, _Float16, _Float16, K67F)
 IE_DEF_FUSED(zdce_k67n_conv6_conv7_curve_e_bf16, __bf16, __bf16, __bf16, __bf16, K67F)
 IE_DEF_FUSED(zdce_k67n_conv6_conv7_curve_e_mix, _Float16, __bf16, _Float16, _Float16, K67F)
+IE_DEF_FUSED(zdce_k67n_conv6_conv7_curve_u8_f16, _Float16, _Float16, _Float16, _Float16, K67U)
+IE_DEF_FUSED(zdce_k67n_conv6_conv7_curve_u8_bf16, __bf16, __bf16, __bf16, __bf16, K67U)
+IE_DEF_FUSED(zdce_k67n_conv6_conv7_curve_u8_mix, _Float16, __bf16, _Float16, _Float16, K67U)
 #undef IE_DEF_FUSED
 #define IE_DEF_FUSED3(NAME, TA0, T3, TH, TO) \
     __global__ __launch_bounds__(512, 2) void NAME(FusedParams p) { zdce_fused2_body<TA0, TA0, TH, TO, K345, T3>(p); }
@@ -1393,7 +1414,7 @@ static int launch_fused_t(FusedFn fn, const ZdceFusedLaunch& a, hipStream_t st) 
     p.N = a.N; p.H = a.H; p.W = a.W; p.y_begin = a.y_begin; p.y_end = a.y_end; p.rows_per_block = a.rows_per_block;
     p.n_begin = a.n_begin;
     p.stamps = (unsigned long long*)a.stamps;
-    p.strips = ie_cdiv(a.W, KIND == K345 ? TW - 6 : ((KIND == K67 || KIND == K67N || KIND == K67F) ? TW - 4 : TS));
+    p.strips = ie_cdiv(a.W, KIND == K345 ? TW - 6 : ((KIND == K67 || KIND == K67N || KIND == K67F || KIND == K67U) ? TW - 4 : TS));
     if (KIND == K67N && a.adjust && (size_t)a.H * a.W * 24 * 4 >= 0x7fffffffull) IE_FAIL(IE_ERR_UNSUPPORTED, "zdce fused: frame too large for 31-bit offsets into `adjust`");
     p.chunks = ie_cdiv(a.y_end - a.y_begin, a.rows_per_block);
     const long long blocks = (long long)p.strips * p.chunks * a.n_count;
@@ -1431,6 +1452,10 @@ int ie_zdce_launch_fused(const ZdceFusedLaunch& a, hipStream_t st) {
         if (h_all) return launch_fused_t<K67F>(zdce_k67n_conv6_conv7_curve_e_f16, a, st);
         if (b_all) return launch_fused_t<K67F>(zdce_k67n_conv6_conv7_curve_e_bf16, a, st);
         if (a.dt_a0 == IE_F16 && a.dt_a1 == IE_BF16 && a.dt_h == IE_F16) return launch_fused_t<K67F>(zdce_k67n_conv6_conv7_curve_e_mix, a, st);
+    } else if (a.kind == 670 && a.u8 && !a.enhanced && !a.adjust && (a.W & 3) == 0) {       // the uint8 pipeline: the HWC bytes alone
+        if (h_all) return launch_fused_t<K67U>(zdce_k67n_conv6_conv7_curve_u8_f16, a, st);
+        if (b_all) return launch_fused_t<K67U>(zdce_k67n_conv6_conv7_curve_u8_bf16, a, st);
+        if (a.dt_a0 == IE_F16 && a.dt_a1 == IE_BF16 && a.dt_h == IE_F16) return launch_fused_t<K67U>(zdce_k67n_conv6_conv7_curve_u8_mix, a, st);
     } else if (a.kind == 670) {
         if (h_all) return launch_fused_t<K67N>(zdce_k67n_conv6_conv7_curve_f16, a, st);
         if (b_all) return launch_fused_t<K67N>(zdce_k67n_conv6_conv7_curve_bf16, a, st);
