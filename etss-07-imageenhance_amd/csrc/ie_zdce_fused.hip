@@ -41,7 +41,8 @@ constexpr unsigned OOB = 0x80000000u;
 #endif
 constexpr int PF_DEFAULT = IE_PF; // rows of DMA issued ahead (K67 is LDS-limited to 3)
 
-enum { K12 = 12, K45 = 45, K67 = 67, K345 = 345, K67N = 670, K67F = 671, K67U = 672 };   // K67U: K67N compiled for the uint8 HWC output alone (the u8 pipeline, ie_zdce_forward_u8)
+enum { K12 = 12, K45 = 45, K67 = 67, K345 = 345, K67N = 670, K67F = 671, K67U = 672, K67A = 673 };   // K67A: enhanced + the 24 curve maps, fp32, W % 4 == 0 (what model.forward() returns)
+//   // K67U: K67N compiled for the uint8 HWC output alone (the u8 pipeline, ie_zdce_forward_u8)
 //   // K67N: K67 with the curve in stage B's registers (below); K67F: K67N
                                                                               // compiled for `enhanced` fp32 as the only output and W % 4 == 0 (no output-mode branches)
 
@@ -86,7 +87,7 @@ template <int KIND> struct FusedGeom {
     // is as long as its MFMA time, and its rings are small: it runs TWO rows between barriers (the stages then talk through rows
     // that are one barrier period old, so every hand-off lags RPB rows and the rings hold 2 RPB slots).
     static constexpr int RPB = (KIND == K12) ? IE_K12_RPB : 1;
-    static constexpr bool IS67N = (KIND == K67N || KIND == K67F || KIND == K67U);
+    static constexpr bool IS67N = (KIND == K67N || KIND == K67F || KIND == K67U || KIND == K67A);
     static constexpr bool IS67 = (KIND == K67 || IS67N);
     static constexpr int PF = IS67 ? 3 : (KIND == K12 && RPB > 1 ? 5 : PF_DEFAULT);   // rows of DMA issued ahead
     static constexpr int ROW_B = ROW_PX * 64;
@@ -181,8 +182,8 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     constexpr int PXB = 32 * 2;                             // 64 B per pixel per tensor
     constexpr int ROW_B = G::ROW_B;                         // one ring row of one tensor
     constexpr int NSA = G::NSA;
-    constexpr bool IS67 = G::IS67, IS67N = G::IS67N, FAST67 = (KIND == K67F), U8ONLY = (KIND == K67U), LEAN67 = FAST67 || U8ONLY;
-    (void)FAST67; (void)U8ONLY; (void)LEAN67;
+    constexpr bool IS67 = G::IS67, IS67N = G::IS67N, FAST67 = (KIND == K67F || KIND == K67A), U8ONLY = (KIND == K67U), LEAN67 = (KIND == K67F) || U8ONLY, NOU8 = LEAN67 || KIND == K67A;
+    (void)FAST67; (void)U8ONLY; (void)LEAN67; (void)NOU8;
     constexpr int NFB = (KIND == K45 || KIND == K12 || KIND == K345 || IS67N) ? 18 : 9;         // stage B weight fragments (K12: e_conv2 + e_conv7a; K67N: both 16-row tiles of e_conv7b)
     constexpr int NW = IS67 ? 18 : NFB;                     // weight fragments held per wave (K12 stage A: 2, K67 / K345 stage A: 18)
     // K67 and K345 load NO halo columns for stage A's HBM rows (one 8-lane LDS-DMA instruction per tensor and row on the
@@ -1080,7 +1081,7 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsE, (int)off, 0, 0);
                 }
             }
-            if constexpr (!LEAN67) {
+            if constexpr (!NOU8) {
             if (p.u8 && sw == 3) {        // HWC bytes: 372 per strip row, wave 7 quantises them from the staged fp32 values
                 const int nbytes = row_ok ? min(TSK, W - xs) * 3 : 0;
                 if ((W & 3) == 0) {
@@ -1392,6 +1393,9 @@ IE_DEF_FUSED(zdce_k67n_conv6_conv7_curve_mix, _Float16, __bf16, _Float16, _Float
 IE_DEF_FUSED(zdce_k67n_conv6_conv7_curve_e_f16, _Float16, _Float16, _Float16, _Float16, K67F)
 IE_DEF_FUSED(zdce_k67n_conv6_conv7_curve_e_bf16, __bf16, __bf16, __bf16, __bf16, K67F)
 IE_DEF_FUSED(zdce_k67n_conv6_conv7_curve_e_mix, _Float16, __bf16, _Float16, _Float16, K67F)
+IE_DEF_FUSED(zdce_k67n_conv6_conv7_curve_ea_f16, _Float16, _Float16, _Float16, _Float16, K67A)
+IE_DEF_FUSED(zdce_k67n_conv6_conv7_curve_ea_bf16, __bf16, __bf16, __bf16, __bf16, K67A)
+IE_DEF_FUSED(zdce_k67n_conv6_conv7_curve_ea_mix, _Float16, __bf16, _Float16, _Float16, K67A)
 IE_DEF_FUSED(zdce_k67n_conv6_conv7_curve_u8_f16, _Float16, _Float16, _Float16, _Float16, K67U)
 IE_DEF_FUSED(zdce_k67n_conv6_conv7_curve_u8_bf16, __bf16, __bf16, __bf16, __bf16, K67U)
 IE_DEF_FUSED(zdce_k67n_conv6_conv7_curve_u8_mix, _Float16, __bf16, _Float16, _Float16, K67U)
@@ -1414,7 +1418,7 @@ static int launch_fused_t(FusedFn fn, const ZdceFusedLaunch& a, hipStream_t st) 
     p.N = a.N; p.H = a.H; p.W = a.W; p.y_begin = a.y_begin; p.y_end = a.y_end; p.rows_per_block = a.rows_per_block;
     p.n_begin = a.n_begin;
     p.stamps = (unsigned long long*)a.stamps;
-    p.strips = ie_cdiv(a.W, KIND == K345 ? TW - 6 : ((KIND == K67 || KIND == K67N || KIND == K67F || KIND == K67U) ? TW - 4 : TS));
+    p.strips = ie_cdiv(a.W, KIND == K345 ? TW - 6 : ((KIND == K67 || KIND == K67N || KIND == K67F || KIND == K67U || KIND == K67A) ? TW - 4 : TS));
     if (KIND == K67N && a.adjust && (size_t)a.H * a.W * 24 * 4 >= 0x7fffffffull) IE_FAIL(IE_ERR_UNSUPPORTED, "zdce fused: frame too large for 31-bit offsets into `adjust`");
     p.chunks = ie_cdiv(a.y_end - a.y_begin, a.rows_per_block);
     const long long blocks = (long long)p.strips * p.chunks * a.n_count;
@@ -1452,6 +1456,10 @@ int ie_zdce_launch_fused(const ZdceFusedLaunch& a, hipStream_t st) {
         if (h_all) return launch_fused_t<K67F>(zdce_k67n_conv6_conv7_curve_e_f16, a, st);
         if (b_all) return launch_fused_t<K67F>(zdce_k67n_conv6_conv7_curve_e_bf16, a, st);
         if (a.dt_a0 == IE_F16 && a.dt_a1 == IE_BF16 && a.dt_h == IE_F16) return launch_fused_t<K67F>(zdce_k67n_conv6_conv7_curve_e_mix, a, st);
+    } else if (a.kind == 670 && a.enhanced && a.adjust && !a.u8 && (a.W & 3) == 0 && ((size_t)a.enhanced & 15) == 0) {       // model.forward(): enhanced + curve maps
+        if (h_all) return launch_fused_t<K67A>(zdce_k67n_conv6_conv7_curve_ea_f16, a, st);
+        if (b_all) return launch_fused_t<K67A>(zdce_k67n_conv6_conv7_curve_ea_bf16, a, st);
+        if (a.dt_a0 == IE_F16 && a.dt_a1 == IE_BF16 && a.dt_h == IE_F16) return launch_fused_t<K67A>(zdce_k67n_conv6_conv7_curve_ea_mix, a, st);
     } else if (a.kind == 670 && a.u8 && !a.enhanced && !a.adjust && (a.W & 3) == 0) {       // the uint8 pipeline: the HWC bytes alone
         if (h_all) return launch_fused_t<K67U>(zdce_k67n_conv6_conv7_curve_u8_f16, a, st);
         if (b_all) return launch_fused_t<K67U>(zdce_k67n_conv6_conv7_curve_u8_bf16, a, st);

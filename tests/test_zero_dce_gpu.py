@@ -109,8 +109,9 @@ def test_kernel_variants_bit_identical(variant, dtype, base):
 @pytest.mark.parametrize("dtype", ["f16", "bf16", "bf16_pure"])
 @pytest.mark.parametrize("shape", [(2, 37, 132), (1, 140, 256), (3, 9, 260), (1, 5, 4)])
 def test_last_kernel_output_modes_agree(shape, dtype):
-    """The last kernel is compiled three times: for `enhanced` alone with W % 4 == 0 (zdce_k67n_*_e_*, the throughput path), for the uint8 HWC
-    output alone with W % 4 == 0 (zdce_k67n_*_u8_*, the uint8 pipeline) and for any combination of outputs / any width.  Same arithmetic: the
+    """The last kernel is compiled four times: for `enhanced` alone with W % 4 == 0 (zdce_k67n_*_e_*, the throughput path), for `enhanced` + the curve
+    maps (zdce_k67n_*_ea_*, model.forward()), for the uint8 HWC output alone (zdce_k67n_*_u8_*, the uint8 pipeline) and for any combination of outputs /
+    any width.  Same arithmetic: the
     same bits, whichever outputs are asked for."""
     n, h, w = shape
     sd = o_zdce.init_state_dict(seed=13, gain=3.0)

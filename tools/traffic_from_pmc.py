@@ -11,7 +11,7 @@ for line in open(sys.argv[1]):
     d = ast.literal_eval(line)
     if "zdce" not in d["kernel"]:
         continue
-    name = re.sub(r"(_e|_u8)?_(f16|bf16|mix)$", "", d["kernel"].split(" grid=")[0])      # (zdce_k67n_*_e_*: the form compiled for `enhanced` alone)
+    name = re.sub(r"(_e|_ea|_u8)?_(f16|bf16|mix)$", "", d["kernel"].split(" grid=")[0])      # (zdce_k67n_*_e_*: the form compiled for `enhanced` alone)
     if "fetch_MB_x2" in d:
         parts.setdefault(name, {})["read"] = int(d["fetch_MB_x2"] * 1024 * 1024)
     if "write_MB" in d and d.get("write_MB"):
