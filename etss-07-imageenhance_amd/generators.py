@@ -1400,6 +1400,39 @@ class GCENet(_GraphModel):
         return out
 
 
+@MODELS.register(name="gcenet_zsn2n", arch="gcenet")
+class GCENet_ZSN2N(GCENet):
+    """gcenet.py:504-536: GCENet whose TRAINING loss adds the ZS-N2N pair-downsampling residual / consistency terms; ``forward`` is GCENet's, so checkpoints
+    trained that way predict here unchanged.  The training step (``forward_loss``) is not built: GCENet has no training graph in this engine yet (DSConv
+    adjoints, the brightness-attention curve and the guided filter backward -- DESIGN.md 8)."""
+
+    def __init__(self, *args, **kwargs):
+        kwargs.pop("name", None)
+        super().__init__(*args, **kwargs)
+        self.name = self.fullname = "gcenet_zsn2n"
+
+    def forward_loss(self, datapoint: dict, *args, **kwargs) -> dict:
+        raise capi.IEError("gcenet_zsn2n: the training step (gcenet.py:510-536) is not built in this engine; forward() / infer() are GCENet's")
+
+
+@MODELS.register(name="gcenet_instance", arch="gcenet")
+class GCENet_Instance(GCENet):
+    """gcenet.py:539-600: GCENet fitted to ONE image at inference time (``infer`` runs ``epochs`` Adam steps on the zero-reference loss, then predicts).
+    ``forward`` is GCENet's; the per-image fitting needs GCENet's training graph, which this engine does not have yet: ``infer(..., epochs=0)`` predicts
+    with the loaded weights, any other ``epochs`` raises."""
+
+    def __init__(self, *args, **kwargs):
+        kwargs.pop("name", None)
+        super().__init__(*args, **kwargs)
+        self.name = self.fullname = "gcenet_instance"
+
+    def infer(self, datapoint: dict, epochs: int = 300, lr: float = 0.00005, weight_decay: float = 0.00001, reset_weights: bool = True, *args, **kwargs) -> dict:
+        if epochs:
+            raise capi.IEError("gcenet_instance: per-image fitting (gcenet.py:552-600, `epochs` Adam steps on the zero-reference loss) needs GCENet's "
+                               "training graph, which is not built in this engine; infer(..., epochs=0) predicts with the loaded weights")
+        return super().infer(datapoint, *args, **kwargs)
+
+
 # ----------------------------------------------------------------------------------------------------------------
 @MODELS.register(name="retinexnet", arch="retinexnet")
 class RetinexNet(_GraphModel):

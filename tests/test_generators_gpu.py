@@ -506,6 +506,25 @@ def test_gcenet_vs_oracle():
     assert rel_err(got, want) <= 1e-3
 
 
+def test_gcenet_registry_variants_resolve_and_predict():
+    """`gcenet_zsn2n` / `gcenet_instance` (gcenet.py:504, 539): the names resolve, load GCENet checkpoints and predict like GCENet (their forward IS GCENet's);
+    the parts that need a GCENet training step say so instead of silently doing something else."""
+    base = mon_amd.MODELS.build(name="gcenet", seed=3).to("cuda")
+    sd = base.state_dict()
+    x = _smooth(1, 3, 32, 48, seed=8, lo=0.02, hi=0.6)
+    depth = _smooth(1, 1, 32, 48, seed=9)
+    want = base.forward({"image": x.cuda(), "depth": depth.cuda()})["enhanced"]
+    for name in ("gcenet_zsn2n", "gcenet_instance"):
+        m = mon_amd.MODELS.build(name=name, weights=dict(sd)).to("cuda")
+        assert m.name == name and torch.equal(m.forward({"image": x.cuda(), "depth": depth.cuda()})["enhanced"], want)
+    with pytest.raises(mon_amd.capi.IEError):
+        mon_amd.MODELS.build(name="gcenet_zsn2n", weights=dict(sd)).to("cuda").forward_loss({"image": x.cuda(), "depth": depth.cuda()})
+    inst = mon_amd.MODELS.build(name="gcenet_instance", weights=dict(sd)).to("cuda")
+    with pytest.raises(mon_amd.capi.IEError):
+        inst.infer({"image": x.cuda(), "depth": depth.cuda()})
+    assert "enhanced" in inst.infer({"image": x.cuda(), "depth": depth.cuda()}, epochs=0)
+
+
 @pytest.mark.parametrize("dt", ["f16", "bf16"])
 def test_gcenet_16bit_vs_oracle(dt):
     """GCENet with EnhanceNet on the matrix cores (16-bit activations, fp32 accumulation): the curve map within the 16-bit bound of the oracle's, the
