@@ -40,6 +40,9 @@ constexpr unsigned OOB = 0x80000000u;
 #ifndef IE_SC_NR_C64O32
 #define IE_SC_NR_C64O32 3
 #endif
+#ifndef IE_SC_RING4
+#define IE_SC_RING4 2        // four-chunk kernels: bias through LDS + a pinned fragment ring read IE_SC_RING4 fragments ahead (0: the round-2 pipeline, one fragment register)
+#endif
 template <int NCH, int NCF> struct SGeom { static constexpr int NR = NCH == 4 ? 3 : ((NCH == 2 && NCF == 2) ? IE_SC_NR_C64O32 : 4), PF = NR - 1; };
 
 struct SConvParams {
@@ -152,9 +155,17 @@ __device__ __forceinline__ void sconv3_body(const SConvParams& p) {
             for (int t = 0; t < 9; ++t)
                 wA[c * 9 + t] = *(const frag*)(wp + ((size_t)(c * 9 + t) * (16 * NCF) + cf * 16 + p16) * 64 + ((kq ^ ((p16 >> 1) & 3)) << 4));
     }
-    ie_f32x4 bias4;
+    // Four K chunks (144 weight + 48 accumulator VGPRs): the bias does not ride in registers as the first C operand but waits in LDS and joins when a row is
+    // parked -- the four registers it frees are the second slot of the fragment ring below (IE_SC_RING4).
+    constexpr bool LDS_BIAS = NCH == 4 && IE_SC_RING4 > 0 && !FIRST && !SUB2;
+    constexpr int OFF_BIAS = OFF_IMG;          // (no image ring in these kernels) 16 NCF floats behind the parked rows
+    ie_f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (LDS_BIAS) {
+        if (tid < 16 * NCF) *(float*)(smem + OFF_BIAS + tid * 4) = p.bias ? p.bias[tid] : 0.f;      // published by the first step's barrier, read from step 2 on
+    } else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) bias4[i] = p.bias ? p.bias[16 * cf + 4 * kq + i] : 0.f;
+        for (int i = 0; i < 4; ++i) bias4[i] = p.bias ? p.bias[16 * cf + 4 * kq + i] : 0.f;
+    }
 
     // ---- DMA geometry: piece m = 16 pixels x 64 B of one chunk; 16-byte position (lane & 3) of ring pixel q holds channel piece
     //      (lane & 3) ^ ((q >> 1) & 3), so the B-operand reads are bank-conflict free at every tap offset ------------------------
@@ -322,8 +333,17 @@ __device__ __forceinline__ void sconv3_body(const SConvParams& p) {
             tl_col[t] = (p16 < p.tail_c && xo < W) ? (unsigned)((p16 * H * W + xo) * 4) : OOB;
         }
     }
-    auto park = [&](const ie_f32x4 (&acc)[4], char* oslot) __attribute__((always_inline)) {
+    auto park = [&](const ie_f32x4 (&acc_)[4], char* oslot) __attribute__((always_inline)) {
         ie_u32x2 pk[4];
+        ie_f32x4 acc[4];
+        if constexpr (LDS_BIAS) {
+            const ie_f32x4 bv = *(const ie_f32x4*)(smem + OFF_BIAS + (16 * cf + 4 * kq) * 4);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[nt] = acc_[nt] + bv;
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[nt] = acc_[nt];
+        }
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             if constexpr (ACT == IE_ACT_RELU) {
@@ -431,7 +451,29 @@ __device__ __forceinline__ void sconv3_body(const SConvParams& p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        } else {      // four K chunks: no registers for a fragment ring (256 VGPRs, 2 spilled with one fragment of look-ahead): the round-2 pipeline
+        } else if constexpr (LDS_BIAS) {      // four K chunks: a ring of TWO fragment registers, the read one fragment ahead of its three MFMAs, order pinned
+            constexpr int NG = NCH * 12, RA = IE_SC_RING4;       // RA fragments ahead, RA + 1 ring slots
+            frag bx[RA + 1];
+            auto rdf = [&](int g) __attribute__((always_inline)) {
+                const int c = g / 12, kx = (g % 12) >> 2, nt = g & 3;
+                const int off = (kx == 0 && nt == 0) ? rd_first : (kx == 2 && nt == 3) ? rd_last : rd_base[kx] + 1024 * nt;
+                bx[g % (RA + 1)] = *(const frag*)(slot + c * SRC_ROW_B + off);
+            };
+#pragma unroll
+            for (int g = 0; g < RA; ++g) rdf(g);
+            __builtin_amdgcn_sched_barrier(0);
+            const ie_f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const int c = g / 12, kx = (g % 12) >> 2, nt = g & 3;
+                if (g + RA < NG) rdf(g + RA);
+                const frag b_ = bx[g % (RA + 1)];
+                accN[nt] = ie_mfma16_raw<T>(wA[c * 9 + 0 * 3 + kx], b_, (c == 0 && kx == 0) ? zero4 : accN[nt]);
+                accM[nt] = ie_mfma16_raw<T>(wA[c * 9 + 1 * 3 + kx], b_, accM[nt]);
+                accO[nt] = ie_mfma16_raw<T>(wA[c * 9 + 2 * 3 + kx], b_, accO[nt]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {      // four K chunks without IE_SC_RING4: no registers for a fragment ring (256 VGPRs, 2 spilled with one fragment of look-ahead): the round-2 pipeline
 #pragma unroll
         for (int c = 0; c < NCH; ++c)
 #pragma unroll
@@ -725,7 +767,7 @@ int ie_sconv3_launch(const void* const* srcs, const int* cs, int nsrc, const voi
     const long long blocks = (long long)p.strips * p.chunks * N;
     if (blocks <= 0 || blocks > 0x7fffffffLL) IE_FAIL(IE_ERR_INVALID, "ie_sconv3: bad grid");
     const int ncf = Cout / 16;
-    const size_t lds = (size_t)(nch == 4 ? 3 : ((nch == 2 && ncf == 2) ? IE_SC_NR_C64O32 : 4)) * SRC_ROW_B * nch + (pool_dst ? 3 : 2) * (size_t)TW * (Cout * 2);
+    const size_t lds = (size_t)(nch == 4 ? 3 : ((nch == 2 && ncf == 2) ? IE_SC_NR_C64O32 : 4)) * SRC_ROW_B * nch + (pool_dst ? 3 : 2) * (size_t)TW * (Cout * 2) + (nch == 4 ? 256 : 0);       // + the bias area of the four-chunk kernels
     SConvFn fn = pick_kernel(dtype == IE_F16, nch, ncf, act, pool_dst != nullptr, tail != nullptr);
     if (!fn) IE_FAIL(IE_ERR_UNSUPPORTED, "ie_sconv3: the fused max-pool / head forms cover Cin <= 64 (ask ie_sconv3_fused_ok)");
     static const int s2skip = getenv("IE_SCONV_S2SKIP") ? atoi(getenv("IE_SCONV_S2SKIP")) : 1;      // A/B: 0 = every row computed
