@@ -162,3 +162,24 @@ def test_rrdnet_restatement_matches_reference():
         assert np.abs(out[k].numpy() - g[k]).max() <= 1e-6, k
     want = torch.clamp(torch.pow(torch.from_numpy(g["illumination"]), 0.4) * ((x - torch.from_numpy(g["noise"])) / torch.from_numpy(g["illumination"])), 0, 1)
     assert torch.equal(out["enhanced"], want)
+
+
+def test_hvi_transform_restatement_properties():
+    """oracle.rgb_to_hvi / hvi_to_rgb (core/image/color.py:313-434; parity unpinned -- `mon.core` is not importable here): known values and the algebra the
+    reference relies on.  Grey pixels sit on the intensity axis, black maps to the origin, the inverse undoes the forward transform on in-gamut colours, the
+    intensity channel is max(R, G, B), and the radius (sin(v pi / 2) + eps)^k shrinks the colour plane for dark pixels."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(2, 3, 16, 20, generator=g)
+    x[0, :, 0, :] = x[0, :1, 0, :]              # greys
+    x[0, :, 1, :] = 0.0                         # black
+    hvi = og.rgb_to_hvi(x, 0.2)
+    assert torch.equal(hvi[:, 2], x.max(1)[0])
+    assert float(hvi[0, :2, 0].abs().max()) == 0.0 and float(hvi[0, :, 1].abs().max()) == 0.0
+    assert float((og.hvi_to_rgb(hvi, 0.2) - x).abs().max()) <= 2e-6
+    pure = torch.tensor([[1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]]).t().reshape(1, 3, 1, 3)      # R, G, B at full value: hue 0, 1/3, 2/3, radius 1
+    h = og.rgb_to_hvi(pure, 0.2)[0]
+    want = torch.tensor([[1.0, -0.5, -0.5], [0.0, 3 ** 0.5 / 2, -(3 ** 0.5) / 2], [1.0, 1.0, 1.0]]).reshape(3, 1, 3)
+    assert float((h - want).abs().max()) <= 1e-6
+    dark, bright = og.rgb_to_hvi(pure * 0.05, 0.2)[0, :2], og.rgb_to_hvi(pure, 0.2)[0, :2]
+    assert float(dark.norm(dim=0).max()) < float(bright.norm(dim=0).min())
+    assert float((og.rgb_to_hvi(pure * 0.05, 1.0)[0, :2].norm(dim=0) - (torch.sin(torch.tensor(0.05 * 3.141592653589793 / 2)) + 1e-8)).abs().max()) <= 1e-6
