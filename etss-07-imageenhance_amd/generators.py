@@ -959,7 +959,34 @@ class UNet(_GraphModel):
             return self._dc_head(f"up{k}.conv", [x2, x1], clamp=clamp)
         return self._dc(f"up{k}.conv", [x2, x1])
 
+    def _first_level_nchw(self, datapoint):
+        """``inc`` + the first max-pool straight from the fp32 NCHW image (ie_unet_first_pool_nchw, 32 channels), or None."""
+        if self.compute_dtype == "f32" or self._f[0] != 32 or self.in_channels != 3:
+            return None
+        x = datapoint.get("image")
+        if not isinstance(x, torch.Tensor):
+            return None
+        x = x[None] if x.dim() == 3 else x
+        if x.dim() != 4 or x.shape[1] != 3:
+            return None
+        self._require_cuda()
+        key = ("unetfirst", "inc.conv1")
+        if self._dev_cache is None:
+            self._dev_cache = {}
+        if key not in self._dev_cache:
+            self._dev_cache[key] = ops.UNetFirstWeights(*self._wb("inc.conv1", "inc.norm1"), self._tdt, self.device)
+        w1, mw2 = self._dev_cache[key], self._mw_plain((32,), "inc.conv2", "inc.norm2")
+        x = x.to(self.device, torch.float32)
+        if not ops.unet_first_pool_applicable(x, w1, mw2):
+            return None
+        return ops.unet_first_pool(x, w1, mw2)
+
     def forward(self, datapoint: dict, *args, **kwargs) -> dict:
+        first = self._first_level_nchw(datapoint)
+        if first is not None:
+            self.assert_datapoint(datapoint)
+            x1, p1 = first
+            return self._after_first_level(x1, p1)
         x = self._input_any(datapoint)
         x1 = None
         if self.compute_dtype != "f32" and x.shape[1] == 8:       # the first DoubleConv + its pool as one launch (conv1's output stays in the kernel)
@@ -969,6 +996,9 @@ class UNet(_GraphModel):
                 x1, p1 = ops.mconv2d_first_pool(x, mw1, mw2)
         if x1 is None:
             x1, p1 = self._dc("inc", [x], pool=True)
+        return self._after_first_level(x1, p1)
+
+    def _after_first_level(self, x1, p1):
         x2, p2 = self._dc("down1.conv", [p1], pool=True)
         x3, p3 = self._dc("down2.conv", [p2], pool=True)
         x4, p4 = self._dc("down3.conv", [p3], pool=True)

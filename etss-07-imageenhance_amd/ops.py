@@ -1037,6 +1037,46 @@ def mconv2d_pair_thin(x, mwa: MConvWeights, mwb: MConvWeights, pad_mode="zeros",
     return (out, out16) if copy16 else out
 
 
+class UNetFirstWeights:
+    """Fragment image of a U-Net's first conv (32, 3, 3, 3) (BatchNorm folded) for ie_unet_first_pool_nchw (+ fp32 bias)."""
+
+    def __init__(self, w_oihw: torch.Tensor, bias, dtype, device):
+        w = w_oihw.detach().to("cpu", torch.float32).contiguous()
+        if tuple(w.shape) != (32, 3, 3, 3):
+            raise capi.IEError(f"UNetFirstWeights: (32, 3, 3, 3) expected, got {tuple(w.shape)}")
+        self.dtype = dtype
+        L = capi.lib()
+        self.w = torch.empty(int(L.ie_unet_first_packed_bytes()), device=device, dtype=torch.uint8)
+        with torch.cuda.device(self.w.device):
+            capi.check(L.ie_unet_first_pack_weights(capi.ptr(w), IE_DT[dtype], capi.ptr(self.w), capi.current_stream()), "ie_unet_first_pack_weights")
+        self.b = None if bias is None else bias.detach().to(device, torch.float32).contiguous()
+
+
+def unet_first_pool_applicable(x_nchw, w1: "UNetFirstWeights", mw2: MConvWeights) -> bool:
+    if x_nchw.dim() != 4 or x_nchw.shape[1] != 3 or x_nchw.dtype != torch.float32 or not x_nchw.is_cuda or w1.dtype != mw2.dtype:
+        return False
+    if mw2.split != [32] or mw2.cout != 32 or (mw2.kh, mw2.kw) != (3, 3):
+        return False
+    return bool(capi.lib().ie_unet_first_applicable(32, int(x_nchw.shape[2]), int(x_nchw.shape[3])))
+
+
+def unet_first_pool(x_nchw, w1: "UNetFirstWeights", mw2: MConvWeights):
+    """fp32 NCHW image -> ``(x1, max_pool2d(x1, 2))`` with x1 = relu(conv2(relu(conv1(image)))) (BatchNorm folded), 16-bit NHWC, in one launch
+    (ie_unet_first_pool_nchw)."""
+    if not unet_first_pool_applicable(x_nchw, w1, mw2):
+        raise capi.IEError("unet_first_pool: (N,3,H,W) fp32 CUDA image, 32 channels, W >= 64")
+    x_nchw = x_nchw.contiguous()
+    n, _, h, w = (int(v) for v in x_nchw.shape)
+    out = torch.empty((n, 32, h, w), device=x_nchw.device, dtype=w1.dtype, memory_format=CL)
+    pooled = torch.empty((n, 32, h // 2, w // 2), device=x_nchw.device, dtype=w1.dtype, memory_format=CL)
+    _count_macs(n, h, w, 32, 3, 3, 3)
+    _count_macs(n, h, w, 32, 32, 3, 3)
+    with torch.cuda.device(x_nchw.device):
+        capi.check(capi.lib().ie_unet_first_pool_nchw(capi.ptr(x_nchw), capi.ptr(w1.w), capi.ptr(w1.b), capi.ptr(mw2.w), capi.ptr(mw2.b), capi.ptr(out), capi.ptr(pooled),
+                                                      IE_DT[w1.dtype], n, h, w, capi.current_stream()), "ie_unet_first_pool_nchw")
+    return out, pooled
+
+
 def unet_up_head_applicable(skip, up, mwa: MConvWeights, mwb: MConvWeights, tail: MTailWeights) -> bool:
     """Can the last decoder level (cat -> DoubleConv -> 1x1 head) run as one launch (ie_unet_up_head_nhwc)?  ``up``: the skip's resolution or half of it."""
     if skip.dim() != 4 or up.dim() != 4 or skip.dtype != up.dtype or skip.dtype != mwa.dtype or mwb.dtype != mwa.dtype or tail.dtype != mwa.dtype:

@@ -238,6 +238,16 @@ size_t ie_conv3x3_c4_packed_bytes(void);
 int ie_conv3x3_c4_pack_weights(const float* w_oihw_host, int dtype, void* dst_dev, void* stream);
 int ie_conv3x3_c4_nhwc(const void* src4_dev, const void* packed_w_dev, const float* bias_dev, void* dst_dev, int dtype, int N, int H, int W, void* stream);
 
+/* The FIRST level of a 32-channel U-Net in one launch, from the caller's fp32 NCHW image: replaces, in reference terms (unet.py:43-48 `inc` = DoubleConv(3, 32),
+ * :70-72 the MaxPool2d(2) of `down1`), x1 = relu(bn(conv3x3(relu(bn(conv3x3(image)))))) and p1 = max_pool2d(x1, 2), BatchNorm folded into the weights.
+ * packed_w1: ie_unet_first_pack_weights of the folded (32, 3, 3, 3) weights (ie_unet_first_packed_bytes() bytes); packed_w2: ie_mconv_pack_weights(channels {32},
+ * Cout 32).  dst: NHWC 32 channels dtype (N, H, W); pool_dst: (N, H / 2, W / 2).  Agrees with the layout pass + ie_mconv_first_pool_nhwc to fp32 rounding. */
+size_t ie_unet_first_packed_bytes(void);
+int ie_unet_first_pack_weights(const float* w_oihw_host, int dtype, void* dst_dev, void* stream);
+int ie_unet_first_applicable(int C, int H, int W);
+int ie_unet_first_pool_nchw(const float* img_nchw_dev, const void* packed_w1_dev, const float* bias1_dev, const void* packed_w2_dev, const float* bias2_dev, void* dst_dev,
+                            void* pool_dst_dev, int dtype, int N, int H, int W, void* stream);
+
 /* The last decoder level of a C-channel U-Net + its head in one launch: replaces, in reference terms (unet.py:75-112 `Up.forward`, :186-195 `outc`),
  *   x = cat([skip, up], 1); x = relu(bn(conv3x3(x)))  [2C -> C];  x = relu(bn(conv3x3(x)))  [C -> C];  y = conv1x1(x)  [C -> tail_cout]  (+ clamp)
  * with BatchNorm folded into the weights.  skip: NHWC C channels dtype.  up: the second source of the concatenation, NHWC C channels -- at the skip's

@@ -298,6 +298,34 @@ def test_thin_output_conv_over_sources_at_their_own_resolution(shape, cout, act,
 
 
 @pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 38, 150), (1, 200, 64), (3, 6, 130), (2, 2, 66), (1, 3, 254), (1, 132, 126), (1, 270, 480), (1, 64, 500)], ids=lambda s: "x".join(map(str, s)))
+def test_unet_first_level_from_the_nchw_image(shape, dt):
+    """ie_unet_first_pool_nchw (unet.py:43-48 `inc`, :70-72 the first MaxPool2d(2)): conv1 + conv2 + pool from the caller's fp32 NCHW image in one launch equals the
+    layout pass + ie_mconv_first_pool_nhwc to fp32 rounding of conv1 (another K order), the pooled copy is F.max_pool2d of ITS full-resolution output bit for bit,
+    and both agree with torch on the same 16-bit operands."""
+    tdt = ops.TORCH_DT[dt]
+    n, h, w = shape
+    g = torch.Generator().manual_seed(59)
+    img = torch.rand(n, 3, h, w, generator=g)
+    w1 = (torch.randn(32, 3, 3, 3, generator=g) / 27 ** 0.5).to(tdt).float()
+    w2 = (torch.randn(32, 32, 3, 3, generator=g) / 17.0).to(tdt).float()
+    b1, b2 = torch.randn(32, generator=g) * 0.2, torch.randn(32, generator=g) * 0.2
+    fw = ops.UNetFirstWeights(w1, b1, tdt, "cuda")
+    mw2 = ops.MConvWeights(w2, b2, [32], tdt, "cuda")
+    assert ops.unet_first_pool_applicable(img.cuda(), fw, mw2)
+    out, pooled = ops.unet_first_pool(img.cuda(), fw, mw2)
+    assert tuple(out.shape) == (n, 32, h, w) and tuple(pooled.shape) == (n, 32, h // 2, w // 2) and out.dtype == tdt
+    assert torch.equal(pooled.float().cpu(), F.max_pool2d(out.float().cpu(), 2))
+    x8 = ops.to_nhwc16(img.cuda(), tdt, 8)
+    mw1 = ops.MConvWeights(w1, b1, [8], tdt, "cuda", cin_map=[0, 1, 2, -1, -1, -1, -1, -1])
+    want, want_p = ops.mconv2d_first_pool(x8, mw1, mw2)
+    tol = 2e-3 if dt == "f16" else 1.6e-2          # a 1-ulp difference of the 16-bit intermediate (conv1 summed in another order) through conv2
+    assert rel_err(out.float().cpu(), want.float().cpu()) <= tol and rel_err(pooled.float().cpu(), want_p.float().cpu()) <= tol
+    ref = F.relu(F.conv2d(F.relu(F.conv2d(x8[:, :3].float().cpu(), w1, b1, padding=1)).to(tdt).float(), w2, b2, padding=1))
+    assert rel_err(out.float().cpu(), ref) <= (3e-3 if dt == "f16" else 2e-2)
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
 @pytest.mark.parametrize("shape", [(2, 37, 150), (1, 200, 64), (3, 6, 129), (1, 270, 480), (2, 2, 66)], ids=lambda s: "x".join(map(str, s)))
 @pytest.mark.parametrize("c", [32, 64])
 def test_first_double_conv_with_pool(c, dt, shape):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Randomised shapes through the strip kernels added in round 3, each against the launches it replaces (or torch on the same 16-bit inputs):
-ie_mconv_pair_nhwc, ie_mconv_pair_thin_nhwc, ie_conv9x9_c4_nhwc, the thin-output form of ie_mconv_nhwc, ie_unet_up_head_nhwc (both forms).
+ie_unet_first_pool_nchw, ie_mconv_pair_nhwc, ie_mconv_pair_thin_nhwc, ie_conv9x9_c4_nhwc, the thin-output form of ie_mconv_nhwc, ie_unet_up_head_nhwc (both forms).
 Usage: python tools/fuzz_round3.py [seconds] [seed]"""
 import os, sys, time, random
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -87,7 +87,21 @@ def case_updc(tdt, n, h, w, pm):
     return rel(got, want), (2e-3 if tdt == torch.float16 else 2e-2) if half else 3e-6      # half: a rare 1-ulp flip of an up-sampled value, amplified by the two convs
 
 
-CASES = {"pair": case_pair, "pair_thin": case_pair_thin, "conv9": case_conv9, "thin3": case_thin3, "updc": case_updc}
+def case_first(tdt, n, h, w, pm):
+    img = torch.rand(n, 3, h, w, generator=g)
+    w1 = (torch.randn(32, 3, 3, 3, generator=g) / 27 ** 0.5).to(tdt).float(); w2 = (torch.randn(32, 32, 3, 3, generator=g) / 17.0).to(tdt).float()
+    b1, b2 = torch.randn(32, generator=g) * 0.2, torch.randn(32, generator=g) * 0.2
+    fw = ops.UNetFirstWeights(w1, b1, tdt, "cuda"); m2 = ops.MConvWeights(w2, b2, [32], tdt, "cuda")
+    if h < 2 or not ops.unet_first_pool_applicable(img.cuda(), fw, m2):
+        return 0.0, 0.0
+    out, pooled = ops.unet_first_pool(img.cuda(), fw, m2)
+    if not torch.equal(pooled.float().cpu(), F.max_pool2d(out.float().cpu(), 2)):
+        return 1.0, 0.0
+    ref = F.relu(F.conv2d(F.relu(F.conv2d(img.to(tdt).float(), w1, b1, padding=1)).to(tdt).float(), w2, b2, padding=1))
+    return rel(out.float().cpu(), ref), 3e-3 if tdt == torch.float16 else 2e-2
+
+
+CASES = {"first": case_first, "pair": case_pair, "pair_thin": case_pair_thin, "conv9": case_conv9, "thin3": case_thin3, "updc": case_updc}
 t0, done, bad = time.time(), {k: 0 for k in CASES}, 0
 while time.time() - t0 < budget:
     name = rng.choice(list(CASES))
