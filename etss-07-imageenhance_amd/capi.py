@@ -33,7 +33,7 @@ SYMBOLS = [
     "ie_mconv_packed_bytes", "ie_mconv_pack_weights", "ie_mconv_pack_weights_dev", "ie_mconv_nhwc", "ie_dsconv_nhwc",
     "ie_norm_forward_nhwc_f32", "ie_norm_backward_nhwc_f32", "ie_convn_wgrad_nhwc_f32", "ie_convn_dgrad_nhwc_f32",
     "ie_maxpool2x2_backward_nhwc_f32", "ie_resize_backward_nhwc_f32", "ie_crop_nhwc_f32", "ie_pixel_unshuffle_nhwc_f32",
-    "ie_act_backward_f32", "ie_act_backward", "ie_pixel_unshuffle_nhwc", "ie_l1_loss_f32", "ie_ssim_forward_f32", "ie_ssim_backward_f32", "ie_sumsq_f32", "ie_adam_step_f32", "ie_adam_step_counted_f32", "ie_set_deterministic", "ie_get_deterministic", "ie_zdce_forward_u8", "ie_mconv_pair_applicable", "ie_mconv_pair_nhwc", "ie_mconv_pair_thin_applicable", "ie_mconv_pair_thin_nhwc", "ie_retinex_decom_input", "ie_retinex_outputs_f32", "ie_unet_up_head_applicable", "ie_unet_up_head_nhwc", "ie_unet_first_packed_bytes", "ie_unet_first_pack_weights", "ie_unet_first_applicable", "ie_unet_first_pool_nchw", "ie_conv9x9_c4_packed_bytes", "ie_conv9x9_c4_pack_weights", "ie_conv9x9_c4_nhwc", "ie_conv3x3_c4_packed_bytes", "ie_conv3x3_c4_pack_weights", "ie_conv3x3_c4_nhwc", "ie_paste_nhwc", "ie_channel_stats_nhwc", "ie_channel_affine_nhwc", "ie_channel_affine_add_nhwc", "ie_simam_nhwc", "ie_retinex_recon_f32", "ie_l1_detached_f32", "ie_retinex_smooth_ws_floats",
+    "ie_act_backward_f32", "ie_act_backward", "ie_pixel_unshuffle_nhwc", "ie_l1_loss_f32", "ie_ssim_forward_f32", "ie_ssim_backward_f32", "ie_sumsq_f32", "ie_adam_step_f32", "ie_adam_step_counted_f32", "ie_set_deterministic", "ie_get_deterministic", "ie_zdce_forward_u8", "ie_mconv_pair_applicable", "ie_mconv_pair_nhwc", "ie_mconv_pair_thin_applicable", "ie_mconv_pair_thin_nhwc", "ie_mconv_pair_pool_applicable", "ie_mconv_pair_pool_nhwc", "ie_retinex_decom_input", "ie_retinex_outputs_f32", "ie_unet_up_head_applicable", "ie_unet_up_head_nhwc", "ie_unet_first_packed_bytes", "ie_unet_first_pack_weights", "ie_unet_first_applicable", "ie_unet_first_pool_nchw", "ie_conv9x9_c4_packed_bytes", "ie_conv9x9_c4_pack_weights", "ie_conv9x9_c4_nhwc", "ie_conv3x3_c4_packed_bytes", "ie_conv3x3_c4_pack_weights", "ie_conv3x3_c4_nhwc", "ie_paste_nhwc", "ie_channel_stats_nhwc", "ie_channel_affine_nhwc", "ie_channel_affine_add_nhwc", "ie_simam_nhwc", "ie_retinex_recon_f32", "ie_l1_detached_f32", "ie_retinex_smooth_ws_floats",
     "ie_retinex_smooth_f32", "ie_pad_replicate_nhwc_f32", "ie_pad_replicate_backward_nhwc_f32", "ie_pad_replicate_nhwc", "ie_pad_replicate_backward_nhwc", "ie_zero_insert2_nhwc", "ie_rgb_to_hsv_nhwc_f32", "ie_hsv_to_rgb_nhwc_f32", "ie_rgb_to_hvi_nhwc_f32", "ie_hvi_to_rgb_nhwc_f32", "ie_le_curve_nhwc_f32", "ie_box_filter_nhwc_f32", "ie_guided_filter_nhwc_f32", "ie_fast_guided_filter_nhwc_f32", "ie_resize_bicubic_nhwc_f32", "ie_reduce_max_f32", "ie_median_blur_nhwc_f32", "ie_sobel_nhwc_f32", "ie_channel_stats_nhwc_f32", "ie_lin_coeffs_f32", "ie_stats_mean_f32", "ie_channel_affine_nhwc_f32", "ie_simam_nhwc_f32",
     "ie_norm_forward_nhwc", "ie_norm_backward_nhwc", "ie_convn_wgrad_nhwc", "ie_maxpool2x2_backward_nhwc", "ie_resize_backward_nhwc", "ie_crop_nhwc",
     "ie_zref_workspace_floats", "ie_zref_image_losses_f32", "ie_tv_loss_nhwc_f32", "ie_le_curve_backward",
@@ -134,6 +134,8 @@ def lib():
     L.ie_mconv_pair_nhwc.argtypes = [vp, vp, vp, vp, vp, vp, ip, ip, ip, ip, ip, vp]
     L.ie_mconv_pair_thin_applicable.argtypes = [ip] * 11
     L.ie_mconv_pair_thin_nhwc.argtypes = [vp, vp, vp, vp, vp, vp, vp, ip, ip, ip, ip, ip, ip, ip, ip, vp]
+    L.ie_mconv_pair_pool_applicable.argtypes = [ip] * 12
+    L.ie_mconv_pair_pool_nhwc.argtypes = [vp, vp, vp, vp, vp, vp, vp, ip, ip, ip, ip, ip, vp]
     L.ie_pad_replicate_nhwc.argtypes = [vp, vp, ip, ip, ip, ip, ip, ip, vp]
     L.ie_pad_replicate_backward_nhwc.argtypes = [vp, vp, ip, ip, ip, ip, ip, ip, ip, vp]
     L.ie_zero_insert2_nhwc.argtypes = [vp, vp, ip, ip, ip, ip, ip, ip, ip, vp]

@@ -50,4 +50,4 @@ int ie_sconv3_thin3_launch(const void* const* srcs, int nsrc, const int* src_h, 
                            int H, int W, int Cout, int act, int pad_mode, hipStream_t st);
 // two stacked Conv3x3(64 -> 64) + bias + ReLU layers, the intermediate in LDS only (ie_conv_pair.hip)
 int ie_sconv3x2_launch(const void* src, const void* w_a, const float* bias_a, const void* w_b, const float* bias_b, void* dst, int dtype, int N, int H, int W,
-                       int pad_mode, int cout_b, int act_b, void* dst16, int dst16_c, hipStream_t st);
+                       int pad_mode, int cout_b, int act_b, void* dst16, int dst16_c, void* pool_dst, hipStream_t st);

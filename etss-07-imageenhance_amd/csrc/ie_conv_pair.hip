@@ -21,6 +21,7 @@
 #include "ie_conv_internal.h"
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 
 namespace {
 
@@ -33,11 +34,13 @@ constexpr int PF = 3, NRA = PF + 1, NRH = 3;
 constexpr int OPB = 128;                      // output bytes per pixel
 constexpr int OUT_ROW_B = TW * OPB;
 constexpr int OFF_H = NRA * SLOT_B, OFF_OUT = OFF_H + NRH * SLOT_B, LDS_B = OFF_OUT + 2 * OUT_ROW_B;      // 67,584 + 50,688 + 32,768 = 151,040
+constexpr int LDS_POOL_B = NRA * CH_ROW_B + NRH * SLOT_B + 3 * OUT_ROW_B;                               // 32 -> 64 -> 64 + pool: 33,792 + 50,688 + 49,152 = 133,632
 
 struct PairParams {
     const void* src; const void* wa; const float* ba; const void* wb; const float* bb; void* dst;
     int N, H, W, rows_per_block, strips, chunks, replicate;
     int cout_b, act_b;       // thin second layer (CB == 16): its real output channels (4, 8, 12 or 16) and activation; dst is fp32 NHWC then
+    void* pool;              // POOL: the 2x2 max-pooled copy of dst (NHWC 64 channels, N x H/2 x W/2)
     void* dst16;             // thin: optional second copy of the output as 16-bit NHWC (cout_b == 4), with dst16_c = 4 channels or padded to 8, or null
     int dst16_c;
 };
@@ -59,9 +62,15 @@ __device__ __forceinline__ void wait_vm_cold(int n) {
 // CB = 64: the second layer is 64 -> 64 + ReLU, 16-bit output.  CB = 16: the second layer is thin (64 -> cout_b <= 16, any activation, fp32 output):
 // its four waves split the strip by pixel tiles (two each) instead of by output channels, and a finished row leaves straight from the accumulators --
 // lane (pixel, kq) holds channels 4 kq .. 4 kq + 3 of its pixel, 16 contiguous bytes of the fp32 NHWC row.
-template <typename T, int CB>
+// CA = 32: the first layer is 32 -> 64 (one K chunk: U-Net-32's `down1`, unet.py:70-72 + 43-48).  POOL: the 64-channel output also leaves max-pooled 2x2 (three parked
+// rows; a pooled row every second step from the two newest ones; values are ReLU outputs: compared as unsigned 16-bit integers).
+template <typename T, int CB, int CA = 64, bool POOL = false>
 __device__ __forceinline__ void sconv3x2_body(const PairParams& p) {
     constexpr bool THIN = CB == 16;
+    constexpr int NCA = CA / 32, IPB = CA * 2;                     // stage A's K chunks; input bytes per pixel
+    constexpr int SLOT_A = NCA * CH_ROW_B;                         // stage A's ring row
+    constexpr int OFF_H = NRA * SLOT_A, OFF_OUT = OFF_H + NRH * SLOT_B, NPARK = POOL ? 3 : 2;
+    static_assert(!POOL || (!THIN && CA == 32), "the pooled form exists for 32 -> 64 -> 64 (LDS)");
     using frag = ie_u32x4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -82,9 +91,12 @@ __device__ __forceinline__ void sconv3x2_body(const PairParams& p) {
     auto mk = [&](const void* base, size_t bytes) __attribute__((always_inline)) {
         return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
     };
-    const size_t frame_b = (size_t)H * W * OPB;
+    const size_t frame_b = (size_t)H * W * IPB;
     const auto rsS = mk((const char*)p.src + (size_t)n * frame_b, frame_b);
-    const size_t dframe_b = THIN ? (size_t)H * W * p.cout_b * 4 : frame_b;
+    const size_t dframe_b = THIN ? (size_t)H * W * p.cout_b * 4 : (size_t)H * W * OPB;
+    const int Hp = H >> 1, Wp = W >> 1;
+    const size_t pool_b = (size_t)Hp * Wp * OPB;
+    const auto rsP = mk(POOL ? (char*)p.pool + (size_t)n * pool_b : (char*)p.dst, POOL ? pool_b : 0);
     const auto rsD = mk((char*)p.dst + (size_t)n * dframe_b, dframe_b);
 
     // ---- this wave's 18 weight fragments and 4 biases ----------------------------------------------------------------------------------
@@ -96,7 +108,8 @@ __device__ __forceinline__ void sconv3x2_body(const PairParams& p) {
         for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int t = 0; t < 9; ++t)
-                wv[c * 9 + t] = *(const frag*)(wp + ((size_t)(c * 9 + t) * wrows + wcf * 16 + p16) * 64 + ((kq ^ ((p16 >> 1) & 3)) << 4));
+                wv[c * 9 + t] = (stg == 0 && c >= NCA) ? frag{0u, 0u, 0u, 0u}
+                                                        : *(const frag*)(wp + ((size_t)(c * 9 + t) * wrows + wcf * 16 + p16) * 64 + ((kq ^ ((p16 >> 1) & 3)) << 4));
     }
     ie_f32x4 bias4;
     {
@@ -114,7 +127,7 @@ __device__ __forceinline__ void sconv3x2_body(const PairParams& p) {
         const int q = (2 * cf + j) * 16 + (lane >> 2);
         int x = xc0 + q;
         if (rep) x = min(max(x, 0), W - 1);
-        body_off[j] = (x >= 0 && x < W) ? (unsigned)(x * OPB + (((lane & 3) ^ ((q >> 1) & 3)) << 4)) : OOB;
+        body_off[j] = (x >= 0 && x < W) ? (unsigned)(x * IPB + (((lane & 3) ^ ((q >> 1) & 3)) << 4)) : OOB;
     }
     {
         // the two halo pixels (ring pixels 128, 129; (128 >> 1) & 3 == (129 >> 1) & 3 == 0: no swizzle) as ONE 4-byte-per-lane DMA over ring pixels
@@ -124,16 +137,16 @@ __device__ __forceinline__ void sconv3x2_body(const PairParams& p) {
         const int hp = lane >> 4;
         int x = hp == 0 ? (xc0 - 1) : (xc0 + TW);
         if (rep) x = min(max(x, 0), W - 1);
-        halo_off = (hp < 2 && x >= 0 && x < W) ? (unsigned)(x * OPB + (lane & 15) * 4) : OOB;
+        halo_off = (hp < 2 && x >= 0 && x < W) ? (unsigned)(x * IPB + (lane & 15) * 4) : OOB;
     }
     auto issue = [&](int t) __attribute__((always_inline)) {        // input row of stage A's step t
         int yi = ys - 2 + t;
         if (rep) yi = min(max(yi, 0), H - 1);
         const unsigned rmask = (yi >= 0 && yi < H) ? 0u : OOB;
-        const unsigned row_b = rmask ? 0u : (unsigned)yi * (unsigned)W * OPB;
-        char* slot = smem + (t % NRA) * SLOT_B;
+        const unsigned row_b = rmask ? 0u : (unsigned)yi * (unsigned)W * IPB;
+        char* slot = smem + (t % NRA) * SLOT_A;
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
+        for (int c = 0; c < NCA; ++c) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsS, (__attribute__((address_space(3))) void*)(slot + c * CH_ROW_B + (2 * cf + j) * 1024), 16,
@@ -143,7 +156,7 @@ __device__ __forceinline__ void sconv3x2_body(const PairParams& p) {
                                                          (int)((row_b + halo_off + c * 64) | rmask), 0, 0, 0);
         }
     };
-    const int LA = 4 + (cf == 3 ? 2 : 0);             // DMA instructions per step of this (stage A) wave
+    const int LA = 2 * NCA + (cf == 3 ? NCA : 0);     // DMA instructions per step of this (stage A) wave
 
     // ---- fragment read offsets: lane (p16, kq) of pixel tile nt at tap column kx reads chunk piece kq of ring pixel 16 nt + p16 + kx - 1 ----
     auto lds_px = [&](int q) __attribute__((always_inline)) { return q * PXB + ((kq ^ ((q >> 1) & 3)) << 4); };
@@ -200,7 +213,8 @@ __device__ __forceinline__ void sconv3x2_body(const PairParams& p) {
     // one row into the three live accumulator sets (ky = 0: the set this row starts takes the bias as its first C operand)
     // The order is pinned (sched_barrier after every fragment's three MFMAs) with the fragment reads three ahead of their use: left to itself the
     // scheduler chained the 144 MFMAs per accumulator and waited lgkmcnt(0) behind every read.
-    auto row_mfma = [&](const char* slot, ie_f32x4 (&accN)[8], ie_f32x4 (&accM)[8], ie_f32x4 (&accO)[8]) __attribute__((always_inline)) {
+    auto row_mfma = [&](const char* slot, auto nck_tag, ie_f32x4 (&accN)[8], ie_f32x4 (&accM)[8], ie_f32x4 (&accO)[8]) __attribute__((always_inline)) {
+        constexpr int NG = decltype(nck_tag)::value * 24;
         frag bx[4];
         auto rdf = [&](int g) __attribute__((always_inline)) {         // g = (chunk, kx, tile), compile-time at every call
             const int c = g / 24, kx = (g % 24) >> 3, nt = g & 7;
@@ -210,9 +224,9 @@ __device__ __forceinline__ void sconv3x2_body(const PairParams& p) {
         rdf(0); rdf(1); rdf(2);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int g = 0; g < 48; ++g) {
+        for (int g = 0; g < NG; ++g) {
             const int c = g / 24, kx = (g % 24) >> 3, nt = g & 7;
-            if (g + 3 < 48) rdf(g + 3);
+            if (g + 3 < NG) rdf(g + 3);
             accN[nt] = ie_mfma16_raw<T>(wv[c * 9 + 0 * 3 + kx], bx[g & 3], (c == 0 && kx == 0) ? bias4 : accN[nt]);
             accM[nt] = ie_mfma16_raw<T>(wv[c * 9 + 1 * 3 + kx], bx[g & 3], accM[nt]);
             accO[nt] = ie_mfma16_raw<T>(wv[c * 9 + 2 * 3 + kx], bx[g & 3], accO[nt]);
@@ -255,6 +269,20 @@ __device__ __forceinline__ void sconv3x2_body(const PairParams& p) {
         st_lds[i] = q * OPB + ((c ^ (q & 7)) << 4);
     }
 
+    // POOL: lane (of stage B's 256) owns pieces e = 0, 1 of the pooled row: pooled pixel xp = computed columns 2 xp + 1, 2 xp + 2 (image columns xc0 + 1 + 2 xp, even), piece pc
+    int pl_lds[2][2] = {{0, 0}, {0, 0}};
+    unsigned pl_col[2] = {OOB, OOB};
+    if constexpr (POOL) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int pi = e * 256 + cf * 64 + lane, xp = pi >> 3, pc = pi & 7, q0 = 2 * xp + 1, q1 = 2 * xp + 2;
+            pl_lds[e][0] = q0 * OPB + ((pc ^ (q0 & 7)) << 4);
+            pl_lds[e][1] = (q1 < TW ? q1 : q0) * OPB + ((pc ^ ((q1 < TW ? q1 : q0) & 7)) << 4);
+            const int xcol = ((xc0 + 1) >> 1) + xp;
+            pl_col[e] = (q1 <= TS && xcol < (p.W >> 1)) ? (unsigned)(xcol * OPB + pc * 16) : OOB;
+        }
+    }
+
     ie_f32x4 a0[8], a1[8], a2[8];
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) { a0[nt] = bias4; a1[nt] = bias4; a2[nt] = bias4; }
@@ -264,11 +292,11 @@ __device__ __forceinline__ void sconv3x2_body(const PairParams& p) {
 #pragma unroll
         for (int t = 0; t < PF; ++t) issue(t);
         auto step_a = [&](int t, ie_f32x4 (&accN)[8], ie_f32x4 (&accM)[8], ie_f32x4 (&accO)[8]) __attribute__((always_inline)) {
-            if (cf == 3) ie_wait_vm_hot<(PF - 1) * 6>((PF - 1) * 6, [](int n_) __attribute__((always_inline)) { wait_vm_cold(n_); });
-            else ie_wait_vm_hot<(PF - 1) * 4>((PF - 1) * 4, [](int n_) __attribute__((always_inline)) { wait_vm_cold(n_); });
+            if (cf == 3) ie_wait_vm_hot<(PF - 1) * 3 * NCA>((PF - 1) * 3 * NCA, [](int n_) __attribute__((always_inline)) { wait_vm_cold(n_); });
+            else ie_wait_vm_hot<(PF - 1) * 2 * NCA>((PF - 1) * 2 * NCA, [](int n_) __attribute__((always_inline)) { wait_vm_cold(n_); });
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            row_mfma(smem + (t % NRA) * SLOT_B, accN, accM, accO);
+            row_mfma(smem + (t % NRA) * SLOT_A, std::integral_constant<int, NCA>{}, accN, accM, accO);
             issue(t + PF);
             const int m = ys - 3 + t;
             const bool row_in = m >= 0 && m < H;
@@ -343,18 +371,32 @@ __device__ __forceinline__ void sconv3x2_body(const PairParams& p) {
                 const int yo = ys - 8 + t;
                 const unsigned rmask = (yo >= ys && yo < ye) ? 0u : OOB;
                 const unsigned row_b = rmask ? 0u : (unsigned)yo * (unsigned)W * OPB;
-                const char* islot = smem + OFF_OUT + ((t + 1) & 1) * OUT_ROW_B;
+                const char* islot = smem + OFF_OUT + ((t + NPARK - 1) % NPARK) * OUT_ROW_B;          // parked at step t - 1
                 ie_u32x4 ln[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) ln[i] = *(const ie_u32x4*)(islot + st_lds[i]);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_buffer_store_b128(ln[i], rsD, (int)((row_b + st_col[i]) | rmask), 0, 0);
+                if constexpr (POOL) {       // rows yo - 1 (parked at step t - 2) and yo make pooled row (yo - 1) / 2 when yo is odd (ys is even)
+                    const char* jslot = smem + OFF_OUT + ((t + NPARK - 2) % NPARK) * OUT_ROW_B;
+                    const bool ok = !rmask && (yo & 1) && yo - 1 >= ys && (yo >> 1) < Hp;
+                    const unsigned pmask = ok ? 0u : OOB;
+                    const unsigned prow_b = ok ? (unsigned)(yo >> 1) * (unsigned)Wp * OPB : 0u;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        typedef __attribute__((ext_vector_type(8))) short i16x8;      // ReLU outputs: non-negative floats order as signed integers (-0 loses)
+                        const i16x8 v0 = *(const i16x8*)(jslot + pl_lds[e][0]), v1 = *(const i16x8*)(jslot + pl_lds[e][1]);
+                        const i16x8 v2 = *(const i16x8*)(islot + pl_lds[e][0]), v3 = *(const i16x8*)(islot + pl_lds[e][1]);
+                        const i16x8 pv = __builtin_elementwise_max(__builtin_elementwise_max(v0, v1), __builtin_elementwise_max(v2, v3));
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ie_u32x4, pv), rsP, (int)((prow_b + pl_col[e]) | pmask), 0, 0);
+                    }
+                }
             }
-            put_row(accN, smem + OFF_OUT + (t & 1) * OUT_ROW_B, pk_off, 32 * OPB, 0xfu);
+            put_row(accN, smem + OFF_OUT + (t % NPARK) * OUT_ROW_B, pk_off, 32 * OPB, 0xfu);
             int mc = ys - 5 + t;
             if (rep) mc = min(max(mc, 0), H - 1);
             const int ta = mc - ys + 3;                       // stage A's step that wrote it (>= 2)
-            row_mfma(smem + OFF_H + ((ta < 0 ? 0 : ta) % NRH) * SLOT_B, accN, accM, accO);
+            row_mfma(smem + OFF_H + ((ta < 0 ? 0 : ta) % NRH) * SLOT_B, std::integral_constant<int, 2>{}, accN, accM, accO);
         };
         for (int t = 0; t < n_steps; t += 3) {
             step_b(t, a0, a1, a2);
@@ -367,6 +409,8 @@ __device__ __forceinline__ void sconv3x2_body(const PairParams& p) {
 
 __global__ __launch_bounds__(512) void sconv3x2_f16_c64_c64_c64_relu(PairParams p) { sconv3x2_body<_Float16, 64>(p); }
 __global__ __launch_bounds__(512) void sconv3x2_bf16_c64_c64_c64_relu(PairParams p) { sconv3x2_body<__bf16, 64>(p); }
+__global__ __launch_bounds__(512) void sconv3x2_f16_c32_c64_c64_relu_pool(PairParams p) { sconv3x2_body<_Float16, 64, 32, true>(p); }
+__global__ __launch_bounds__(512) void sconv3x2_bf16_c32_c64_c64_relu_pool(PairParams p) { sconv3x2_body<__bf16, 64, 32, true>(p); }
 __global__ __launch_bounds__(512) void sconv3x2_f16_c64_c64_thin_f32(PairParams p) { sconv3x2_body<_Float16, 16>(p); }
 __global__ __launch_bounds__(512) void sconv3x2_bf16_c64_c64_thin_f32(PairParams p) { sconv3x2_body<__bf16, 16>(p); }
 
@@ -377,9 +421,10 @@ __global__ __launch_bounds__(512) void sconv3x2_bf16_c64_c64_thin_f32(PairParams
 // cout_b = 64: as above.  cout_b in {4, 8, 12, 16}: the second layer is thin -- dst is fp32 NHWC with cout_b channels, act_b its activation (none / relu /
 // sigmoid / tanh), dst16 an optional 16-bit NHWC copy padded to 8 channels (cout_b == 4).
 int ie_sconv3x2_launch(const void* src, const void* w_a, const float* bias_a, const void* w_b, const float* bias_b, void* dst, int dtype, int N, int H, int W,
-                       int pad_mode, int cout_b, int act_b, void* dst16, int dst16_c, hipStream_t st) {
+                       int pad_mode, int cout_b, int act_b, void* dst16, int dst16_c, void* pool_dst, hipStream_t st) {
     if (!src || !w_a || !w_b || !dst || N <= 0 || H < 1 || W < 64) IE_FAIL(IE_ERR_UNSUPPORTED, "ie_sconv3x2: 64 channels, W >= 64");
-    const bool thin = cout_b != 64;
+    const bool thin = cout_b != 64, pool = pool_dst != nullptr;       // pool: the 32 -> 64 -> 64 form (src has 32 channels)
+    if (pool && (thin || H < 2)) IE_FAIL(IE_ERR_UNSUPPORTED, "ie_sconv3x2: the pooled form has 64 output channels and H >= 2");
     if (thin && (cout_b < 4 || cout_b > 16 || (cout_b & 3) || (dst16 && cout_b != 4)))
         IE_FAIL(IE_ERR_UNSUPPORTED, "ie_sconv3x2: thin second layer needs 4, 8, 12 or 16 output channels (4 with a 16-bit copy), got %d", cout_b);
     if (thin && act_b != IE_ACT_NONE && act_b != IE_ACT_RELU && act_b != IE_ACT_SIGMOID && act_b != IE_ACT_TANH)
@@ -389,7 +434,7 @@ int ie_sconv3x2_launch(const void* src, const void* w_a, const float* bias_a, co
     PairParams p;
     memset(&p, 0, sizeof(p));
     p.src = src; p.wa = w_a; p.ba = bias_a; p.wb = w_b; p.bb = bias_b; p.dst = dst; p.N = N; p.H = H; p.W = W; p.replicate = pad_mode == IE_PAD_REPLICATE;
-    p.cout_b = cout_b; p.act_b = act_b; p.dst16 = thin ? dst16 : nullptr; p.dst16_c = dst16_c == 4 ? 4 : 8;
+    p.cout_b = cout_b; p.act_b = act_b; p.dst16 = thin ? dst16 : nullptr; p.dst16_c = dst16_c == 4 ? 4 : 8; p.pool = pool_dst;
     p.strips = ie_cdiv(W, TS);
     {
         // row chunks: whole rounds of the chip's 256 workgroup slots (one 8-wave workgroup per CU), few apron rows (8 steps per chunk)
@@ -398,29 +443,34 @@ int ie_sconv3x2_launch(const void* src, const void* w_a, const float* bias_a, co
         int best_c = 1;
         double best = -1.0;
         for (int c = 1; c <= H && c <= 64; ++c) {
-            const int rpb = ie_cdiv(H, c), cc = ie_cdiv(H, rpb);
+            int rpb = ie_cdiv(H, c);
+            if (pool) rpb += rpb & 1;                  // pooled rows are made of a chunk's own row pairs
+            const int cc = ie_cdiv(H, rpb);
             const long long blocks = base * cc;
             const long long rounds = (blocks + slots - 1) / slots;
             const double score = (double)blocks / (double)(rounds * slots) * ((double)rpb / (double)(rpb + 8));
             if (score > best + 1e-9) { best = score; best_c = cc; }
         }
         p.rows_per_block = ie_cdiv(H, best_c);
+        if (pool) p.rows_per_block += p.rows_per_block & 1;
         p.chunks = ie_cdiv(H, p.rows_per_block);
     }
     const long long blocks = (long long)p.strips * p.chunks * N;
     if (blocks <= 0 || blocks > 0x7fffffffLL) IE_FAIL(IE_ERR_INVALID, "ie_sconv3x2: bad grid");
     typedef void (*Fn)(PairParams);
-    const int fi = (dtype == IE_F16 ? 0 : 1) + (thin ? 2 : 0);
-    static const Fn fns[4] = {sconv3x2_f16_c64_c64_c64_relu, sconv3x2_bf16_c64_c64_c64_relu, sconv3x2_f16_c64_c64_thin_f32, sconv3x2_bf16_c64_c64_thin_f32};
+    const int fi = (dtype == IE_F16 ? 0 : 1) + (pool ? 4 : thin ? 2 : 0);
+    static const Fn fns[6] = {sconv3x2_f16_c64_c64_c64_relu, sconv3x2_bf16_c64_c64_c64_relu, sconv3x2_f16_c64_c64_thin_f32, sconv3x2_bf16_c64_c64_thin_f32,
+                              sconv3x2_f16_c32_c64_c64_relu_pool, sconv3x2_bf16_c32_c64_c64_relu_pool};
     const Fn fn = fns[fi];
-    static bool granted[4] = {false, false, false, false};
+    const int lds = pool ? LDS_POOL_B : LDS_B;
+    static bool granted[6] = {false, false, false, false, false, false};
     if (!granted[fi]) {
-        hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
-        if (e != hipSuccess) IE_FAIL(IE_ERR_HIP, "hipFuncSetAttribute(lds=%d): %s", LDS_B, hipGetErrorString(e));
+        hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) IE_FAIL(IE_ERR_HIP, "hipFuncSetAttribute(lds=%d): %s", lds, hipGetErrorString(e));
         granted[fi] = true;
     }
     void* args[] = {(void*)&p};
-    IE_HIP_CHECK(hipLaunchKernel((const void*)fn, dim3((unsigned)blocks), dim3(512), args, LDS_B, st));
+    IE_HIP_CHECK(hipLaunchKernel((const void*)fn, dim3((unsigned)blocks), dim3(512), args, lds, st));
     return IE_OK;
 }
 
@@ -434,7 +484,22 @@ IE_EXPORT int ie_mconv_pair_applicable(int cin, int cmid, int cout, int kh, int 
 IE_EXPORT int ie_mconv_pair_nhwc(const void* src, const void* packed_w_a, const float* bias_a, const void* packed_w_b, const float* bias_b, void* dst,
                                  int dtype, int N, int H, int W, int pad_mode, void* stream) {
     if (pad_mode != IE_PAD_ZEROS && pad_mode != IE_PAD_REPLICATE) IE_FAIL(IE_ERR_INVALID, "ie_mconv_pair_nhwc: pad_mode %d", pad_mode);
-    return ie_sconv3x2_launch(src, packed_w_a, bias_a, packed_w_b, bias_b, dst, dtype, N, H, W, pad_mode, 64, IE_ACT_RELU, nullptr, 8, (hipStream_t)stream);
+    return ie_sconv3x2_launch(src, packed_w_a, bias_a, packed_w_b, bias_b, dst, dtype, N, H, W, pad_mode, 64, IE_ACT_RELU, nullptr, 8, nullptr, (hipStream_t)stream);
+}
+
+// U-Net-32's second encoder level (unet.py:70-72: MaxPool after DoubleConv(32, 64)): Conv3x3(32 -> 64) + ReLU, Conv3x3(64 -> 64) + ReLU, and the 2x2 max-pooled copy
+// of the result, in one launch.  src: NHWC 32 channels; dst: NHWC 64 channels (the skip tensor); pool_dst: NHWC 64 channels, N x floor(H/2) x floor(W/2).
+IE_EXPORT int ie_mconv_pair_pool_applicable(int cin, int cmid, int cout, int kh, int kw, int stride, int pad, int pad_mode, int act_a, int act_b, int H, int W) {
+    static const int off = getenv("IE_SCONV_PAIR_POOL") ? !atoi(getenv("IE_SCONV_PAIR_POOL")) : 0;
+    return (!off && cin == 32 && cmid == 64 && cout == 64 && kh == 3 && kw == 3 && stride == 1 && pad == 1 && (pad_mode == IE_PAD_ZEROS || pad_mode == IE_PAD_REPLICATE) &&
+            act_a == IE_ACT_RELU && act_b == IE_ACT_RELU && W >= 64 && H >= 2) ? 1 : 0;
+}
+
+IE_EXPORT int ie_mconv_pair_pool_nhwc(const void* src, const void* packed_w_a, const float* bias_a, const void* packed_w_b, const float* bias_b, void* dst, void* pool_dst,
+                                      int dtype, int N, int H, int W, int pad_mode, void* stream) {
+    if (pad_mode != IE_PAD_ZEROS && pad_mode != IE_PAD_REPLICATE) IE_FAIL(IE_ERR_INVALID, "ie_mconv_pair_pool_nhwc: pad_mode %d", pad_mode);
+    if (!pool_dst) IE_FAIL(IE_ERR_INVALID, "ie_mconv_pair_pool_nhwc: pool_dst is null");
+    return ie_sconv3x2_launch(src, packed_w_a, bias_a, packed_w_b, bias_b, dst, dtype, N, H, W, pad_mode, 64, IE_ACT_RELU, nullptr, 8, pool_dst, (hipStream_t)stream);
 }
 
 IE_EXPORT int ie_mconv_pair_thin_applicable(int cin, int cmid, int cout, int kh, int kw, int stride, int pad, int pad_mode, int act_a, int act_b, int W) {
@@ -449,5 +514,5 @@ IE_EXPORT int ie_mconv_pair_thin_nhwc(const void* src, const void* packed_w_a, c
     if (pad_mode != IE_PAD_ZEROS && pad_mode != IE_PAD_REPLICATE) IE_FAIL(IE_ERR_INVALID, "ie_mconv_pair_thin_nhwc: pad_mode %d", pad_mode);
     if (cout_b == 64) IE_FAIL(IE_ERR_INVALID, "ie_mconv_pair_thin_nhwc: 64 output channels is ie_mconv_pair_nhwc");
     if (dst16 && dst16_channels != 4 && dst16_channels != 8) IE_FAIL(IE_ERR_INVALID, "ie_mconv_pair_thin_nhwc: the 16-bit copy has 4 or 8 channels");
-    return ie_sconv3x2_launch(src, packed_w_a, bias_a, packed_w_b, bias_b, dst_f32, dtype, N, H, W, pad_mode, cout_b, act_b, dst16, dst16_channels, (hipStream_t)stream);
+    return ie_sconv3x2_launch(src, packed_w_a, bias_a, packed_w_b, bias_b, dst_f32, dtype, N, H, W, pad_mode, cout_b, act_b, dst16, dst16_channels, nullptr, (hipStream_t)stream);
 }

@@ -907,6 +907,11 @@ class UNet(_GraphModel):
 
     def _dc(self, name, srcs, pool=False):
         """DoubleConv; ``pool=True`` also returns the MaxPool2d(2) the next ``Down`` starts with (unet.py:70-72)."""
+        if pool and self.compute_dtype != "f32" and isinstance(srcs, (list, tuple)) and len(srcs) == 1 and int(srcs[0].shape[1]) == 32:
+            mwa = self._mw_plain((32,), f"{name}.conv1", f"{name}.norm1")          # 32 -> 64 -> 64 + pool: one launch, the intermediate in LDS only
+            mwb = self._mw_plain((mwa.cout,), f"{name}.conv2", f"{name}.norm2")
+            if ops.mconv2d_pair_pool_applicable(srcs[0], mwa, mwb):
+                return ops.mconv2d_pair_pool(srcs[0], mwa, mwb)
         x = self._conv(srcs, f"{name}.conv1", f"{name}.norm1", act="relu")
         return self._conv(x, f"{name}.conv2", f"{name}.norm2", act="relu", pool=pool)
 

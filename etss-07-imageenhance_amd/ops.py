@@ -1006,6 +1006,35 @@ def mconv2d_pair(x, mwa: MConvWeights, mwb: MConvWeights, pad_mode="zeros"):
     return out
 
 
+def mconv2d_pair_pool_applicable(x, mwa: MConvWeights, mwb: MConvWeights, pad_mode="zeros") -> bool:
+    """Can ``y = relu(conv_b(relu(conv_a(x))))`` with a 32-channel ``x`` and ``MaxPool2d(2)(y)`` run as ONE launch?"""
+    if not isinstance(x, torch.Tensor) or x.dim() != 4 or mwa.dtype != mwb.dtype or x.dtype != mwa.dtype:
+        return False
+    if mwa.split != [int(x.shape[1])] or mwb.split != [mwa.cout] or getattr(mwa, "shuffle", 0) or getattr(mwb, "shuffle", 0):
+        return False
+    if (mwa.kh, mwa.kw, mwb.kh, mwb.kw) != (3, 3, 3, 3):
+        return False
+    return bool(capi.lib().ie_mconv_pair_pool_applicable(int(x.shape[1]), mwa.cout, mwb.cout, 3, 3, 1, 1, capi.PAD[pad_mode], capi.ACT["relu"], capi.ACT["relu"],
+                                                         int(x.shape[2]), int(x.shape[3])))
+
+
+def mconv2d_pair_pool(x, mwa: MConvWeights, mwb: MConvWeights, pad_mode="zeros"):
+    """``(y, MaxPool2d(2)(y))`` for ``y = relu(conv_b(relu(conv_a(x))))`` in one launch (ie_mconv_pair_pool_nhwc): a U-Net encoder level whose first
+    layer has 32 input channels.  The same bits as ``mconv2d`` + ``mconv2d(..., pool=True)``."""
+    _chk16(x)
+    if not mconv2d_pair_pool_applicable(x, mwa, mwb, pad_mode):
+        raise capi.IEError("mconv2d_pair_pool: 3x3 / stride 1 / padding 1 / ReLU layers 32 -> 64 -> 64 on a 16-bit NHWC tensor with W >= 64, H >= 2")
+    n, c, h, w = (int(v) for v in x.shape)
+    out = torch.empty((n, mwb.cout, h, w), device=x.device, dtype=x.dtype, memory_format=CL)
+    pooled = torch.empty((n, mwb.cout, h // 2, w // 2), device=x.device, dtype=x.dtype, memory_format=CL)
+    _count_macs(n, h, w, mwa.cout, c, 3, 3)
+    _count_macs(n, h, w, mwb.cout, mwa.cout, 3, 3)
+    with torch.cuda.device(x.device):
+        capi.check(capi.lib().ie_mconv_pair_pool_nhwc(capi.ptr(x), capi.ptr(mwa.w), capi.ptr(mwa.b), capi.ptr(mwb.w), capi.ptr(mwb.b), capi.ptr(out), capi.ptr(pooled),
+                                                      IE_DT[x.dtype], n, h, w, capi.PAD[pad_mode], capi.current_stream()), "ie_mconv_pair_pool_nhwc")
+    return out, pooled
+
+
 def mconv2d_pair_thin_applicable(x, mwa: MConvWeights, mwb: MConvWeights, pad_mode="zeros", act_a="relu", act_b="none") -> bool:
     """Can ``act_b(conv_b(relu(conv_a(x))))`` with a thin conv_b (4 .. 16 output channels, fp32 output) run as ONE launch?"""
     if not isinstance(x, torch.Tensor) or x.dim() != 4 or mwa.dtype != mwb.dtype or x.dtype != mwa.dtype:

@@ -224,6 +224,13 @@ int ie_mconv_pair_thin_applicable(int cin, int cmid, int cout, int kh, int kw, i
 int ie_mconv_pair_thin_nhwc(const void* src_dev, const void* packed_w_a_dev, const float* bias_a_dev, const void* packed_w_b_dev, const float* bias_b_dev,
                             float* dst_f32_dev, void* dst16_dev, int dst16_channels, int dtype, int N, int H, int W, int cout_b, int act_b, int pad_mode,
                             void* stream);
+/* The pair whose first layer has 32 input channels, with the MaxPool2d(2) of the next encoder level in the same launch (reference: U-Net's `down1` =
+ * DoubleConv(32, 64) followed by `down2`'s MaxPool2d(2), unet.py:43-48,70-72 for features = 32).  src: NHWC 32 channels; dst: NHWC 64 channels (the skip
+ * tensor); pool_dst: NHWC 64 channels, N x floor(H / 2) x floor(W / 2).  packed_w_a: ie_mconv_pack_weights image of the 32 -> 64 layer.  Bit-identical to
+ * ie_mconv_nhwc + ie_mconv_nhwc(pool).  Covered: 32 -> 64 -> 64, W >= 64, H >= 2 (ie_mconv_pair_pool_applicable). */
+int ie_mconv_pair_pool_applicable(int cin, int cmid, int cout, int kh, int kw, int stride, int pad, int pad_mode, int act_a, int act_b, int H, int W);
+int ie_mconv_pair_pool_nhwc(const void* src_dev, const void* packed_w_a_dev, const float* bias_a_dev, const void* packed_w_b_dev, const float* bias_b_dev,
+                            void* dst_dev, void* pool_dst_dev, int dtype, int N, int H, int W, int pad_mode, void* stream);
 
 /* Conv2d(4, 64, kernel_size 9, padding 4, padding_mode="replicate") on a 4-channel 16-bit NHWC image (reference: DecomNet's `net1_conv0`,
  * retinexnet/model.py:26, whose input is cat(max_c(x), x)): a strip kernel with K = 8 kx taps x 4 channels per MFMA and nine rotating accumulator sets.

@@ -180,6 +180,36 @@ def test_stacked_conv_with_thin_second_layer(shape, cout, act, pad_mode, dt):
 
 
 @pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("pad_mode", ["zeros", "replicate"])
+@pytest.mark.parametrize("shape", [(2, 38, 150), (1, 201, 64), (3, 7, 131), (2, 2, 66), (1, 3, 254), (1, 132, 126), (1, 133, 127), (2, 270, 480), (1, 540, 960)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_stacked_conv_32_64_64_with_pooled_output(shape, pad_mode, dt):
+    """ie_mconv_pair_pool_nhwc (U-Net-32's `down1`: DoubleConv(32, 64) and the MaxPool2d(2) of `down2`, unet.py:43-48,70-72) in one launch: the skip tensor
+    and its pooled copy carry the same bits as ie_mconv_nhwc + ie_mconv_nhwc(pool) (odd sizes: the last row / column is not pooled, as nn.MaxPool2d(2))."""
+    tdt = ops.TORCH_DT[dt]
+    n, h, w = shape
+    g = torch.Generator().manual_seed(43)
+    x = torch.randn(n, 32, h, w, generator=g).to(tdt).cuda().contiguous(memory_format=CL)
+    wa = (torch.randn(64, 32, 3, 3, generator=g) / 17.0).to(tdt).float()
+    wb = (torch.randn(64, 64, 3, 3, generator=g) / 24.0).to(tdt).float()
+    mwa = ops.MConvWeights(wa, torch.randn(64, generator=g) * 0.2, [32], tdt, "cuda")
+    mwb = ops.MConvWeights(wb, torch.randn(64, generator=g) * 0.2, [64], tdt, "cuda")
+    assert ops.mconv2d_pair_pool_applicable(x, mwa, mwb, pad_mode=pad_mode)
+    y, yp = ops.mconv2d_pair_pool(x, mwa, mwb, pad_mode=pad_mode)
+    mid = ops.mconv2d(x, mwa, pad_mode=pad_mode, act="relu")
+    want, want_p = ops.mconv2d(mid, mwb, pad_mode=pad_mode, act="relu", pool=True)
+    assert tuple(y.shape) == (n, 64, h, w) and tuple(yp.shape) == (n, 64, h // 2, w // 2) and y.dtype == tdt and yp.is_contiguous(memory_format=CL)
+    assert torch.equal(y, want)
+    assert torch.equal(yp, want_p)
+    assert torch.equal(yp.float(), F.max_pool2d(y.float(), 2))
+    pm = "replicate" if pad_mode == "replicate" else "constant"
+    cv = lambda t, w_, b_: F.conv2d(F.pad(t, (1, 1, 1, 1), mode=pm), w_, b_)
+    ref = F.relu(cv(F.relu(cv(x.float().cpu(), wa, mwa.b.cpu())).to(tdt).float(), wb, mwb.b.cpu()))
+    assert rel_err(y.float().cpu(), ref) <= (3e-3 if dt == "f16" else 2e-2)
+    assert not ops.mconv2d_pair_pool_applicable(torch.zeros(1, 64, 8, 64, dtype=tdt, device="cuda").contiguous(memory_format=CL), mwb, mwb)
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
 @pytest.mark.parametrize("classes,clamp", [(3, (0.0, 1.0)), (16, None), (1, (-0.5, 0.5))])
 @pytest.mark.parametrize("shape", [(2, 38, 150), (1, 200, 64), (3, 6, 130), (2, 2, 66), (1, 2, 254), (1, 132, 126), (1, 270, 480)], ids=lambda s: "x".join(map(str, s)))
 def test_unet_last_level_in_one_launch(shape, classes, clamp, dt):

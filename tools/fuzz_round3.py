@@ -36,6 +36,15 @@ def case_pair(tdt, n, h, w, pm):
     return 0.0 if torch.equal(got, want) else 1.0, 0.0
 
 
+def case_pair_pool(tdt, n, h, w, pm):
+    h = max(h, 2)
+    x = t16(n, 32, h, w, tdt)
+    a, _ = mw(64, [32], tdt); b, _ = mw(64, [64], tdt)
+    y, yp = ops.mconv2d_pair_pool(x, a, b, pad_mode=pm)
+    want, want_p = ops.mconv2d(ops.mconv2d(x, a, pad_mode=pm, act="relu"), b, pad_mode=pm, act="relu", pool=True)
+    return 0.0 if (torch.equal(y, want) and torch.equal(yp, want_p)) else 1.0, 0.0
+
+
 def case_pair_thin(tdt, n, h, w, pm):
     x = t16(n, 64, h, w, tdt)
     cout = rng.choice([4, 8, 12, 16]); act = rng.choice(["none", "relu", "sigmoid", "tanh"])
@@ -101,7 +110,7 @@ def case_first(tdt, n, h, w, pm):
     return rel(out.float().cpu(), ref), 3e-3 if tdt == torch.float16 else 2e-2
 
 
-CASES = {"first": case_first, "pair": case_pair, "pair_thin": case_pair_thin, "conv9": case_conv9, "thin3": case_thin3, "updc": case_updc}
+CASES = {"first": case_first, "pair": case_pair, "pair_pool": case_pair_pool, "pair_thin": case_pair_thin, "conv9": case_conv9, "thin3": case_thin3, "updc": case_updc}
 t0, done, bad = time.time(), {k: 0 for k in CASES}, 0
 while time.time() - t0 < budget:
     name = rng.choice(list(CASES))
