@@ -29,7 +29,7 @@ SYMBOLS = [
     "ie_conv2d_nhwc_f32", "ie_pack_weight_hwio_f32", "ie_le_curve",
     "ie_convn_nhwc_f32", "ie_instnorm_nhwc_f32", "ie_maxpool2x2_nhwc_f32", "ie_resize_nhwc_f32", "ie_pixel_shuffle_nhwc_f32",
     "ie_conv_transpose2x2_nhwc_f32", "ie_pad_nhwc_f32", "ie_eltwise_nhwc_f32", "ie_max_concat_nhwc_f32",
-    "ie_maxpool2x2_nhwc", "ie_mconv_pool_nhwc", "ie_mconv_tail_applicable", "ie_mconv_tail_nhwc", "ie_mconv_first_applicable", "ie_mconv_first_pool_nhwc", "ie_resize_nhwc", "ie_pad_nhwc", "ie_pixel_shuffle_nhwc", "ie_eltwise_nhwc", "ie_cast_nhwc", "ie_concat_cast_nhwc", "ie_instnorm_nhwc", "ie_dwconv3x3_nhwc",
+    "ie_maxpool2x2_nhwc", "ie_mconv_pool_nhwc", "ie_mconv_tail_applicable", "ie_mconv_tail_nhwc", "ie_mconv_first_applicable", "ie_mconv_first_pool_nhwc", "ie_resize_nhwc", "ie_resize_pad_nhwc", "ie_pad_nhwc", "ie_pixel_shuffle_nhwc", "ie_eltwise_nhwc", "ie_cast_nhwc", "ie_concat_cast_nhwc", "ie_instnorm_nhwc", "ie_dwconv3x3_nhwc",
     "ie_mconv_packed_bytes", "ie_mconv_pack_weights", "ie_mconv_pack_weights_dev", "ie_mconv_nhwc", "ie_dsconv_nhwc",
     "ie_norm_forward_nhwc_f32", "ie_norm_backward_nhwc_f32", "ie_convn_wgrad_nhwc_f32", "ie_convn_dgrad_nhwc_f32",
     "ie_maxpool2x2_backward_nhwc_f32", "ie_resize_backward_nhwc_f32", "ie_crop_nhwc_f32", "ie_pixel_unshuffle_nhwc_f32",
@@ -115,6 +115,7 @@ def lib():
     i64, sz = C.c_int64, C.c_size_t
     L.ie_maxpool2x2_nhwc.argtypes = [vp, vp, ip, ip, ip, ip, ip, vp]
     L.ie_resize_nhwc.argtypes = [vp, vp, ip, ip, ip, ip, ip, ip, ip, ip, vp]
+    L.ie_resize_pad_nhwc.argtypes = [vp, vp, ip, ip, ip, ip, ip, ip, ip, ip, ip, ip, ip, ip, vp]
     L.ie_pad_nhwc.argtypes = [vp, vp, ip, ip, ip, ip, ip, ip, ip, ip, ip, vp]
     L.ie_pixel_shuffle_nhwc.argtypes = [vp, vp, ip, ip, ip, ip, ip, ip, vp]
     L.ie_eltwise_nhwc.argtypes = [ip, vp, vp, vp, ip, C.c_size_t, ip, ip, vp]

@@ -33,60 +33,104 @@ __device__ __forceinline__ Idx split(size_t i, int H, int W, int C8) {
     return r;
 }
 
-template <typename T>
-__global__ void maxpool2_v8(const T* __restrict__ x, T* __restrict__ y, int H, int W, int C, int Ho, int Wo, size_t total) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const Idx o = split(i, Ho, Wo, C / 8);
-    const T* p = x + ((o.n * H + 2 * o.h) * W + 2 * o.w) * C + o.c;
-    float a[8], b[8], c[8], d[8], r[8];
-    unpack8<T>(ld8(p), a); unpack8<T>(ld8(p + C), b); unpack8<T>(ld8(p + (size_t)W * C), c); unpack8<T>(ld8(p + (size_t)W * C + C), d);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) r[k] = fmaxf(fmaxf(a[k], b[k]), fmaxf(c[k], d[k]));
-    st8(y + ((o.n * Ho + o.h) * Wo + o.w) * C + o.c, pack8<T>(r));
+// Row form of the three ops a U-Net runs between its convolutions (max-pool, resize, zero pad): blockIdx.x = output row (n, h), the row's scalars computed
+// once per workgroup in SGPRs, lanes over the row's 16-byte pieces with 32-bit index arithmetic.  (The flat form split a 64-bit index with six 64-bit
+// divisions per 16 bytes moved: ALU-bound at 2.2 TB/s.)
+struct RowIdx { unsigned n, h; };
+__device__ __forceinline__ RowIdx row_of_block(int Ho) {
+    const unsigned r = blockIdx.x, n = r / (unsigned)Ho;
+    return RowIdx{n, r - n * (unsigned)Ho};
+}
+__device__ __forceinline__ void piece_of(unsigned j, unsigned C8, int c8_shift, unsigned& w, unsigned& c) {
+    w = c8_shift >= 0 ? (j >> c8_shift) : (j / C8);
+    c = (j - w * C8) * 8u;
+}
+inline int c8_shift_of(int C8) { int s = 0; while ((1 << s) < C8) ++s; return (1 << s) == C8 ? s : -1; }
+inline dim3 row_grid(size_t rows, size_t pieces) {          // y: four pieces per lane, at most 64 column blocks
+    size_t gy = (pieces + 1023) / 1024;
+    return dim3((unsigned)rows, (unsigned)(gy < 1 ? 1 : gy > 64 ? 64 : gy));
 }
 
 template <typename T>
-__global__ void resize_v8(const T* __restrict__ x, T* __restrict__ y, int Hi, int Wi, int C, int Ho, int Wo, int mode, size_t total) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const Idx o = split(i, Ho, Wo, C / 8);
-    const T* p = x + o.n * (size_t)Hi * Wi * C + o.c;
-    T* q = y + ((o.n * Ho + o.h) * Wo + o.w) * C + o.c;
-    if (mode == 0) {
-        const int ys = min((int)floorf(o.h * ((float)Hi / (float)Ho)), Hi - 1);
-        const int xs = min((int)floorf(o.w * ((float)Wi / (float)Wo)), Wi - 1);
-        st8(q, ld8(p + ((size_t)ys * Wi + xs) * C));
+__global__ __launch_bounds__(256) void maxpool2_v8(const T* __restrict__ x, T* __restrict__ y, int H, int W, int C, int Ho, int Wo, int c8_shift) {
+    const RowIdx o = row_of_block(Ho);
+    const unsigned C8 = (unsigned)C / 8u, pieces = (unsigned)Wo * C8;
+    const T* xr = x + ((size_t)o.n * H + 2 * o.h) * (size_t)W * C;
+    T* yr = y + ((size_t)o.n * Ho + o.h) * (size_t)Wo * C;
+    for (unsigned j = blockIdx.y * 256u + threadIdx.x; j < pieces; j += gridDim.y * 256u) {
+        unsigned w, c;
+        piece_of(j, C8, c8_shift, w, c);
+        const T* p = xr + (size_t)(2 * w) * C + c;
+        float a[8], b[8], cc[8], d[8], r[8];
+        unpack8<T>(ld8(p), a); unpack8<T>(ld8(p + C), b); unpack8<T>(ld8(p + (size_t)W * C), cc); unpack8<T>(ld8(p + (size_t)W * C + C), d);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[k] = fmaxf(fmaxf(a[k], b[k]), fmaxf(cc[k], d[k]));
+        st8(yr + (size_t)w * C + c, pack8<T>(r));
+    }
+}
+
+// (top, left, Hp, Wp): the resized image sits at (top, left) of a zero (Hp, Wp) output -- F.pad of the up-sampled tensor in the same pass (unet.py:97-103)
+template <typename T>
+__global__ __launch_bounds__(256) void resize_v8(const T* __restrict__ x, T* __restrict__ y, int Hi, int Wi, int C, int Ho, int Wo, int mode, int c8_shift,
+                                                 int top, int left, int Hp, int Wp) {
+    const RowIdx o = row_of_block(Hp);
+    const unsigned C8 = (unsigned)C / 8u, pieces = (unsigned)Wp * C8;
+    const T* p = x + (size_t)o.n * Hi * Wi * C;
+    T* yr = y + ((size_t)o.n * Hp + o.h) * (size_t)Wp * C;
+    const int h = (int)o.h - top;
+    if (h < 0 || h >= Ho) {
+        for (unsigned j = blockIdx.y * 256u + threadIdx.x; j < pieces; j += gridDim.y * 256u) st8(yr + (size_t)j * 8, ie_u32x4{0u, 0u, 0u, 0u});
         return;
     }
-    float sy, sx;
-    if (mode == 2) {
-        sy = (Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f) * o.h;
-        sx = (Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f) * o.w;
-    } else {
-        sy = fmaxf((float)Hi / (float)Ho * (o.h + 0.5f) - 0.5f, 0.f);
-        sx = fmaxf((float)Wi / (float)Wo * (o.w + 0.5f) - 0.5f, 0.f);
+    if (mode == 0) {
+        const int ys = min((int)floorf(h * ((float)Hi / (float)Ho)), Hi - 1);
+        for (unsigned j = blockIdx.y * 256u + threadIdx.x; j < pieces; j += gridDim.y * 256u) {
+            unsigned wp, c;
+            piece_of(j, C8, c8_shift, wp, c);
+            const int w = (int)wp - left;
+            const int xs = min((int)floorf(w * ((float)Wi / (float)Wo)), Wi - 1);
+            st8(yr + (size_t)wp * C + c, (w >= 0 && w < Wo) ? ld8(p + ((size_t)ys * Wi + xs) * C + c) : ie_u32x4{0u, 0u, 0u, 0u});
+        }
+        return;
     }
-    const int y0 = min((int)sy, Hi - 1), x0 = min((int)sx, Wi - 1);
-    const int y1 = min(y0 + 1, Hi - 1), x1 = min(x0 + 1, Wi - 1);
-    const float ly = sy - (float)y0, lx = sx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
-    float a[8], b[8], c[8], d[8], r[8];
-    unpack8<T>(ld8(p + ((size_t)y0 * Wi + x0) * C), a); unpack8<T>(ld8(p + ((size_t)y0 * Wi + x1) * C), b);
-    unpack8<T>(ld8(p + ((size_t)y1 * Wi + x0) * C), c); unpack8<T>(ld8(p + ((size_t)y1 * Wi + x1) * C), d);
+    const float sy = mode == 2 ? (Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f) * h : fmaxf((float)Hi / (float)Ho * (h + 0.5f) - 0.5f, 0.f);
+    const int y0 = min((int)sy, Hi - 1), y1 = min(y0 + 1, Hi - 1);
+    const float ly = sy - (float)y0, hy = 1.f - ly;
+    const T* r0 = p + (size_t)y0 * Wi * C;
+    const T* r1 = p + (size_t)y1 * Wi * C;
+    for (unsigned j = blockIdx.y * 256u + threadIdx.x; j < pieces; j += gridDim.y * 256u) {
+        unsigned wp, c;
+        piece_of(j, C8, c8_shift, wp, c);
+        const int w = (int)wp - left;
+        if (w < 0 || w >= Wo) { st8(yr + (size_t)wp * C + c, ie_u32x4{0u, 0u, 0u, 0u}); continue; }
+        const float sx = mode == 2 ? (Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f) * w : fmaxf((float)Wi / (float)Wo * (w + 0.5f) - 0.5f, 0.f);
+        const int x0 = min((int)sx, Wi - 1), x1 = min(x0 + 1, Wi - 1);
+        const float lx = sx - (float)x0, hx = 1.f - lx;
+        float a[8], b[8], cc[8], d[8], r[8];
+        unpack8<T>(ld8(r0 + (size_t)x0 * C + c), a); unpack8<T>(ld8(r0 + (size_t)x1 * C + c), b);
+        unpack8<T>(ld8(r1 + (size_t)x0 * C + c), cc); unpack8<T>(ld8(r1 + (size_t)x1 * C + c), d);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) r[k] = hy * (hx * a[k] + lx * b[k]) + ly * (hx * c[k] + lx * d[k]);
-    st8(q, pack8<T>(r));
+        for (int k = 0; k < 8; ++k) r[k] = hy * (hx * a[k] + lx * b[k]) + ly * (hx * cc[k] + lx * d[k]);
+        st8(yr + (size_t)wp * C + c, pack8<T>(r));
+    }
 }
 
 template <typename T>
-__global__ void pad_v8(const T* __restrict__ x, T* __restrict__ y, int H, int W, int C, int top, int left, int Ho, int Wo, size_t total) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const Idx o = split(i, Ho, Wo, C / 8);
-    const int h = o.h - top, w = o.w - left;
-    ie_u32x4 v = {0u, 0u, 0u, 0u};
-    if (h >= 0 && h < H && w >= 0 && w < W) v = ld8(x + ((o.n * H + h) * W + w) * C + o.c);
-    st8(y + ((o.n * Ho + o.h) * Wo + o.w) * C + o.c, v);
+__global__ __launch_bounds__(256) void pad_v8(const T* __restrict__ x, T* __restrict__ y, int H, int W, int C, int top, int left, int Ho, int Wo, int c8_shift) {
+    const RowIdx o = row_of_block(Ho);
+    const unsigned C8 = (unsigned)C / 8u, pieces = (unsigned)Wo * C8;
+    const int h = (int)o.h - top;
+    const bool row_in = h >= 0 && h < H;
+    const T* xr = x + ((size_t)o.n * H + (row_in ? h : 0)) * (size_t)W * C;
+    T* yr = y + ((size_t)o.n * Ho + o.h) * (size_t)Wo * C;
+    for (unsigned j = blockIdx.y * 256u + threadIdx.x; j < pieces; j += gridDim.y * 256u) {
+        unsigned wo, c;
+        piece_of(j, C8, c8_shift, wo, c);
+        const int w = (int)wo - left;
+        ie_u32x4 v = {0u, 0u, 0u, 0u};
+        if (row_in && w >= 0 && w < W) v = ld8(xr + (size_t)w * C + c);
+        st8(yr + (size_t)wo * C + c, v);
+    }
 }
 
 // F.pad(x, (pad,) * 4, mode="replicate") on a 16-bit tensor, its adjoint (every border pixel of x collects the padding pixels that copied it: fp32 sum, one
@@ -332,22 +376,35 @@ IE_EXPORT int ie_maxpool2x2_nhwc(const void* x, void* y, int dtype, int N, int H
     if (dtype == IE_F32) return ie_maxpool2x2_nhwc_f32((const float*)x, (float*)y, N, H, W, C, stream);
     if (!x || !y || !is16(dtype) || N <= 0 || H < 2 || W < 2 || C <= 0 || (C & 7)) IE_FAIL(IE_ERR_INVALID, "ie_maxpool2x2_nhwc: bad args (C %% 8 == 0 on the 16-bit path)");
     const int Ho = H / 2, Wo = W / 2;
-    const size_t total = (size_t)N * Ho * Wo * (C / 8);
-    if (dtype == IE_F16) hipLaunchKernelGGL(maxpool2_v8<_Float16>, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, (_Float16*)y, H, W, C, Ho, Wo, total);
-    else hipLaunchKernelGGL(maxpool2_v8<__bf16>, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, (__bf16*)y, H, W, C, Ho, Wo, total);
+    if ((size_t)N * Ho > 0x7fffffffull) IE_FAIL(IE_ERR_INVALID, "ie_maxpool2x2_nhwc: too many rows");
+    if (dtype == IE_F16) hipLaunchKernelGGL(maxpool2_v8<_Float16>, row_grid((size_t)N * Ho, (size_t)Wo * (C / 8)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, (_Float16*)y, H, W, C, Ho, Wo, c8_shift_of(C / 8));
+    else hipLaunchKernelGGL(maxpool2_v8<__bf16>, row_grid((size_t)N * Ho, (size_t)Wo * (C / 8)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, (__bf16*)y, H, W, C, Ho, Wo, c8_shift_of(C / 8));
+    IE_LAUNCH_CHECK();
+    return IE_OK;
+}
+
+static int resize_pad16(const void* x, void* y, int dtype, int N, int Hi, int Wi, int C, int Ho, int Wo, int mode, int top, int bottom, int left, int right, void* stream,
+                        const char* who) {
+    if (!x || !y || !is16(dtype) || N <= 0 || Hi <= 0 || Wi <= 0 || C <= 0 || (C & 7) || Ho <= 0 || Wo <= 0 || mode < 0 || mode > 2 || top < 0 || bottom < 0 || left < 0 ||
+        right < 0)
+        IE_FAIL(IE_ERR_INVALID, "%s: bad args (16-bit tensors, C %% 8 == 0, padding >= 0)", who);
+    const int Hp = Ho + top + bottom, Wp = Wo + left + right;
+    if ((size_t)N * Hp > 0x7fffffffull) IE_FAIL(IE_ERR_INVALID, "%s: too many rows", who);
+    if (dtype == IE_F16) hipLaunchKernelGGL(resize_v8<_Float16>, row_grid((size_t)N * Hp, (size_t)Wp * (C / 8)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, (_Float16*)y, Hi, Wi, C, Ho, Wo, mode, c8_shift_of(C / 8), top, left, Hp, Wp);
+    else hipLaunchKernelGGL(resize_v8<__bf16>, row_grid((size_t)N * Hp, (size_t)Wp * (C / 8)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, (__bf16*)y, Hi, Wi, C, Ho, Wo, mode, c8_shift_of(C / 8), top, left, Hp, Wp);
     IE_LAUNCH_CHECK();
     return IE_OK;
 }
 
 IE_EXPORT int ie_resize_nhwc(const void* x, void* y, int dtype, int N, int Hi, int Wi, int C, int Ho, int Wo, int mode, void* stream) {
     if (dtype == IE_F32) return ie_resize_nhwc_f32((const float*)x, (float*)y, N, Hi, Wi, C, Ho, Wo, mode, stream);
-    if (!x || !y || !is16(dtype) || N <= 0 || Hi <= 0 || Wi <= 0 || C <= 0 || (C & 7) || Ho <= 0 || Wo <= 0 || mode < 0 || mode > 2)
-        IE_FAIL(IE_ERR_INVALID, "ie_resize_nhwc: bad args (C %% 8 == 0 on the 16-bit path)");
-    const size_t total = (size_t)N * Ho * Wo * (C / 8);
-    if (dtype == IE_F16) hipLaunchKernelGGL(resize_v8<_Float16>, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, (_Float16*)y, Hi, Wi, C, Ho, Wo, mode, total);
-    else hipLaunchKernelGGL(resize_v8<__bf16>, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, (__bf16*)y, Hi, Wi, C, Ho, Wo, mode, total);
-    IE_LAUNCH_CHECK();
-    return IE_OK;
+    return resize_pad16(x, y, dtype, N, Hi, Wi, C, Ho, Wo, mode, 0, 0, 0, 0, stream, "ie_resize_nhwc");
+}
+
+// F.pad(resize(x, (Ho, Wo)), [left, right, top, bottom]) in one pass: y is (N, Ho + top + bottom, Wo + left + right, C), zeros in the border
+IE_EXPORT int ie_resize_pad_nhwc(const void* x, void* y, int dtype, int N, int Hi, int Wi, int C, int Ho, int Wo, int mode, int top, int bottom, int left, int right,
+                                 void* stream) {
+    return resize_pad16(x, y, dtype, N, Hi, Wi, C, Ho, Wo, mode, top, bottom, left, right, stream, "ie_resize_pad_nhwc");
 }
 
 IE_EXPORT int ie_pad_nhwc(const void* x, void* y, int dtype, int N, int H, int W, int C, int top, int bottom, int left, int right, void* stream) {
@@ -355,9 +412,9 @@ IE_EXPORT int ie_pad_nhwc(const void* x, void* y, int dtype, int N, int H, int W
     if (!x || !y || !is16(dtype) || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7) || top < 0 || bottom < 0 || left < 0 || right < 0)
         IE_FAIL(IE_ERR_INVALID, "ie_pad_nhwc: bad args (C %% 8 == 0 on the 16-bit path)");
     const int Ho = H + top + bottom, Wo = W + left + right;
-    const size_t total = (size_t)N * Ho * Wo * (C / 8);
-    if (dtype == IE_F16) hipLaunchKernelGGL(pad_v8<_Float16>, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, (_Float16*)y, H, W, C, top, left, Ho, Wo, total);
-    else hipLaunchKernelGGL(pad_v8<__bf16>, dim3(nblk(total)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, (__bf16*)y, H, W, C, top, left, Ho, Wo, total);
+    if ((size_t)N * Ho > 0x7fffffffull) IE_FAIL(IE_ERR_INVALID, "ie_pad_nhwc: too many rows");
+    if (dtype == IE_F16) hipLaunchKernelGGL(pad_v8<_Float16>, row_grid((size_t)N * Ho, (size_t)Wo * (C / 8)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, (_Float16*)y, H, W, C, top, left, Ho, Wo, c8_shift_of(C / 8));
+    else hipLaunchKernelGGL(pad_v8<__bf16>, row_grid((size_t)N * Ho, (size_t)Wo * (C / 8)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, (__bf16*)y, H, W, C, top, left, Ho, Wo, c8_shift_of(C / 8));
     IE_LAUNCH_CHECK();
     return IE_OK;
 }

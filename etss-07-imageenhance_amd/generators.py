@@ -950,7 +950,11 @@ class UNet(_GraphModel):
             if y is not None:
                 return y
         if self.upsampler == "bilinear":
-            x1 = ops.upsample2x_bilinear(x1)
+            dy, dx = x2.shape[2] - 2 * x1.shape[2], x2.shape[3] - 2 * x1.shape[3]
+            if self.compute_dtype != "f32" and (dy > 0 or dx > 0) and dy >= 0 and dx >= 0:       # odd skip size: up-sample straight into the padded tensor
+                x1 = ops.resize_pad(x1, (2 * x1.shape[2], 2 * x1.shape[3]), (dy // 2, dy - dy // 2, dx // 2, dx - dx // 2))
+            else:
+                x1 = ops.upsample2x_bilinear(x1)
         elif self.upsampler == "convtranspose":
             x1 = self._conv_transpose2x2(x1, f"up{k}.up")
         else:

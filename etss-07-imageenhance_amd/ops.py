@@ -177,6 +177,18 @@ def resize(x, size, mode="bilinear_align") -> torch.Tensor:
     return y
 
 
+def resize_pad(x, size, pads, mode="bilinear_align") -> torch.Tensor:
+    """``F.pad(resize(x, size), [left, right, top, bottom])`` in one pass on a 16-bit tensor (ie_resize_pad_nhwc); ``pads`` = (top, bottom, left, right)."""
+    _chk16(x)
+    n, c, h, w = x.shape
+    top, bottom, left, right = (int(v) for v in pads)
+    y = empty_nhwc(n, c, size[0] + top + bottom, size[1] + left + right, x.device, x.dtype)
+    with torch.cuda.device(x.device):
+        capi.check(capi.lib().ie_resize_pad_nhwc(capi.ptr(x), capi.ptr(y), _dt(x), n, h, w, c, size[0], size[1], _RESIZE[mode], top, bottom, left, right,
+                                                 capi.current_stream()), "ie_resize_pad_nhwc")
+    return y
+
+
 def upsample2x_bilinear(x) -> torch.Tensor:
     return resize(x, (x.shape[2] * 2, x.shape[3] * 2), "bilinear_align")
 

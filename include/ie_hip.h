@@ -273,6 +273,11 @@ int ie_unet_up_head_nhwc(const void* skip_dev, const void* up_dev, int up_h, int
 int ie_maxpool2x2_nhwc(const void* x_dev, void* y_dev, int dtype, int N, int H, int W, int C, void* stream);
 int ie_resize_nhwc(const void* x_dev, void* y_dev, int dtype, int N, int Hi, int Wi, int C, int Ho, int Wo, int mode, void* stream);
 int ie_pad_nhwc(const void* x_dev, void* y_dev, int dtype, int N, int H, int W, int C, int top, int bottom, int left, int right, void* stream);
+/* F.pad(up(x), [left, right, top, bottom]) in one pass (reference: `Up.forward`, unet.py:95-103 -- the up-sampled tensor padded to the skip tensor's
+ * size): y is (N, Ho + top + bottom, Wo + left + right, C) with the resized image at (top, left) and zeros around it.  16-bit dtypes only; the bits of
+ * ie_resize_nhwc followed by ie_pad_nhwc. */
+int ie_resize_pad_nhwc(const void* x_dev, void* y_dev, int dtype, int N, int Hi, int Wi, int C, int Ho, int Wo, int mode, int top, int bottom, int left, int right,
+                       void* stream);
 int ie_pixel_shuffle_nhwc(const void* x_dev, void* y_dev, int dtype, int N, int H, int W, int Cout, int r, void* stream);
 /* op 0: a + b, 1: a * b; b has C channels or one (broadcast). */
 int ie_eltwise_nhwc(int op, const void* a_dev, const void* b_dev, void* y_dev, int dtype, size_t npix, int C, int Cb, void* stream);

@@ -203,3 +203,22 @@ def test_16bit_replicate_pad_and_zero_insert(dt):
     want = torch.zeros(2, 16, 18, 27)
     want[:, :, 0:17:2, 0:25:2] = x.float()
     assert torch.equal(z.float().cpu(), want)
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("mode", ["bilinear_align", "bilinear", "nearest"])
+@pytest.mark.parametrize("case", [((2, 16, 7, 9), (14, 18), (0, 1, 0, 0)), ((1, 24, 5, 6), (10, 12), (1, 0, 2, 1)), ((3, 8, 4, 4), (9, 7), (0, 0, 0, 3)),
+                                  ((1, 256, 67, 120), (134, 240), (0, 1, 0, 0))], ids=lambda c: "x".join(map(str, c[0])))
+def test_resize_into_a_padded_tensor(case, mode, dt):
+    """ie_resize_pad_nhwc (`Up.forward`: up-sample, then F.pad to the skip tensor's size, unet.py:95-103) = ie_resize_nhwc + ie_pad_nhwc, bit for bit."""
+    shape, size, pads = case
+    tdt = ops.TORCH_DT[dt]
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(5)).to(tdt).cuda().contiguous(memory_format=torch.channels_last)
+    got = ops.resize_pad(x, size, pads, mode)
+    want = ops.pad(ops.resize(x, size, mode), *pads)
+    assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(got, want)
+    ref = F.pad(F.interpolate(x.float(), size=size, mode="nearest" if mode == "nearest" else "bilinear",
+                              **({} if mode == "nearest" else {"align_corners": mode == "bilinear_align"})), (pads[2], pads[3], pads[0], pads[1]))
+    assert float((got.float() - ref).abs().max()) <= (4e-3 if dt == "f16" else 3e-2) * max(1.0, float(ref.abs().max()))
+
