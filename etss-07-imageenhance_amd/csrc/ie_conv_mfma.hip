@@ -36,6 +36,7 @@ struct MConvParams {
     int Ho, Wo;                  // stride-1 output extent
     int Hs, Ws;                  // stored extent (= Ho, Wo, or the sub-sampled size)
     int sh[IE_CONV_MAX_SRC], sw[IE_CONV_MAX_SRC];   // stored size of source s (== H, W unless the conv reads it through a nearest-neighbour up-sampling)
+    void* pool;                  // mconv3_kernel, ReLU layers: also write nn.MaxPool2d(2) of the output (N x Ho/2 x Wo/2 x Cout), or null
     int shuf_c;                  // fused PixelShuffle(2): channels of the shuffled output (Cout = 4 shuf_c, rows packed as [i][j][c]); 0 = off
     int tiles_x, tiles_y, cout_tiles, total_blocks;
     int taps_stage, nstages;     // weight staging: taps per LDS stage
@@ -491,6 +492,13 @@ __device__ __forceinline__ void mconv3_epilogue(const MConvParams& p, ie_f32x4 (
             ie_u32x4 rnext = {0u, 0u, 0u, 0u};          // one row pair ahead: the accumulators leave little room (128 of 256 VGPRs)
             if (rtile) rnext = *(const ie_u32x4*)(rtile + lane_off16);
             const float slope = p.slope;
+            // fused MaxPool2d(2) (ReLU layers: 16-bit values >= +0 order as signed integers): rows 2q, 2q + 1 are this lane's, the column pair is lanes l16, l16 ^ 1
+            typedef __attribute__((ext_vector_type(8))) short s16x8;
+            const bool pool = ACT == IE_ACT_RELU && p.pool != nullptr;
+            const unsigned prow_b = (unsigned)(p.Wo >> 1) * (unsigned)p.Cout * (unsigned)sizeof(T);
+            const char* ptile = pool ? (const char*)((T*)p.pool + (((size_t)n * (p.Ho >> 1) + ((oy0 + r0) >> 1)) * (p.Wo >> 1) + (ox0 >> 1)) * p.Cout) : nullptr;
+            const unsigned plane_off = (unsigned)((((l16 >> 1) + 8 * (kc & 1)) * p.Cout + c0 + 4 * (kc & 2)) * (int)sizeof(T));
+            s16x8 prev_row = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
             for (int t = 0; t < NT; t += 2) {
                 ie_u32x2 o[2];
@@ -519,7 +527,21 @@ __device__ __forceinline__ void mconv3_epilogue(const MConvParams& p, ie_f32x4 (
                 }
                 const auto sx = __builtin_amdgcn_permlane16_swap(o[0][0], o[1][0], false, false);
                 const auto sy = __builtin_amdgcn_permlane16_swap(o[0][1], o[1][1], false, false);
-                *(ie_u32x4*)(const_cast<char*>(tile) + (unsigned)(t >> 1) * row_b + lane_off16) = ie_u32x4{sx[0], sy[0], sx[1], sy[1]};
+                const ie_u32x4 line = {sx[0], sy[0], sx[1], sy[1]};
+                *(ie_u32x4*)(const_cast<char*>(tile) + (unsigned)(t >> 1) * row_b + lane_off16) = line;
+                if constexpr (ACT == IE_ACT_RELU) {
+                    if (pool) {          // wave-uniform
+                        const s16x8 cur_row = __builtin_bit_cast(s16x8, line);
+                        if ((t >> 1) & 1) {
+                            const ie_u32x4 m = __builtin_bit_cast(ie_u32x4, __builtin_elementwise_max(prev_row, cur_row));
+                            ie_u32x4 nb;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) nb[e] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)m[e], 0xb1, 0xf, 0xf, true);      // quad_perm [1, 0, 3, 2]
+                            const s16x8 mm = __builtin_elementwise_max(__builtin_bit_cast(s16x8, m), __builtin_bit_cast(s16x8, nb));
+                            if (!(l16 & 1)) *(ie_u32x4*)(const_cast<char*>(ptile) + (unsigned)(t >> 2) * prow_b + plane_off) = __builtin_bit_cast(ie_u32x4, mm);
+                        } else prev_row = cur_row;
+                    }
+                }
             }
             return;
         }
@@ -535,6 +557,38 @@ __device__ __forceinline__ void mconv3_epilogue(const MConvParams& p, ie_f32x4 (
         const unsigned row_stride = (unsigned)(SS * SS) * (unsigned)p.Ws * (unsigned)SC;       // elements
         const unsigned half_stride = 16u * (unsigned)SS * (unsigned)SC;
         const int rows_live = p.Ho - (oy0 + r0);                             // wave-uniform
+        const bool pool = ACT == IE_ACT_RELU && p.pool != nullptr && !p.shuf_c;
+        if (pool) {          // edge tiles of a layer with the fused MaxPool2d(2): every lane runs the row pair (the column pair is lanes l16, l16 ^ 1), stores are masked
+            const int Hp = p.Ho >> 1, Wp = p.Wo >> 1;
+            T* pdst = (T*)p.pool + ((((size_t)n * Hp + ((oy0 + r0) >> 1)) * Wp + (ox_a >> 1)) * p.Cout + co);
+            const unsigned prow_stride = (unsigned)Wp * (unsigned)p.Cout, phalf_stride = 8u * (unsigned)p.Cout;
+            const int prow_live = Hp - ((oy0 + r0) >> 1);
+            const bool plive_x[2] = {!(l16 & 1) && (ox_a >> 1) < Wp, !(l16 & 1) && ((ox_a + 16) >> 1) < Wp};
+#pragma unroll
+            for (int t = 0; t < NT; t += 4) {             // rows 2q, 2q + 1; halves 0, 1
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    float m[4];
+#pragma unroll
+                    for (int rr = 0; rr < 2; ++rr) {
+                        const int tt = t + 2 * rr + h;
+                        float v[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = act_fast<ACT>(acc[tt][j] + bv[j], slope);
+                        if ((tt >> 1) < rows_live && live_x[h])
+                            *(ie_u32x2*)(dst + (unsigned)(tt >> 1) * row_stride + (unsigned)h * half_stride) = ie_u32x2{ie_pack2<T>(v[0], v[1]), ie_pack2<T>(v[2], v[3])};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) m[j] = rr ? fmaxf(m[j], v[j]) : v[j];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        m[j] = fmaxf(m[j], __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m[j]), 0xb1, 0xf, 0xf, true)));
+                    if ((t >> 2) < prow_live && plive_x[h])
+                        *(ie_u32x2*)(pdst + (unsigned)(t >> 2) * prow_stride + (unsigned)h * phalf_stride) = ie_u32x2{ie_pack2<T>(m[0], m[1]), ie_pack2<T>(m[2], m[3])};
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             if ((t >> 1) >= rows_live || !live_x[t & 1]) continue;
@@ -1058,6 +1112,7 @@ static int mconv_impl(ie_mconv_desc* d, const void* const* srcs, const int* chan
         return ie_sconv3_launch(srcs, channels, d->nsrc, packed_w, bias, dst, d->in_dtype, d->N, d->H, d->W, d->Cout, d->act, d->slope, d->pad_mode,
                                 d->src_h, d->src_w, pd, nullptr, d->stride, (hipStream_t)stream);
     }
+    if (pooled) *pooled = false;
     if (!pool_dst && (double)d->H * d->W * 256.0 < 2147483647.0 &&
         ie_sconv3_thin3_applicable(d->nsrc, channels, d->Cout, d->kh, d->kw, d->stride, d->pad, d->pad_mode, d->act, residual != nullptr, d->clamp != 0,
                                    d->out_dtype == IE_F32, d->pixel_shuffle != 0, d->W)) {
@@ -1160,6 +1215,15 @@ static int mconv_impl(ie_mconv_desc* d, const void* const* srcs, const int* chan
         if (!granted[slot]) {
             IE_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             granted[slot] = true;
+        }
+    }
+    if (k3 && !use_v1 && !pl.thin && pool_dst) {
+        // the 3x3 register-weights kernel pools in its epilogue (ReLU layer, whole 16-cout fragments, 16-bit output, no residual / clamp / shuffle)
+        static const int fuse3 = getenv("IE_MCONV_POOL") ? atoi(getenv("IE_MCONV_POOL")) : 1;      // A/B: 0 = the separate pool kernel
+        if (fuse3 && d->act == IE_ACT_RELU && d->stride == 1 && !(d->Cout & 15) && !residual && !d->clamp && d->out_dtype != IE_F32 && !d->pixel_shuffle &&
+            p.Ho >= 2 && p.Wo >= 2) {
+            p.pool = pool_dst;
+            if (pooled) *pooled = true;
         }
     }
     int grid = p.total_blocks;
