@@ -1185,8 +1185,18 @@ static int mconv_impl(ie_mconv_desc* d, const void* const* srcs, const int* chan
     } else if (k3 && !use_v1) {
         // 64-cout tiles (one cout fragment per wave, 16-row tile = 128 accumulator VGPRs) leave room for only two workgroups per
         // CU; an 8-row tile (64 accumulator VGPRs, 2 x 22 KB of LDS) runs three and overlaps the per-tile serial work better
-        static const int th_nf4 = getenv("IE_MCONV_TH") ? atoi(getenv("IE_MCONV_TH")) : 16;   // measured: 8-row tiles x 3 workgroups are ~7 % slower (582 vs 624 TFLOP/s on 64->64)
-        if (pl.nf == 4 && th_nf4 == 8) { th3 = 8; wgs_per_cu = 3; }
+        // Which is faster depends on K and on the rows the last tile row wastes (profiles/r03/mconv3_tile_height_ab.log, U-Net-32's layers at batch 32): with <= 4 K chunks
+        // the per-tile serial part (epilogue, drain, first fill) dominates and three small workgroups hide it better (8-row tiles 6 % faster); at 8 chunks 8-row tiles cost
+        // ~3 %, at 16 chunks ~6.5 % per row -- but 135 or 67 rows pad to 144 / 80 with 16-row tiles and to 136 / 72 with 8-row ones.  IE_MCONV_TH = 8 | 16 forces one.
+        static const int th_nf4 = getenv("IE_MCONV_TH") ? atoi(getenv("IE_MCONV_TH")) : 0;
+        if (pl.nf == 4) {
+            bool th8 = th_nf4 == 8;
+            if (th_nf4 != 8 && th_nf4 != 16) {
+                const double per_row8 = pl.nchunks <= 4 ? 0.95 : (pl.nchunks <= 8 ? 1.03 : 1.065);
+                th8 = per_row8 * (double)(ie_cdiv(p.Ho, 8) * 8) < (double)(ie_cdiv(p.Ho, 16) * 16);
+            }
+            if (th8) { th3 = 8; wgs_per_cu = 3; }
+        }
         switch (pl.nf) {
         case 1: fn = h ? mconv3_kernel<_Float16, 4, 16> : mconv3_kernel<__bf16, 4, 16>; break;
         case 2: fn = h ? mconv3_kernel<_Float16, 2, 16> : mconv3_kernel<__bf16, 2, 16>; break;

@@ -65,12 +65,13 @@ def test_strip_conv_vs_torch(c, dt, shape):
 @pytest.mark.parametrize("shape", [(2, 37, 150), (1, 200, 64), (3, 6, 129), (1, 270, 480), (2, 2, 66)], ids=lambda s: "x".join(map(str, s)))
 @pytest.mark.parametrize("cs,co,act", [([32], 32, "relu"), ([64], 64, "relu"), ([32], 64, "relu"), ([32, 32], 32, "relu"), ([64, 64], 64, "relu"),
                                        ([64], 64, "none"), ([128], 128, "relu"), ([64], 128, "relu"), ([128], 16, "relu"), ([96], 32, "relu"), ([128], 128, "lrelu"),
-                                       ([256], 80, "relu")], ids=lambda v: str(v).replace(" ", ""))
+                                       ([256], 80, "relu"), ([320], 64, "relu")], ids=lambda v: str(v).replace(" ", ""))
 def test_conv_with_fused_maxpool(cs, co, act, dt, shape):
     """ie_mconv_pool_nhwc (unet.py:70-72, MaxPool2d(2) behind the DoubleConv): the full-resolution output is the plain conv's, bit for bit,
     and the pooled copy is F.max_pool2d of it, bit for bit -- from the strip kernel's parked rows (first five cases; odd heights and widths
     drop the last row / column like torch), from the register-weights kernel's epilogue (wide ReLU layers: row pairs are a lane's own accumulators,
-    column pairs neighbouring lanes; all three wave layouts), or from the conv followed by the pool kernel (no ReLU)."""
+    column pairs neighbouring lanes; all three wave layouts; 8-row tiles for few K chunks, 16-row tiles for [320] -> 64 at 200 / 270 rows), or from the conv
+    followed by the pool kernel (no ReLU)."""
     tdt = ops.TORCH_DT[dt]
     n, h, w = shape
     g = torch.Generator().manual_seed(23)
