@@ -833,11 +833,141 @@ IE_EXPORT int ie_convn_dgrad_nhwc_f32(ie_convn_desc* d, const float* dy, const f
     return IE_OK;
 }
 
+// ---- row forms of the two adjoints for 16-bit tensors (8 channels = 16 bytes per lane) -------------------------------------------------------------
+// blockIdx.x = (frame, row pair | input row): the row's scalars are computed once per workgroup, the lanes run over the row's 16-byte pieces with 32-bit
+// arithmetic.  Same operations in the same order as the flat kernels above (bit-identical results); what goes away is the 64-bit index split per 16 bytes,
+// the four-fold re-read of every pooling window (one lane now owns the window's four elements) and the per-lane candidate arithmetic of the row direction.
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2_backward_rows_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, int H, int W, int C, int Ho,
+                                                                     int Wo, int accumulate, int c8_shift) {
+    typedef __attribute__((ext_vector_type(8))) T TV;
+    const unsigned HP = (unsigned)(H + 1) >> 1, WP = (unsigned)(W + 1) >> 1;
+    const unsigned n = blockIdx.x / HP, hp = blockIdx.x - n * HP;
+    const unsigned C8 = (unsigned)C >> 3, pieces = WP * C8;
+    const int h0 = 2 * (int)hp;
+    const bool two_rows = h0 + 1 < H, win_row = (int)hp < Ho;
+    const T* xr = x + ((size_t)n * H + h0) * (size_t)W * C;
+    T* dr = dx + ((size_t)n * H + h0) * (size_t)W * C;
+    const T* dyr = dy + ((size_t)n * Ho + (win_row ? hp : 0)) * (size_t)Wo * C;
+    const size_t rowe = (size_t)W * C;
+    for (unsigned j = blockIdx.y * 256u + threadIdx.x; j < pieces; j += gridDim.y * 256u) {
+        const unsigned wp = c8_shift >= 0 ? (j >> c8_shift) : (j / C8), c = (j - wp * C8) * 8u;
+        const int w0 = 2 * (int)wp;
+        const bool two_cols = w0 + 1 < W, win = win_row && (int)wp < Wo;
+        const size_t o00 = (size_t)w0 * C + c;
+        float g[4][8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) g[k][e] = 0.f;
+        if (win) {          // both rows and both columns exist
+            TV v[4];
+            v[0] = *(const TV*)(xr + o00); v[1] = *(const TV*)(xr + o00 + C); v[2] = *(const TV*)(xr + rowe + o00); v[3] = *(const TV*)(xr + rowe + o00 + C);
+            const TV d = *(const TV*)(dyr + (size_t)wp * C + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float f[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) f[k] = (float)v[k][e];
+                int best = 0;
+#pragma unroll
+                for (int k = 1; k < 4; ++k) if (f[k] > f[best] || (f[k] != f[k] && f[best] == f[best])) best = k;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) g[k][e] = best == k ? (float)d[e] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (((k & 2) && !two_rows) || ((k & 1) && !two_cols)) continue;
+            T* o = dr + (k & 2 ? rowe : 0) + o00 + (k & 1 ? C : 0);
+            TV out;
+            if (accumulate) {
+                const TV old = *(const TV*)o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) out[e] = (T)((float)old[e] + g[k][e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) out[e] = (T)g[k][e];
+            }
+            *(TV*)o = out;
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void resize_backward_rows_kernel(const T* __restrict__ dy, T* __restrict__ dx, int Hi, int Wi, int C, int Ho, int Wo, int mode,
+                                                                   int accumulate, int c8_shift) {
+    typedef __attribute__((ext_vector_type(8))) T TV;
+    const unsigned n = blockIdx.x / (unsigned)Hi;
+    const int yi = (int)(blockIdx.x - n * (unsigned)Hi);
+    const unsigned C8 = (unsigned)C >> 3, pieces = (unsigned)Wi * C8;
+    int ylo, yhi;
+    resize_candidates(yi, Hi, Ho, mode, ylo, yhi);
+    const T* p = dy + (size_t)n * Ho * Wo * C;
+    T* dr = dx + ((size_t)n * Hi + yi) * (size_t)Wi * C;
+    for (unsigned j = blockIdx.y * 256u + threadIdx.x; j < pieces; j += gridDim.y * 256u) {
+        const unsigned xw = c8_shift >= 0 ? (j >> c8_shift) : (j / C8), c = (j - xw * C8) * 8u;
+        const int xi = (int)xw;
+        int xlo, xhi;
+        resize_candidates(xi, Wi, Wo, mode, xlo, xhi);
+        float g[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] = 0.f;
+        for (int yo = ylo; yo <= yhi; ++yo) {          // wave-uniform
+            int a0, a1; float ly;
+            resize_src(yo, Hi, Ho, mode, a0, a1, ly);
+            float wy = 0.f;
+            if (mode == 0) wy = (a0 == yi) ? 1.f : 0.f;
+            else { if (a0 == yi) wy += 1.f - ly; if (a1 == yi) wy += ly; }
+            if (wy == 0.f) continue;
+            float rowacc[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) rowacc[e] = 0.f;
+            const T* prow = p + (size_t)yo * Wo * C + c;
+            for (int xo = xlo; xo <= xhi; ++xo) {
+                int b0, b1; float lx;
+                resize_src(xo, Wi, Wo, mode, b0, b1, lx);
+                float wx = 0.f;
+                if (mode == 0) wx = (b0 == xi) ? 1.f : 0.f;
+                else { if (b0 == xi) wx += 1.f - lx; if (b1 == xi) wx += lx; }
+                if (wx != 0.f) {
+                    const TV d = *(const TV*)(prow + (size_t)xo * C);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) rowacc[e] = fmaf(wx, (float)d[e], rowacc[e]);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) g[e] = fmaf(wy, rowacc[e], g[e]);
+        }
+        T* o = dr + (size_t)xi * C + c;
+        TV out;
+        if (accumulate) {
+            const TV old = *(const TV*)o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) out[e] = (T)((float)old[e] + g[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) out[e] = (T)g[e];
+        }
+        *(TV*)o = out;
+    }
+}
+
+static inline int c8_shift_of(int C8) { int s = 0; while ((1 << s) < C8) ++s; return (1 << s) == C8 ? s : -1; }
+static inline dim3 row_grid(size_t rows, size_t pieces) {
+    size_t gy = (pieces + 1023) / 1024;
+    return dim3((unsigned)rows, (unsigned)(gy < 1 ? 1 : gy > 64 ? 64 : gy));
+}
+
 template <typename T>
 static int maxpool_bwd_impl(const void* x, const void* dy, void* dx, int N, int H, int W, int C, int accumulate, void* stream) {
     if (!x || !dy || !dx || N <= 0 || H < 2 || W < 2 || C <= 0) IE_FAIL(IE_ERR_INVALID, "ie_maxpool2x2_backward_nhwc: bad args");
     const size_t total = (size_t)N * H * W * C;
-    if (sizeof(T) == 2 && (C & 7) == 0)
+    static const int rows_form = getenv("IE_TRAIN_ROWS") ? atoi(getenv("IE_TRAIN_ROWS")) : 1;      // A/B: 0 = the flat 16-bit kernels
+    if (sizeof(T) == 2 && (C & 7) == 0 && rows_form && (size_t)N * ((H + 1) / 2) <= 0x7fffffffull)
+        hipLaunchKernelGGL((maxpool2_backward_rows_kernel<T>), row_grid((size_t)N * ((H + 1) / 2), (size_t)((W + 1) / 2) * (C / 8)), dim3(256), 0, (hipStream_t)stream,
+                           (const T*)x, (const T*)dy, (T*)dx, H, W, C, H / 2, W / 2, accumulate, c8_shift_of(C / 8));
+    else if (sizeof(T) == 2 && (C & 7) == 0)
         hipLaunchKernelGGL((maxpool2_backward_kernel<T, 8>), dim3(nblk(total / 8)), dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)dy, (T*)dx,
                            H, W, C, H / 2, W / 2, accumulate, total / 8);
     else
@@ -864,7 +994,11 @@ static int resize_bwd_impl(const void* dy, void* dx, int N, int Hi, int Wi, int 
     if (!dy || !dx || N <= 0 || Hi <= 0 || Wi <= 0 || C <= 0 || Ho <= 0 || Wo <= 0 || mode < 0 || mode > 2)
         IE_FAIL(IE_ERR_INVALID, "ie_resize_backward_nhwc: bad args");
     const size_t total = (size_t)N * Hi * Wi * C;
-    if (sizeof(T) == 2 && (C & 7) == 0)
+    static const int rows_form = getenv("IE_TRAIN_ROWS") ? atoi(getenv("IE_TRAIN_ROWS")) : 1;      // A/B: 0 = the flat 16-bit kernels
+    if (sizeof(T) == 2 && (C & 7) == 0 && rows_form && (size_t)N * Hi <= 0x7fffffffull)
+        hipLaunchKernelGGL((resize_backward_rows_kernel<T>), row_grid((size_t)N * Hi, (size_t)Wi * (C / 8)), dim3(256), 0, (hipStream_t)stream, (const T*)dy, (T*)dx, Hi, Wi,
+                           C, Ho, Wo, mode, accumulate, c8_shift_of(C / 8));
+    else if (sizeof(T) == 2 && (C & 7) == 0)
         hipLaunchKernelGGL((resize_backward_kernel<T, 8>), dim3(nblk(total / 8)), dim3(256), 0, (hipStream_t)stream, (const T*)dy, (T*)dx, Hi, Wi, C, Ho,
                            Wo, mode, accumulate, total / 8);
     else
