@@ -220,6 +220,13 @@ def run_generator_workload(args, ctx):
                                  + (" (forward and data-gradient calls; the weight-gradient kernel is outside this census)" if train else "")})
     except Exception as e:       # noqa: BLE001
         roofline["census_error"] = str(e)[:200]
+    try:      # HBM bytes per launch of that kernel from the committed PMC passes (profiles/traffic.json "workloads"), when it is the kernel they were taken on
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            tw = json.load(f).get("workloads", {}).get(args.workload)
+        if tw and roofline.get("kernel") and tw["kernel_contains"] in roofline["kernel"] and wl["batch"] == 32:
+            roofline.update({"traffic": tw["traffic"], "traffic_source": tw["source"], "mfma_busy_frac_pmc": tw.get("mfma_busy_frac"), "clock_GHz_pmc": tw.get("clock_GHz")})
+    except Exception:       # noqa: BLE001
+        pass
     cpu_baseline = parity = None
     if world == 1 and not args.no_cpu_baseline:
         ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)

@@ -21,4 +21,11 @@ for name, rw in parts.items():
         out[name] = rw["read"] + rw["write"]
         out["_" + name + "_read_write"] = [rw["read"], rw["write"]]
 out["_source"] = "rocprofv3 --pmc FETCH_SIZE WRITE_SIZE on `bench.py --steps 2 --warmup 1 --no-extras` (launches of 16 frames 1080p); FETCH_SIZE x2 (gfx950) + WRITE_SIZE, KB -> bytes"
+try:      # the per-workload entries (tools/pmc_models.sh passes of configs 3 / 4) live in the same file: carry them over
+    import os
+    old = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")))
+    if "workloads" in old:
+        out["workloads"] = old["workloads"]
+except Exception:
+    pass
 print(json.dumps(out, indent=1))
