@@ -1044,9 +1044,11 @@ class UNet(_GraphModel):
         def up(k, a, skip):
             if self.upsampler == "bilinear":
                 a = T.t_resize(tape, a, (a.shape[2] * 2, a.shape[3] * 2), "bilinear_align")
-            elif self.upsampler == "convtranspose":      # fp32 detour on the 16-bit graph, like HINet's
-                a = T.t_conv_transpose2x2(tape, T.t_cast(tape, a, torch.float32) if mixed else a, store, f"up{k}.up")
-                a = T.t_cast(tape, a, tdt) if mixed else a
+            elif self.upsampler == "convtranspose":      # on the 16-bit graph: the 1x1 matrix-core conv to 4*Cout channels + pixel shuffle (IE_CONVT_FP32=1: the fp32 detour)
+                if mixed and os.environ.get("IE_CONVT_FP32") == "1":
+                    a = T.t_cast(tape, T.t_conv_transpose2x2(tape, T.t_cast(tape, a, torch.float32), store, f"up{k}.up"), tdt)
+                else:
+                    a = T.t_conv_transpose2x2(tape, a, store, f"up{k}.up")
             else:
                 a = T.t_pixel_shuffle(tape, T.t_conv(tape, a, store.conv(f"up{k}.up.0"), *store.conv_grads(f"up{k}.up.0")), 2)
             dy, dx = skip.shape[2] - a.shape[2], skip.shape[3] - a.shape[3]
@@ -1855,7 +1857,7 @@ class HINet_RE(_GraphModel):
                             cout_pad=cout_pad if mixed else None)
 
         def up2x2(t, name):
-            if mixed:
+            if mixed and os.environ.get("IE_CONVT_FP32") == "1":      # A/B: the fp32 detour of rounds 2 - 3
                 return T.t_cast(tape, T.t_conv_transpose2x2(tape, T.t_cast(tape, t, torch.float32), store, name), tdt)
             return T.t_conv_transpose2x2(tape, t, store, name)
 

@@ -135,6 +135,9 @@ class ParamStore:
             _, _, (co, ci, kh, kw), _ = self.index[f"{name}.weight"]
             dt = ops.TORCH_DT[self.compute_dtype]
             b = self.view(f"{name}.bias") if f"{name}.bias" in self.index else None
+            if f"{name}.weight" in self.convT:       # (Cin, Cout, 2, 2) read as the HWIO matrix of a 1x1 conv Cin -> 4*Cout; its bias is the expanded one
+                ci, co, kh, kw = co, 4 * ci, 1, 1          # (the index holds (Cin, Cout, 2, 2), unpacked above as (co, ci, kh, kw))
+                b = self.conv_transpose_bias4(name) if b is not None else None
             w = self.view(f"{name}.weight")
             co_p, pad = cout_pad or co, None
             if sum(real) != ci or co_p < co or any(r > c for r, c in zip(real, split)):
@@ -160,7 +163,20 @@ class ParamStore:
         over the 4 sub-pixels: ``expand_bias`` / ``reduce_bias_grad`` move between the (Cout) parameter and the 4*Cout conv bias."""
         _, n, (ci, co, kh, kw), _ = self.index[f"{name}.weight"]
         w = ops.ConvWeightsView(self.view(f"{name}.weight"), None, co * 4, ci, 1, 1)
+        w.store, w.name = self, name          # the 16-bit graph packs it through conv16 (the 1x1 conv to 4*Cout channels)
         return w, self.view(f"{name}.weight", self.grads)
+
+    def conv_transpose_bias4(self, name):
+        """The (4*Cout) bias of the 1x1 conv that stands for ConvTranspose2d ``name``: a persistent buffer (the packed 16-bit forward keeps a pointer
+        to it), refreshed from the (Cout) parameter at every forward."""
+        if not hasattr(self, "_ct_bias"):
+            self._ct_bias = {}
+        b = self.view(f"{name}.bias").repeat_interleave(4)
+        if name not in self._ct_bias:
+            self._ct_bias[name] = b.contiguous().clone()
+        else:
+            self._ct_bias[name].copy_(b)
+        return self._ct_bias[name]
 
     def conv_grads(self, name):
         db = self.view(f"{name}.bias", self.grads) if f"{name}.bias" in self.index else None
@@ -493,7 +509,7 @@ def t_conv_transpose2x2(tape, x, store, name):
     sub-pixels (expanded for the forward, its gradient summed back)."""
     cw, dw = store.conv_transpose(name)
     has_b = f"{name}.bias" in store.index
-    b4 = store.view(f"{name}.bias").repeat_interleave(4).contiguous() if has_b else None     # parameter plumbing, Cout values
+    b4 = store.conv_transpose_bias4(name) if has_b else None     # parameter plumbing, Cout values
     cw.b = b4
     db4 = torch.empty_like(b4) if has_b else None
     y = t_pixel_shuffle(tape, t_conv(tape, x, cw, dw, db4, pad=0), 2)

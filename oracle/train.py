@@ -101,6 +101,8 @@ def unet_forward_train(p: dict, buffers: dict, x, upsampler="bilinear", enhance=
     def up(k, a, skip):
         if upsampler == "bilinear":
             a = qa(F.interpolate(a, scale_factor=2, mode="bilinear", align_corners=True))
+        elif upsampler == "convtranspose":      # the reference's bilinear=False branch (unet.py:85-86): nn.ConvTranspose2d(in, in // 2, kernel_size=2, stride=2)
+            a = qa(F.conv_transpose2d(a, qw(p[f"up{k}.up.weight"]), p.get(f"up{k}.up.bias"), stride=2))
         else:
             a = F.pixel_shuffle(qa(F.conv2d(a, qw(p[f"up{k}.up.0.weight"]), p[f"up{k}.up.0.bias"], padding=1)), 2)
         dy, dx = skip.shape[2] - a.shape[2], skip.shape[3] - a.shape[3]

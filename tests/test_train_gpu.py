@@ -383,7 +383,7 @@ def _batches(n, h, w, steps, seed):
     return out
 
 
-@pytest.mark.parametrize("upsampler,h,w", [("bilinear", 48, 64), ("bilinear", 44, 60), ("pixelshuffle", 32, 48)])
+@pytest.mark.parametrize("upsampler,h,w", [("bilinear", 48, 64), ("bilinear", 44, 60), ("pixelshuffle", 32, 48), ("convtranspose", 32, 48), ("convtranspose", 44, 60)])
 def test_unet_training_steps_match_torch(upsampler, h, w):
     """Two optimiser steps.  Adam's default eps (1e-8) makes the update sign-like -- lr * g/(|g|+eps) -- so rounding-sized
     gradient differences on near-zero gradients change a few weights by a fraction of lr and the second step then starts
@@ -782,10 +782,12 @@ def test_hinet_training_step_matches_torch():
 
 
 @pytest.mark.parametrize("dt,min_cos,min_layer,upsampler", [("f16", 0.985, 0.97, "bilinear"), ("bf16", 0.97, 0.94, "bilinear"),
-                                                            ("f16", 0.985, 0.97, "pixelshuffle"), ("bf16", 0.97, 0.94, "pixelshuffle")])
+                                                            ("f16", 0.985, 0.97, "pixelshuffle"), ("bf16", 0.97, 0.94, "pixelshuffle"),
+                                                            ("f16", 0.985, 0.97, "convtranspose"), ("bf16", 0.97, 0.94, "convtranspose")])
 def test_unet_mixed_precision_training_step(dt, min_cos, min_layer, upsampler):
     """compute_dtype f16 / bf16: 16-bit activations and gradients between matrix-core convolutions (forward and data gradient), fp32
-    master weights / statistics / weight gradients / Adam.
+    master weights / statistics / weight gradients / Adam.  The ConvTranspose2d(k=2, s=2) decoder (unet.py:85-86) runs on the same graph as the 1x1
+    matrix-core conv to 4*Cout channels + pixel shuffle (forward, data gradient, single-tap weight gradient; the tied bias through its 4*Cout expansion).
 
     The reference of THIS test is oracle.train.unet_forward_train(q=storage_rounding(dtype)): torch float64 arithmetic with every
     tensor between two kernels -- and its gradient -- rounded to the 16-bit storage format, i.e. the same graph with the same
@@ -1113,8 +1115,8 @@ def test_retinexnet_mixed_precision_training_step(phase, dt, min_cos):
 
 @pytest.mark.parametrize("dt,min_cos", [("f16", 0.9995), ("bf16", 0.995)])
 def test_hinet_mixed_precision_training_step(dt, min_cos):
-    """HINet on the 16-bit graph: stride-1 convolutions, half instance norms, adds and the attention product on 16-bit tensors; the
-    Conv4x4 stride-2 and ConvTranspose 2x2 layers through their fp32 detour.  Gradient direction against the storage-rounding
+    """HINet on the 16-bit graph: every convolution (stride 1, Conv4x4 stride 2, ConvTranspose 2x2 as a 1x1 conv + pixel shuffle), half instance norms,
+    adds and the attention product on 16-bit tensors.  Gradient direction against the storage-rounding
     restatement of the same graph (oracle.generators.hinet_forward(q=...)); against plain float64 the engine must be about as close as
     that restatement is."""
     from oracle import generators as og
