@@ -35,6 +35,8 @@ constexpr int WM_LDS = 4 * WM_ROWB + 2 * WM_DYB;
 struct WgradMParams {
     const void* x; const void* dy; float* dw;
     int N, H, W, Cs, Cout, Cin_total, cbase, rows_per_wg, co_tiles, xchunks, nci;
+    int xo, xH, xW;    // input geometry: the tensor is xH x xW and input pixel (y, x) of the pad-1 formulation is its pixel (y + xo, x + xo).  pad 1: xo = 0, xH x xW = H x W;
+                       // pad 0 ("valid" 3x3 on a tensor the caller padded, e.g. by replication): xo = 1, xH x xW = (H + 2) x (W + 2) -- its border takes the zero padding's place
     float* slab;       // deterministic mode: [split = blockIdx.z * gridDim.y + blockIdx.y][tile = blockIdx.x][tap][64 ci][64 co], else NULL
 };
 
@@ -68,15 +70,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_kernel(WgradMParams p)
     const int co_t = (blockIdx.x % p.co_tiles) * 64, ci_t = (blockIdx.x / p.co_tiles) * 64;
     const int n = blockIdx.y / p.xchunks, x0 = (blockIdx.y % p.xchunks) * WM_PX;
     const int y0 = blockIdx.z * p.rows_per_wg, y1 = min(y0 + p.rows_per_wg, p.H);
-    const T* xn = (const T*)p.x + (size_t)n * p.H * p.W * p.Cs;
+    const T* xn = (const T*)p.x + (size_t)n * p.xH * p.xW * p.Cs;
     const T* dn = (const T*)p.dy + (size_t)n * p.H * p.W * p.Cout;
 
     // loader slots: 16-byte chunk (t & 7) of staged pixel (t >> 3); threads 0..15 also take pixels 32, 33 of the input row
     const int lpix = t >> 3, lch = t & 7;
     const bool x_ch_ok = ci_t + lch * 8 < p.Cs, d_ch_ok = co_t + lch * 8 < p.Cout;
     const int gx_a = x0 - 1 + lpix, gx_b = x0 + 31 + lpix;      // input columns of the two loader slots
-    const bool xa_ok = x_ch_ok && gx_a >= 0 && gx_a < p.W;
-    const bool xb_ok = t < 16 && x_ch_ok && gx_b < p.W;
+    const bool xa_ok = x_ch_ok && gx_a + p.xo >= 0 && gx_a + p.xo < p.xW;
+    const bool xb_ok = t < 16 && x_ch_ok && gx_b + p.xo < p.xW;
     const bool d_ok = d_ch_ok && x0 + lpix < p.W;
     const int xoff_a = wm_chunk_off(lpix, lch), xoff_b = wm_chunk_off(32 + lpix, lch), doff = 4 * WM_ROWB + wm_chunk_off(lpix, lch);
     const ie_u32x4 zero4 = {0u, 0u, 0u, 0u};
@@ -84,15 +86,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_kernel(WgradMParams p)
     // where the value is stored to LDS, a step later.  With the same number of loads in flight on every path and no use of the
     // value near the load, the compiler waits for the OLDER prefetch set with a counted vmcnt and the newer set stays in flight.
     auto ld_x = [&](int y, bool ok, int gx) -> ie_u32x4 {
-        const bool v = ok && y >= 0 && y < p.H;
-        return *(const ie_u32x4*)(v ? xn + ((size_t)y * p.W + gx) * p.Cs + ci_t + lch * 8 : xn);
+        const bool v = ok && y + p.xo >= 0 && y + p.xo < p.xH;
+        return *(const ie_u32x4*)(v ? xn + ((size_t)(y + p.xo) * p.xW + gx + p.xo) * p.Cs + ci_t + lch * 8 : xn);
     };
     auto ld_d = [&](int y) -> ie_u32x4 {
         const bool v = d_ok && y < p.H;
         return *(const ie_u32x4*)(v ? dn + ((size_t)y * p.W + x0 + lpix) * p.Cout + co_t + lch * 8 : dn);
     };
     auto sel = [&](ie_u32x4 r, bool v) -> ie_u32x4 { return v ? r : zero4; };
-    auto row_ok = [&](int y) -> bool { return y >= 0 && y < p.H; };
+    auto row_ok = [&](int y) -> bool { return y + p.xo >= 0 && y + p.xo < p.xH; };
     auto st_x = [&](int rr, ie_u32x4 a, ie_u32x4 b) {
         unsigned char* row = lds + (rr & 3) * WM_ROWB;
         *(ie_u32x4*)(row + xoff_a) = a;
@@ -217,13 +219,17 @@ __global__ void wgrad_mfma_reduce_kernel(const float* __restrict__ slab, float* 
 // dw_hwio[tap][cbase + ci][co] += X (*) dY.  dtype IE_F16 / IE_BF16,
 // cs % 8 == 0 and Cout % 8 == 0 (16-byte channel chunks); the caller checked applicability with ie_wgrad_mfma_applicable.
 bool ie_wgrad_mfma_applicable(int kh, int kw, int stride, int pad, int pad_mode, int cs, int cout) {
-    const bool k3 = kh == 3 && kw == 3 && pad == 1 && pad_mode == IE_PAD_ZEROS, k1 = kh == 1 && kw == 1 && pad == 0;
+    // 3x3 / pad 0: the layers behind an explicit padding op (RetinexNet's replicate-padded DecomNet / RelightNet on the 16-bit graph, retinexnet/model.py:26-36)
+    const bool k3 = kh == 3 && kw == 3 && ((pad == 1 && pad_mode == IE_PAD_ZEROS) || pad == 0), k1 = kh == 1 && kw == 1 && pad == 0;
     return (k3 || k1) && stride == 1 && (cs & 7) == 0 && (cout & 7) == 0;
 }
 
+// H x W: the OUTPUT (dY) size; pad = 1 (input H x W) or, for ksize 3, 0 (input (H + 2) x (W + 2))
 int ie_wgrad_mfma_launch(const void* x, const void* dy, int dtype, float* dw_hwio, int N, int H, int W, int cs, int cout, int cin_total, int cbase,
-                         int ksize, hipStream_t stream) {
+                         int ksize, int pad, hipStream_t stream) {
     WgradMParams p;
+    const bool valid3 = ksize == 3 && pad == 0;
+    p.xo = valid3 ? 1 : 0; p.xH = valid3 ? H + 2 : H; p.xW = valid3 ? W + 2 : W;
     p.x = x; p.dy = dy; p.dw = dw_hwio; p.N = N; p.H = H; p.W = W; p.Cs = cs; p.Cout = cout; p.Cin_total = cin_total; p.cbase = cbase;
     p.co_tiles = ie_cdiv(cout, 64);
     const int ci_tiles = ie_cdiv(cs, 64);

@@ -210,11 +210,14 @@ WGRAD16_CASES = [
     dict(cs=[12], co=20, n=1, h=6, w=9),          # channels not multiples of 8 -> scalar kernel
     dict(cs=[64, 32, 8], co=40, n=2, h=21, w=45, k=1),   # 1x1 / pad 0 (LLUnet++ skip convs): the single-tap form of the kernel
     dict(cs=[16], co=16, n=1, h=4, w=100, k=1),
+    dict(cs=[64], co=64, n=2, h=21, w=72, p=0),   # 3x3 "valid" on a tensor the caller padded (RetinexNet's replicate-padded layers on the 16-bit graph, model.py:28-33)
+    dict(cs=[64], co=16, n=1, h=35, w=34, p=0),   # ... the 4-channel head computed as 16 (`net1_recon`, model.py:34-36)
+    dict(cs=[16, 48], co=72, n=1, h=3, w=33, p=0),
 ]
 
 
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
-@pytest.mark.parametrize("c", WGRAD16_CASES, ids=lambda c: f"{'+'.join(map(str, c['cs']))}-{c['co']}-{c['h']}x{c['w']}-k{c.get('k', 3)}")
+@pytest.mark.parametrize("c", WGRAD16_CASES, ids=lambda c: f"{'+'.join(map(str, c['cs']))}-{c['co']}-{c['h']}x{c['w']}-k{c.get('k', 3)}" + ("-valid" if c.get("p") == 0 else ""))
 def test_conv_wgrad_16bit_matrix_core(c, dtype):
     """16-bit weight gradient (matrix-core kernel where it applies) against float64 autograd on the SAME rounded inputs."""
     tdt = ops.TORCH_DT[dtype]
@@ -222,22 +225,23 @@ def test_conv_wgrad_16bit_matrix_core(c, dtype):
     g = torch.Generator().manual_seed(11)
     xs16 = [torch.randn(n, ci, h, w, generator=g).to(tdt) for ci in c["cs"]]
     cin = sum(c["cs"])
-    dy16 = torch.randn(n, c["co"], h, w, generator=g).to(tdt)
     k = c.get("k", 3)
+    pad = c.get("p", k // 2)
+    dy16 = torch.randn(n, c["co"], h + 2 * pad - k + 1, w + 2 * pad - k + 1, generator=g).to(tdt)
     wt = torch.zeros(c["co"], cin, k, k, dtype=torch.float64, requires_grad=True)
     b = torch.zeros(c["co"], dtype=torch.float64, requires_grad=True)
-    F.conv2d(torch.cat([x.double() for x in xs16], 1), wt, b, padding=k // 2).backward(dy16.double())
+    F.conv2d(torch.cat([x.double() for x in xs16], 1), wt, b, padding=pad).backward(dy16.double())
     cw = ops.ConvWeights(wt.detach().float(), b.detach().float(), "cuda")
     xd = [x.cuda().contiguous(memory_format=CL) for x in xs16]
     dyd = dy16.cuda().contiguous(memory_format=CL)
     dw = torch.full((k * k * cin * c["co"],), 7.0, device="cuda")
     db = torch.full((c["co"],), 7.0, device="cuda")
-    ops.conv2d_wgrad(xd, dyd, cw, dw, db, 1, k // 2)
+    ops.conv2d_wgrad(xd, dyd, cw, dw, db, 1, pad)
     got = host(dw.reshape(k, k, cin, c["co"]).permute(3, 2, 0, 1)).double()
     # products of 16-bit values are exact in fp32; only the fp32 summation order differs
     assert rel_err(got, wt.grad) < 2e-5
     assert rel_err(host(db).double(), b.grad) < 2e-5
-    ops.conv2d_wgrad(xd, dyd, cw, dw, None, 1, k // 2, accumulate=True)
+    ops.conv2d_wgrad(xd, dyd, cw, dw, None, 1, pad, accumulate=True)
     assert rel_err(host(dw.reshape(k, k, cin, c["co"]).permute(3, 2, 0, 1)).double(), 2 * wt.grad) < 2e-5
 
 
