@@ -213,6 +213,8 @@ WGRAD16_CASES = [
     dict(cs=[64], co=64, n=2, h=21, w=72, p=0),   # 3x3 "valid" on a tensor the caller padded (RetinexNet's replicate-padded layers on the 16-bit graph, model.py:28-33)
     dict(cs=[64], co=16, n=1, h=35, w=34, p=0),   # ... the 4-channel head computed as 16 (`net1_recon`, model.py:34-36)
     dict(cs=[16, 48], co=72, n=1, h=3, w=33, p=0),
+    dict(cs=[16], co=64, n=2, h=30, w=75, k=9, p=0),   # 9x9 "valid" (`net1_conv0` on the replicate-padded 16-channel carrier, model.py:26): nine launches of the 3x3 form, one per block of taps
+    dict(cs=[8, 16], co=24, n=1, h=9, w=41, k=9, p=0),
 ]
 
 
