@@ -698,8 +698,8 @@ static int wgrad_impl(ie_convn_desc* d, const void* const* srcs, const int* cs, 
     for (int s = 0; s < d->nsrc; ++s) {
         if constexpr (sizeof(T) == 2) {
             if (!force_fma && (ie_wgrad_mfma_applicable(d->kh, d->kw, d->stride, d->pad, d->pad_mode, cs[s], d->Cout) ||
-                               ie_wgrad_mfma_applicable9(d->kh, d->kw, d->stride, d->pad, cs[s], d->Cout))) {
-                rc = ie_wgrad_mfma_launch(srcs[s], dy, ie_elem<T>::dtype, dw_hwio, d->N, d->Ho, d->Wo, cs[s], d->Cout, Cin, cbase, d->kh, d->pad, st);
+                               ie_wgrad_mfma_applicable_blocks(d->kh, d->kw, d->stride, d->pad, d->pad_mode, cs[s], d->Cout))) {
+                rc = ie_wgrad_mfma_launch(srcs[s], dy, ie_elem<T>::dtype, dw_hwio, d->N, d->Ho, d->Wo, cs[s], d->Cout, Cin, cbase, d->kh, d->pad, d->H, d->W, st);
                 if (rc != IE_OK) return rc;
                 cbase += cs[s];
                 continue;

@@ -35,10 +35,13 @@ constexpr int WM_LDS = 4 * WM_ROWB + 2 * WM_DYB;
 struct WgradMParams {
     const void* x; const void* dy; float* dw;
     int N, H, W, Cs, Cout, Cin_total, cbase, rows_per_wg, co_tiles, xchunks, nci;
-    int xoy, xox, xH, xW;   // input geometry: the tensor is xH x xW and input pixel (y, x) of the pad-1 formulation is its pixel (y + xoy, x + xox).  pad 1: 0, 0, H x W;
-                            // pad 0 ("valid" 3x3 on a tensor the caller padded, e.g. by replication): 1, 1, (H + 2) x (W + 2) -- its border takes the zero padding's place;
-                            // block (by, bx) of a valid 9x9 kernel's taps: 3 by + 1, 3 bx + 1, (H + 8) x (W + 8)
-    int tap_row, tap_base;  // tap (i, j) of this launch is tap tap_base + i * tap_row + j of dW (3x3: 3, 0; block (by, bx) of 9x9: 9, 27 by + 3 bx)
+    // Input geometry: the tensor is xH x xW and input pixel (y, x) of the pad-1 formulation is its pixel (xs y + xoy, xs x + xox); outside = zero padding.
+    //   3x3 pad 1: xs 1, offsets 0, H x W.   3x3 pad 0 ("valid" conv on a tensor the caller padded, e.g. by replication): offsets 1, (H + 2) x (W + 2).
+    //   block (by, bx) of a valid 9x9 kernel's taps: offsets 3 by + 1, 3 bx + 1, (H + 8) x (W + 8).
+    //   4x4 stride 2 pad 1 (hinet.py:65): the four parity sub-images (py, px) of the input, xs 2, offsets py, px -- tap ky - 1 = 2 a + py is offset a in {-1, 0, 1} there.
+    int xs, xoy, xox, xH, xW;
+    // tap (i, j) of the 3x3 window of this launch is tap (ts i + toy, ts j + tox) of the layer's KH x KW kernel (outside: not a tap of the layer, dropped)
+    int ts, toy, tox, KH, KW;
     float* slab;       // deterministic mode: [split = blockIdx.z * gridDim.y + blockIdx.y][tile = blockIdx.x][tap][64 ci][64 co], else NULL
 };
 
@@ -79,8 +82,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_kernel(WgradMParams p)
     const int lpix = t >> 3, lch = t & 7;
     const bool x_ch_ok = ci_t + lch * 8 < p.Cs, d_ch_ok = co_t + lch * 8 < p.Cout;
     const int gx_a = x0 - 1 + lpix, gx_b = x0 + 31 + lpix;      // input columns of the two loader slots
-    const bool xa_ok = x_ch_ok && gx_a + p.xox >= 0 && gx_a + p.xox < p.xW;
-    const bool xb_ok = t < 16 && x_ch_ok && gx_b + p.xox < p.xW;
+    const bool xa_ok = x_ch_ok && p.xs * gx_a + p.xox >= 0 && p.xs * gx_a + p.xox < p.xW;
+    const bool xb_ok = t < 16 && x_ch_ok && p.xs * gx_b + p.xox < p.xW;
     const bool d_ok = d_ch_ok && x0 + lpix < p.W;
     const int xoff_a = wm_chunk_off(lpix, lch), xoff_b = wm_chunk_off(32 + lpix, lch), doff = 4 * WM_ROWB + wm_chunk_off(lpix, lch);
     const ie_u32x4 zero4 = {0u, 0u, 0u, 0u};
@@ -88,15 +91,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_kernel(WgradMParams p)
     // where the value is stored to LDS, a step later.  With the same number of loads in flight on every path and no use of the
     // value near the load, the compiler waits for the OLDER prefetch set with a counted vmcnt and the newer set stays in flight.
     auto ld_x = [&](int y, bool ok, int gx) -> ie_u32x4 {
-        const bool v = ok && y + p.xoy >= 0 && y + p.xoy < p.xH;
-        return *(const ie_u32x4*)(v ? xn + ((size_t)(y + p.xoy) * p.xW + gx + p.xox) * p.Cs + ci_t + lch * 8 : xn);
+        const bool v = ok && p.xs * y + p.xoy >= 0 && p.xs * y + p.xoy < p.xH;
+        return *(const ie_u32x4*)(v ? xn + ((size_t)(p.xs * y + p.xoy) * p.xW + p.xs * gx + p.xox) * p.Cs + ci_t + lch * 8 : xn);
     };
     auto ld_d = [&](int y) -> ie_u32x4 {
         const bool v = d_ok && y < p.H;
         return *(const ie_u32x4*)(v ? dn + ((size_t)y * p.W + x0 + lpix) * p.Cout + co_t + lch * 8 : dn);
     };
     auto sel = [&](ie_u32x4 r, bool v) -> ie_u32x4 { return v ? r : zero4; };
-    auto row_ok = [&](int y) -> bool { return y + p.xoy >= 0 && y + p.xoy < p.xH; };
+    auto row_ok = [&](int y) -> bool { return p.xs * y + p.xoy >= 0 && p.xs * y + p.xoy < p.xH; };
     auto st_x = [&](int rr, ie_u32x4 a, ie_u32x4 b) {
         unsigned char* row = lds + (rr & 3) * WM_ROWB;
         *(ie_u32x4*)(row + xoff_a) = a;
@@ -187,7 +190,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_kernel(WgradMParams p)
         return;
     }
 #pragma unroll
-    for (int tap = 0; tap < NT; ++tap)
+    for (int tap = 0; tap < NT; ++tap) {
+        const int ky = p.ts * (tap / 3) + p.toy, kx = p.ts * (tap % 3) + p.tox;          // wave-uniform
+        if (ky < 0 || ky >= p.KH || kx < 0 || kx >= p.KW) continue;
+        const int ltap = ky * p.KW + kx;
 #pragma unroll
         for (int cob = 0; cob < NCO; ++cob) {
             const int co = co_t + (cob0 + cob) * 16 + co_l;
@@ -195,9 +201,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_mfma_kernel(WgradMParams p)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int ci = ci_t + cb * 16 + g * 4 + j;
-                if (ci < p.Cs) atomicAdd(p.dw + ((size_t)(p.tap_base + (tap / 3) * p.tap_row + tap % 3) * p.Cin_total + p.cbase + ci) * p.Cout + co, acc[tap][cob][j]);
+                if (ci < p.Cs) atomicAdd(p.dw + ((size_t)ltap * p.Cin_total + p.cbase + ci) * p.Cout + co, acc[tap][cob][j]);
             }
         }
+    }
 }
 
 // deterministic mode, second stage: one thread per (tile, tap, ci, co); adds the splits' slabs in split order (fp64 accumulate)
@@ -226,35 +233,42 @@ bool ie_wgrad_mfma_applicable(int kh, int kw, int stride, int pad, int pad_mode,
     return (k3 || k1) && stride == 1 && (cs & 7) == 0 && (cout & 7) == 0;
 }
 
-// H x W: the OUTPUT (dY) size; pad = 1 (input H x W) or, for ksize 3, 0 (input (H + 2) x (W + 2)).
-// ksize 9 (pad 0, input (H + 8) x (W + 8); not in deterministic mode): nine launches of the 3x3 form, one per 3x3 block of the 81 taps.
+// H x W: the OUTPUT (dY) size.  ksize 3: pad 1 (input H x W) or 0 (input (H + 2) x (W + 2)); ksize 1: pad 0.
+// Not in deterministic mode (one launch per block of taps, the slab reduction knows 3x3 / 1x1 only):
+//   ksize 9, pad 0 (input (H + 8) x (W + 8)): nine launches of the 3x3 form, one per 3x3 block of the 81 taps;
+//   ksize 4, stride 2, pad 1 (input in_h x in_w): four launches, one per parity sub-image of the input (4 of each launch's 9 taps are taps of the layer).
+struct WgradGeom { int xs, xoy, xox, xH, xW, ts, toy, tox, KH, KW; };
 static int wgrad_mfma_launch_one(const void* x, const void* dy, int dtype, float* dw_hwio, int N, int H, int W, int cs, int cout, int cin_total, int cbase,
-                                 int ksize, int xoy, int xox, int xH, int xW, int tap_row, int tap_base, hipStream_t stream);
+                                 int ksize, const WgradGeom& g, hipStream_t stream);
 
-bool ie_wgrad_mfma_applicable9(int kh, int kw, int stride, int pad, int cs, int cout) {
-    return kh == 9 && kw == 9 && stride == 1 && pad == 0 && (cs & 7) == 0 && (cout & 7) == 0 && !ie_get_deterministic();
+bool ie_wgrad_mfma_applicable_blocks(int kh, int kw, int stride, int pad, int pad_mode, int cs, int cout) {
+    const bool k9 = kh == 9 && kw == 9 && stride == 1 && pad == 0, k4 = kh == 4 && kw == 4 && stride == 2 && pad == 1 && pad_mode == IE_PAD_ZEROS;
+    return (k9 || k4) && (cs & 7) == 0 && (cout & 7) == 0 && !ie_get_deterministic();
 }
 
 int ie_wgrad_mfma_launch(const void* x, const void* dy, int dtype, float* dw_hwio, int N, int H, int W, int cs, int cout, int cin_total, int cbase,
-                         int ksize, int pad, hipStream_t stream) {
-    if (ksize == 9) {
-        if (pad != 0 || ie_get_deterministic()) IE_FAIL(IE_ERR_UNSUPPORTED, "ie_convn_wgrad_nhwc: the matrix-core 9x9 form is pad 0, non-deterministic mode");
-        for (int by = 0; by < 3; ++by)
-            for (int bx = 0; bx < 3; ++bx) {
-                const int rc = wgrad_mfma_launch_one(x, dy, dtype, dw_hwio, N, H, W, cs, cout, cin_total, cbase, 3, 3 * by + 1, 3 * bx + 1, H + 8, W + 8, 9, 27 * by + 3 * bx, stream);
+                         int ksize, int pad, int in_h, int in_w, hipStream_t stream) {
+    if (ksize == 9 || ksize == 4) {
+        if (ie_get_deterministic()) IE_FAIL(IE_ERR_UNSUPPORTED, "ie_convn_wgrad_nhwc: the blocked matrix-core forms do not run in deterministic mode");
+        const int nb = ksize == 9 ? 3 : 2;
+        for (int by = 0; by < nb; ++by)
+            for (int bx = 0; bx < nb; ++bx) {
+                const WgradGeom g = ksize == 9 ? WgradGeom{1, 3 * by + 1, 3 * bx + 1, H + 8, W + 8, 1, 3 * by, 3 * bx, 9, 9}
+                                               : WgradGeom{2, by, bx, in_h, in_w, 2, by - 1, bx - 1, 4, 4};
+                const int rc = wgrad_mfma_launch_one(x, dy, dtype, dw_hwio, N, H, W, cs, cout, cin_total, cbase, 3, g, stream);
                 if (rc != IE_OK) return rc;
             }
         return IE_OK;
     }
     const bool valid3 = ksize == 3 && pad == 0;
-    return wgrad_mfma_launch_one(x, dy, dtype, dw_hwio, N, H, W, cs, cout, cin_total, cbase, ksize, valid3 ? 1 : 0, valid3 ? 1 : 0, valid3 ? H + 2 : H, valid3 ? W + 2 : W,
-                                 3, 0, stream);
+    const int o = valid3 ? 1 : 0;
+    return wgrad_mfma_launch_one(x, dy, dtype, dw_hwio, N, H, W, cs, cout, cin_total, cbase, ksize, WgradGeom{1, o, o, H + 2 * o, W + 2 * o, 1, 0, 0, ksize, ksize}, stream);
 }
 
 static int wgrad_mfma_launch_one(const void* x, const void* dy, int dtype, float* dw_hwio, int N, int H, int W, int cs, int cout, int cin_total, int cbase,
-                                 int ksize, int xoy, int xox, int xH, int xW, int tap_row, int tap_base, hipStream_t stream) {
+                                 int ksize, const WgradGeom& g, hipStream_t stream) {
     WgradMParams p;
-    p.xoy = xoy; p.xox = xox; p.xH = xH; p.xW = xW; p.tap_row = tap_row; p.tap_base = tap_base;
+    p.xs = g.xs; p.xoy = g.xoy; p.xox = g.xox; p.xH = g.xH; p.xW = g.xW; p.ts = g.ts; p.toy = g.toy; p.tox = g.tox; p.KH = g.KH; p.KW = g.KW;
     p.x = x; p.dy = dy; p.dw = dw_hwio; p.N = N; p.H = H; p.W = W; p.Cs = cs; p.Cout = cout; p.Cin_total = cin_total; p.cbase = cbase;
     p.co_tiles = ie_cdiv(cout, 64);
     const int ci_tiles = ie_cdiv(cs, 64);

@@ -215,11 +215,14 @@ WGRAD16_CASES = [
     dict(cs=[16, 48], co=72, n=1, h=3, w=33, p=0),
     dict(cs=[16], co=64, n=2, h=30, w=75, k=9, p=0),   # 9x9 "valid" (`net1_conv0` on the replicate-padded 16-channel carrier, model.py:26): nine launches of the 3x3 form, one per block of taps
     dict(cs=[8, 16], co=24, n=1, h=9, w=41, k=9, p=0),
+    dict(cs=[32], co=32, n=2, h=36, w=70, k=4, p=1, s=2),   # Conv4x4 stride 2 (HINet's down-sampling, hinet.py:65): four launches, one per parity sub-image of the input
+    dict(cs=[64], co=128, n=1, h=19, w=33, k=4, p=1, s=2),  # odd sizes
+    dict(cs=[16, 8], co=16, n=1, h=4, w=6, k=4, p=1, s=2),
 ]
 
 
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
-@pytest.mark.parametrize("c", WGRAD16_CASES, ids=lambda c: f"{'+'.join(map(str, c['cs']))}-{c['co']}-{c['h']}x{c['w']}-k{c.get('k', 3)}" + ("-valid" if c.get("p") == 0 else ""))
+@pytest.mark.parametrize("c", WGRAD16_CASES, ids=lambda c: f"{'+'.join(map(str, c['cs']))}-{c['co']}-{c['h']}x{c['w']}-k{c.get('k', 3)}" + ("-valid" if c.get("p") == 0 else "") + ("-s2" if c.get("s") == 2 else ""))
 def test_conv_wgrad_16bit_matrix_core(c, dtype):
     """16-bit weight gradient (matrix-core kernel where it applies) against float64 autograd on the SAME rounded inputs."""
     tdt = ops.TORCH_DT[dtype]
@@ -228,22 +231,22 @@ def test_conv_wgrad_16bit_matrix_core(c, dtype):
     xs16 = [torch.randn(n, ci, h, w, generator=g).to(tdt) for ci in c["cs"]]
     cin = sum(c["cs"])
     k = c.get("k", 3)
-    pad = c.get("p", k // 2)
-    dy16 = torch.randn(n, c["co"], h + 2 * pad - k + 1, w + 2 * pad - k + 1, generator=g).to(tdt)
+    pad, st = c.get("p", k // 2), c.get("s", 1)
+    dy16 = torch.randn(n, c["co"], (h + 2 * pad - k) // st + 1, (w + 2 * pad - k) // st + 1, generator=g).to(tdt)
     wt = torch.zeros(c["co"], cin, k, k, dtype=torch.float64, requires_grad=True)
     b = torch.zeros(c["co"], dtype=torch.float64, requires_grad=True)
-    F.conv2d(torch.cat([x.double() for x in xs16], 1), wt, b, padding=pad).backward(dy16.double())
+    F.conv2d(torch.cat([x.double() for x in xs16], 1), wt, b, stride=st, padding=pad).backward(dy16.double())
     cw = ops.ConvWeights(wt.detach().float(), b.detach().float(), "cuda")
     xd = [x.cuda().contiguous(memory_format=CL) for x in xs16]
     dyd = dy16.cuda().contiguous(memory_format=CL)
     dw = torch.full((k * k * cin * c["co"],), 7.0, device="cuda")
     db = torch.full((c["co"],), 7.0, device="cuda")
-    ops.conv2d_wgrad(xd, dyd, cw, dw, db, 1, pad)
+    ops.conv2d_wgrad(xd, dyd, cw, dw, db, st, pad)
     got = host(dw.reshape(k, k, cin, c["co"]).permute(3, 2, 0, 1)).double()
     # products of 16-bit values are exact in fp32; only the fp32 summation order differs
     assert rel_err(got, wt.grad) < 2e-5
     assert rel_err(host(db).double(), b.grad) < 2e-5
-    ops.conv2d_wgrad(xd, dyd, cw, dw, None, 1, pad, accumulate=True)
+    ops.conv2d_wgrad(xd, dyd, cw, dw, None, st, pad, accumulate=True)
     assert rel_err(host(dw.reshape(k, k, cin, c["co"]).permute(3, 2, 0, 1)).double(), 2 * wt.grad) < 2e-5
 
 
