@@ -21,7 +21,7 @@ int ie_convn_launch(const ConvNParams& p, hipStream_t stream);
 // multiples of 8.
 bool ie_wgrad_mfma_applicable(int kh, int kw, int stride, int pad, int pad_mode, int cs, int cout);
 int ie_wgrad_mfma_launch(const void* x, const void* dy, int dtype, float* dw_hwio, int N, int H, int W, int cs, int cout, int cin_total, int cbase,
-                         int ksize, int pad, int in_h, int in_w, hipStream_t stream);
+                         int ksize, int pad, int stride, int in_h, int in_w, hipStream_t stream);
 bool ie_wgrad_mfma_applicable_blocks(int kh, int kw, int stride, int pad, int pad_mode, int cs, int cout);      // 9x9 / pad 0 and 4x4 / stride 2 / pad 1 as launches of the 3x3 form
 // deterministic mode (ie_core.hip): library-owned scratch of at least `bytes` for the split-K partial slabs
 extern "C" int ie_get_deterministic(void);

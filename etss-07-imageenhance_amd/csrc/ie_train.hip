@@ -699,7 +699,7 @@ static int wgrad_impl(ie_convn_desc* d, const void* const* srcs, const int* cs, 
         if constexpr (sizeof(T) == 2) {
             if (!force_fma && (ie_wgrad_mfma_applicable(d->kh, d->kw, d->stride, d->pad, d->pad_mode, cs[s], d->Cout) ||
                                ie_wgrad_mfma_applicable_blocks(d->kh, d->kw, d->stride, d->pad, d->pad_mode, cs[s], d->Cout))) {
-                rc = ie_wgrad_mfma_launch(srcs[s], dy, ie_elem<T>::dtype, dw_hwio, d->N, d->Ho, d->Wo, cs[s], d->Cout, Cin, cbase, d->kh, d->pad, d->H, d->W, st);
+                rc = ie_wgrad_mfma_launch(srcs[s], dy, ie_elem<T>::dtype, dw_hwio, d->N, d->Ho, d->Wo, cs[s], d->Cout, Cin, cbase, d->kh, d->pad, d->stride, d->H, d->W, st);
                 if (rc != IE_OK) return rc;
                 cbase += cs[s];
                 continue;

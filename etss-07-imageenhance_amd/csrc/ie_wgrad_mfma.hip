@@ -236,25 +236,26 @@ bool ie_wgrad_mfma_applicable(int kh, int kw, int stride, int pad, int pad_mode,
 // H x W: the OUTPUT (dY) size.  ksize 3: pad 1 (input H x W) or 0 (input (H + 2) x (W + 2)); ksize 1: pad 0.
 // Not in deterministic mode (one launch per block of taps, the slab reduction knows 3x3 / 1x1 only):
 //   ksize 9, pad 0 (input (H + 8) x (W + 8)): nine launches of the 3x3 form, one per 3x3 block of the 81 taps;
-//   ksize 4, stride 2, pad 1 (input in_h x in_w): four launches, one per parity sub-image of the input (4 of each launch's 9 taps are taps of the layer).
+//   stride 2 (ksize 4 pad 1; ksize 3 pad 0 / 1; input in_h x in_w): four launches, one per parity sub-image of the input (each launch's 3x3 window holds up to 4 taps of the layer).
 struct WgradGeom { int xs, xoy, xox, xH, xW, ts, toy, tox, KH, KW; };
 static int wgrad_mfma_launch_one(const void* x, const void* dy, int dtype, float* dw_hwio, int N, int H, int W, int cs, int cout, int cin_total, int cbase,
                                  int ksize, const WgradGeom& g, hipStream_t stream);
 
 bool ie_wgrad_mfma_applicable_blocks(int kh, int kw, int stride, int pad, int pad_mode, int cs, int cout) {
     const bool k9 = kh == 9 && kw == 9 && stride == 1 && pad == 0, k4 = kh == 4 && kw == 4 && stride == 2 && pad == 1 && pad_mode == IE_PAD_ZEROS;
-    return (k9 || k4) && (cs & 7) == 0 && (cout & 7) == 0 && !ie_get_deterministic();
+    const bool k3s2 = kh == 3 && kw == 3 && stride == 2 && (pad == 0 || (pad == 1 && pad_mode == IE_PAD_ZEROS));      // RelightNet's stride-2 layers (model.py:60-62)
+    return (k9 || k4 || k3s2) && (cs & 7) == 0 && (cout & 7) == 0 && !ie_get_deterministic();
 }
 
 int ie_wgrad_mfma_launch(const void* x, const void* dy, int dtype, float* dw_hwio, int N, int H, int W, int cs, int cout, int cin_total, int cbase,
-                         int ksize, int pad, int in_h, int in_w, hipStream_t stream) {
-    if (ksize == 9 || ksize == 4) {
+                         int ksize, int pad, int stride, int in_h, int in_w, hipStream_t stream) {
+    if (ksize == 9 || stride == 2) {
         if (ie_get_deterministic()) IE_FAIL(IE_ERR_UNSUPPORTED, "ie_convn_wgrad_nhwc: the blocked matrix-core forms do not run in deterministic mode");
         const int nb = ksize == 9 ? 3 : 2;
         for (int by = 0; by < nb; ++by)
             for (int bx = 0; bx < nb; ++bx) {
                 const WgradGeom g = ksize == 9 ? WgradGeom{1, 3 * by + 1, 3 * bx + 1, H + 8, W + 8, 1, 3 * by, 3 * bx, 9, 9}
-                                               : WgradGeom{2, by, bx, in_h, in_w, 2, by - 1, bx - 1, 4, 4};
+                                               : WgradGeom{2, by, bx, in_h, in_w, 2, by + pad - 2, bx + pad - 2, ksize, ksize};      // tap ky - pad = 2 a + py, a = i - 1
                 const int rc = wgrad_mfma_launch_one(x, dy, dtype, dw_hwio, N, H, W, cs, cout, cin_total, cbase, 3, g, stream);
                 if (rc != IE_OK) return rc;
             }

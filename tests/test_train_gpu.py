@@ -218,6 +218,8 @@ WGRAD16_CASES = [
     dict(cs=[32], co=32, n=2, h=36, w=70, k=4, p=1, s=2),   # Conv4x4 stride 2 (HINet's down-sampling, hinet.py:65): four launches, one per parity sub-image of the input
     dict(cs=[64], co=128, n=1, h=19, w=33, k=4, p=1, s=2),  # odd sizes
     dict(cs=[16, 8], co=16, n=1, h=4, w=6, k=4, p=1, s=2),
+    dict(cs=[64], co=64, n=2, h=38, w=71, k=3, p=0, s=2),   # Conv3x3 stride 2 behind the replicate padding (RelightNet, model.py:60-62)
+    dict(cs=[64], co=64, n=1, h=37, w=70, k=3, p=1, s=2),
 ]
 
 
