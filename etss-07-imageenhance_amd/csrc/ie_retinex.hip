@@ -12,19 +12,27 @@ inline unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }
 
 __device__ __forceinline__ float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }      // torch: d|x|/dx = sign(x), 0 at 0
 
+inline unsigned nblk_capped(size_t n) { const unsigned b = nblk(n); return b < 2048u ? b : 2048u; }      // grid-stride kernels: one loss atomic per workgroup
+
 __device__ __forceinline__ void block_add(double v, double* dst) {
-    // wave reduction, then one fp64 atomic per wave
+    // wave reduction, the four waves through LDS, then ONE fp64 atomic per workgroup (256 threads).  One atomic per wave on one address serialised in L2:
+    // 65 k of them made the L1 term of two 1080p frames a 2.3 ms kernel (its operands take 30 us to read) -- round 3 profile of the relight phase.
+    __shared__ double part[4];
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    if ((threadIdx.x & 63) == 0 && v != 0.0) atomicAdd(dst, v);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double t = (part[0] + part[1]) + (part[2] + part[3]);
+        if (t != 0.0) atomicAdd(dst, t);
+    }
 }
 
 // loss += w * mean|R * I - T| over N*H*W*3;  dR += w sign(.) I / numel,  dI += w sum_c sign(.) R_c / numel       (model.py:216-221)
 // R / dR have a pixel stride of rs floats, I / dI of is (3 and 1 for separate tensors, 4 and 4 for DecomNet's (R, L) output)
 __global__ void recon_kernel(const float* __restrict__ R, int rs, const float* __restrict__ I, int is, const float* __restrict__ T,
                              float w_over_numel, float* __restrict__ dR, float* __restrict__ dI, double* __restrict__ loss, size_t npx) {
-    const size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     double acc = 0.0;
-    if (p < npx) {
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < npx; p += (size_t)gridDim.x * blockDim.x) {
         const float i = I[is * p];
         float gi = 0.f;
 #pragma unroll
@@ -44,12 +52,11 @@ __global__ void recon_kernel(const float* __restrict__ R, int rs, const float* _
 // A, B, dA: C channels of pixels with a stride of st floats
 __global__ void l1_detached_kernel(const float* __restrict__ A, const float* __restrict__ B, int st, int C, float w_over_numel, float* __restrict__ dA,
                                    double* __restrict__ loss, size_t n) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     double acc = 0.0;
-    if (i < n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const size_t o = (i / C) * st + (i % C);
         const float d = A[o] - B[o];
-        acc = fabsf(d);
+        acc += fabsf(d);
         if (dA) dA[o] += sgn(d) * w_over_numel;
     }
     block_add(acc * (double)w_over_numel, loss);
@@ -94,16 +101,17 @@ __global__ void smooth_term_kernel(const float* __restrict__ I, const float* __r
                                    float* __restrict__ wy, float* __restrict__ qx, float* __restrict__ qy, double* __restrict__ loss, float w_over_numel,
                                    int H, int W) {
     const int n = blockIdx.z;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
     double acc = 0.0;
-    if (j <= W) {
+    if (j <= W)
+    for (int i = blockIdx.y; i <= H; i += gridDim.y) {          // rows strided over gridDim.y workgroups: one loss atomic per workgroup, not per row
         const float* In = I + (size_t)n * H * W;
         const size_t base = (size_t)n * (H + 1) * (W + 1), o = base + (size_t)i * (W + 1) + j;
         const float gix = fabsf(at(In, H, W, i, j) - at(In, H, W, i, j - 1)), giy = fabsf(at(In, H, W, i, j) - at(In, H, W, i - 1, j));
         const float ex = expf(-10.f * avg9(hx + base, H + 1, W + 1, i, j)), ey = expf(-10.f * avg9(hy + base, H + 1, W + 1, i, j));
         wx[o] = ex; wy[o] = ey;
         qx[o] = -10.f * gix * ex; qy[o] = -10.f * giy * ey;
-        acc = (double)gix * ex + (double)giy * ey;
+        acc += (double)gix * ex + (double)giy * ey;
     }
     block_add(acc * (double)w_over_numel, loss);
 }
@@ -230,7 +238,7 @@ IE_EXPORT int ie_retinex_recon_f32(const float* R, int r_stride, const float* I,
                                    double* loss, int N, int H, int W, void* stream) {
     if (!R || !I || !T || !loss || N <= 0 || H <= 0 || W <= 0 || r_stride < 3 || i_stride < 1) IE_FAIL(IE_ERR_INVALID, "ie_retinex_recon_f32: bad args");
     const size_t npx = (size_t)N * H * W;
-    hipLaunchKernelGGL(recon_kernel, dim3(nblk(npx)), dim3(256), 0, (hipStream_t)stream, R, r_stride, I, i_stride, T, weight / (float)(3.0 * (double)npx),
+    hipLaunchKernelGGL(recon_kernel, dim3(nblk_capped(npx)), dim3(256), 0, (hipStream_t)stream, R, r_stride, I, i_stride, T, weight / (float)(3.0 * (double)npx),
                        dR, dI, loss, npx);
     IE_LAUNCH_CHECK();
     return IE_OK;
@@ -239,7 +247,7 @@ IE_EXPORT int ie_retinex_recon_f32(const float* R, int r_stride, const float* I,
 IE_EXPORT int ie_l1_detached_f32(const float* A, const float* B, int stride, int C, float weight, float* dA, double* loss, size_t npx, void* stream) {
     if (!A || !B || !loss || npx == 0 || C <= 0 || stride < C) IE_FAIL(IE_ERR_INVALID, "ie_l1_detached_f32: bad args");
     const size_t n = npx * C;
-    hipLaunchKernelGGL(l1_detached_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, A, B, stride, C, weight / (float)n, dA, loss, n);
+    hipLaunchKernelGGL(l1_detached_kernel, dim3(nblk_capped(n)), dim3(256), 0, (hipStream_t)stream, A, B, stride, C, weight / (float)n, dA, loss, n);
     IE_LAUNCH_CHECK();
     return IE_OK;
 }
@@ -258,7 +266,8 @@ IE_EXPORT int ie_retinex_smooth_f32(const float* I, int i_stride, const float* R
     hipLaunchKernelGGL(gray_kernel, dim3(nblk(npx)), dim3(256), 0, st, R, r_stride, I, i_stride, g, ic, npx);
     const dim3 gg((unsigned)((W + 1 + 255) / 256), (unsigned)(H + 1), (unsigned)N), gi((unsigned)((W + 255) / 256), (unsigned)H, (unsigned)N);
     hipLaunchKernelGGL(smooth_h_kernel, gg, dim3(256), 0, st, g, hx, hy, H, W);
-    hipLaunchKernelGGL(smooth_term_kernel, gg, dim3(256), 0, st, ic, hx, hy, wx, wy, qx, qy, loss, wn, H, W);
+    const dim3 gt(gg.x, (unsigned)(H + 1 < 128 ? H + 1 : 128), gg.z);
+    hipLaunchKernelGGL(smooth_term_kernel, gt, dim3(256), 0, st, ic, hx, hy, wx, wy, qx, qy, loss, wn, H, W);
     if (dI || dR) hipLaunchKernelGGL(smooth_grad_kernel, gi, dim3(256), 0, st, ic, g, wx, wy, qx, qy, dI, i_stride, dR, r_stride, wn, H, W);
     IE_LAUNCH_CHECK();
     return IE_OK;

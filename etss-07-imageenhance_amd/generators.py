@@ -1627,7 +1627,8 @@ class RetinexNet(_GraphModel):
             raise ValueError(f"`image` {tuple(low.shape)} and `ref_image` {tuple(high.shape)} must have one shape.")
         n, _, h, w = low.shape
         decom_phase = self.train_phase == "decom"
-        tape_d, tape_r = (tape, T.Tape()) if decom_phase else (T.Tape(), tape)        # the other net runs on a tape that is never played back
+        idle = T.Tape(recording=False)                                                  # the other net runs forward only: its tape keeps no closures
+        tape_d, tape_r = (tape, idle) if decom_phase else (idle, tape)
         store.grads.zero_()                                                             # the idle net's gradients must read zero
 
         def conv(tp, name, srcs, pad, act="none", stride=1, cout_pad=None):

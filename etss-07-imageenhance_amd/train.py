@@ -25,8 +25,12 @@ CL = torch.channels_last
 class Tape:
     """Reverse-mode recorder.  Gradient buffers are created on first use; a second producer accumulates."""
 
-    def __init__(self):
-        self._fns, self._g, self._nograd = [], {}, set()
+    def __init__(self, recording=True):
+        # recording=False: a forward-only tape (a sub-network that runs inside a training forward but is not trained in this phase).  Its backward closures
+        # are dropped on the spot: kept, they would reference the tape that holds them -- a cycle nothing ever breaks, because backward() is never called on
+        # such a tape -- and every activation of that sub-network would live until Python's cycle collector happens to run (RetinexNet, round 3: +12 GB of
+        # reserved memory every second step, 0.4 s segment allocations, 152 GB after 18 steps).
+        self._fns, self._g, self._nograd, self._recording = [], {}, set(), bool(recording)
 
     def no_grad(self, t):
         self._nograd.add(id(t))
@@ -59,7 +63,8 @@ class Tape:
         self._g.pop(id(t), None)
 
     def record(self, fn):
-        self._fns.append(fn)
+        if self._recording:
+            self._fns.append(fn)
 
     def mark_grad_bucket(self, offset: int):
         """Forward-order mark: every parameter used AFTER this point lives at flat-buffer offsets >= ``offset``.  When the backward pass
@@ -75,6 +80,7 @@ class Tape:
         for fn in reversed(self._fns):
             fn()
         self._fns = []
+        self._g, self._nograd = {}, set()          # gradient buffers and their tensors: nothing of a finished step stays reachable through the tape
 
 
 class ParamStore:

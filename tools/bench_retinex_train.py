@@ -20,12 +20,12 @@ for dt in ("f32", "bf16", "f16"):
         for _ in range(3):
             tr.training_step({"image": low, "ref_image": high})
         ts = []          # median of individually synchronised steps: an allocator hiccup (hundreds of ms, once) must not pass for the step time
-        for _ in range(7):
+        for _ in range(9):
             torch.cuda.synchronize(); t0 = time.perf_counter()
             out = tr.training_step({"image": low, "ref_image": high})
             torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
         d = sorted(ts)[len(ts) // 2]
         print(json.dumps({"model": "retinexnet", "phase": phase, "graph": dt, "frames": n, "ms_per_step": round(d * 1e3, 1), "frames_per_s": round(n / d, 2),
-                          "loss": round(float(out["loss"]), 5), "ms_min_max": [round(min(ts) * 1e3, 1), round(max(ts) * 1e3, 1)]}), flush=True)
+                          "loss": round(float(out["loss"]), 5), "ms_steps": [round(t * 1e3, 1) for t in ts]}), flush=True)
         del tr, model
         torch.cuda.empty_cache()
