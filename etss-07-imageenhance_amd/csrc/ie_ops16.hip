@@ -217,6 +217,21 @@ __global__ void cast_kernel(const S* __restrict__ src, D* __restrict__ dst, int 
     dst[i] = c < Cs ? (D)(float)src[px * Cs + c] : (D)0.f;
 }
 
+// the same into a 16-bit tensor whose channel count is a multiple of 8 (the RGB image carried as 8 / 16 channels): a thread writes one 16-byte group of 8 channels
+// (the element-wise form above: one 2-byte store and a 64-bit division per element -- 549 us for the 8 x 1080p input of a U-Net-64 training step)
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void cast_pad8_kernel(const S* __restrict__ src, D* __restrict__ dst, int Cs, int g_shift, size_t groups) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= groups) return;
+    const size_t px = i >> g_shift;
+    const int c0 = (int)(i - (px << g_shift)) * 8;
+    const S* sp = src + px * Cs + c0;
+    float f[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] = c0 + k < Cs ? (float)sp[k] : 0.f;
+    st8(dst + i * 8, pack8<D>(f));
+}
+
 // torch.cat(srcs, dim=1) of up to four fp32 NHWC tensors, converted to D and zero-padded to Cd channels in one pass (a thread = one output element)
 struct CatSrcs { const float* p[4]; int c[4]; int n; };
 template <typename D>
@@ -482,6 +497,13 @@ static int cast_from(const S* src, void* dst, int ddt, int Cs, int Cd, size_t to
         case IE_BF16: hipLaunchKernelGGL((cast8_kernel<S, __bf16>), dim3(nblk(t8)), dim3(256), 0, st, src, (__bf16*)dst, t8); break;
         default: IE_FAIL(IE_ERR_INVALID, "ie_cast_nhwc: bad destination dtype");
         }
+        IE_LAUNCH_CHECK();
+        return IE_OK;
+    }
+    if ((ddt == IE_F16 || ddt == IE_BF16) && (Cd & 7) == 0 && c8_shift_of(Cd / 8) >= 0) {
+        const size_t groups = total / 8;
+        if (ddt == IE_F16) hipLaunchKernelGGL((cast_pad8_kernel<S, _Float16>), dim3(nblk(groups)), dim3(256), 0, st, src, (_Float16*)dst, Cs, c8_shift_of(Cd / 8), groups);
+        else hipLaunchKernelGGL((cast_pad8_kernel<S, __bf16>), dim3(nblk(groups)), dim3(256), 0, st, src, (__bf16*)dst, Cs, c8_shift_of(Cd / 8), groups);
         IE_LAUNCH_CHECK();
         return IE_OK;
     }
