@@ -49,6 +49,11 @@ bool ie_sconv3_thin3_applicable(int nsrc, const int* cs, int Cout, int kh, int k
                                 bool out_f32, bool shuffle, int W);
 int ie_sconv3_thin3_launch(const void* const* srcs, int nsrc, const int* src_h, const int* src_w, const void* wpk, const float* bias, float* dst, int dtype, int N,
                            int H, int W, int Cout, int act, int pad_mode, hipStream_t st);
+// 1x1 convolution as a streaming GEMM over 128-pixel rows (ie_conv1x1.hip)
+bool ie_conv1x1_applicable(int nsrc, const int* cs, int Cout, int kh, int kw, int stride, int pad, int act, bool residual, bool clamp, bool out_f32,
+                           bool pixel_shuffle, bool any_up);
+int ie_conv1x1_launch(const void* const* srcs, const int* cs, int nsrc, const void* packed_w, const float* bias, void* dst, int dtype, long long npx, int Cout, int nf,
+                      int cout_tiles, int act, float slope, hipStream_t st);
 // two stacked Conv3x3(64 -> 64) + bias + ReLU layers, the intermediate in LDS only (ie_conv_pair.hip)
 int ie_sconv3x2_launch(const void* src, const void* w_a, const float* bias_a, const void* w_b, const float* bias_b, void* dst, int dtype, int N, int H, int W,
                        int pad_mode, int cout_b, int act_b, void* dst16, int dst16_c, void* pool_dst, hipStream_t st);

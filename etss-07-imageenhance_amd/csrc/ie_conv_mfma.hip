@@ -1124,6 +1124,17 @@ static int mconv_impl(ie_mconv_desc* d, const void* const* srcs, const int* chan
         return ie_sconv3_thin3_launch(srcs, d->nsrc, d->src_h, d->src_w, packed_w, bias, (float*)dst, d->in_dtype, d->N, d->H, d->W, d->Cout, d->act, d->pad_mode,
                                       (hipStream_t)stream);
     }
+    {
+        bool up = false;
+        for (int s = 0; s < d->nsrc; ++s) up = up || (d->src_h[s] > 0 && d->src_h[s] != d->H) || (d->src_w[s] > 0 && d->src_w[s] != d->W);
+        if (!pl.thin && ie_conv1x1_applicable(d->nsrc, channels, d->Cout, d->kh, d->kw, d->stride, d->pad, d->act, residual != nullptr, d->clamp != 0,
+                                              d->out_dtype == IE_F32, d->pixel_shuffle != 0, up)) {
+            // 1x1 layers: the streaming GEMM over 128-pixel rows (ie_conv1x1.hip)
+            d->Ho = d->H; d->Wo = d->W;
+            return ie_conv1x1_launch(srcs, channels, d->nsrc, packed_w, bias, dst, d->in_dtype, (long long)d->N * d->H * d->W, d->Cout, pl.nf, pl.cout_tiles, d->act,
+                                     d->slope, (hipStream_t)stream);
+        }
+    }
     MConvParams p;
     memset(&p, 0, sizeof(p));
     bool any_up = false;

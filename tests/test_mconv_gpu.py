@@ -543,3 +543,28 @@ def test_nearest_upsampled_sources(case, dt):
     out = ops.mconv2d([x.cuda().contiguous(memory_format=CL) for x in xs], mw, pad=p, pad_mode=case["mode"], act=case["act"])
     assert tuple(out.shape) == tuple(ref.shape)
     assert rel_err(out.float().cpu(), ref) <= (1.5e-3 if dt == "f16" else 1e-2)
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+@pytest.mark.parametrize("act", ["none", "relu", "lrelu"])
+@pytest.mark.parametrize("cs,co", [([64], 64), ([192], 64), ([24, 40], 48), ([128, 64, 16], 272), ([16], 16), ([72], 32), ([512], 128)], ids=lambda v: str(v).replace(" ", ""))
+@pytest.mark.parametrize("shape", [(2, 37, 150), (1, 5, 7), (1, 128, 129), (3, 16, 8)], ids=lambda s: "x".join(map(str, s)))
+def test_1x1_conv_as_streaming_gemm(shape, cs, co, act, dt):
+    """1x1 layers (HINet's identity / csff convs hinet.py:60-83, LLUnet++'s skip convs llunetpp.py:55-70, RelightNet's fusion conv retinexnet/model.py:66) run on
+    ie_conv1x1.hip: 128-pixel rows of the [pixel][Cin] matrix through an LDS double buffer.  Against torch fp32 on the same 16-bit operands; ragged last
+    workgroups, short last K chunks (24, 40, 16, 72 channels), several cout tiles, all three wave layouts."""
+    tdt = ops.TORCH_DT[dt]
+    n, h, w = shape
+    g = torch.Generator().manual_seed(53)
+    xs = [torch.randn(n, c, h, w, generator=g).to(tdt).cuda().contiguous(memory_format=CL) for c in cs]
+    cin = sum(cs)
+    wt = (torch.randn(co, cin, 1, 1, generator=g) / cin ** 0.5).to(tdt).float()
+    b = torch.randn(co, generator=g) * 0.3
+    mw = ops.MConvWeights(wt, b, cs, tdt, "cuda")
+    kw = dict(act=act, slope=0.2) if act == "lrelu" else dict(act=act)
+    y = ops.mconv2d(xs, mw, pad=0, **kw)
+    assert tuple(y.shape) == (n, co, h, w) and y.dtype == tdt and y.is_contiguous(memory_format=CL)
+    ref = F.conv2d(torch.cat([x.float().cpu() for x in xs], 1), wt, b)
+    ref = {"none": lambda t: t, "relu": F.relu, "lrelu": lambda t: F.leaky_relu(t, 0.2)}[act](ref)
+    assert rel_err(y.float().cpu(), ref) <= (2e-3 if dt == "f16" else 1.2e-2)
+
