@@ -2,7 +2,7 @@
 // of a dense [pixel][Cin] matrix, so a workgroup takes 128 consecutive pixels, double-buffers their K chunks (32 channels = 64 B per pixel) through LDS with
 // LDS-DMA and contracts them with weight fragments read straight from the packed image (L2-resident).  Reference call sites: HINet's `identity` / `csff` convs
 // (hinet.py:60-83), LLUnet++'s skip convs (llunetpp.py:55-70), RelightNet's `net2_fusion` (retinexnet/model.py:66): every one of them moves more bytes than the
-// matrix cores need time for (Cin Cout / (Cin + Cout) FLOP per byte, < 312 up to 512 -> 512), so the kernel is built for occupancy -- 16 KB of LDS and ~48
+// matrix cores need time for (Cin Cout / (Cin + Cout) FLOP per byte, < 312 up to 512 -> 512), so the kernel is built for occupancy -- 24 KB of LDS and <= 80
 // VGPRs per workgroup -- not for MFMA density.  (The tiled LDS-weights kernel these layers ran on stages a 16 x 32 pixel tile with its weights, single
 // buffered: 2.1 TB/s.)
 //
@@ -38,7 +38,7 @@ template <int ACT> __device__ __forceinline__ float c1_act(float v, float slope)
 // NF = 16-cout fragments per cout tile (the packing's): the four waves are NF fragments x (4 / NF) groups of 8 NF / 4 pixel tiles
 template <typename T, int NF, int ACT>
 __global__ __launch_bounds__(256) void conv1x1_kernel(C1Params p) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * C1_BUF];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * C1_BUF];          // three buffers: two chunks in flight behind the one being contracted
     typedef __attribute__((address_space(3))) void* lds_ptr;
     constexpr int RW = 4 / NF, NTW = 8 / RW;          // pixel-tile groups, pixel tiles (of 16) per wave
     const int tid = threadIdx.x, lane = tid & 63;
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(C1Params p) {
         const unsigned cs_b = info & 0xffffu, c0_b = info >> 16;
         const char* base = (const char*)p.cd_base[ch] + (size_t)px0 * cs_b;
         const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)((unsigned)live * cs_b), 0x00020000);
-        unsigned char* buf = lds + (ch & 1) * C1_BUF;
+        unsigned char* buf = lds + (ch % 3) * C1_BUF;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const unsigned piece = (unsigned)((lane & 3) ^ ((dpx[j] >> 1) & 3));
@@ -75,14 +75,19 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(C1Params p) {
     for (int i = 0; i < NTW; ++i) acc[i] = ie_f32x4{0.f, 0.f, 0.f, 0.f};
     const int rd0 = (rw * NTW * 16 + l16) * 64 + ((kq ^ ((l16 >> 1) & 3)) << 4);       // tile i of the wave: + i * 1024
 
+    // vector-memory order per chunk: [DMA, DMA, weight load].  At the top of chunk ch the three operations of chunk ch + 1 (issued one iteration ago) may stay
+    // in flight; chunk ch + 2 is issued behind the barrier, into the buffer chunk ch - 1 was read from.
     issue(0);
-    ie_u32x4 wn = load_w(0);
+    ie_u32x4 wn = load_w(0), wn2 = wn;
+    if (p.nchunks > 1) { issue(1); wn2 = load_w(1); }
     for (int ch = 0; ch < p.nchunks; ++ch) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's part of chunk ch (issued a whole chunk ago) and its weights
-        __syncthreads();                                           // everyone's part has landed; everyone is done reading the other buffer
+        if (ch + 1 < p.nchunks) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                           // everyone's part of chunk ch has landed; everyone is done reading chunk ch - 1's buffer
         const ie_u32x4 w = wn;
-        if (ch + 1 < p.nchunks) { issue(ch + 1); wn = load_w(ch + 1); }
-        const unsigned char* buf = lds + (ch & 1) * C1_BUF + rd0;
+        wn = wn2;
+        if (ch + 2 < p.nchunks) { issue(ch + 2); wn2 = load_w(ch + 2); }
+        const unsigned char* buf = lds + (ch % 3) * C1_BUF + rd0;
 #pragma unroll
         for (int i = 0; i < NTW; ++i) {
             const ie_u32x4 b = *(const ie_u32x4*)(buf + i * 1024);
