@@ -223,7 +223,7 @@ def run_generator_workload(args, ctx):
     try:      # HBM bytes per launch of that kernel from the committed PMC passes (profiles/traffic.json "workloads"), when it is the kernel they were taken on
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             tw = json.load(f).get("workloads", {}).get(args.workload)
-        if tw and roofline.get("kernel") and tw["kernel_contains"] in roofline["kernel"] and wl["batch"] == 32:
+        if tw and roofline.get("kernel") and tw["kernel_contains"] in roofline["kernel"] and wl["batch"] == tw.get("batch", 32):
             roofline.update({"traffic": tw["traffic"], "traffic_source": tw["source"], "mfma_busy_frac_pmc": tw.get("mfma_busy_frac"), "clock_GHz_pmc": tw.get("clock_GHz")})
     except Exception:       # noqa: BLE001
         pass
