@@ -223,7 +223,7 @@ def run_generator_workload(args, ctx):
     try:      # HBM bytes per launch of that kernel from the committed PMC passes (profiles/traffic.json "workloads"), when it is the kernel they were taken on
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             tw = json.load(f).get("workloads", {}).get(args.workload)
-        if tw and roofline.get("kernel") and tw["kernel_contains"] in roofline["kernel"] and wl["batch"] == tw.get("batch", 32):
+        if tw and roofline.get("kernel") and tw["kernel_contains"] in roofline["kernel"] and n == tw.get("batch", 32) and (H, W) == (1080, 1920):
             roofline.update({"traffic": tw["traffic"], "traffic_source": tw["source"], "mfma_busy_frac_pmc": tw.get("mfma_busy_frac"), "clock_GHz_pmc": tw.get("clock_GHz")})
     except Exception:       # noqa: BLE001
         pass
@@ -433,6 +433,10 @@ def main():
             try:
                 tj = json.load(open(tpath))
                 traffic, tsrc = tj.get(kname), tj.get("_source")
+                ref_px = tj.get("_px_per_launch", 16 * 1080 * 1920)         # the PMC passes were taken on 16-frame 1080p launches
+                if traffic is not None and int(px_per_launch) != ref_px:    # another launch size: scale by pixels and say so
+                    traffic = int(traffic * px_per_launch / ref_px)
+                    tsrc = f"{tsrc}; scaled by pixels per launch ({int(px_per_launch)} / {ref_px})"
             except Exception:
                 traffic = None
         ach_tflops = flops / (avg_ms * 1e-3) / 1e12

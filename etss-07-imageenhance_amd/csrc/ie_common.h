@@ -15,6 +15,9 @@ void ie_set_error(const char* fmt, ...);
     ie_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
     return IE_ERR_HIP; } } while (0)
 #define IE_LAUNCH_CHECK() IE_HIP_CHECK(hipGetLastError())
+// Raise a kernel's dynamic-LDS limit to `bytes` on the CURRENT device (once per (device, function); ie_core.hip).  Returns IE_OK or a status.
+int ie_grant_lds(const void* fn, int bytes);
+#define IE_GRANT_LDS(fn, bytes) do { int s__ = ie_grant_lds((const void*)(fn), (int)(bytes)); if (s__ != IE_OK) return s__; } while (0)
 
 static inline size_t ie_dtype_size(int dt) {
     switch (dt) { case IE_F32: return 4; case IE_F16: case IE_BF16: return 2; case IE_U8: return 1; default: return 0; }

@@ -121,7 +121,7 @@ __device__ __forceinline__ void mconv_epilogue(const MConvParams& p, ie_f32x4 (&
                 else
 #pragma unroll
                     for (int j = 0; j < 4; ++j) if (co + j < p.Cout) dp[j] = v[f][j];
-            } else {
+    } else {
                 T* dp = (T*)p.dst + o;
                 if (full) *(ie_u32x2*)dp = ie_u32x2{ie_pack2<T>(v[f][0], v[f][1]), ie_pack2<T>(v[f][2], v[f][3])};
                 else
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void mconv_kernel(MConvParams p) {
                         __builtin_amdgcn_sched_barrier(0);      // keep the fragment reads of later rows from being hoisted (VGPR budget)
                     }
                 }
-            } else {
+    } else {
                 const int tap0 = st * p.taps_stage;
                 for (int t = 0; t < p.taps_stage; ++t) {
                     const int tap = tap0 + t;
@@ -625,7 +625,7 @@ __device__ __forceinline__ void mconv3_epilogue(const MConvParams& p, ie_f32x4 (
                 const t4 r4 = *(const t4*)rp;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] += (float)r4[j];
-            } else {
+    } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) if (co + j < p.Cout) v[j] += (float)rp[j];
             }
@@ -1182,7 +1182,6 @@ static int mconv_impl(ie_mconv_desc* d, const void* const* srcs, const int* chan
     static const int use_v1_env = getenv("IE_MCONV_V1") ? atoi(getenv("IE_MCONV_V1")) : 0;     // A/B switch: single-buffered LDS-weights kernel
     const int use_v1 = use_v1_env || any_up;      // nearest-up-sampled sources: the strip kernel (above) or this one fold them into their addressing
     size_t lds_bytes = lds;
-    int slot;
     int th3 = TH, wgs_per_cu = 2;
     if (pl.thin) {
         switch (pl.nf) {
@@ -1192,7 +1191,6 @@ static int mconv_impl(ie_mconv_desc* d, const void* const* srcs, const int* chan
         }
         const int twh = TW + 4 * pl.kxg - 1, thh = TH + d->kh - 1;
         lds_bytes = (size_t)((twh * thh + 63) / 64) * 1024 + pl.stage_bytes;
-        slot = 20 + (h ? 0 : 3) + (pl.nf == 1 ? 0 : (pl.nf == 2 ? 1 : 2));
     } else if (k3 && !use_v1) {
         // 64-cout tiles (one cout fragment per wave, 16-row tile = 128 accumulator VGPRs) leave room for only two workgroups per
         // CU; an 8-row tile (64 accumulator VGPRs, 2 x 22 KB of LDS) runs three and overlaps the per-tile serial work better
@@ -1218,8 +1216,6 @@ static int mconv_impl(ie_mconv_desc* d, const void* const* srcs, const int* chan
         }
         p.tiles_y = ie_cdiv(p.Ho, th3);
         lds_bytes = 2 * (size_t)((((th3 + 2) * (TW + 2) + 15) / 16 + 3) / 4 * 4) * 1024;
-        slot = 12 + (h ? 0 : 3) + (pl.nf == 1 ? 0 : (pl.nf == 2 ? 1 : 2));
-        if (th3 == 8) slot = 18 + (h ? 0 : 1);
     } else {
         switch (pl.nf * 2 + (k3 ? 1 : 0)) {
         case 2: fn = h ? mconv_kernel<_Float16, 1, false> : mconv_kernel<__bf16, 1, false>; break;
@@ -1229,14 +1225,9 @@ static int mconv_impl(ie_mconv_desc* d, const void* const* srcs, const int* chan
         case 8: fn = h ? mconv_kernel<_Float16, 4, false> : mconv_kernel<__bf16, 4, false>; break;
         default: fn = h ? mconv_kernel<_Float16, 4, true> : mconv_kernel<__bf16, 4, true>; break;
         }
-        slot = (h ? 0 : 6) + (pl.nf == 1 ? 0 : (pl.nf == 2 ? 1 : 2)) * 2 + (k3 ? 1 : 0);
     }
     if (lds_bytes > 64 * 1024) {       // opt in to > 64 KB of dynamic LDS once per kernel
-        static bool granted[26] = {false};
-        if (!granted[slot]) {
-            IE_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            granted[slot] = true;
-        }
+        IE_GRANT_LDS(fn, 160 * 1024);
     }
     if (k3 && !use_v1 && !pl.thin && pool_dst) {
         // the 3x3 register-weights kernel pools in its epilogue (ReLU layer, whole 16-cout fragments, 16-bit output, no residual / clamp / shuffle)
@@ -1299,12 +1290,7 @@ IE_EXPORT int ie_dsconv_nhwc(ie_mconv_desc* d, const void* const* srcs, const in
     case 2: fn = h ? dsconv_kernel<_Float16, 2> : dsconv_kernel<__bf16, 2>; break;
     default: fn = h ? dsconv_kernel<_Float16, 4> : dsconv_kernel<__bf16, 4>; break;
     }
-    static bool granted[6] = {false};
-    const int slot = (h ? 0 : 3) + (pl.nf == 1 ? 0 : (pl.nf == 2 ? 1 : 2));
-    if (!granted[slot]) {
-        IE_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        granted[slot] = true;
-    }
+    IE_GRANT_LDS(fn, 160 * 1024);
     hipLaunchKernelGGL(fn, dim3(p.total_blocks), dim3(256), lds, (hipStream_t)stream, dp);
     IE_LAUNCH_CHECK();
     return IE_OK;

@@ -463,12 +463,7 @@ int ie_sconv3x2_launch(const void* src, const void* w_a, const float* bias_a, co
                               sconv3x2_f16_c32_c64_c64_relu_pool, sconv3x2_bf16_c32_c64_c64_relu_pool};
     const Fn fn = fns[fi];
     const int lds = pool ? LDS_POOL_B : LDS_B;
-    static bool granted[6] = {false, false, false, false, false, false};
-    if (!granted[fi]) {
-        hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) IE_FAIL(IE_ERR_HIP, "hipFuncSetAttribute(lds=%d): %s", lds, hipGetErrorString(e));
-        granted[fi] = true;
-    }
+    IE_GRANT_LDS(fn, lds);
     void* args[] = {(void*)&p};
     IE_HIP_CHECK(hipLaunchKernel((const void*)fn, dim3((unsigned)blocks), dim3(512), args, lds, st));
     return IE_OK;

@@ -708,13 +708,7 @@ int ie_sconv3_first_launch(const void* img8, const void* w1, const float* b1, co
     const size_t lds = (size_t)4 * SRC_ROW_B * nch + 3 * (size_t)TW * (C * 2) + (size_t)6 * 3072;       // NR = 4 (PF = 3), three parked rows, NRI = PF + 3 image rows
     SConvFn fn = C == 32 ? (dtype == IE_F16 ? sconv3_f16_c32_o32_relu_pool_first : sconv3_bf16_c32_o32_relu_pool_first)
                          : (dtype == IE_F16 ? sconv3_f16_c64_o64_relu_pool_first : sconv3_bf16_c64_o64_relu_pool_first);
-    static SConvFn granted[4] = {nullptr};
-    bool done = false;
-    for (auto f : granted) done = done || f == fn;
-    if (!done) {
-        IE_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        for (auto& f : granted) if (!f) { f = fn; break; }
-    }
+    IE_GRANT_LDS(fn, lds);
     hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(ncf * 128), lds, st, p);
     IE_LAUNCH_CHECK();
     return IE_OK;
@@ -772,13 +766,7 @@ int ie_sconv3_launch(const void* const* srcs, const int* cs, int nsrc, const voi
     if (!fn) IE_FAIL(IE_ERR_UNSUPPORTED, "ie_sconv3: the fused max-pool / head forms cover Cin <= 64 (ask ie_sconv3_fused_ok)");
     static const int s2skip = getenv("IE_SCONV_S2SKIP") ? atoi(getenv("IE_SCONV_S2SKIP")) : 1;      // A/B: 0 = every row computed
     if (stride == 2 && s2skip && nch == 2 && ncf == 4 && act == IE_ACT_RELU) fn = dtype == IE_F16 ? sconv3_f16_c64_o64_relu_s2 : sconv3_bf16_c64_o64_relu_s2;
-    static SConvFn granted[64] = {nullptr};
-    bool done = false;
-    for (auto f : granted) done = done || f == fn;
-    if (!done) {
-        IE_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        for (auto& f : granted) if (!f) { f = fn; break; }
-    }
+    IE_GRANT_LDS(fn, lds);
     hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(ncf * 128), lds, st, p);
     IE_LAUNCH_CHECK();
     return IE_OK;

@@ -253,12 +253,7 @@ int ie_sconv3_thin3_launch(const void* const* srcs, int nsrc, const int* src_h, 
     typedef void (*Fn)(Thin3Params);
     const int fi = dtype == IE_F16 ? 0 : 1;
     static const Fn fns[2] = {sconv3_thin3_f16, sconv3_thin3_bf16};
-    static bool granted[2] = {false, false};
-    if (!granted[fi]) {
-        hipError_t e = hipFuncSetAttribute((const void*)fns[fi], hipFuncAttributeMaxDynamicSharedMemorySize, OFF_PART + 2 * (MAXS * TW * 4 * 4 + 256));
-        if (e != hipSuccess) IE_FAIL(IE_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-        granted[fi] = true;
-    }
+    IE_GRANT_LDS(fns[fi], OFF_PART + 2 * (MAXS * TW * 4 * 4 + 256));
     void* args[] = {(void*)&p};
     IE_HIP_CHECK(hipLaunchKernel((const void*)fns[fi], dim3((unsigned)blocks), dim3(384), args, lds, st));
     return IE_OK;

@@ -463,12 +463,7 @@ IE_EXPORT int ie_unet_up_head_nhwc(const void* skip, const void* up, int up_h, i
     typedef void (*Fn)(UpdcParams);
     const int fi = (dtype == IE_F16 ? 0 : 1) + ((up_h != H || up_w != W) ? 2 : 0);
     static const Fn fns[4] = {unet_updc32_head_f16, unet_updc32_head_bf16, unet_updc32_bilinear_head_f16, unet_updc32_bilinear_head_bf16};
-    static bool granted[4] = {false, false, false, false};
-    if (!granted[fi]) {
-        hipError_t e = hipFuncSetAttribute((const void*)fns[fi], hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
-        if (e != hipSuccess) IE_FAIL(IE_ERR_HIP, "hipFuncSetAttribute(lds=%d): %s", LDS_B, hipGetErrorString(e));
-        granted[fi] = true;
-    }
+    IE_GRANT_LDS(fns[fi], LDS_B);
     void* args[] = {(void*)&p};
     IE_HIP_CHECK(hipLaunchKernel((const void*)fns[fi], dim3((unsigned)blocks), dim3(512), args, LDS_B, (hipStream_t)stream));
     return IE_OK;

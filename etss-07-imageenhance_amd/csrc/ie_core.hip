@@ -3,6 +3,7 @@
 // the layout allows, bounded by HBM bandwidth.
 #include "ie_common.h"
 #include <string.h>
+#include <mutex>
 
 // ---- error plumbing ---------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -39,6 +40,28 @@ int ie_det_workspace(size_t bytes, void** out) {
         g_det_bytes[dev] = want;
     }
     *out = g_det_ws[dev];
+    return IE_OK;
+}
+
+// ---- dynamic-LDS grants --------------------------------------------------------------------
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-(device, function) attribute: a flag per function would skip the grant on the second
+// GPU of a process and that launch fails with "invalid value".  One table for the whole library, keyed by the current device ordinal.
+int ie_grant_lds(const void* fn, int bytes) {
+    struct Grant { const void* fn; int dev; int bytes; };
+    static Grant table[512];
+    static int count = 0;
+    static std::mutex mu;
+    int dev = 0;
+    IE_HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    Grant* slot = nullptr;
+    for (int i = 0; i < count; ++i)
+        if (table[i].fn == fn && table[i].dev == dev) { slot = &table[i]; break; }
+    if (slot && slot->bytes >= bytes) return IE_OK;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) IE_FAIL(IE_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize = %d) on device %d: %s", bytes, dev, hipGetErrorString(e));
+    if (slot) slot->bytes = bytes;
+    else if (count < 512) table[count++] = Grant{fn, dev, bytes};      // a full table only means the attribute is set again next time
     return IE_OK;
 }
 

@@ -1425,15 +1425,7 @@ static int launch_fused_t(FusedFn fn, const ZdceFusedLaunch& a, hipStream_t st) 
     if (blocks <= 0 || blocks > 0x7fffffffLL) IE_FAIL(IE_ERR_INVALID, "zdce fused: bad grid %lld", blocks);
     if ((size_t)a.H * a.W * 32 * 2 >= 0x7fffffffull) IE_FAIL(IE_ERR_UNSUPPORTED, "zdce fused: frame too large for 31-bit offsets");
     const size_t lds = FusedGeom<KIND>::LDS_B;
-    // the dynamic-LDS limit is a per-function attribute: set it once per kernel
-    static FusedFn attr_done[24] = {nullptr};
-    bool done = false;
-    for (FusedFn f : attr_done) done = done || (f == fn);
-    if (!done) {
-        hipError_t e = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) IE_FAIL(IE_ERR_HIP, "hipFuncSetAttribute(lds=%zu): %s", lds, hipGetErrorString(e));
-        for (FusedFn& f : attr_done) if (!f) { f = fn; break; }
-    }
+    IE_GRANT_LDS(fn, lds);       // a per-(device, function) attribute
     void* args[] = {(void*)&p};
     IE_HIP_CHECK(hipLaunchKernel((const void*)fn, dim3((unsigned)blocks), dim3(512), args, lds, st));
     return IE_OK;

@@ -1032,7 +1032,9 @@ def mconv2d_pair_pool_applicable(x, mwa: MConvWeights, mwb: MConvWeights, pad_mo
 
 def mconv2d_pair_pool(x, mwa: MConvWeights, mwb: MConvWeights, pad_mode="zeros"):
     """``(y, MaxPool2d(2)(y))`` for ``y = relu(conv_b(relu(conv_a(x))))`` in one launch (ie_mconv_pair_pool_nhwc): a U-Net encoder level whose first
-    layer has 32 input channels.  The same bits as ``mconv2d`` + ``mconv2d(..., pool=True)``."""
+    layer has 32 input channels.  Bit-identical to the two-launch path ``mconv2d`` + ``mconv2d(..., pool=True)`` (same packed weights, same
+    contraction order, the intermediate rounded once to the storage type: ``torch.equal`` in test_stacked_conv_32_64_64_with_pooled_output); against an
+    fp32 torch convolution of the same 16-bit operands both paths carry the storage rounding of the intermediate (<= 3e-3 fp16 / 2e-2 bf16 there)."""
     _chk16(x)
     if not mconv2d_pair_pool_applicable(x, mwa, mwb, pad_mode):
         raise capi.IEError("mconv2d_pair_pool: 3x3 / stride 1 / padding 1 / ReLU layers 32 -> 64 -> 64 on a 16-bit NHWC tensor with W >= 64, H >= 2")

@@ -774,10 +774,17 @@ class Trainer:
         import torch.distributed as dist
         multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
         if not multi or dist.get_rank(self.group) == 0:       # data parallel: the replicas are bit-identical, rank 0 writes (Lightning's rank_zero_only)
+            # No collective in here: a caller may guard the call with ``if rank == 0`` (a barrier would hang it until the collective times
+            # out) or call it on every rank -- both work.  The file appears atomically (temporary name + os.replace), so a reader on another
+            # rank sees either no file / the previous one or the complete new one, never a partial write.
             os.makedirs(os.path.dirname(os.path.abspath(str(path))) or ".", exist_ok=True)
-            torch.save(ckpt, str(path))
-        if multi:
-            dist.barrier(group=self.group)                     # nobody reads the file before it is complete
+            tmp = f"{path}.tmp.{os.getpid()}"
+            try:
+                torch.save(ckpt, tmp)
+                os.replace(tmp, str(path))
+            finally:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
         return str(path)
 
     def load_checkpoint(self, path):

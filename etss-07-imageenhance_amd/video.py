@@ -60,6 +60,25 @@ def _frame_u8(frame, denormalize: bool = False) -> np.ndarray:
     return np.ascontiguousarray(a)
 
 
+def _frame_u8_ffmpeg(frame, denormalize: bool = False) -> np.ndarray:
+    """The ffmpeg writer's rule (core/video/io.py:78-101, ``write_video_ffmpeg``), which differs by container type: a torch.Tensor goes
+    through ``to_image_nparray`` with the explicit flag (like every other writer here), an ndarray is **auto-detected** --
+    ``is_normalized_image`` (core/image/utils.py:165-170: ``abs(max) <= 1.0``) -> x * 255 -- whatever the flag says, then made channel-last
+    and cast.  A float ndarray in [0, 1] written without the flag therefore is a picture, not a black frame."""
+    if isinstance(frame, np.ndarray) and frame.dtype != np.uint8:
+        a = frame
+        if a.ndim == 4 and a.shape[0] == 1:
+            a = a[0]
+        if a.ndim != 3:
+            raise ValueError(f"`frame` must be a 3-D image, but got {tuple(frame.shape)}.")
+        if a.size and abs(float(np.amax(a))) <= 1.0:                  # is_normalized_image
+            a = np.clip(a.astype(np.float32), 0.0, 1.0) * 255.0      # denormalize_image
+        if a.shape[0] in (1, 3, 4) and a.shape[-1] not in (1, 3, 4):  # is_channel_first_image -> to_channel_last_image
+            a = np.transpose(a, (1, 2, 0))
+        return np.ascontiguousarray(np.clip(a, 0.0, 255.0).astype(np.uint8))
+    return _frame_u8(frame, denormalize)
+
+
 # ---- loaders -------------------------------------------------------------------------------------------------------------------
 class VideoLoader(abc.ABC):
     """Frames of one source, indexable and iterable; ``loader[i]`` -> ``{"frame": HWC uint8 ndarray (or CHW float tensor with
@@ -290,6 +309,52 @@ class VideoWriterCV(VideoWriter):
         if getattr(self, "video_writer", None) is not None:
             self.video_writer.release()
             self.video_writer = None
+
+
+class VideoWriterFFmpeg(VideoWriter):
+    """Raw rgb24 frames piped into an ``ffmpeg`` process (io.py:318-470: ``<dst>/result.mp4`` for a directory, ``<dst stem>.mp4``
+    otherwise, ``pix_fmt`` yuv420p, extra kwargs handed to ffmpeg as ``-key value``).  The reference drives the binary through
+    ffmpeg-python; this is the same command line through ``subprocess``.  Gated like the cv2 classes: no binary, no writer."""
+
+    def __init__(self, dst, image_size: int | Sequence[int] = (480, 640), frame_rate: float = 10, pix_fmt: str = "yuv420p",
+                 save_image: bool = False, denormalize: bool = False, verbose: bool = False, *args, **kwargs):
+        self.pix_fmt, self.ffmpeg_process, self.ffmpeg_kwargs = pix_fmt, None, kwargs
+        super().__init__(dst, image_size, frame_rate, save_image, denormalize, verbose)
+
+    def command(self, video_file) -> list:
+        cmd = ["ffmpeg", "-f", "rawvideo", "-pix_fmt", "rgb24", "-s", f"{self.image_size[1]}x{self.image_size[0]}", "-i", "pipe:",
+               "-pix_fmt", self.pix_fmt]
+        for k, v in self.ffmpeg_kwargs.items():
+            cmd += [f"-{k}", str(v)]
+        cmd += [str(video_file)]
+        if not self.verbose:
+            cmd += ["-loglevel", "quiet"]
+        return cmd + ["-y"]
+
+    def init(self):
+        import shutil
+        import subprocess
+        if shutil.which("ffmpeg") is None:
+            raise capi.IEError("the ffmpeg binary is not installed in this image: VideoWriterFFmpeg needs it (use FrameSequenceWriter)")
+        video_file = self.dst / "result.mp4" if self.dst.is_dir() else self.dst.parent / f"{self.dst.stem}.mp4"
+        video_file.parent.mkdir(parents=True, exist_ok=True)
+        self.ffmpeg_process = subprocess.Popen(self.command(video_file), stdin=subprocess.PIPE)
+
+    def write(self, frame, path=None, denormalize: bool = False):
+        denormalize = denormalize or self.denormalize
+        if self.save_image:
+            from PIL import Image
+            a = _frame_u8(frame, denormalize)
+            d = self.dst if self.dst.is_dir() else self.dst.parent
+            Image.fromarray(a if a.shape[2] != 1 else a[:, :, 0]).save(d / f"{pathlib.Path(path).stem}.png")
+        self.ffmpeg_process.stdin.write(_frame_u8_ffmpeg(frame, denormalize).tobytes())
+        self.index += 1
+
+    def close(self):
+        if getattr(self, "ffmpeg_process", None) is not None:
+            self.ffmpeg_process.stdin.close()
+            self.ffmpeg_process.wait()
+            self.ffmpeg_process = None
 
 
 def open_video(source, **kw) -> VideoLoader:

@@ -231,6 +231,33 @@ def test_video_frame_sequence_round_trip(tmp_path):
     f = np.full((2, 3, 3), 0.5, np.float32); f[0, 0, 0] = 1.01
     assert video._frame_u8(f, denormalize=True).max() == 255 and video._frame_u8(f, denormalize=True)[1, 1, 1] == 127
     assert video._frame_u8(f * 200.0).max() == 202 and video._frame_u8(np.array([[[300.0, -4.0, 7.9]]], np.float32)).tolist() == [[[255, 0, 7]]]
+    # the ffmpeg writer's own rule (io.py:78-101): an ndarray is auto-detected with is_normalized_image whatever the flag says, a tensor follows the flag
+    g01 = np.linspace(0.0, 1.0, 2 * 3 * 3, dtype=np.float32).reshape(2, 3, 3)
+    assert video._frame_u8_ffmpeg(g01).max() == 255 and video._frame_u8_ffmpeg(g01)[0, 1, 1] == int(g01[0, 1, 1] * 255.0)
+    assert video._frame_u8_ffmpeg(g01 * 200.0).max() == 200                                   # not normalised: taken as [0, 255]
+    chw = np.zeros((3, 4, 5), np.float32); chw[1] = 0.5
+    assert video._frame_u8_ffmpeg(chw).shape == (4, 5, 3) and video._frame_u8_ffmpeg(chw)[2, 2].tolist() == [0, 127, 0]
+    tt = torch.full((3, 4, 5), 0.5)
+    assert video._frame_u8_ffmpeg(tt).max() == 0 and video._frame_u8_ffmpeg(tt, denormalize=True).max() == 127
+    class Pipe:
+        def __init__(self): self.buf = b""
+        def write(self, b): self.buf += b
+        def close(self): pass
+    class Proc:
+        stdin = Pipe()
+        def wait(self): pass
+    fw = video.VideoWriterFFmpeg.__new__(video.VideoWriterFFmpeg)       # no ffmpeg binary in this image: drive write() over a stand-in pipe
+    fw.dst, fw.denormalize, fw.index, fw.save_image, fw.ffmpeg_process = tmp_path, False, 0, False, Proc()
+    fw.image_size, fw.pix_fmt, fw.ffmpeg_kwargs, fw.verbose = (2, 3), "yuv420p", {"crf": 18}, False
+    fw.write(g01)
+    assert len(Proc.stdin.buf) == 2 * 3 * 3 and max(Proc.stdin.buf) == 255 and len(fw) == 1
+    cmd = fw.command(tmp_path / "result.mp4")
+    assert cmd[:8] == ["ffmpeg", "-f", "rawvideo", "-pix_fmt", "rgb24", "-s", "3x2", "-i"] and "-crf" in cmd and cmd[-1] == "-y"
+    fw.close()
+    import shutil
+    if shutil.which("ffmpeg") is None:
+        with pytest.raises(capi.IEError):
+            video.VideoWriterFFmpeg(tmp_path / "out.mp4", image_size=(2, 3))
     # batches(): front to back through get_frame until the source ends -- also for a source that does not know its length (a stream)
     got = [b for b, _ in ld.batches(2)]
     assert [int(b.shape[0]) for b in got] == [2, 2, 1] and got[0].dtype == torch.uint8
