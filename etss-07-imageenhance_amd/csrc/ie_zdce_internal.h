@@ -27,3 +27,20 @@ struct ZdceFusedLaunch {
     void* stamps;   // diagnostic builds only
 };
 int ie_zdce_launch_fused(const ZdceFusedLaunch& a, hipStream_t st);
+
+// round-4 schedule (ie_zdce_x.hip): kind 12 = K12X (e_conv1 + e_conv2: image -> x2), kind 67 = K67X (e_conv1 again + e_conv6 + e_conv7 + curve: image, x2, x5 -> outputs)
+struct ZdceXLaunch {
+    int kind;
+    int dt_h;            // element type of x1 / x6 (LDS only), of e_conv1's operands and of e_conv7's weights; K12X: also x2's
+    int dt_a0, dt_a1;    // K67X: element types of x2 and x5
+    const float* img;
+    void* x2;            // K12X: destination; K67X: source
+    const void* x5;
+    const void* w1; const float* b1;     // e_conv1 as [cout half][ky][lane][8] fragments over [R, G, B, 0] pixels (K = 8 kx taps x 4 channels)
+    const void* w2; const float* b2;     // K12X: e_conv2 fragments
+    const void* w6; const float* b6;     // K67X: e_conv6 fragments
+    const void* w7; const float* b7;     // K67X: e_conv7 over [x1, x6], rows permuted (chan_k67) and scaled by 2 / ln 2: [tile][18][lane][8]; bias in row order
+    float* enhanced; float* adjust; unsigned char* u8;
+    int N, H, W, y_begin, y_end, n_begin, n_count, rows_per_block;
+};
+int ie_zdce_launch_x(const ZdceXLaunch& a, hipStream_t st);

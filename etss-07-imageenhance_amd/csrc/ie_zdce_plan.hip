@@ -53,6 +53,9 @@ struct ie_zdce_plan {
     size_t off_w27 = 0;   // K12 stage B: e_conv2 fragments followed by the x1 half of e_conv7
     size_t off_w7b = 0;   // K67 stage B: the x6 half of e_conv7
     size_t off_b7p = 0;   // e_conv7's bias in K12's row order (what P is seeded with)
+    size_t off_w1x = 0;   // round-4 schedule: e_conv1 as [cout half][ky][lane][8] fragments, K = 8 kx taps x 4 channels (K12X and K67X)
+    size_t off_w7x = 0;   // K67X stage B: e_conv7 over [x1, x6], [row tile][source * 9 + tap][lane][8], rows permuted and scaled like off_w7b
+    size_t off_b7x = 0;   // ... and its bias in that row order
     // workspace
     char* ws = nullptr;
     size_t ws_bytes = 0;
@@ -266,6 +269,51 @@ IE_EXPORT int ie_zdce_finalize(ie_zdce_plan* p, void* stream) {
             host.insert(host.end(), q, q + 32 * 4);
         }
     }
+    if (dt != IE_F32) {
+        // Round-4 schedule (ie_zdce_x.hip).  e_conv1 over [R, G, B, 0] 16-bit pixels, one K = 32 fragment per kernel row ky:
+        //   [hc][ky][lane][j] = W1[16 hc + (lane & 15)][c][ky][kx],  kx = 2 (lane >> 4) + (j >> 2), c = j & 3   (kx >= 3, c == 3: zero)
+        align(256);
+        p->off_w1x = host.size();
+        {
+            const float* w = p->w[0].data();
+            std::vector<unsigned short> hw((size_t)2 * 3 * 64 * 8, 0);
+            for (int hc = 0; hc < 2; ++hc) for (int ky = 0; ky < 3; ++ky) for (int lane = 0; lane < 64; ++lane) for (int j = 0; j < 8; ++j) {
+                const int kx = 2 * (lane >> 4) + (j >> 2), c = j & 3;
+                float v = 0.f;
+                if (kx < 3 && c < 3) v = w[((size_t)(16 * hc + (lane & 15)) * 3 + c) * 9 + ky * 3 + kx];
+                hw[(((size_t)hc * 3 + ky) * 64 + lane) * 8 + j] = p->xdt[1] == IE_F16 ? f32_to_f16_bits(v) : f32_to_bf16_bits(v);
+            }
+            const char* q = (const char*)hw.data();
+            host.insert(host.end(), q, q + hw.size() * 2);
+        }
+        // e_conv7 over BOTH sources for K67X's stage B: tile j = 16 rows, row 4 kq + i = curve map r_{4j+i} of colour kq (channel 3 (4 j + i) + kq,
+        // zero_dce.py:183-188; kq = 3: zero rows), scaled by 2 / ln 2 so that exp(2x) is one v_exp_f32 of the accumulator.
+        const float s7 = 2.885390081777927f;
+        auto chan67 = [&](int row) { const int j = row >> 4, m = row & 15; return (m >> 2) < 3 ? 3 * (4 * j + (m & 3)) + (m >> 2) : -1; };
+        align(256);
+        p->off_w7x = host.size();
+        {
+            const float* w = p->w[6].data();
+            std::vector<unsigned short> hw((size_t)2 * 18 * 64 * 8, 0);
+            for (int tj = 0; tj < 2; ++tj) for (int s = 0; s < 2; ++s) for (int t = 0; t < 9; ++t) for (int lane = 0; lane < 64; ++lane) for (int j = 0; j < 8; ++j) {
+                const int co = chan67(16 * tj + (lane & 15));
+                const int ci = 32 * s + 8 * (lane >> 4) + j;
+                const float v = co >= 0 ? s7 * w[((size_t)co * 64 + ci) * 9 + t] : 0.f;
+                const int sdt = p->xdt[s == 0 ? 1 : 6];
+                hw[(((size_t)tj * 18 + s * 9 + t) * 64 + lane) * 8 + j] = sdt == IE_F16 ? f32_to_f16_bits(v) : f32_to_bf16_bits(v);
+            }
+            const char* q = (const char*)hw.data();
+            host.insert(host.end(), q, q + hw.size() * 2);
+        }
+        align(256);
+        p->off_b7x = host.size();
+        {
+            std::vector<float> hb(32, 0.f);
+            for (int row = 0; row < 32; ++row) { const int c = chan67(row); hb[row] = c >= 0 ? s7 * p->b[6][c] : 0.f; }
+            const char* q = (const char*)hb.data();
+            host.insert(host.end(), q, q + 32 * 4);
+        }
+    }
     if (p->d_w) { (void)hipFree(p->d_w); p->d_w = nullptr; }
     IE_HIP_CHECK(hipMalloc(&p->d_w, host.size()));
     hipStream_t st = (hipStream_t)stream;
@@ -415,8 +463,28 @@ static int forward_mfma(ie_zdce_plan* p, const float* image, float* enhanced, fl
                     rc = ie_zdce_launch_conv1(image, (const float*)W_(0), B_(0), x[1], p->xdt[1], N, H, W, lo(1), hi(1), n0, g, st);
                 }
                 for (int l = 1; l < NL && rc == IE_OK; ++l) rc = single(l);
+            } else if (!(p->cfg.variant & (IE_ZDCE_VAR_P_SCHEDULE | IE_ZDCE_VAR_NO_K345 | IE_ZDCE_VAR_K67_LEGACY))) {
+                // round-4 schedule: K12X (image -> x2), K345 (x2 -> x5), K67X (image, x2, x5 -> outputs); x1 / x3 / x4 / x6 never reach HBM and P does not exist
+                static const int only = getenv("IE_ZDCE_ONLY") ? atoi(getenv("IE_ZDCE_ONLY")) : 0;      // diagnostic (wrong results): time one kernel alone
+                auto xk = [&](int kind, int prof_layer) -> int {
+                    if (only && only != kind) return IE_OK;
+                    ProfScope ps(p, prof_layer, st);
+                    ZdceXLaunch a;
+                    memset(&a, 0, sizeof(a));
+                    a.kind = kind; a.N = N; a.H = H; a.W = W; a.n_begin = n0; a.n_count = g; a.rows_per_block = rb;
+                    a.img = image; a.x2 = x[2]; a.x5 = x[5];
+                    a.w1 = p->d_w + p->off_w1x; a.b1 = B_(0); a.w2 = W_(1); a.b2 = B_(1); a.w6 = W_(5); a.b6 = B_(5);
+                    a.w7 = p->d_w + p->off_w7x; a.b7 = (const float*)(p->d_w + p->off_b7x);
+                    a.dt_h = p->xdt[1]; a.dt_a0 = p->xdt[2]; a.dt_a1 = p->xdt[5];
+                    if (kind == 12) { a.y_begin = lo(2); a.y_end = hi(2); }
+                    else { a.enhanced = enhanced; a.adjust = adjust; a.u8 = u8; a.y_begin = b0; a.y_end = b1; }
+                    return ie_zdce_launch_x(a, st);
+                };
+                rc = xk(12, 1);
+                if (rc == IE_OK) rc = fused(345, 4);
+                if (rc == IE_OK) rc = xk(67, 6);
             } else {
-                // K12 writes x1 over the rows conv7 and conv2's consumers need (= x2's range), then conv3, K45, K67
+                // round-3 schedule (IE_ZDCE_VAR_P_SCHEDULE): K12 also writes P = W7a * x1 + b7 into x1's slot, then conv3, K45, K67
                 rc = fused(12, 1);
                 if (p->cfg.variant & IE_ZDCE_VAR_NO_K345) {
                     if (rc == IE_OK) rc = single(2);
@@ -542,6 +610,7 @@ IE_EXPORT int ie_zdce_profile_forward(ie_zdce_plan* p, const float* image, float
     const bool k345 = fused && !(p->cfg.variant & IE_ZDCE_VAR_NO_K345);
     for (int l = 0; l < NL; ++l) { ms[l] = 0.f; names[l] = k345 ? kFused3Names[l] : (fused ? kFusedNames[l] : kLayerNames[l]); if (launches) launches[l] = 0; }
     if (fused && !(p->cfg.variant & IE_ZDCE_VAR_K67_LEGACY)) names[6] = "zdce_k67n_conv6_conv7_curve";
+    if (fused && !(p->cfg.variant & (IE_ZDCE_VAR_P_SCHEDULE | IE_ZDCE_VAR_NO_K345 | IE_ZDCE_VAR_K67_LEGACY))) { names[1] = "zdce_k12x_conv1_conv2"; names[6] = "zdce_k67x_conv1_conv6_conv7_curve"; }
     for (size_t i = 0; i < p->ev_layer.size(); ++i) {
         float t = 0.f;
         IE_HIP_CHECK(hipEventElapsedTime(&t, p->ev[2 * i], p->ev[2 * i + 1]));

@@ -1,0 +1,669 @@
+// Zero-DCE, round-4 schedule: the partial sum P = W7a * x1 + b7 no longer exists.
+//
+//   K12X : e_conv1 + e_conv2                      image -> x2                       12 + 64      =  76 B/px   (K12: 140)
+//   K345 : e_conv3 + e_conv4 + e_conv5            x2 -> x5   (ie_zdce_fused.hip)    64 + 64      = 128 B/px
+//   K67X : e_conv1 (again) + e_conv6 + e_conv7    image, x2, x5 -> enhanced         12 + 128 + 12 = 152 B/px  (K67N: 216)
+//          + tanh + LE curve
+//
+// Round 3 ended with K12 write-bound (128 B/px written at 3.2 TB/s) and K67N on the HBM roof (225 B/px at 4.8 TB/s) beside an
+// MFMA-bound K345: the 128 B/px P costs (written by K12, read by K67N) bought 36 MFMAs per row that K67N did not have to run.
+// e_conv1 is 1 % of the network's arithmetic, so the last kernel recomputes x1 from the image it reads anyway (for the curve)
+// and contracts e_conv7 over BOTH of its sources [x1, x6] (zero_dce.py:182): 356 B/px instead of 484, every kernel on the MFMA
+// side of the balance point, and e_conv7 accumulates in fp32 over all 64 input channels (P was rounded to 16 bits).
+//
+// Reference semantics: src/mon/vision/enhance/llie/zero_dce/zero_dce.py:173-191.
+//
+// Both kernels are two-stage eight-wave strip kernels (ie_zdce_fused.hip's machinery in ie_conv_first32.hip's compact form): a workgroup
+// marches down a 128-column strip, weights are MFMA A operands in registers for the whole launch, rows travel through LDS rings,
+// every pixel fragment read from LDS feeds the three ky taps into three rotating accumulator sets, one s_barrier per row.
+#include "ie_zdce_internal.h"
+#include <string.h>
+#include <type_traits>
+
+namespace {
+
+constexpr int TW = 128, MARG = 2, TS = 124;    // computed / dropped-per-side / stored columns of a strip (no halo columns are loaded: each layer simply
+                                               // does not use the outermost computed column of the one before; e_conv1 has the image's halo)
+constexpr int PXB = 64;                        // one pixel of a 32-channel 16-bit tensor
+constexpr int ROW_B = TW * PXB;                // 8,192
+constexpr int IPX = 136, IPB = 8;              // converted image row: [136 px][R, G, B, 0] 16-bit; pixel i = image column xc0 - 1 + i (fragments read up to pixel 134)
+constexpr int IMG_PART_B = IPX * IPB;          // 1,088 (bf16 operands: a hi and a lo part, so the fp32 pixel survives bf16's 8 mantissa bits)
+constexpr int RAW_SLOT_B = 2048;               // three fp32 plane rows of 136 pixels = 1,632 bytes (8 DMA instructions x 256 bytes)
+constexpr unsigned OOB = 0x80000000u;
+
+#define IE_SB() __builtin_amdgcn_sched_barrier(0)
+typedef __attribute__((address_space(3))) void* lds_ptr;
+
+template <typename T> constexpr int parts_of() { return ie_elem<T>::dtype == IE_BF16 ? 2 : 1; }
+
+// ---- pieces shared by the two kernels ----------------------------------------------------------------------------------------------------
+// raw image rows: instruction j of wave w4 covers flat indices (4 j + w4) * 64 + lane of [plane][pixel] (3 x 136 floats)
+__device__ __forceinline__ void raw_offsets(int w4, int lane, int xc0, int W, size_t plane, unsigned (&raw_off)[2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int idx = (4 * j + w4) * 64 + lane, pl = idx / IPX, px = idx - pl * IPX, x = xc0 - 1 + px;
+        raw_off[j] = (idx < 3 * IPX && x >= 0 && x < W) ? (unsigned)(((size_t)pl * plane + x) * 4) : OOB;
+    }
+}
+
+// one fp32 raw row (three planes) -> [px][R, G, B, 0] 16-bit (hi part; bf16: + lo part = x - hi).  Lane ci of the stage's 256 converts pixel ci (< 136).
+template <typename T> __device__ __forceinline__ void convert_row(const char* raw_slot, char* img_slot, char* dump, int ci, int lane) {
+    const bool ok = ci < IPX;
+    const char* rs = raw_slot + (ok ? ci : 0) * 4;
+    const float r = *(const float*)rs, g = *(const float*)(rs + IPX * 4), b = *(const float*)(rs + 2 * IPX * 4);
+    char* d = ok ? img_slot + ci * IPB : dump + lane * 8;
+    *(ie_u32x2*)d = ie_u32x2{ie_pack2<T>(r, g), ie_pack2<T>(b, 0.f)};
+    if constexpr (parts_of<T>() == 2) {
+        const float rl = r - (float)(T)r, gl = g - (float)(T)g, bl = b - (float)(T)b;
+        *(ie_u32x2*)(d + (ok ? IMG_PART_B : 512)) = ie_u32x2{ie_pack2<T>(rl, gl), ie_pack2<T>(bl, 0.f)};
+    }
+}
+
+// a finished row (ReLU, 16 bits, zero where `keep` says the pixel lies outside the image = the next layer's zero padding) into an LDS row image as 16-byte
+// pieces: lanes l / l + 16 exchange halves, so a ds_write_b128 serves 8 consecutive pixels x 16 bytes (every bank once).  Wave = (cout fragment cf, half hf).
+template <typename T> __device__ __forceinline__ void put_row(const ie_f32x4 (&acc)[4], char* base, int em_off, unsigned keep) {
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const ie_u32x2 a = {ie_pack2_relu<T>(acc[2 * jj][0], acc[2 * jj][1]), ie_pack2_relu<T>(acc[2 * jj][2], acc[2 * jj][3])};
+        const ie_u32x2 b2 = {ie_pack2_relu<T>(acc[2 * jj + 1][0], acc[2 * jj + 1][1]), ie_pack2_relu<T>(acc[2 * jj + 1][2], acc[2 * jj + 1][3])};
+        const auto sx = __builtin_amdgcn_permlane16_swap(a[0], b2[0], false, false);
+        const auto sy = __builtin_amdgcn_permlane16_swap(a[1], b2[1], false, false);
+        const bool k = (keep >> jj) & 1u;
+        *(ie_u32x4*)(base + em_off + jj * 32 * PXB) = ie_u32x4{k ? sx[0] : 0u, k ? sy[0] : 0u, k ? sx[1] : 0u, k ? sy[1] : 0u};
+    }
+}
+
+// e_conv1 of one converted image row into three rotating accumulator sets: K = 8 kx taps x 4 channels per MFMA (taps 3..7 and channel 3 carry zero weights),
+// lane (p16, kq) of tile j reads taps kx = 2 kq, 2 kq + 1 = 16 bytes at ring pixel (column + 2 kq)
+template <typename T> __device__ __forceinline__ void conv1_row(const char* img_slot, const int (&rdi)[4], const ie_u32x4 (&w1)[3], const ie_f32x4& bias4,
+                                                               ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4]) {
+#pragma unroll
+    for (int part = 0; part < parts_of<T>(); ++part) {
+        ie_u32x4 bx[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const ie_u32x2 lo = *(const ie_u32x2*)(img_slot + part * IMG_PART_B + rdi[j]), hi = *(const ie_u32x2*)(img_slot + part * IMG_PART_B + rdi[j] + 8);
+            bx[j] = ie_u32x4{lo[0], lo[1], hi[0], hi[1]};
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            accN[j] = ie_mfma16_raw<T>(w1[0], bx[j], part == 0 ? bias4 : accN[j]);
+            accM[j] = ie_mfma16_raw<T>(w1[1], bx[j], accM[j]);
+            accO[j] = ie_mfma16_raw<T>(w1[2], bx[j], accO[j]);
+        }
+    }
+}
+
+// fragment offsets of a 128-pixel LDS row image for the wave's half hf: tile 0 / the other tiles / the last tile's right tap (the two out-of-strip columns are
+// clamped: they only feed dropped columns)
+struct RowRead { int rd0[3], rd1[3], rd23; };
+__device__ __forceinline__ RowRead row_read(int hf, int p16, int kq) {
+    auto lds_px = [&](int q) __attribute__((always_inline)) { return q * PXB + ((kq ^ ((q >> 1) & 3)) << 4); };
+    auto fix = [&](int q) __attribute__((always_inline)) { return min(max(q, 0), TW - 1); };
+    RowRead r;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        r.rd1[kx] = lds_px(16 * (4 * hf + 1) + p16 + kx - 1);
+        r.rd0[kx] = lds_px(fix(16 * (4 * hf) + p16 + kx - 1));
+    }
+    r.rd23 = lds_px(fix(16 * (4 * hf + 3) + p16 + 1));
+    return r;
+}
+__device__ __forceinline__ int row_off(const RowRead& r, int g) {       // g = (kx, tile)
+    const int kx = g >> 2, j = g & 3;
+    return j == 0 ? r.rd0[kx] : ((kx == 2 && j == 3) ? r.rd23 : r.rd1[kx] + 1024 * (j - 1));
+}
+
+// One source row (32 channels) into three rotating accumulator sets: 12 fragments read three ahead, 36 MFMAs in a pinned order; fill(s) is placed behind MFMA s
+// (a wave's vector work is close to free between its OWN MFMAs and costs its full length as a phase of its own: tools/micro/coissue.hip).
+template <typename T, int AHEAD = 3, typename F>
+__device__ __forceinline__ void mfma_row(const char* slot, const RowRead& rr, const ie_u32x4* wv, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4],
+                                         bool first, const ie_f32x4& init, F&& fill) {
+    ie_u32x4 bx[12];
+    auto rd = [&](int g) __attribute__((always_inline)) { bx[g] = *(const ie_u32x4*)(slot + row_off(rr, g)); };
+#pragma unroll
+    for (int g = 0; g < AHEAD; ++g) rd(g);
+    IE_SB();
+#pragma unroll
+    for (int g = 0; g < 12; ++g) {
+        const int kx = g >> 2, j = g & 3;
+        if (g + AHEAD < 12) rd(g + AHEAD);
+        accN[j] = ie_mfma16_raw<T>(wv[0 * 3 + kx], bx[g], (first && kx == 0) ? init : accN[j]);
+        fill(3 * g);
+        IE_SB();
+        accM[j] = ie_mfma16_raw<T>(wv[1 * 3 + kx], bx[g], accM[j]);
+        fill(3 * g + 1);
+        IE_SB();
+        accO[j] = ie_mfma16_raw<T>(wv[2 * 3 + kx], bx[g], accO[j]);
+        fill(3 * g + 2);
+        IE_SB();
+    }
+}
+
+// ==========================================================================================================================================
+// K12X: e_conv1 + e_conv2 -> x2
+// ==========================================================================================================================================
+struct K12XParams {
+    const float* img; const void* w1; const float* b1; const void* w2; const float* b2; void* dst;
+    int H, W, y_begin, y_end, rows_per_block, strips, chunks, n_begin;
+};
+
+template <typename T> struct K12XGeom {
+    static constexpr int PFR = 2, NRAW = PFR + 1, NRI = 2, NRH = 3, NPARK = 2;
+    static constexpr int IMG_ROW_B = parts_of<T>() * IMG_PART_B;
+    static constexpr int OFF_RAW = 0, OFF_IMG = OFF_RAW + NRAW * RAW_SLOT_B, OFF_H = OFF_IMG + NRI * IMG_ROW_B, OFF_PARK = OFF_H + NRH * ROW_B;
+    static constexpr int OFF_DUMP = OFF_PARK + NPARK * ROW_B, LDS_B = OFF_DUMP + 1024;        // f16: 6,144 + 2,176 + 24,576 + 16,384 + 1,024 = 50,304: two workgroups per CU
+};
+
+template <typename T>
+__device__ __forceinline__ void k12x_body(const K12XParams& p) {
+    using G = K12XGeom<T>;
+    using frag = ie_u32x4;
+    constexpr int PFR = G::PFR, NRAW = G::NRAW, NRI = G::NRI, NRH = G::NRH, NPARK = G::NPARK;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    ie_fp16_saturate_on();
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p16 = lane & 15, kq = lane >> 4;
+    const int stg = wave >> 2, w4 = wave & 3, cf = w4 & 1, hf = w4 >> 1;      // stage; 16-cout fragment; half of the strip (tiles 4 hf .. 4 hf + 3)
+
+    int b = blockIdx.x;
+    const int strip = b % p.strips; b /= p.strips;
+    const int chunk = b % p.chunks; b /= p.chunks;
+    const int n = p.n_begin + b;
+    const int xc0 = strip * TS - MARG;
+    const int H = p.H, W = p.W;
+    const int ys = p.y_begin + chunk * p.rows_per_block, ye = min(ys + p.rows_per_block, p.y_end);
+    const int n_steps = (ye - ys) + 8;
+
+    auto mk = [&](const void* base, size_t bytes) __attribute__((always_inline)) { return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000); };
+    const size_t plane = (size_t)H * W;
+    const auto rsI = mk((const char*)(p.img + (size_t)n * 3 * plane), 3 * plane * 4);
+    const auto rsD = mk((char*)p.dst + (size_t)n * plane * PXB, plane * PXB);
+
+    frag wv[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        if (stg == 0) wv[t] = t < 3 ? ((const frag*)p.w1)[(cf * 3 + t) * 64 + lane] : frag{0u, 0u, 0u, 0u};
+        else wv[t] = ((const frag*)p.w2)[(cf * 9 + t) * 64 + lane];
+    }
+    ie_f32x4 bias4;
+    {
+        const float* bp = stg ? p.b2 : p.b1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bias4[i] = bp[16 * cf + 4 * kq + i];
+    }
+    int em_off;
+    unsigned em_in = 0;
+    {
+        const int q = 16 * (4 * hf + (kq & 1)) + p16;
+        em_off = q * PXB + (((2 * cf + (kq >> 1)) ^ ((q >> 1) & 3)) << 4);
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int x = xc0 + q + 32 * jj;
+            em_in |= (x >= 0 && x < W) ? (1u << jj) : 0u;
+        }
+    }
+    ie_f32x4 a0[4], a1[4], a2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { a0[j] = bias4; a1[j] = bias4; a2[j] = bias4; }
+
+    if (stg == 0) {
+        // ---- stage A: image rows (LDS-DMA, converted one step ahead) -> e_conv1 -> hand-off ring; image row of step t: ys - 2 + t ----
+        unsigned raw_off[2];
+        raw_offsets(w4, lane, xc0, W, plane, raw_off);
+        auto issue_raw = [&](int t) __attribute__((always_inline)) {
+            const int yi = ys - 2 + t;
+            const unsigned rmask = (yi >= 0 && yi < H) ? 0u : OOB;
+            const unsigned row_b = rmask ? 0u : (unsigned)yi * (unsigned)W * 4u;
+            char* slot = smem + G::OFF_RAW + (t % NRAW) * RAW_SLOT_B;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsI, (lds_ptr)(slot + (4 * j + w4) * 256), 4, (int)((row_b + raw_off[j]) | rmask), 0, 0, 0);
+        };
+        const int ci = w4 * 64 + lane;
+        auto convert = [&](int t) __attribute__((always_inline)) {
+            convert_row<T>(smem + G::OFF_RAW + (t % NRAW) * RAW_SLOT_B, smem + G::OFF_IMG + (t % NRI) * G::IMG_ROW_B, smem + G::OFF_DUMP, ci, lane);
+        };
+        int rdi[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rdi[j] = (16 * (4 * hf + j) + p16 + 2 * kq) * IPB;
+        const frag w1[3] = {wv[0], wv[1], wv[2]};
+
+#pragma unroll
+        for (int t = 0; t <= PFR; ++t) issue_raw(t);
+        ie_wait_vm_imm<2 * PFR>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                    // prologue barrier (all eight waves): raw row 0 has landed
+        convert(0);
+        auto step_a = [&](int t, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4]) __attribute__((always_inline)) {
+            ie_wait_vm_imm<2 * (PFR - 1)>();             // raw row t + 1 has landed (behind it: rows up to t + PFR)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            conv1_row<T>(smem + G::OFF_IMG + (t % NRI) * G::IMG_ROW_B, rdi, w1, bias4, accN, accM, accO);
+            convert(t + 1);                              // next step's image row (its ring slot was last read at step t - 1)
+            issue_raw(t + 1 + PFR);
+            const int m = ys - 3 + t;                    // the x1 row finished now; outside the image it is e_conv2's zero padding
+            put_row<T>(accO, smem + G::OFF_H + (t % NRH) * ROW_B, em_off, (m >= 0 && m < H) ? em_in : 0u);
+        };
+        for (int t = 0; t < n_steps; t += 3) {
+            step_a(t, a0, a1, a2);
+            if (t + 1 < n_steps) step_a(t + 1, a2, a0, a1);
+            if (t + 2 < n_steps) step_a(t + 2, a1, a2, a0);
+        }
+    } else {
+        // ---- stage B: e_conv2; finished rows are parked as whole 64-byte pixel lines and leave one step later, 1 KiB of lines per store instruction ----
+        const RowRead rr = row_read(hf, p16, kq);
+        unsigned st_col[2];
+        int st_lds[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = 32 * w4 + 16 * i + (lane >> 2), c = lane & 3, x = xc0 + q;
+            st_col[i] = (q >= MARG && q < MARG + TS && x < W) ? (unsigned)(x * PXB + c * 16) : OOB;
+            st_lds[i] = q * PXB + ((c ^ ((q >> 1) & 3)) << 4);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                    // prologue barrier
+        // step t: the x1 row ys - 5 + t (stage A's step t - 2) finishes x2 row ys - 6 + t; accN = the row finished at step t - 1 is parked into slot t % 2;
+        // the row parked at step t - 1 (ys - 8 + t) leaves
+        auto step_b = [&](int t, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4]) __attribute__((always_inline)) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const int yo = ys - 8 + t;
+            const unsigned rmask = (yo >= ys && yo < ye) ? 0u : OOB;
+            const char* islot = smem + G::OFF_PARK + ((t + 1) % NPARK) * ROW_B;        // parked at step t - 1
+            put_row<T>(accN, smem + G::OFF_PARK + (t % NPARK) * ROW_B, em_off, 0x3u);
+            auto nofill = [&](int) __attribute__((always_inline)) {};
+            mfma_row<T, 3>(smem + G::OFF_H + ((t + 1) % NRH) * ROW_B, rr, wv, accN, accM, accO, true, bias4, nofill);     // (a third fragment ahead costs the second workgroup per CU)
+            // the leaving row is read AFTER the MFMA stream (its slot is not written during this step): 8 registers that do not have to live across it
+            ie_u32x4 ln[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) ln[i] = *(const ie_u32x4*)(islot + st_lds[i]);
+            const unsigned row_b = rmask ? 0u : (unsigned)yo * (unsigned)W * PXB;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) __builtin_amdgcn_raw_buffer_store_b128(ln[i], rsD, (int)((row_b + st_col[i]) | rmask), 0, 0);
+        };
+        for (int t = 0; t < n_steps; t += 3) {
+            step_b(t, a0, a1, a2);
+            if (t + 1 < n_steps) step_b(t + 1, a2, a0, a1);
+            if (t + 2 < n_steps) step_b(t + 2, a1, a2, a0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void zdce_k12x_conv1_conv2_f16(K12XParams p) { k12x_body<_Float16>(p); }
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void zdce_k12x_conv1_conv2_bf16(K12XParams p) { k12x_body<__bf16>(p); }
+
+// ==========================================================================================================================================
+// K67X: e_conv1 (recomputed) + e_conv6 + e_conv7 + tanh + LE curve -> enhanced
+// ==========================================================================================================================================
+// Stage A (waves 0-3 = 2 cout fragments x 2 strip halves): e_conv1 on the image row (12 MFMAs, as in K12X) and e_conv6 on [x2, x5] (72 MFMAs, rows by LDS-DMA);
+//   both finished rows (same row index) go to stage B through 3-slot LDS rings.
+// Stage B (waves 4-7 = 2 row tiles of e_conv7 x 2 strip halves): e_conv7 over [x1, x6] (72 MFMAs per wave and row).  e_conv7's 24 output rows are permuted on
+//   the host (ie_zdce_plan.hip, chan_k67): row 4 kq + i of 16-row tile j is curve map r_{4j+i} of colour kq (kq = 3: zero rows), and scaled by 2 / ln 2, so after
+//   the MFMAs lane (pixel, kq) of a tile-j wave holds r_{4j} .. r_{4j+3} of ONE colour of its pixel as log2(e) * 2x: tanh = 1 - 2 / (exp2(acc) + 1) and four
+//   curve steps (zero_dce.py:183-188) run straight off the accumulators.  The curve is a chain over the eight maps, so the tile-1 waves run ONE STEP BEHIND the
+//   tile-0 waves: tile 0 takes the fp32 pixel from the raw image ring through iterations 0-3 and leaves y4 in a small LDS exchange row, tile 1 picks it up a step
+//   later (its own finished row is that same image row then), runs iterations 4-7 and stages the result; staged rows leave a step later as 16-byte vectors.
+//   The 96 tanh / curve operations of a wave's finished row ride as fillers behind fixed MFMAs of the next step's 72-MFMA stream; FOUR accumulator sets rotate
+//   (the finished row is only read while the set freed a step earlier restarts from the bias).
+// Stage B's waves also issue the image row DMA (2 instructions per wave and step); stage A's waves convert the landed row one step ahead of e_conv1.
+struct K67XParams {
+    const float* img; const void* x2; const void* x5;
+    const void* w1; const float* b1; const void* w6; const float* b6; const void* w7; const float* b7;
+    float* enhanced; float* adjust; unsigned char* u8;
+    int H, W, y_begin, y_end, rows_per_block, strips, chunks, n_begin;
+};
+
+template <typename TH> struct K67XGeom {
+    static constexpr int PF = 3, NRA = PF + 1;           // x2 / x5 rows of DMA issued ahead, ring slots
+    static constexpr int PFR = 2, NRAW = 8;              // raw image rows issued ahead; a raw row is read by the conversion (step u - 1) and by the curve (step u + 4)
+    static constexpr int NRI = 2, NRH = 3;
+    static constexpr int IMG_ROW_B = parts_of<TH>() * IMG_PART_B;
+    static constexpr int YPLANE_B = 132 * 4, YSLOT_B = 4 * YPLANE_B;      // fp32 [colour (+ a spare plane for lane group kq = 3)][pixel q at float q + 2]
+    static constexpr int OFF_X2 = 0, OFF_X5 = OFF_X2 + NRA * ROW_B, OFF_H6 = OFF_X5 + NRA * ROW_B, OFF_H1 = OFF_H6 + NRH * ROW_B;
+    static constexpr int OFF_RAW = OFF_H1 + NRH * ROW_B, OFF_IMG = OFF_RAW + NRAW * RAW_SLOT_B, OFF_Y4 = OFF_IMG + NRI * IMG_ROW_B;
+    static constexpr int OFF_OUT = OFF_Y4 + 2 * YSLOT_B, OFF_DUMP = OFF_OUT + 2 * YSLOT_B, LDS_B = OFF_DUMP + 1024;
+    // f16: 65,536 + 49,152 + 16,384 + 2,176 + 4,224 + 4,224 + 1,024 = 142,720 bytes: one workgroup per CU
+};
+
+// MODE 0: any mix of enhanced / adjust / u8, any width.  MODE 1: `enhanced` fp32 as the only output, W % 4 == 0 (the throughput path: no output-mode branches).
+template <typename TA0, typename TA1, typename TH, int MODE>
+__device__ __forceinline__ void k67x_body(const K67XParams& p) {
+    using G = K67XGeom<TH>;
+    using frag = ie_u32x4;
+    constexpr int PF = G::PF, NRA = G::NRA, PFR = G::PFR, NRAW = G::NRAW, NRI = G::NRI, NRH = G::NRH;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    ie_fp16_saturate_on();
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p16 = lane & 15, kq = lane >> 4;
+    const int stg = wave >> 2, w4 = wave & 3, cf = w4 & 1, hf = w4 >> 1;      // stage; stage A: 16-cout fragment / stage B: 16-row tile of e_conv7; half of the strip
+
+    int b = blockIdx.x;
+    const int strip = b % p.strips; b /= p.strips;
+    const int chunk = b % p.chunks; b /= p.chunks;
+    const int n = p.n_begin + b;
+    const int xc0 = strip * TS - MARG;                     // image column of computed column 0 (xc0 + MARG is a multiple of 4)
+    const int H = p.H, W = p.W;
+    const int ys = p.y_begin + chunk * p.rows_per_block, ye = min(ys + p.rows_per_block, p.y_end);
+    const int n_steps = (ye - ys) + 8;
+    const size_t plane = (size_t)H * W;
+    const size_t frame_b = plane * PXB;
+
+    auto mk = [&](const void* base, size_t bytes) __attribute__((always_inline)) { return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000); };
+    const RowRead rr = row_read(hf, p16, kq);
+
+    if (stg == 0) {
+        // ================================================================ stage A ================================================================
+        const auto rs2 = mk((const char*)p.x2 + (size_t)n * frame_b, frame_b);
+        const auto rs5 = mk((const char*)p.x5 + (size_t)n * frame_b, frame_b);
+        frag wv[18], w1[3];
+#pragma unroll
+        for (int f = 0; f < 18; ++f) wv[f] = ((const frag*)p.w6)[(cf * 18 + f) * 64 + lane];
+#pragma unroll
+        for (int f = 0; f < 3; ++f) w1[f] = ((const frag*)p.w1)[(cf * 3 + f) * 64 + lane];
+        ie_f32x4 bias6, bias1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { bias6[i] = p.b6[16 * cf + 4 * kq + i]; bias1[i] = p.b1[16 * cf + 4 * kq + i]; }
+        // x2 / x5 rows: piece m = 2 w4 + j (16 pixels x 64 bytes); lane -> (pixel, LDS chunk position); the source chunk is the position's un-swizzled one
+        unsigned body_xoff[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int q = (2 * w4 + j) * 16 + (lane >> 2);
+            const int s = (lane & 3) ^ ((q >> 1) & 3);
+            const int x = xc0 + q;
+            body_xoff[j] = (x >= 0 && x < W) ? (unsigned)(x * PXB + s * 16) : OOB;
+        }
+        auto issue = [&](int t) __attribute__((always_inline)) {
+            const int y = ys - 2 + t;
+            const unsigned rmask = (y >= 0 && y < H) ? 0u : OOB;
+            const unsigned row_b = rmask ? 0u : (unsigned)y * (unsigned)W * PXB;
+            char* s2 = smem + G::OFF_X2 + (t % NRA) * ROW_B;
+            char* s5 = smem + G::OFF_X5 + (t % NRA) * ROW_B;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (lds_ptr)(s2 + (2 * w4 + j) * 1024), 16, (int)((row_b + body_xoff[j]) | rmask), 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs5, (lds_ptr)(s5 + (2 * w4 + j) * 1024), 16, (int)((row_b + body_xoff[j]) | rmask), 0, 0, 0);
+        };
+        const int ci = w4 * 64 + lane;
+        auto convert = [&](int t) __attribute__((always_inline)) {
+            convert_row<TH>(smem + G::OFF_RAW + (t % NRAW) * RAW_SLOT_B, smem + G::OFF_IMG + (t % NRI) * G::IMG_ROW_B, smem + G::OFF_DUMP, ci, lane);
+        };
+        int rdi[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rdi[j] = (16 * (4 * hf + j) + p16 + 2 * kq) * IPB;
+        int em_off;
+        unsigned em_in = 0;
+        {
+            const int q = 16 * (4 * hf + (kq & 1)) + p16;
+            em_off = q * PXB + (((2 * cf + (kq >> 1)) ^ ((q >> 1) & 3)) << 4);
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int x = xc0 + q + 32 * jj;
+                em_in |= (x >= 0 && x < W) ? (1u << jj) : 0u;
+            }
+        }
+        ie_f32x4 a0[4], a1[4], a2[4], e0[4], e1[4], e2[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a0[j] = bias6; a1[j] = bias6; a2[j] = bias6; e0[j] = bias1; e1[j] = bias1; e2[j] = bias1; }
+
+#pragma unroll
+        for (int t = 0; t < PF; ++t) issue(t);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                    // prologue barrier: stage B waited for raw row 0
+        convert(0);
+        // step t: image / x2 / x5 row ys - 2 + t; the x1 and x6 rows ys - 3 + t are finished and handed over in slot t % 3
+        auto step_a = [&](int t, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4], ie_f32x4 (&eN)[4], ie_f32x4 (&eM)[4], ie_f32x4 (&eO)[4]) __attribute__((always_inline)) {
+            ie_wait_vm_imm<4 * (PF - 1)>();              // the x2 / x5 rows of step t have landed (behind them: the rows of steps t + 1 .. t + PF - 1)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            conv1_row<TH>(smem + G::OFF_IMG + (t % NRI) * G::IMG_ROW_B, rdi, w1, bias1, eN, eM, eO);
+            auto nofill = [&](int) __attribute__((always_inline)) {};
+            mfma_row<TA0>(smem + G::OFF_X2 + (t % NRA) * ROW_B, rr, wv, accN, accM, accO, true, bias6, nofill);
+            mfma_row<TA1>(smem + G::OFF_X5 + (t % NRA) * ROW_B, rr, wv + 9, accN, accM, accO, false, bias6, nofill);
+            issue(t + PF);
+            convert(t + 1);
+            const int m = ys - 3 + t;
+            const unsigned keep = (m >= 0 && m < H) ? em_in : 0u;
+            put_row<TH>(eO, smem + G::OFF_H1 + (t % NRH) * ROW_B, em_off, keep);
+            put_row<TH>(accO, smem + G::OFF_H6 + (t % NRH) * ROW_B, em_off, keep);
+        };
+        for (int t = 0; t < n_steps; t += 3) {
+            step_a(t, a0, a1, a2, e0, e1, e2);
+            if (t + 1 < n_steps) step_a(t + 1, a2, a0, a1, e2, e0, e1);
+            if (t + 2 < n_steps) step_a(t + 2, a1, a2, a0, e1, e2, e0);
+        }
+    } else {
+        // ================================================================ stage B ================================================================
+        const int cj = cf;                                  // this wave's 16-row tile of e_conv7 = curve iterations 4 cj .. 4 cj + 3; tile 1 runs one step behind
+        const auto rsI = mk((const char*)(p.img + (size_t)n * 3 * plane), 3 * plane * 4);
+        const auto rsE = mk(p.enhanced ? (const void*)(p.enhanced + (size_t)n * 3 * plane) : (const void*)p.w7, p.enhanced ? 3 * plane * 4 : 0);
+        const auto rsJ = mk((MODE == 0 && p.adjust) ? (const void*)(p.adjust + (size_t)n * 24 * plane) : (const void*)p.w7, (MODE == 0 && p.adjust) ? 24 * plane * 4 : 0);
+        const auto rsU = mk((MODE == 0 && p.u8) ? (const void*)(p.u8 + (size_t)n * 3 * plane) : (const void*)p.w7, (MODE == 0 && p.u8) ? 3 * plane : 0);
+        frag wv[18];
+#pragma unroll
+        for (int f = 0; f < 18; ++f) wv[f] = ((const frag*)p.w7)[(cj * 18 + f) * 64 + lane];
+        ie_f32x4 bias7;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bias7[i] = p.b7[16 * cj + 4 * kq + i];
+        unsigned raw_off[2];
+        raw_offsets(w4, lane, xc0, W, plane, raw_off);
+        auto issue_raw = [&](int t) __attribute__((always_inline)) {
+            const int yi = ys - 2 + t;
+            const unsigned rmask = (yi >= 0 && yi < H) ? 0u : OOB;
+            const unsigned row_b = rmask ? 0u : (unsigned)yi * (unsigned)W * 4u;
+            char* slot = smem + G::OFF_RAW + (t % NRAW) * RAW_SLOT_B;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsI, (lds_ptr)(slot + (4 * j + w4) * 256), 4, (int)((row_b + raw_off[j]) | rmask), 0, 0, 0);
+        };
+        // where this lane's curve value of tile j comes from / goes to: the raw row's plane kq at ring pixel q + 1 (tile 0), the exchange / output rows at float q + 2
+        int yin_off[4], yout_off[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = 16 * (4 * hf + j) + p16;
+            yout_off[j] = kq * G::YPLANE_B + (q + 2) * 4;                                        // (kq = 3: the spare plane)
+            yin_off[j] = cj ? yout_off[j] : (kq < 3 ? kq : 2) * (IPX * 4) + (q + 1) * 4;
+        }
+        // enhanced, W % 4 == 0: wave w4 < 3 stores colour w4; lane l < 31: pixels 4 l .. 4 l + 3 of the strip's 124 stored ones
+        unsigned est_off;
+        int est_lds;
+        {
+            const int x = xc0 + MARG + 4 * lane;
+            est_off = (w4 < 3 && lane < 31 && x < W) ? (unsigned)(((size_t)w4 * plane + x) * 4) : OOB;
+            est_lds = (w4 < 3 ? w4 : 0) * G::YPLANE_B + 16 + 16 * (lane < 31 ? lane : 0);
+        }
+
+#pragma unroll
+        for (int t = 0; t <= PFR; ++t) issue_raw(t);
+        ie_wait_vm_imm<2 * PFR>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                    // prologue barrier: raw row 0 has landed (stage A converts it behind the barrier)
+
+        ie_f32x4 a0[4], a1[4], a2[4], a3[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a0[j] = bias7; a1[j] = bias7; a2[j] = bias7; a3[j] = bias7; }
+
+        // step t (tile 0; tile 1 does the same one step later): the x1 / x6 rows ys - 4 + t (stage A's step t - 1) finish e_conv7 row ys - 5 + t; accF = the row
+        // finished at step t - 1 (ys - 6 + t): its curve runs now; the row staged at step t - 1 by the tile-1 waves (ys - 8 + t) leaves
+        auto step_b = [&](int t, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4], const ie_f32x4 (&accF)[4]) __attribute__((always_inline)) {
+            ie_wait_vm_imm<2 * (PFR - 1)>();             // raw row t + 1 has landed (the stores issued since only make this stricter)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            {   // (1) the staged row leaves
+                const int yo = ys - 8 + t;
+                const bool row_ok = (yo >= ys) && (yo < ye);
+                const char* os = smem + G::OFF_OUT + ((t + 1) & 1) * G::YSLOT_B;
+                const int xs = xc0 + MARG;
+                if (MODE == 1 || (p.enhanced && (W & 3) == 0 && ((size_t)p.enhanced & 15) == 0)) {
+                    const ie_u32x4 v = *(const ie_u32x4*)(os + est_lds);
+                    const unsigned rmask = row_ok ? 0u : OOB;
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rsE, (int)((est_off + (rmask ? 0u : (unsigned)yo * (unsigned)W * 4u)) | rmask), 0, 0);
+                } else if (p.enhanced) {
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int q = lane + 64 * k, x = xc0 + q;
+                        const float v = *(const float*)(os + (w4 < 3 ? w4 : 0) * G::YPLANE_B + (q + 2) * 4);
+                        const bool ok = row_ok && w4 < 3 && q >= MARG && q < TW - MARG && x < W;
+                        const unsigned off = ok ? (unsigned)(((size_t)w4 * plane + (size_t)yo * W + x) * 4) : OOB;
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsE, (int)off, 0, 0);
+                    }
+                }
+                if constexpr (MODE == 0) {
+                    if (p.u8 && w4 == 3) {        // HWC bytes: 372 per strip row, one wave quantises them from the staged fp32 values (save_image rule)
+                        const int nbytes = row_ok ? min(TS, W - xs) * 3 : 0;
+                        if ((W & 3) == 0) {
+#pragma unroll
+                            for (int k = 0; k < 2; ++k) {
+                                const int d = lane + 64 * k;
+                                unsigned pk = 0;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const int bb = 4 * d + e, pxr = bb / 3, c = bb - 3 * pxr;
+                                    const float v = *(const float*)(os + c * G::YPLANE_B + ((pxr < TS ? pxr : 0) + MARG + 2) * 4);
+                                    pk |= (unsigned)ie_quant_u8(v) << (8 * e);
+                                }
+                                const unsigned off = (4 * d < nbytes) ? (unsigned)(((size_t)yo * W + xs) * 3 + 4 * d) : OOB;
+                                __builtin_amdgcn_raw_buffer_store_b32(pk, rsU, (int)off, 0, 0);
+                            }
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 6; ++k) {
+                                const int bb = lane + 64 * k, pxr = bb / 3, c = bb - 3 * pxr;
+                                const float v = *(const float*)(os + c * G::YPLANE_B + ((pxr < TS ? pxr : 0) + MARG + 2) * 4);
+                                const unsigned off = (bb < nbytes) ? (unsigned)(((size_t)yo * W + xs) * 3 + bb) : OOB;
+                                __builtin_amdgcn_raw_buffer_store_b8(ie_quant_u8(v), rsU, (int)off, 0, 0);
+                            }
+                        }
+                    }
+                }
+            }
+            issue_raw(t + 1 + PFR);                      // (2)
+            // (3) the curve's running value of the row in accF: row ys - 6 + t - cj = raw row of step t - 4 - cj; tile 1 reads what tile 0 left at step t - 1
+            const char* yin = cj ? smem + G::OFF_Y4 + ((t + 1) & 1) * G::YSLOT_B : smem + G::OFF_RAW + ((t + 4) % NRAW) * RAW_SLOT_B;
+            char* yout = cj ? smem + G::OFF_OUT + (t & 1) * G::YSLOT_B : smem + G::OFF_Y4 + (t & 1) * G::YSLOT_B;
+            float v[4], e[4], u[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[j] = *(const float*)(yin + yin_off[j]); e[j] = 0.f; u[j] = 0.f; }
+            // the 24 curve maps (optional output, MODE 0) leave straight from the lane that computed them: NCHW fp32, plane 3 (4 cj + i) + colour
+            unsigned aj_off[4] = {OOB, OOB, OOB, OOB};
+            if constexpr (MODE == 0) {
+                if (p.adjust) {
+                    const int yc = ys - 6 + t - cj;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int q = 16 * (4 * hf + j) + p16, x = xc0 + q;
+                        const bool ok = (yc >= ys) && (yc < ye) && kq < 3 && q >= MARG && q < TW - MARG && x < W;
+                        aj_off[j] = ok ? (unsigned)(((size_t)(12 * cj + kq) * plane + (size_t)yc * W + x) * 4) : OOB;
+                    }
+                }
+            }
+            // filler o of 96: k = o / 24 (curve iteration 4 cj + k), op = (o % 24) / 4, tile = o % 4;  tanh(x) = 1 - 2 / (exp(2x) + 1) (ie_tanh_fast)
+            auto op = [&](int o) __attribute__((always_inline)) {
+                const int k = o / 24, w = (o % 24) >> 2, j = o & 3;
+                if (w == 0) e[j] = __builtin_amdgcn_exp2f(accF[j][k]);
+                if (w == 1) e[j] = e[j] + 1.0f;
+                if (w == 2) e[j] = __builtin_amdgcn_rcpf(e[j]);
+                if (w == 3) {
+                    e[j] = __builtin_fmaf(e[j], -2.0f, 1.0f);       // r_{4 cj + k}
+                    if constexpr (MODE == 0) {                        // (an absent `adjust` has an empty descriptor range and out-of-range offsets: the store is dropped)
+                        const unsigned off = aj_off[j] == OOB ? OOB : aj_off[j] + (unsigned)((size_t)(3 * k) * plane * 4);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(e[j]), rsJ, (int)off, 0, 0);
+                    }
+                }
+                if (w == 4) u[j] = __builtin_fmaf(v[j], v[j], -v[j]);
+                if (w == 5) v[j] = __builtin_fmaf(e[j], u[j], v[j]);
+            };
+            // (4) the x1 / x6 rows handed over by stage A at step t - 1 - cj into the three live sets: two 36-MFMA streams, fillers 4 per 3 MFMAs
+            const int hs = ((t + 2 - cj) % NRH) * ROW_B;
+            auto fill1 = [&](int s) __attribute__((always_inline)) {
+#pragma unroll
+                for (int o = (s * 4) / 3; o < ((s + 1) * 4) / 3; ++o) op(o);
+            };
+            auto fill6 = [&](int s) __attribute__((always_inline)) {
+#pragma unroll
+                for (int o = ((s + 36) * 4) / 3; o < ((s + 37) * 4) / 3; ++o) op(o);
+            };
+            mfma_row<TH>(smem + G::OFF_H1 + hs, rr, wv, accN, accM, accO, true, bias7, fill1);
+            mfma_row<TH>(smem + G::OFF_H6 + hs, rr, wv + 9, accN, accM, accO, false, bias7, fill6);
+            // (5) the running values go on: to the tile-1 waves (exchange row) or into the staged output row
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *(float*)(yout + yout_off[j]) = v[j];
+        };
+        // tile-1 waves run one step behind: they see step index t - 1 (their step -1 works on rows that are never stored)
+        for (int t = 0; t < n_steps; t += 4) {      // (N, M, O, F) -> (F, N, M, O)
+            step_b(t, a0, a1, a2, a3);
+            if (t + 1 < n_steps) step_b(t + 1, a3, a0, a1, a2);
+            if (t + 2 < n_steps) step_b(t + 2, a2, a3, a0, a1);
+            if (t + 3 < n_steps) step_b(t + 3, a1, a2, a3, a0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+#define IE_DEF_K67X(NAME, TA0, TA1, TH, MODE) \
+    __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void NAME(K67XParams p) { k67x_body<TA0, TA1, TH, MODE>(p); }
+IE_DEF_K67X(zdce_k67x_conv1_conv6_conv7_curve_f16, _Float16, _Float16, _Float16, 0)
+IE_DEF_K67X(zdce_k67x_conv1_conv6_conv7_curve_bf16, __bf16, __bf16, __bf16, 0)
+IE_DEF_K67X(zdce_k67x_conv1_conv6_conv7_curve_mix, _Float16, __bf16, _Float16, 0)
+IE_DEF_K67X(zdce_k67x_conv1_conv6_conv7_curve_e_f16, _Float16, _Float16, _Float16, 1)
+IE_DEF_K67X(zdce_k67x_conv1_conv6_conv7_curve_e_bf16, __bf16, __bf16, __bf16, 1)
+IE_DEF_K67X(zdce_k67x_conv1_conv6_conv7_curve_e_mix, _Float16, __bf16, _Float16, 1)
+#undef IE_DEF_K67X
+
+}  // namespace
+
+int ie_zdce_launch_x(const ZdceXLaunch& a, hipStream_t st) {
+    if ((size_t)a.H * a.W * 32 * 2 >= 0x7fffffffull) IE_FAIL(IE_ERR_UNSUPPORTED, "zdce x: frame too large for 31-bit offsets");
+    const int strips = ie_cdiv(a.W, TS);
+    if (a.kind == 12) {
+        if (a.dt_h != IE_F16 && a.dt_h != IE_BF16) IE_FAIL(IE_ERR_UNSUPPORTED, "zdce k12x: dtype %d", a.dt_h);
+        K12XParams p;
+        memset(&p, 0, sizeof(p));
+        p.img = a.img; p.w1 = a.w1; p.b1 = a.b1; p.w2 = a.w2; p.b2 = a.b2; p.dst = a.x2;
+        p.H = a.H; p.W = a.W; p.y_begin = a.y_begin; p.y_end = a.y_end; p.n_begin = a.n_begin; p.strips = strips;
+        // 50 KiB of LDS and 128 VGPRs: two workgroups per CU = 512 slots; as few row chunks as fill them (every chunk re-runs 8 apron rows)
+        const int rows = a.y_end - a.y_begin;
+        long long chunks = 512 / ((long long)strips * a.n_count);
+        if (chunks < 1) chunks = 1;
+        if (chunks > (rows + 7) / 8) chunks = (rows + 7) / 8;
+        p.rows_per_block = ie_cdiv(rows, (int)chunks);
+        p.chunks = ie_cdiv(rows, p.rows_per_block);
+        const long long blocks = (long long)strips * p.chunks * a.n_count;
+        if (blocks <= 0 || blocks > 0x7fffffffLL) IE_FAIL(IE_ERR_INVALID, "zdce k12x: bad grid %lld", blocks);
+        typedef void (*Fn)(K12XParams);
+        const Fn fn = a.dt_h == IE_F16 ? zdce_k12x_conv1_conv2_f16 : zdce_k12x_conv1_conv2_bf16;
+        const int lds = a.dt_h == IE_F16 ? K12XGeom<_Float16>::LDS_B : K12XGeom<__bf16>::LDS_B;
+        void* args[] = {(void*)&p};
+        IE_HIP_CHECK(hipLaunchKernel((const void*)fn, dim3((unsigned)blocks), dim3(512), args, lds, st));
+        return IE_OK;
+    }
+    if (a.kind != 67) IE_FAIL(IE_ERR_INVALID, "zdce x: kind %d", a.kind);
+    if (a.adjust && (size_t)a.H * a.W * 24 * 4 >= 0x7fffffffull) IE_FAIL(IE_ERR_UNSUPPORTED, "zdce k67x: frame too large for 31-bit offsets into `adjust`");
+    K67XParams p;
+    memset(&p, 0, sizeof(p));
+    p.img = a.img; p.x2 = a.x2; p.x5 = a.x5; p.w1 = a.w1; p.b1 = a.b1; p.w6 = a.w6; p.b6 = a.b6; p.w7 = a.w7; p.b7 = a.b7;
+    p.enhanced = a.enhanced; p.adjust = a.adjust; p.u8 = a.u8;
+    p.H = a.H; p.W = a.W; p.y_begin = a.y_begin; p.y_end = a.y_end; p.n_begin = a.n_begin; p.strips = strips;
+    p.rows_per_block = a.rows_per_block;
+    p.chunks = ie_cdiv(a.y_end - a.y_begin, a.rows_per_block);
+    const long long blocks = (long long)strips * p.chunks * a.n_count;
+    if (blocks <= 0 || blocks > 0x7fffffffLL) IE_FAIL(IE_ERR_INVALID, "zdce k67x: bad grid %lld", blocks);
+    typedef void (*Fn)(K67XParams);
+    const bool fast = a.enhanced && !a.adjust && !a.u8 && (a.W & 3) == 0 && ((size_t)a.enhanced & 15) == 0;
+    const bool h_all = a.dt_h == IE_F16 && a.dt_a0 == IE_F16 && a.dt_a1 == IE_F16;
+    const bool b_all = a.dt_h == IE_BF16 && a.dt_a0 == IE_BF16 && a.dt_a1 == IE_BF16;
+    const bool mix = a.dt_h == IE_F16 && a.dt_a0 == IE_F16 && a.dt_a1 == IE_BF16;
+    Fn fn = nullptr;
+    if (h_all) fn = fast ? zdce_k67x_conv1_conv6_conv7_curve_e_f16 : zdce_k67x_conv1_conv6_conv7_curve_f16;
+    else if (b_all) fn = fast ? zdce_k67x_conv1_conv6_conv7_curve_e_bf16 : zdce_k67x_conv1_conv6_conv7_curve_bf16;
+    else if (mix) fn = fast ? zdce_k67x_conv1_conv6_conv7_curve_e_mix : zdce_k67x_conv1_conv6_conv7_curve_mix;
+    if (!fn) IE_FAIL(IE_ERR_UNSUPPORTED, "zdce k67x: dtypes x2=%d x5=%d h=%d", a.dt_a0, a.dt_a1, a.dt_h);
+    const int lds = a.dt_h == IE_F16 ? K67XGeom<_Float16>::LDS_B : K67XGeom<__bf16>::LDS_B;
+    IE_GRANT_LDS(fn, lds);
+    void* args[] = {(void*)&p};
+    IE_HIP_CHECK(hipLaunchKernel((const void*)fn, dim3((unsigned)blocks), dim3(512), args, lds, st));
+    return IE_OK;
+}

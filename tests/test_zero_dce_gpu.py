@@ -101,18 +101,38 @@ def test_kernel_variants_bit_identical(variant, dtype, base):
     (on both the fused and the one-kernel-per-layer schedule)."""
     sd, g = load_golden(zero_dce_goldens()[-1])
     x = torch.from_numpy(g["image"]).cuda()
+    if variant == capi.VAR_NO_K345 and not base:
+        base = capi.VAR_P_SCHEDULE         # the two-kernel middle belongs to the round-3 schedule (P = W7a * x1 + b7 through HBM): compared inside it
     a = _model(sd, dtype, base).forward({"image": x})
     b = _model(sd, dtype, base | variant).forward({"image": x})
     assert torch.equal(a["enhanced"], b["enhanced"]) and torch.equal(a["adjust"], b["adjust"])
 
 
 @pytest.mark.parametrize("dtype", ["f16", "bf16", "bf16_pure"])
+@pytest.mark.parametrize("path", zero_dce_goldens(), ids=lambda p: p.split("zero_dce_")[-1][:-4])
+def test_round3_schedule_golden_parity(path, dtype):
+    """IE_ZDCE_VAR_P_SCHEDULE (K12 writes P = W7a * x1 + b7, the last kernel adds the x6 half; kept for A/B) meets the same bounds as the shipped
+    schedule, which recomputes x1 in the last kernel and contracts e_conv7 over both sources in fp32 (zero_dce.py:182-183) -- and the two agree to the
+    rounding of P."""
+    sd, g = load_golden(path)
+    x = torch.from_numpy(g["image"]).cuda()
+    a = _model(sd, dtype).forward({"image": x})
+    b = _model(sd, dtype, capi.VAR_P_SCHEDULE).forward({"image": x})
+    tol = _tol(path, dtype)
+    assert rel_err(b["enhanced"].cpu(), g["enhanced"]) <= tol and rel_err(b["adjust"].cpu(), g["adjust"]) <= 5 * tol
+    assert rel_err(a["enhanced"].cpu(), b["enhanced"].cpu()) <= tol and rel_err(a["adjust"].cpu(), b["adjust"].cpu()) <= 5 * tol
+    # x2 leaves the two first kernels with the same bits (same operands, same contraction order per row)
+    ma, mb = _model(sd, dtype), _model(sd, dtype, capi.VAR_P_SCHEDULE)
+    ma.enhance(x); mb.enhance(x)
+    assert rel_err(ma.feature(2).cpu(), mb.feature(2).cpu()) <= (1e-3 if dtype != "bf16_pure" else 8e-3)
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16", "bf16_pure"])
 @pytest.mark.parametrize("shape", [(2, 37, 132), (1, 140, 256), (3, 9, 260), (1, 5, 4)])
 def test_last_kernel_output_modes_agree(shape, dtype):
-    """The last kernel is compiled four times: for `enhanced` alone with W % 4 == 0 (zdce_k67n_*_e_*, the throughput path), for `enhanced` + the curve
-    maps (zdce_k67n_*_ea_*, model.forward()), for the uint8 HWC output alone (zdce_k67n_*_u8_*, the uint8 pipeline) and for any combination of outputs /
-    any width.  Same arithmetic: the
-    same bits, whichever outputs are asked for."""
+    """The last kernel is compiled several times: for `enhanced` alone with W % 4 == 0 (zdce_k67x_*_e_*, the throughput path), for `enhanced` + the curve
+    maps (model.forward()), for the uint8 HWC output alone (the uint8 pipeline) and for any combination of outputs / any width.  Same arithmetic: the
+    same bits, whichever outputs are asked for -- on the shipped schedule and on the round-3 one (zdce_k67n_*)."""
     n, h, w = shape
     sd = o_zdce.init_state_dict(seed=13, gain=3.0)
     x = torch.rand(n, 3, h, w, generator=torch.Generator().manual_seed(8)).cuda()
@@ -152,7 +172,7 @@ def test_last_kernel_round2_form(dtype):
     form (rows permuted and scaled by 2 / ln 2 on the host, curve in registers): both inside the bound, and close to each other."""
     sd, g = load_golden(zero_dce_goldens()[-1])
     x = torch.from_numpy(g["image"]).cuda()
-    a = _model(sd, dtype).forward({"image": x})
+    a = _model(sd, dtype, capi.VAR_P_SCHEDULE).forward({"image": x})
     b = _model(sd, dtype, capi.VAR_K67_LEGACY).forward({"image": x})
     tol = _tol(zero_dce_goldens()[-1], dtype)
     assert rel_err(b["enhanced"].cpu(), g["enhanced"]) <= tol and rel_err(a["enhanced"].cpu(), g["enhanced"]) <= tol
