@@ -42,5 +42,6 @@ struct ZdceXLaunch {
     const void* w7; const float* b7;     // K67X: e_conv7 over [x1, x6], rows permuted (chan_k67) and scaled by 2 / ln 2: [tile][18][lane][8]; bias in row order
     float* enhanced; float* adjust; unsigned char* u8;
     int N, H, W, y_begin, y_end, n_begin, n_count, rows_per_block;
+    void* stamps;        // diagnostic builds only
 };
 int ie_zdce_launch_x(const ZdceXLaunch& a, hipStream_t st);

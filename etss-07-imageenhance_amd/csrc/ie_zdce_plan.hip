@@ -476,6 +476,7 @@ static int forward_mfma(ie_zdce_plan* p, const float* image, float* enhanced, fl
                     a.w1 = p->d_w + p->off_w1x; a.b1 = B_(0); a.w2 = W_(1); a.b2 = B_(1); a.w6 = W_(5); a.b6 = B_(5);
                     a.w7 = p->d_w + p->off_w7x; a.b7 = (const float*)(p->d_w + p->off_b7x);
                     a.dt_h = p->xdt[1]; a.dt_a0 = p->xdt[2]; a.dt_a1 = p->xdt[5];
+                    a.stamps = g_ie_stamps ? (void*)((unsigned long long*)g_ie_stamps + (size_t)(kind == 12 ? 0 : 2) * (1u << 20)) : nullptr;
                     if (kind == 12) { a.y_begin = lo(2); a.y_end = hi(2); }
                     else { a.enhanced = enhanced; a.adjust = adjust; a.u8 = u8; a.y_begin = b0; a.y_end = b1; }
                     return ie_zdce_launch_x(a, st);

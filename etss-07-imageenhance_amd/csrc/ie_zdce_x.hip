@@ -25,12 +25,18 @@ namespace {
 constexpr int TW = 128, MARG = 2, TS = 124;    // computed / dropped-per-side / stored columns of a strip (no halo columns are loaded: each layer simply
                                                // does not use the outermost computed column of the one before; e_conv1 has the image's halo)
 constexpr int PXB = 64;                        // one pixel of a 32-channel 16-bit tensor
-constexpr int ROW_B = TW * PXB;                // 8,192
+constexpr int ROW_B = TW * PXB;                // 8,192: parked output rows (pixel q at index q)
+constexpr int ROWH_B = (TW + 2) * PXB;         // 8,320: rows that feed a convolution: pixel q at index q + 1, so that taps q - 1 .. q + 1 of EVERY tile are base + immediate
+                                               // (the two end pixels are never written: they only feed the dropped columns 0 and 127)
 constexpr int IPX = 136, IPB = 8;              // converted image row: [136 px][R, G, B, 0] 16-bit; pixel i = image column xc0 - 1 + i (fragments read up to pixel 134)
 constexpr int IMG_PART_B = IPX * IPB;          // 1,088 (bf16 operands: a hi and a lo part, so the fp32 pixel survives bf16's 8 mantissa bits)
 constexpr int RAW_SLOT_B = 2048;               // three fp32 plane rows of 136 pixels = 1,632 bytes (8 DMA instructions x 256 bytes)
 constexpr unsigned OOB = 0x80000000u;
 
+#ifndef IE_XEXP
+#define IE_XEXP 0     // K67X timing experiments (WRONG results), tools/exp_build.sh ie_zdce_x.hip <tag> -DIE_XEXP=bits: 1 no curve fillers, 2 no e_conv1 / row conversion,
+#endif                // 4 no hand-off writes, 8 no x2 / x5 DMA, 16 no image DMA / output stores, 32 no e_conv6 MFMAs, 64 no e_conv7 MFMAs, 128 curve without its transcendentals,
+                      // 256 transcendentals only, 512 transcendentals replaced by v_fma
 #define IE_SB() __builtin_amdgcn_sched_barrier(0)
 typedef __attribute__((address_space(3))) void* lds_ptr;
 
@@ -61,16 +67,21 @@ template <typename T> __device__ __forceinline__ void convert_row(const char* ra
 
 // a finished row (ReLU, 16 bits, zero where `keep` says the pixel lies outside the image = the next layer's zero padding) into an LDS row image as 16-byte
 // pieces: lanes l / l + 16 exchange halves, so a ds_write_b128 serves 8 consecutive pixels x 16 bytes (every bank once).  Wave = (cout fragment cf, half hf).
-template <typename T> __device__ __forceinline__ void put_row(const ie_f32x4 (&acc)[4], char* base, int em_off, unsigned keep) {
+template <typename T, bool MASKED = true> __device__ __forceinline__ void put_row(const ie_f32x4 (&acc)[4], char* base, int em_off, unsigned keep) {
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
         const ie_u32x2 a = {ie_pack2_relu<T>(acc[2 * jj][0], acc[2 * jj][1]), ie_pack2_relu<T>(acc[2 * jj][2], acc[2 * jj][3])};
         const ie_u32x2 b2 = {ie_pack2_relu<T>(acc[2 * jj + 1][0], acc[2 * jj + 1][1]), ie_pack2_relu<T>(acc[2 * jj + 1][2], acc[2 * jj + 1][3])};
         const auto sx = __builtin_amdgcn_permlane16_swap(a[0], b2[0], false, false);
         const auto sy = __builtin_amdgcn_permlane16_swap(a[1], b2[1], false, false);
-        const bool k = (keep >> jj) & 1u;
+        const bool k = !MASKED || ((keep >> jj) & 1u);
         *(ie_u32x4*)(base + em_off + jj * 32 * PXB) = ie_u32x4{k ? sx[0] : 0u, k ? sy[0] : 0u, k ? sx[1] : 0u, k ? sy[1] : 0u};
     }
+}
+// this lane's 16-byte piece of tile pair 0 in a row image whose pixel q sits at index q + halo; pair 1 is 32 pixels on.  Wave = (cout fragment cf, half hf).
+__device__ __forceinline__ int put_off(int cf, int hf, int p16, int kq, int halo) {
+    const int P = 16 * (4 * hf + (kq & 1)) + p16 + halo;
+    return P * PXB + (((2 * cf + (kq >> 1)) ^ ((P >> 1) & 3)) << 4);
 }
 
 // e_conv1 of one converted image row into three rotating accumulator sets: K = 8 kx taps x 4 channels per MFMA (taps 3..7 and channel 3 carry zero weights),
@@ -94,41 +105,39 @@ template <typename T> __device__ __forceinline__ void conv1_row(const char* img_
     }
 }
 
-// fragment offsets of a 128-pixel LDS row image for the wave's half hf: tile 0 / the other tiles / the last tile's right tap (the two out-of-strip columns are
-// clamped: they only feed dropped columns)
-struct RowRead { int rd0[3], rd1[3], rd23; };
+// Fragment reads of a halo row image (pixel q at index q + 1): lane (p16, kq) of the wave's half hf reads chunk kq of pixel 64 hf + 16 j + p16 + kx - 1 for tile j
+// and tap column kx: base[kx] + 1024 j -- three address registers, every tile an immediate (the 16-byte chunks of pixel P are XOR-swizzled by (P >> 1) & 3, which
+// does not depend on the tile: conflict-free ds_read_b128 at every tap offset).
+struct RowRead { int base[3]; };
 __device__ __forceinline__ RowRead row_read(int hf, int p16, int kq) {
-    auto lds_px = [&](int q) __attribute__((always_inline)) { return q * PXB + ((kq ^ ((q >> 1) & 3)) << 4); };
-    auto fix = [&](int q) __attribute__((always_inline)) { return min(max(q, 0), TW - 1); };
     RowRead r;
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
-        r.rd1[kx] = lds_px(16 * (4 * hf + 1) + p16 + kx - 1);
-        r.rd0[kx] = lds_px(fix(16 * (4 * hf) + p16 + kx - 1));
+        const int P = 64 * hf + p16 + kx;
+        r.base[kx] = P * PXB + ((kq ^ ((P >> 1) & 3)) << 4);
     }
-    r.rd23 = lds_px(fix(16 * (4 * hf + 3) + p16 + 1));
     return r;
 }
-__device__ __forceinline__ int row_off(const RowRead& r, int g) {       // g = (kx, tile)
-    const int kx = g >> 2, j = g & 3;
-    return j == 0 ? r.rd0[kx] : ((kx == 2 && j == 3) ? r.rd23 : r.rd1[kx] + 1024 * (j - 1));
-}
 
-// One source row (32 channels) into three rotating accumulator sets: 12 fragments read three ahead, 36 MFMAs in a pinned order; fill(s) is placed behind MFMA s
-// (a wave's vector work is close to free between its OWN MFMAs and costs its full length as a phase of its own: tools/micro/coissue.hip).
+// One source row (32 channels) into three rotating accumulator sets: 12 fragments read AHEAD ahead, 36 MFMAs in a pinned order; fill(s) is placed behind MFMA s
+// (a wave's vector work is close to free between its OWN MFMAs while the gap's issue costs stay under the MFMA's 16 cycles -- 8 for the MFMA itself, 4 per vector
+// instruction, 8 per transcendental one -- and costs its full length as a phase of its own: tools/micro/coissue.hip, MI355X_MICROARCH.md constants table).
+// The fragment read of a group comes right behind the group's first MFMA, so a gap that ends in a transcendental filler is followed by an MFMA, not by a vector
+// instruction (hipcc puts an s_nop between the two, another 4 cycles of the issue port).
 template <typename T, int AHEAD = 3, typename F>
 __device__ __forceinline__ void mfma_row(const char* slot, const RowRead& rr, const ie_u32x4* wv, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4],
                                          bool first, const ie_f32x4& init, F&& fill) {
     ie_u32x4 bx[12];
-    auto rd = [&](int g) __attribute__((always_inline)) { bx[g] = *(const ie_u32x4*)(slot + row_off(rr, g)); };
+    const char* bk[3] = {slot + rr.base[0], slot + rr.base[1], slot + rr.base[2]};
+    auto rd = [&](int g) __attribute__((always_inline)) { bx[g] = *(const ie_u32x4*)(bk[g >> 2] + 1024 * (g & 3)); };
 #pragma unroll
     for (int g = 0; g < AHEAD; ++g) rd(g);
     IE_SB();
 #pragma unroll
     for (int g = 0; g < 12; ++g) {
         const int kx = g >> 2, j = g & 3;
-        if (g + AHEAD < 12) rd(g + AHEAD);
         accN[j] = ie_mfma16_raw<T>(wv[0 * 3 + kx], bx[g], (first && kx == 0) ? init : accN[j]);
+        if (g + AHEAD < 12) rd(g + AHEAD);
         fill(3 * g);
         IE_SB();
         accM[j] = ie_mfma16_raw<T>(wv[1 * 3 + kx], bx[g], accM[j]);
@@ -151,8 +160,8 @@ struct K12XParams {
 template <typename T> struct K12XGeom {
     static constexpr int PFR = 2, NRAW = PFR + 1, NRI = 2, NRH = 3, NPARK = 2;
     static constexpr int IMG_ROW_B = parts_of<T>() * IMG_PART_B;
-    static constexpr int OFF_RAW = 0, OFF_IMG = OFF_RAW + NRAW * RAW_SLOT_B, OFF_H = OFF_IMG + NRI * IMG_ROW_B, OFF_PARK = OFF_H + NRH * ROW_B;
-    static constexpr int OFF_DUMP = OFF_PARK + NPARK * ROW_B, LDS_B = OFF_DUMP + 1024;        // f16: 6,144 + 2,176 + 24,576 + 16,384 + 1,024 = 50,304: two workgroups per CU
+    static constexpr int OFF_RAW = 0, OFF_IMG = OFF_RAW + NRAW * RAW_SLOT_B, OFF_H = OFF_IMG + NRI * IMG_ROW_B, OFF_PARK = OFF_H + NRH * ROWH_B;
+    static constexpr int OFF_DUMP = OFF_PARK + NPARK * ROW_B, LDS_B = OFF_DUMP + 1024;        // f16: 6,144 + 2,176 + 24,960 + 16,384 + 1,024 = 50,688: two workgroups per CU
 };
 
 template <typename T>
@@ -193,11 +202,10 @@ __device__ __forceinline__ void k12x_body(const K12XParams& p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) bias4[i] = bp[16 * cf + 4 * kq + i];
     }
-    int em_off;
+    const int em_off = put_off(cf, hf, p16, kq, stg == 0 ? 1 : 0);      // stage A writes the hand-off ring (halo rows), stage B the parked rows
     unsigned em_in = 0;
     {
         const int q = 16 * (4 * hf + (kq & 1)) + p16;
-        em_off = q * PXB + (((2 * cf + (kq >> 1)) ^ ((q >> 1) & 3)) << 4);
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
             const int x = xc0 + q + 32 * jj;
@@ -244,7 +252,7 @@ __device__ __forceinline__ void k12x_body(const K12XParams& p) {
             convert(t + 1);                              // next step's image row (its ring slot was last read at step t - 1)
             issue_raw(t + 1 + PFR);
             const int m = ys - 3 + t;                    // the x1 row finished now; outside the image it is e_conv2's zero padding
-            put_row<T>(accO, smem + G::OFF_H + (t % NRH) * ROW_B, em_off, (m >= 0 && m < H) ? em_in : 0u);
+            put_row<T>(accO, smem + G::OFF_H + (t % NRH) * ROWH_B, em_off, (m >= 0 && m < H) ? em_in : 0u);
         };
         for (int t = 0; t < n_steps; t += 3) {
             step_a(t, a0, a1, a2);
@@ -274,7 +282,7 @@ __device__ __forceinline__ void k12x_body(const K12XParams& p) {
             const char* islot = smem + G::OFF_PARK + ((t + 1) % NPARK) * ROW_B;        // parked at step t - 1
             put_row<T>(accN, smem + G::OFF_PARK + (t % NPARK) * ROW_B, em_off, 0x3u);
             auto nofill = [&](int) __attribute__((always_inline)) {};
-            mfma_row<T, 3>(smem + G::OFF_H + ((t + 1) % NRH) * ROW_B, rr, wv, accN, accM, accO, true, bias4, nofill);     // (a third fragment ahead costs the second workgroup per CU)
+            mfma_row<T, 3>(smem + G::OFF_H + ((t + 1) % NRH) * ROWH_B, rr, wv, accN, accM, accO, true, bias4, nofill);     // (a third fragment ahead costs the second workgroup per CU)
             // the leaving row is read AFTER the MFMA stream (its slot is not written during this step): 8 registers that do not have to live across it
             ie_u32x4 ln[2];
 #pragma unroll
@@ -299,36 +307,63 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // K67X: e_conv1 (recomputed) + e_conv6 + e_conv7 + tanh + LE curve -> enhanced
 // ==========================================================================================================================================
 // Stage A (waves 0-3 = 2 cout fragments x 2 strip halves): e_conv1 on the image row (12 MFMAs, as in K12X) and e_conv6 on [x2, x5] (72 MFMAs, rows by LDS-DMA);
-//   both finished rows (same row index) go to stage B through 3-slot LDS rings.
+//   both finished rows (same row index) go to stage B through 3-slot LDS rings.  Stage A also carries every chore of the step that is not stage B's own
+//   arithmetic -- ALL the DMA issue (x2, x5, the raw image row), the image row conversion and the `enhanced` stores: in-kernel stamps of the first build had
+//   stage B as the step's critical chain with stage A waiting 1,100 of 4,000 cycles at the barrier (profiles/r04/k67x_experiments.log).
 // Stage B (waves 4-7 = 2 row tiles of e_conv7 x 2 strip halves): e_conv7 over [x1, x6] (72 MFMAs per wave and row).  e_conv7's 24 output rows are permuted on
-//   the host (ie_zdce_plan.hip, chan_k67): row 4 kq + i of 16-row tile j is curve map r_{4j+i} of colour kq (kq = 3: zero rows), and scaled by 2 / ln 2, so after
+//   the host (ie_zdce_plan.hip): row 4 kq + i of 16-row tile j is curve map r_{4j+i} of colour kq (kq = 3: zero rows), and scaled by 2 / ln 2, so after
 //   the MFMAs lane (pixel, kq) of a tile-j wave holds r_{4j} .. r_{4j+3} of ONE colour of its pixel as log2(e) * 2x: tanh = 1 - 2 / (exp2(acc) + 1) and four
 //   curve steps (zero_dce.py:183-188) run straight off the accumulators.  The curve is a chain over the eight maps, so the tile-1 waves run ONE STEP BEHIND the
 //   tile-0 waves: tile 0 takes the fp32 pixel from the raw image ring through iterations 0-3 and leaves y4 in a small LDS exchange row, tile 1 picks it up a step
 //   later (its own finished row is that same image row then), runs iterations 4-7 and stages the result; staged rows leave a step later as 16-byte vectors.
 //   The 96 tanh / curve operations of a wave's finished row ride as fillers behind fixed MFMAs of the next step's 72-MFMA stream; FOUR accumulator sets rotate
 //   (the finished row is only read while the set freed a step earlier restarts from the bias).
-// Stage B's waves also issue the image row DMA (2 instructions per wave and step); stage A's waves convert the landed row one step ahead of e_conv1.
 struct K67XParams {
     const float* img; const void* x2; const void* x5;
     const void* w1; const float* b1; const void* w6; const float* b6; const void* w7; const float* b7;
     float* enhanced; float* adjust; unsigned char* u8;
     int H, W, y_begin, y_end, rows_per_block, strips, chunks, n_begin;
+    unsigned long long* stamps;   // diagnostic builds (-DIE_STAMP) only: [block][wave][8] cycle sums
 };
+
+#ifdef IE_STAMP
+#define IE_T(var) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define IE_TACC(i) do { unsigned long long now_; IE_T(now_); st_acc[i] += now_ - st_last; st_last = now_; } while (0)
+#else
+#define IE_TACC(i) do { } while (0)
+#endif
+#ifndef IE_K67X_HEAD
+#define IE_K67X_HEAD 8      // MFMA gaps at the head of stage B's stream that carry no curve work
+#endif
+#ifndef IE_K67X_AHA
+#define IE_K67X_AHA 3       // fragments read ahead of their MFMAs in stage A's / stage B's streams (each one in flight = 4 VGPRs; a stream alone is bound by the LDS
+#endif                      // latency its reads in flight cover: stage A alone ran 22.6 cycles per MFMA at 3, stamps in profiles/r04/k67x_experiments.log)
+#ifndef IE_K67X_AHB
+#define IE_K67X_AHB 3
+#endif
+#ifndef IE_K67X_PRIO
+#define IE_K67X_PRIO 0      // s_setprio level of stage B's waves (the younger half of the workgroup loses the vector-issue arbitration at equal priority)
+#endif
 
 template <typename TH> struct K67XGeom {
     static constexpr int PF = 3, NRA = PF + 1;           // x2 / x5 rows of DMA issued ahead, ring slots
-    static constexpr int PFR = 2, NRAW = 8;              // raw image rows issued ahead; a raw row is read by the conversion (step u - 1) and by the curve (step u + 4)
+    static constexpr int PFR = 2, NRAW = 8;              // raw image rows issued ahead; the raw row of step u is read by the conversion (step u - 1) and by the curve (step u + 4)
     static constexpr int NRI = 2, NRH = 3;
     static constexpr int IMG_ROW_B = parts_of<TH>() * IMG_PART_B;
     static constexpr int YPLANE_B = 132 * 4, YSLOT_B = 4 * YPLANE_B;      // fp32 [colour (+ a spare plane for lane group kq = 3)][pixel q at float q + 2]
-    static constexpr int OFF_X2 = 0, OFF_X5 = OFF_X2 + NRA * ROW_B, OFF_H6 = OFF_X5 + NRA * ROW_B, OFF_H1 = OFF_H6 + NRH * ROW_B;
-    static constexpr int OFF_RAW = OFF_H1 + NRH * ROW_B, OFF_IMG = OFF_RAW + NRAW * RAW_SLOT_B, OFF_Y4 = OFF_IMG + NRI * IMG_ROW_B;
+    static constexpr int OFF_X2 = 0, OFF_X5 = OFF_X2 + NRA * ROWH_B, OFF_H6 = OFF_X5 + NRA * ROWH_B, OFF_H1 = OFF_H6 + NRH * ROWH_B;
+    static constexpr int OFF_RAW = OFF_H1 + NRH * ROWH_B, OFF_IMG = OFF_RAW + NRAW * RAW_SLOT_B, OFF_Y4 = OFF_IMG + NRI * IMG_ROW_B;
     static constexpr int OFF_OUT = OFF_Y4 + 2 * YSLOT_B, OFF_DUMP = OFF_OUT + 2 * YSLOT_B, LDS_B = OFF_DUMP + 1024;
-    // f16: 65,536 + 49,152 + 16,384 + 2,176 + 4,224 + 4,224 + 1,024 = 142,720 bytes: one workgroup per CU
+    // f16: 66,560 + 49,920 + 16,384 + 2,176 + 4,224 + 4,224 + 1,024 = 144,512 bytes: one workgroup per CU
+    // vector-memory operations of a stage-A wave per step, in issue order: [enhanced store (waves 0-2)] raw x 2, x2 x 2, x5 x 2.  At the barrier of step t the raw row
+    // t + 1 (issued first in step t - PFR) and the x2 / x5 rows t (issued in step t - PF) must have landed: at most min(4 + (PFR - 1) S, (PF - 1) S) younger
+    // operations may be outstanding, S = 6 or 7 (8 on the scalar store path: the count for S = 6 is safe for all)
+    static constexpr int WAIT_A = (4 + (PFR - 1) * 6) < (PF - 1) * 6 ? (4 + (PFR - 1) * 6) : (PF - 1) * 6;
 };
 
-// MODE 0: any mix of enhanced / adjust / u8, any width.  MODE 1: `enhanced` fp32 as the only output, W % 4 == 0 (the throughput path: no output-mode branches).
+// MODE (what the kernel is compiled for; same arithmetic, same bits): 0 any mix of enhanced / adjust / u8, any width; 1 `enhanced` fp32 alone, W % 4 == 0 and 16-byte
+// aligned (the throughput path: no output-mode branches); 2 enhanced + the 24 curve maps, W % 4 == 0 (what model.forward() returns); 3 the uint8 HWC image alone
+// (the uint8 pipeline).
 template <typename TA0, typename TA1, typename TH, int MODE>
 __device__ __forceinline__ void k67x_body(const K67XParams& p) {
     using G = K67XGeom<TH>;
@@ -351,14 +386,23 @@ __device__ __forceinline__ void k67x_body(const K67XParams& p) {
     const int n_steps = (ye - ys) + 8;
     const size_t plane = (size_t)H * W;
     const size_t frame_b = plane * PXB;
+#ifdef IE_STAMP
+    unsigned long long st_acc[7] = {0, 0, 0, 0, 0, 0, 0}, st_last = 0;
+    IE_T(st_last);
+#endif
 
     auto mk = [&](const void* base, size_t bytes) __attribute__((always_inline)) { return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000); };
     const RowRead rr = row_read(hf, p16, kq);
 
+#ifdef IE_ONLY_STAGE      // register-pressure diagnostic (tools/kregs.sh ... -DIE_ONLY_STAGE=0|1): compile one stage's code only
+    if (stg != IE_ONLY_STAGE) return;
+#endif
     if (stg == 0) {
         // ================================================================ stage A ================================================================
         const auto rs2 = mk((const char*)p.x2 + (size_t)n * frame_b, frame_b);
         const auto rs5 = mk((const char*)p.x5 + (size_t)n * frame_b, frame_b);
+        const auto rsI = mk((const char*)(p.img + (size_t)n * 3 * plane), 3 * plane * 4);
+        const auto rsE = mk(p.enhanced ? (const void*)(p.enhanced + (size_t)n * 3 * plane) : (const void*)p.w7, p.enhanced ? 3 * plane * 4 : 0);
         frag wv[18], w1[3];
 #pragma unroll
         for (int f = 0; f < 18; ++f) wv[f] = ((const frag*)p.w6)[(cf * 18 + f) * 64 + lane];
@@ -367,21 +411,33 @@ __device__ __forceinline__ void k67x_body(const K67XParams& p) {
         ie_f32x4 bias6, bias1;
 #pragma unroll
         for (int i = 0; i < 4; ++i) { bias6[i] = p.b6[16 * cf + 4 * kq + i]; bias1[i] = p.b1[16 * cf + 4 * kq + i]; }
-        // x2 / x5 rows: piece m = 2 w4 + j (16 pixels x 64 bytes); lane -> (pixel, LDS chunk position); the source chunk is the position's un-swizzled one
+        // x2 / x5 rows: piece m = 2 w4 + j (16 pixels x 64 bytes) lands at ring pixels 16 m + 1 ..; lane -> (pixel, LDS chunk position); the source chunk is the
+        // position's un-swizzled one
         unsigned body_xoff[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int q = (2 * w4 + j) * 16 + (lane >> 2);
-            const int s = (lane & 3) ^ ((q >> 1) & 3);
+            const int s = (lane & 3) ^ (((q + 1) >> 1) & 3);
             const int x = xc0 + q;
             body_xoff[j] = (x >= 0 && x < W) ? (unsigned)(x * PXB + s * 16) : OOB;
         }
-        auto issue = [&](int t) __attribute__((always_inline)) {
+        unsigned raw_off[2];
+        raw_offsets(w4, lane, xc0, W, plane, raw_off);
+        auto issue = [&](int t) __attribute__((always_inline)) {      // raw image row of step t - PF + 1 + PFR first, then the x2 / x5 rows of step t
+            {
+                const int tr = t - PF + 1 + PFR, yi = ys - 2 + tr;
+                const unsigned rmask = (yi >= 0 && yi < H) ? 0u : OOB;
+                const unsigned row_b = rmask ? 0u : (unsigned)yi * (unsigned)W * 4u;
+                char* slot = smem + G::OFF_RAW + (tr % NRAW) * RAW_SLOT_B;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsI, (lds_ptr)(slot + (4 * j + w4) * 256), 4, (int)((row_b + raw_off[j]) | rmask), 0, 0, 0);
+            }
             const int y = ys - 2 + t;
             const unsigned rmask = (y >= 0 && y < H) ? 0u : OOB;
             const unsigned row_b = rmask ? 0u : (unsigned)y * (unsigned)W * PXB;
-            char* s2 = smem + G::OFF_X2 + (t % NRA) * ROW_B;
-            char* s5 = smem + G::OFF_X5 + (t % NRA) * ROW_B;
+            char* s2 = smem + G::OFF_X2 + (t % NRA) * ROWH_B + PXB;
+            char* s5 = smem + G::OFF_X5 + (t % NRA) * ROWH_B + PXB;
 #pragma unroll
             for (int j = 0; j < 2; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (lds_ptr)(s2 + (2 * w4 + j) * 1024), 16, (int)((row_b + body_xoff[j]) | rmask), 0, 0, 0);
 #pragma unroll
@@ -394,79 +450,17 @@ __device__ __forceinline__ void k67x_body(const K67XParams& p) {
         int rdi[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) rdi[j] = (16 * (4 * hf + j) + p16 + 2 * kq) * IPB;
-        int em_off;
+        const int em_off = put_off(cf, hf, p16, kq, 1);
         unsigned em_in = 0;
         {
             const int q = 16 * (4 * hf + (kq & 1)) + p16;
-            em_off = q * PXB + (((2 * cf + (kq >> 1)) ^ ((q >> 1) & 3)) << 4);
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
                 const int x = xc0 + q + 32 * jj;
                 em_in |= (x >= 0 && x < W) ? (1u << jj) : 0u;
             }
         }
-        ie_f32x4 a0[4], a1[4], a2[4], e0[4], e1[4], e2[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { a0[j] = bias6; a1[j] = bias6; a2[j] = bias6; e0[j] = bias1; e1[j] = bias1; e2[j] = bias1; }
-
-#pragma unroll
-        for (int t = 0; t < PF; ++t) issue(t);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                    // prologue barrier: stage B waited for raw row 0
-        convert(0);
-        // step t: image / x2 / x5 row ys - 2 + t; the x1 and x6 rows ys - 3 + t are finished and handed over in slot t % 3
-        auto step_a = [&](int t, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4], ie_f32x4 (&eN)[4], ie_f32x4 (&eM)[4], ie_f32x4 (&eO)[4]) __attribute__((always_inline)) {
-            ie_wait_vm_imm<4 * (PF - 1)>();              // the x2 / x5 rows of step t have landed (behind them: the rows of steps t + 1 .. t + PF - 1)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            conv1_row<TH>(smem + G::OFF_IMG + (t % NRI) * G::IMG_ROW_B, rdi, w1, bias1, eN, eM, eO);
-            auto nofill = [&](int) __attribute__((always_inline)) {};
-            mfma_row<TA0>(smem + G::OFF_X2 + (t % NRA) * ROW_B, rr, wv, accN, accM, accO, true, bias6, nofill);
-            mfma_row<TA1>(smem + G::OFF_X5 + (t % NRA) * ROW_B, rr, wv + 9, accN, accM, accO, false, bias6, nofill);
-            issue(t + PF);
-            convert(t + 1);
-            const int m = ys - 3 + t;
-            const unsigned keep = (m >= 0 && m < H) ? em_in : 0u;
-            put_row<TH>(eO, smem + G::OFF_H1 + (t % NRH) * ROW_B, em_off, keep);
-            put_row<TH>(accO, smem + G::OFF_H6 + (t % NRH) * ROW_B, em_off, keep);
-        };
-        for (int t = 0; t < n_steps; t += 3) {
-            step_a(t, a0, a1, a2, e0, e1, e2);
-            if (t + 1 < n_steps) step_a(t + 1, a2, a0, a1, e2, e0, e1);
-            if (t + 2 < n_steps) step_a(t + 2, a1, a2, a0, e1, e2, e0);
-        }
-    } else {
-        // ================================================================ stage B ================================================================
-        const int cj = cf;                                  // this wave's 16-row tile of e_conv7 = curve iterations 4 cj .. 4 cj + 3; tile 1 runs one step behind
-        const auto rsI = mk((const char*)(p.img + (size_t)n * 3 * plane), 3 * plane * 4);
-        const auto rsE = mk(p.enhanced ? (const void*)(p.enhanced + (size_t)n * 3 * plane) : (const void*)p.w7, p.enhanced ? 3 * plane * 4 : 0);
-        const auto rsJ = mk((MODE == 0 && p.adjust) ? (const void*)(p.adjust + (size_t)n * 24 * plane) : (const void*)p.w7, (MODE == 0 && p.adjust) ? 24 * plane * 4 : 0);
-        const auto rsU = mk((MODE == 0 && p.u8) ? (const void*)(p.u8 + (size_t)n * 3 * plane) : (const void*)p.w7, (MODE == 0 && p.u8) ? 3 * plane : 0);
-        frag wv[18];
-#pragma unroll
-        for (int f = 0; f < 18; ++f) wv[f] = ((const frag*)p.w7)[(cj * 18 + f) * 64 + lane];
-        ie_f32x4 bias7;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) bias7[i] = p.b7[16 * cj + 4 * kq + i];
-        unsigned raw_off[2];
-        raw_offsets(w4, lane, xc0, W, plane, raw_off);
-        auto issue_raw = [&](int t) __attribute__((always_inline)) {
-            const int yi = ys - 2 + t;
-            const unsigned rmask = (yi >= 0 && yi < H) ? 0u : OOB;
-            const unsigned row_b = rmask ? 0u : (unsigned)yi * (unsigned)W * 4u;
-            char* slot = smem + G::OFF_RAW + (t % NRAW) * RAW_SLOT_B;
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsI, (lds_ptr)(slot + (4 * j + w4) * 256), 4, (int)((row_b + raw_off[j]) | rmask), 0, 0, 0);
-        };
-        // where this lane's curve value of tile j comes from / goes to: the raw row's plane kq at ring pixel q + 1 (tile 0), the exchange / output rows at float q + 2
-        int yin_off[4], yout_off[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int q = 16 * (4 * hf + j) + p16;
-            yout_off[j] = kq * G::YPLANE_B + (q + 2) * 4;                                        // (kq = 3: the spare plane)
-            yin_off[j] = cj ? yout_off[j] : (kq < 3 ? kq : 2) * (IPX * 4) + (q + 1) * 4;
-        }
+        const bool strip_inside = xc0 >= 0 && xc0 + TW <= W;       // every computed column lies inside the image: no column masks
         // enhanced, W % 4 == 0: wave w4 < 3 stores colour w4; lane l < 31: pixels 4 l .. 4 l + 3 of the strip's 124 stored ones
         unsigned est_off;
         int est_lds;
@@ -475,33 +469,36 @@ __device__ __forceinline__ void k67x_body(const K67XParams& p) {
             est_off = (w4 < 3 && lane < 31 && x < W) ? (unsigned)(((size_t)w4 * plane + x) * 4) : OOB;
             est_lds = (w4 < 3 ? w4 : 0) * G::YPLANE_B + 16 + 16 * (lane < 31 ? lane : 0);
         }
-
+        constexpr bool M_ENH = MODE != 3, M_U8 = MODE == 0 || MODE == 3;
+        const auto rsU = mk((M_U8 && p.u8) ? (const void*)(p.u8 + (size_t)n * 3 * plane) : (const void*)p.w7, (M_U8 && p.u8) ? 3 * plane : 0);
+        const bool vec_store = MODE == 1 || MODE == 2 || (M_ENH && p.enhanced && (W & 3) == 0 && ((size_t)p.enhanced & 15) == 0);
+        ie_f32x4 a0[4], a1[4], a2[4], e0[4], e1[4], e2[4];
 #pragma unroll
-        for (int t = 0; t <= PFR; ++t) issue_raw(t);
-        ie_wait_vm_imm<2 * PFR>();
+        for (int j = 0; j < 4; ++j) { a0[j] = bias6; a1[j] = bias6; a2[j] = bias6; e0[j] = bias1; e1[j] = bias1; e2[j] = bias1; }
+
+        // prologue: raw rows 0 .. PFR and x2 / x5 rows 0 .. PF - 1 (issue(t) carries the raw row t - PF + 1 + PFR)
+#pragma unroll
+        for (int t = PF - 1 - PFR; t < PF; ++t) issue(t);      // (t < 0: a raw row only -- its x2 / x5 rows land in slots that row PF + t overwrites before any read)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                    // prologue barrier: raw row 0 has landed (stage A converts it behind the barrier)
-
-        ie_f32x4 a0[4], a1[4], a2[4], a3[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { a0[j] = bias7; a1[j] = bias7; a2[j] = bias7; a3[j] = bias7; }
-
-        // step t (tile 0; tile 1 does the same one step later): the x1 / x6 rows ys - 4 + t (stage A's step t - 1) finish e_conv7 row ys - 5 + t; accF = the row
-        // finished at step t - 1 (ys - 6 + t): its curve runs now; the row staged at step t - 1 by the tile-1 waves (ys - 8 + t) leaves
-        auto step_b = [&](int t, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4], const ie_f32x4 (&accF)[4]) __attribute__((always_inline)) {
-            ie_wait_vm_imm<2 * (PFR - 1)>();             // raw row t + 1 has landed (the stores issued since only make this stricter)
+        __builtin_amdgcn_s_barrier();                    // prologue barrier: raw row 0 has landed
+        convert(0);
+        // step t: image / x2 / x5 row ys - 2 + t; the x1 and x6 rows ys - 3 + t are finished and handed over in slot t % 3; the staged output row ys - 8 + t leaves
+        auto step_a = [&](int t, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4], ie_f32x4 (&eN)[4], ie_f32x4 (&eM)[4], ie_f32x4 (&eO)[4]) __attribute__((always_inline)) {
+            IE_TACC(3);
+            ie_wait_vm_imm<G::WAIT_A>();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            {   // (1) the staged row leaves
+            IE_TACC(0);
+            if constexpr (!(IE_XEXP & 16) && M_ENH) {   // the row staged by the tile-1 waves at step t - 1 leaves
                 const int yo = ys - 8 + t;
                 const bool row_ok = (yo >= ys) && (yo < ye);
                 const char* os = smem + G::OFF_OUT + ((t + 1) & 1) * G::YSLOT_B;
-                const int xs = xc0 + MARG;
-                if (MODE == 1 || (p.enhanced && (W & 3) == 0 && ((size_t)p.enhanced & 15) == 0)) {
+                if (vec_store) {
                     const ie_u32x4 v = *(const ie_u32x4*)(os + est_lds);
                     const unsigned rmask = row_ok ? 0u : OOB;
                     __builtin_amdgcn_raw_buffer_store_b128(v, rsE, (int)((est_off + (rmask ? 0u : (unsigned)yo * (unsigned)W * 4u)) | rmask), 0, 0);
-                } else if (p.enhanced) {
+                } else if (MODE == 0 && p.enhanced) {      // (any width / alignment: dword stores)
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
                         const int q = lane + 64 * k, x = xc0 + q;
@@ -511,88 +508,177 @@ __device__ __forceinline__ void k67x_body(const K67XParams& p) {
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsE, (int)off, 0, 0);
                     }
                 }
-                if constexpr (MODE == 0) {
-                    if (p.u8 && w4 == 3) {        // HWC bytes: 372 per strip row, one wave quantises them from the staged fp32 values (save_image rule)
-                        const int nbytes = row_ok ? min(TS, W - xs) * 3 : 0;
-                        if ((W & 3) == 0) {
+            }
+            if constexpr (M_U8 && !(IE_XEXP & 16)) {
+                if (p.u8 && w4 == 3) {        // HWC bytes: 372 per strip row: wave 3 (it stores no colour plane) quantises the staged fp32 values (save_image rule)
+                    const int yo = ys - 8 + t;
+                    const bool row_ok = (yo >= ys) && (yo < ye);
+                    const char* os = smem + G::OFF_OUT + ((t + 1) & 1) * G::YSLOT_B;
+                    const int xs = xc0 + MARG;
+                    const int nbytes = row_ok ? min(TS, W - xs) * 3 : 0;
+                    int ln = lane;
+                    asm volatile("" : "+v"(ln));      // the byte -> (pixel, colour) arithmetic below is loop-invariant: recomputed per step rather than carried in 8+ VGPRs across the MFMAs
+                    if ((W & 3) == 0) {
 #pragma unroll
-                            for (int k = 0; k < 2; ++k) {
-                                const int d = lane + 64 * k;
-                                unsigned pk = 0;
+                        for (int k = 0; k < 2; ++k) {
+                            const int d = ln + 64 * k;
+                            unsigned pk = 0;
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) {
-                                    const int bb = 4 * d + e, pxr = bb / 3, c = bb - 3 * pxr;
-                                    const float v = *(const float*)(os + c * G::YPLANE_B + ((pxr < TS ? pxr : 0) + MARG + 2) * 4);
-                                    pk |= (unsigned)ie_quant_u8(v) << (8 * e);
-                                }
-                                const unsigned off = (4 * d < nbytes) ? (unsigned)(((size_t)yo * W + xs) * 3 + 4 * d) : OOB;
-                                __builtin_amdgcn_raw_buffer_store_b32(pk, rsU, (int)off, 0, 0);
-                            }
-                        } else {
-#pragma unroll
-                            for (int k = 0; k < 6; ++k) {
-                                const int bb = lane + 64 * k, pxr = bb / 3, c = bb - 3 * pxr;
+                            for (int e = 0; e < 4; ++e) {
+                                const int bb = 4 * d + e, pxr = bb / 3, c = bb - 3 * pxr;
                                 const float v = *(const float*)(os + c * G::YPLANE_B + ((pxr < TS ? pxr : 0) + MARG + 2) * 4);
-                                const unsigned off = (bb < nbytes) ? (unsigned)(((size_t)yo * W + xs) * 3 + bb) : OOB;
-                                __builtin_amdgcn_raw_buffer_store_b8(ie_quant_u8(v), rsU, (int)off, 0, 0);
+                                pk |= (unsigned)ie_quant_u8(v) << (8 * e);
                             }
+                            const unsigned off = (4 * d < nbytes) ? (unsigned)(((size_t)yo * W + xs) * 3 + 4 * d) : OOB;
+                            __builtin_amdgcn_raw_buffer_store_b32(pk, rsU, (int)off, 0, 0);
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) {
+                            const int bb = ln + 64 * k, pxr = bb / 3, c = bb - 3 * pxr;
+                            const float v = *(const float*)(os + c * G::YPLANE_B + ((pxr < TS ? pxr : 0) + MARG + 2) * 4);
+                            const unsigned off = (bb < nbytes) ? (unsigned)(((size_t)yo * W + xs) * 3 + bb) : OOB;
+                            __builtin_amdgcn_raw_buffer_store_b8(ie_quant_u8(v), rsU, (int)off, 0, 0);
                         }
                     }
                 }
             }
-            issue_raw(t + 1 + PFR);                      // (2)
-            // (3) the curve's running value of the row in accF: row ys - 6 + t - cj = raw row of step t - 4 - cj; tile 1 reads what tile 0 left at step t - 1
+            IE_TACC(4);
+            if constexpr (!(IE_XEXP & 2)) conv1_row<TH>(smem + G::OFF_IMG + (t % NRI) * G::IMG_ROW_B, rdi, w1, bias1, eN, eM, eO);
+            auto nofill = [&](int) __attribute__((always_inline)) {};
+            if constexpr (!(IE_XEXP & 32)) {
+            mfma_row<TA0, IE_K67X_AHA>(smem + G::OFF_X2 + (t % NRA) * ROWH_B, rr, wv, accN, accM, accO, true, bias6, nofill);
+            IE_TACC(2);
+            mfma_row<TA1, IE_K67X_AHA>(smem + G::OFF_X5 + (t % NRA) * ROWH_B, rr, wv + 9, accN, accM, accO, false, bias6, nofill);
+            }
+            IE_TACC(1);
+            if constexpr (!(IE_XEXP & 8)) issue(t + PF);
+            IE_TACC(5);
+            if constexpr (!(IE_XEXP & 2)) convert(t + 1);
+            IE_TACC(6);
+            const int m = ys - 3 + t;
+            if constexpr (!(IE_XEXP & 4)) {
+            if (strip_inside && m >= 0 && m < H) {
+                put_row<TH, false>(eO, smem + G::OFF_H1 + (t % NRH) * ROWH_B, em_off, 3u);
+                put_row<TH, false>(accO, smem + G::OFF_H6 + (t % NRH) * ROWH_B, em_off, 3u);
+            } else {
+                const unsigned keep = (m >= 0 && m < H) ? em_in : 0u;
+                put_row<TH, true>(eO, smem + G::OFF_H1 + (t % NRH) * ROWH_B, em_off, keep);
+                put_row<TH, true>(accO, smem + G::OFF_H6 + (t % NRH) * ROWH_B, em_off, keep);
+            }
+            }
+        };
+        for (int t = 0; t < n_steps; t += 3) {
+            step_a(t, a0, a1, a2, e0, e1, e2);
+            if (t + 1 < n_steps) step_a(t + 1, a2, a0, a1, e2, e0, e1);
+            if (t + 2 < n_steps) step_a(t + 2, a1, a2, a0, e1, e2, e0);
+        }
+    } else {
+        // ================================================================ stage B ================================================================
+        const int cj = cf;                                  // this wave's 16-row tile of e_conv7 = curve iterations 4 cj .. 4 cj + 3; tile 1 runs one step behind
+        constexpr bool M_ADJ = MODE == 0 || MODE == 2;
+        const auto rsJ = mk((M_ADJ && p.adjust) ? (const void*)(p.adjust + (size_t)n * 24 * plane) : (const void*)p.w7, (M_ADJ && p.adjust) ? 24 * plane * 4 : 0);
+        frag wv[18];
+#pragma unroll
+        for (int f = 0; f < 18; ++f) wv[f] = ((const frag*)p.w7)[(cj * 18 + f) * 64 + lane];
+        ie_f32x4 bias7;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bias7[i] = p.b7[16 * cj + 4 * kq + i];
+        // where this lane's curve value of tile j comes from / goes to: the raw row's plane kq at ring pixel q + 1 (tile 0), the exchange / output rows at float q + 2
+        // (tile j: + 64 j bytes, an immediate)
+        const int q0 = 64 * hf + p16;
+        const int yout_off = kq * G::YPLANE_B + (q0 + 2) * 4;                                    // (kq = 3: the spare plane)
+        const int yin_off = cj ? yout_off : (kq < 3 ? kq : 2) * (IPX * 4) + (q0 + 1) * 4;
+        // the 24 curve maps: this lane's tile j is valid when its column is a stored one inside the image (bit j)
+        unsigned aj_ok = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = q0 + 16 * j, x = xc0 + q;
+            aj_ok |= (kq < 3 && q >= MARG && q < TW - MARG && x < W) ? (1u << j) : 0u;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                    // prologue barrier (stage A converts the first image row behind it)
+#if IE_K67X_PRIO
+        __builtin_amdgcn_s_setprio(IE_K67X_PRIO);
+#endif
+
+        ie_f32x4 a0[4], a1[4], a2[4], a3[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a0[j] = bias7; a1[j] = bias7; a2[j] = bias7; a3[j] = bias7; }
+
+        // step t (tile 0; tile 1 does the same one step later): the x1 / x6 rows ys - 4 + t (stage A's step t - 1) finish e_conv7 row ys - 5 + t; accF = the row
+        // finished at step t - 1 (ys - 6 + t): its curve runs now
+        auto step_b = [&](int t, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4], const ie_f32x4 (&accF)[4]) __attribute__((always_inline)) {
+            IE_TACC(3);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (this stage issues no loads; its stores are only waited for at the end)
+            __builtin_amdgcn_s_barrier();
+            IE_TACC(0);
+            IE_TACC(4);
+            // the curve's running value of the row in accF: row ys - 6 + t - cj = raw row of step t - 4 - cj; tile 1 reads what tile 0 left at step t - 1
             const char* yin = cj ? smem + G::OFF_Y4 + ((t + 1) & 1) * G::YSLOT_B : smem + G::OFF_RAW + ((t + 4) % NRAW) * RAW_SLOT_B;
             char* yout = cj ? smem + G::OFF_OUT + (t & 1) * G::YSLOT_B : smem + G::OFF_Y4 + (t & 1) * G::YSLOT_B;
             float v[4], e[4], u[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { v[j] = *(const float*)(yin + yin_off[j]); e[j] = 0.f; u[j] = 0.f; }
-            // the 24 curve maps (optional output, MODE 0) leave straight from the lane that computed them: NCHW fp32, plane 3 (4 cj + i) + colour
-            unsigned aj_off[4] = {OOB, OOB, OOB, OOB};
-            if constexpr (MODE == 0) {
-                if (p.adjust) {
-                    const int yc = ys - 6 + t - cj;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int q = 16 * (4 * hf + j) + p16, x = xc0 + q;
-                        const bool ok = (yc >= ys) && (yc < ye) && kq < 3 && q >= MARG && q < TW - MARG && x < W;
-                        aj_off[j] = ok ? (unsigned)(((size_t)(12 * cj + kq) * plane + (size_t)yc * W + x) * 4) : OOB;
-                    }
-                }
+            for (int j = 0; j < 4; ++j) { v[j] = *(const float*)(yin + yin_off + 64 * j); e[j] = 0.f; u[j] = 0.f; }
+            // the 24 curve maps (optional output) leave straight from the lane that computed them: NCHW fp32, plane 3 (4 cj + i) + colour
+            unsigned aj_base = OOB;        // byte offset of curve map 12 cj of this lane's colour at tile 0's pixel; tile j: + 64 j, map k: + 3 k planes
+            if constexpr (M_ADJ) {
+                const int yc = ys - 6 + t - cj;
+                if ((MODE == 2 || p.adjust) && yc >= ys && yc < ye) aj_base = (unsigned)(((size_t)(12 * cj + kq) * plane + (size_t)yc * W + xc0 + q0) * 4);
             }
-            // filler o of 96: k = o / 24 (curve iteration 4 cj + k), op = (o % 24) / 4, tile = o % 4;  tanh(x) = 1 - 2 / (exp(2x) + 1) (ie_tanh_fast)
-            auto op = [&](int o) __attribute__((always_inline)) {
-                const int k = o / 24, w = (o % 24) >> 2, j = o & 3;
+            IE_TACC(6);
+            // The 96 tanh / curve operations (per curve iteration k and pixel tile j: E = exp2, A = + 1, R = rcp, F = r = 1 - 2 R, U = v v - v, V = v + r u;
+            // tanh(x) = 1 - 2 / (exp(2x) + 1), ie_tanh_fast) as 64 gap items of 8 issue cycles each -- ONE transcendental or TWO plain vector instructions: an
+            // MFMA holds the SIMD's vector issue for 8 of its 16 cycles, so that is what a gap hides; two transcendentals in one gap (the first build's 4 fillers per
+            // 3 MFMAs) cost twice their issue time (profiles/r04/k67x_experiments.log).  Item i of iteration k: 0-3 E(j = i), 4-5 A pairs, 6-9 R(j = i - 6), 10-11 F
+            // pairs, 12-13 U pairs, 14-15 V pairs; gap s of the step's 72 carries item s - IE_K67X_HEAD (the head of a segment is the worst place for vector work).
+            auto op = [&](int k, int w, int j) __attribute__((always_inline)) {
+                if constexpr (IE_XEXP & 128) { if (w == 0 || w == 2) return; }       // no transcendentals
+                if constexpr (IE_XEXP & 256) { if (w != 0 && w != 2) return; }       // transcendentals only
+                if constexpr (IE_XEXP & 512) {                                       // transcendentals replaced by plain vector instructions
+                    if (w == 0) { e[j] = __builtin_fmaf(accF[j][k], 0.25f, 1.0f); return; }
+                    if (w == 2) { e[j] = __builtin_fmaf(e[j], 0.25f, 1.0f); return; }
+                }
                 if (w == 0) e[j] = __builtin_amdgcn_exp2f(accF[j][k]);
                 if (w == 1) e[j] = e[j] + 1.0f;
                 if (w == 2) e[j] = __builtin_amdgcn_rcpf(e[j]);
                 if (w == 3) {
                     e[j] = __builtin_fmaf(e[j], -2.0f, 1.0f);       // r_{4 cj + k}
-                    if constexpr (MODE == 0) {                        // (an absent `adjust` has an empty descriptor range and out-of-range offsets: the store is dropped)
-                        const unsigned off = aj_off[j] == OOB ? OOB : aj_off[j] + (unsigned)((size_t)(3 * k) * plane * 4);
+                    if constexpr (M_ADJ) {                            // (an absent `adjust` has an empty descriptor range and out-of-range offsets: the store is dropped)
+                        const unsigned off = (aj_base != OOB && ((aj_ok >> j) & 1u)) ? aj_base + (unsigned)(64 * j) + (unsigned)((size_t)(3 * k) * plane * 4) : OOB;
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(e[j]), rsJ, (int)off, 0, 0);
                     }
                 }
                 if (w == 4) u[j] = __builtin_fmaf(v[j], v[j], -v[j]);
                 if (w == 5) v[j] = __builtin_fmaf(e[j], u[j], v[j]);
             };
-            // (4) the x1 / x6 rows handed over by stage A at step t - 1 - cj into the three live sets: two 36-MFMA streams, fillers 4 per 3 MFMAs
-            const int hs = ((t + 2 - cj) % NRH) * ROW_B;
-            auto fill1 = [&](int s) __attribute__((always_inline)) {
-#pragma unroll
-                for (int o = (s * 4) / 3; o < ((s + 1) * 4) / 3; ++o) op(o);
+            auto gap = [&](int s) __attribute__((always_inline)) {
+                if constexpr (IE_XEXP & 1) return;
+                const int it = s - IE_K67X_HEAD;
+                if (it < 0 || it >= 64) return;
+                const int k = it >> 4, i = it & 15;
+                if (i < 4) op(k, 0, i);
+                else if (i < 6) { op(k, 1, 2 * (i - 4)); op(k, 1, 2 * (i - 4) + 1); }
+                else if (i < 10) op(k, 2, i - 6);
+                else { const int w = 3 + ((i - 10) >> 1), j0 = 2 * ((i - 10) & 1); op(k, w, j0); op(k, w, j0 + 1); }
             };
-            auto fill6 = [&](int s) __attribute__((always_inline)) {
+            // the x1 / x6 rows handed over by stage A at step t - 1 - cj into the three live sets: two 36-MFMA streams
+            const int hs = ((t + 2 - cj) % NRH) * ROWH_B;
+            auto fill1 = [&](int s) __attribute__((always_inline)) { gap(s); };
+            auto fill6 = [&](int s) __attribute__((always_inline)) { gap(s + 36); };
+            if constexpr (!(IE_XEXP & 64)) {
+            mfma_row<TH, (M_ADJ ? IE_K67X_AHB - 1 : IE_K67X_AHB)>(smem + G::OFF_H1 + hs, rr, wv, accN, accM, accO, true, bias7, fill1);
+            IE_TACC(5);
+            mfma_row<TH, (M_ADJ ? IE_K67X_AHB - 1 : IE_K67X_AHB)>(smem + G::OFF_H6 + hs, rr, wv + 9, accN, accM, accO, false, bias7, fill6);
+            } else {
 #pragma unroll
-                for (int o = ((s + 36) * 4) / 3; o < ((s + 37) * 4) / 3; ++o) op(o);
-            };
-            mfma_row<TH>(smem + G::OFF_H1 + hs, rr, wv, accN, accM, accO, true, bias7, fill1);
-            mfma_row<TH>(smem + G::OFF_H6 + hs, rr, wv + 9, accN, accM, accO, false, bias7, fill6);
-            // (5) the running values go on: to the tile-1 waves (exchange row) or into the staged output row
+                for (int s = 0; s < 72; ++s) gap(s);
+            }
+            IE_TACC(1);
+            // the running values go on: to the tile-1 waves (exchange row) or into the staged output row
 #pragma unroll
-            for (int j = 0; j < 4; ++j) *(float*)(yout + yout_off[j]) = v[j];
+            for (int j = 0; j < 4; ++j) *(float*)(yout + yout_off + 64 * j) = v[j];
         };
-        // tile-1 waves run one step behind: they see step index t - 1 (their step -1 works on rows that are never stored)
         for (int t = 0; t < n_steps; t += 4) {      // (N, M, O, F) -> (F, N, M, O)
             step_b(t, a0, a1, a2, a3);
             if (t + 1 < n_steps) step_b(t + 1, a3, a0, a1, a2);
@@ -601,6 +687,14 @@ __device__ __forceinline__ void k67x_body(const K67XParams& p) {
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef IE_STAMP
+    // per wave: [0] wait + barrier, [1] MFMA phase, [2] the rest of the step, n_steps, fine buckets [4..6]: A stores / DMA issue / conversion, B u8 stores / - / curve value reads
+    IE_TACC(3);
+    if (p.stamps && lane == 0) {
+        unsigned long long* d = p.stamps + ((size_t)blockIdx.x * 8 + wave) * 8;
+        d[0] = st_acc[0]; d[1] = st_acc[1]; d[2] = st_acc[3]; d[3] = n_steps; d[4] = st_acc[4]; d[5] = st_acc[5]; d[6] = st_acc[6]; d[7] = st_acc[2];
+    }
+#endif
 }
 
 #define IE_DEF_K67X(NAME, TA0, TA1, TH, MODE) \
@@ -611,6 +705,12 @@ IE_DEF_K67X(zdce_k67x_conv1_conv6_conv7_curve_mix, _Float16, __bf16, _Float16, 0
 IE_DEF_K67X(zdce_k67x_conv1_conv6_conv7_curve_e_f16, _Float16, _Float16, _Float16, 1)
 IE_DEF_K67X(zdce_k67x_conv1_conv6_conv7_curve_e_bf16, __bf16, __bf16, __bf16, 1)
 IE_DEF_K67X(zdce_k67x_conv1_conv6_conv7_curve_e_mix, _Float16, __bf16, _Float16, 1)
+IE_DEF_K67X(zdce_k67x_conv1_conv6_conv7_curve_ea_f16, _Float16, _Float16, _Float16, 2)
+IE_DEF_K67X(zdce_k67x_conv1_conv6_conv7_curve_ea_bf16, __bf16, __bf16, __bf16, 2)
+IE_DEF_K67X(zdce_k67x_conv1_conv6_conv7_curve_ea_mix, _Float16, __bf16, _Float16, 2)
+IE_DEF_K67X(zdce_k67x_conv1_conv6_conv7_curve_u8_f16, _Float16, _Float16, _Float16, 3)
+IE_DEF_K67X(zdce_k67x_conv1_conv6_conv7_curve_u8_bf16, __bf16, __bf16, __bf16, 3)
+IE_DEF_K67X(zdce_k67x_conv1_conv6_conv7_curve_u8_mix, _Float16, __bf16, _Float16, 3)
 #undef IE_DEF_K67X
 
 }  // namespace
@@ -648,18 +748,21 @@ int ie_zdce_launch_x(const ZdceXLaunch& a, hipStream_t st) {
     p.enhanced = a.enhanced; p.adjust = a.adjust; p.u8 = a.u8;
     p.H = a.H; p.W = a.W; p.y_begin = a.y_begin; p.y_end = a.y_end; p.n_begin = a.n_begin; p.strips = strips;
     p.rows_per_block = a.rows_per_block;
+    p.stamps = (unsigned long long*)a.stamps;
     p.chunks = ie_cdiv(a.y_end - a.y_begin, a.rows_per_block);
     const long long blocks = (long long)strips * p.chunks * a.n_count;
     if (blocks <= 0 || blocks > 0x7fffffffLL) IE_FAIL(IE_ERR_INVALID, "zdce k67x: bad grid %lld", blocks);
     typedef void (*Fn)(K67XParams);
-    const bool fast = a.enhanced && !a.adjust && !a.u8 && (a.W & 3) == 0 && ((size_t)a.enhanced & 15) == 0;
+    const bool al = (a.W & 3) == 0 && ((size_t)a.enhanced & 15) == 0;
+    const int mode = (a.enhanced && !a.adjust && !a.u8 && al) ? 1 : (a.enhanced && a.adjust && !a.u8 && al) ? 2 : (a.u8 && !a.enhanced && !a.adjust) ? 3 : 0;
     const bool h_all = a.dt_h == IE_F16 && a.dt_a0 == IE_F16 && a.dt_a1 == IE_F16;
     const bool b_all = a.dt_h == IE_BF16 && a.dt_a0 == IE_BF16 && a.dt_a1 == IE_BF16;
     const bool mix = a.dt_h == IE_F16 && a.dt_a0 == IE_F16 && a.dt_a1 == IE_BF16;
-    Fn fn = nullptr;
-    if (h_all) fn = fast ? zdce_k67x_conv1_conv6_conv7_curve_e_f16 : zdce_k67x_conv1_conv6_conv7_curve_f16;
-    else if (b_all) fn = fast ? zdce_k67x_conv1_conv6_conv7_curve_e_bf16 : zdce_k67x_conv1_conv6_conv7_curve_bf16;
-    else if (mix) fn = fast ? zdce_k67x_conv1_conv6_conv7_curve_e_mix : zdce_k67x_conv1_conv6_conv7_curve_mix;
+    static const Fn fns[3][4] = {
+        {zdce_k67x_conv1_conv6_conv7_curve_f16, zdce_k67x_conv1_conv6_conv7_curve_e_f16, zdce_k67x_conv1_conv6_conv7_curve_ea_f16, zdce_k67x_conv1_conv6_conv7_curve_u8_f16},
+        {zdce_k67x_conv1_conv6_conv7_curve_bf16, zdce_k67x_conv1_conv6_conv7_curve_e_bf16, zdce_k67x_conv1_conv6_conv7_curve_ea_bf16, zdce_k67x_conv1_conv6_conv7_curve_u8_bf16},
+        {zdce_k67x_conv1_conv6_conv7_curve_mix, zdce_k67x_conv1_conv6_conv7_curve_e_mix, zdce_k67x_conv1_conv6_conv7_curve_ea_mix, zdce_k67x_conv1_conv6_conv7_curve_u8_mix}};
+    const Fn fn = h_all ? fns[0][mode] : (b_all ? fns[1][mode] : (mix ? fns[2][mode] : nullptr));
     if (!fn) IE_FAIL(IE_ERR_UNSUPPORTED, "zdce k67x: dtypes x2=%d x5=%d h=%d", a.dt_a0, a.dt_a1, a.dt_h);
     const int lds = a.dt_h == IE_F16 ? K67XGeom<_Float16>::LDS_B : K67XGeom<__bf16>::LDS_B;
     IE_GRANT_LDS(fn, lds);
