@@ -38,6 +38,16 @@ constexpr unsigned OOB = 0x80000000u;
 #endif                // 4 no hand-off writes, 8 no x2 / x5 DMA, 16 no image DMA / output stores, 32 no e_conv6 MFMAs, 64 no e_conv7 MFMAs, 128 curve without its transcendentals,
                       // 256 transcendentals only, 512 transcendentals replaced by v_fma
 #define IE_SB() __builtin_amdgcn_sched_barrier(0)
+#ifndef IE_PRIO_TOGGLE
+#define IE_PRIO_TOGGLE 0    // experiment: a wave drops its issue priority right behind each of its MFMAs and raises it again at the end of the gap, so that the SIMD's
+#endif                      // two waves alternate on the matrix pipe instead of the older one taking every slot it is ready for
+#if IE_PRIO_TOGGLE
+#define IE_PRIO_LO() do { IE_SB(); __builtin_amdgcn_s_setprio(0); IE_SB(); } while (0)
+#define IE_PRIO_HI() do { IE_SB(); __builtin_amdgcn_s_setprio(1); IE_SB(); } while (0)
+#else
+#define IE_PRIO_LO() do { } while (0)
+#define IE_PRIO_HI() do { } while (0)
+#endif
 typedef __attribute__((address_space(3))) void* lds_ptr;
 
 template <typename T> constexpr int parts_of() { return ie_elem<T>::dtype == IE_BF16 ? 2 : 1; }
@@ -137,14 +147,20 @@ __device__ __forceinline__ void mfma_row(const char* slot, const RowRead& rr, co
     for (int g = 0; g < 12; ++g) {
         const int kx = g >> 2, j = g & 3;
         accN[j] = ie_mfma16_raw<T>(wv[0 * 3 + kx], bx[g], (first && kx == 0) ? init : accN[j]);
+        IE_PRIO_LO();
         if (g + AHEAD < 12) rd(g + AHEAD);
         fill(3 * g);
+        IE_PRIO_HI();
         IE_SB();
         accM[j] = ie_mfma16_raw<T>(wv[1 * 3 + kx], bx[g], accM[j]);
+        IE_PRIO_LO();
         fill(3 * g + 1);
+        IE_PRIO_HI();
         IE_SB();
         accO[j] = ie_mfma16_raw<T>(wv[2 * 3 + kx], bx[g], accO[j]);
+        IE_PRIO_LO();
         fill(3 * g + 2);
+        IE_PRIO_HI();
         IE_SB();
     }
 }
@@ -340,6 +356,12 @@ struct K67XParams {
 #endif                      // latency its reads in flight cover: stage A alone ran 22.6 cycles per MFMA at 3, stamps in profiles/r04/k67x_experiments.log)
 #ifndef IE_K67X_AHB
 #define IE_K67X_AHB 3
+#endif
+#ifndef IE_K67X_PACE_A
+#define IE_K67X_PACE_A -1
+#endif
+#ifndef IE_K67X_IPG
+#define IE_K67X_IPG 1       // gap items per MFMA gap
 #endif
 #ifndef IE_K67X_PRIO
 #define IE_K67X_PRIO 0      // s_setprio level of stage B's waves (the younger half of the workgroup loses the vector-issue arbitration at equal priority)
@@ -545,7 +567,12 @@ __device__ __forceinline__ void k67x_body(const K67XParams& p) {
             }
             IE_TACC(4);
             if constexpr (!(IE_XEXP & 2)) conv1_row<TH>(smem + G::OFF_IMG + (t % NRI) * G::IMG_ROW_B, rdi, w1, bias1, eN, eM, eO);
+#if IE_K67X_PACE_A >= 0
+            // experiment: stage A leaves pipe slots to stage B by not being ready for its next MFMA (IE_K67X_PACE_A = the s_nop argument after every MFMA)
+            auto nofill = [&](int) __attribute__((always_inline)) { asm volatile("s_nop %0" ::"n"(IE_K67X_PACE_A)); };
+#else
             auto nofill = [&](int) __attribute__((always_inline)) {};
+#endif
             if constexpr (!(IE_XEXP & 32)) {
             mfma_row<TA0, IE_K67X_AHA>(smem + G::OFF_X2 + (t % NRA) * ROWH_B, rr, wv, accN, accM, accO, true, bias6, nofill);
             IE_TACC(2);
@@ -652,15 +679,22 @@ __device__ __forceinline__ void k67x_body(const K67XParams& p) {
                 if (w == 4) u[j] = __builtin_fmaf(v[j], v[j], -v[j]);
                 if (w == 5) v[j] = __builtin_fmaf(e[j], u[j], v[j]);
             };
-            auto gap = [&](int s) __attribute__((always_inline)) {
-                if constexpr (IE_XEXP & 1) return;
-                const int it = s - IE_K67X_HEAD;
+            auto item = [&](int it) __attribute__((always_inline)) {
                 if (it < 0 || it >= 64) return;
+                if constexpr (IE_XEXP & 2048) {       // experiment: 16 plain adds instead of the 96 curve operations (keeps the MFMAs alive)
+                    if ((it & 3) == 0) { const int k = it >> 4, j = (it >> 2) & 3; v[j] += accF[j][k]; }
+                    return;
+                }
                 const int k = it >> 4, i = it & 15;
                 if (i < 4) op(k, 0, i);
                 else if (i < 6) { op(k, 1, 2 * (i - 4)); op(k, 1, 2 * (i - 4) + 1); }
                 else if (i < 10) op(k, 2, i - 6);
                 else { const int w = 3 + ((i - 10) >> 1), j0 = 2 * ((i - 10) & 1); op(k, w, j0); op(k, w, j0 + 1); }
+            };
+            auto gap = [&](int s) __attribute__((always_inline)) {
+                if constexpr ((IE_XEXP & 1) || (IE_XEXP & 1024)) return;
+#pragma unroll
+                for (int r = 0; r < IE_K67X_IPG; ++r) item((s - IE_K67X_HEAD) * IE_K67X_IPG + r);
             };
             // the x1 / x6 rows handed over by stage A at step t - 1 - cj into the three live sets: two 36-MFMA streams
             const int hs = ((t + 2 - cj) % NRH) * ROWH_B;
@@ -673,6 +707,10 @@ __device__ __forceinline__ void k67x_body(const K67XParams& p) {
             } else {
 #pragma unroll
                 for (int s = 0; s < 72; ++s) gap(s);
+            }
+            if constexpr (IE_XEXP & 1024) {       // experiment: the curve as a burst behind the streams
+#pragma unroll
+                for (int it = 0; it < 64; ++it) item(it);
             }
             IE_TACC(1);
             // the running values go on: to the tile-1 waves (exchange row) or into the staged output row

@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/pmc14
+O=$R/gpurun_out/${1:-pmc_r04}
 mkdir -p $O
 rocprofv3 -L > $O/counters.txt 2>&1 || true
 i=0
