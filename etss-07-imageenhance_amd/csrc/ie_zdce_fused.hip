@@ -206,8 +206,16 @@ __device__ __forceinline__ void zdce_fused2_body(const FusedParams& p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifndef IE_PAIR_SAME
+#define IE_PAIR_SAME 0    // experiment: 1 = the two waves of a SIMD (w and w + 4) belong to the SAME stage (stage A = waves 0, 1, 4, 5; stage B = waves 2, 3, 6, 7)
+#endif
+#if IE_PAIR_SAME
+    const int stg = (wave >> 1) & 1;
+    const int sw = (wave & 1) | ((wave >> 2) << 1);
+#else
     const int stg = wave >> 2;          // 0 = stage A, 1 = stage B
     const int sw = wave & 3;            // wave within the stage
+#endif
     const int p16 = lane & 15, kq = lane >> 4;
     const int ph = sw & 1, ch = sw >> 1;
 

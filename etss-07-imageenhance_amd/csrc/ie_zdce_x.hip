@@ -396,7 +396,14 @@ __device__ __forceinline__ void k67x_body(const K67XParams& p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int p16 = lane & 15, kq = lane >> 4;
+#ifndef IE_PAIR_SAME
+#define IE_PAIR_SAME 0    // experiment: 1 = the two waves of a SIMD (w and w + 4) belong to the SAME stage (stage A = waves 0, 1, 4, 5; stage B = waves 2, 3, 6, 7)
+#endif
+#if IE_PAIR_SAME
+    const int stg = (wave >> 1) & 1, w4 = (wave & 1) | ((wave >> 2) << 1), cf = w4 & 1, hf = w4 >> 1;
+#else
     const int stg = wave >> 2, w4 = wave & 3, cf = w4 & 1, hf = w4 >> 1;      // stage; stage A: 16-cout fragment / stage B: 16-row tile of e_conv7; half of the strip
+#endif
 
     int b = blockIdx.x;
     const int strip = b % p.strips; b /= p.strips;

@@ -22,6 +22,11 @@ from .losses import LOSSES, Loss
 CL = torch.channels_last
 
 
+def _os_env(name, default):
+    import os
+    return os.environ.get(name, default)
+
+
 class Tape:
     """Reverse-mode recorder.  Gradient buffers are created on first use; a second producer accumulates."""
 
@@ -75,10 +80,35 @@ class Tape:
         self._fns.append(fire)
 
     on_grad_bucket = None
+    # Weight gradients off the critical path (Trainer.overlap_wgrad): a layer's weight gradient has no consumer before the optimiser step, while its data gradient
+    # heads the chain the rest of the backward pass waits for.  With a side stream set, ``on_side`` enqueues the weight-gradient launches there (behind everything
+    # the current stream has enqueued so far); the matrix-core weight-gradient kernels then run beside the HBM-bound BatchNorm / pooling / resize passes of the
+    # layers in front.  ``join_side`` makes the current stream wait for them (before the gradient exchange and at the end of the pass).
+    wgrad_stream = None
+    _side_used = False
+
+    def on_side(self, tensors, fn):
+        side = self.wgrad_stream
+        if side is None:
+            fn()
+            return
+        side.wait_stream(torch.cuda.current_stream(side.device))
+        with torch.cuda.stream(side):
+            fn()
+        for t in tensors:                           # the caching allocator must not hand their memory out again before the side stream is done with it
+            if t is not None:
+                t.record_stream(side)
+        self._side_used = True
+
+    def join_side(self):
+        if self._side_used:
+            torch.cuda.current_stream(self.wgrad_stream.device).wait_stream(self.wgrad_stream)
+            self._side_used = False
 
     def backward(self):
         for fn in reversed(self._fns):
             fn()
+        self.join_side()
         self._fns = []
         self._g, self._nograd = {}, set()          # gradient buffers and their tensors: nothing of a finished step stays reachable through the tape
 
@@ -280,12 +310,14 @@ def t_conv16(tape, srcs, cw, dw, db, pad=1, cout_pad=None, act="none", slope=0.0
             return
         if act != "none":
             ops.act_backward_into(dy, y, dy, act, slope)          # in place: this op owns the gradient buffer of its output
-        if edge is None:
-            ops.conv2d_wgrad(srcs, dy, cw, dw, db, stride, pad, "zeros")
-        else:
-            ev = ops.ConvWeightsView(edge.w, edge.b, fwd.cout, sum(fwd.split), cw.kh, cw.kw)
-            ops.conv2d_wgrad(srcs, dy, ev, edge.dw, edge.db if db is not None else None, stride, pad, "zeros")
-            edge.scatter_grads(dw, db)
+        def wgrad():
+            if edge is None:
+                ops.conv2d_wgrad(srcs, dy, cw, dw, db, stride, pad, "zeros")
+            else:
+                ev = ops.ConvWeightsView(edge.w, edge.b, fwd.cout, sum(fwd.split), cw.kh, cw.kw)
+                ops.conv2d_wgrad(srcs, dy, ev, edge.dw, edge.db if db is not None else None, stride, pad, "zeros")
+                edge.scatter_grads(dw, db)
+        tape.on_side(list(srcs) + [dy], wgrad)      # (dy is final here: this op owns the gradient buffer of its output and nothing writes it again)
         dyz = None
         for i, src in enumerate(srcs):
             if tape.is_no_grad(src):
@@ -521,7 +553,8 @@ def t_conv_transpose2x2(tape, x, store, name):
     y = t_pixel_shuffle(tape, t_conv(tape, x, cw, dw, db4, pad=0), 2)
     if has_b:
         def bwd():
-            store.view(f"{name}.bias", store.grads).copy_(db4.view(-1, 4).sum(1))
+            # (behind the layer's weight gradient, on the stream that ran it)
+            tape.on_side([db4], lambda: store.view(f"{name}.bias", store.grads).copy_(db4.view(-1, 4).sum(1)))
         # the tape runs in reverse order of recording: placed BEFORE the conv node, the reduction executes right after it
         tape._fns.insert(len(tape._fns) - 2, bwd)
     return y
@@ -587,6 +620,11 @@ class Trainer:
         # on the collective's own stream while the rest of the backward pass (the encoder's data / weight gradients) still runs
         self.overlap_allreduce = True
         self.sync_gradients = True               # False: skip the exchange (timing the step without it)
+        # 16-bit graphs: weight-gradient launches on a side stream, beside the HBM-bound passes of the layers in front (Tape.on_side).  Off in deterministic mode (the
+        # fixed-order reduction shares one library workspace per device) and with IE_WGRAD_STREAM=0 (A/B).
+        import os as _os
+        self.overlap_wgrad = (not deterministic) and _os.environ.get("IE_WGRAD_STREAM", "1") != "0"
+        self._wgrad_stream = None
         self._pending = []                        # [(async work handle)], first bucket offset
         self._bucket_off = None
         # process-wide switch of the library (capi.set_deterministic): turned on here, restored by ``close()`` (or use the trainer as a context manager)
@@ -697,13 +735,24 @@ class Trainer:
             tape.seed(pred, g)
         self._pending, self._bucket_off = [], None
         tape.on_grad_bucket = self._early_allreduce if (self.overlap_allreduce and self.sync_gradients and self._world() > 1) else None
+        if self.overlap_wgrad and self.compute_dtype != "f32":
+            if self._wgrad_stream is None:
+                # higher priority than the main stream: the weight-gradient kernel's few fat workgroups (144 accumulator VGPRs, LDS tiles) are placed first and the thin
+                # workgroups of the streaming passes fill the wave slots beside them; at equal priority a streaming kernel's thousands of workgroups take every slot
+                # and the two kernels run one after the other (IE_WGRAD_PRIO=0: equal priority, A/B)
+                self._wgrad_stream = torch.cuda.Stream(device=self.device, priority=-1 if _os_env("IE_WGRAD_PRIO", "1") != "0" else 0)
+            tape.wgrad_stream = self._wgrad_stream
+        self._tape_in_backward = tape
         tape.backward()
+        self._tape_in_backward = None
 
     def _early_allreduce(self, offset: int):
         import torch.distributed as dist
         if self._bucket_off is not None or offset <= 0 or offset >= self.store.numel:
             return                                # one early bucket per step
         self._bucket_off = offset
+        if getattr(self, "_tape_in_backward", None) is not None:
+            self._tape_in_backward.join_side()     # the tail's weight gradients may still be running on the side stream
         self._pending.append(dist.all_reduce(self.store.grads[offset:], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def optimizer_step(self):
