@@ -35,7 +35,7 @@ SYMBOLS = [
     "ie_maxpool2x2_backward_nhwc_f32", "ie_resize_backward_nhwc_f32", "ie_crop_nhwc_f32", "ie_pixel_unshuffle_nhwc_f32",
     "ie_act_backward_f32", "ie_act_backward", "ie_pixel_unshuffle_nhwc", "ie_l1_loss_f32", "ie_ssim_forward_f32", "ie_ssim_backward_f32", "ie_sumsq_f32", "ie_adam_step_f32", "ie_adam_step_counted_f32", "ie_set_deterministic", "ie_get_deterministic", "ie_zdce_forward_u8", "ie_mconv_pair_applicable", "ie_mconv_pair_nhwc", "ie_mconv_pair_thin_applicable", "ie_mconv_pair_thin_nhwc", "ie_mconv_pair_pool_applicable", "ie_mconv_pair_pool_nhwc", "ie_retinex_decom_input", "ie_retinex_outputs_f32", "ie_unet_up_head_applicable", "ie_unet_up_head_nhwc", "ie_unet_first_packed_bytes", "ie_unet_first_pack_weights", "ie_unet_first_applicable", "ie_unet_first_pool_nchw", "ie_conv9x9_c4_packed_bytes", "ie_conv9x9_c4_pack_weights", "ie_conv9x9_c4_nhwc", "ie_conv3x3_c4_packed_bytes", "ie_conv3x3_c4_pack_weights", "ie_conv3x3_c4_nhwc", "ie_paste_nhwc", "ie_channel_stats_nhwc", "ie_channel_affine_nhwc", "ie_channel_affine_add_nhwc", "ie_simam_nhwc", "ie_retinex_recon_f32", "ie_l1_detached_f32", "ie_retinex_smooth_ws_floats",
     "ie_retinex_smooth_f32", "ie_pad_replicate_nhwc_f32", "ie_pad_replicate_backward_nhwc_f32", "ie_pad_replicate_nhwc", "ie_pad_replicate_backward_nhwc", "ie_zero_insert2_nhwc", "ie_rgb_to_hsv_nhwc_f32", "ie_hsv_to_rgb_nhwc_f32", "ie_rgb_to_hvi_nhwc_f32", "ie_hvi_to_rgb_nhwc_f32", "ie_le_curve_nhwc_f32", "ie_box_filter_nhwc_f32", "ie_guided_filter_nhwc_f32", "ie_fast_guided_filter_nhwc_f32", "ie_resize_bicubic_nhwc_f32", "ie_reduce_max_f32", "ie_median_blur_nhwc_f32", "ie_sobel_nhwc_f32", "ie_channel_stats_nhwc_f32", "ie_lin_coeffs_f32", "ie_stats_mean_f32", "ie_channel_affine_nhwc_f32", "ie_simam_nhwc_f32",
-    "ie_norm_forward_nhwc", "ie_norm_backward_nhwc", "ie_convn_wgrad_nhwc", "ie_maxpool2x2_backward_nhwc", "ie_resize_backward_nhwc", "ie_crop_nhwc",
+    "ie_norm_forward_nhwc", "ie_norm_backward_nhwc", "ie_norm_backward_pre_nhwc", "ie_convn_wgrad_nhwc", "ie_maxpool2x2_backward_nhwc", "ie_resize_backward_nhwc", "ie_crop_nhwc",
     "ie_zref_workspace_floats", "ie_zref_image_losses_f32", "ie_tv_loss_nhwc_f32", "ie_le_curve_backward",
     "ie_zdce_create", "ie_zdce_set_layer", "ie_zdce_finalize", "ie_zdce_reserve", "ie_zdce_forward",
     "ie_zdce_get_feature", "ie_zdce_workspace_bytes", "ie_zdce_destroy", "ie_zdce_time_forward",
@@ -198,6 +198,7 @@ def lib():
     L.ie_adam_step_counted_f32.argtypes = [vp, vp, vp, vp, sz, vp, fp, fp, fp, fp, fp, fp, vp, fp, vp]
     L.ie_norm_forward_nhwc.argtypes = [vp, vp, vp, vp, ip, vp, vp, vp, vp, vp, fp, ip, ip, ip, ip, ip, ip, ip, fp, ip, fp, vp]
     L.ie_norm_backward_nhwc.argtypes = [vp, vp, vp, ip, vp, vp, vp, vp, vp, vp, vp, ip, ip, ip, ip, ip, ip, ip, ip, ip, fp, vp]
+    L.ie_norm_backward_pre_nhwc.argtypes = [vp, vp, ip, vp, vp, vp, vp, vp, vp, vp, vp, ip, ip, ip, ip, ip, ip, ip, ip, ip, fp, vp]
     L.ie_convn_wgrad_nhwc.argtypes = [C.POINTER(ConvNDesc), C.POINTER(vp), C.POINTER(ip), vp, ip, vp, vp, ip, vp, vp]
     L.ie_maxpool2x2_backward_nhwc.argtypes = [vp, vp, vp, ip, ip, ip, ip, ip, ip, vp]
     L.ie_resize_backward_nhwc.argtypes = [vp, vp, ip, ip, ip, ip, ip, ip, ip, ip, ip, vp]

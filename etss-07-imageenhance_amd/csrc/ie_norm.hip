@@ -11,10 +11,15 @@ namespace {
 inline unsigned nblk(size_t n) { return (unsigned)((n + 255) / 256); }
 
 // thread = (pixel slot, channel); accumulates sum / sum of squares of x, or of g and g*xhat (backward)
+// PRE (backward passes): the activation's derivative is taken from the RECOMPUTED pre-activation v = gamma * xhat + beta instead of the stored layer output
+// (ReLU / LeakyReLU: the sign of v is the sign of the output) -- one tensor read less in both passes of the backward; pg / pb = gamma / beta of the range or null.
+__device__ __forceinline__ float ie_act_grad_from_pre(float v, int act, float slope) { return v > 0.f ? 1.f : (act == IE_ACT_LRELU ? slope : 0.f); }
+
 template <bool BWD, typename T>
 __global__ void norm_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ yact,
                                    const float* __restrict__ mean, const float* __restrict__ inv, double* __restrict__ stats,
-                                   int HW, int C, int c0, int cn, int cn_total, int c_off, int n_mul, int act, float slope) {
+                                   int HW, int C, int c0, int cn, int cn_total, int c_off, int n_mul, int act, float slope,
+                                   const float* __restrict__ pg = nullptr, const float* __restrict__ pb = nullptr, int pre = 0) {
     const int n = blockIdx.y;
     const int tpc = max(1, 256 / cn);
     const int c = threadIdx.x % cn, ps = threadIdx.x / cn;
@@ -22,14 +27,15 @@ __global__ void norm_reduce_kernel(const T* __restrict__ x, const T* __restrict_
     double s = 0.0, ss = 0.0;
     if (ps < tpc) {
         const size_t base = (size_t)n * HW * C + c0 + c;
-        float m = 0.f, iv = 1.f;
+        float m = 0.f, iv = 1.f, ga = 1.f, be = 0.f;
         if (BWD) { m = mean[(size_t)g * cn_total + c_off + c]; iv = inv[(size_t)g * cn_total + c_off + c]; }
+        if (BWD && pre && pg) { ga = pg[c_off + c]; be = pb[c_off + c]; }
         for (int pix = blockIdx.x * tpc + ps; pix < HW; pix += gridDim.x * tpc) {
             const size_t i = base + (size_t)pix * C;
             if (BWD) {
                 float gr = (float)dy[i];
-                if (act != IE_ACT_NONE) gr *= ie_act_grad_from_output((float)yact[i], act, slope);
                 const float xh = ((float)x[i] - m) * iv;
+                if (act != IE_ACT_NONE) gr *= pre ? ie_act_grad_from_pre(fmaf(xh, ga, be), act, slope) : ie_act_grad_from_output((float)yact[i], act, slope);
                 s += gr; ss += (double)gr * xh;
             } else {
                 const float v = (float)x[i];
@@ -84,16 +90,22 @@ template <typename T>
 __global__ void norm_backward_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ yact,
                                            const float* __restrict__ mean, const float* __restrict__ inv,
                                            const float* __restrict__ gamma, const double* __restrict__ stats, T* __restrict__ dx,
-                                           int HW, int C, int c0, int cn, int n_mul, double count, int act, float slope, size_t total) {
+                                           int HW, int C, int c0, int cn, int n_mul, double count, int act, float slope, size_t total,
+                                           const float* __restrict__ pb = nullptr, int pre = 0) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int c = (int)(i % C);
     float gr = (float)dy[i];
-    if (act != IE_ACT_NONE) gr *= ie_act_grad_from_output((float)yact[i], act, slope);
-    if (c >= c0 && c < c0 + cn) {
+    const bool in = c >= c0 && c < c0 + cn;
+    if (act != IE_ACT_NONE) {
+        if (!pre) gr *= ie_act_grad_from_output((float)yact[i], act, slope);
+        else if (!in) gr *= ie_act_grad_from_pre((float)x[i], act, slope);      // outside the range the layer is the bare activation
+    }
+    if (in) {
         const size_t k = (i / ((size_t)HW * C)) * n_mul * cn + (c - c0);
         const float iv = inv[k];
         const float xh = ((float)x[i] - mean[k]) * iv;
+        if (act != IE_ACT_NONE && pre) gr *= ie_act_grad_from_pre(fmaf(xh, gamma ? gamma[c - c0] : 1.f, pb ? pb[c - c0] : 0.f), act, slope);
         const float m1 = (float)(stats[2 * k] / count), m2 = (float)(stats[2 * k + 1] / count);
         gr = (gamma ? gamma[c - c0] : 1.f) * iv * (gr - m1 - xh * m2);
     }
@@ -120,7 +132,8 @@ template <bool BWD, typename T>
 __global__ __launch_bounds__(256) void norm_reduce_v8_kernel(const T* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ yact,
                                                              const float* __restrict__ mean, const float* __restrict__ inv,
                                                              double* __restrict__ stats, int HW, int C, int c0, int nch, int cn_total, int c_off,
-                                                             int n_mul, int act, float slope) {
+                                                             int n_mul, int act, float slope, const float* __restrict__ pg = nullptr,
+                                                             const float* __restrict__ pb = nullptr, int pre = 0) {
     typedef typename ie_vec8<T>::type V;
     const int n = blockIdx.y;
     const int tpc = 256 / nch;
@@ -131,12 +144,14 @@ __global__ __launch_bounds__(256) void norm_reduce_v8_kernel(const T* __restrict
     for (int k = 0; k < 8; ++k) { s[k] = 0.f; ss[k] = 0.f; }
     if (ps < tpc) {
         const size_t base = (size_t)n * HW * C + c0 + ch * 8;
-        float m[8], iv[8];
+        float m[8], iv[8], ga[8], be[8];
         if (BWD) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 m[k] = mean[(size_t)g * cn_total + c_off + ch * 8 + k];
                 iv[k] = inv[(size_t)g * cn_total + c_off + ch * 8 + k];
+                ga[k] = (pre && pg) ? pg[c_off + ch * 8 + k] : 1.f;
+                be[k] = (pre && pg) ? pb[c_off + ch * 8 + k] : 0.f;
             }
         }
         for (int pix = blockIdx.x * tpc + ps; pix < HW; pix += gridDim.x * tpc) {
@@ -145,13 +160,14 @@ __global__ __launch_bounds__(256) void norm_reduce_v8_kernel(const T* __restrict
             if (BWD) {
                 const V dv = *(const V*)(dy + i);
                 V yv = xv;
-                if (act != IE_ACT_NONE) yv = *(const V*)(yact + i);
+                if (act != IE_ACT_NONE && !pre) yv = *(const V*)(yact + i);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     float gr = (float)dv[k];
-                    if (act != IE_ACT_NONE) gr *= ie_act_grad_from_output((float)yv[k], act, slope);
+                    const float xh = ((float)xv[k] - m[k]) * iv[k];
+                    if (act != IE_ACT_NONE) gr *= pre ? ie_act_grad_from_pre(fmaf(xh, ga[k], be[k]), act, slope) : ie_act_grad_from_output((float)yv[k], act, slope);
                     s[k] += gr;
-                    ss[k] = fmaf(gr, ((float)xv[k] - m[k]) * iv[k], ss[k]);
+                    ss[k] = fmaf(gr, xh, ss[k]);
                 }
             } else {
 #pragma unroll
@@ -214,22 +230,24 @@ __global__ __launch_bounds__(256, 4) void norm_backward_apply_v8_kernel(const T*
                                                                      const float* __restrict__ mean, const float* __restrict__ inv,
                                                                      const float* __restrict__ gamma, const double* __restrict__ stats,
                                                                      T* __restrict__ dx, int HW, int C, int c0, int cn, int n_mul, double count,
-                                                                     int act, float slope, int nchb) {
+                                                                     int act, float slope, int nchb, const float* __restrict__ pb = nullptr, int pre = 0) {
     typedef typename ie_vec8<T>::type V;
     const int n = blockIdx.y;
     const int tpc = 256 / nchb;
     const int c = (blockIdx.z * nchb + threadIdx.x % nchb) * 8, ps = threadIdx.x / nchb;
     if (ps >= tpc || c >= C) return;
     const bool in = c >= c0 && c < c0 + cn;
-    float m[8], iv[8], gi[8], m1[8], m2[8];
+    float m[8], iv[8], gi[8], m1[8], m2[8], ga[8], be[8];
     const double rcount = 1.0 / count;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        m[k] = 0.f; iv[k] = 1.f; gi[k] = 1.f; m1[k] = 0.f; m2[k] = 0.f;
+        m[k] = 0.f; iv[k] = 1.f; gi[k] = 1.f; m1[k] = 0.f; m2[k] = 0.f; ga[k] = 1.f; be[k] = 0.f;
         if (in) {
             const size_t idx = (size_t)n * n_mul * cn + (c - c0) + k;
             m[k] = mean[idx]; iv[k] = inv[idx];
-            gi[k] = (gamma ? gamma[c - c0 + k] : 1.f) * iv[k];
+            ga[k] = gamma ? gamma[c - c0 + k] : 1.f;
+            be[k] = (pre && pb) ? pb[c - c0 + k] : 0.f;
+            gi[k] = ga[k] * iv[k];
             m1[k] = (float)(stats[2 * idx] * rcount); m2[k] = (float)(stats[2 * idx + 1] * rcount);
         }
     }
@@ -240,7 +258,7 @@ __global__ __launch_bounds__(256, 4) void norm_backward_apply_v8_kernel(const T*
         float gr[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) gr[k] = (float)dv[k];
-        if (act != IE_ACT_NONE) {
+        if (act != IE_ACT_NONE && !pre) {
             const V yv = *(const V*)(yact + i);
 #pragma unroll
             for (int k = 0; k < 8; ++k) gr[k] *= ie_act_grad_from_output((float)yv[k], act, slope);
@@ -251,9 +269,15 @@ __global__ __launch_bounds__(256, 4) void norm_backward_apply_v8_kernel(const T*
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const float xh = ((float)xv[k] - m[k]) * iv[k];
+                if (act != IE_ACT_NONE && pre) gr[k] *= ie_act_grad_from_pre(fmaf(xh, ga[k], be[k]), act, slope);
                 out[k] = (T)(gi[k] * (gr[k] - m1[k] - xh * m2[k]));
             }
         } else {
+            if (act != IE_ACT_NONE && pre) {      // outside the range the layer is the bare activation of x
+                const V xv = *(const V*)(x + i);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) gr[k] *= ie_act_grad_from_pre((float)xv[k], act, slope);
+            }
 #pragma unroll
             for (int k = 0; k < 8; ++k) out[k] = (T)gr[k];
         }
@@ -282,7 +306,7 @@ template <typename T> constexpr bool norm_v8_ok(int C, int c_begin, int c_count)
 
 template <bool BWD, typename T>
 int launch_reduce_v8(const T* x, const T* dy, const T* yact, const float* mean, const float* inv, double* ws, int N, int HW,
-                     int C, int c_begin, int c_count, int n_mul, int act, float slope, hipStream_t st) {
+                     int C, int c_begin, int c_count, int n_mul, int act, float slope, hipStream_t st, const float* pg = nullptr, const float* pb = nullptr, int pre = 0) {
     const int groups = n_mul ? N : 1;
     IE_HIP_CHECK(hipMemsetAsync(ws, 0, sizeof(double) * 2 * (size_t)groups * c_count, st));
     for (int off = 0; off < c_count; off += 2048) {      // <= 256 chunks of 8 channels per launch
@@ -295,7 +319,7 @@ int launch_reduce_v8(const T* x, const T* dy, const T* yact, const float* mean, 
         if (chunks < min_chunks) chunks = min_chunks;
         if (chunks < 1) chunks = 1;
         hipLaunchKernelGGL((norm_reduce_v8_kernel<BWD, T>), dim3(chunks, N), dim3(256), 0, st, x, dy, yact, mean, inv, ws, HW, C, c_begin + off,
-                           nch, c_count, off, n_mul, act, slope);
+                           nch, c_count, off, n_mul, act, slope, pg, pb, pre);
         IE_LAUNCH_CHECK();
     }
     return IE_OK;
@@ -303,9 +327,9 @@ int launch_reduce_v8(const T* x, const T* dy, const T* yact, const float* mean, 
 
 template <bool BWD, typename T>
 int launch_reduce(const T* x, const T* dy, const T* yact, const float* mean, const float* inv, double* ws, int N, int HW,
-                  int C, int c_begin, int c_count, int n_mul, int act, float slope, hipStream_t st) {
+                  int C, int c_begin, int c_count, int n_mul, int act, float slope, hipStream_t st, const float* pg = nullptr, const float* pb = nullptr, int pre = 0) {
     if constexpr (sizeof(T) == 2) {
-        if (norm_v8_ok<T>(C, c_begin, c_count)) return launch_reduce_v8<BWD, T>(x, dy, yact, mean, inv, ws, N, HW, C, c_begin, c_count, n_mul, act, slope, st);
+        if (norm_v8_ok<T>(C, c_begin, c_count)) return launch_reduce_v8<BWD, T>(x, dy, yact, mean, inv, ws, N, HW, C, c_begin, c_count, n_mul, act, slope, st, pg, pb, pre);
     }
     const int groups = n_mul ? N : 1;
     IE_HIP_CHECK(hipMemsetAsync(ws, 0, sizeof(double) * 2 * (size_t)groups * c_count, st));
@@ -317,7 +341,7 @@ int launch_reduce(const T* x, const T* dy, const T* yact, const float* mean, con
         if (chunks > cap) chunks = cap;
         if (chunks < 1) chunks = 1;
         hipLaunchKernelGGL((norm_reduce_kernel<BWD, T>), dim3(chunks, N), dim3(256), 0, st, x, dy, yact, mean, inv, ws, HW, C, c_begin + off,
-                           cn, c_count, off, n_mul, act, slope);
+                           cn, c_count, off, n_mul, act, slope, pg, pb, pre);
         IE_LAUNCH_CHECK();
     }
     return IE_OK;
@@ -359,13 +383,15 @@ static int norm_forward_impl(const T* x, const float* gamma, const float* beta, 
 template <typename T>
 static int norm_backward_impl(const T* x, const T* dy, const T* y, const float* gamma, const float* save_mean, const float* save_invstd, double* ws,
                               T* dx, float* dgamma, float* dbeta, int accumulate_param_grads, int per_sample, int N, int H, int W, int C,
-                              int c_begin, int c_count, int act, float slope, void* stream) {
+                              int c_begin, int c_count, int act, float slope, void* stream, const float* beta = nullptr, int pre = 0) {
     if (!x || !dy || !save_mean || !save_invstd || !ws || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || c_begin < 0 || c_count <= 0 ||
-        c_begin + c_count > C || (act != IE_ACT_NONE && !y) || (dgamma == nullptr) != (dbeta == nullptr))
+        c_begin + c_count > C || (act != IE_ACT_NONE && !y && !pre) || (dgamma == nullptr) != (dbeta == nullptr))
         IE_FAIL(IE_ERR_INVALID, "ie_norm_backward_nhwc: bad args");
+    if (pre && ((gamma == nullptr) != (beta == nullptr) || (act != IE_ACT_NONE && act != IE_ACT_RELU && act != IE_ACT_LRELU)))
+        IE_FAIL(IE_ERR_INVALID, "ie_norm_backward_pre_nhwc: gamma and beta go together; none / ReLU / LeakyReLU only (the derivative must be a function of the pre-activation's sign)");
     hipStream_t st = (hipStream_t)stream;
     const int HW = H * W, n_mul = per_sample ? 1 : 0, groups = per_sample ? N : 1;
-    int rc = launch_reduce<true, T>(x, dy, y, save_mean, save_invstd, ws, N, HW, C, c_begin, c_count, n_mul, act, slope, st);
+    int rc = launch_reduce<true, T>(x, dy, y, save_mean, save_invstd, ws, N, HW, C, c_begin, c_count, n_mul, act, slope, st, gamma, beta, pre);
     if (rc != IE_OK) return rc;
     const double count = per_sample ? (double)HW : (double)N * HW;
     const size_t total = (size_t)N * HW * C;
@@ -373,10 +399,10 @@ static int norm_backward_impl(const T* x, const T* dy, const T* y, const float* 
         int nchb;
         const dim3 grid = norm_apply_v8_grid(N, HW, C, nchb);
         hipLaunchKernelGGL(norm_backward_apply_v8_kernel<T>, grid, dim3(256), 0, st, x, dy, y, save_mean, save_invstd, gamma, ws, dx, HW, C,
-                           c_begin, c_count, n_mul, count, act, slope, nchb);
+                           c_begin, c_count, n_mul, count, act, slope, nchb, beta, pre);
     } else
         hipLaunchKernelGGL(norm_backward_apply_kernel<T>, dim3(nblk(total)), dim3(256), 0, st, x, dy, y, save_mean, save_invstd, gamma, ws, dx,
-                           HW, C, c_begin, c_count, n_mul, count, act, slope, total);
+                           HW, C, c_begin, c_count, n_mul, count, act, slope, total, beta, pre);
     IE_LAUNCH_CHECK();
     if (dgamma) {
         hipLaunchKernelGGL(norm_param_grad_kernel, dim3(nblk(c_count)), dim3(256), 0, st, ws, dgamma, dbeta, groups, c_count,
@@ -405,6 +431,17 @@ IE_EXPORT int ie_norm_backward_nhwc(const void* x, const void* dy, const void* y
     case IE_F16: return norm_backward_impl((const _Float16*)x, (const _Float16*)dy, (const _Float16*)y, gamma, save_mean, save_invstd, ws, (_Float16*)dx, dgamma, dbeta, accumulate_param_grads, per_sample, N, H, W, C, c_begin, c_count, act, slope, stream);
     case IE_BF16: return norm_backward_impl((const __bf16*)x, (const __bf16*)dy, (const __bf16*)y, gamma, save_mean, save_invstd, ws, (__bf16*)dx, dgamma, dbeta, accumulate_param_grads, per_sample, N, H, W, C, c_begin, c_count, act, slope, stream);
     default: IE_FAIL(IE_ERR_INVALID, "ie_norm_backward_nhwc: bad dtype");
+    }
+}
+
+IE_EXPORT int ie_norm_backward_pre_nhwc(const void* x, const void* dy, int dtype, const float* gamma, const float* beta, const float* save_mean,
+                                        const float* save_invstd, double* ws, void* dx, float* dgamma, float* dbeta, int accumulate_param_grads,
+                                        int per_sample, int N, int H, int W, int C, int c_begin, int c_count, int act, float slope, void* stream) {
+    switch (dtype) {
+    case IE_F32: return norm_backward_impl((const float*)x, (const float*)dy, (const float*)nullptr, gamma, save_mean, save_invstd, ws, (float*)dx, dgamma, dbeta, accumulate_param_grads, per_sample, N, H, W, C, c_begin, c_count, act, slope, stream, beta, 1);
+    case IE_F16: return norm_backward_impl((const _Float16*)x, (const _Float16*)dy, (const _Float16*)nullptr, gamma, save_mean, save_invstd, ws, (_Float16*)dx, dgamma, dbeta, accumulate_param_grads, per_sample, N, H, W, C, c_begin, c_count, act, slope, stream, beta, 1);
+    case IE_BF16: return norm_backward_impl((const __bf16*)x, (const __bf16*)dy, (const __bf16*)nullptr, gamma, save_mean, save_invstd, ws, (__bf16*)dx, dgamma, dbeta, accumulate_param_grads, per_sample, N, H, W, C, c_begin, c_count, act, slope, stream, beta, 1);
+    default: IE_FAIL(IE_ERR_INVALID, "ie_norm_backward_pre_nhwc: bad dtype");
     }
 }
 

@@ -588,7 +588,9 @@ def norm_forward(x, gamma, beta, per_sample: bool, running_mean=None, running_va
 
 
 def norm_backward(x, dy, y, gamma, mean, inv, per_sample: bool, dgamma=None, dbeta=None, accumulate=False, act="none", slope=0.0,
-                  c_begin=0, c_count=None):
+                  c_begin=0, c_count=None, beta=None, recompute=False):
+    """``recompute`` (act none / relu / lrelu): the activation's derivative comes from the recomputed pre-activation gamma * xhat + beta instead of the
+    stored output ``y`` (ie_norm_backward_pre_nhwc: neither pass reads ``y``; pass ``beta`` whenever ``gamma`` is given)."""
     _chk_any(x); _chk_any(dy)
     if dy.dtype != x.dtype:
         raise capi.IEError("norm_backward: x and dy must have the same dtype")
@@ -597,6 +599,13 @@ def norm_backward(x, dy, y, gamma, mean, inv, per_sample: bool, dgamma=None, dbe
     g = n if per_sample else 1
     dx = torch.empty_like(x, memory_format=CL)
     ws = torch.empty(2 * g * c_count, device=x.device, dtype=torch.float64)
+    if recompute:
+        with torch.cuda.device(x.device):
+            capi.check(capi.lib().ie_norm_backward_pre_nhwc(capi.ptr(x), capi.ptr(dy), _dt(x), capi.ptr(gamma), capi.ptr(beta), capi.ptr(mean),
+                                                            capi.ptr(inv), capi.ptr(ws), capi.ptr(dx), capi.ptr(dgamma), capi.ptr(dbeta),
+                                                            int(accumulate), int(per_sample), n, h, w, c, c_begin, c_count,
+                                                            capi.ACT[act], slope, capi.current_stream()), "ie_norm_backward_pre_nhwc")
+        return dx
     with torch.cuda.device(x.device):
         capi.check(capi.lib().ie_norm_backward_nhwc(capi.ptr(x), capi.ptr(dy), capi.ptr(y), _dt(x), capi.ptr(gamma), capi.ptr(mean),
                                                     capi.ptr(inv), capi.ptr(ws), capi.ptr(dx), capi.ptr(dgamma), capi.ptr(dbeta),

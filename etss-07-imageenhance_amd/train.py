@@ -372,7 +372,9 @@ def t_norm(tape, x, gamma, beta, dgamma, dbeta, per_sample, running_mean=None, r
         dy = tape.grad(y)
         if dy is None:
             return
-        dx = ops.norm_backward(x, dy, y, gamma, mean, inv, per_sample, dgamma, dbeta, False, act, slope, c_begin, c_count)
+        # none / ReLU / LeakyReLU: the activation's derivative from the recomputed pre-activation -- the two passes read x and dy, not y (IE_NORM_RECOMPUTE=0: A/B)
+        pre = act in ("none", "relu", "lrelu") and _os_env("IE_NORM_RECOMPUTE", "1") != "0"
+        dx = ops.norm_backward(x, dy, y, gamma, mean, inv, per_sample, dgamma, dbeta, False, act, slope, c_begin, c_count, beta=beta, recompute=pre)
         if tape.is_no_grad(x):
             return
         if tape.grad(x) is not None:

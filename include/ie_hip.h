@@ -394,6 +394,13 @@ int ie_norm_backward_nhwc(const void* x_dev, const void* dy_dev, const void* y_d
                           const float* save_invstd_dev, double* ws_dev, void* dx_dev, float* dgamma_dev, float* dbeta_dev,
                           int accumulate_param_grads, int per_sample, int N, int H, int W, int C, int c_begin, int c_count, int act, float slope,
                           void* stream);
+/* The same backward with the activation's derivative taken from the RECOMPUTED pre-activation v = gamma * xhat + beta (channels outside the range: v = x)
+ * instead of the stored layer output: for act = none / ReLU / LeakyReLU the derivative is a function of sign(v) = sign(y), and neither pass reads y -- two
+ * tensor reads per pass instead of three (what torch's fused BatchNorm + ReLU backward saves the output for: nn.BatchNorm2d + nn.ReLU, unet.py:42-47). */
+int ie_norm_backward_pre_nhwc(const void* x_dev, const void* dy_dev, int dtype, const float* gamma_dev, const float* beta_dev, const float* save_mean_dev,
+                              const float* save_invstd_dev, double* ws_dev, void* dx_dev, float* dgamma_dev, float* dbeta_dev,
+                              int accumulate_param_grads, int per_sample, int N, int H, int W, int C, int c_begin, int c_count, int act, float slope,
+                              void* stream);
 int ie_convn_wgrad_nhwc(ie_convn_desc* d, const void* const* srcs_dev, const int* channels, const void* dy_dev, int dtype, float* dw_hwio_dev,
                         float* dbias_dev, int accumulate, double* ws_dev, void* stream);
 int ie_maxpool2x2_backward_nhwc(const void* x_dev, const void* dy_dev, void* dx_dev, int dtype, int N, int H, int W, int C, int accumulate, void* stream);

@@ -115,6 +115,13 @@ def test_norm_forward_backward(per_sample, c, act, c_begin, c_count):
     dx = ops.norm_backward(xd, dev(dy), y, gd, mean, inv, per_sample, dg, db, False, act, 0.2, c_begin, c_count)
     assert rel_err(host(dx), xr.grad) < 2e-5
     assert rel_err(host(dg), gr.grad) < 2e-5 and rel_err(host(db), br.grad) < 2e-5
+    # the same from the recomputed pre-activation (ie_norm_backward_pre_nhwc: the layer output is not read)
+    dg2, db2 = torch.empty(cc, device="cuda"), torch.empty(cc, device="cuda")
+    dx2 = ops.norm_backward(xd, dev(dy), None, gd, mean, inv, per_sample, dg2, db2, False, act, 0.2, c_begin, c_count, beta=bd, recompute=True)
+    assert rel_err(host(dx2), xr.grad) < 2e-5
+    assert rel_err(host(dg2), gr.grad) < 2e-5 and rel_err(host(db2), br.grad) < 2e-5
+    with pytest.raises(capi.IEError):
+        ops.norm_backward(xd, dev(dy), None, gd, mean, inv, per_sample, dg2, db2, False, "tanh", 0.2, c_begin, c_count, beta=bd, recompute=True)
 
 
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
@@ -152,6 +159,14 @@ def test_norm_forward_backward_16bit(per_sample, c, act, c_begin, c_count, dtype
     assert dx.dtype == tdt
     assert rel_err(host(dx), xr.grad) < tol
     assert rel_err(host(dg), gr.grad) < tol and rel_err(host(db), br.grad) < tol
+    # ... and from the recomputed pre-activation (what the training tape runs): the mask is sign(gamma * xhat + beta) instead of sign(rounded output) --
+    # the two differ only where the pre-activation rounds to zero in 16 bits
+    dg2, db2 = torch.empty(cc, device="cuda"), torch.empty(cc, device="cuda")
+    dx2 = ops.norm_backward(xd, dyd, None, gd, mean, inv, per_sample, dg2, db2, False, act, 0.2, c_begin, c_count, beta=bd, recompute=True)
+    assert dx2.dtype == tdt
+    assert rel_err(host(dx2), xr.grad) < tol
+    assert rel_err(host(dg2), gr.grad) < tol and rel_err(host(db2), br.grad) < tol
+    assert rel_err(host(dx2), host(dx)) < 1e-3
 
 
 # ---- conv gradients ------------------------------------------------------------------------------------------------------
@@ -493,6 +508,35 @@ def test_training_steps_deterministic_run_to_run(cdt):
             assert torch.equal(finals[0][k], finals[1][k]), k
     finally:
         capi.set_deterministic(prev)
+
+
+@pytest.mark.parametrize("upsampler", ["bilinear", "convtranspose"])
+@pytest.mark.parametrize("cdt", ["bf16", "f16"])
+def test_weight_gradients_on_the_side_stream_match_the_in_line_order(cdt, upsampler):
+    """Trainer.overlap_wgrad (16-bit graphs): the weight-gradient launches run on a side stream beside the rest of the backward pass.  Same kernels on the
+    same operands: the gradients agree with the single-stream order to the fp32 atomics' summation order, three optimiser steps stay together, and the
+    ConvTranspose bias reduction (which reads what the layer's weight gradient wrote) stays behind it."""
+    res = []
+    for overlap in (False, True):
+        model = _unet(upsampler, seed=17, base=16)
+        tr = mon_amd.Trainer(model, optimizer={"name": "adam", "lr": 1e-3, "eps": 1e-3}, loss={"name": "l1_ssim_loss"}, gradient_clip_val=0.1, compute_dtype=cdt)
+        tr.overlap_wgrad = overlap
+        batches = _batches(2, 64, 96, 3, seed=9)
+        out = tr.forward_loss({"image": batches[0][0], "ref_image": batches[0][1]})
+        tr.backward(out)
+        torch.cuda.synchronize()
+        g = {k: v.clone() for k, v in tr.gradients().items()}
+        assert (tr._wgrad_stream is not None) == overlap
+        for img, tgt in batches:
+            tr.training_step({"image": img, "ref_image": tgt})
+        res.append((g, tr.state_dict(), float(tr.forward_loss({"image": batches[0][0], "ref_image": batches[0][1]})["loss"])))
+    (g0, s0, l0), (g1, s1, l1) = res
+    for k in g0:
+        assert torch.isfinite(g1[k]).all(), k
+        assert float((g0[k] - g1[k]).abs().max()) <= 1e-5 * max(1.0, float(g0[k].abs().max())) + 1e-7, k
+    for k in s0:
+        assert float((s0[k] - s1[k]).abs().max()) <= 2e-4, k
+    assert abs(l0 - l1) < 1e-4
 
 
 def test_overflowed_step_is_skipped_without_clipping():
