@@ -134,6 +134,28 @@ __device__ __forceinline__ RowRead row_read(int hf, int p16, int kq) {
 // instruction, 8 per transcendental one -- and costs its full length as a phase of its own: tools/micro/coissue.hip, MI355X_MICROARCH.md constants table).
 // The fragment read of a group comes right behind the group's first MFMA, so a gap that ends in a transcendental filler is followed by an MFMA, not by a vector
 // instruction (hipcc puts an s_nop between the two, another 4 cycles of the issue port).
+// compiler-scheduled form of the same row (no pinned order): experiment IE_K67X_UNPIN_A
+template <typename T>
+__device__ __forceinline__ void mfma_row_free(const char* slot, const RowRead& rr, const ie_u32x4* wv, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4],
+                                              bool first, const ie_f32x4& init) {
+    const char* bk[3] = {slot + rr.base[0], slot + rr.base[1], slot + rr.base[2]};
+#pragma unroll
+    for (int g = 0; g < 12; ++g) {
+        const int kx = g >> 2, j = g & 3;
+        const ie_u32x4 bx = *(const ie_u32x4*)(bk[kx] + 1024 * j);
+        accN[j] = ie_mfma16_raw<T>(wv[0 * 3 + kx], bx, (first && kx == 0) ? init : accN[j]);
+        accM[j] = ie_mfma16_raw<T>(wv[1 * 3 + kx], bx, accM[j]);
+        accO[j] = ie_mfma16_raw<T>(wv[2 * 3 + kx], bx, accO[j]);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+    for (int f = 0; f < 9; ++f) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);
+}
+
 template <typename T, int AHEAD = 3, typename F>
 __device__ __forceinline__ void mfma_row(const char* slot, const RowRead& rr, const ie_u32x4* wv, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4],
                                          bool first, const ie_f32x4& init, F&& fill) {
@@ -360,6 +382,12 @@ struct K67XParams {
 #ifndef IE_K67X_PACE_A
 #define IE_K67X_PACE_A -1
 #endif
+#ifndef IE_K67X_BURST_FIRST
+#define IE_K67X_BURST_FIRST 1      // the curve as one burst at the head of stage B's step (0: as 8-cycle items in the gaps of its MFMA stream).  At the head of a step the older stage
+#endif                             // (A) takes every matrix-pipe slot it is ready for, so stage B's MFMAs would wait anyway: -6 % on the kernel (profiles/r04/k67x_experiments.log, 10)
+#ifndef IE_K67X_UNPIN_A
+#define IE_K67X_UNPIN_A 0
+#endif
 #ifndef IE_K67X_IPG
 #define IE_K67X_IPG 1       // gap items per MFMA gap
 #endif
@@ -580,7 +608,11 @@ __device__ __forceinline__ void k67x_body(const K67XParams& p) {
 #else
             auto nofill = [&](int) __attribute__((always_inline)) {};
 #endif
-            if constexpr (!(IE_XEXP & 32)) {
+            if constexpr (IE_K67X_UNPIN_A) {
+            mfma_row_free<TA0>(smem + G::OFF_X2 + (t % NRA) * ROWH_B, rr, wv, accN, accM, accO, true, bias6);
+            IE_TACC(2);
+            mfma_row_free<TA1>(smem + G::OFF_X5 + (t % NRA) * ROWH_B, rr, wv + 9, accN, accM, accO, false, bias6);
+            } else if constexpr (!(IE_XEXP & 32)) {
             mfma_row<TA0, IE_K67X_AHA>(smem + G::OFF_X2 + (t % NRA) * ROWH_B, rr, wv, accN, accM, accO, true, bias6, nofill);
             IE_TACC(2);
             mfma_row<TA1, IE_K67X_AHA>(smem + G::OFF_X5 + (t % NRA) * ROWH_B, rr, wv + 9, accN, accM, accO, false, bias6, nofill);
@@ -698,8 +730,13 @@ __device__ __forceinline__ void k67x_body(const K67XParams& p) {
                 else if (i < 10) op(k, 2, i - 6);
                 else { const int w = 3 + ((i - 10) >> 1), j0 = 2 * ((i - 10) & 1); op(k, w, j0); op(k, w, j0 + 1); }
             };
+            if constexpr (IE_K67X_BURST_FIRST) {       // the whole curve as a burst BEFORE the stage's MFMAs: at the head of a step the older stage has the matrix pipe anyway
+#pragma unroll
+                for (int it = 0; it < 64; ++it) item(it);
+                IE_SB();
+            }
             auto gap = [&](int s) __attribute__((always_inline)) {
-                if constexpr ((IE_XEXP & 1) || (IE_XEXP & 1024)) return;
+                if constexpr ((IE_XEXP & 1) || (IE_XEXP & 1024) || IE_K67X_BURST_FIRST) return;
 #pragma unroll
                 for (int r = 0; r < IE_K67X_IPG; ++r) item((s - IE_K67X_HEAD) * IE_K67X_IPG + r);
             };
@@ -707,7 +744,30 @@ __device__ __forceinline__ void k67x_body(const K67XParams& p) {
             const int hs = ((t + 2 - cj) % NRH) * ROWH_B;
             auto fill1 = [&](int s) __attribute__((always_inline)) { gap(s); };
             auto fill6 = [&](int s) __attribute__((always_inline)) { gap(s + 36); };
-            if constexpr (!(IE_XEXP & 64)) {
+            if constexpr (IE_XEXP & 8192) {
+                // timing experiment (wrong results): stage B's arithmetic as 36 v_mfma_f32_32x32x16 on the same number of LDS fragments (12 per step, two thirds of them
+                // dummies of the first row's) -- the same matrix-pipe cycles as 72 16x16x32, but a single wave sustains the 32-cycle instruction back to back
+                ie_f32x16 big[3];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { big[0][i] = accN[i >> 2][i & 3]; big[1][i] = accM[i >> 2][i & 3]; big[2][i] = accO[i >> 2][i & 3]; }
+                const char* r1 = smem + G::OFF_H1 + hs;
+                const char* r6 = smem + G::OFF_H6 + hs;
+                ie_u32x4 fx[12];
+#pragma unroll
+                for (int g = 0; g < 3; ++g) fx[g] = *(const ie_u32x4*)(r1 + rr.base[g % 3] + 1024 * (g & 3));
+                IE_SB();
+#pragma unroll
+                for (int g = 0; g < 12; ++g) {
+                    if (g + 3 < 12) fx[g + 3] = *(const ie_u32x4*)((g + 3 < 6 ? r1 : r6) + rr.base[(g + 3) % 3] + 1024 * ((g + 3) & 3));
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) {
+                        big[ky] = ie_elem<TH>::mfma32(__builtin_bit_cast(typename ie_elem<TH>::frag, wv[(g + ky) % 18]), __builtin_bit_cast(typename ie_elem<TH>::frag, fx[g]), big[ky]);
+                        IE_SB();
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { accN[i >> 2][i & 3] = big[0][i]; accM[i >> 2][i & 3] = big[1][i]; accO[i >> 2][i & 3] = big[2][i]; }
+            } else if constexpr (!(IE_XEXP & 64)) {
             mfma_row<TH, (M_ADJ ? IE_K67X_AHB - 1 : IE_K67X_AHB)>(smem + G::OFF_H1 + hs, rr, wv, accN, accM, accO, true, bias7, fill1);
             IE_TACC(5);
             mfma_row<TH, (M_ADJ ? IE_K67X_AHB - 1 : IE_K67X_AHB)>(smem + G::OFF_H6 + hs, rr, wv + 9, accN, accM, accO, false, bias7, fill6);
