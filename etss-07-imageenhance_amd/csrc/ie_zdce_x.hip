@@ -388,6 +388,9 @@ struct K67XParams {
 #ifndef IE_K67X_UNPIN_A
 #define IE_K67X_UNPIN_A 0
 #endif
+#ifndef IE_K67X_CONVERT_B
+#define IE_K67X_CONVERT_B 0
+#endif
 #ifndef IE_K67X_IPG
 #define IE_K67X_IPG 1       // gap items per MFMA gap
 #endif
@@ -620,7 +623,7 @@ __device__ __forceinline__ void k67x_body(const K67XParams& p) {
             IE_TACC(1);
             if constexpr (!(IE_XEXP & 8)) issue(t + PF);
             IE_TACC(5);
-            if constexpr (!(IE_XEXP & 2)) convert(t + 1);
+            if constexpr (!(IE_XEXP & 2) && !IE_K67X_CONVERT_B) convert(t + 1);
             IE_TACC(6);
             const int m = ys - 3 + t;
             if constexpr (!(IE_XEXP & 4)) {
@@ -679,6 +682,8 @@ __device__ __forceinline__ void k67x_body(const K67XParams& p) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (this stage issues no loads; its stores are only waited for at the end)
             __builtin_amdgcn_s_barrier();
             IE_TACC(0);
+            if constexpr (IE_K67X_CONVERT_B)       // experiment: the image row conversion at the head of stage B's step instead of in stage A's tail
+                convert_row<TH>(smem + G::OFF_RAW + ((t + 1) % NRAW) * RAW_SLOT_B, smem + G::OFF_IMG + ((t + 1) % NRI) * G::IMG_ROW_B, smem + G::OFF_DUMP, w4 * 64 + lane, lane);
             IE_TACC(4);
             // the curve's running value of the row in accF: row ys - 6 + t - cj = raw row of step t - 4 - cj; tile 1 reads what tile 0 left at step t - 1
             const char* yin = cj ? smem + G::OFF_Y4 + ((t + 1) & 1) * G::YSLOT_B : smem + G::OFF_RAW + ((t + 4) % NRAW) * RAW_SLOT_B;
