@@ -5,6 +5,7 @@
 // Reference call sites are cited at the entry points in include/ie_hip.h.
 #include "ie_common.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -285,13 +286,14 @@ __global__ __launch_bounds__(256, 4) void norm_backward_apply_v8_kernel(const T*
     }
 }
 
-// grid of the apply passes: ~8 pixels per thread, at most ~8192 workgroups
+// grid of the apply passes: ~8 pixels per thread, at most ~1024 workgroups
 inline dim3 norm_apply_v8_grid(int N, int HW, int C, int& nchb) {
     const int C8 = C / 8;
     nchb = C8 < 256 ? C8 : 256;
     const int tpc = 256 / nchb;
     int chunks = ie_cdiv(HW, tpc * 8);
-    const int cap = ie_cdiv(8192, N);
+    static const int wg_cap = getenv("IE_NORM_GRID_CAP") ? atoi(getenv("IE_NORM_GRID_CAP")) : 1024;      // few, long-running workgroups (grid-stride) leave wave slots to the weight-gradient kernel on the side stream: 8192 -> 1024 = +1 % on the U-Net-64 step, 512 = -6 %
+    const int cap = ie_cdiv(wg_cap, N);
     if (chunks > cap) chunks = cap;
     if (chunks < 1) chunks = 1;
     return dim3(chunks, N, ie_cdiv(C8, nchb));
