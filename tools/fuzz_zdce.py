@@ -30,5 +30,12 @@ for case in range(n_cases):
         if not (err <= tol[dt]) or du8 > (2 if dt == "bf16_pure" else 1) or not bool(torch.isfinite(out["enhanced"]).all()):
             bad += 1
             print(f"FAIL case {case}: n={n} h={h} w={w} dt={dt} err={err:.3e} u8 diff {du8}")
+        # the last kernel's other compiled forms (enhanced alone / enhanced + curve maps / uint8 alone) must give the same bits as the general one
+        e_only = models[dt].enhance(x)["enhanced"]
+        ea = models[dt].enhance(x, want_adjust=True)
+        u_only = models[dt].enhance(x, want_enhanced=False, want_u8=True)["u8"]
+        if not (torch.equal(e_only, out["enhanced"]) and torch.equal(ea["enhanced"], out["enhanced"]) and torch.equal(u_only, out["u8"]) and bool(torch.isfinite(ea["adjust"]).all())):
+            bad += 1
+            print(f"FAIL case {case}: n={n} h={h} w={w} dt={dt}: output-mode forms disagree")
 print(f"{n_cases} cases x 3 modes, {bad} failures")
 sys.exit(1 if bad else 0)
