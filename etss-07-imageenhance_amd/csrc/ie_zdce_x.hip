@@ -611,7 +611,30 @@ __device__ __forceinline__ void k67x_body(const K67XParams& p) {
 #else
             auto nofill = [&](int) __attribute__((always_inline)) {};
 #endif
-            if constexpr (IE_K67X_UNPIN_A) {
+            if constexpr (IE_XEXP & 16384) {
+                // timing experiment (wrong results): stage A's e_conv6 as 36 v_mfma_f32_32x32x16 on 12 of its 24 LDS fragments per step (the instruction a lone wave sustains
+                // back to back) -- same matrix-pipe cycles as the 72 16x16x32
+                ie_f32x16 big[3];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { big[0][i] = accN[i >> 2][i & 3]; big[1][i] = accM[i >> 2][i & 3]; big[2][i] = accO[i >> 2][i & 3]; }
+                const char* r2 = smem + G::OFF_X2 + (t % NRA) * ROWH_B;
+                const char* r5 = smem + G::OFF_X5 + (t % NRA) * ROWH_B;
+                ie_u32x4 fx[12];
+#pragma unroll
+                for (int g = 0; g < 3; ++g) fx[g] = *(const ie_u32x4*)(r2 + rr.base[g % 3] + 1024 * (g & 3));
+                IE_SB();
+#pragma unroll
+                for (int g = 0; g < 12; ++g) {
+                    if (g + 3 < 12) fx[g + 3] = *(const ie_u32x4*)((g + 3 < 6 ? r2 : r5) + rr.base[(g + 3) % 3] + 1024 * ((g + 3) & 3));
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) {
+                        big[ky] = ie_elem<TH>::mfma32(__builtin_bit_cast(typename ie_elem<TH>::frag, wv[(g + ky) % 18]), __builtin_bit_cast(typename ie_elem<TH>::frag, fx[g]), big[ky]);
+                        IE_SB();
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { accN[i >> 2][i & 3] = big[0][i]; accM[i >> 2][i & 3] = big[1][i]; accO[i >> 2][i & 3] = big[2][i]; }
+            } else if constexpr (IE_K67X_UNPIN_A) {
             mfma_row_free<TA0>(smem + G::OFF_X2 + (t % NRA) * ROWH_B, rr, wv, accN, accM, accO, true, bias6);
             IE_TACC(2);
             mfma_row_free<TA1>(smem + G::OFF_X5 + (t % NRA) * ROWH_B, rr, wv + 9, accN, accM, accO, false, bias6);
