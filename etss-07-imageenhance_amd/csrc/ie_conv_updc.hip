@@ -386,21 +386,30 @@ __device__ __forceinline__ void updc_body(const UpdcParams& p) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) ta[i] = *(const frag*)(islot + tl_lds[i]);
             park_row(accN, smem + OFF_PARK + (t & 1) * PARK_B);
+            // The 1x1 head of the row parked a step earlier and its stores come BEFORE this step's MFMA stream (round 4): at the head of a step the older stage holds the
+            // matrix pipe anyway (finding 14), so everything of this stage that is not part of the stream belongs here (IE_UPDC_TAIL_LAST=1: behind it, A/B)
+            auto head_1x1 = [&]() __attribute__((always_inline)) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    ie_f32x4 o = {tl_bias, tl_bias, tl_bias, tl_bias};
+                    o = ie_mfma16_raw<T>(ta[i], tW, o);
+                    if (p.tail_clamp) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = fminf(fmaxf(o[e], p.lo), p.hi);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float oe = o[e];       // (__builtin_bit_cast straight on the vector ELEMENT o[e] compiled to element 0 four times: hipcc 7.2)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, oe), rsD, (int)((trow_b + tl_col[i][e]) | rmask), 0, 0);
+                    }
+                }
+            };
+#ifndef IE_UPDC_TAIL_LAST
+#define IE_UPDC_TAIL_LAST 0
+#endif
+            if constexpr (!IE_UPDC_TAIL_LAST) { head_1x1(); __builtin_amdgcn_sched_barrier(0); }
             row_mfma(smem + OFF_H + ((t + 1) % NRH) * CH_ROW_B, one{}, accN, accM, accO);       // stage A's step t - 2 wrote slot (t - 2) % NRH == (t + 1) % NRH
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                ie_f32x4 o = {tl_bias, tl_bias, tl_bias, tl_bias};
-                o = ie_mfma16_raw<T>(ta[i], tW, o);
-                if (p.tail_clamp) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = fminf(fmaxf(o[e], p.lo), p.hi);
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float oe = o[e];       // (__builtin_bit_cast straight on the vector ELEMENT o[e] compiled to element 0 four times: hipcc 7.2)
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, oe), rsD, (int)((trow_b + tl_col[i][e]) | rmask), 0, 0);
-                }
-            }
+            if constexpr (IE_UPDC_TAIL_LAST) head_1x1();
         };
         for (int t = 0; t < n_steps; t += 3) {
             step_b(t, a0, a1, a2);

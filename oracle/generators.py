@@ -23,8 +23,11 @@
                        tests/golden/rrdnet_*.npz (reference file mon_extra/vision/enhance/llie/rrdnet/model/RRDNet.py, same
                        Sequential keys); the recombination of :271-279 is five torch ops on those pinned maps.
   zsn2n_forward        src/mon/vision/enhance/denoise/zsn2n/zsn2n.py:73-124: parity unpinned (same).
-  retinexnet_forward   src/mon_extra/vision/enhance/llie/retinexnet/model.py:21-90,199-238: parity unpinned (file
-                       imports cv2/thop/mon and hard-codes .cuda()); single Decom pass, S = R * I_delta.
+  retinexnet_forward   src/mon_extra/vision/enhance/llie/retinexnet/model.py:21-90,199-238; single Decom pass, S = R * I_delta.
+  retinex_decom / retinexnet_losses / retinex_smooth: the same file's DecomNet, RetinexNet.forward (both losses, nine terms), smooth.
+                       PINNED (round 4) by tests/golden/retinexnet_c16_*.npz: the file cannot be imported as a module (cv2, thop, mon), so
+                       tests/golden/make_golden.py takes the classes DecomNet / RelightNet / RetinexNet out of its syntax tree by name and executes
+                       them unmodified (`.cuda()` the identity) -- RetinexNet.forward(input_low, input_high) as shipped, at channel = 16.
 """
 from __future__ import annotations
 

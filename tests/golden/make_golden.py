@@ -232,9 +232,131 @@ def gen_rrdnet():
           "| illumination", float(illumination.min()), float(illumination.max()), "noise |max|", float(noise.abs().max()))
 
 
+# ---- reference files whose module-level imports cannot be satisfied here (cv2, thop, torchmetrics, torchvision, the mon package) ---------------
+# Their pure-torch definitions are taken out of the file by NAME through its syntax tree and executed UNMODIFIED (same code object the file would
+# give, compiled under the file's own name) with only torch / nn / F (/ numpy / Variable) in scope: the arithmetic that produces the fixture is the
+# reference's own, nothing of it is restated or stored.  `.cuda()` -- hard-coded in some forward() bodies -- is the identity while they run.
+def _extract(rel, names, ns):
+    import ast
+    path = os.path.join(REF, rel)
+    tree = ast.parse(open(path).read(), filename=path)
+    keep = [n for n in tree.body if isinstance(n, (ast.FunctionDef, ast.ClassDef)) and n.name in names]
+    assert sorted(n.name for n in keep) == sorted(names), (rel, [n.name for n in keep])
+    exec(compile(ast.Module(body=keep, type_ignores=[]), path, "exec"), ns)
+    return ns
+
+
+class _no_cuda:
+    def __enter__(self):
+        self.saved = (torch.Tensor.cuda, torch.nn.Module.cuda)
+        torch.Tensor.cuda = lambda self, *a, **k: self
+        torch.nn.Module.cuda = lambda self, *a, **k: self
+        return self
+
+    def __exit__(self, *exc):
+        torch.Tensor.cuda, torch.nn.Module.cuda = self.saved
+        return False
+
+
+def gen_retinexnet():
+    """RetinexNet (BASELINE config 4): DecomNet / RelightNet / RetinexNet.forward with its two losses, out of
+    src/mon_extra/vision/enhance/llie/retinexnet/model.py (the file imports cv2, thop and mon).  The two sub-networks are built at channel = 16
+    (their own constructor argument; 64 is 2.2 MB of weights) and put into a RetinexNet() instance, whose forward(input_low, input_high) then runs
+    as shipped: DecomNet on both frames, RelightNet(I_low, R_low), every loss term, output_S = R_low * I_delta_3."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from torch.autograd import Variable
+    ns = _extract("src/mon_extra/vision/enhance/llie/retinexnet/model.py", ["DecomNet", "RelightNet", "RetinexNet"],
+                  {"torch": torch, "nn": nn, "F": F, "np": np, "Variable": Variable})
+    torch.manual_seed(81)
+    with _no_cuda():
+        net = ns["RetinexNet"]()
+        net.DecomNet, net.RelightNet = ns["DecomNet"](channel=16), ns["RelightNet"](channel=16)
+        with torch.no_grad():       # "trained-like" weights: torch's default init x 3 on the conv kernels, so R / L / I_delta vary over the frame instead of sitting at sigmoid(0)
+            for m_ in list(net.DecomNet.modules()) + list(net.RelightNet.modules()):
+                if isinstance(m_, nn.Conv2d):
+                    m_.weight.mul_(3.0)
+        g = torch.Generator().manual_seed(82)
+        high = torch.rand(2, 3, 42, 58, generator=g)
+        low = (high ** 2.2 * 0.3 + 0.02 * torch.rand(2, 3, 42, 58, generator=g)).clamp(0, 1)
+        net.forward(low.numpy(), high.numpy())          # (no eval(): the class overrides nn.Module.train with its training loop; it has no mode-dependent layer)
+        r_high, i_high = net.DecomNet(high)
+    out = {f"w.decom.{k}": v.detach().numpy() for k, v in net.DecomNet.state_dict().items()}
+    out.update({f"w.relight.{k}": v.detach().numpy() for k, v in net.RelightNet.state_dict().items()})
+    out.update(low=low.numpy(), high=high.numpy(), R_low=net.output_R_low.numpy(), I_low_3=net.output_I_low.numpy(), I_delta_3=net.output_I_delta.numpy(),
+               S=net.output_S.numpy(), R_high=r_high.detach().numpy(), I_high=i_high.detach().numpy(),
+               loss_Decom=np.array(float(net.loss_Decom)), loss_Relight=np.array(float(net.loss_Relight)),
+               **{k: np.array(float(getattr(net, k))) for k in ("recon_loss_low", "recon_loss_high", "recon_loss_mutal_low", "recon_loss_mutal_high", "equal_R_loss",
+                                                                 "relight_loss", "Ismooth_loss_low", "Ismooth_loss_high", "Ismooth_loss_delta")})
+    path = os.path.join(HERE, "retinexnet_c16_seed81_2x42x58.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB | loss_Decom", float(net.loss_Decom), "loss_Relight", float(net.loss_Relight), "S range", float(net.output_S.min()), float(net.output_S.max()))
+
+
+def gen_ssim():
+    """custom_ssim / _custom_ssim / _gaussian_filter / _fspecial_gauss_1d of src/mon/nn/metric/image.py:90-237 (the module imports torchmetrics and mon.globals):
+    what SSIMLoss (nn/loss/image.py:834-866) and BASELINE config 5's L1 + SSIM loss compute."""
+    import torch.nn.functional as F
+    ns = _extract("src/mon/nn/metric/image.py", ["_fspecial_gauss_1d", "_gaussian_filter", "_custom_ssim", "custom_ssim"], {"torch": torch, "F": F})
+    g = torch.Generator().manual_seed(91)
+    a = torch.rand(2, 3, 40, 56, generator=g)
+    pairs = {"noisy": (a, (a + 0.1 * torch.randn(2, 3, 40, 56, generator=g)).clamp(0, 1)), "dark": (a ** 2.2 * 0.4, a), "inverse": (a, 1.0 - a)}
+    out = {}
+    for name, (x, y) in pairs.items():
+        out[f"{name}.x"], out[f"{name}.y"] = x.numpy(), y.numpy()
+        for dr in (1.0, 255.0):
+            for nn_ in (False, True):
+                tag = f"{name}.dr{int(dr)}.nn{int(nn_)}"
+                out[tag + ".mean"] = np.array(float(ns["custom_ssim"](x, y, data_range=dr, size_average=True, non_negative_ssim=nn_)))
+                out[tag + ".per_image"] = ns["custom_ssim"](x, y, data_range=dr, size_average=False, non_negative_ssim=nn_).numpy()
+        win = ns["_fspecial_gauss_1d"](11, 1.5).repeat([3, 1, 1, 1])
+        spc, cs = ns["_custom_ssim"](x, y, data_range=1.0, window=win, size_average=False)
+        out[f"{name}.ssim_per_channel"], out[f"{name}.cs_per_channel"] = spc.numpy(), cs.numpy()
+    out["window"] = ns["_fspecial_gauss_1d"](11, 1.5).numpy()
+    path = os.path.join(HERE, "ssim_seed91_2x40x56.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB |", {k: float(v) for k, v in out.items() if k.endswith("dr1.nn0.mean")})
+
+
+def gen_zero_dce_losses():
+    """The four zero-reference loss terms of the original Zero-DCE repository (L_color, L_spa, L_exp, L_TV of src/mon_extra/vision/enhance/llie/zero_dce/myloss.py; the module
+    imports torchvision) on the outputs of the reference network, combined as its trainer does (my_train.py:80-85: 200 L_TV(A) + mean L_spa + 5 mean L_color + 10 mean L_exp).
+    mon's own classes (nn/loss/image.py:191-217, 534-568, 904-1270, 1355-1392) are these with ONE difference the fixture records: TotalVariationLoss counts the
+    channels into its denominators (L_TV / C)."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    ns = _extract("src/mon_extra/vision/enhance/llie/zero_dce/myloss.py", ["L_color", "L_spa", "L_exp", "L_TV"], {"torch": torch, "nn": nn, "F": F})
+    mod = _load("src/mon_extra/vision/enhance/llie/zero_dce/model.py", "ref_zero_dce_for_losses")
+    sd = o_zdce.init_state_dict(seed=5, gain=3.0)
+    net = mod.enhance_net_nopool()
+    net.load_state_dict(sd, strict=True)
+    net.eval()
+    x = torch.rand(2, 3, 64, 80, generator=torch.Generator().manual_seed(101)) ** 2.2 * 0.5
+    with torch.no_grad(), _no_cuda():
+        _, enhanced, A = net(x)
+        l_color, l_spa, l_exp, l_tv = ns["L_color"](), ns["L_spa"](), ns["L_exp"](16, 0.6), ns["L_TV"]()
+        tv, spa, col, exp = l_tv(A), torch.mean(l_spa(enhanced, x)), torch.mean(l_color(enhanced)), torch.mean(l_exp(enhanced))
+        total = 200 * tv + spa + 5 * col + 10 * exp
+    out = {f"w.{k}": v.numpy() for k, v in sd.items()}
+    # (enhanced / adjust are not stored: the network's forward is pinned by zero_dce_*.npz and the tests recompute them from the weights)
+    out.update(image=x.numpy(), L_TV=np.array(float(tv)), L_spa=np.array(float(spa)), L_color=np.array(float(col)),
+               L_exp=np.array(float(exp)), total=np.array(float(total)), enhanced_mean=np.array(float(enhanced.mean())), adjust_abs_mean=np.array(float(A.abs().mean())))
+    with _no_cuda():
+        out["L_spa_map"] = ns["L_spa"]()(enhanced, x).numpy()
+    path = os.path.join(HERE, "zero_dce_losses_seed5_2x64x80.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB | tv", float(tv), "spa", float(spa), "col", float(col), "exp", float(exp), "total", float(total))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["zero_dce", "zero_dcepp", "llunetpp", "hinet", "zero_ig", "unet", "rrdnet"]
+    which = sys.argv[1:] or ["zero_dce", "zero_dcepp", "llunetpp", "hinet", "zero_ig", "unet", "rrdnet", "retinexnet", "ssim", "zero_dce_losses"]
+    if "retinexnet" in which:
+        gen_retinexnet()
+    if "ssim" in which:
+        gen_ssim()
+    if "zero_dce_losses" in which:
+        gen_zero_dce_losses()
     if "zero_dce" in which:
         gen_zero_dce()
     if "zero_dcepp" in which:

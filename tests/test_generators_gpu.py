@@ -198,6 +198,31 @@ def test_retinexnet_vs_oracle(hw):
         assert rel_err(out[k].cpu(), ref[k]) <= TOL, k
 
 
+def test_retinexnet_reference_golden():
+    """The engine against RetinexNet.forward of the reference's own file run on CPU (tests/golden/retinexnet_c16_*.npz: DecomNet + RelightNet at channel = 16, their
+    class bodies executed out of src/mon_extra/vision/enhance/llie/retinexnet/model.py by make_golden._extract): fp32 path inside 1e-4 on R, L, I_delta and S, and the
+    training forward's two losses (forward_train_loss: DecomNet on both frames, RelightNet, nine terms, model.py:199-238)."""
+    g = np.load(os.path.join(GOLDEN, "retinexnet_c16_seed81_2x42x58.npz"))
+    sd = {k[len("w.decom."):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w.decom.")}
+    sd.update({k[len("w.relight."):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w.relight.")})
+    m = mon_amd.MODELS.build(name="retinexnet", channels=16, weights=dict(sd)).to("cuda")
+    low, high = torch.from_numpy(g["low"]), torch.from_numpy(g["high"])
+    out = m.forward({"image": low.cuda()})
+    assert rel_err(out["reflectance"].cpu(), g["R_low"]) <= TOL
+    assert rel_err(out["illumination"].cpu(), g["I_low_3"][:, :1]) <= TOL
+    assert rel_err(out["illumination_delta"].cpu(), g["I_delta_3"][:, :1]) <= TOL
+    assert rel_err(out["enhanced"].cpu(), g["S"]) <= TOL
+    for phase in ("decom", "relight"):
+        m.train_phase = phase
+        tr = mon_amd.Trainer(m, optimizer={"name": "adam", "lr": 1e-4}, gradient_clip_val=None)
+        res = tr.forward_loss({"image": low, "ref_image": high})
+        assert abs(float(res["loss_decom"]) - float(g["loss_Decom"])) <= 2e-5 * float(g["loss_Decom"])
+        assert abs(float(res["loss_relight"]) - float(g["loss_Relight"])) <= 2e-5 * float(g["loss_Relight"])
+    for dt, tol in (("f16", 2e-3), ("bf16", 2e-2)):         # the 16-bit matrix-core path on the same golden (trained-like weights x 3: a harder case than the seed-6 test)
+        m16 = mon_amd.MODELS.build(name="retinexnet", channels=16, weights=dict(sd), compute_dtype=dt).to("cuda")
+        assert rel_err(m16.forward({"image": low.cuda()})["enhanced"].cpu(), g["S"]) <= tol, dt
+
+
 def test_retinexnet_two_file_checkpoints(tmp_path):
     m = mon_amd.RetinexNet(seed=7)
     sd = m.state_dict()

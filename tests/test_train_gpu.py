@@ -62,6 +62,34 @@ def test_ssim_loss_value_and_grad(layout, data_range, nonneg, shape):
     assert rel_err(host(gd), xr.grad) < 2e-4
 
 
+def test_ssim_and_zero_dce_losses_reference_goldens():
+    """The loss kernels against values the reference's own function / class bodies produced on CPU (tests/golden/ssim_*.npz: custom_ssim of
+    src/mon/nn/metric/image.py:90-237; zero_dce_losses_*.npz: L_TV / L_spa / L_color / L_exp of the original repository's myloss.py)."""
+    import numpy as np
+    from tests.helpers import GOLDEN
+    import os
+    g = np.load(os.path.join(GOLDEN, "ssim_seed91_2x40x56.npz"))
+    for name in ("noisy", "dark", "inverse"):
+        x, y = torch.from_numpy(g[f"{name}.x"]).cuda(), torch.from_numpy(g[f"{name}.y"]).cuda()
+        for dr in (1.0, 255.0):
+            for nn_ in (False, True):
+                want = 1.0 - float(g[f"{name}.dr{int(dr)}.nn{int(nn_)}.mean"])
+                got = float(losses.SSIMLoss(data_range=dr, non_negative_ssim=nn_)(x, y))
+                assert abs(got - want) <= 2e-5, (name, dr, nn_, got, want)
+    g = np.load(os.path.join(GOLDEN, "zero_dce_losses_seed5_2x64x80.npz"))
+    sd = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w.")}
+    m = mon_amd.MODELS.build(name="zero_dce_re", weights=dict(sd), compute_dtype="f32").to("cuda").eval()
+    x = torch.from_numpy(g["image"]).cuda()
+    out = m.forward({"image": x})
+    loss = losses.ZeroDCELoss()
+    float(loss(x, out["adjust"].contiguous(memory_format=CL), out["enhanced"]))       # (the terms are read back when the value is)
+    t = loss.last_terms
+    assert abs(t["tva"] * 24 - float(g["L_TV"])) <= 1e-4 * float(g["L_TV"])        # (mon's TotalVariationLoss divides by the channel count as well: zero_dce.py:65-79)
+    assert abs(t["spa"] - float(g["L_spa"])) <= 1e-4 * float(g["L_spa"]) + 1e-9
+    assert abs(t["col"] - float(g["L_color"])) <= 1e-4 * float(g["L_color"]) + 1e-9
+    assert abs(t["exp"] - float(g["L_exp"])) <= 1e-4 * float(g["L_exp"])
+
+
 def test_ssim_non_negative_masks_gradient():
     x = torch.rand(1, 3, 24, 24, generator=torch.Generator().manual_seed(5))
     y = 1.0 - x                                                        # anti-correlated -> negative SSIM
