@@ -343,7 +343,7 @@ def gen_zero_dce_losses():
                L_exp=np.array(float(exp)), total=np.array(float(total)), enhanced_mean=np.array(float(enhanced.mean())), adjust_abs_mean=np.array(float(A.abs().mean())))
     with _no_cuda():
         out["L_spa_map"] = ns["L_spa"]()(enhanced, x).numpy()
-    path = os.path.join(HERE, "zero_dce_losses_seed5_2x64x80.npz")
+    path = os.path.join(HERE, "zdce_losses_seed5_2x64x80.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB | tv", float(tv), "spa", float(spa), "col", float(col), "exp", float(exp), "total", float(total))
 

@@ -240,7 +240,7 @@ def test_zero_dce_loss_restatement_matches_reference():
     into its denominators: L_TV = C x mon's value."""
     from oracle import train as otr
     from oracle import zero_dce as o_zdce
-    g = np.load(os.path.join(GOLDEN, "zero_dce_losses_seed5_2x64x80.npz"))
+    g = np.load(os.path.join(GOLDEN, "zdce_losses_seed5_2x64x80.npz"))
     sd = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w.")}
     x = torch.from_numpy(g["image"])
     out = o_zdce.forward(sd, x)

@@ -64,7 +64,7 @@ def test_ssim_loss_value_and_grad(layout, data_range, nonneg, shape):
 
 def test_ssim_and_zero_dce_losses_reference_goldens():
     """The loss kernels against values the reference's own function / class bodies produced on CPU (tests/golden/ssim_*.npz: custom_ssim of
-    src/mon/nn/metric/image.py:90-237; zero_dce_losses_*.npz: L_TV / L_spa / L_color / L_exp of the original repository's myloss.py)."""
+    src/mon/nn/metric/image.py:90-237; zdce_losses_*.npz: L_TV / L_spa / L_color / L_exp of the original repository's myloss.py)."""
     import numpy as np
     from tests.helpers import GOLDEN
     import os
@@ -76,7 +76,7 @@ def test_ssim_and_zero_dce_losses_reference_goldens():
                 want = 1.0 - float(g[f"{name}.dr{int(dr)}.nn{int(nn_)}.mean"])
                 got = float(losses.SSIMLoss(data_range=dr, non_negative_ssim=nn_)(x, y))
                 assert abs(got - want) <= 2e-5, (name, dr, nn_, got, want)
-    g = np.load(os.path.join(GOLDEN, "zero_dce_losses_seed5_2x64x80.npz"))
+    g = np.load(os.path.join(GOLDEN, "zdce_losses_seed5_2x64x80.npz"))
     sd = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w.")}
     m = mon_amd.MODELS.build(name="zero_dce_re", weights=dict(sd), compute_dtype="f32").to("cuda").eval()
     x = torch.from_numpy(g["image"]).cuda()
