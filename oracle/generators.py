@@ -11,7 +11,8 @@
                        mon_extra/vision/enhance/llie/mtfe/unet_model.py + unet_parts.py (bilinear and ConvTranspose2d decoders,
                        convs with bias, keys ``*.double_conv.{0,1,3,4}`` -> unet_from_mtfe_keys), run in the build container.
   unet_ps variant      + Upsampler conv3x3 + nn.PixelShuffle(2) (nn/modules/encoder/edsr.py:88-123): the encoder / DoubleConv /
-                       pad / cat / head around it are the pinned ones; the upsampler leaf itself is parity unpinned.
+                       pad / cat / head around it are the pinned ones; the upsampler leaf is ``upsampler_forward`` below, PINNED by
+                       tests/golden/upsampler_edsr.npz (round 4: edsr.py imports torch only and loads as a module).
   zero_ig_enhance      src/mon/vision/enhance/llie/zero_ig/zero_ig.py:307-348 (Enhance)
   zero_ig_denoise      zero_ig.py:257-304 (Denoise1 / Denoise2)
   zero_ig_forward      zero_ig.py:434-452 (ZeroIG.forward, predicting branch)
@@ -41,6 +42,18 @@ def _c(sd, name, x, stride=1, padding=1, groups=1, mode="zeros"):
         x = F.pad(x, (padding,) * 4, mode="replicate")
         padding = 0
     return F.conv2d(x, w, b, stride=stride, padding=padding, groups=groups)
+
+
+# ---- PixelShuffle up-sampler (the config-3 decoder variant's leaf) ------------------------------------------------
+def upsampler_forward(sd: dict, x: torch.Tensor, relu: bool = False) -> torch.Tensor:
+    """Upsampler (src/mon/nn/modules/encoder/edsr.py:88-123) for scale = 2^n: per stage conv3x3(n_feats -> 4 n_feats, padding 1) -> nn.PixelShuffle(2) [-> ReLU];
+    ``sd`` holds the nn.Sequential's own keys ("0.weight", "0.bias", then "2." or "3." ... for the next stage).  PINNED by tests/golden/upsampler_edsr.npz
+    (the file imports torch only: loaded as a module by make_golden.py)."""
+    for k in sorted({k.rsplit(".", 1)[0] for k in sd}, key=lambda t: int(t)):
+        x = F.pixel_shuffle(_c(sd, k, x), 2)
+        if relu:
+            x = F.relu(x)
+    return x
 
 
 # ---- Zero-DCE++ -----------------------------------------------------------------------------------------------

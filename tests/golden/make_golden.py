@@ -10,6 +10,11 @@ the pure-torch reference files
     src/mon_extra/vision/enhance/llie/zero_ig/model.py       (Enhancer, Denoise_1, Denoise_2, Finetunemodel.forward)
     src/mon_extra/vision/enhance/llie/mtfe/unet_model.py     (UNet: DoubleConv / Down / Up / OutConv of unet_parts.py)
     src/mon_extra/vision/enhance/llie/rrdnet/model/RRDNet.py (RRDNet)
+    src/mon/nn/modules/encoder/edsr.py                       (Upsampler: conv3x3 + nn.PixelShuffle; round 4)
+and (round 4) executes, out of files whose module-level imports are not installed here, the pure-torch definitions
+    DecomNet / RelightNet / RetinexNet of src/mon_extra/vision/enhance/llie/retinexnet/model.py,
+    custom_ssim / _custom_ssim / _gaussian_filter / _fspecial_gauss_1d of src/mon/nn/metric/image.py,
+    L_color / L_spa / L_exp / L_TV of src/mon_extra/vision/enhance/llie/zero_dce/myloss.py  (see _extract below),
 loads seeded weights into them, runs their forward on CPU fp32 and stores
 inputs / weights / outputs as small fixtures.  The fixtures are data only; no
 reference source is copied.  Usage:  python tests/golden/make_golden.py
@@ -348,9 +353,29 @@ def gen_zero_dce_losses():
     print("wrote", path, os.path.getsize(path) // 1024, "KiB | tv", float(tv), "spa", float(spa), "col", float(col), "exp", float(exp), "total", float(total))
 
 
+def gen_upsampler():
+    """The PixelShuffle up-sampler leaf of the BASELINE config-3 decoder variant: Upsampler(default_conv, scale, n_feats, act=...) of
+    src/mon/nn/modules/encoder/edsr.py:88-123 -- a file that imports torch only, loaded as a module."""
+    mod = _load("src/mon/nn/modules/encoder/edsr.py", "ref_edsr")
+    out = {}
+    for tag, (nf, scale, act, hw, seed) in {"s2_c16": (16, 2, False, (9, 13), 111), "s4_c8_relu": (8, 4, "relu", (6, 7), 112), "s2_c32_relu": (32, 2, "relu", (5, 20), 113)}.items():
+        torch.manual_seed(seed)
+        up = mod.Upsampler(mod.default_conv, scale, nf, bn=False, act=act)
+        x = torch.randn(2, nf, *hw, generator=torch.Generator().manual_seed(seed + 1000))
+        with torch.no_grad():
+            y = up(x)
+        out.update({f"{tag}.w.{k}": v.numpy() for k, v in up.state_dict().items()})
+        out[f"{tag}.x"], out[f"{tag}.y"], out[f"{tag}.scale"], out[f"{tag}.relu"] = x.numpy(), y.numpy(), np.array(scale), np.array(int(act == "relu"))
+    path = os.path.join(HERE, "upsampler_edsr.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["zero_dce", "zero_dcepp", "llunetpp", "hinet", "zero_ig", "unet", "rrdnet", "retinexnet", "ssim", "zero_dce_losses"]
+    which = sys.argv[1:] or ["zero_dce", "zero_dcepp", "llunetpp", "hinet", "zero_ig", "unet", "rrdnet", "retinexnet", "ssim", "zero_dce_losses", "upsampler"]
+    if "upsampler" in which:
+        gen_upsampler()
     if "retinexnet" in which:
         gen_retinexnet()
     if "ssim" in which:

@@ -198,6 +198,31 @@ def test_retinexnet_vs_oracle(hw):
         assert rel_err(out[k].cpu(), ref[k]) <= TOL, k
 
 
+def test_upsampler_reference_golden():
+    """The PixelShuffle up-sampler leaf (edsr.py:88-123) against the reference module's own output: fp32 conv + ie_pixel_shuffle_nhwc, and the 16-bit path's ONE kernel
+    (conv3x3 with the shuffle in its epilogue, ie_mconv_desc.pixel_shuffle)."""
+    g = np.load(os.path.join(GOLDEN, "upsampler_edsr.npz"))
+    for tag in ("s2_c16", "s4_c8_relu", "s2_c32_relu"):
+        sd = {k[len(tag) + 3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(tag + ".w.")}
+        relu = bool(g[f"{tag}.relu"])
+        stages = sorted({k.rsplit(".", 1)[0] for k in sd}, key=int)
+        a = ops.to_nhwc(torch.from_numpy(g[f"{tag}.x"]).cuda())
+        for k in stages:
+            cw = ops.ConvWeights(sd[f"{k}.weight"], sd[f"{k}.bias"], "cuda")
+            a = ops.pixel_shuffle(ops.conv2d([a], cw, act="relu" if relu else "none"), 2)      # (ReLU commutes with the shuffle)
+        assert rel_err(ops.to_nchw(a).cpu(), g[f"{tag}.y"]) <= TOL, tag
+        for dt, tol in (("f16", 2e-3), ("bf16", 1.5e-2)):
+            tdt = ops.TORCH_DT[dt]
+            a = torch.from_numpy(g[f"{tag}.x"]).to(tdt).cuda().contiguous(memory_format=torch.channels_last)
+            for k in stages:
+                fused = int(sd[f"{k}.weight"].shape[0]) % 64 == 0          # the one-kernel form takes whole 64-channel output tiles; others: conv, then the shuffle pass
+                mw = ops.MConvWeights(sd[f"{k}.weight"], sd[f"{k}.bias"], [int(a.shape[1])], tdt, "cuda", shuffle=2 if fused else 0)
+                a = ops.mconv2d(a, mw, act="relu" if relu else "none")
+                if not fused:
+                    a = ops.pixel_shuffle(a, 2)
+            assert rel_err(a.float().cpu(), g[f"{tag}.y"]) <= tol, (tag, dt)
+
+
 def test_retinexnet_reference_golden():
     """The engine against RetinexNet.forward of the reference's own file run on CPU (tests/golden/retinexnet_c16_*.npz: DecomNet + RelightNet at channel = 16, their
     class bodies executed out of src/mon_extra/vision/enhance/llie/retinexnet/model.py by make_golden._extract): fp32 path inside 1e-4 on R, L, I_delta and S, and the

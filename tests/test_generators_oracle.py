@@ -254,3 +254,13 @@ def test_zero_dce_loss_restatement_matches_reference():
     # mon's composite (zero_dce.py:65-79: the same weights, its own TV normalisation)
     mon_total = float(otr.zero_dce_loss(x, adj, enh))
     assert abs(mon_total - (float(g["total"]) - 200 * float(g["L_TV"]) * (1 - 1 / adj.shape[1]))) <= 2e-5 * float(g["total"])
+
+
+def test_upsampler_restatement_matches_reference():
+    """oracle.generators.upsampler_forward against Upsampler(default_conv, scale, n_feats, act) of src/mon/nn/modules/encoder/edsr.py:88-123 (scale 2 and 4, with / without ReLU)."""
+    g = np.load(os.path.join(GOLDEN, "upsampler_edsr.npz"))
+    for tag in ("s2_c16", "s4_c8_relu", "s2_c32_relu"):
+        sd = {k[len(tag) + 3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(tag + ".w.")}
+        y = og.upsampler_forward(sd, torch.from_numpy(g[f"{tag}.x"]), relu=bool(g[f"{tag}.relu"]))
+        assert tuple(y.shape) == tuple(g[f"{tag}.y"].shape)
+        assert np.abs(y.numpy() - g[f"{tag}.y"]).max() <= 1e-6, tag
