@@ -5,7 +5,8 @@
   llunetpp_forward     src/mon/vision/enhance/llie/llunetpp/llunetpp.py:97-137, 218-243
                        PINNED by tests/golden/llunetpp_*.npz (reference file mon_extra/.../llunet++/model.py)
   lllinet_forward      src/mon/vision/enhance/llie/lllinet/lllinet.py:97-260 (+ normalization.py:177-224, attention.py:1156-1182): parity unpinned.
-  lllinet_hvi_forward  lllinet.py:262-388 + core/image/color.py:313-434 (RGBToHVI): parity unpinned (the transform lives in `mon.core`, not importable here).
+  lllinet_hvi_forward  lllinet.py:262-388 + core/image/color.py:313-434 (RGBToHVI).  rgb_to_hvi / hvi_to_rgb are PINNED (round 4) by tests/golden/hvi_transform_*.npz: the class
+                       RGBToHVI executed out of color.py's syntax tree (the module imports cv2 and kornia, the class is pure torch); the LLLINet grid around it: parity unpinned.
   unet_forward         src/mon/vision/segment/unet/unet.py:35-197 with line 51's typo read as conv1; eval-mode BN.
                        PINNED by tests/golden/unet_mtfe_*.npz: the reference tree's pure-torch twin of the same topology,
                        mon_extra/vision/enhance/llie/mtfe/unet_model.py + unet_parts.py (bilinear and ConvTranspose2d decoders,

@@ -14,7 +14,8 @@ the pure-torch reference files
 and (round 4) executes, out of files whose module-level imports are not installed here, the pure-torch definitions
     DecomNet / RelightNet / RetinexNet of src/mon_extra/vision/enhance/llie/retinexnet/model.py,
     custom_ssim / _custom_ssim / _gaussian_filter / _fspecial_gauss_1d of src/mon/nn/metric/image.py,
-    L_color / L_spa / L_exp / L_TV of src/mon_extra/vision/enhance/llie/zero_dce/myloss.py  (see _extract below),
+    L_color / L_spa / L_exp / L_TV of src/mon_extra/vision/enhance/llie/zero_dce/myloss.py,
+    RGBToHVI of src/mon/core/image/color.py  (see _extract below),
 loads seeded weights into them, runs their forward on CPU fp32 and stores
 inputs / weights / outputs as small fixtures.  The fixtures are data only; no
 reference source is copied.  Usage:  python tests/golden/make_golden.py
@@ -353,6 +354,34 @@ def gen_zero_dce_losses():
     print("wrote", path, os.path.getsize(path) // 1024, "KiB | tv", float(tv), "spa", float(spa), "col", float(col), "exp", float(exp), "total", float(total))
 
 
+def gen_hvi():
+    """RGBToHVI.rgb_to_hvi / hvi_to_rgb of src/mon/core/image/color.py:313-434 (the colour transform around LLLINet's grid in `lllinet_hvi`; the module imports cv2 and
+    kornia, the class is pure torch): a random frame with grey, black and saturated rows, density_k = 0.2 (the parameter's initial value) and 0.35."""
+    import torch.nn as nn
+    ns = _extract("src/mon/core/image/color.py", ["RGBToHVI"], {"torch": torch, "nn": nn})
+    g = torch.Generator().manual_seed(121)
+    x = torch.rand(2, 3, 18, 24, generator=g)
+    x[0, :, 0, :] = x[0, :1, 0, :]                   # greys
+    x[0, :, 1, :] = 0.0                              # black
+    x[0, 1:, 2, :] = 0.0                             # pure reds of varying value
+    x[1] = x[1] ** 2.2 * 0.3                         # a low-light frame
+    out = {"image": x.numpy()}
+    for k in (0.2, 0.35):
+        t = ns["RGBToHVI"]()
+        with torch.no_grad():
+            t.density_k.fill_(k)
+            hvi = t.rgb_to_hvi(x)
+            back = t.hvi_to_rgb(hvi)
+            # an arbitrary (out-of-gamut) HVI tensor through the inverse: what the network's output looks like before the transform back
+            pert = hvi + 0.1 * torch.randn(hvi.shape, generator=torch.Generator().manual_seed(122))
+            back_p = t.hvi_to_rgb(pert)
+        tag = f"k{int(round(k * 100))}"
+        out[f"{tag}.hvi"], out[f"{tag}.rgb"], out[f"{tag}.pert"], out[f"{tag}.rgb_pert"] = hvi.numpy(), back.numpy(), pert.numpy(), back_p.numpy()
+    path = os.path.join(HERE, "hvi_transform_seed121.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB | round trip", float((out["k20.rgb"] - x.numpy()).__abs__().max()))
+
+
 def gen_upsampler():
     """The PixelShuffle up-sampler leaf of the BASELINE config-3 decoder variant: Upsampler(default_conv, scale, n_feats, act=...) of
     src/mon/nn/modules/encoder/edsr.py:88-123 -- a file that imports torch only, loaded as a module."""
@@ -373,9 +402,11 @@ def gen_upsampler():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["zero_dce", "zero_dcepp", "llunetpp", "hinet", "zero_ig", "unet", "rrdnet", "retinexnet", "ssim", "zero_dce_losses", "upsampler"]
+    which = sys.argv[1:] or ["zero_dce", "zero_dcepp", "llunetpp", "hinet", "zero_ig", "unet", "rrdnet", "retinexnet", "ssim", "zero_dce_losses", "upsampler", "hvi"]
     if "upsampler" in which:
         gen_upsampler()
+    if "hvi" in which:
+        gen_hvi()
     if "retinexnet" in which:
         gen_retinexnet()
     if "ssim" in which:

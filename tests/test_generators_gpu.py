@@ -223,6 +223,21 @@ def test_upsampler_reference_golden():
             assert rel_err(a.float().cpu(), g[f"{tag}.y"]) <= tol, (tag, dt)
 
 
+def test_hvi_transform_reference_golden():
+    """ie_rgb_to_hvi_nhwc_f32 / ie_hvi_to_rgb_nhwc_f32 against the reference class's own outputs (tests/golden/hvi_transform_*.npz).  Hue is discontinuous where two
+    channels tie for the maximum and at the sector borders of the inverse: those few pixels may land on the other branch by rounding, everything else agrees to 1e-5."""
+    g = np.load(os.path.join(GOLDEN, "hvi_transform_seed121.npz"))
+    x = ops.to_nhwc(torch.from_numpy(g["image"]).cuda())
+    for k, tag in ((0.2, "k20"), (0.35, "k35")):
+        hvi = ops.to_nchw(ops.rgb_to_hvi(x, k)).cpu().numpy()
+        d = np.abs(hvi - g[f"{tag}.hvi"]).max(1)
+        assert (d > 1e-5).mean() <= 2e-3 and np.median(d) <= 1e-6, (tag, float(d.max()))
+        for src, want in ((f"{tag}.hvi", f"{tag}.rgb"), (f"{tag}.pert", f"{tag}.rgb_pert")):
+            rgb = ops.to_nchw(ops.hvi_to_rgb(ops.to_nhwc(torch.from_numpy(g[src]).cuda()), k)).cpu().numpy()
+            d = np.abs(rgb - g[want]).max(1)
+            assert (d > 1e-5).mean() <= 5e-3 and np.median(d) <= 1e-6, (src, float(d.max()))
+
+
 def test_retinexnet_reference_golden():
     """The engine against RetinexNet.forward of the reference's own file run on CPU (tests/golden/retinexnet_c16_*.npz: DecomNet + RelightNet at channel = 16, their
     class bodies executed out of src/mon_extra/vision/enhance/llie/retinexnet/model.py by make_golden._extract): fp32 path inside 1e-4 on R, L, I_delta and S, and the

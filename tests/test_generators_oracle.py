@@ -264,3 +264,14 @@ def test_upsampler_restatement_matches_reference():
         y = og.upsampler_forward(sd, torch.from_numpy(g[f"{tag}.x"]), relu=bool(g[f"{tag}.relu"]))
         assert tuple(y.shape) == tuple(g[f"{tag}.y"].shape)
         assert np.abs(y.numpy() - g[f"{tag}.y"]).max() <= 1e-6, tag
+
+
+def test_hvi_transform_restatement_matches_reference():
+    """oracle.generators.rgb_to_hvi / hvi_to_rgb against RGBToHVI.rgb_to_hvi / hvi_to_rgb of src/mon/core/image/color.py:313-434 (class body executed out of the file:
+    make_golden._extract), density_k 0.2 and 0.35, in-gamut and perturbed HVI tensors."""
+    g = np.load(os.path.join(GOLDEN, "hvi_transform_seed121.npz"))
+    x = torch.from_numpy(g["image"])
+    for k, tag in ((0.2, "k20"), (0.35, "k35")):
+        assert np.abs(og.rgb_to_hvi(x, k).numpy() - g[f"{tag}.hvi"]).max() <= 1e-6
+        assert np.abs(og.hvi_to_rgb(torch.from_numpy(g[f"{tag}.hvi"]), k).numpy() - g[f"{tag}.rgb"]).max() <= 1e-6
+        assert np.abs(og.hvi_to_rgb(torch.from_numpy(g[f"{tag}.pert"]), k).numpy() - g[f"{tag}.rgb_pert"]).max() <= 1e-6
