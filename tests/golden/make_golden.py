@@ -382,6 +382,31 @@ def gen_hvi():
     print("wrote", path, os.path.getsize(path) // 1024, "KiB | round trip", float((out["k20.rgb"] - x.numpy()).__abs__().max()))
 
 
+def gen_learnable_instance_norm():
+    """LearnableInstanceNorm2d.forward of src/mon/nn/modules/normalization.py:177-224 (LLLINet's norm leaf: y = IN(x)*r + x*(1 - r) with a learnable r per channel; the
+    module imports mon, the class is pure torch): random affine parameters and r in [0, 1] and outside it, 12 and 32 channels, an odd frame size."""
+    import math
+    from typing import Any
+    import torch.nn as nn
+    import torch.nn.functional as F
+    ns = _extract("src/mon/nn/modules/normalization.py", ["LearnableInstanceNorm2d"], {"torch": torch, "nn": nn, "F": F, "math": math, "Any": Any})
+    out = {}
+    for tag, c, h, w, seed in (("c12", 12, 19, 23, 131), ("c32", 32, 16, 40, 132)):
+        g = torch.Generator().manual_seed(seed)
+        m = ns["LearnableInstanceNorm2d"](c)
+        with torch.no_grad():
+            m.weight.copy_(torch.rand(c, generator=g) * 1.5 + 0.25)
+            m.bias.copy_(torch.randn(c, generator=g) * 0.3)
+            m.r.copy_(torch.rand(c, generator=g) * 1.4 - 0.2)
+            x = torch.randn(2, c, h, w, generator=g) * (torch.rand(1, c, 1, 1, generator=g) * 2 + 0.1) + torch.randn(1, c, 1, 1, generator=g)
+            y = m(x)
+        out[f"{tag}.x"], out[f"{tag}.y"] = x.numpy(), y.numpy()
+        out[f"{tag}.weight"], out[f"{tag}.bias"], out[f"{tag}.r"] = m.weight.detach().numpy(), m.bias.detach().numpy(), m.r.detach().numpy()
+    path = os.path.join(HERE, "learnable_instance_norm.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
 def gen_upsampler():
     """The PixelShuffle up-sampler leaf of the BASELINE config-3 decoder variant: Upsampler(default_conv, scale, n_feats, act=...) of
     src/mon/nn/modules/encoder/edsr.py:88-123 -- a file that imports torch only, loaded as a module."""
@@ -402,11 +427,13 @@ def gen_upsampler():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["zero_dce", "zero_dcepp", "llunetpp", "hinet", "zero_ig", "unet", "rrdnet", "retinexnet", "ssim", "zero_dce_losses", "upsampler", "hvi"]
+    which = sys.argv[1:] or ["zero_dce", "zero_dcepp", "llunetpp", "hinet", "zero_ig", "unet", "rrdnet", "retinexnet", "ssim", "zero_dce_losses", "upsampler", "hvi", "lin"]
     if "upsampler" in which:
         gen_upsampler()
     if "hvi" in which:
         gen_hvi()
+    if "lin" in which:
+        gen_learnable_instance_norm()
     if "retinexnet" in which:
         gen_retinexnet()
     if "ssim" in which:

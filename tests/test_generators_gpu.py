@@ -223,6 +223,23 @@ def test_upsampler_reference_golden():
             assert rel_err(a.float().cpu(), g[f"{tag}.y"]) <= tol, (tag, dt)
 
 
+def test_learnable_instance_norm_reference_golden():
+    """ops.learnable_instance_norm (instance statistics + ONE channel-affine pass, the blend folded into scale and shift) against the reference class's own output
+    (tests/golden/learnable_instance_norm.npz, normalization.py:177-224): fp32 and the 16-bit storage types, with and without the fused LeakyReLU LLLINet applies."""
+    g = np.load(os.path.join(GOLDEN, "learnable_instance_norm.npz"))
+    for tag in ("c12", "c32"):
+        t = {k: torch.from_numpy(g[f"{tag}.{k}"]).cuda() for k in ("x", "weight", "bias", "r")}
+        y = ops.to_nchw(ops.learnable_instance_norm(ops.to_nhwc(t["x"]), t["weight"], t["bias"], t["r"])).cpu()
+        assert rel_err(y, g[f"{tag}.y"]) <= TOL, tag
+        ya = ops.to_nchw(ops.learnable_instance_norm(ops.to_nhwc(t["x"]), t["weight"], t["bias"], t["r"], 1e-5, "lrelu", 0.2)).cpu()
+        assert rel_err(ya, torch.nn.functional.leaky_relu(torch.from_numpy(g[f"{tag}.y"]), 0.2)) <= TOL, tag
+        if tag == "c32":
+            for dt, tol in (("f16", 2e-3), ("bf16", 1.5e-2)):
+                x16 = t["x"].to(ops.TORCH_DT[dt]).contiguous(memory_format=torch.channels_last)
+                y16 = ops.learnable_instance_norm(x16, t["weight"], t["bias"], t["r"])
+                assert rel_err(y16.float().cpu(), g[f"{tag}.y"]) <= tol, (tag, dt)
+
+
 def test_hvi_transform_reference_golden():
     """ie_rgb_to_hvi_nhwc_f32 / ie_hvi_to_rgb_nhwc_f32 against the reference class's own outputs (tests/golden/hvi_transform_*.npz).  Hue is discontinuous where two
     channels tie for the maximum and at the sector borders of the inverse: those few pixels may land on the other branch by rounding, everything else agrees to 1e-5."""

@@ -275,3 +275,13 @@ def test_hvi_transform_restatement_matches_reference():
         assert np.abs(og.rgb_to_hvi(x, k).numpy() - g[f"{tag}.hvi"]).max() <= 1e-6
         assert np.abs(og.hvi_to_rgb(torch.from_numpy(g[f"{tag}.hvi"]), k).numpy() - g[f"{tag}.rgb"]).max() <= 1e-6
         assert np.abs(og.hvi_to_rgb(torch.from_numpy(g[f"{tag}.pert"]), k).numpy() - g[f"{tag}.rgb_pert"]).max() <= 1e-6
+
+
+def test_learnable_instance_norm_restatement_matches_reference():
+    """oracle.generators.learnable_instance_norm against LearnableInstanceNorm2d.forward of src/mon/nn/modules/normalization.py:177-224 (LLLINet's norm leaf; class
+    body executed out of the file by make_golden._extract), r inside and outside [0, 1]."""
+    g = np.load(os.path.join(GOLDEN, "learnable_instance_norm.npz"))
+    for tag in ("c12", "c32"):
+        t = {k: torch.from_numpy(g[f"{tag}.{k}"]) for k in ("x", "weight", "bias", "r")}
+        y = og.learnable_instance_norm(t["x"], t["weight"], t["bias"], t["r"])
+        assert np.abs(y.numpy() - g[f"{tag}.y"]).max() <= 1e-6, tag
