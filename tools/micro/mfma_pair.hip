@@ -8,10 +8,20 @@
 //   form 3  register-only (no LDS reads: the same fragment registers every time)
 //   chores  0 none   1 stage A ends its step with a latency-bound tail (LDS read -> pack -> 4 ds_write_b128 -> 6 LDS-DMA pieces), stage B opens its step with
 //           a 96-operation transcendental burst -- the shape of K67X
-// Build: hipcc --offload-arch=gfx950 -O3 -Wno-unused-value mfma_pair.hip -o mfma_pair
+// Build: hipcc --offload-arch=gfx950 -O3 -Wno-unused-value [-DUSE_BF16] [-DRELU_DATA] mfma_pair.hip -o mfma_pair     (RELU_DATA: half of the LDS values zero, as behind a ReLU)
 #include <hip/hip_runtime.h>
 #include <cstdio>
-typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+#include <cstdlib>
+#ifdef USE_BF16
+typedef __bf16 elem_t;
+#define MFMA_NAME "v_mfma_f32_16x16x32_bf16"
+#define MFMA_BUILTIN __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#else
+typedef _Float16 elem_t;
+#define MFMA_NAME "v_mfma_f32_16x16x32_f16"
+#define MFMA_BUILTIN __builtin_amdgcn_mfma_f32_16x16x32_f16
+#endif
+typedef __attribute__((ext_vector_type(8))) elem_t f16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -22,10 +32,10 @@ template <int FORM>
 __device__ __forceinline__ f32x4 mfma(u32x4 a, u32x4 b, f32x4 c) {
     if constexpr (FORM == 3) {      // (loop-invariant operands: keep the compiler from hoisting / merging the register-only stream)
         f32x4 d;
-        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+        asm volatile(MFMA_NAME " %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
         return d;
     } else {
-        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+        return MFMA_BUILTIN(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     }
 }
 
@@ -62,6 +72,31 @@ __device__ __forceinline__ void mfma_row(const char* slot, const int (&base)[3],
     }
 }
 
+// form 7: the same stream with the fragments in AccVGPRs (ds_read_b128 a[..] / MFMA B operand from a[..]; inline asm, counted lgkmcnt by hand): does the LDS return
+// path cost less when it does not write the architectural VGPR banks the MFMAs in flight read their A operand and accumulators from?
+__device__ __forceinline__ void mfma_row_acc(const char* slot, const int (&base)[3], const u32x4* wv, f32x4 (&accN)[4], f32x4 (&accM)[4], f32x4 (&accO)[4], bool first,
+                                             const f32x4& init) {
+    u32x4 bx[12];
+    const unsigned ad[3] = {(unsigned)(size_t)(slot + base[0]), (unsigned)(size_t)(slot + base[1]), (unsigned)(size_t)(slot + base[2])};
+#define RD(g) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(bx[g]) : "v"(ad[(g) >> 2]), "n"(1024 * ((g) & 3)))
+#define MF(d, a, b, c) asm volatile(MFMA_NAME " %0, %1, %2, %3" : "=v"(d) : "v"(a), "a"(b), "v"(c))
+    RD(0); RD(1); RD(2);
+#pragma unroll
+    for (int g = 0; g < 12; ++g) {
+        const int kx = g >> 2, j = g & 3;
+        if (g <= 9) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+        else if (g == 10) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (first && kx == 0) MF(accN[j], wv[0 * 3 + kx], bx[g], init); else MF(accN[j], wv[0 * 3 + kx], bx[g], accN[j]);
+        if (g + 3 < 12) { switch (g + 3) { case 3: RD(3); break; case 4: RD(4); break; case 5: RD(5); break; case 6: RD(6); break; case 7: RD(7); break; case 8: RD(8); break;
+                                           case 9: RD(9); break; case 10: RD(10); break; default: RD(11); break; } }
+        MF(accM[j], wv[1 * 3 + kx], bx[g], accM[j]);
+        MF(accO[j], wv[2 * 3 + kx], bx[g], accO[j]);
+    }
+#undef RD
+#undef MF
+}
+
 template <int PAIR, int FORM, int CHORES>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k(float* out, unsigned long long* cyc, const float* src, int iters) {
     __shared__ __attribute__((aligned(16))) char smem[NR * ROWH_B + 8192];
@@ -71,14 +106,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int stg = wave >> 2, w4 = wave & 3, hf = w4 >> 1;
     for (int i = tid; i < (NR * ROWH_B + 8192) / 4; i += 512) {
         unsigned h = (unsigned)(i + blockIdx.x * 7919) * 2654435761u;
-        const _Float16 a = (_Float16)((int)(h >> 8 & 0xffff) * (1.f / 32768.f) - 1.f), b = (_Float16)((int)(h >> 12 & 0xffff) * (1.f / 32768.f) - 1.f);
+        const elem_t a = (elem_t)((int)(h >> 8 & 0xffff) * (1.f / 32768.f) - 1.f), b = (elem_t)((int)(h >> 12 & 0xffff) * (1.f / 32768.f) - 1.f);
+#ifdef RELU_DATA
+        ((unsigned*)smem)[i] = ((float)a > 0.f ? (unsigned)__builtin_bit_cast(unsigned short, a) : 0u) | (((float)b > 0.f ? (unsigned)__builtin_bit_cast(unsigned short, b) : 0u) << 16);
+#else
         ((unsigned*)smem)[i] = (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+#endif
     }
     u32x4 wv[18], keep[12];
     for (int f = 0; f < 18; ++f)
         for (int e = 0; e < 4; ++e) {
             unsigned h = (unsigned)((wave * 18 + f) * 256 + lane * 4 + e) * 2246822519u;
-            const _Float16 a = (_Float16)(((int)(h >> 8 & 0xffff) * (1.f / 32768.f) - 1.f) * 0.05f), b = (_Float16)(((int)(h >> 12 & 0xffff) * (1.f / 32768.f) - 1.f) * 0.05f);
+            const elem_t a = (elem_t)(((int)(h >> 8 & 0xffff) * (1.f / 32768.f) - 1.f) * 0.05f), b = (elem_t)(((int)(h >> 12 & 0xffff) * (1.f / 32768.f) - 1.f) * 0.05f);
             wv[f][e] = (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
         }
     int base[3];
@@ -131,23 +170,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 SB();
             }
         };
+#define ROW(r, w, n, m, o, f) do { if constexpr (FORM == 7) mfma_row_acc(r, base, wv, n, m, o, f, bias);       /* (one row's nine weight fragments for both rows: the unified file splits 128 + 128 here) */ else mfma_row<FORM>(r, base, w, n, m, o, f, bias, keep); } while (0)
         auto step = [&](int t, f32x4 (&aN)[4], f32x4 (&aM)[4], f32x4 (&aO)[4], f32x4 (&pN)[4], f32x4 (&pM)[4], f32x4 (&pO)[4]) __attribute__((always_inline)) {
             const char* r0 = smem + ((2 * t) % NR) * ROWH_B;
             const char* r1 = smem + ((2 * t + 1) % NR) * ROWH_B;
             if (PAIR == 3 && stg == 1) {       // half a step behind: second row of the previous step, barrier, first row of this one
-                mfma_row<FORM>(r1, base, wv + 9, pN, pM, pO, false, bias, keep);      // (p* = the previous step's sets)
+                ROW(r1, wv + 9, pN, pM, pO, false);      // (p* = the previous step's sets)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) sink[j] += pO[j][j];
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 chores_b(pO);
-                mfma_row<FORM>(r0, base, wv, aN, aM, aO, true, bias, keep);
+                ROW(r0, wv, aN, aM, aO, true);
                 return;
             } else {
                 if (PAIR >= 2) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
                 if (stg == 1) chores_b(aO);
-                mfma_row<FORM>(r0, base, wv, aN, aM, aO, true, bias, keep);
-                mfma_row<FORM>(r1, base, wv + 9, aN, aM, aO, false, bias, keep);
+                ROW(r0, wv, aN, aM, aO, true);
+                ROW(r1, wv + 9, aN, aM, aO, false);
                 if (stg == 0) chores_a(t, aO);
             }
 #pragma unroll
@@ -192,13 +232,18 @@ static void run(const char* what, float* d, unsigned long long* dc, const float*
     printf("pair %d form %d chores %d  %-60s %7.1f ns/step %6.2f ns/MFMA | cycles/step A %6.0f B %6.0f = %5.2f cycles/MFMA at %.2f GHz\n", PAIR, FORM, CHORES, what, ns,
            ns / per_simd, ca, cb, cmax / per_simd, cmax / ns);
     fflush(stdout);
+    if (getenv("PROBE")) {       // socket power and shader clock while this stream runs (60 more launches in flight behind a read-only rocm-smi poll)
+        for (int r = 0; r < 60; ++r) hipLaunchKernelGGL((k<PAIR, FORM, CHORES>), dim3(blocks), dim3(512), 0, 0, d, dc, src, iters);
+        if (system("sleep 1; rocm-smi -d 0 --showpower --showclocks 2>/dev/null | grep -E 'Socket|sclk' | sed -E 's/\\s+/ /g' | tr '\\n' ' '; echo")) {}
+        hipDeviceSynchronize();
+    }
 }
 
 int main() {
     float* d; unsigned long long* dc; float* src;
     hipMalloc(&d, 4096); hipMalloc(&dc, 512 * 8); hipMalloc(&src, 1 << 20);
     hipMemset(src, 0x3c, 1 << 20);
-    for (int rep = 0; rep < 2; ++rep) {
+    for (int rep = 0; rep < (getenv("PROBE") ? 1 : 2); ++rep) {
     printf("-- pass %d\n", rep);
     run<0, 3, 0>("one wave per SIMD, register-only", d, dc, src);
     run<1, 3, 0>("two waves per SIMD, register-only, no barrier", d, dc, src);
@@ -219,6 +264,8 @@ int main() {
     run<2, 5, 0>("two waves, read between 2nd and 3rd MFMA, barrier", d, dc, src);
     run<0, 6, 0>("one wave, registers rest 2 groups + mid read", d, dc, src);
     run<2, 6, 0>("two waves, registers rest 2 groups + mid read, barrier", d, dc, src);
+    run<0, 7, 0>("one wave, 3 ahead, fragments in AccVGPRs", d, dc, src);
+    run<2, 7, 0>("two waves, fragments in AccVGPRs, barrier", d, dc, src);
     run<2, 0, 1>("K67X shape: A tail chores, B head burst; barrier per step", d, dc, src);
     run<3, 0, 1>("K67X shape, waves 4-7 half a step behind", d, dc, src);
     run<2, 3, 1>("K67X shape, register-only fragments", d, dc, src);
