@@ -20,6 +20,8 @@
   zero_ig_forward      zero_ig.py:434-452 (ZeroIG.forward, predicting branch)
                        all three PINNED by tests/golden/zero_ig_*.npz (reference file mon_extra/.../zero_ig/model.py:
                        Enhancer, Denoise_1, Denoise_2 and Finetunemodel.forward run in the build container)
+  mprnet_forward       src/mon/vision/enhance/multitask/mprnet/mprnet.py:34-357, 483-553: blocks PINNED (round 4) by tests/golden/mprnet_c8_*.npz (the
+                       block classes executed out of mprnet.py); the call order of forward() transcribed.
   hinet_forward        src/mon/vision/enhance/multitask/hinet/hinet.py:34-198, 322-362
                        PINNED by tests/golden/hinet_*.npz (reference file mon_extra/.../hinet/basicsr/models/archs/hinet_arch.py)
   rrdnet_forward       src/mon/vision/enhance/llie/rrdnet/rrdnet.py:208-289: the three stacks + sigmoid / sigmoid / tanh are PINNED by
@@ -468,11 +470,13 @@ def hinet_forward(sd: dict, x: torch.Tensor, depth: int = 5, relu_slope: float =
 
 
 # ---- MPRNet ------------------------------------------------------------------------------------------------------
-def mprnet_forward(sd: dict, x: torch.Tensor, num_cab: int = 8) -> dict:
+def mprnet_forward(sd: dict, x: torch.Tensor, num_cab: int = 8, taps: dict = None) -> dict:
     """src/mon/vision/enhance/multitask/mprnet/mprnet.py:33-340 (modules) and :455-548 (three-stage forward with the 4 / 2 / 1 patch
     hierarchy).  The ONE nn.PReLU() instance (mprnet.py:421) is shared by every CAB and appears in the checkpoint under each
-    ``...body.1.weight``.  parity unpinned: the mon package does not import here and MPRNet has no mon_extra twin; the leaf
-    operations are torch's own."""
+    ``...body.1.weight``.  The BLOCKS are PINNED (round 4) by tests/golden/mprnet_c8_*.npz: conv / CAB / SAM / Encoder (plain and CSFF) /
+    Decoder / ORSNet executed out of mprnet.py (plain torch.nn classes in a module that imports mon), with block-level taps; the model class
+    derives from mon's Lightning base and cannot be defined here, so the order of the block calls in forward() (crops, cats) is a
+    transcription in the fixture's generator as it is here.  ``taps``: filled with the intermediate lists the fixture holds."""
     def cv(n, t):
         w = sd[f"{n}.weight"]
         return F.conv2d(t, w, sd.get(f"{n}.bias"), padding=w.shape[2] // 2)
@@ -529,6 +533,8 @@ def mprnet_forward(sd: dict, x: torch.Tensor, num_cab: int = 8) -> dict:
     s_top, img_top = sam("sam12", r1_top[0], top)
     s_bot, img_bot = sam("sam12", r1_bot[0], bot)
     stage1 = torch.cat([img_top, img_bot], 2)
+    if taps is not None:
+        taps.update(feat1_ltop=f1[0], res1_top=r1_top, sam12_top_feats=s_top, sam12_top_img=img_top)
     c_top = cv("concat12", torch.cat([shallow(2, top), s_top], 1))
     c_bot = cv("concat12", torch.cat([shallow(2, bot), s_bot], 1))
     f2_top = encoder("stage2_encoder", c_top, f1_top, r1_top)
@@ -542,4 +548,6 @@ def mprnet_forward(sd: dict, x: torch.Tensor, num_cab: int = 8) -> dict:
     t = orb(f"{o}.orb2", t) + cv(f"{o}.conv_enc2", up(f"{o}.up_enc1", f2[1])) + cv(f"{o}.conv_dec2", up(f"{o}.up_dec1", r2[1]))
     t = orb(f"{o}.orb3", t) + cv(f"{o}.conv_enc3", up(f"{o}.up_enc2.1", up(f"{o}.up_enc2.0", f2[2]))) \
         + cv(f"{o}.conv_dec3", up(f"{o}.up_dec2.1", up(f"{o}.up_dec2.0", r2[2])))
+    if taps is not None:
+        taps.update(feat2_top=f2_top, res2=r2, orsnet=t)
     return {"stage1": stage1, "stage2": stage2, "enhanced": cv("tail", t) + x}

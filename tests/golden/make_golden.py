@@ -407,6 +407,78 @@ def gen_learnable_instance_norm():
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
+def gen_mprnet():
+    """MPRNet's building blocks (rank-3 widening): conv / DownSample / UpSample / SkipUpSample / CALayer / CAB / SAM / Encoder / Decoder / ORB / ORSNet of
+    src/mon/vision/enhance/multitask/mprnet/mprnet.py:34-357 are plain torch.nn classes inside a module that imports mon; they are executed out of the file.  The model
+    class itself derives from mon's Lightning base (and evaluates a mon loss as a default argument), so it cannot be defined here: the blocks are instantiated under the
+    attribute names and with the arguments of MPRNet.__init__ (mprnet.py:427-451) and wired as MPRNet.forward does (mprnet.py:483-553) -- that wiring (crops, cats, the
+    order of the calls) is a transcription, every arithmetic step runs inside the reference's own block code.  Reduced width (8 / 4 / 4 channels, 2 CABs per ORB)."""
+    from typing import Any, Sequence
+    import torch.nn as nn
+    from torch.nn.common_types import _size_2_t
+    ns = _extract("src/mon/vision/enhance/multitask/mprnet/mprnet.py", ["conv", "DownSample", "UpSample", "SkipUpSample", "CALayer", "CAB", "SAM", "Encoder", "Decoder", "ORB", "ORSNet"],
+                  {"torch": torch, "nn": nn, "Any": Any, "Sequence": Sequence, "_size_2_t": _size_2_t})
+    conv, CAB, SAM, Encoder, Decoder, ORSNet = (ns[k] for k in ("conv", "CAB", "SAM", "Encoder", "Decoder", "ORSNet"))
+    cin, c, su, so, ncab, ks, red, bias = 3, 8, 4, 4, 2, 3, 4, False
+    torch.manual_seed(141)
+    m = nn.Module()                                   # a bag of the reference's blocks under MPRNet's attribute names (= its state_dict keys)
+    act = nn.PReLU()
+    for k in (1, 2, 3):
+        setattr(m, f"shallow_feat{k}", nn.Sequential(conv(cin, c, ks, bias=bias), CAB(c, ks, red, bias=bias, act_layer=act)))
+    m.stage1_encoder = Encoder(c, ks, red, act, bias, su, csff=False)
+    m.stage1_decoder = Decoder(c, ks, red, act, bias, su)
+    m.stage2_encoder = Encoder(c, ks, red, act, bias, su, csff=True)
+    m.stage2_decoder = Decoder(c, ks, red, act, bias, su)
+    m.stage3_orsnet = ORSNet(c, so, ks, red, act, bias, su, ncab)
+    m.sam12, m.sam23 = SAM(c, kernel_size=1, bias=bias), SAM(c, kernel_size=1, bias=bias)
+    m.concat12 = conv(c * 2, c, ks, bias=bias)
+    m.concat23 = conv(c * 2, c + so, ks, bias=bias)
+    m.tail = conv(c + so, cin, ks, bias=bias)
+    with torch.no_grad():                             # "trained-like": livelier kernels and gates, the shared PReLU slope away from its default
+        for name, p_ in m.named_parameters():
+            if name.endswith("body.1.weight"):
+                p_.fill_(0.17)
+            elif p_.dim() == 4:
+                p_.mul_(3.0 if (name.endswith("conv_du.2.weight") or name.endswith("conv3.weight")) else 1.3)
+    g = torch.Generator().manual_seed(142)
+    x = torch.rand(2, 3, 24, 32, generator=g)
+    x[1] = x[1] ** 2.2 * 0.4
+    taps = {}
+    with torch.no_grad():
+        h, w = x.size(2), x.size(3)
+        x2top_img, x2bot_img = x[:, :, 0:int(h / 2), :], x[:, :, int(h / 2):h, :]
+        x1ltop_img, x1rtop_img = x2top_img[:, :, :, 0:int(w / 2)], x2top_img[:, :, :, int(w / 2):w]
+        x1lbot_img, x1rbot_img = x2bot_img[:, :, :, 0:int(w / 2)], x2bot_img[:, :, :, int(w / 2):w]
+        feat1_ltop, feat1_rtop = m.stage1_encoder(m.shallow_feat1(x1ltop_img)), m.stage1_encoder(m.shallow_feat1(x1rtop_img))
+        feat1_lbot, feat1_rbot = m.stage1_encoder(m.shallow_feat1(x1lbot_img)), m.stage1_encoder(m.shallow_feat1(x1rbot_img))
+        feat1_top = [torch.cat((k, v), 3) for k, v in zip(feat1_ltop, feat1_rtop)]
+        feat1_bot = [torch.cat((k, v), 3) for k, v in zip(feat1_lbot, feat1_rbot)]
+        res1_top, res1_bot = m.stage1_decoder(feat1_top), m.stage1_decoder(feat1_bot)
+        x2top_samfeats, stage1_img_top = m.sam12(res1_top[0], x2top_img)
+        x2bot_samfeats, stage1_img_bot = m.sam12(res1_bot[0], x2bot_img)
+        stage1_img = torch.cat([stage1_img_top, stage1_img_bot], 2)
+        x2top_cat = m.concat12(torch.cat([m.shallow_feat2(x2top_img), x2top_samfeats], 1))
+        x2bot_cat = m.concat12(torch.cat([m.shallow_feat2(x2bot_img), x2bot_samfeats], 1))
+        feat2_top, feat2_bot = m.stage2_encoder(x2top_cat, feat1_top, res1_top), m.stage2_encoder(x2bot_cat, feat1_bot, res1_bot)
+        feat2 = [torch.cat((k, v), 2) for k, v in zip(feat2_top, feat2_bot)]
+        res2 = m.stage2_decoder(feat2)
+        x3_samfeats, stage2_img = m.sam23(res2[0], x)
+        x3_cat = m.concat23(torch.cat([m.shallow_feat3(x), x3_samfeats], 1))
+        x3_ors = m.stage3_orsnet(x3_cat, feat2, res2)
+        stage3_img = m.tail(x3_ors)
+        for nm, lst in (("feat1_ltop", feat1_ltop), ("res1_top", res1_top), ("feat2_top", feat2_top), ("res2", res2)):     # block-level taps: Encoder (plain and CSFF), Decoder
+            for i, t_ in enumerate(lst):
+                taps[f"tap.{nm}.{i}"] = t_.numpy()
+        taps["tap.sam12_top_feats"], taps["tap.sam12_top_img"], taps["tap.orsnet"] = x2top_samfeats.numpy(), stage1_img_top.numpy(), x3_ors.numpy()
+    out = {f"w.{k}": v.detach().numpy() for k, v in m.state_dict().items()}
+    out.update(taps)
+    out.update(image=x.numpy(), stage1=stage1_img.numpy(), stage2=stage2_img.numpy(), enhanced=(stage3_img + x).numpy())
+    path = os.path.join(HERE, "mprnet_c8_seed141_2x24x32.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB |", len(m.state_dict()), "tensors | enhanced - image", float((stage3_img).abs().max()), "stage1 - stage2",
+          float((stage1_img - stage2_img).abs().max()))
+
+
 def gen_upsampler():
     """The PixelShuffle up-sampler leaf of the BASELINE config-3 decoder variant: Upsampler(default_conv, scale, n_feats, act=...) of
     src/mon/nn/modules/encoder/edsr.py:88-123 -- a file that imports torch only, loaded as a module."""
@@ -427,13 +499,15 @@ def gen_upsampler():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["zero_dce", "zero_dcepp", "llunetpp", "hinet", "zero_ig", "unet", "rrdnet", "retinexnet", "ssim", "zero_dce_losses", "upsampler", "hvi", "lin"]
+    which = sys.argv[1:] or ["zero_dce", "zero_dcepp", "llunetpp", "hinet", "zero_ig", "unet", "rrdnet", "retinexnet", "ssim", "zero_dce_losses", "upsampler", "hvi", "lin", "mprnet"]
     if "upsampler" in which:
         gen_upsampler()
     if "hvi" in which:
         gen_hvi()
     if "lin" in which:
         gen_learnable_instance_norm()
+    if "mprnet" in which:
+        gen_mprnet()
     if "retinexnet" in which:
         gen_retinexnet()
     if "ssim" in which:

@@ -785,6 +785,18 @@ def test_mprnet_vs_oracle_and_patch_ops():
             assert rel_err(o16[k].cpu(), ref[k]) <= tol, (dt, k, rel_err(o16[k].cpu(), ref[k]))
 
 
+def test_mprnet_reference_blocks_golden():
+    """The engine's MPRNet against the reference's own blocks run on CPU (tests/golden/mprnet_c8_*.npz: conv / CAB / SAM / Encoder / Decoder / ORSNet executed out of
+    mprnet.py and called in MPRNet.forward's order): fp32 path on the three outputs."""
+    g = np.load(os.path.join(GOLDEN, "mprnet_c8_seed141_2x24x32.npz"))
+    sd = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w.")}
+    m = mon_amd.MODELS.build(name="mprnet", weights=sd, num_channels=8, scale_unetfeats=4, scale_orsnetfeats=4, num_cab=2, reduction=4).to("cuda")
+    out = m.forward({"image": torch.from_numpy(g["image"]).cuda()})
+    assert list(out) == ["stage1", "stage2", "enhanced"]
+    for k in out:
+        assert rel_err(out[k].cpu(), g[k]) <= 5e-5, (k, rel_err(out[k].cpu(), g[k]))
+
+
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 def test_channel_stats_and_affine_16bit(dt):
     """The 16-bit forms of the channel-attention leaves (vectorised 8 channels per thread, and the scalar fallback for C % 8 != 0)."""

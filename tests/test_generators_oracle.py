@@ -285,3 +285,23 @@ def test_learnable_instance_norm_restatement_matches_reference():
         t = {k: torch.from_numpy(g[f"{tag}.{k}"]) for k in ("x", "weight", "bias", "r")}
         y = og.learnable_instance_norm(t["x"], t["weight"], t["bias"], t["r"])
         assert np.abs(y.numpy() - g[f"{tag}.y"]).max() <= 1e-6, tag
+
+
+def test_mprnet_restatement_matches_reference_blocks():
+    """oracle.generators.mprnet_forward against the reference's own MPRNet blocks (conv / CAB / SAM / Encoder with and without CSFF / Decoder / ORSNet of
+    src/mon/vision/enhance/multitask/mprnet/mprnet.py:34-357, executed out of the file by make_golden.gen_mprnet and called in the order of MPRNet.forward,
+    mprnet.py:483-553): the three outputs and the block-level taps."""
+    g = np.load(os.path.join(GOLDEN, "mprnet_c8_seed141_2x24x32.npz"))
+    sd = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w.")}
+    assert len(sd) == 226 and "stage2_encoder.csff_dec3.weight" in sd and tuple(sd["shallow_feat1.1.body.1.weight"].shape) == (1,)
+    taps = {}
+    out = og.mprnet_forward(sd, torch.from_numpy(g["image"]), num_cab=2, taps=taps)
+    for k in ("stage1", "stage2", "enhanced"):
+        assert np.abs(out[k].numpy() - g[k]).max() <= 2e-5 * max(1.0, np.abs(g[k]).max()), k
+    for nm in ("feat1_ltop", "res1_top", "feat2_top", "res2"):
+        for i in range(3):
+            want = g[f"tap.{nm}.{i}"]
+            assert np.abs(taps[nm][i].numpy() - want).max() <= 2e-5 * max(1.0, np.abs(want).max()), (nm, i)
+    for nm in ("sam12_top_feats", "sam12_top_img", "orsnet"):
+        want = g[f"tap.{nm}"]
+        assert np.abs(taps[nm].numpy() - want).max() <= 2e-5 * max(1.0, np.abs(want).max()), nm
