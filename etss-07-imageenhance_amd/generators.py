@@ -515,7 +515,7 @@ class LLLINet(_GraphModel):
     tasks = [Task.LLIE]
     schemes = [Scheme.SUPERVISED]
 
-    def __init__(self, in_channels: int = 3, out_channels: int = 3, weights: Any = None, loss_weights=None, seed: int = None, *args, **kwargs):
+    def __init__(self, in_channels: int = 3, out_channels: int = 3, weights: Any = None, loss_weights=None, seed: int = None, filters=None, *args, **kwargs):
         kwargs.pop("name", None)
         super().__init__(name="lllinet", in_channels=in_channels, weights=weights, *args, **kwargs)
         if isinstance(self.weights, dict):
@@ -523,7 +523,9 @@ class LLLINet(_GraphModel):
             out_channels = self.weights.get("out_channels", out_channels)
         self.in_channels, self._out = in_channels, out_channels
         self.predicting = True
-        f = [32, 64, 128, 256, 512]
+        f = list(filters) if filters else [32, 64, 128, 256, 512]      # (lllinet.py:194 hard-codes the widths; ``filters`` lets a test build the same grid narrow)
+        if len(f) != 5:
+            raise ValueError(f"LLLINet: filters must name five widths (got {f})")
         io = {"conv0_0": (in_channels, f[0]), "conv1_0": (f[0], f[1]), "conv2_0": (f[1], f[2]), "conv3_0": (f[2], f[3]), "conv4_0": (f[3], f[4]),
               "conv0_1": (f[0] + 2 * f[1], f[0]), "conv1_1": (f[1] + 2 * f[2], f[1]), "conv2_1": (f[2] + 2 * f[3], f[2]), "conv3_1": (f[3] + f[4], f[3]),
               "conv0_2": (2 * f[0] + 2 * f[1], f[0]), "conv1_2": (2 * f[1] + 2 * f[2], f[1]), "conv2_2": (2 * f[2] + f[3], f[2]),

@@ -4,8 +4,9 @@
                        PINNED by tests/golden/zero_dcepp_*.npz (reference file mon_extra/.../zero_dce++/model.py)
   llunetpp_forward     src/mon/vision/enhance/llie/llunetpp/llunetpp.py:97-137, 218-243
                        PINNED by tests/golden/llunetpp_*.npz (reference file mon_extra/.../llunet++/model.py)
-  lllinet_forward      src/mon/vision/enhance/llie/lllinet/lllinet.py:97-260 (+ normalization.py:177-224, attention.py:1156-1182): parity unpinned, except its norm leaf
-                       ``learnable_instance_norm``, PINNED (round 4) by tests/golden/learnable_instance_norm.npz (class LearnableInstanceNorm2d executed out of normalization.py).
+  lllinet_forward      src/mon/vision/enhance/llie/lllinet/lllinet.py:97-260 (+ normalization.py:177-224, attention.py:1156-1182): the BLOCK is PINNED (round 4) by
+                       tests/golden/lllinet_w2_*.npz (UNetConvBlock, LearnableInstanceNorm2d and SimAM executed out of their files; grid order transcribed, widths 2 .. 32)
+                       and its norm leaf by tests/golden/learnable_instance_norm.npz.
   lllinet_hvi_forward  lllinet.py:262-388 + core/image/color.py:313-434 (RGBToHVI).  rgb_to_hvi / hvi_to_rgb are PINNED (round 4) by tests/golden/hvi_transform_*.npz: the class
                        RGBToHVI executed out of color.py's syntax tree (the module imports cv2 and kornia, the class is pure torch); the LLLINet grid around it: parity unpinned.
   unet_forward         src/mon/vision/segment/unet/unet.py:35-197 with line 51's typo read as conv1; eval-mode BN.
@@ -141,7 +142,7 @@ def llunetpp_to_extra_keys(sd: dict) -> dict:
     return out
 
 
-# ---- LLLINet (parity unpinned but for the norm leaf: the mon package does not import here and the model has no mon_extra twin) ---------------------------
+# ---- LLLINet (block pinned by tests/golden/lllinet_w2_*.npz; the model class itself does not import here) ---------------------------
 def learnable_instance_norm(x, weight, bias, r, eps=1e-5):
     """src/mon/nn/modules/normalization.py:208-224 (pinned: tests/golden/learnable_instance_norm.npz)."""
     xn = F.instance_norm(x, weight=weight, bias=bias, eps=eps)

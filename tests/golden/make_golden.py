@@ -479,6 +479,68 @@ def gen_mprnet():
           float((stage1_img - stage2_img).abs().max()))
 
 
+def gen_lllinet():
+    """LLLINet's block (rank-3 widening): UNetConvBlock of src/mon/vision/enhance/llie/lllinet/lllinet.py:97-156 with the two mon layers it is made of,
+    LearnableInstanceNorm2d (nn/modules/normalization.py:177-224) and SimAM (nn/modules/attention.py:1154-1181; its ``act.Sigmoid`` is torch's own class: mon's
+    activation module star-imports torch.nn.modules.activation) -- all three executed out of their files.  The block resolves its layers through ``nn.``: the namespace
+    it runs in is torch.nn's public names plus those two extracted classes, which is what ``mon.nn`` is for this block.  The model class derives from mon's Lightning base,
+    so the fifteen blocks are instantiated under the attribute names of LLLINet.__init__ (lllinet.py:196-219) and called in the order of its forward (:229-260): a
+    transcription, at widths 2 .. 32 instead of 32 .. 512 (the class hard-codes them; 32 .. 512 is 120 MB of weights)."""
+    import math, types
+    from typing import Any
+    import torch.nn as nn
+    import torch.nn.functional as F
+    lin = _extract("src/mon/nn/modules/normalization.py", ["LearnableInstanceNorm2d"], {"torch": torch, "nn": nn, "F": F, "math": math, "Any": Any})["LearnableInstanceNorm2d"]
+    simam = _extract("src/mon/nn/modules/attention.py", ["SimAM"], {"torch": torch, "nn": nn, "act": torch.nn.modules.activation})["SimAM"]
+    mon_nn = types.SimpleNamespace(**{k: getattr(nn, k) for k in dir(nn) if not k.startswith("_")}, LearnableInstanceNorm2d=lin, SimAM=simam)
+    Block = _extract("src/mon/vision/enhance/llie/lllinet/lllinet.py", ["UNetConvBlock"], {"torch": torch, "nn": mon_nn})["UNetConvBlock"]
+    f = [2, 4, 8, 16, 32]
+    torch.manual_seed(151)
+    m = nn.Module()
+    m.conv0_0 = Block(3, f[0], use_in=False)
+    m.conv1_0, m.conv2_0, m.conv3_0, m.conv4_0 = Block(f[0], f[1]), Block(f[1], f[2]), Block(f[2], f[3]), Block(f[3], f[4])
+    m.conv0_1, m.conv1_1, m.conv2_1, m.conv3_1 = Block(f[0] + 2 * f[1], f[0]), Block(f[1] + 2 * f[2], f[1]), Block(f[2] + 2 * f[3], f[2]), Block(f[3] + f[4], f[3])
+    m.conv0_2, m.conv1_2, m.conv2_2 = Block(f[0] * 2 + 2 * f[1], f[0]), Block(f[1] * 2 + 2 * f[2], f[1]), Block(f[2] * 2 + f[3], f[2])
+    m.conv0_3, m.conv1_3 = Block(f[0] * 3 + 2 * f[1], f[0]), Block(f[1] * 3 + f[2], f[1])
+    m.conv0_4 = Block(f[0] * 4 + f[1], f[0])
+    m.final = nn.Conv2d(f[0], 3, kernel_size=1)
+    g = torch.Generator().manual_seed(152)
+    with torch.no_grad():                             # "trained-like": the learnable normalisation away from its initial r = 0.5 / weight 1 / bias 0
+        for name, p_ in m.named_parameters():
+            if name.endswith("norm1.r"):
+                p_.copy_(torch.rand(p_.shape, generator=g) * 0.9 + 0.05)
+            elif name.endswith("norm1.weight"):
+                p_.copy_(torch.rand(p_.shape, generator=g) + 0.5)
+            elif name.endswith("norm1.bias"):
+                p_.copy_(torch.randn(p_.shape, generator=g) * 0.2)
+            elif p_.dim() == 4:
+                p_.mul_(1.4)
+        m.final.bias.add_(0.35)
+    x = torch.rand(2, 3, 32, 48, generator=g)
+    x[1] = x[1] ** 2.2 * 0.3
+    pool, up = nn.MaxPool2d(2, 2), nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True)
+    with torch.no_grad():
+        x0_0 = m.conv0_0(x)
+        x1_0 = m.conv1_0(pool(x0_0)); x2_0 = m.conv2_0(pool(x1_0)); x3_0 = m.conv3_0(pool(x2_0)); x4_0 = m.conv4_0(pool(x3_0))
+        x3_1 = m.conv3_1(torch.cat([x3_0, up(x4_0)], 1))
+        x2_1 = m.conv2_1(torch.cat([x2_0, up(x3_0), up(x3_1)], 1))
+        x1_1 = m.conv1_1(torch.cat([x1_0, up(x2_0), up(x2_1)], 1))
+        x0_1 = m.conv0_1(torch.cat([x0_0, up(x1_0), up(x1_1)], 1))
+        x2_2 = m.conv2_2(torch.cat([x2_0, x2_1, up(x3_1)], 1))
+        x1_2 = m.conv1_2(torch.cat([x1_0, x1_1, up(x2_1), up(x2_2)], 1))
+        x0_2 = m.conv0_2(torch.cat([x0_0, x0_1, up(x1_1), up(x1_2)], 1))
+        x1_3 = m.conv1_3(torch.cat([x1_0, x1_1, x1_2, up(x2_2)], 1))
+        x0_3 = m.conv0_3(torch.cat([x0_0, x0_1, x0_2, up(x1_2), up(x1_3)], 1))
+        x0_4 = m.conv0_4(torch.cat([x0_0, x0_1, x0_2, x0_3, up(x1_3)], 1))
+        y = m.final(x0_4)
+    out = {f"w.{k}": v.detach().numpy() for k, v in m.state_dict().items()}
+    out.update(image=x.numpy(), y=y.numpy(), enhanced=torch.clamp(y, 0, 1).numpy(), **{f"tap.{k}": v.numpy() for k, v in (("x0_0", x0_0), ("x1_0", x1_0), ("x3_1", x3_1), ("x0_4", x0_4))})
+    path = os.path.join(HERE, "lllinet_w2_seed151_2x32x48.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB |", len(m.state_dict()), "tensors | y range", float(y.min()), float(y.max()), "clamped share",
+          float(((y < 0) | (y > 1)).float().mean()))
+
+
 def gen_upsampler():
     """The PixelShuffle up-sampler leaf of the BASELINE config-3 decoder variant: Upsampler(default_conv, scale, n_feats, act=...) of
     src/mon/nn/modules/encoder/edsr.py:88-123 -- a file that imports torch only, loaded as a module."""
@@ -499,7 +561,7 @@ def gen_upsampler():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["zero_dce", "zero_dcepp", "llunetpp", "hinet", "zero_ig", "unet", "rrdnet", "retinexnet", "ssim", "zero_dce_losses", "upsampler", "hvi", "lin", "mprnet"]
+    which = sys.argv[1:] or ["zero_dce", "zero_dcepp", "llunetpp", "hinet", "zero_ig", "unet", "rrdnet", "retinexnet", "ssim", "zero_dce_losses", "upsampler", "hvi", "lin", "mprnet", "lllinet"]
     if "upsampler" in which:
         gen_upsampler()
     if "hvi" in which:
@@ -508,6 +570,8 @@ if __name__ == "__main__":
         gen_learnable_instance_norm()
     if "mprnet" in which:
         gen_mprnet()
+    if "lllinet" in which:
+        gen_lllinet()
     if "retinexnet" in which:
         gen_retinexnet()
     if "ssim" in which:

@@ -785,6 +785,18 @@ def test_mprnet_vs_oracle_and_patch_ops():
             assert rel_err(o16[k].cpu(), ref[k]) <= tol, (dt, k, rel_err(o16[k].cpu(), ref[k]))
 
 
+def test_lllinet_reference_blocks_golden():
+    """The engine's LLLINet (``filters`` = the fixture's widths) against the reference's own UNetConvBlock / LearnableInstanceNorm2d / SimAM run on CPU
+    (tests/golden/lllinet_w2_*.npz, grid order of lllinet.py:229-260): fp32 path."""
+    g = np.load(os.path.join(GOLDEN, "lllinet_w2_seed151_2x32x48.npz"))
+    sd = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w.")}
+    m = mon_amd.MODELS.build(name="lllinet", weights=sd, filters=[2, 4, 8, 16, 32]).to("cuda")
+    out = m.forward({"image": torch.from_numpy(g["image"]).cuda()})["enhanced"].cpu()
+    assert float(np.abs(out.numpy() - g["enhanced"]).max()) <= 5e-5
+    with pytest.raises(ValueError):
+        mon_amd.MODELS.build(name="lllinet", filters=[4, 8])
+
+
 def test_mprnet_reference_blocks_golden():
     """The engine's MPRNet against the reference's own blocks run on CPU (tests/golden/mprnet_c8_*.npz: conv / CAB / SAM / Encoder / Decoder / ORSNet executed out of
     mprnet.py and called in MPRNet.forward's order): fp32 path on the three outputs."""

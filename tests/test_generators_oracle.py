@@ -305,3 +305,18 @@ def test_mprnet_restatement_matches_reference_blocks():
     for nm in ("sam12_top_feats", "sam12_top_img", "orsnet"):
         want = g[f"tap.{nm}"]
         assert np.abs(taps[nm].numpy() - want).max() <= 2e-5 * max(1.0, np.abs(want).max()), nm
+
+
+def test_lllinet_restatement_matches_reference_blocks():
+    """oracle.generators.lllinet_forward against the reference's own UNetConvBlock (lllinet.py:97-156, with LearnableInstanceNorm2d and SimAM, all executed out of
+    their files by make_golden.gen_lllinet) on the grid of LLLINet.forward (lllinet.py:229-260) at widths 2 .. 32: output before and after the clamp, block-level taps."""
+    g = np.load(os.path.join(GOLDEN, "lllinet_w2_seed151_2x32x48.npz"))
+    sd = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w.")}
+    assert "conv0_0.norm1.r" not in sd and tuple(sd["conv3_1.norm1.r"].shape) == (48,)
+    x = torch.from_numpy(g["image"])
+    assert np.abs(og.lllinet_forward(sd, x, clamp=False)["enhanced"].numpy() - g["y"]).max() <= 2e-5
+    assert np.abs(og.lllinet_forward(sd, x)["enhanced"].numpy() - g["enhanced"]).max() <= 2e-5
+    x0_0 = og._lllinet_block(sd, "conv0_0", x)
+    assert np.abs(x0_0.numpy() - g["tap.x0_0"]).max() <= 1e-5
+    x1_0 = og._lllinet_block(sd, "conv1_0", torch.nn.functional.max_pool2d(x0_0, 2, 2))
+    assert np.abs(x1_0.numpy() - g["tap.x1_0"]).max() <= 1e-5
