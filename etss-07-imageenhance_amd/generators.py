@@ -1368,7 +1368,8 @@ class GCENet(_GraphModel):
     the model builds it, :387) on [image, depth, edge] with Zero-DCE's concat pattern -> ONE 3-channel curve map; edge =
     BoundaryAwarePrior(depth) (Sobel magnitude / max > ``dba_eps``); the curve runs ``num_iters`` times in its brightness-attention
     form (bam = (1 - V(median_blur(image, bam_ksize)))^bam_gamma, :478-484) and the result goes through GuidedFilter(gf_radius,
-    gf_eps)(image, enhanced).  ``datapoint`` needs ``depth`` (N,1,H,W) when ``use_depth``.  Keys ``en.e_conv{k}.conv.{dw,pw}_conv``."""
+    gf_eps)(image, enhanced) -- whose windows are ``gf_radius`` pixels WIDE: the class passes its radius to BoxFilter as the kernel size (``ops.guided_filter_module``;
+    pinned by tests/golden/guided_filter_seed161.npz).  ``datapoint`` needs ``depth`` (N,1,H,W) when ``use_depth``.  Keys ``en.e_conv{k}.conv.{dw,pw}_conv``."""
 
     arch = "gcenet"
     tasks = [Task.LLIE]
@@ -1432,7 +1433,7 @@ class GCENet(_GraphModel):
             _, v = ops.rgb_to_hsv(blurred, want_hsv=False)
             bam = ops.pow_scalar(ops.affine(v, -1.0, 1.0), self.bam_gamma)                    # (1 - v)^gamma
         enhanced = ops.le_curve(image, adjust, self.num_iters, bam)
-        enhanced = ops.guided_filter(image, enhanced, self.gf_radius, self.gf_eps)
+        enhanced = ops.guided_filter_module(image, enhanced, self.gf_radius, self.gf_eps)      # (windows gf_radius pixels WIDE, as the reference class filters)
         out = OrderedDict()
         if self.debug:
             out["adjust"] = ops.to_nchw(adjust)

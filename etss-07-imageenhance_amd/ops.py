@@ -474,8 +474,20 @@ def box_filter(x, radius):
     return y
 
 
+def guided_filter_module(x, y, radius, eps=1e-8):
+    """``GuidedFilter(radius, eps)(image=x, guide=y)`` as the reference CLASS behaves (guided_filter.py:111-146): it hands ``radius`` to BoxFilter as the kernel SIZE
+    (box_filter.py:163-172), so its windows are ``radius`` pixels wide = box radius int((radius - 1) / 2); radius 1 / 2 give the guide back (window of one pixel:
+    cov = 0, A = 0, b = y).  Found by the fixture tests/golden/guided_filter_seed161.npz; GCENet's gf_radius = 3 means 3x3 windows."""
+    rb = int((radius - 1) / 2)
+    if rb < 1:
+        _chk(x); _chk(y)
+        return y.clone(memory_format=CL)
+    return guided_filter(x, y, rb, eps)
+
+
 def guided_filter(x, y, radius, eps=1e-8):
-    """GuidedFilter(radius, eps)(image=x, guide=y) (guided_filter.py:99-147)."""
+    """The guided filter with (2 radius + 1)^2 windows (He et al.; the arithmetic of guided_filter.py:117-146 with a BoxFilter of that radius).  The reference's
+    GuidedFilter class does NOT use its ``radius`` this way: see ``guided_filter_module``."""
     _chk(x); _chk(y)
     n, cy, h, w = y.shape
     out = torch.empty_like(y, memory_format=CL)

@@ -1,7 +1,8 @@
 """Oracle (TEST INFRASTRUCTURE): CPU fp32 restatements of the filtering / colour-space side of the V-channel and guided curve
 models, in the reference's own operation order.
 
-  box_filter, guided_filter, fast_guided_filter   src/mon/vision/filtering/box_filter.py:24-110, guided_filter.py:99-204
+  box_filter, guided_filter, fast_guided_filter   src/mon/vision/filtering/box_filter.py:24-110, guided_filter.py:99-204; box_filter and the GuidedFilter class
+                                                   (guided_filter_module: its window is `radius` pixels WIDE) are PINNED by tests/golden/guided_filter_seed161.npz
   zero_dce_v_forward                               src/mon/vision/enhance/llie/zero_dce/zero_dce_v.py:172-230
   gcenet_forward                                   src/mon/vision/enhance/llie/gcenet/gcenet.py:203-309, 460-502
   boundary_aware_prior, brightness_attention_map   src/mon/nn/modules/prior/image.py:187-331
@@ -94,6 +95,8 @@ def _diff_y(image, r):
 
 
 def box_filter(x: torch.Tensor, r: int) -> torch.Tensor:
+    """box_filter.py:71-110 (sum over the (2r + 1)^2 window by two cumulative sums; r = 0 runs the same differences of cumulative sums and returns the tensor up to
+    their rounding).  PINNED by tests/golden/guided_filter_seed161.npz."""
     return _diff_y(_diff_x(x.cumsum(dim=2), r).cumsum(dim=3), r)
 
 
@@ -110,6 +113,14 @@ def _gf_coeffs(x, y, r, eps):
 def guided_filter(x: torch.Tensor, y: torch.Tensor, r: int, eps: float = 1e-8) -> torch.Tensor:
     a, b, n = _gf_coeffs(x, y, r, eps)
     return box_filter(a, r) / n * x + box_filter(b, r) / n
+
+
+def guided_filter_module(x: torch.Tensor, y: torch.Tensor, radius: int, eps: float = 1e-8) -> torch.Tensor:
+    """``GuidedFilter(radius, eps)(image=x, guide=y)`` AS THE REFERENCE CLASS BEHAVES (guided_filter.py:111-146): its constructor passes ``radius`` as BoxFilter's first
+    positional argument, which is ``kernel_size`` (box_filter.py:163-172), so the windows are ``radius`` pixels wide -- box radius int((radius - 1) / 2): GCENet's
+    ``gf_radius = 3`` (gcenet.py:355, 391) filters with 3x3 windows, and radius 1 or 2 degenerates to the guide itself (window 1: cov = 0, A = 0, b = y).
+    FastGuidedFilter passes ``radius=`` by keyword and gets what it asks for.  PINNED by tests/golden/guided_filter_seed161.npz (the class executed out of the file)."""
+    return guided_filter(x, y, int((radius - 1) / 2), eps)
 
 
 def fast_guided_filter(x_lr, y_lr, x_hr, r: int, eps: float = 1e-8) -> torch.Tensor:
@@ -181,5 +192,5 @@ def gcenet_forward(sd: dict, image: torch.Tensor, depth: torch.Tensor | None, nu
             bright = enhanced * (1 - bam)
             dark = enhanced * bam
             enhanced = bright + dark + adjust * (torch.pow(dark, 2) - dark)
-    enhanced = guided_filter(image, enhanced, gf_radius, gf_eps)
+    enhanced = guided_filter_module(image, enhanced, gf_radius, gf_eps)
     return {"adjust": adjust, "edge": edge, "bam": bam, "enhanced": enhanced}

@@ -541,6 +541,31 @@ def gen_lllinet():
           float(((y < 0) | (y > 1)).float().mean()))
 
 
+def gen_guided_filter():
+    """The box filter and the guided filter behind GCENet's last step (rank-4 widening): diff_x / diff_y / box_filter / BoxFilter of
+    src/mon/vision/filtering/box_filter.py:27-177 and class GuidedFilter of guided_filter.py:99-146 (the modules import cv2, plum and mon; these definitions are pure
+    torch) executed out of their files.  FastGuidedFilter's two forwards are plum-dispatched overloads and do not define without plum: not in the fixture."""
+    import torch.nn as nn
+    from torch.autograd import Variable
+    ns = _extract("src/mon/vision/filtering/box_filter.py", ["diff_x", "diff_y", "box_filter", "BoxFilter"], {"torch": torch, "nn": nn, "np": np})
+    gf = _extract("src/mon/vision/filtering/guided_filter.py", ["GuidedFilter"], {"torch": torch, "nn": nn, "Variable": Variable, "BoxFilter": ns["BoxFilter"]})["GuidedFilter"]
+    g = torch.Generator().manual_seed(161)
+    x = torch.rand(2, 3, 26, 34, generator=g)
+    x[1] = x[1] ** 2.2 * 0.3
+    y = (x * 1.7 + 0.05 * torch.randn(x.shape, generator=g)).clamp(0, 1.5)          # an "enhanced" frame: brighter, noisy
+    out = {"x": x.numpy(), "y": y.numpy()}
+    with torch.no_grad():
+        for r in (1, 3):
+            out[f"box_r{r}"] = ns["box_filter"](x, radius=r).numpy()
+        out["box_k5"] = ns["BoxFilter"](kernel_size=5)(y).numpy()
+        for r, eps in ((3, 1e-4), (1, 1e-2), (5, 1e-8)):
+            out[f"gf_r{r}_eps{eps:g}"] = gf(r, eps)(x, y).numpy()
+        out["gf_r3_gray_guide3"] = gf(3, 1e-4)(x[:, :1], y).numpy()                # a one-channel image against a three-channel guide (c_x == 1 branch)
+    path = os.path.join(HERE, "guided_filter_seed161.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB |", sorted(k for k in out if k not in ("x", "y")))
+
+
 def gen_upsampler():
     """The PixelShuffle up-sampler leaf of the BASELINE config-3 decoder variant: Upsampler(default_conv, scale, n_feats, act=...) of
     src/mon/nn/modules/encoder/edsr.py:88-123 -- a file that imports torch only, loaded as a module."""
@@ -561,7 +586,7 @@ def gen_upsampler():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["zero_dce", "zero_dcepp", "llunetpp", "hinet", "zero_ig", "unet", "rrdnet", "retinexnet", "ssim", "zero_dce_losses", "upsampler", "hvi", "lin", "mprnet", "lllinet"]
+    which = sys.argv[1:] or ["zero_dce", "zero_dcepp", "llunetpp", "hinet", "zero_ig", "unet", "rrdnet", "retinexnet", "ssim", "zero_dce_losses", "upsampler", "hvi", "lin", "mprnet", "lllinet", "guided_filter"]
     if "upsampler" in which:
         gen_upsampler()
     if "hvi" in which:
@@ -572,6 +597,8 @@ if __name__ == "__main__":
         gen_mprnet()
     if "lllinet" in which:
         gen_lllinet()
+    if "guided_filter" in which:
+        gen_guided_filter()
     if "retinexnet" in which:
         gen_retinexnet()
     if "ssim" in which:

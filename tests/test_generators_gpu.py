@@ -785,6 +785,21 @@ def test_mprnet_vs_oracle_and_patch_ops():
             assert rel_err(o16[k].cpu(), ref[k]) <= tol, (dt, k, rel_err(o16[k].cpu(), ref[k]))
 
 
+def test_guided_filter_reference_golden():
+    """ie_box_filter_nhwc_f32 / ie_guided_filter_nhwc_f32 against box_filter / BoxFilter / GuidedFilter of the reference's own files (tests/golden/guided_filter_*.npz):
+    the class's window is ``radius`` pixels wide (ops.guided_filter_module), radius 1 returns the guide."""
+    g = np.load(os.path.join(GOLDEN, "guided_filter_seed161.npz"))
+    x, y = ops.to_nhwc(torch.from_numpy(g["x"]).cuda()), ops.to_nhwc(torch.from_numpy(g["y"]).cuda())
+    for r in (1, 3):
+        assert rel_err(ops.to_nchw(ops.box_filter(x, r)).cpu(), g[f"box_r{r}"]) <= 1e-5
+    assert rel_err(ops.to_nchw(ops.box_filter(y, 2)).cpu(), g["box_k5"]) <= 1e-5
+    for r, eps, tol in ((3, 1e-4, 1e-4), (1, 1e-2, 1e-5), (5, 1e-8, 5e-3)):
+        got = ops.to_nchw(ops.guided_filter_module(x, y, r, eps)).cpu().numpy()
+        assert np.abs(got - g[f"gf_r{r}_eps{eps:g}"]).max() <= tol, (r, eps, float(np.abs(got - g[f"gf_r{r}_eps{eps:g}"]).max()))
+    x1 = ops.to_nhwc(torch.from_numpy(g["x"][:, :1].copy()).cuda())
+    assert np.abs(ops.to_nchw(ops.guided_filter_module(x1, y, 3, 1e-4)).cpu().numpy() - g["gf_r3_gray_guide3"]).max() <= 1e-4
+
+
 def test_lllinet_reference_blocks_golden():
     """The engine's LLLINet (``filters`` = the fixture's widths) against the reference's own UNetConvBlock / LearnableInstanceNorm2d / SimAM run on CPU
     (tests/golden/lllinet_w2_*.npz, grid order of lllinet.py:229-260): fp32 path."""

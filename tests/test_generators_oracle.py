@@ -320,3 +320,20 @@ def test_lllinet_restatement_matches_reference_blocks():
     assert np.abs(x0_0.numpy() - g["tap.x0_0"]).max() <= 1e-5
     x1_0 = og._lllinet_block(sd, "conv1_0", torch.nn.functional.max_pool2d(x0_0, 2, 2))
     assert np.abs(x1_0.numpy() - g["tap.x1_0"]).max() <= 1e-5
+
+
+def test_guided_filter_restatement_matches_reference():
+    """oracle.filters.box_filter / guided_filter against box_filter / BoxFilter (src/mon/vision/filtering/box_filter.py:27-177) and GuidedFilter
+    (guided_filter.py:99-146) executed out of their files: radii 1 / 3 / 5, eps 1e-2 .. 1e-8, three- and one-channel image against a three-channel guide."""
+    from oracle import filters as of
+    g = np.load(os.path.join(GOLDEN, "guided_filter_seed161.npz"))
+    x, y = torch.from_numpy(g["x"]), torch.from_numpy(g["y"])
+    for r in (1, 3):
+        assert np.abs(of.box_filter(x, r).numpy() - g[f"box_r{r}"]).max() <= 1e-5
+    assert np.abs(of.box_filter(y, 2).numpy() - g["box_k5"]).max() <= 1e-5
+    # The class hands ``radius`` to BoxFilter as its kernel SIZE (guided_filter.py:115, box_filter.py:163-172): GuidedFilter(3) averages 3x3 windows, GuidedFilter(1)
+    # returns the guide.  The fixture caught the restatement (and the engine's GCENet) filtering with 7x7 windows for gf_radius = 3.
+    for r, eps, tol in ((3, 1e-4, 1e-5), (1, 1e-2, 1e-6), (5, 1e-8, 1e-3)):       # (eps 1e-8: A = cov / (var + eps) amplifies rounding where the window is flat)
+        assert np.abs(of.guided_filter_module(x, y, r, eps).numpy() - g[f"gf_r{r}_eps{eps:g}"]).max() <= tol, (r, eps)
+    assert np.abs(of.guided_filter_module(x[:, :1], y, 3, 1e-4).numpy() - g["gf_r3_gray_guide3"]).max() <= 1e-5
+    assert np.abs(of.guided_filter(x, y, 3, 1e-4).numpy() - g["gf_r3_eps0.0001"]).max() > 1e-2 and np.abs(g["gf_r1_eps0.01"] - g["y"]).max() <= 1e-5
