@@ -12,7 +12,8 @@ ssim / ssim_loss / gauss_1d are PINNED (round 4) by tests/golden/ssim_*.npz: met
 level, so tests/golden/make_golden.py takes custom_ssim / _custom_ssim / _gaussian_filter / _fspecial_gauss_1d out of its syntax tree by name and
 executes them unmodified.  The four zero-reference terms below are pinned the same way by tests/golden/zdce_losses_*.npz against L_TV / L_spa /
 L_color / L_exp of the original repository's myloss.py (src/mon_extra/vision/enhance/llie/zero_dce/myloss.py; mon's TotalVariationLoss, which is what
-this file restates, additionally divides by the channel count).
+this file restates, additionally divides by the channel count) AND by tests/golden/zdce_loss_mon_*.npz against mon's own classes: Loss of zero_dce.py:32-79
+over ColorConstancyLoss / ExposureControlLoss / SpatialConsistencyLoss / TotalVariationLoss of nn/loss/image.py, executed out of their files (terms and composite).
 parity unpinned: the training harness itself (lightning is not installed); its leaf arithmetic is torch's own (F.batch_norm, autograd,
 torch.optim.Adam, clip_grad_norm_).
 """

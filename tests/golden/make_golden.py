@@ -566,6 +566,53 @@ def gen_guided_filter():
     print("wrote", path, os.path.getsize(path) // 1024, "KiB |", sorted(k for k in out if k not in ("x", "y")))
 
 
+def gen_mon_zero_dce_loss():
+    """mon's OWN zero-reference loss: class Loss of src/mon/vision/enhance/llie/zero_dce/zero_dce.py:32-79 with the four classes it is made of -- ColorConstancyLoss,
+    ExposureControlLoss, SpatialConsistencyLoss, TotalVariationLoss (src/mon/nn/loss/image.py:191-217, 534-568, 904-1270, 1355-1392) -- on their base class and
+    reduce_loss (nn/loss/base.py:61-117), registered in the reference's own registry class (core/factory.py:26-133, ``LOSSES = Factory("Losses")`` as mon/globals.py builds
+    it; with explicit names it never reaches its humps calls).  Every definition is executed out of its file; ``nn.`` resolves to torch.nn's public names plus these
+    classes, ``base.`` to the two definitions of loss/base.py.  Inputs: the reference network's outputs on the frame of zdce_losses_seed5 (gen_zero_dce_losses)."""
+    import copy, inspect, types
+    from abc import ABC, abstractmethod
+    from typing import Any, Literal
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from torch.nn.common_types import _size_2_t
+    from torch.nn.modules.loss import _Loss
+    Factory = _extract("src/mon/core/factory.py", ["Factory"], {"copy": copy, "inspect": inspect, "Any": Any})["Factory"]
+    LOSSES = Factory("Losses")
+    b = _extract("src/mon/nn/loss/base.py", ["reduce_loss", "Loss"], {"torch": torch, "nn": nn, "F": F, "_Loss": _Loss, "ABC": ABC, "abstractmethod": abstractmethod, "Literal": Literal})
+    base = types.SimpleNamespace(reduce_loss=b["reduce_loss"], Loss=b["Loss"])
+    names = ["ColorConstancyLoss", "ExposureControlLoss", "SpatialConsistencyLoss", "TotalVariationLoss"]
+    li = _extract("src/mon/nn/loss/image.py", names, {"torch": torch, "nn": nn, "F": F, "Literal": Literal, "_size_2_t": _size_2_t, "base": base, "LOSSES": LOSSES})
+    assert sorted(LOSSES) == ["color_constancy_loss", "exposure_control_loss", "spatial_consistency_loss", "total_variation_loss", "tv_loss"]
+    mon_nn = types.SimpleNamespace(**{k: getattr(nn, k) for k in dir(nn) if not k.startswith("_")}, Loss=base.Loss, **{k: li[k] for k in names})
+    ZLoss = _extract("src/mon/vision/enhance/llie/zero_dce/zero_dce.py", ["Loss"], {"torch": torch, "nn": mon_nn, "Literal": Literal})["Loss"]
+    mod = _load("src/mon_extra/vision/enhance/llie/zero_dce/model.py", "ref_zero_dce_for_mon_losses")
+    sd = o_zdce.init_state_dict(seed=5, gain=3.0)
+    net = mod.enhance_net_nopool()
+    net.load_state_dict(sd, strict=True)
+    net.eval()
+    x = torch.rand(2, 3, 64, 80, generator=torch.Generator().manual_seed(101)) ** 2.2 * 0.5       # (the frame of zdce_losses_seed5)
+    out = {"image": x.numpy(), "seed": np.array(5), "gain": np.array(3.0)}
+    with torch.no_grad():
+        _, enhanced, A = net(x)
+        loss = ZLoss()
+        out["total"] = np.array(float(loss(input=x, adjust=A, enhance=enhanced)))
+        out["spa"], out["exp"] = np.array(float(loss.loss_spa(input=enhanced, target=x))), np.array(float(loss.loss_exp(input=enhanced)))
+        out["col"], out["tva"] = np.array(float(loss.loss_col(input=enhanced))), np.array(float(loss.loss_tva(input=A)))
+        out["weights"] = np.array([loss.spa_weight, loss.exp_weight, loss.col_weight, loss.tva_weight])
+        # other constructor arguments: a coarser exposure grid and target, the 8-region spatial term, reduction "sum"
+        out["exp_p8_e05"] = np.array(float(li["ExposureControlLoss"](patch_size=8, mean_val=0.5)(input=enhanced)))
+        out["spa_r8"] = np.array(float(li["SpatialConsistencyLoss"](num_regions=8)(input=enhanced, target=x)))
+        out["spa_sum"] = np.array(float(li["SpatialConsistencyLoss"](reduction="sum")(input=enhanced, target=x)))
+        out["col_none"] = li["ColorConstancyLoss"](reduction="none")(input=enhanced).numpy()
+        out["tva_w3"] = np.array(float(li["TotalVariationLoss"](loss_weight=3.0)(input=A)))
+    path = os.path.join(HERE, "zdce_loss_mon_seed5_2x64x80.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB |", {k: float(out[k]) for k in ("total", "spa", "exp", "col", "tva")})
+
+
 def gen_upsampler():
     """The PixelShuffle up-sampler leaf of the BASELINE config-3 decoder variant: Upsampler(default_conv, scale, n_feats, act=...) of
     src/mon/nn/modules/encoder/edsr.py:88-123 -- a file that imports torch only, loaded as a module."""
@@ -586,7 +633,7 @@ def gen_upsampler():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["zero_dce", "zero_dcepp", "llunetpp", "hinet", "zero_ig", "unet", "rrdnet", "retinexnet", "ssim", "zero_dce_losses", "upsampler", "hvi", "lin", "mprnet", "lllinet", "guided_filter"]
+    which = sys.argv[1:] or ["zero_dce", "zero_dcepp", "llunetpp", "hinet", "zero_ig", "unet", "rrdnet", "retinexnet", "ssim", "zero_dce_losses", "upsampler", "hvi", "lin", "mprnet", "lllinet", "guided_filter", "mon_zero_dce_loss"]
     if "upsampler" in which:
         gen_upsampler()
     if "hvi" in which:
@@ -599,6 +646,8 @@ if __name__ == "__main__":
         gen_lllinet()
     if "guided_filter" in which:
         gen_guided_filter()
+    if "mon_zero_dce_loss" in which:
+        gen_mon_zero_dce_loss()
     if "retinexnet" in which:
         gen_retinexnet()
     if "ssim" in which:

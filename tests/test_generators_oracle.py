@@ -337,3 +337,25 @@ def test_guided_filter_restatement_matches_reference():
         assert np.abs(of.guided_filter_module(x, y, r, eps).numpy() - g[f"gf_r{r}_eps{eps:g}"]).max() <= tol, (r, eps)
     assert np.abs(of.guided_filter_module(x[:, :1], y, 3, 1e-4).numpy() - g["gf_r3_gray_guide3"]).max() <= 1e-5
     assert np.abs(of.guided_filter(x, y, 3, 1e-4).numpy() - g["gf_r3_eps0.0001"]).max() > 1e-2 and np.abs(g["gf_r1_eps0.01"] - g["y"]).max() <= 1e-5
+
+
+def test_zero_dce_loss_restatement_matches_mon_classes():
+    """oracle.train's zero-reference terms and composite against mon's OWN classes: Loss of zero_dce.py:32-79 over ColorConstancyLoss / ExposureControlLoss /
+    SpatialConsistencyLoss / TotalVariationLoss (nn/loss/image.py) on nn/loss/base.py's Loss, all executed out of their files (make_golden.gen_mon_zero_dce_loss)."""
+    from oracle import train as otr
+    from oracle import zero_dce as o_zdce
+    g = np.load(os.path.join(GOLDEN, "zdce_loss_mon_seed5_2x64x80.npz"))
+    sd = o_zdce.init_state_dict(seed=int(g["seed"]), gain=float(g["gain"]))
+    x = torch.from_numpy(g["image"])
+    out = o_zdce.forward(sd, x)
+    enh, adj = out["enhanced"], out["adjust"]
+    rel = lambda got, key: abs(float(got) - float(g[key])) <= 2e-5 * abs(float(g[key])) + 1e-10
+    assert rel(otr.spatial_consistency_loss(enh, x), "spa") and rel(otr.exposure_control_loss(enh, 16, 0.6), "exp")
+    assert rel(otr.color_constancy_loss(enh), "col") and rel(otr.total_variation_loss(adj), "tva")
+    assert list(g["weights"]) == [1.0, 10.0, 5.0, 200.0] and rel(otr.zero_dce_loss(x, adj, enh), "total")
+    assert rel(otr.exposure_control_loss(enh, 8, 0.5), "exp_p8_e05") and rel(3.0 * otr.total_variation_loss(adj), "tva_w3")
+    assert rel(otr.spatial_consistency_loss(enh, x) * (2 * 16 * 20), "spa_sum")          # reduction "sum": the 16 x 20 pooled map of both frames
+    m = enh.mean((2, 3), keepdim=True)
+    mr, mg, mb = torch.split(m, 1, dim=1)
+    want = torch.pow(((mr - mg) ** 2) ** 2 + ((mr - mb) ** 2) ** 2 + ((mb - mg) ** 2) ** 2, 0.5)
+    assert np.abs(want.numpy() - g["col_none"]).max() <= 1e-9

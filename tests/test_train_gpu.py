@@ -88,6 +88,14 @@ def test_ssim_and_zero_dce_losses_reference_goldens():
     assert abs(t["spa"] - float(g["L_spa"])) <= 1e-4 * float(g["L_spa"]) + 1e-9
     assert abs(t["col"] - float(g["L_color"])) <= 1e-4 * float(g["L_color"]) + 1e-9
     assert abs(t["exp"] - float(g["L_exp"])) <= 1e-4 * float(g["L_exp"])
+    # ... and against mon's own classes (zdce_loss_mon_*.npz: Loss of zero_dce.py:32-79 and the four nn/loss/image.py classes executed out of their files), the composite too
+    gm = np.load(os.path.join(GOLDEN, "zdce_loss_mon_seed5_2x64x80.npz"))
+    assert np.array_equal(gm["image"], g["image"])
+    total = float(loss(x, out["adjust"].contiguous(memory_format=CL), out["enhanced"]))
+    t = loss.last_terms
+    for k in ("spa", "exp", "col", "tva"):
+        assert abs(t[k] - float(gm[k])) <= 1e-4 * abs(float(gm[k])) + 1e-9, (k, t[k], float(gm[k]))
+    assert abs(total - float(gm["total"])) <= 1e-4 * float(gm["total"])
 
 
 def test_ssim_non_negative_masks_gradient():
