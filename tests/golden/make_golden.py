@@ -319,6 +319,23 @@ def gen_ssim():
         spc, cs = ns["_custom_ssim"](x, y, data_range=1.0, window=win, size_average=False)
         out[f"{name}.ssim_per_channel"], out[f"{name}.cs_per_channel"] = spc.numpy(), cs.numpy()
     out["window"] = ns["_fspecial_gauss_1d"](11, 1.5).numpy()
+    # the two CLASSES BASELINE config 5's loss is made of: CustomSSIM (metric/image.py:316-346, what SSIMLoss.forward calls: loss = 1 - ssim) and L1Loss on its base class
+    # (nn/loss/base.py:61-117, 164-178; registered through the reference's Factory, core/factory.py:26-133)
+    import copy, inspect, types
+    from abc import ABC, abstractmethod
+    from typing import Any, Literal
+    import torch.nn as nn
+    from torch.nn.modules.loss import _Loss
+    ns["nn"] = nn
+    cls = _extract("src/mon/nn/metric/image.py", ["CustomSSIM"], ns)["CustomSSIM"]
+    Factory = _extract("src/mon/core/factory.py", ["Factory"], {"copy": copy, "inspect": inspect, "Any": Any})["Factory"]
+    b = _extract("src/mon/nn/loss/base.py", ["reduce_loss", "Loss", "L1Loss"], {"torch": torch, "nn": nn, "F": F, "_Loss": _Loss, "ABC": ABC, "abstractmethod": abstractmethod,
+                                                                                "Literal": Literal, "LOSSES": Factory("Losses")})
+    for name, (x, y) in pairs.items():
+        out[f"{name}.class.dr1"] = np.array(float(cls(data_range=1.0)(x, y)))
+        out[f"{name}.class.dr255.nn1"] = np.array(float(cls(non_negative_ssim=True)(x, y)))
+        out[f"{name}.l1.mean"], out[f"{name}.l1.sum"] = np.array(float(b["L1Loss"]()(x, y))), np.array(float(b["L1Loss"](reduction="sum")(x, y)))
+        out[f"{name}.l1.w05"] = np.array(float(b["L1Loss"](loss_weight=0.5)(x, y)))
     path = os.path.join(HERE, "ssim_seed91_2x40x56.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB |", {k: float(v) for k, v in out.items() if k.endswith("dr1.nn0.mean")})

@@ -232,6 +232,13 @@ def test_ssim_restatement_matches_reference():
                 per = g[f"{name}.dr{int(dr)}.nn{int(nn_)}.per_image"]
                 for i in range(x.shape[0]):
                     assert abs(float(otr.ssim(x[i:i + 1], y[i:i + 1], data_range=dr, non_negative=nn_)) - float(per[i])) <= 2e-6 * max(1.0, abs(float(per[i])))
+        # the classes the loss is built from: CustomSSIM (metric/image.py:316-346) and L1Loss (nn/loss/base.py:164-178), executed out of their files
+        assert abs(float(otr.ssim(x, y, data_range=1.0)) - float(g[f"{name}.class.dr1"])) <= 2e-6 and float(g[f"{name}.class.dr1"]) == float(g[f"{name}.dr1.nn0.mean"])
+        assert abs(float(otr.ssim(x, y, data_range=255.0, non_negative=True)) - float(g[f"{name}.class.dr255.nn1"])) <= 2e-6
+        assert abs(float(otr.l1_loss(x, y)) - float(g[f"{name}.l1.mean"])) <= 1e-7 and abs(float(otr.l1_loss(x, y, 0.5)) - float(g[f"{name}.l1.w05"])) <= 1e-7
+        assert abs(float((x - y).abs().sum()) - float(g[f"{name}.l1.sum"])) <= 1e-5 * float(g[f"{name}.l1.sum"])
+        want = float(g[f"{name}.l1.mean"]) + 1.0 - float(g[f"{name}.class.dr1"])
+        assert abs(float(otr.l1_ssim_loss(x, y, 1.0, 1.0, 1.0)) - want) <= 3e-6
 
 
 def test_zero_dce_loss_restatement_matches_reference():

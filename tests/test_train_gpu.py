@@ -76,6 +76,11 @@ def test_ssim_and_zero_dce_losses_reference_goldens():
                 want = 1.0 - float(g[f"{name}.dr{int(dr)}.nn{int(nn_)}.mean"])
                 got = float(losses.SSIMLoss(data_range=dr, non_negative_ssim=nn_)(x, y))
                 assert abs(got - want) <= 2e-5, (name, dr, nn_, got, want)
+        # the classes of BASELINE config 5's loss (CustomSSIM, metric/image.py:316-346; L1Loss, nn/loss/base.py:164-178) executed out of their files
+        assert abs(float(losses.L1Loss()(x, y)) - float(g[f"{name}.l1.mean"])) <= 1e-6 and abs(float(losses.L1Loss(loss_weight=0.5)(x, y)) - float(g[f"{name}.l1.w05"])) <= 1e-6
+        assert abs(float(losses.L1Loss(reduction="sum")(x, y)) - float(g[f"{name}.l1.sum"])) <= 1e-5 * float(g[f"{name}.l1.sum"])
+        want = float(g[f"{name}.l1.mean"]) + 1.0 - float(g[f"{name}.class.dr1"])
+        assert abs(float(losses.L1SSIMLoss(data_range=1.0)(x, y)) - want) <= 3e-5
     g = np.load(os.path.join(GOLDEN, "zdce_losses_seed5_2x64x80.npz"))
     sd = {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("w.")}
     m = mon_amd.MODELS.build(name="zero_dce_re", weights=dict(sd), compute_dtype="f32").to("cuda").eval()
