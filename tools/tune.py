@@ -44,6 +44,8 @@ def run(rb, band, group, reps=3):
 CFGS = [(0, 0, 0), (135, 0, 8), (270, 0, 8), (540, 0, 8), (1080, 0, 8), (270, 0, 16), (540, 0, 16), (1080, 0, 16), (270, 0, 4), (135, 0, 4), (540, 0, 32), (1080, 0, 32)]
 if len(sys.argv) > 3 and sys.argv[3] == "bands":       # row bands small enough for the intermediates of a band to stay in the 256 MB Infinity Cache
     CFGS = [(0, 0, 0), (0, 540, 8), (0, 270, 8), (0, 128, 8), (0, 64, 8), (0, 270, 4), (0, 128, 4), (0, 270, 16), (0, 128, 16), (64, 128, 8), (32, 64, 8)]
+if len(sys.argv) > 3 and sys.argv[3] == "mall":        # small frame groups / row bands: do x2 / x5 of one job survive in the Infinity Cache between the kernels? (the schedule is power-capped)
+    CFGS = [(0, 0, 0), (0, 0, 2), (0, 0, 4), (0, 0, 8), (0, 0, 0), (0, 270, 16), (0, 136, 16), (0, 68, 16), (0, 0, 0), (0, 540, 4), (0, 270, 8), (0, 540, 8)]
 for cfg in CFGS:
     if cfg[2] > N:
         continue
