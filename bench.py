@@ -232,7 +232,7 @@ def run_generator_workload(args, ctx):
         pass
     cpu_baseline = parity = None
     if world == 1 and not args.no_cpu_baseline:
-        ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        ncpu = _usable_cpus()
         torch.set_num_threads(max(1, ncpu))
         from oracle import generators as o_gen
         if train:
@@ -305,6 +305,53 @@ def _cpu_model():
     return "unknown"
 
 
+
+def _usable_cpus() -> int:
+    """Host cores this process may actually use: the affinity mask, cut to the cgroup's CPU quota (a 1-GPU box of the pool shows 256 CPUs in the mask and a quota of 16:
+    256 worker threads on 16 cores' worth of time ran the CPU baseline five times slower than 16 threads)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except Exception:       # noqa: BLE001
+        pass
+    return max(1, n)
+
+
+def _board_state(enqueue_step, step_ms: float, device_index: int = 0):
+    """Socket power, power cap and shader clock WHILE the workload runs: ~1.5 s of extra, untimed steps are enqueued, a read-only `rocm-smi` poll runs beside them
+    0.6 s in, then the stream is drained.  The Zero-DCE schedule sits at the board's power cap (finding 16): the clock the chip holds there, not the
+    pipe cycles a kernel needs, sets its MFMA rate -- the line a reader needs next to `roofline.frac`.  None when rocm-smi is absent or fails; never raises."""
+    import re
+    import shutil
+    import subprocess
+    import time
+    import torch
+    try:
+        if shutil.which("rocm-smi") is None:
+            return None
+        k = max(20, min(400, int(1500.0 / max(step_ms, 0.1))))
+        for _ in range(k):
+            enqueue_step()
+        time.sleep(0.6)
+        out = subprocess.run(["rocm-smi", "-d", str(device_index), "--showpower", "--showclocks", "--showmaxpower"], capture_output=True, text=True, timeout=20).stdout
+        torch.cuda.synchronize()
+        pw = re.search(r"Current Socket Graphics Package Power \(W\): ([\d.]+)", out) or re.search(r"Average Graphics Package Power \(W\): ([\d.]+)", out)
+        cap = re.search(r"Max Graphics Package Power \(W\): ([\d.]+)", out)
+        sclk = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", out)
+        if not (pw and sclk):
+            return None
+        return {"socket_power_W": float(pw.group(1)), "power_cap_W": float(cap.group(1)) if cap else None, "sclk_MHz": int(sclk.group(1)),
+                "how": f"rocm-smi polled 0.6 s into {k} extra untimed steps"}
+    except Exception as e:       # noqa: BLE001
+        print(f"[bench] board probe skipped: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+        try:
+            torch.cuda.synchronize()
+        except Exception:   # noqa: BLE001
+            pass
+        return None
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -319,6 +366,7 @@ def main():
     ap.add_argument("--output", default="f32", choices=["f32", "u8"], help="enhanced as fp32 NCHW or uint8 NHWC")
     ap.add_argument("--variant", type=int, default=0, help="kernel variant bitmask (capi.VAR_*), A-B runs only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-board", action="store_true", help="skip the rocm-smi poll (socket power / sclk while the workload runs)")
     ap.add_argument("--no-extras", action="store_true", help="skip the short side measurements of the other BASELINE configs")
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
@@ -463,6 +511,8 @@ def main():
         roofline["model_bytes_per_px"] = sum(KERNEL_WORK[k][1] for k in layer_ms)
         roofline["kernel_mfma_tflops"] = {k: round(KERNEL_WORK[k][0] * n * H * W / (v * 1e-3) / 1e12, 1) for k, v in layer_ms.items() if v > 0}
         roofline["model_mfma_frac"] = round(value / world * H * W * FLOP_PER_PX / (PEAK_MFMA_TFLOPS * 1e12), 4)
+        if world == 1 and not args.no_board:
+            roofline["board"] = _board_state(lambda: model.enhance(x, **kw), ms_per_step, torch.cuda.current_device())
 
         # The GPU side of the parity check runs here; the CPU legs (oracle timing + parity) run AFTER the side measurements: the
         # 64 CPU worker threads of the oracle slowed the launch-bound U-Net forward that followed them by a quarter.
@@ -565,8 +615,8 @@ def main():
 
         # ---- CPU baseline (oracle, "port") + parity of this very configuration on one frame ----------------------------------
         if world == 1 and not args.no_cpu_baseline:
-            ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-            torch.set_num_threads(max(1, ncpu))             # every host core this process may use; `cores` reports the number
+            ncpu = _usable_cpus()
+            torch.set_num_threads(max(1, ncpu))             # every host core this process may use (affinity mask cut to the cgroup quota); `cores` reports the number
             def cpu_rate(batch):
                 with torch.no_grad():
                     o_zdce.forward(sd, batch)               # warm-up
