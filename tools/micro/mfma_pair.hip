@@ -5,7 +5,7 @@
 //   pair 0  waves 0-3 stream, waves 4-7 idle            pair 1  all stream, no barrier
 //   pair 2  all stream, one s_barrier per step          pair 3  as 2, waves 4-7 half a step behind (their barrier sits between their two rows)
 //   form 0  the kernels' pinned form, fragments read AHEAD = 3 ahead       form 1  AHEAD = 6        form 2  all 12 fragments of a row read up front
-//   form 3  register-only (no LDS reads: the same fragment registers every time)
+//   form 3  register-only (no LDS reads: the same fragment registers every time)        forms 4-8: see mfma_row / mfma_row_acc / mfma_row_both
 //   chores  0 none   1 stage A ends its step with a latency-bound tail (LDS read -> pack -> 4 ds_write_b128 -> 6 LDS-DMA pieces), stage B opens its step with
 //           a 96-operation transcendental burst -- the shape of K67X
 // Build: hipcc --offload-arch=gfx950 -O3 -Wno-unused-value [-DUSE_BF16] [-DRELU_DATA] mfma_pair.hip -o mfma_pair     (RELU_DATA: half of the LDS values zero, as behind a ReLU)
@@ -69,6 +69,29 @@ __device__ __forceinline__ void mfma_row(const char* slot, const int (&base)[3],
         accO[j] = mfma<FORM>(wv[2 * 3 + kx], bx[g], accO[j]);
         if constexpr (LAG > 0) { if (g >= LAG) asm volatile("" ::"v"(bx[g - LAG])); }
         SB();
+    }
+}
+
+// form 8: a wave that owns BOTH 16-cout fragments of its layer over a quarter of the strip (2 pixel tiles instead of 4): every fragment feeds 6 MFMAs instead of 3, so a
+// row's 36 MFMAs need 6 ds_read_b128 instead of 12 (the price in a real kernel: 18 more weight fragments = 72 VGPRs).  Same accumulators (12), same MFMA count.
+__device__ __forceinline__ void mfma_row_both(const char* slot, const int (&base)[3], const u32x4* wv, f32x4 (&accN)[4], f32x4 (&accM)[4], f32x4 (&accO)[4], bool first,
+                                              const f32x4& init) {
+    u32x4 bx[6];
+    const char* bk[3] = {slot + base[0], slot + base[1], slot + base[2]};
+    auto rd = [&](int g) __attribute__((always_inline)) { bx[g] = *(const u32x4*)(bk[g >> 1] + 1024 * (g & 1)); };
+    rd(0); rd(1);
+    SB();
+#pragma unroll
+    for (int g = 0; g < 6; ++g) {
+        const int kx = g >> 1, j = g & 1;       // accumulator j: cout fragment 0, j + 2: cout fragment 1
+        accN[j] = mfma<0>(wv[0 * 3 + kx], bx[g], (first && kx == 0) ? init : accN[j]);
+        if (g + 2 < 6) rd(g + 2);
+        SB();
+        accM[j] = mfma<0>(wv[1 * 3 + kx], bx[g], accM[j]); SB();
+        accO[j] = mfma<0>(wv[2 * 3 + kx], bx[g], accO[j]); SB();
+        accN[j + 2] = mfma<0>(wv[9 + 0 * 3 + kx], bx[g], (first && kx == 0) ? init : accN[j + 2]); SB();
+        accM[j + 2] = mfma<0>(wv[9 + 1 * 3 + kx], bx[g], accM[j + 2]); SB();
+        accO[j + 2] = mfma<0>(wv[9 + 2 * 3 + kx], bx[g], accO[j + 2]); SB();
     }
 }
 
@@ -170,7 +193,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 SB();
             }
         };
-#define ROW(r, w, n, m, o, f) do { if constexpr (FORM == 7) mfma_row_acc(r, base, wv, n, m, o, f, bias);       /* (one row's nine weight fragments for both rows: the unified file splits 128 + 128 here) */ else mfma_row<FORM>(r, base, w, n, m, o, f, bias, keep); } while (0)
+#define ROW(r, w, n, m, o, f) do { if constexpr (FORM == 8) mfma_row_both(r, base, wv, n, m, o, f, bias); else if constexpr (FORM == 7) mfma_row_acc(r, base, wv, n, m, o, f, bias);       /* (one row's nine weight fragments for both rows: the unified file splits 128 + 128 here) */ else mfma_row<FORM>(r, base, w, n, m, o, f, bias, keep); } while (0)
         auto step = [&](int t, f32x4 (&aN)[4], f32x4 (&aM)[4], f32x4 (&aO)[4], f32x4 (&pN)[4], f32x4 (&pM)[4], f32x4 (&pO)[4]) __attribute__((always_inline)) {
             const char* r0 = smem + ((2 * t) % NR) * ROWH_B;
             const char* r1 = smem + ((2 * t + 1) % NR) * ROWH_B;
@@ -266,6 +289,9 @@ int main() {
     run<2, 6, 0>("two waves, registers rest 2 groups + mid read, barrier", d, dc, src);
     run<0, 7, 0>("one wave, 3 ahead, fragments in AccVGPRs", d, dc, src);
     run<2, 7, 0>("two waves, fragments in AccVGPRs, barrier", d, dc, src);
+    run<0, 8, 0>("one wave, both cout fragments: a fragment feeds 6 MFMAs", d, dc, src);
+    run<2, 8, 0>("two waves, both cout fragments (6 reads per row), barrier", d, dc, src);
+    run<2, 8, 1>("K67X shape with both cout fragments per wave", d, dc, src);
     run<2, 0, 1>("K67X shape: A tail chores, B head burst; barrier per step", d, dc, src);
     run<3, 0, 1>("K67X shape, waves 4-7 half a step behind", d, dc, src);
     run<2, 3, 1>("K67X shape, register-only fragments", d, dc, src);
