@@ -319,15 +319,24 @@ def _usable_cpus() -> int:
     return max(1, n)
 
 
-def _board_state(enqueue_step, step_ms: float, device_index: int = 0):
-    """Socket power, power cap and shader clock WHILE the workload runs: ~1.5 s of extra, untimed steps are enqueued, a read-only `rocm-smi` poll runs beside them
-    0.6 s in, then the stream is drained.  The Zero-DCE schedule sits at the board's power cap (finding 16): the clock the chip holds there, not the
-    pipe cycles a kernel needs, sets its MFMA rate -- the line a reader needs next to `roofline.frac`.  None when rocm-smi is absent or fails; never raises."""
+def _parse_rocm_smi(text: str):
+    """{socket_power_W, power_cap_W, sclk_MHz} out of `rocm-smi --showpower --showclocks --showmaxpower` text (None when power or sclk is missing)."""
     import re
+    pw = re.search(r"Current Socket Graphics Package Power \(W\): ([\d.]+)", text) or re.search(r"Average Graphics Package Power \(W\): ([\d.]+)", text)
+    cap = re.search(r"Max Graphics Package Power \(W\): ([\d.]+)", text)
+    sclk = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", text)
+    if not (pw and sclk):
+        return None
+    return {"socket_power_W": float(pw.group(1)), "power_cap_W": float(cap.group(1)) if cap else None, "sclk_MHz": int(sclk.group(1))}
+
+
+def _board_state(enqueue_step, drain, step_ms: float, device_index: int = 0):
+    """Socket power, power cap and shader clock WHILE the workload runs: ~1.5 s of extra, untimed steps are enqueued, a read-only `rocm-smi` poll runs beside them
+    0.6 s in, then the stream is drained (`drain`).  The Zero-DCE schedule sits at the board's power cap (finding 16): the clock the chip holds there, not the
+    pipe cycles a kernel needs, sets its MFMA rate -- the line a reader needs next to `roofline.frac`.  None when rocm-smi is absent or fails; never raises."""
     import shutil
     import subprocess
     import time
-    import torch
     try:
         if shutil.which("rocm-smi") is None:
             return None
@@ -336,18 +345,16 @@ def _board_state(enqueue_step, step_ms: float, device_index: int = 0):
             enqueue_step()
         time.sleep(0.6)
         out = subprocess.run(["rocm-smi", "-d", str(device_index), "--showpower", "--showclocks", "--showmaxpower"], capture_output=True, text=True, timeout=20).stdout
-        torch.cuda.synchronize()
-        pw = re.search(r"Current Socket Graphics Package Power \(W\): ([\d.]+)", out) or re.search(r"Average Graphics Package Power \(W\): ([\d.]+)", out)
-        cap = re.search(r"Max Graphics Package Power \(W\): ([\d.]+)", out)
-        sclk = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", out)
-        if not (pw and sclk):
+        drain()
+        st = _parse_rocm_smi(out)
+        if st is None:
             return None
-        return {"socket_power_W": float(pw.group(1)), "power_cap_W": float(cap.group(1)) if cap else None, "sclk_MHz": int(sclk.group(1)),
-                "how": f"rocm-smi polled 0.6 s into {k} extra untimed steps"}
+        st["how"] = f"rocm-smi polled 0.6 s into {k} extra untimed steps"
+        return st
     except Exception as e:       # noqa: BLE001
         print(f"[bench] board probe skipped: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
         try:
-            torch.cuda.synchronize()
+            drain()
         except Exception:   # noqa: BLE001
             pass
         return None
@@ -512,7 +519,7 @@ def main():
         roofline["kernel_mfma_tflops"] = {k: round(KERNEL_WORK[k][0] * n * H * W / (v * 1e-3) / 1e12, 1) for k, v in layer_ms.items() if v > 0}
         roofline["model_mfma_frac"] = round(value / world * H * W * FLOP_PER_PX / (PEAK_MFMA_TFLOPS * 1e12), 4)
         if world == 1 and not args.no_board:
-            roofline["board"] = _board_state(lambda: model.enhance(x, **kw), ms_per_step, torch.cuda.current_device())
+            roofline["board"] = _board_state(lambda: model.enhance(x, **kw), torch.cuda.synchronize, ms_per_step, torch.cuda.current_device())
 
         # The GPU side of the parity check runs here; the CPU legs (oracle timing + parity) run AFTER the side measurements: the
         # 64 CPU worker threads of the oracle slowed the launch-bound U-Net forward that followed them by a quarter.

@@ -90,3 +90,9 @@ def test_bench_gpus_n_starts_n_ranks_command():
     assert cmd[cmd.index("--master-port") + 2].endswith("bench.py")
     src = open(os.path.join(root, "bench.py")).read()
     assert src.index("_spawn_ranks(args.gpus)") < src.index("import torch\n")      # spawn happens before torch / HIP is touched
+    # the board probe's text parser and the CPU-baseline thread count (affinity mask cut to the cgroup quota)
+    t = "GPU[0]\t\t: sclk clock level: 1: (1828Mhz)\nGPU[0]\t\t: Max Graphics Package Power (W): 1400.0\nGPU[0]\t\t: Current Socket Graphics Package Power (W): 1399.0\n"
+    assert b._parse_rocm_smi(t) == {"socket_power_W": 1399.0, "power_cap_W": 1400.0, "sclk_MHz": 1828} and b._parse_rocm_smi("no such tool") is None
+    assert 1 <= b._usable_cpus() <= (os.cpu_count() or 1)
+    calls = []
+    assert b._board_state(lambda: calls.append(1), lambda: calls.append("drained"), 1e9) is None or calls       # no rocm-smi here (or a real one): never raises
