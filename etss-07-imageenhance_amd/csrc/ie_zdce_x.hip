@@ -187,6 +187,37 @@ __device__ __forceinline__ void mfma_row(const char* slot, const RowRead& rr, co
     }
 }
 
+// The same row for a wave that owns BOTH 16-row tiles of its layer over a quarter of the strip (2 pixel tiles): every fragment feeds SIX MFMAs, a row's 36 MFMAs need 6
+// ds_read_b128 instead of 12 (tools/micro/mfma_pair.hip form 8: -4 % wall time per MFMA at the power cap).  acc index = 2 * tile + j.
+#ifndef IE_K67X_AHBOTH
+#define IE_K67X_AHBOTH 1
+#endif
+template <typename T, int AHEAD = IE_K67X_AHBOTH>
+__device__ __forceinline__ void mfma_row_both(const char* smem_base, const char* slot, const RowRead& rr, const ie_u32x4* w0, const ie_u32x4* w1, ie_f32x4 (&accN)[4],
+                                              ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4], bool first) {
+    const ie_f32x4 init0 = {0.f, 0.f, 0.f, 0.f}, init1 = init0;      // (the bias joins in the curve: an inline-constant srcC costs no registers)
+    ie_u32x4 bx[6];
+    // the row's offset stays a scalar the compiler cannot fold into per-row copies of the three lane offsets (six address registers held across the stream spilled)
+    unsigned so = (unsigned)(slot - smem_base);
+    asm volatile("" : "+s"(so));
+    auto rd = [&](int g) __attribute__((always_inline)) { bx[g] = *(const ie_u32x4*)(smem_base + (unsigned)(rr.base[g >> 1] + 1024 * (g & 1)) + so); };
+#pragma unroll
+    for (int g = 0; g < AHEAD; ++g) rd(g);
+    IE_SB();
+#pragma unroll
+    for (int g = 0; g < 6; ++g) {
+        const int kx = g >> 1, j = g & 1;
+        accN[j] = ie_mfma16_raw<T>(w0[0 * 3 + kx], bx[g], (first && kx == 0) ? init0 : accN[j]);
+        if (g + AHEAD < 6) rd(g + AHEAD);
+        IE_SB();
+        accM[j] = ie_mfma16_raw<T>(w0[1 * 3 + kx], bx[g], accM[j]); IE_SB();
+        accO[j] = ie_mfma16_raw<T>(w0[2 * 3 + kx], bx[g], accO[j]); IE_SB();
+        accN[2 + j] = ie_mfma16_raw<T>(w1[0 * 3 + kx], bx[g], (first && kx == 0) ? init1 : accN[2 + j]); IE_SB();
+        accM[2 + j] = ie_mfma16_raw<T>(w1[1 * 3 + kx], bx[g], accM[2 + j]); IE_SB();
+        accO[2 + j] = ie_mfma16_raw<T>(w1[2 * 3 + kx], bx[g], accO[2 + j]); IE_SB();
+    }
+}
+
 // ==========================================================================================================================================
 // K12X: e_conv1 + e_conv2 -> x2
 // ==========================================================================================================================================
@@ -348,14 +379,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 //   both finished rows (same row index) go to stage B through 3-slot LDS rings.  Stage A also carries every chore of the step that is not stage B's own
 //   arithmetic -- ALL the DMA issue (x2, x5, the raw image row), the image row conversion and the `enhanced` stores: in-kernel stamps of the first build had
 //   stage B as the step's critical chain with stage A waiting 1,100 of 4,000 cycles at the barrier (profiles/r04/k67x_experiments.log).
-// Stage B (waves 4-7 = 2 row tiles of e_conv7 x 2 strip halves): e_conv7 over [x1, x6] (72 MFMAs per wave and row).  e_conv7's 24 output rows are permuted on
-//   the host (ie_zdce_plan.hip): row 4 kq + i of 16-row tile j is curve map r_{4j+i} of colour kq (kq = 3: zero rows), and scaled by 2 / ln 2, so after
-//   the MFMAs lane (pixel, kq) of a tile-j wave holds r_{4j} .. r_{4j+3} of ONE colour of its pixel as log2(e) * 2x: tanh = 1 - 2 / (exp2(acc) + 1) and four
-//   curve steps (zero_dce.py:183-188) run straight off the accumulators.  The curve is a chain over the eight maps, so the tile-1 waves run ONE STEP BEHIND the
-//   tile-0 waves: tile 0 takes the fp32 pixel from the raw image ring through iterations 0-3 and leaves y4 in a small LDS exchange row, tile 1 picks it up a step
-//   later (its own finished row is that same image row then), runs iterations 4-7 and stages the result; staged rows leave a step later as 16-byte vectors.
-//   The 96 tanh / curve operations of a wave's finished row ride as fillers behind fixed MFMAs of the next step's 72-MFMA stream; FOUR accumulator sets rotate
-//   (the finished row is only read while the set freed a step earlier restarts from the bias).
+// Stage B (waves 4-7 = the four quarters of the strip; IE_K67X_BOTH): e_conv7 over [x1, x6], BOTH 16-row tiles per wave (72 MFMAs per wave and row; all 36 weight
+//   fragments = 144 VGPRs).  e_conv7's 24 output rows are permuted on the host (ie_zdce_plan.hip): row 4 kq + i of tile j is curve map r_{4j+i} of colour kq (kq = 3:
+//   zero rows), scaled by 2 / ln 2, so after the MFMAs lane (pixel, kq) holds r_0 .. r_7 of ONE colour of its pixel as log2(e) * 2x: tanh = 1 - 2 / (exp2(acc) + 1) and
+//   the eight curve steps (zero_dce.py:183-188) run straight off the accumulators in one lane: fp32 pixel from the raw image ring in, staged row out (it leaves a step
+//   later as 16-byte vectors).  A fragment feeds SIX MFMAs (both tiles x ky), so a wave reads 12 fragments per step instead of 24: at the board's power cap that is
+//   wall time (tools/micro/mfma_pair.hip form 8): 8.36 -> 8.02 ms per 64 frames same box.  To fit 256 VGPRs: accumulators start from the inline constant 0 and the bias
+//   (a 32-float LDS table) joins in the curve; the row offsets stay scalar (six folded address registers held across the streams had spilled); fragments one ahead.
+//   The whole curve of the row finished at step t - 1 runs as ONE BURST at the head of step t, before the stage's MFMAs (finding 14); FOUR accumulator sets rotate (the
+//   finished row is only read while the set freed a step earlier restarts).
+//   IE_K67X_BOTH = 0 keeps the first mapping (2 row tiles x 2 strip halves; the tile-1 waves one step behind the tile-0 waves, y4 through an LDS exchange row).
 struct K67XParams {
     const float* img; const void* x2; const void* x5;
     const void* w1; const float* b1; const void* w6; const float* b6; const void* w7; const float* b7;
@@ -376,6 +409,10 @@ struct K67XParams {
 #ifndef IE_K67X_AHA
 #define IE_K67X_AHA 3       // fragments read ahead of their MFMAs in stage A's / stage B's streams (each one in flight = 4 VGPRs; a stream alone is bound by the LDS
 #endif                      // latency its reads in flight cover: stage A alone ran 22.6 cycles per MFMA at 3, stamps in profiles/r04/k67x_experiments.log)
+#ifndef IE_K67X_BOTH
+#define IE_K67X_BOTH 1      // stage B's waves own BOTH row tiles of e_conv7 over a quarter of the strip: half the fragment reads, no exchange row between the tiles, the staged row a
+                            // step earlier: 8.36 -> 8.02 ms per 64 frames same box (profiles/r04/k67x_experiments.log, 16).  0: the (row tile, strip half) mapping of the first K67X
+#endif
 #ifndef IE_K67X_AHB
 #define IE_K67X_AHB 3
 #endif
@@ -406,7 +443,7 @@ template <typename TH> struct K67XGeom {
     static constexpr int YPLANE_B = 132 * 4, YSLOT_B = 4 * YPLANE_B;      // fp32 [colour (+ a spare plane for lane group kq = 3)][pixel q at float q + 2]
     static constexpr int OFF_X2 = 0, OFF_X5 = OFF_X2 + NRA * ROWH_B, OFF_H6 = OFF_X5 + NRA * ROWH_B, OFF_H1 = OFF_H6 + NRH * ROWH_B;
     static constexpr int OFF_RAW = OFF_H1 + NRH * ROWH_B, OFF_IMG = OFF_RAW + NRAW * RAW_SLOT_B, OFF_Y4 = OFF_IMG + NRI * IMG_ROW_B;
-    static constexpr int OFF_OUT = OFF_Y4 + 2 * YSLOT_B, OFF_DUMP = OFF_OUT + 2 * YSLOT_B, LDS_B = OFF_DUMP + 1024;
+    static constexpr int OFF_OUT = OFF_Y4 + 2 * YSLOT_B, OFF_DUMP = OFF_OUT + 2 * YSLOT_B, OFF_BIAS = OFF_DUMP + 1024, LDS_B = OFF_BIAS + 128;      // (bias table: IE_K67X_BOTH)
     // f16: 66,560 + 49,920 + 16,384 + 2,176 + 4,224 + 4,224 + 1,024 = 144,512 bytes: one workgroup per CU
     // vector-memory operations of a stage-A wave per step, in issue order: [enhanced store (waves 0-2)] raw x 2, x2 x 2, x5 x 2.  At the barrier of step t the raw row
     // t + 1 (issued first in step t - PFR) and the x2 / x5 rows t (issued in step t - PF) must have landed: at most min(4 + (PFR - 1) S, (PF - 1) S) younger
@@ -443,7 +480,7 @@ __device__ __forceinline__ void k67x_body(const K67XParams& p) {
     const int xc0 = strip * TS - MARG;                     // image column of computed column 0 (xc0 + MARG is a multiple of 4)
     const int H = p.H, W = p.W;
     const int ys = p.y_begin + chunk * p.rows_per_block, ye = min(ys + p.rows_per_block, p.y_end);
-    const int n_steps = (ye - ys) + 8;
+    const int n_steps = (ye - ys) + (IE_K67X_BOTH ? 7 : 8);
     const size_t plane = (size_t)H * W;
     const size_t frame_b = plane * PXB;
 #ifdef IE_STAMP
@@ -551,7 +588,7 @@ __device__ __forceinline__ void k67x_body(const K67XParams& p) {
             __builtin_amdgcn_s_barrier();
             IE_TACC(0);
             if constexpr (!(IE_XEXP & 16) && M_ENH) {   // the row staged by the tile-1 waves at step t - 1 leaves
-                const int yo = ys - 8 + t;
+                const int yo = ys - (IE_K67X_BOTH ? 7 : 8) + t;
                 const bool row_ok = (yo >= ys) && (yo < ye);
                 const char* os = smem + G::OFF_OUT + ((t + 1) & 1) * G::YSLOT_B;
                 if (vec_store) {
@@ -571,7 +608,7 @@ __device__ __forceinline__ void k67x_body(const K67XParams& p) {
             }
             if constexpr (M_U8 && !(IE_XEXP & 16)) {
                 if (p.u8 && w4 == 3) {        // HWC bytes: 372 per strip row: wave 3 (it stores no colour plane) quantises the staged fp32 values (save_image rule)
-                    const int yo = ys - 8 + t;
+                    const int yo = ys - (IE_K67X_BOTH ? 7 : 8) + t;
                     const bool row_ok = (yo >= ys) && (yo < ye);
                     const char* os = smem + G::OFF_OUT + ((t + 1) & 1) * G::YSLOT_B;
                     const int xs = xc0 + MARG;
@@ -664,6 +701,86 @@ __device__ __forceinline__ void k67x_body(const K67XParams& p) {
             step_a(t, a0, a1, a2, e0, e1, e2);
             if (t + 1 < n_steps) step_a(t + 1, a2, a0, a1, e2, e0, e1);
             if (t + 2 < n_steps) step_a(t + 2, a1, a2, a0, e1, e2, e0);
+        }
+    } else if constexpr (IE_K67X_BOTH) {
+        // ===================================================== stage B, both row tiles per wave =====================================================
+        // wave w4 = quarter of the strip (pixels 32 w4 .. 32 w4 + 31 = tiles j = 0, 1); it holds all 36 weight fragments of e_conv7, so a fragment feeds six MFMAs, and the
+        // eight curve iterations of a pixel run in ONE lane: no exchange row, no tile-1 lag (the staged row leaves one step earlier: n_steps = rows + 7)
+        constexpr bool M_ADJ = MODE == 0 || MODE == 2;
+        const auto rsJ = mk((M_ADJ && p.adjust) ? (const void*)(p.adjust + (size_t)n * 24 * plane) : (const void*)p.w7, (M_ADJ && p.adjust) ? 24 * plane * 4 : 0);
+        frag wv0[18], wv1[18];
+#pragma unroll
+        for (int f = 0; f < 18; ++f) { wv0[f] = ((const frag*)p.w7)[f * 64 + lane]; wv1[f] = ((const frag*)p.w7)[(18 + f) * 64 + lane]; }
+        // e_conv7's bias: a 32-float table in LDS (OFF_BIAS), read back by (tile, kq) at the head of each curve burst -- not 8 registers held across the streams
+        if (w4 == 0 && lane < 32) *(float*)(smem + G::OFF_BIAS + 4 * lane) = p.b7[lane];
+        const int bias_off = G::OFF_BIAS + 16 * kq;
+        RowRead rq;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int P = 32 * w4 + p16 + kx;
+            rq.base[kx] = P * PXB + ((kq ^ ((P >> 1) & 3)) << 4);
+        }
+        const int q0 = 32 * w4 + p16;
+        const int yout_off = kq * G::YPLANE_B + (q0 + 2) * 4;
+        const int yin_off = (kq < 3 ? kq : 2) * (IPX * 4) + (q0 + 1) * 4;
+        unsigned aj_ok = 0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int q = q0 + 16 * j, x = xc0 + q;
+            aj_ok |= (kq < 3 && q >= MARG && q < TW - MARG && x < W) ? (1u << j) : 0u;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                    // prologue barrier
+        ie_f32x4 a0[4], a1[4], a2[4], a3[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const ie_f32x4 b = {0.f, 0.f, 0.f, 0.f}; a0[j] = b; a1[j] = b; a2[j] = b; a3[j] = b; }
+        // step t: the x1 / x6 rows ys - 4 + t (stage A's step t - 1) finish e_conv7 row ys - 5 + t; accF = the row finished at step t - 1 (ys - 6 + t): its whole curve runs now
+        auto step_b = [&](int t, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4], const ie_f32x4 (&accF)[4]) __attribute__((always_inline)) {
+            IE_TACC(3);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            IE_TACC(0);
+            const char* yin = smem + G::OFF_RAW + ((t + 4) % NRAW) * RAW_SLOT_B;
+            char* yout = smem + G::OFF_OUT + (t & 1) * G::YSLOT_B;
+            float v[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) v[j] = *(const float*)(yin + yin_off + 64 * j);
+            unsigned aj_base = OOB;
+            if constexpr (M_ADJ) {
+                const int yc = ys - 6 + t;
+                if ((MODE == 2 || p.adjust) && yc >= ys && yc < ye) aj_base = (unsigned)(((size_t)kq * plane + (size_t)yc * W + xc0 + q0) * 4);
+            }
+            const ie_f32x4 bz[2] = {*(const ie_f32x4*)(smem + bias_off), *(const ie_f32x4*)(smem + bias_off + 64)};
+            IE_TACC(6);
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float e = __builtin_amdgcn_exp2f(accF[2 * (kk >> 2) + j][kk & 3] + bz[kk >> 2][kk & 3]);
+                    e = __builtin_amdgcn_rcpf(e + 1.0f);
+                    e = __builtin_fmaf(e, -2.0f, 1.0f);                                        // r_kk
+                    if constexpr (M_ADJ) {
+                        const unsigned off = (aj_base != OOB && ((aj_ok >> j) & 1u)) ? aj_base + (unsigned)(64 * j) + (unsigned)((size_t)(3 * kk) * plane * 4) : OOB;
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(e), rsJ, (int)off, 0, 0);
+                    }
+                    const float u = __builtin_fmaf(v[j], v[j], -v[j]);
+                    v[j] = __builtin_fmaf(e, u, v[j]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) *(float*)(yout + yout_off + 64 * j) = v[j];
+            IE_SB();
+            const int hs = ((t + 2) % NRH) * ROWH_B;
+            mfma_row_both<TH>(smem, smem + G::OFF_H1 + hs, rq, wv0, wv1, accN, accM, accO, true);
+            IE_TACC(5);
+            mfma_row_both<TH>(smem, smem + G::OFF_H6 + hs, rq, wv0 + 9, wv1 + 9, accN, accM, accO, false);
+            IE_TACC(1);
+        };
+        for (int t = 0; t < n_steps; t += 4) {
+            step_b(t, a0, a1, a2, a3);
+            if (t + 1 < n_steps) step_b(t + 1, a3, a0, a1, a2);
+            if (t + 2 < n_steps) step_b(t + 2, a2, a3, a0, a1);
+            if (t + 3 < n_steps) step_b(t + 3, a1, a2, a3, a0);
         }
     } else {
         // ================================================================ stage B ================================================================
