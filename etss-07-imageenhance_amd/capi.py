@@ -19,7 +19,7 @@ DTYPES = {"f32": IE_F32, "fp32": IE_F32, "float32": IE_F32, "f16": IE_F16, "fp16
 ACT = {"none": 0, "relu": 1, "lrelu": 2, "tanh": 3, "sigmoid": 4}
 PAD = {"zeros": 0, "replicate": 1}
 SUMSQ_WS_DOUBLES = 2048
-VAR_SYNC_STAGE, VAR_NARROW_STORE, VAR_NO_DMA, VAR_UNFUSED, VAR_PURE_BF16, VAR_NO_K345, VAR_K67_LEGACY, VAR_P_SCHEDULE = 1, 2, 4, 8, 16, 32, 64, 128
+VAR_SYNC_STAGE, VAR_NARROW_STORE, VAR_NO_DMA, VAR_UNFUSED, VAR_PURE_BF16, VAR_NO_K345, VAR_K67_LEGACY, VAR_P_SCHEDULE, VAR_K345_LEGACY = 1, 2, 4, 8, 16, 32, 64, 128, 256
 
 # every exported symbol of include/ie_hip.h (checked by tests/test_capi_symbols.py)
 SYMBOLS = [

@@ -34,11 +34,13 @@ struct ZdceXLaunch {
     int dt_h;            // element type of x1 / x6 (LDS only), of e_conv1's operands and of e_conv7's weights; K12X: also x2's
     int dt_a0, dt_a1;    // K67X: element types of x2 and x5
     const float* img;
-    void* x2;            // K12X: destination; K67X: source
-    const void* x5;
+    void* x2;            // K12X: destination; K345X / K67X: source
+    const void* x5;      // K345X: destination; K67X: source
     const void* w1; const float* b1;     // e_conv1 as [cout half][ky][lane][8] fragments over [R, G, B, 0] pixels (K = 8 kx taps x 4 channels)
     const void* w2; const float* b2;     // K12X: e_conv2 fragments
     const void* w6; const float* b6;     // K67X: e_conv6 fragments
+    const void* w3; const float* b3; const void* w4; const float* b4; const void* w5; const float* b5;     // K345X: e_conv3 / 4 / 5 fragments ([cout half][src * 9 + tap][lane][8])
+    int dt_3;            // K345X: element type of x3 / x4 / x5 (dt_a0 = x2's)
     const void* w7; const float* b7;     // K67X: e_conv7 over [x1, x6], rows permuted (chan_k67) and scaled by 2 / ln 2: [tile][18][lane][8]; bias in row order
     float* enhanced; float* adjust; unsigned char* u8;
     int N, H, W, y_begin, y_end, n_begin, n_count, rows_per_block;

@@ -475,14 +475,16 @@ static int forward_mfma(ie_zdce_plan* p, const float* image, float* enhanced, fl
                     a.img = image; a.x2 = x[2]; a.x5 = x[5];
                     a.w1 = p->d_w + p->off_w1x; a.b1 = B_(0); a.w2 = W_(1); a.b2 = B_(1); a.w6 = W_(5); a.b6 = B_(5);
                     a.w7 = p->d_w + p->off_w7x; a.b7 = (const float*)(p->d_w + p->off_b7x);
-                    a.dt_h = p->xdt[1]; a.dt_a0 = p->xdt[2]; a.dt_a1 = p->xdt[5];
+                    a.w3 = W_(2); a.b3 = B_(2); a.w4 = W_(3); a.b4 = B_(3); a.w5 = W_(4); a.b5 = B_(4);
+                    a.dt_h = p->xdt[1]; a.dt_a0 = p->xdt[2]; a.dt_a1 = p->xdt[5]; a.dt_3 = p->xdt[3];
                     a.stamps = g_ie_stamps ? (void*)((unsigned long long*)g_ie_stamps + (size_t)(kind == 12 ? 0 : 2) * (1u << 20)) : nullptr;
                     if (kind == 12) { a.y_begin = lo(2); a.y_end = hi(2); }
+                    else if (kind == 345) { a.y_begin = lo(5); a.y_end = hi(5); }
                     else { a.enhanced = enhanced; a.adjust = adjust; a.u8 = u8; a.y_begin = b0; a.y_end = b1; }
                     return ie_zdce_launch_x(a, st);
                 };
                 rc = xk(12, 1);
-                if (rc == IE_OK) rc = fused(345, 4);
+                if (rc == IE_OK) rc = (p->cfg.variant & IE_ZDCE_VAR_K345_LEGACY) || p->xdt[3] != p->xdt[4] || p->xdt[3] != p->xdt[5] ? fused(345, 4) : xk(345, 4);
                 if (rc == IE_OK) rc = xk(67, 6);
             } else {
                 // round-3 schedule (IE_ZDCE_VAR_P_SCHEDULE): K12 also writes P = W7a * x1 + b7 into x1's slot, then conv3, K45, K67
@@ -611,7 +613,10 @@ IE_EXPORT int ie_zdce_profile_forward(ie_zdce_plan* p, const float* image, float
     const bool k345 = fused && !(p->cfg.variant & IE_ZDCE_VAR_NO_K345);
     for (int l = 0; l < NL; ++l) { ms[l] = 0.f; names[l] = k345 ? kFused3Names[l] : (fused ? kFusedNames[l] : kLayerNames[l]); if (launches) launches[l] = 0; }
     if (fused && !(p->cfg.variant & IE_ZDCE_VAR_K67_LEGACY)) names[6] = "zdce_k67n_conv6_conv7_curve";
-    if (fused && !(p->cfg.variant & (IE_ZDCE_VAR_P_SCHEDULE | IE_ZDCE_VAR_NO_K345 | IE_ZDCE_VAR_K67_LEGACY))) { names[1] = "zdce_k12x_conv1_conv2"; names[6] = "zdce_k67x_conv1_conv6_conv7_curve"; }
+    if (fused && !(p->cfg.variant & (IE_ZDCE_VAR_P_SCHEDULE | IE_ZDCE_VAR_NO_K345 | IE_ZDCE_VAR_K67_LEGACY))) {
+        names[1] = "zdce_k12x_conv1_conv2"; names[6] = "zdce_k67x_conv1_conv6_conv7_curve";
+        if (!(p->cfg.variant & IE_ZDCE_VAR_K345_LEGACY) && p->xdt[3] == p->xdt[4] && p->xdt[3] == p->xdt[5]) names[4] = "zdce_k345x_conv3_conv4_conv5";
+    }
     for (size_t i = 0; i < p->ev_layer.size(); ++i) {
         float t = 0.f;
         IE_HIP_CHECK(hipEventElapsedTime(&t, p->ev[2 * i], p->ev[2 * i + 1]));

@@ -88,6 +88,15 @@ template <typename T, bool MASKED = true> __device__ __forceinline__ void put_ro
         *(ie_u32x4*)(base + em_off + jj * 32 * PXB) = ie_u32x4{k ? sx[0] : 0u, k ? sy[0] : 0u, k ? sx[1] : 0u, k ? sy[1] : 0u};
     }
 }
+// one tile pair (2 jj, 2 jj + 1) of put_row: lets a stream hand a row over in two halves, the first one while its last MFMAs still run
+template <typename T, bool MASKED = true> __device__ __forceinline__ void put_pair(const ie_f32x4 (&acc)[4], int jj, char* base, int em_off, unsigned keep) {
+    const ie_u32x2 a = {ie_pack2_relu<T>(acc[2 * jj][0], acc[2 * jj][1]), ie_pack2_relu<T>(acc[2 * jj][2], acc[2 * jj][3])};
+    const ie_u32x2 b2 = {ie_pack2_relu<T>(acc[2 * jj + 1][0], acc[2 * jj + 1][1]), ie_pack2_relu<T>(acc[2 * jj + 1][2], acc[2 * jj + 1][3])};
+    const auto sx = __builtin_amdgcn_permlane16_swap(a[0], b2[0], false, false);
+    const auto sy = __builtin_amdgcn_permlane16_swap(a[1], b2[1], false, false);
+    const bool k = !MASKED || ((keep >> jj) & 1u);
+    *(ie_u32x4*)(base + em_off + jj * 32 * PXB) = ie_u32x4{k ? sx[0] : 0u, k ? sy[0] : 0u, k ? sx[1] : 0u, k ? sy[1] : 0u};
+}
 // this lane's 16-byte piece of tile pair 0 in a row image whose pixel q sits at index q + halo; pair 1 is 32 pixels on.  Wave = (cout fragment cf, half hf).
 __device__ __forceinline__ int put_off(int cf, int hf, int p16, int kq, int halo) {
     const int P = 16 * (4 * hf + (kq & 1)) + p16 + halo;
@@ -192,10 +201,13 @@ __device__ __forceinline__ void mfma_row(const char* slot, const RowRead& rr, co
 #ifndef IE_K67X_AHBOTH
 #define IE_K67X_AHBOTH 1
 #endif
-template <typename T, int AHEAD = IE_K67X_AHBOTH>
+template <typename T, int AHEAD = IE_K67X_AHBOTH, bool ZINIT = true>
 __device__ __forceinline__ void mfma_row_both(const char* smem_base, const char* slot, const RowRead& rr, const ie_u32x4* w0, const ie_u32x4* w1, ie_f32x4 (&accN)[4],
-                                              ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4], bool first) {
-    const ie_f32x4 init0 = {0.f, 0.f, 0.f, 0.f}, init1 = init0;      // (the bias joins in the curve: an inline-constant srcC costs no registers)
+                                              ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4], bool first, const ie_f32x4& b0 = ie_f32x4{0.f, 0.f, 0.f, 0.f},
+                                              const ie_f32x4& b1 = ie_f32x4{0.f, 0.f, 0.f, 0.f}) {
+    // ZINIT (K67X): the new row starts from the inline constant 0 -- no registers -- and the bias joins in the curve; else from the bias pair b0 / b1
+    const ie_f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const ie_f32x4 init0 = ZINIT ? zero : b0, init1 = ZINIT ? zero : b1;
     ie_u32x4 bx[6];
     // the row's offset stays a scalar the compiler cannot fold into per-row copies of the three lane offsets (six address registers held across the stream spilled)
     unsigned so = (unsigned)(slot - smem_base);
@@ -963,6 +975,247 @@ IE_DEF_K67X(zdce_k67x_conv1_conv6_conv7_curve_u8_bf16, __bf16, __bf16, __bf16, 3
 IE_DEF_K67X(zdce_k67x_conv1_conv6_conv7_curve_u8_mix, _Float16, __bf16, _Float16, 3)
 #undef IE_DEF_K67X
 
+
+// ==========================================================================================================================================
+// K345X: e_conv3 + e_conv4 + e_conv5 (x2 -> x5; x3 and x4 live in LDS rings only), every wave owning BOTH 16-cout fragments of its layer
+// ==========================================================================================================================================
+// The strip form at the board's power cap is paid per MFMA AND per fragment read (tools/micro/mfma_pair.hip form 8): a wave that holds both cout fragments of a layer
+// reuses a fragment six times instead of three.  Roles (wave w and w + 4 share a SIMD; 72 MFMAs per wave and row everywhere):
+//   waves 0, 1  e_conv3 over a HALF of the strip (4 pixel tiles), 18 weight fragments (72 VGPRs), 3 x 8 accumulators; x2 rows by LDS-DMA -> x3 ring
+//   waves 2, 3  e_conv4 the same way on the x3 row e_conv3 finished a step earlier -> x4 ring
+//   waves 4..7  e_conv5 over a QUARTER of the strip (2 pixel tiles) on [x3, x4] rows of one index, 36 weight fragments (144 VGPRs), 3 x 4 accumulators -> x5 to HBM
+// Each layer drops the outermost computed column of the one before (no halo columns are loaded): 128 computed, 122 stored columns per strip.
+// Step t: x2 row ys - 3 + t arrives; e_conv3 finishes x3 row ys - 4 + t (ring slot t % 4), e_conv4 x4 row ys - 6 + t (slot t % 3) from the x3 row of step t - 1,
+// e_conv5 x5 row ys - 8 + t from the x3 row of step t - 3 and the x4 row of step t - 1.  Rows / columns outside the image are written as zeros (the next layer's padding).
+struct K345XParams {
+    const void* x2; void* x5;
+    const void* w3; const float* b3; const void* w4; const float* b4; const void* w5; const float* b5;
+    int H, W, y_begin, y_end, rows_per_block, strips, chunks, n_begin;
+};
+constexpr int MARG3 = 3, TS3 = TW - 2 * MARG3;      // 122 stored columns per strip
+struct K345XGeom {
+    static constexpr int PF = 3, NRA = PF + 1, NR3 = 4, NR4 = 3;
+    static constexpr int OFF_X2 = 0, OFF_X3 = OFF_X2 + NRA * ROWH_B, OFF_X4 = OFF_X3 + NR3 * ROWH_B, LDS_B = OFF_X4 + NR4 * ROWH_B;      // 11 x 8,320 = 91,520 bytes
+};
+
+#ifndef IE_K345X_EARLY
+#define IE_K345X_EARLY 0
+#endif
+#ifndef IE_K345X_SWAP
+#define IE_K345X_SWAP 0
+#endif
+#ifndef IE_K345X_EXP
+#define IE_K345X_EXP 0      // timing experiments (WRONG results): 1 no hand-off writes of stage A, 2 no x5 stores, 4 no x2 DMA
+#endif
+// one source row of a 32-channel tensor over HALF a strip for both cout fragments: 12 fragments, 72 MFMAs; n / m / o = the three rotating rows, index = tile
+#ifndef IE_K345X_AHA
+#define IE_K345X_AHA 1
+#endif
+#ifndef IE_K345X_AHB
+#define IE_K345X_AHB 1
+#endif
+template <typename T, int AHEAD = IE_K345X_AHA, typename F>
+__device__ __forceinline__ void mfma_row_both4(const char* smem_base, const char* slot, const RowRead& rr, const ie_u32x4* w0, const ie_u32x4* w1,
+                                               ie_f32x4 (&n0)[4], ie_f32x4 (&m0)[4], ie_f32x4 (&o0)[4], ie_f32x4 (&n1)[4], ie_f32x4 (&m1)[4], ie_f32x4 (&o1)[4],
+                                               const ie_f32x4& init0, const ie_f32x4& init1, F&& early) {
+    ie_u32x4 bx[12];
+    unsigned so = (unsigned)(slot - smem_base);
+    asm volatile("" : "+s"(so));
+    auto rd = [&](int g) __attribute__((always_inline)) { bx[g] = *(const ie_u32x4*)(smem_base + (unsigned)(rr.base[g >> 2] + 1024 * (g & 3)) + so); };
+#pragma unroll
+    for (int g = 0; g < AHEAD; ++g) rd(g);
+    IE_SB();
+#pragma unroll
+    for (int g = 0; g < 12; ++g) {
+        const int kx = g >> 2, j = g & 3;
+        n0[j] = ie_mfma16_raw<T>(w0[0 * 3 + kx], bx[g], kx == 0 ? init0 : n0[j]);
+        if (g + AHEAD < 12) rd(g + AHEAD);
+        IE_SB();
+        m0[j] = ie_mfma16_raw<T>(w0[1 * 3 + kx], bx[g], m0[j]); IE_SB();
+        o0[j] = ie_mfma16_raw<T>(w0[2 * 3 + kx], bx[g], o0[j]); IE_SB();
+        n1[j] = ie_mfma16_raw<T>(w1[0 * 3 + kx], bx[g], kx == 0 ? init1 : n1[j]); IE_SB();
+        m1[j] = ie_mfma16_raw<T>(w1[1 * 3 + kx], bx[g], m1[j]); IE_SB();
+        o1[j] = ie_mfma16_raw<T>(w1[2 * 3 + kx], bx[g], o1[j]); IE_SB();
+        if (IE_K345X_EARLY && g == 9) { early(); IE_SB(); }       // experiment: tiles 0, 1 of the oldest row are final behind fragment 9 -- their half of the hand-off under the last 12 MFMAs: slower (7.33 against 7.22 ms)
+    }
+}
+
+// T2: element type of x2 (and of e_conv3's weights / MFMAs); T3: of x3, x4, x5 (e_conv4 / e_conv5)
+template <typename T2, typename T3>
+__device__ __forceinline__ void k345x_body(const K345XParams& p) {
+    using G = K345XGeom;
+    using frag = ie_u32x4;
+    constexpr int PF = G::PF, NRA = G::NRA, NR3 = G::NR3, NR4 = G::NR4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    ie_fp16_saturate_on();
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p16 = lane & 15, kq = lane >> 4;
+    const int stg = (wave >> 2) ^ IE_K345X_SWAP, w4 = wave & 3;      // (IE_K345X_SWAP: e_conv5 on the older waves 0-3)
+
+    int b = blockIdx.x;
+    const int strip = b % p.strips; b /= p.strips;
+    const int chunk = b % p.chunks; b /= p.chunks;
+    const int n = p.n_begin + b;
+    const int xc0 = strip * TS3 - MARG3;
+    const int H = p.H, W = p.W;
+    const int ys = p.y_begin + chunk * p.rows_per_block, ye = min(ys + p.rows_per_block, p.y_end);
+    const int n_steps = (ye - ys) + 8;
+    const size_t frame_b = (size_t)H * W * PXB;
+    auto mk = [&](const void* base, size_t bytes) __attribute__((always_inline)) { return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000); };
+#ifdef IE_ONLY_STAGE
+    if (stg != IE_ONLY_STAGE) return;
+#endif
+
+    if (stg == 0) {
+        // ============================================== stage A: waves 0, 1 e_conv3; waves 2, 3 e_conv4 ==============================================
+        const int hf = w4 & 1;
+        // (the role is a template constant of the whole stage: as a run-time select inside the step the two instantiations of the stream kept both sets of temporaries alive and spilled 78 VGPRs)
+        auto stage_a = [&](auto role_c) __attribute__((always_inline)) {
+        constexpr int role = decltype(role_c)::value;
+        const auto rs2 = mk((const char*)p.x2 + (size_t)n * frame_b, frame_b);
+        frag wc0[9], wc1[9];
+        {
+            const frag* wp = (const frag*)(role ? p.w4 : p.w3);
+#pragma unroll
+            for (int f = 0; f < 9; ++f) { wc0[f] = wp[f * 64 + lane]; wc1[f] = wp[(9 + f) * 64 + lane]; }
+        }
+        ie_f32x4 bias0, bias1;
+        {
+            const float* bp = role ? p.b4 : p.b3;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { bias0[i] = bp[4 * kq + i]; bias1[i] = bp[16 + 4 * kq + i]; }
+        }
+        const RowRead rr = row_read(hf, p16, kq);
+        // x2 rows: piece m = 2 w4 + j (16 pixels x 64 bytes) lands at ring pixels 16 m + 1 ..; the source chunk is the position's un-swizzled one
+        unsigned body_xoff[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int q = (2 * w4 + j) * 16 + (lane >> 2);
+            const int sc = (lane & 3) ^ (((q + 1) >> 1) & 3);
+            const int x = xc0 + q;
+            body_xoff[j] = (x >= 0 && x < W) ? (unsigned)(x * PXB + sc * 16) : OOB;
+        }
+        auto issue = [&](int t) __attribute__((always_inline)) {
+            const int y = ys - 3 + t;
+            const unsigned rmask = (y >= 0 && y < H) ? 0u : OOB;
+            const unsigned row_b = rmask ? 0u : (unsigned)y * (unsigned)W * PXB;
+            char* s2 = smem + G::OFF_X2 + (t % NRA) * ROWH_B + PXB;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (lds_ptr)(s2 + (2 * w4 + j) * 1024), 16, (int)((row_b + body_xoff[j]) | rmask), 0, 0, 0);
+        };
+        const int em_off0 = put_off(0, hf, p16, kq, 1), em_off1 = put_off(1, hf, p16, kq, 1);
+        unsigned em_in = 0;
+        {
+            const int q = 16 * (4 * hf + (kq & 1)) + p16;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int x = xc0 + q + 32 * jj;
+                em_in |= (x >= 0 && x < W) ? (1u << jj) : 0u;
+            }
+        }
+        const bool strip_inside = xc0 >= 0 && xc0 + TW <= W;
+        ie_f32x4 a0[4], a1[4], a2[4], c0[4], c1[4], c2[4];      // a*: cout fragment 0, c*: cout fragment 1
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a0[j] = bias0; a1[j] = bias0; a2[j] = bias0; c0[j] = bias1; c1[j] = bias1; c2[j] = bias1; }
+#pragma unroll
+        for (int t = 0; t < PF; ++t) issue(t);
+        auto step_a = [&](int t, ie_f32x4 (&n0)[4], ie_f32x4 (&m0)[4], ie_f32x4 (&o0)[4], ie_f32x4 (&n1)[4], ie_f32x4 (&m1)[4], ie_f32x4 (&o1)[4]) __attribute__((always_inline)) {
+            ie_wait_vm_imm<(PF - 1) * 2>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const int m = role == 0 ? ys - 4 + t : ys - 6 + t;       // the row this step finishes
+            char* dst = role == 0 ? smem + G::OFF_X3 + (t % NR3) * ROWH_B : smem + G::OFF_X4 + (t % NR4) * ROWH_B;
+            const bool plain = strip_inside && m >= 0 && m < H;
+            const unsigned keep = (m >= 0 && m < H) ? em_in : 0u;
+            auto hand = [&](int jj) __attribute__((always_inline)) {
+                if (plain) { put_pair<T3, false>(o0, jj, dst, em_off0, 3u); put_pair<T3, false>(o1, jj, dst, em_off1, 3u); }
+                else { put_pair<T3, true>(o0, jj, dst, em_off0, keep); put_pair<T3, true>(o1, jj, dst, em_off1, keep); }
+            };
+            auto early = [&]() __attribute__((always_inline)) { hand(0); };
+            if constexpr (role == 0) mfma_row_both4<T2>(smem, smem + G::OFF_X2 + (t % NRA) * ROWH_B, rr, wc0, wc1, n0, m0, o0, n1, m1, o1, bias0, bias1, early);
+            else mfma_row_both4<T3>(smem, smem + G::OFF_X3 + ((t + NR3 - 1) % NR3) * ROWH_B, rr, wc0, wc1, n0, m0, o0, n1, m1, o1, bias0, bias1, early);
+            if (!(IE_K345X_EXP & 1)) {
+            if (!IE_K345X_EARLY) hand(0);
+            hand(1);
+            }
+            if (!(IE_K345X_EXP & 4)) issue(t + PF);       // (behind the hand-off writes: they are what the barrier waits for)
+        };
+        for (int t = 0; t < n_steps; t += 3) {
+            step_a(t, a0, a1, a2, c0, c1, c2);
+            if (t + 1 < n_steps) step_a(t + 1, a2, a0, a1, c2, c0, c1);
+            if (t + 2 < n_steps) step_a(t + 2, a1, a2, a0, c1, c2, c0);
+        }
+        };
+        if ((w4 >> 1) == 0) stage_a(std::integral_constant<int, 0>{}); else stage_a(std::integral_constant<int, 1>{});
+    } else {
+        // ===================================================== stage B: e_conv5, a quarter of the strip per wave =====================================================
+        const auto rs5 = mk((char*)p.x5 + (size_t)n * frame_b, frame_b);
+        frag wv0[18], wv1[18];
+#pragma unroll
+        for (int f = 0; f < 18; ++f) { wv0[f] = ((const frag*)p.w5)[f * 64 + lane]; wv1[f] = ((const frag*)p.w5)[(18 + f) * 64 + lane]; }
+        ie_f32x4 bias0, bias1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { bias0[i] = p.b5[4 * kq + i]; bias1[i] = p.b5[16 + 4 * kq + i]; }
+        RowRead rq;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int P = 32 * w4 + p16 + kx;
+            rq.base[kx] = P * PXB + ((kq ^ ((P >> 1) & 3)) << 4);
+        }
+        // after the lane-pair exchange this lane holds, per cout fragment cf, the 16-byte chunk 2 cf + (kq >> 1) of pixel 32 w4 + 16 (kq & 1) + p16
+        unsigned st_off[2];
+        {
+            const int q = 32 * w4 + 16 * (kq & 1) + p16, x = xc0 + q;
+            const bool ok = q >= MARG3 && q < TW - MARG3 && x < W;
+#pragma unroll
+            for (int cf = 0; cf < 2; ++cf) st_off[cf] = ok ? (unsigned)(x * PXB + (2 * cf + (kq >> 1)) * 16) : OOB;
+        }
+        ie_f32x4 a0[4], a1[4], a2[4];       // index 2 * cout fragment + tile
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const ie_f32x4 bb = j < 2 ? bias0 : bias1; a0[j] = bb; a1[j] = bb; a2[j] = bb; }
+        // the finished row leaves at the HEAD of the next step (the younger stage does what is not an MFMA while the older one streams, finding 14): accN of step t is
+        // the set that was accO at step t - 1 -- its row ys - 9 + t is packed and stored before the first MFMA restarts it
+        auto store_row = [&](int yo, const ie_f32x4 (&acc)[4]) __attribute__((always_inline)) {
+            const unsigned rmask = (yo >= ys && yo < ye) ? 0u : OOB;
+            const unsigned row_b = rmask ? 0u : (unsigned)yo * (unsigned)W * PXB;
+#pragma unroll
+            for (int cf = 0; cf < 2; ++cf) {
+                const ie_u32x2 a = {ie_pack2_relu<T3>(acc[2 * cf][0], acc[2 * cf][1]), ie_pack2_relu<T3>(acc[2 * cf][2], acc[2 * cf][3])};
+                const ie_u32x2 b2 = {ie_pack2_relu<T3>(acc[2 * cf + 1][0], acc[2 * cf + 1][1]), ie_pack2_relu<T3>(acc[2 * cf + 1][2], acc[2 * cf + 1][3])};
+                const auto sx = __builtin_amdgcn_permlane16_swap(a[0], b2[0], false, false);
+                const auto sy = __builtin_amdgcn_permlane16_swap(a[1], b2[1], false, false);
+                __builtin_amdgcn_raw_buffer_store_b128(ie_u32x4{sx[0], sy[0], sx[1], sy[1]}, rs5, (int)((row_b + st_off[cf]) | rmask), 0, 0);
+            }
+        };
+        auto step_b = [&](int t, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4]) __attribute__((always_inline)) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (!(IE_K345X_EXP & 2)) store_row(ys - 9 + t, accN);
+            IE_SB();
+            mfma_row_both<T3, IE_K345X_AHB, false>(smem, smem + G::OFF_X3 + ((t + NR3 - 3) % NR3) * ROWH_B, rq, wv0, wv1, accN, accM, accO, true, bias0, bias1);
+            mfma_row_both<T3, IE_K345X_AHB, false>(smem, smem + G::OFF_X4 + ((t + NR4 - 1) % NR4) * ROWH_B, rq, wv0 + 9, wv1 + 9, accN, accM, accO, false, bias0, bias1);
+        };
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        int t = 0;
+        for (; t < n_steps; t += 3) {
+            step_b(t, a0, a1, a2);
+            if (t + 1 < n_steps) step_b(t + 1, a2, a0, a1);
+            if (t + 2 < n_steps) step_b(t + 2, a1, a2, a0);
+        }
+        // the last row (finished at step n_steps - 1 = accO of that step): which set it is depends on n_steps % 3
+        const int last = n_steps - 1;
+        if (last % 3 == 0) store_row(ys - 8 + last, a2); else if (last % 3 == 1) store_row(ys - 8 + last, a1); else store_row(ys - 8 + last, a0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+#define IE_DEF_K345X(NAME, T2, T3) \
+    __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void NAME(K345XParams p) { k345x_body<T2, T3>(p); }
+IE_DEF_K345X(zdce_k345x_conv3_conv4_conv5_f16, _Float16, _Float16)
+IE_DEF_K345X(zdce_k345x_conv3_conv4_conv5_bf16, __bf16, __bf16)
+IE_DEF_K345X(zdce_k345x_conv3_conv4_conv5_mix, _Float16, __bf16)
+
 }  // namespace
 
 int ie_zdce_launch_x(const ZdceXLaunch& a, hipStream_t st) {
@@ -988,6 +1241,25 @@ int ie_zdce_launch_x(const ZdceXLaunch& a, hipStream_t st) {
         const int lds = a.dt_h == IE_F16 ? K12XGeom<_Float16>::LDS_B : K12XGeom<__bf16>::LDS_B;
         void* args[] = {(void*)&p};
         IE_HIP_CHECK(hipLaunchKernel((const void*)fn, dim3((unsigned)blocks), dim3(512), args, lds, st));
+        return IE_OK;
+    }
+    if (a.kind == 345) {
+        K345XParams p;
+        memset(&p, 0, sizeof(p));
+        p.x2 = a.x2; p.x5 = (void*)a.x5; p.w3 = a.w3; p.b3 = a.b3; p.w4 = a.w4; p.b4 = a.b4; p.w5 = a.w5; p.b5 = a.b5;
+        p.H = a.H; p.W = a.W; p.y_begin = a.y_begin; p.y_end = a.y_end; p.n_begin = a.n_begin; p.strips = ie_cdiv(a.W, TS3);
+        p.rows_per_block = a.rows_per_block;
+        p.chunks = ie_cdiv(a.y_end - a.y_begin, a.rows_per_block);
+        const long long blocks = (long long)p.strips * p.chunks * a.n_count;
+        if (blocks <= 0 || blocks > 0x7fffffffLL) IE_FAIL(IE_ERR_INVALID, "zdce k345x: bad grid %lld", blocks);
+        typedef void (*Fn)(K345XParams);
+        const Fn fn = (a.dt_a0 == IE_F16 && a.dt_3 == IE_F16) ? zdce_k345x_conv3_conv4_conv5_f16
+                      : (a.dt_a0 == IE_BF16 && a.dt_3 == IE_BF16) ? zdce_k345x_conv3_conv4_conv5_bf16
+                      : (a.dt_a0 == IE_F16 && a.dt_3 == IE_BF16) ? zdce_k345x_conv3_conv4_conv5_mix : (Fn) nullptr;
+        if (!fn) IE_FAIL(IE_ERR_UNSUPPORTED, "zdce k345x: dtypes x2=%d x3=%d", a.dt_a0, a.dt_3);
+        IE_GRANT_LDS(fn, K345XGeom::LDS_B);
+        void* args[] = {(void*)&p};
+        IE_HIP_CHECK(hipLaunchKernel((const void*)fn, dim3((unsigned)blocks), dim3(512), args, K345XGeom::LDS_B, st));
         return IE_OK;
     }
     if (a.kind != 67) IE_FAIL(IE_ERR_INVALID, "zdce x: kind %d", a.kind);

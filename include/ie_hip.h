@@ -552,7 +552,8 @@ typedef struct ie_zdce_config {
 #define IE_ZDCE_VAR_UNFUSED 8 /* one kernel per layer instead of the fused conv1+2 / conv4+5 / conv6+7 kernels */
 #define IE_ZDCE_VAR_NO_K345 32 /* e_conv3 as its own kernel + the two-layer conv4+5 kernel instead of the three-layer conv3+4+5 kernel (A-B) */
 #define IE_ZDCE_VAR_K67_LEGACY 64 /* round-2 form of the last kernel: e_conv7 rows in channel order, tanh + curve on fp32 rows parked in LDS (A-B) */
-#define IE_ZDCE_VAR_P_SCHEDULE 128 /* round-3 schedule (A-B): the first kernel also computes P = W7a * x1 + b7 (64 B/px written, read back by the last kernel) instead of
+#define IE_ZDCE_VAR_P_SCHEDULE 128
+#define IE_ZDCE_VAR_K345_LEGACY 256      /* e_conv3 + e_conv4 + e_conv5 in round 2's (cout fragment, strip half) wave mapping instead of K345X (A-B runs) */ /* round-3 schedule (A-B): the first kernel also computes P = W7a * x1 + b7 (64 B/px written, read back by the last kernel) instead of
                                       the last kernel recomputing x1 from the image and contracting e_conv7 over both of its sources */
 #define IE_ZDCE_VAR_PURE_BF16 16 /* compute_dtype IE_BF16 only: every 16-bit tensor and weight in bf16.  Without it the
                                     "bf16" schedule holds the tensors that carry the rounding error (x1, x2, x6, the partial

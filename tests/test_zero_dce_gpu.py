@@ -128,6 +128,24 @@ def test_round3_schedule_golden_parity(path, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["f16", "bf16", "bf16_pure"])
+@pytest.mark.parametrize("shape", [(2, 37, 132), (1, 140, 256), (3, 9, 260), (1, 5, 4), (1, 64, 123), (2, 11, 245)])
+def test_k345x_against_the_first_middle_kernel(shape, dtype):
+    """K345X (every wave owns both cout fragments of its layer: e_conv3 / e_conv4 on half-strips, e_conv5 on quarter-strips, half the LDS fragment reads) against
+    IE_ZDCE_VAR_K345_LEGACY (round 2's (cout fragment, strip half) mapping): x5 and the outputs agree to accumulation-order rounding on widths that are one strip,
+    exactly two (245 = 2 x 122 + 1 column) and ragged, few rows and many."""
+    n, h, w = shape
+    sd = o_zdce.init_state_dict(seed=7, gain=3.0)
+    x = torch.rand(n, 3, h, w, generator=torch.Generator().manual_seed(h * 1000 + w)).cuda()
+    ma, mb = _model(sd, dtype), _model(sd, dtype, capi.VAR_K345_LEGACY)
+    a, b = ma.forward({"image": x}), mb.forward({"image": x})
+    tol = 2e-3 if dtype != "bf16_pure" else 1.5e-2
+    assert rel_err(a["enhanced"].cpu(), b["enhanced"].cpu()) <= tol and rel_err(a["adjust"].cpu(), b["adjust"].cpu()) <= 5 * tol
+    assert rel_err(ma.feature(5).cpu(), mb.feature(5).cpu()) <= tol
+    ref = o_zdce.forward(sd, x.cpu())
+    assert rel_err(a["enhanced"].cpu(), ref["enhanced"]) <= (3e-3 if dtype != "bf16_pure" else 2e-2)
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16", "bf16_pure"])
 @pytest.mark.parametrize("shape", [(2, 37, 132), (1, 140, 256), (3, 9, 260), (1, 5, 4)])
 def test_last_kernel_output_modes_agree(shape, dtype):
     """The last kernel is compiled several times: for `enhanced` alone with W % 4 == 0 (zdce_k67x_*_e_*, the throughput path), for `enhanced` + the curve

@@ -6,7 +6,7 @@
 //   pair 2  all stream, one s_barrier per step          pair 3  as 2, waves 4-7 half a step behind (their barrier sits between their two rows)
 //   form 0  the kernels' pinned form, fragments read AHEAD = 3 ahead       form 1  AHEAD = 6        form 2  all 12 fragments of a row read up front
 //   form 3  register-only (no LDS reads: the same fragment registers every time)        forms 4-8: see mfma_row / mfma_row_acc / mfma_row_both
-//   chores  0 none   1 stage A ends its step with a latency-bound tail (LDS read -> pack -> 4 ds_write_b128 -> 6 LDS-DMA pieces), stage B opens its step with
+//   chores  0 none   2 as 1 with stage A's tail moved to the head of its next step   1 stage A ends its step with a latency-bound tail (LDS read -> pack -> 4 ds_write_b128 -> 6 LDS-DMA pieces), stage B opens its step with
 //           a 96-operation transcendental burst -- the shape of K67X
 // Build: hipcc --offload-arch=gfx950 -O3 -Wno-unused-value [-DUSE_BF16] [-DRELU_DATA] mfma_pair.hip -o mfma_pair     (RELU_DATA: half of the LDS values zero, as behind a ReLU)
 #include <hip/hip_runtime.h>
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     if (active) {
         auto chores_a = [&](int t, const f32x4 (&acc)[4]) __attribute__((always_inline)) {
-            if constexpr (CHORES == 1) {
+            if constexpr (CHORES >= 1) {
                 // a staged row leaves (LDS read -> use), a finished row is packed and written, the next rows are requested
                 const u32x4 v = *(const u32x4*)(smem + NR * ROWH_B + lane * 16);
                 unsigned pk[8];
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         };
         auto chores_b = [&](const f32x4 (&acc)[4]) __attribute__((always_inline)) {
-            if constexpr (CHORES == 1) {
+            if constexpr (CHORES >= 1) {
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
@@ -209,9 +209,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             } else {
                 if (PAIR >= 2) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
                 if (stg == 1) chores_b(aO);
+                if (CHORES == 2 && stg == 0) chores_a(t, aN);       // chores 2: stage A's hand-off work at the HEAD of its step (on the row finished a step earlier), under stage B's stream
                 ROW(r0, wv, aN, aM, aO, true);
                 ROW(r1, wv + 9, aN, aM, aO, false);
-                if (stg == 0) chores_a(t, aO);
+                if (CHORES == 1 && stg == 0) chores_a(t, aO);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) sink[j] += aO[j][j];      // the finished row is consumed (keeps its MFMAs alive)
@@ -292,6 +293,8 @@ int main() {
     run<0, 8, 0>("one wave, both cout fragments: a fragment feeds 6 MFMAs", d, dc, src);
     run<2, 8, 0>("two waves, both cout fragments (6 reads per row), barrier", d, dc, src);
     run<2, 8, 1>("K67X shape with both cout fragments per wave", d, dc, src);
+    run<2, 0, 2>("K67X shape, stage A's chores at the HEAD of its step", d, dc, src);
+    run<2, 8, 2>("both cout fragments per wave, stage A's chores at the head", d, dc, src);
     run<2, 0, 1>("K67X shape: A tail chores, B head burst; barrier per step", d, dc, src);
     run<3, 0, 1>("K67X shape, waves 4-7 half a step behind", d, dc, src);
     run<2, 3, 1>("K67X shape, register-only fragments", d, dc, src);

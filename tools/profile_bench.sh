@@ -8,13 +8,13 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
-ARGS="--steps 10 --warmup 3 --no-extras --no-cpu-baseline"
+ARGS="--steps 10 --warmup 3 --no-extras --no-cpu-baseline --no-board"      # (no child processes under the profiler)
 (cd $R && timeout -k 10 240 rocprofv3 --kernel-trace --stats -d $O/kt -o kt --output-format csv -- python bench.py $ARGS > $O/bench_under_rocprof.json.log 2> $O/kt.err) || echo "kernel-trace pass failed"
 f=$(find $O/kt -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/kernel_stats.csv
 i=0
 for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  (cd $R && timeout -k 10 150 rocprofv3 --pmc $C --kernel-trace -d $O/p$i -o p$i --output-format csv -- python bench.py --steps 2 --warmup 1 --no-extras --no-cpu-baseline > $O/p$i.log 2>&1) || echo "pmc pass $i failed"
+  (cd $R && timeout -k 10 150 rocprofv3 --pmc $C --kernel-trace -d $O/p$i -o p$i --output-format csv -- python bench.py --steps 2 --warmup 1 --no-extras --no-cpu-baseline --no-board > $O/p$i.log 2>&1) || echo "pmc pass $i failed"
   f=$(find $O/p$i -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python $R/tools/pmc_summary.py $f all > $O/pmc_pass$i.txt 2>&1
   rm -rf $O/p$i
