@@ -37,6 +37,7 @@ struct ZdceXLaunch {
     void* x2;            // K12X: destination; K345X / K67X: source
     const void* x5;      // K345X: destination; K67X: source
     const void* w1; const float* b1;     // e_conv1 as [cout half][ky][lane][8] fragments over [R, G, B, 0] pixels (K = 8 kx taps x 4 channels)
+    const void* w1q;                     // K67X: e_conv1 as [cout half][lane][8]: ONE K = 32 fragment over a 3-row window (lane groups 0-2: row ky, (kx, c) pairs 0..7; group 3: the three (kx 2, B) taps)
     const void* w2; const float* b2;     // K12X: e_conv2 fragments
     const void* w6; const float* b6;     // K67X: e_conv6 fragments
     const void* w3; const float* b3; const void* w4; const float* b4; const void* w5; const float* b5;     // K345X: e_conv3 / 4 / 5 fragments ([cout half][src * 9 + tap][lane][8])

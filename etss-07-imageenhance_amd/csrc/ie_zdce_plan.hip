@@ -54,6 +54,7 @@ struct ie_zdce_plan {
     size_t off_w7b = 0;   // K67 stage B: the x6 half of e_conv7
     size_t off_b7p = 0;   // e_conv7's bias in K12's row order (what P is seeded with)
     size_t off_w1x = 0;   // round-4 schedule: e_conv1 as [cout half][ky][lane][8] fragments, K = 8 kx taps x 4 channels (K12X and K67X)
+    size_t off_w1q = 0;   // K67X stage A (both cout fragments per wave): e_conv1 as [cout half][lane][8], one K = 32 fragment over a 3-row window
     size_t off_w7x = 0;   // K67X stage B: e_conv7 over [x1, x6], [row tile][source * 9 + tap][lane][8], rows permuted and scaled like off_w7b
     size_t off_b7x = 0;   // ... and its bias in that row order
     // workspace
@@ -286,6 +287,23 @@ IE_EXPORT int ie_zdce_finalize(ie_zdce_plan* p, void* stream) {
             const char* q = (const char*)hw.data();
             host.insert(host.end(), q, q + hw.size() * 2);
         }
+        // ... and as ONE fragment per cout half over the 27 taps of a 3-row window: lane group kq < 3 carries window row ky = kq, k = 8 kq + j with j = 3 kx + c for the
+        // first eight (kx, c) pairs of the row; the ninth -- (kx 2, B) -- of the three rows sits in group 3 (k = 24 + ky), the rest of group 3 is zero
+        align(256);
+        p->off_w1q = host.size();
+        {
+            const float* w = p->w[0].data();
+            std::vector<unsigned short> hw((size_t)2 * 64 * 8, 0);
+            for (int hc = 0; hc < 2; ++hc) for (int lane = 0; lane < 64; ++lane) for (int j = 0; j < 8; ++j) {
+                const int co = 16 * hc + (lane & 15), g = lane >> 4;
+                float v = 0.f;
+                if (g < 3) { const int kx = j / 3, c = j % 3; v = w[((size_t)co * 3 + c) * 9 + g * 3 + kx]; }
+                else if (j < 3) v = w[((size_t)co * 3 + 2) * 9 + j * 3 + 2];
+                hw[((size_t)hc * 64 + lane) * 8 + j] = p->xdt[1] == IE_F16 ? f32_to_f16_bits(v) : f32_to_bf16_bits(v);
+            }
+            const char* q = (const char*)hw.data();
+            host.insert(host.end(), q, q + hw.size() * 2);
+        }
         // e_conv7 over BOTH sources for K67X's stage B: tile j = 16 rows, row 4 kq + i = curve map r_{4j+i} of colour kq (channel 3 (4 j + i) + kq,
         // zero_dce.py:183-188; kq = 3: zero rows), scaled by 2 / ln 2 so that exp(2x) is one v_exp_f32 of the accumulator.
         const float s7 = 2.885390081777927f;
@@ -473,7 +491,7 @@ static int forward_mfma(ie_zdce_plan* p, const float* image, float* enhanced, fl
                     memset(&a, 0, sizeof(a));
                     a.kind = kind; a.N = N; a.H = H; a.W = W; a.n_begin = n0; a.n_count = g; a.rows_per_block = rb;
                     a.img = image; a.x2 = x[2]; a.x5 = x[5];
-                    a.w1 = p->d_w + p->off_w1x; a.b1 = B_(0); a.w2 = W_(1); a.b2 = B_(1); a.w6 = W_(5); a.b6 = B_(5);
+                    a.w1 = p->d_w + p->off_w1x; a.w1q = p->d_w + p->off_w1q; a.b1 = B_(0); a.w2 = W_(1); a.b2 = B_(1); a.w6 = W_(5); a.b6 = B_(5);
                     a.w7 = p->d_w + p->off_w7x; a.b7 = (const float*)(p->d_w + p->off_b7x);
                     a.w3 = W_(2); a.b3 = B_(2); a.w4 = W_(3); a.b4 = B_(3); a.w5 = W_(4); a.b5 = B_(4);
                     a.dt_h = p->xdt[1]; a.dt_a0 = p->xdt[2]; a.dt_a1 = p->xdt[5]; a.dt_3 = p->xdt[3];

@@ -404,6 +404,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 struct K67XParams {
     const float* img; const void* x2; const void* x5;
     const void* w1; const float* b1; const void* w6; const float* b6; const void* w7; const float* b7;
+    const void* w1q;     // e_conv1 as two K = 32 fragments over a 3-row window (IE_K67X_BOTHA)
     float* enhanced; float* adjust; unsigned char* u8;
     int H, W, y_begin, y_end, rows_per_block, strips, chunks, n_begin;
     unsigned long long* stamps;   // diagnostic builds (-DIE_STAMP) only: [block][wave][8] cycle sums
@@ -421,6 +422,15 @@ struct K67XParams {
 #ifndef IE_K67X_AHA
 #define IE_K67X_AHA 3       // fragments read ahead of their MFMAs in stage A's / stage B's streams (each one in flight = 4 VGPRs; a stream alone is bound by the LDS
 #endif                      // latency its reads in flight cover: stage A alone ran 22.6 cycles per MFMA at 3, stamps in profiles/r04/k67x_experiments.log)
+#ifndef IE_K67X_C1POS
+#define IE_K67X_C1POS 1     // where stage A's e_conv1 (gather, 4 MFMAs, hand-off) sits: 0 in front of the e_conv6 streams, 1 between the x2 and the x5 stream
+#endif
+#ifndef IE_K67X_BOTHA
+#define IE_K67X_BOTHA 0     // experiment (correct results; 1): stage A with both cout fragments of e_conv6 per wave over a quarter of the strip + e_conv1 as ONE MFMA per tile over a
+                            // 3-row window (4 instead of 12 MFMAs per wave and row).  Half of stage A's fragment reads and 8 MFMAs fewer, lower draw -- and the kernel 3 % SLOWER
+                            // (7.93 against 7.72 ms; the model the same): the older stage's reads were never on the step's critical chain, its longer e_conv1 chain is
+                            // (profiles/r04/k67x_experiments.log, 18).  Three of the twelve compiled forms spill 2 - 8 VGPRs in this mapping.
+#endif
 #ifndef IE_K67X_BOTH
 #define IE_K67X_BOTH 1      // stage B's waves own BOTH row tiles of e_conv7 over a quarter of the strip: half the fragment reads, no exchange row between the tiles, the staged row a
                             // step earlier: 8.36 -> 8.02 ms per 64 frames same box (profiles/r04/k67x_experiments.log, 16).  0: the (row tile, strip half) mapping of the first K67X
@@ -450,7 +460,7 @@ struct K67XParams {
 template <typename TH> struct K67XGeom {
     static constexpr int PF = 3, NRA = PF + 1;           // x2 / x5 rows of DMA issued ahead, ring slots
     static constexpr int PFR = 2, NRAW = 8;              // raw image rows issued ahead; the raw row of step u is read by the conversion (step u - 1) and by the curve (step u + 4)
-    static constexpr int NRI = 2, NRH = 3;
+    static constexpr int NRI = IE_K67X_BOTHA ? 4 : 2, NRH = 3;      // converted image rows: BOTHA reads a 3-row window while the next row is being converted
     static constexpr int IMG_ROW_B = parts_of<TH>() * IMG_PART_B;
     static constexpr int YPLANE_B = 132 * 4, YSLOT_B = 4 * YPLANE_B;      // fp32 [colour (+ a spare plane for lane group kq = 3)][pixel q at float q + 2]
     static constexpr int OFF_X2 = 0, OFF_X5 = OFF_X2 + NRA * ROWH_B, OFF_H6 = OFF_X5 + NRA * ROWH_B, OFF_H1 = OFF_H6 + NRH * ROWH_B;
@@ -508,6 +518,233 @@ __device__ __forceinline__ void k67x_body(const K67XParams& p) {
 #endif
     if (stg == 0) {
         // ================================================================ stage A ================================================================
+        if constexpr (IE_K67X_BOTHA) {
+        // ---- stage A with both cout fragments per wave: wave w4 = a QUARTER of the strip (pixels 32 w4 ..), e_conv6 with all 36 weight fragments (a fragment feeds six MFMAs),
+        // e_conv1 as ONE K = 32 MFMA per tile and cout fragment over the 27 taps of a 3-row window (k = 8 ky + {(kx, c)} in lane groups 0-2, the three (kx = 2, B) taps in
+        // lane group 3): 4 MFMAs per wave and row instead of 12, no rotating sets -- which is what makes room for e_conv6's second fragment.  The chores keep their lane maps.
+        const auto rs2 = mk((const char*)p.x2 + (size_t)n * frame_b, frame_b);
+        const auto rs5 = mk((const char*)p.x5 + (size_t)n * frame_b, frame_b);
+        const auto rsI = mk((const char*)(p.img + (size_t)n * 3 * plane), 3 * plane * 4);
+        const auto rsE = mk(p.enhanced ? (const void*)(p.enhanced + (size_t)n * 3 * plane) : (const void*)p.w7, p.enhanced ? 3 * plane * 4 : 0);
+        frag wq0[18], wq1[18], w1q[2];
+#pragma unroll
+        for (int f = 0; f < 18; ++f) { wq0[f] = ((const frag*)p.w6)[f * 64 + lane]; wq1[f] = ((const frag*)p.w6)[(18 + f) * 64 + lane]; }
+#pragma unroll
+        for (int f = 0; f < 2; ++f) w1q[f] = ((const frag*)p.w1q)[f * 64 + lane];
+        ie_f32x4 bias6a, bias6b, bias1a, bias1b;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { bias6a[i] = p.b6[4 * kq + i]; bias6b[i] = p.b6[16 + 4 * kq + i]; bias1a[i] = p.b1[4 * kq + i]; bias1b[i] = p.b1[16 + 4 * kq + i]; }
+        unsigned body_xoff[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int q = (2 * w4 + j) * 16 + (lane >> 2);
+            const int sc = (lane & 3) ^ (((q + 1) >> 1) & 3);
+            const int x = xc0 + q;
+            body_xoff[j] = (x >= 0 && x < W) ? (unsigned)(x * PXB + sc * 16) : OOB;
+        }
+        unsigned raw_off[2];
+        raw_offsets(w4, lane, xc0, W, plane, raw_off);
+        auto issue = [&](int t) __attribute__((always_inline)) {      // raw image row of step t - PF + 1 + PFR first, then the x2 / x5 rows of step t
+            {
+                const int tr = t - PF + 1 + PFR, yi = ys - 2 + tr;
+                const unsigned rmask = (yi >= 0 && yi < H) ? 0u : OOB;
+                const unsigned row_b = rmask ? 0u : (unsigned)yi * (unsigned)W * 4u;
+                char* slot = smem + G::OFF_RAW + (tr % NRAW) * RAW_SLOT_B;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsI, (lds_ptr)(slot + (4 * j + w4) * 256), 4, (int)((row_b + raw_off[j]) | rmask), 0, 0, 0);
+            }
+            const int y = ys - 2 + t;
+            const unsigned rmask = (y >= 0 && y < H) ? 0u : OOB;
+            const unsigned row_b = rmask ? 0u : (unsigned)y * (unsigned)W * PXB;
+            char* s2 = smem + G::OFF_X2 + (t % NRA) * ROWH_B + PXB;
+            char* s5 = smem + G::OFF_X5 + (t % NRA) * ROWH_B + PXB;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (lds_ptr)(s2 + (2 * w4 + j) * 1024), 16, (int)((row_b + body_xoff[j]) | rmask), 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs5, (lds_ptr)(s5 + (2 * w4 + j) * 1024), 16, (int)((row_b + body_xoff[j]) | rmask), 0, 0, 0);
+        };
+        const int ci = w4 * 64 + lane;
+        auto convert = [&](int t) __attribute__((always_inline)) {
+            convert_row<TH>(smem + G::OFF_RAW + (t % NRAW) * RAW_SLOT_B, smem + G::OFF_IMG + (t % NRI) * G::IMG_ROW_B, smem + G::OFF_DUMP, ci, lane);
+        };
+        RowRead rq;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int P = 32 * w4 + p16 + kx;
+            rq.base[kx] = P * PXB + ((kq ^ ((P >> 1) & 3)) << 4);
+        }
+        // hand-off: after the lane-pair exchange this lane holds, per cout fragment cf, the 16-byte chunk 2 cf + (kq >> 1) of ring pixel 32 w4 + 16 (kq & 1) + p16 + 1
+        int emq[2];
+        unsigned em_in;
+        {
+            const int P = 32 * w4 + 16 * (kq & 1) + p16 + 1, x = xc0 + P - 1;
+#pragma unroll
+            for (int cf = 0; cf < 2; ++cf) emq[cf] = P * PXB + (((2 * cf + (kq >> 1)) ^ ((P >> 1) & 3)) << 4);
+            em_in = (x >= 0 && x < W) ? 1u : 0u;
+        }
+        // e_conv1's gathered fragment: read r (0..2) of tile j is the 8-byte pixel (column + r) of window row kq (lane groups 0-2) or the pixel (column + 2) of window row r (group 3)
+        const bool is3 = kq == 3;
+        const int gpx = (32 * w4 + p16) * IPB;        // tile j: + 16 pixels = 128 bytes
+        const bool strip_inside = xc0 >= 0 && xc0 + TW <= W;
+        unsigned est_off;
+        int est_lds;
+        {
+            const int x = xc0 + MARG + 4 * lane;
+            est_off = (w4 < 3 && lane < 31 && x < W) ? (unsigned)(((size_t)w4 * plane + x) * 4) : OOB;
+            est_lds = (w4 < 3 ? w4 : 0) * G::YPLANE_B + 16 + 16 * (lane < 31 ? lane : 0);
+        }
+        constexpr bool M_ENH = MODE != 3, M_U8 = MODE == 0 || MODE == 3;
+        const auto rsU = mk((M_U8 && p.u8) ? (const void*)(p.u8 + (size_t)n * 3 * plane) : (const void*)p.w7, (M_U8 && p.u8) ? 3 * plane : 0);
+        const bool vec_store = MODE == 1 || MODE == 2 || (M_ENH && p.enhanced && (W & 3) == 0 && ((size_t)p.enhanced & 15) == 0);
+        ie_f32x4 a0[4], a1[4], a2[4];      // e_conv6: index 2 * cout fragment + tile
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const ie_f32x4 bb = j < 2 ? bias6a : bias6b; a0[j] = bb; a1[j] = bb; a2[j] = bb; }
+#pragma unroll
+        for (int t = PF - 1 - PFR; t < PF; ++t) issue(t);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                    // prologue barrier: raw row 0 has landed
+        convert(0);
+        auto put_q = [&](const ie_f32x4 (&acc)[4], char* dst, bool plain, bool keep) __attribute__((always_inline)) {
+#pragma unroll
+            for (int cf = 0; cf < 2; ++cf) {
+                const ie_u32x2 a = {ie_pack2_relu<TH>(acc[2 * cf][0], acc[2 * cf][1]), ie_pack2_relu<TH>(acc[2 * cf][2], acc[2 * cf][3])};
+                const ie_u32x2 b2 = {ie_pack2_relu<TH>(acc[2 * cf + 1][0], acc[2 * cf + 1][1]), ie_pack2_relu<TH>(acc[2 * cf + 1][2], acc[2 * cf + 1][3])};
+                const auto sx = __builtin_amdgcn_permlane16_swap(a[0], b2[0], false, false);
+                const auto sy = __builtin_amdgcn_permlane16_swap(a[1], b2[1], false, false);
+                const bool k = plain || keep;
+                *(ie_u32x4*)(dst + emq[cf]) = ie_u32x4{k ? sx[0] : 0u, k ? sy[0] : 0u, k ? sx[1] : 0u, k ? sy[1] : 0u};
+            }
+        };
+        auto step_a = [&](int t, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4]) __attribute__((always_inline)) {
+            IE_TACC(3);
+            ie_wait_vm_imm<G::WAIT_A>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            IE_TACC(0);
+            if constexpr (M_ENH) {   // the row staged at step t - 1 leaves
+                const int yo = ys - (IE_K67X_BOTH ? 7 : 8) + t;
+                const bool row_ok = (yo >= ys) && (yo < ye);
+                const char* os = smem + G::OFF_OUT + ((t + 1) & 1) * G::YSLOT_B;
+                if (vec_store) {
+                    const ie_u32x4 v = *(const ie_u32x4*)(os + est_lds);
+                    const unsigned rmask = row_ok ? 0u : OOB;
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rsE, (int)((est_off + (rmask ? 0u : (unsigned)yo * (unsigned)W * 4u)) | rmask), 0, 0);
+                } else if (MODE == 0 && p.enhanced) {
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int q = lane + 64 * k, x = xc0 + q;
+                        const float v = *(const float*)(os + (w4 < 3 ? w4 : 0) * G::YPLANE_B + (q + 2) * 4);
+                        const bool ok = row_ok && w4 < 3 && q >= MARG && q < TW - MARG && x < W;
+                        const unsigned off = ok ? (unsigned)(((size_t)w4 * plane + (size_t)yo * W + x) * 4) : OOB;
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsE, (int)off, 0, 0);
+                    }
+                }
+            }
+            if constexpr (M_U8) {
+                if (p.u8 && w4 == 3) {
+                    const int yo = ys - (IE_K67X_BOTH ? 7 : 8) + t;
+                    const bool row_ok = (yo >= ys) && (yo < ye);
+                    const char* os = smem + G::OFF_OUT + ((t + 1) & 1) * G::YSLOT_B;
+                    const int xs = xc0 + MARG;
+                    const int nbytes = row_ok ? min(TS, W - xs) * 3 : 0;
+                    int ln = lane;
+                    asm volatile("" : "+v"(ln));
+                    if ((W & 3) == 0) {
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            const int d = ln + 64 * k;
+                            unsigned pk = 0;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int bb = 4 * d + e, pxr = bb / 3, c = bb - 3 * pxr;
+                                const float v = *(const float*)(os + c * G::YPLANE_B + ((pxr < TS ? pxr : 0) + MARG + 2) * 4);
+                                pk |= (unsigned)ie_quant_u8(v) << (8 * e);
+                            }
+                            const unsigned off = (4 * d < nbytes) ? (unsigned)(((size_t)yo * W + xs) * 3 + 4 * d) : OOB;
+                            __builtin_amdgcn_raw_buffer_store_b32(pk, rsU, (int)off, 0, 0);
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) {
+                            const int bb = ln + 64 * k, pxr = bb / 3, c = bb - 3 * pxr;
+                            const float v = *(const float*)(os + c * G::YPLANE_B + ((pxr < TS ? pxr : 0) + MARG + 2) * 4);
+                            const unsigned off = (bb < nbytes) ? (unsigned)(((size_t)yo * W + xs) * 3 + bb) : OOB;
+                            __builtin_amdgcn_raw_buffer_store_b8(ie_quant_u8(v), rsU, (int)off, 0, 0);
+                        }
+                    }
+                }
+            }
+            IE_TACC(4);
+            const int m = ys - 3 + t;                                          // the x1 / x6 row this step finishes
+            const bool row_in = m >= 0 && m < H, plain = strip_inside && row_in, keep = row_in && em_in;
+#if IE_K67X_C1POS == 0
+            {   // ---- e_conv1: converted rows t - 2, t - 1, t (image rows m - 1, m, m + 1) -> x1 row m, four MFMAs ----
+                const int s0 = ((t + NRI - 2) % NRI) * G::IMG_ROW_B, s1 = ((t + NRI - 1) % NRI) * G::IMG_ROW_B, s2 = (t % NRI) * G::IMG_ROW_B;
+                const int srow = kq == 0 ? s0 : (kq == 1 ? s1 : s2);
+                const int ad0 = G::OFF_IMG + gpx + (is3 ? s0 + 2 * IPB : srow), ad1 = G::OFF_IMG + gpx + (is3 ? s1 + 2 * IPB : srow + IPB),
+                          ad2 = G::OFF_IMG + gpx + (is3 ? s2 + 2 * IPB : srow + 2 * IPB);
+                ie_f32x4 e[4];
+#pragma unroll
+                for (int part = 0; part < parts_of<TH>(); ++part) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const ie_u32x2 r0 = *(const ie_u32x2*)(smem + ad0 + part * IMG_PART_B + 128 * j), r1 = *(const ie_u32x2*)(smem + ad1 + part * IMG_PART_B + 128 * j),
+                                       r2 = *(const ie_u32x2*)(smem + ad2 + part * IMG_PART_B + 128 * j);
+                        ie_u32x4 fr;
+                        fr[0] = is3 ? ((r0[1] & 0xffffu) | (r1[1] << 16)) : r0[0];
+                        fr[1] = is3 ? (r2[1] & 0xffffu) : ((r0[1] & 0xffffu) | (r1[0] << 16));
+                        fr[2] = is3 ? 0u : ((r1[0] >> 16) | (r1[1] << 16));
+                        fr[3] = is3 ? 0u : r2[0];
+                        e[j] = ie_mfma16_raw<TH>(w1q[0], fr, part == 0 ? bias1a : e[j]);
+                        e[2 + j] = ie_mfma16_raw<TH>(w1q[1], fr, part == 0 ? bias1b : e[2 + j]);
+                    }
+                }
+                put_q(e, smem + G::OFF_H1 + (t % NRH) * ROWH_B, plain, keep);
+            }
+#endif
+            mfma_row_both<TA0, IE_K67X_AHBOTH, false>(smem, smem + G::OFF_X2 + (t % NRA) * ROWH_B, rq, wq0, wq1, accN, accM, accO, true, bias6a, bias6b);
+            IE_TACC(2);
+#if IE_K67X_C1POS == 1
+            {   // ---- e_conv1: converted rows t - 2, t - 1, t (image rows m - 1, m, m + 1) -> x1 row m, four MFMAs ----
+                const int s0 = ((t + NRI - 2) % NRI) * G::IMG_ROW_B, s1 = ((t + NRI - 1) % NRI) * G::IMG_ROW_B, s2 = (t % NRI) * G::IMG_ROW_B;
+                const int srow = kq == 0 ? s0 : (kq == 1 ? s1 : s2);
+                const int ad0 = G::OFF_IMG + gpx + (is3 ? s0 + 2 * IPB : srow), ad1 = G::OFF_IMG + gpx + (is3 ? s1 + 2 * IPB : srow + IPB),
+                          ad2 = G::OFF_IMG + gpx + (is3 ? s2 + 2 * IPB : srow + 2 * IPB);
+                ie_f32x4 e[4];
+#pragma unroll
+                for (int part = 0; part < parts_of<TH>(); ++part) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const ie_u32x2 r0 = *(const ie_u32x2*)(smem + ad0 + part * IMG_PART_B + 128 * j), r1 = *(const ie_u32x2*)(smem + ad1 + part * IMG_PART_B + 128 * j),
+                                       r2 = *(const ie_u32x2*)(smem + ad2 + part * IMG_PART_B + 128 * j);
+                        ie_u32x4 fr;
+                        fr[0] = is3 ? ((r0[1] & 0xffffu) | (r1[1] << 16)) : r0[0];
+                        fr[1] = is3 ? (r2[1] & 0xffffu) : ((r0[1] & 0xffffu) | (r1[0] << 16));
+                        fr[2] = is3 ? 0u : ((r1[0] >> 16) | (r1[1] << 16));
+                        fr[3] = is3 ? 0u : r2[0];
+                        e[j] = ie_mfma16_raw<TH>(w1q[0], fr, part == 0 ? bias1a : e[j]);
+                        e[2 + j] = ie_mfma16_raw<TH>(w1q[1], fr, part == 0 ? bias1b : e[2 + j]);
+                    }
+                }
+                put_q(e, smem + G::OFF_H1 + (t % NRH) * ROWH_B, plain, keep);
+            }
+#endif
+            mfma_row_both<TA1, IE_K67X_AHBOTH, false>(smem, smem + G::OFF_X5 + (t % NRA) * ROWH_B, rq, wq0 + 9, wq1 + 9, accN, accM, accO, false, bias6a, bias6b);
+            IE_TACC(1);
+            issue(t + PF);
+            IE_TACC(5);
+            convert(t + 1);
+            IE_TACC(6);
+            put_q(accO, smem + G::OFF_H6 + (t % NRH) * ROWH_B, plain, keep);
+        };
+        for (int t = 0; t < n_steps; t += 3) {
+            step_a(t, a0, a1, a2);
+            if (t + 1 < n_steps) step_a(t + 1, a2, a0, a1);
+            if (t + 2 < n_steps) step_a(t + 2, a1, a2, a0);
+        }
+        } else {
         const auto rs2 = mk((const char*)p.x2 + (size_t)n * frame_b, frame_b);
         const auto rs5 = mk((const char*)p.x5 + (size_t)n * frame_b, frame_b);
         const auto rsI = mk((const char*)(p.img + (size_t)n * 3 * plane), 3 * plane * 4);
@@ -713,6 +950,7 @@ __device__ __forceinline__ void k67x_body(const K67XParams& p) {
             step_a(t, a0, a1, a2, e0, e1, e2);
             if (t + 1 < n_steps) step_a(t + 1, a2, a0, a1, e2, e0, e1);
             if (t + 2 < n_steps) step_a(t + 2, a1, a2, a0, e1, e2, e0);
+        }
         }
     } else if constexpr (IE_K67X_BOTH) {
         // ===================================================== stage B, both row tiles per wave =====================================================
@@ -998,6 +1236,10 @@ struct K345XGeom {
     static constexpr int OFF_X2 = 0, OFF_X3 = OFF_X2 + NRA * ROWH_B, OFF_X4 = OFF_X3 + NR3 * ROWH_B, LDS_B = OFF_X4 + NR4 * ROWH_B;      // 11 x 8,320 = 91,520 bytes
 };
 
+#ifndef IE_K345X_ASPLIT
+#define IE_K345X_ASPLIT 1     // stage A: 1 = split by LAYER with both cout fragments per wave (half the fragment reads, two rows of hand-off writes at the tail; shipped), 0 = (cout fragment,
+                              // strip half), both layers per wave, the x3 row handed over between the two streams -- with K345X's stage B that is the slowest of the three (series 19)
+#endif
 #ifndef IE_K345X_EARLY
 #define IE_K345X_EARLY 0
 #endif
@@ -1147,7 +1389,73 @@ __device__ __forceinline__ void k345x_body(const K345XParams& p) {
             if (t + 2 < n_steps) step_a(t + 2, a1, a2, a0, c1, c2, c0);
         }
         };
-        if ((w4 >> 1) == 0) stage_a(std::integral_constant<int, 0>{}); else stage_a(std::integral_constant<int, 1>{});
+        if constexpr (IE_K345X_ASPLIT) {
+            if ((w4 >> 1) == 0) stage_a(std::integral_constant<int, 0>{}); else stage_a(std::integral_constant<int, 1>{});
+        } else {
+            // ---- stage A in the (cout fragment, strip half) mapping: every wave runs e_conv3 AND e_conv4 for its fragment (36 + 36 MFMAs, 12 + 12 fragment reads); the x3 row is
+            // handed over BETWEEN the two streams, under stage B's MFMAs, and only the x4 row at the tail (K345X's layer split ended every stage-A step with two rows of writes) ----
+            const int cf = w4 & 1, hfa = w4 >> 1;
+            const auto rs2 = mk((const char*)p.x2 + (size_t)n * frame_b, frame_b);
+            frag wv[18];
+#pragma unroll
+            for (int f = 0; f < 9; ++f) { wv[f] = ((const frag*)p.w3)[(cf * 9 + f) * 64 + lane]; wv[9 + f] = ((const frag*)p.w4)[(cf * 9 + f) * 64 + lane]; }
+            ie_f32x4 bias3, bias4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { bias3[i] = p.b3[16 * cf + 4 * kq + i]; bias4[i] = p.b4[16 * cf + 4 * kq + i]; }
+            const RowRead rr = row_read(hfa, p16, kq);
+            unsigned body_xoff[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int q = (2 * w4 + j) * 16 + (lane >> 2);
+                const int sc = (lane & 3) ^ (((q + 1) >> 1) & 3);
+                const int x = xc0 + q;
+                body_xoff[j] = (x >= 0 && x < W) ? (unsigned)(x * PXB + sc * 16) : OOB;
+            }
+            auto issue = [&](int t) __attribute__((always_inline)) {
+                const int y = ys - 3 + t;
+                const unsigned rmask = (y >= 0 && y < H) ? 0u : OOB;
+                const unsigned row_b = rmask ? 0u : (unsigned)y * (unsigned)W * PXB;
+                char* s2 = smem + G::OFF_X2 + (t % NRA) * ROWH_B + PXB;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (lds_ptr)(s2 + (2 * w4 + j) * 1024), 16, (int)((row_b + body_xoff[j]) | rmask), 0, 0, 0);
+            };
+            const int em_off = put_off(cf, hfa, p16, kq, 1);
+            unsigned em_in = 0;
+            {
+                const int q = 16 * (4 * hfa + (kq & 1)) + p16;
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int x = xc0 + q + 32 * jj;
+                    em_in |= (x >= 0 && x < W) ? (1u << jj) : 0u;
+                }
+            }
+            const bool strip_inside = xc0 >= 0 && xc0 + TW <= W;
+            ie_f32x4 a0[4], a1[4], a2[4], c0[4], c1[4], c2[4];      // a*: e_conv3, c*: e_conv4
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { a0[j] = bias3; a1[j] = bias3; a2[j] = bias3; c0[j] = bias4; c1[j] = bias4; c2[j] = bias4; }
+#pragma unroll
+            for (int t = 0; t < PF; ++t) issue(t);
+            auto nofill = [&](int) __attribute__((always_inline)) {};
+            auto put1 = [&](const ie_f32x4 (&acc)[4], char* dst, int m) __attribute__((always_inline)) {
+                if (strip_inside && m >= 0 && m < H) put_row<T3, false>(acc, dst, em_off, 3u);
+                else put_row<T3, true>(acc, dst, em_off, (m >= 0 && m < H) ? em_in : 0u);
+            };
+            auto step_a = [&](int t, ie_f32x4 (&n3)[4], ie_f32x4 (&m3)[4], ie_f32x4 (&o3)[4], ie_f32x4 (&n4)[4], ie_f32x4 (&m4)[4], ie_f32x4 (&o4)[4]) __attribute__((always_inline)) {
+                ie_wait_vm_imm<(PF - 1) * 2>();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                mfma_row<T2, 3>(smem + G::OFF_X2 + (t % NRA) * ROWH_B, rr, wv, n3, m3, o3, true, bias3, nofill);
+                put1(o3, smem + G::OFF_X3 + (t % NR3) * ROWH_B, ys - 4 + t);
+                mfma_row<T3, 3>(smem + G::OFF_X3 + ((t + NR3 - 1) % NR3) * ROWH_B, rr, wv + 9, n4, m4, o4, true, bias4, nofill);
+                put1(o4, smem + G::OFF_X4 + (t % NR4) * ROWH_B, ys - 6 + t);
+                issue(t + PF);
+            };
+            for (int t = 0; t < n_steps; t += 3) {
+                step_a(t, a0, a1, a2, c0, c1, c2);
+                if (t + 1 < n_steps) step_a(t + 1, a2, a0, a1, c2, c0, c1);
+                if (t + 2 < n_steps) step_a(t + 2, a1, a2, a0, c1, c2, c0);
+            }
+        }
     } else {
         // ===================================================== stage B: e_conv5, a quarter of the strip per wave =====================================================
         const auto rs5 = mk((char*)p.x5 + (size_t)n * frame_b, frame_b);
@@ -1266,7 +1574,7 @@ int ie_zdce_launch_x(const ZdceXLaunch& a, hipStream_t st) {
     if (a.adjust && (size_t)a.H * a.W * 24 * 4 >= 0x7fffffffull) IE_FAIL(IE_ERR_UNSUPPORTED, "zdce k67x: frame too large for 31-bit offsets into `adjust`");
     K67XParams p;
     memset(&p, 0, sizeof(p));
-    p.img = a.img; p.x2 = a.x2; p.x5 = a.x5; p.w1 = a.w1; p.b1 = a.b1; p.w6 = a.w6; p.b6 = a.b6; p.w7 = a.w7; p.b7 = a.b7;
+    p.img = a.img; p.x2 = a.x2; p.x5 = a.x5; p.w1 = a.w1; p.b1 = a.b1; p.w6 = a.w6; p.b6 = a.b6; p.w7 = a.w7; p.b7 = a.b7; p.w1q = a.w1q;
     p.enhanced = a.enhanced; p.adjust = a.adjust; p.u8 = a.u8;
     p.H = a.H; p.W = a.W; p.y_begin = a.y_begin; p.y_end = a.y_end; p.n_begin = a.n_begin; p.strips = strips;
     p.rows_per_block = a.rows_per_block;
