@@ -425,6 +425,9 @@ struct K67XParams {
 #ifndef IE_K67X_C1POS
 #define IE_K67X_C1POS 1     // where stage A's e_conv1 (gather, 4 MFMAs, hand-off) sits: 0 in front of the e_conv6 streams, 1 between the x2 and the x5 stream
 #endif
+#ifndef IE_K67X_EXPB
+#define IE_K67X_EXPB 1      // stage B (both tiles): e_conv7's bias enters the tanh as a factor exp2(b) of exp2(acc) instead of a term of the exponent
+#endif
 #ifndef IE_K67X_BOTHA
 #define IE_K67X_BOTHA 0     // experiment (correct results; 1): stage A with both cout fragments of e_conv6 per wave over a quarter of the strip + e_conv1 as ONE MFMA per tile over a
                             // 3-row window (4 instead of 12 MFMAs per wave and row).  Half of stage A's fragment reads and 8 MFMAs fewer, lower draw -- and the kernel 3 % SLOWER
@@ -962,7 +965,7 @@ __device__ __forceinline__ void k67x_body(const K67XParams& p) {
 #pragma unroll
         for (int f = 0; f < 18; ++f) { wv0[f] = ((const frag*)p.w7)[f * 64 + lane]; wv1[f] = ((const frag*)p.w7)[(18 + f) * 64 + lane]; }
         // e_conv7's bias: a 32-float table in LDS (OFF_BIAS), read back by (tile, kq) at the head of each curve burst -- not 8 registers held across the streams
-        if (w4 == 0 && lane < 32) *(float*)(smem + G::OFF_BIAS + 4 * lane) = p.b7[lane];
+        if (w4 == 0 && lane < 32) *(float*)(smem + G::OFF_BIAS + 4 * lane) = IE_K67X_EXPB ? __builtin_amdgcn_exp2f(p.b7[lane]) : p.b7[lane];      // (EXPB: exp2(acc + b) + 1 = fma(exp2(acc), exp2(b), 1): one instruction less per tanh)
         const int bias_off = G::OFF_BIAS + 16 * kq;
         RowRead rq;
 #pragma unroll
@@ -1006,8 +1009,9 @@ __device__ __forceinline__ void k67x_body(const K67XParams& p) {
             for (int kk = 0; kk < 8; ++kk) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    float e = __builtin_amdgcn_exp2f(accF[2 * (kk >> 2) + j][kk & 3] + bz[kk >> 2][kk & 3]);
-                    e = __builtin_amdgcn_rcpf(e + 1.0f);
+                    float e;
+                    if constexpr (IE_K67X_EXPB) e = __builtin_amdgcn_rcpf(__builtin_fmaf(__builtin_amdgcn_exp2f(accF[2 * (kk >> 2) + j][kk & 3]), bz[kk >> 2][kk & 3], 1.0f));
+                    else e = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(accF[2 * (kk >> 2) + j][kk & 3] + bz[kk >> 2][kk & 3]) + 1.0f);
                     e = __builtin_fmaf(e, -2.0f, 1.0f);                                        // r_kk
                     if constexpr (M_ADJ) {
                         const unsigned off = (aj_base != OOB && ((aj_ok >> j) & 1u)) ? aj_base + (unsigned)(64 * j) + (unsigned)((size_t)(3 * kk) * plane * 4) : OOB;
