@@ -33,6 +33,9 @@ constexpr int IMG_PART_B = IPX * IPB;          // 1,088 (bf16 operands: a hi and
 constexpr int RAW_SLOT_B = 2048;               // three fp32 plane rows of 136 pixels = 1,632 bytes (8 DMA instructions x 256 bytes)
 constexpr unsigned OOB = 0x80000000u;
 
+#ifndef IE_X_ST_AUX
+#define IE_X_ST_AUX 0     // cache-policy bits of the x2 / x5 row stores (experiment: 2 = nt)
+#endif
 #ifndef IE_XEXP
 #define IE_XEXP 0     // K67X timing experiments (WRONG results), tools/exp_build.sh ie_zdce_x.hip <tag> -DIE_XEXP=bits: 1 no curve fillers, 2 no e_conv1 / row conversion,
 #endif                // 4 no hand-off writes, 8 no x2 / x5 DMA, 16 no image DMA / output stores, 32 no e_conv6 MFMAs, 64 no e_conv7 MFMAs, 128 curve without its transcendentals,
@@ -370,7 +373,7 @@ __device__ __forceinline__ void k12x_body(const K12XParams& p) {
             for (int i = 0; i < 2; ++i) ln[i] = *(const ie_u32x4*)(islot + st_lds[i]);
             const unsigned row_b = rmask ? 0u : (unsigned)yo * (unsigned)W * PXB;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) __builtin_amdgcn_raw_buffer_store_b128(ln[i], rsD, (int)((row_b + st_col[i]) | rmask), 0, 0);
+            for (int i = 0; i < 2; ++i) __builtin_amdgcn_raw_buffer_store_b128(ln[i], rsD, (int)((row_b + st_col[i]) | rmask), 0, IE_X_ST_AUX);
         };
         for (int t = 0; t < n_steps; t += 3) {
             step_b(t, a0, a1, a2);
@@ -1497,7 +1500,7 @@ __device__ __forceinline__ void k345x_body(const K345XParams& p) {
                 const ie_u32x2 b2 = {ie_pack2_relu<T3>(acc[2 * cf + 1][0], acc[2 * cf + 1][1]), ie_pack2_relu<T3>(acc[2 * cf + 1][2], acc[2 * cf + 1][3])};
                 const auto sx = __builtin_amdgcn_permlane16_swap(a[0], b2[0], false, false);
                 const auto sy = __builtin_amdgcn_permlane16_swap(a[1], b2[1], false, false);
-                __builtin_amdgcn_raw_buffer_store_b128(ie_u32x4{sx[0], sy[0], sx[1], sy[1]}, rs5, (int)((row_b + st_off[cf]) | rmask), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(ie_u32x4{sx[0], sy[0], sx[1], sy[1]}, rs5, (int)((row_b + st_off[cf]) | rmask), 0, IE_X_ST_AUX);
             }
         };
         auto step_b = [&](int t, ie_f32x4 (&accN)[4], ie_f32x4 (&accM)[4], ie_f32x4 (&accO)[4]) __attribute__((always_inline)) {
