@@ -428,6 +428,9 @@ struct K67XParams {
 #ifndef IE_K67X_C1POS
 #define IE_K67X_C1POS 1     // where stage A's e_conv1 (gather, 4 MFMAs, hand-off) sits: 0 in front of the e_conv6 streams, 1 between the x2 and the x5 stream
 #endif
+#ifndef IE_K67X_BURSTPOS
+#define IE_K67X_BURSTPOS 0      // where stage B's curve burst sits (both-tiles mapping): 0 head of the step, 1 between its two streams, 2 tail
+#endif
 #ifndef IE_K67X_EXPB
 #define IE_K67X_EXPB 1      // stage B (both tiles): e_conv7's bias enters the tanh as a factor exp2(b) of exp2(acc) instead of a term of the exponent
 #endif
@@ -1006,6 +1009,7 @@ __device__ __forceinline__ void k67x_body(const K67XParams& p) {
                 const int yc = ys - 6 + t;
                 if ((MODE == 2 || p.adjust) && yc >= ys && yc < ye) aj_base = (unsigned)(((size_t)kq * plane + (size_t)yc * W + xc0 + q0) * 4);
             }
+            auto curve_burst = [&]() __attribute__((always_inline)) {
             const ie_f32x4 bz[2] = {*(const ie_f32x4*)(smem + bias_off), *(const ie_f32x4*)(smem + bias_off + 64)};
             IE_TACC(6);
 #pragma unroll
@@ -1026,11 +1030,15 @@ __device__ __forceinline__ void k67x_body(const K67XParams& p) {
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) *(float*)(yout + yout_off + 64 * j) = v[j];
+            };
+            if constexpr (IE_K67X_BURSTPOS == 0) curve_burst();
             IE_SB();
             const int hs = ((t + 2) % NRH) * ROWH_B;
             mfma_row_both<TH>(smem, smem + G::OFF_H1 + hs, rq, wv0, wv1, accN, accM, accO, true);
             IE_TACC(5);
+            if constexpr (IE_K67X_BURSTPOS == 1) { curve_burst(); IE_SB(); }
             mfma_row_both<TH>(smem, smem + G::OFF_H6 + hs, rq, wv0 + 9, wv1 + 9, accN, accM, accO, false);
+            if constexpr (IE_K67X_BURSTPOS == 2) curve_burst();
             IE_TACC(1);
         };
         for (int t = 0; t < n_steps; t += 4) {
